@@ -1,0 +1,497 @@
+"""ORACLE -- test infrastructure only.  Never imported by the product (csbsr_amd/), only by tests/,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg.
+
+A CPU restatement, in plain fp32 torch tensor ops, of the reference's joint blind-SR + segmentation
+training hot path ``JointModelWithLoss.forward`` (+ autograd backward):
+
+    /root/reference/model/modeling/build_model.py:370-416      orchestration
+    /root/reference/model/modeling/kbpn.py:84-116, 172-189     KBPN + back-projection stages
+    /root/reference/model/modeling/pspnet_pytorch/pspnet.py:95-123, extractors.py:150-161
+    /root/reference/model/utils/{sr_loss_functions,loss_functions,boundary_loss}.py
+
+The arithmetic of the reference lives in third-party torch ops (F.conv2d, F.conv_transpose2d,
+F.batch_norm, F.interpolate, ... -- torch is unpinned in requirement.txt; this container's
+torch 2.10 is the arbiter) plus scipy.ndimage.distance_transform_edt and
+skimage.segmentation.find_boundaries (absent here; its published rule is restated below).
+
+Pinning: the reference holds NO tests or golden vectors for this path, so the
+oracle is pinned against outputs of the reference itself, imported in the build container by
+tests/golden/make_golden.py (fixtures committed under tests/golden/*.npz) and checked by
+tests/test_oracle_golden.py.
+
+Parameters are passed as a flat ``{state_dict name: tensor}`` dict using the reference's key names.
+Nothing from the reference is imported or copied.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------- config
+
+
+class PathCfg:
+    """The cfg keys the path consumes (reference: model/config/defaults.py:17-97 merged with
+    config/config_csbsr_pspnet.yaml)."""
+
+    def __init__(self, **kw):
+        self.scale = 4                       # MODEL.SCALE_FACTOR
+        self.num_stages = 4                  # MODEL.NUM_STAGES
+        self.ksize = 7                       # BLUR.KERNEL_SIZE (estimated kernel side)
+        self.ksize_out = 21                  # BLUR.KERNEL_SIZE_OUTPUT
+        self.sr_pretrain = (1, 10001)        # SOLVER.SR_SR_MODULE_PRETRAIN_ITER
+        self.kernel_pretrain = (10001, 20001)  # SOLVER.SR_KERNEL_MODULE_PRETRAIN_ITER
+        self.joint_pretrain = (1, 30001)     # SOLVER.SR_PRETRAIN_ITER
+        self.norm_sr = "instance"            # SOLVER.NORM_SR_OUTPUT
+        self.mean = (0.4741, 0.4937, 0.5048)
+        self.std = (0.1621, 0.1532, 0.1523)
+        self.sr_w = (0.4, 0.4, 0.0)          # SOLVER.SR_LOSS_FUNC_SR_WEIGHT[:3]  (defaults.py:72)
+        self.bce_w = (1.0, 1.0)              # SOLVER.BCELOSS_WEIGHT (yaml)
+        self.wbd_w = (1.0, 1.0)              # SOLVER.WB_AND_D_WEIGHT
+        self.aux_w = 0.4                     # SOLVER.SEG_AUX_LOSS_WEIGHT
+        self.main_w = 1.0                    # SOLVER.SEG_MAIN_LOSS_WEIGHT
+        self.beta = 0.3                      # SOLVER.TASK_LOSS_WEIGHT
+        self.antialias = True                # torchvision>=0.17 Resize default on tensors
+        self.oriented_w_iter = -1            # SOLVER.ORIENTED_WEIGHT_ITER
+        self.sfo_sr_amp = 0.0                # SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP
+        self.__dict__.update(kw)
+
+    @property
+    def conv_kspd(self):                     # kbpn.py:22-25
+        return {2: (6, 2, 2), 4: (8, 4, 2), 8: (12, 8, 2)}[self.scale]
+
+
+# ----------------------------------------------------------------------------- small ops
+
+def prelu(x, a):
+    return F.prelu(x, a)
+
+
+def conv_block(P, pre, x, stride=1, padding=1, dilation=1, act=None, slope=0.01):
+    """ConvBlock(norm=None): conv (+bias if present) + activation.  kbpn.py:196-270."""
+    y = F.conv2d(x, P[pre + ".layer.weight"], P.get(pre + ".layer.bias"), stride, padding, dilation)
+    return _act(P, pre, y, act, slope)
+
+
+def deconv_block(P, pre, x, stride, padding, act=None):
+    """DeconvBlock.  kbpn.py:273-277."""
+    y = F.conv_transpose2d(x, P[pre + ".layer.weight"], P.get(pre + ".layer.bias"), stride, padding)
+    return _act(P, pre, y, act, 0.01)
+
+
+def _act(P, pre, y, act, slope):
+    if act == "prelu":
+        return F.prelu(y, P[pre + ".act.weight"])
+    if act == "relu":
+        return F.relu(y)
+    if act == "lrelu":
+        return F.leaky_relu(y, slope)
+    assert act is None
+    return y
+
+
+def bicubic_up(x, size=None, scale=None):
+    """nn.Upsample(mode='bicubic'), align_corners=False, A=-0.75."""
+    return F.interpolate(x, size=size, scale_factor=scale, mode="bicubic", align_corners=False)
+
+
+def kernel_up_normalise(vec, ksize_out):
+    """upscale_and_reshape + sum-normalisation.  kbpn.py:335-341 (predictor), 580-602 (IKC: no
+    normalisation there)."""
+    B, C = vec.shape[:2]
+    ks = int(round(math.sqrt(C)))
+    k = vec.reshape(B, 1, ks, ks)
+    if ks != ksize_out:
+        k = bicubic_up(k, size=(ksize_out, ksize_out))
+    return k
+
+
+def blur_down(sr, vec, ks, stride):
+    """Per-sample depthwise cross-correlation with the (B, ks*ks) kernel.  kbpn.py:394-402 (stride =
+    scale) and sr_loss_functions.py:89-94 (stride 1).  Grouped over batch*channels == the loop."""
+    B, C, H, W = sr.shape
+    w = vec.reshape(B, 1, ks, ks).repeat_interleave(C, dim=0)            # (B*C,1,ks,ks)
+    y = F.conv2d(sr.reshape(1, B * C, H, W), w, stride=stride, padding=(ks - 1) // 2, groups=B * C)
+    return y.reshape(B, C, y.shape[-2], y.shape[-1])
+
+
+# ----------------------------------------------------------------------------- KBPN blocks
+
+def kbpn_feat(P, x):
+    """VGG16 head convs 0,2,5,7 (state_dict indices 0,2,4,6) + ReLU.  kbpn.py:42-44."""
+    f = x
+    for i in (0, 2, 4, 6):
+        f = F.relu(F.conv2d(f, P[f"sr_model.feat.{i}.weight"], P[f"sr_model.feat.{i}.bias"], 1, 1))
+    return f
+
+
+def predictor_with_gap(P, f, cfg):
+    """kbpn.py:292-341 -> normalised kernel vector (B, ksize_out**2)."""
+    pre = "sr_model.predictor.feat_ext"
+    z = f
+    for i in range(3):
+        z = conv_block(P, f"{pre}.{i}", z, act="prelu")
+    vec = z.mean(dim=(2, 3), keepdim=True)                               # GAP
+    ks = int(round(math.sqrt(vec.shape[1])))
+    if ks != cfg.ksize_out:
+        k = kernel_up_normalise(vec, cfg.ksize_out)
+        k = k / k.sum(dim=(2, 3), keepdim=True)
+        return k.reshape(k.shape[0], -1)
+    v = vec.reshape(vec.shape[0], -1)
+    return v / v.sum(dim=1, keepdim=True)
+
+
+def up_block(P, pre, x, cfg):
+    """kbpn.py:450-469."""
+    k, s, p = cfg.conv_kspd
+    x = conv_block(P, pre + ".conv", x, 1, 0, act="prelu")
+    h0 = deconv_block(P, pre + ".up_conv1", x, s, p, act="prelu")
+    l0 = conv_block(P, pre + ".up_conv2", h0, s, p, act="prelu")
+    h1 = deconv_block(P, pre + ".up_conv3", l0 - x, s, p, act="prelu")
+    return h1 + h0
+
+
+def down_block(P, pre, x, cfg):
+    """kbpn.py:472-489."""
+    k, s, p = cfg.conv_kspd
+    x = conv_block(P, pre + ".conv", x, 1, 0, act="prelu")
+    l0 = conv_block(P, pre + ".down_conv1", x, s, p, act="prelu")
+    h0 = deconv_block(P, pre + ".down_conv2", l0, s, p, act="prelu")
+    l1 = conv_block(P, pre + ".down_conv3", h0 - x, s, p, act="prelu")
+    return l1 + l0
+
+
+def sft_layer(P, pre, feats, kvec):
+    """kbpn.py:493-518; ``conditions`` is the kernel vector expanded over the LR grid."""
+    B, _, H, W = feats.shape
+    cond = kvec.reshape(B, -1, 1, 1).expand(B, kvec.shape[1], H, W)
+    cat = torch.cat((feats, cond), 1)
+
+    def c(n, x):
+        return F.conv2d(x, P[f"{pre}.{n}.weight"], P[f"{pre}.{n}.bias"], 1, 1)
+    scale = torch.sigmoid(c("SFT_scale_conv1", F.leaky_relu(c("SFT_scale_conv0", cat), 0.1)))
+    shift = c("SFT_shift_conv1", F.leaky_relu(c("SFT_shift_conv0", cat), 0.1))
+    return feats * scale + shift
+
+
+def kernel_predictor_ikc(P, pre, sr_t, kvec, cfg):
+    """KernelPredictorLikeIKC.forward, kbpn.py:562-578.  Returns the updated kernel vector
+    (pre_kernel + delta); the reference carries it as an expanded (B,441,h,w) map."""
+    B, _, H, W = sr_t.shape
+    x = conv_block(P, pre + ".fe_SR.0", sr_t, act="relu")
+    x = conv_block(P, pre + ".fe_SR.1", x, 1, 0, act="lrelu")
+    for i in (2, 3, 4):
+        x = conv_block(P, f"{pre}.fe_SR.{i}", x, act="lrelu")
+    fh = kvec.reshape(B, -1, 1, 1).expand(B, kvec.shape[1], H, W)
+    fh = conv_block(P, pre + ".fe_kernel.0", fh, act="lrelu")
+    fh = conv_block(P, pre + ".fe_kernel.1", fh, act="lrelu")
+    y = torch.cat((x, fh), 1)
+    y = conv_block(P, pre + ".fe_cat.0", y, 1, 0, act="lrelu")
+    y = conv_block(P, pre + ".fe_cat.1", y, act="lrelu")
+    y = conv_block(P, pre + ".fe_cat.2", y, act=None)
+    delta = y.mean(dim=(2, 3), keepdim=True)
+    ks = int(round(math.sqrt(delta.shape[1])))
+    if ks != cfg.ksize_out:
+        delta = kernel_up_normalise(delta, cfg.ksize_out)
+    return kvec + delta.reshape(B, -1)
+
+
+def k_block(P, pre, concat_h, h, x_lr, kvec, it, cfg):
+    """KBlock.forward (SUM_LR_ERROR_POS='HR'), kbpn.py:380-409."""
+    ksz, s, p = cfg.conv_kspd
+    sr_t = conv_block(P, pre + ".sr_reconst", concat_h, act=None)
+    if not (cfg.sr_pretrain[0] <= it < cfg.sr_pretrain[1]):
+        kvec = kernel_predictor_ikc(P, pre + ".kernel_predictor", sr_t, kvec, cfg)
+    vec = kvec / kvec.sum(dim=1, keepdim=True)
+    pseudo_lr = blur_down(sr_t, vec, cfg.ksize_out, cfg.scale)
+    err = pseudo_lr - x_lr
+    e_h = deconv_block(P, pre + ".up_conv1", err, s, p, act="prelu")
+    return h + e_h, vec, sr_t
+
+
+def kbpn_forward(P, x, it, kernel_gt, cfg, taps=None):
+    """KBPN.forward, kbpn.py:84-116.  Returns (sr, kernel vector (B, ksize_out**2))."""
+    f0 = kbpn_feat(P, x)
+    if cfg.sr_pretrain[0] <= it < cfg.sr_pretrain[1]:
+        kvec = kernel_gt.reshape(kernel_gt.shape[0], -1)
+    else:
+        kvec = predictor_with_gap(P, f0, cfg)
+    if taps is not None:
+        taps["init_f"], taps["init_kernel"] = f0, kvec
+    low, concat_h, concat_l = f0, None, None
+    S = cfg.num_stages
+    for s in range(1, S + 1):
+        pre = f"sr_model.back_projection_stages.{s - 1}"
+        h = up_block(P, pre + ".up", low, cfg)
+        pre_cat = h if concat_h is None else torch.cat((concat_h, h), 1)
+        h, kvec, sr_t = k_block(P, pre + ".kb", pre_cat, h, x, kvec, it, cfg)
+        concat_h = h if concat_h is None else torch.cat((concat_h, h), 1)
+        if taps is not None:
+            taps[f"s{s}.h"], taps[f"s{s}.kvec"], taps[f"s{s}.sr_t"] = h, kvec, sr_t
+        if s < S:
+            low = down_block(P, pre + ".down", concat_h, cfg)
+            concat_l = low if concat_l is None else torch.cat((concat_l, low), 1)
+            low = sft_layer(P, pre + ".sft", concat_l, kvec)
+            if taps is not None:
+                taps[f"s{s}.low"] = low
+    sr = conv_block(P, "sr_model.output_conv", concat_h, act=None)
+    sr = sr + bicubic_up(x, scale=cfg.scale)                              # SR_RESIDUAL_LEARNING
+    return sr, kvec
+
+
+# ----------------------------------------------------------------------------- PSPNet
+
+class BNState:
+    """Train-mode BatchNorm bookkeeping: collects updated running stats."""
+
+    def __init__(self, P, training=True):
+        self.P, self.training, self.new = P, training, {}
+
+    def __call__(self, pre, x):
+        P = self.P
+        rm, rv = P[pre + ".running_mean"].clone(), P[pre + ".running_var"].clone()
+        y = F.batch_norm(x, rm, rv, P[pre + ".weight"], P[pre + ".bias"], self.training, 0.1, 1e-5)
+        if self.training:
+            self.new[pre + ".running_mean"], self.new[pre + ".running_var"] = rm, rv
+            self.new[pre + ".num_batches_tracked"] = P[pre + ".num_batches_tracked"] + 1
+        return y
+
+
+def _drop(x, masks, name):
+    """Dropout2d with an externally supplied (B,C) keep-mask already scaled by 1/(1-p)."""
+    if masks is None or masks.get(name) is None:
+        return x
+    return x * masks[name].reshape(x.shape[0], x.shape[1], 1, 1)
+
+
+def basic_block(P, bn, pre, x, stride, dilation, has_down):
+    """extractors.py:41-70."""
+    out = F.conv2d(x, P[pre + ".conv1.weight"], None, stride, dilation, dilation)
+    out = F.relu(bn(pre + ".bn1", out))
+    out = F.conv2d(out, P[pre + ".conv2.weight"], None, 1, dilation, dilation)
+    out = bn(pre + ".bn2", out)
+    res = x
+    if has_down:
+        res = bn(pre + ".downsample.1", F.conv2d(x, P[pre + ".downsample.0.weight"], None, stride))
+    return F.relu(out + res)
+
+
+RESNET34_LAYERS = ((64, 3, 1, 1), (128, 4, 2, 1), (256, 6, 1, 2), (512, 3, 1, 4))  # planes, blocks, stride, dil
+
+
+def resnet34_dilated(P, bn, x):
+    """extractors.py:112-161: block 0 of every layer gets dilation 1 (``_make_layer`` does not pass
+    it), later blocks get the layer dilation."""
+    pre = "segmentation_model.feats"
+    x = F.relu(bn(pre + ".bn1", F.conv2d(x, P[pre + ".conv1.weight"], None, 2, 3)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    inpl, x3 = 64, None
+    for li, (planes, blocks, stride, dil) in enumerate(RESNET34_LAYERS, 1):
+        for b in range(blocks):
+            first = b == 0
+            has_down = first and (stride != 1 or inpl != planes)
+            x = basic_block(P, bn, f"{pre}.layer{li}.{b}", x, stride if first else 1, 1 if first else dil, has_down)
+        inpl = planes
+        if li == 3:
+            x3 = x
+    return x, x3
+
+
+def psp_module(P, f):
+    """pspnet.py:23-41."""
+    h, w = f.shape[2:]
+    pri = []
+    for i, size in enumerate((1, 2, 3, 6)):
+        p = F.adaptive_avg_pool2d(f, (size, size))
+        p = F.conv2d(p, P[f"segmentation_model.psp.stages.{i}.1.weight"])
+        pri.append(F.interpolate(p, size=(h, w), mode="bilinear", align_corners=False))
+    pri.append(f)
+    y = F.conv2d(torch.cat(pri, 1), P["segmentation_model.psp.bottleneck.weight"], P["segmentation_model.psp.bottleneck.bias"])
+    return F.relu(y)
+
+
+def psp_upsample(P, bn, pre, x):
+    """pspnet.py:44-57."""
+    h, w = 2 * x.shape[2], 2 * x.shape[3]
+    p = F.interpolate(x, size=(h, w), mode="bilinear", align_corners=False)
+    p = F.conv2d(p, P[pre + ".conv.0.weight"], P[pre + ".conv.0.bias"], 1, 1)
+    return F.prelu(bn(pre + ".conv.1", p), P[pre + ".conv.2.weight"])
+
+
+def pspnet_forward(P, x, bn, drop=None):
+    """PSPNet.forward, pspnet.py:95-123 -> (main prob map, aux prob map)."""
+    h, w = x.shape[2:]
+    f, x3 = resnet34_dilated(P, bn, x)
+    p = _drop(psp_module(P, f), drop, "drop_1")
+    p = _drop(psp_upsample(P, bn, "segmentation_model.up_1", p), drop, "drop_2a")
+    p = _drop(psp_upsample(P, bn, "segmentation_model.up_2", p), drop, "drop_2b")
+    p = _drop(psp_upsample(P, bn, "segmentation_model.up_3", p), drop, "drop_2c")
+    a = F.conv2d(x3, P["segmentation_model.aux.0.weight"], None, 1, 1)
+    a = _drop(F.relu(bn("segmentation_model.aux.1", a)), drop, "aux_drop")
+    a = torch.sigmoid(F.conv2d(a, P["segmentation_model.aux.4.weight"], P["segmentation_model.aux.4.bias"]))
+    a = F.interpolate(a, size=(h, w), mode="bilinear", align_corners=True)
+    main = torch.sigmoid(F.conv2d(p, P["segmentation_model.final.0.weight"], P["segmentation_model.final.0.bias"]))
+    return main, a
+
+
+# ----------------------------------------------------------------------------- losses
+
+def norm_sr(sr, cfg):
+    """build_model.py:125-141."""
+    if cfg.norm_sr == "instance":
+        return F.instance_norm(sr, eps=1e-5)
+    if cfg.norm_sr == "all":
+        m = torch.tensor(cfg.mean, dtype=sr.dtype).reshape(1, 3, 1, 1)
+        s = torch.tensor(cfg.std, dtype=sr.dtype).reshape(1, 3, 1, 1)
+        return (sr - m) / s
+    return sr
+
+
+def factor_resize_down(x, factor, antialias=True):
+    """FactorResize('bicubic') -> torchvision Resize on a float tensor, transforms.py:505-531."""
+    H, W = x.shape[-2:]
+    return F.interpolate(x, size=(int(H / factor), int(W / factor)), mode="bicubic", align_corners=False,
+                         antialias=antialias)
+
+
+def kbpn_loss(sr, hr, x_lr, kvec, kernel_gt, cfg, seg=None, seg_t=None, it=0):
+    """KBPNLoss.forward + Get_pseudo_lr, sr_loss_functions.py:39-102 -> (loss (B,), kernel (B,1,K,K))."""
+    B = sr.shape[0]
+    hr_l = (sr - hr).abs()
+    vec = kvec / kvec.sum(dim=1, keepdim=True)
+    blurred = blur_down(sr, vec, cfg.ksize_out, 1)
+    lr_pred = factor_resize_down(blurred, cfg.scale, cfg.antialias)
+    lr_l = (lr_pred - x_lr).abs()
+    kpred = vec.reshape(B, 1, cfg.ksize_out, cfg.ksize_out)
+    k_l = (kpred - kernel_gt) ** 2
+    if it > cfg.oriented_w_iter and cfg.oriented_w_iter != -1 and cfg.sfo_sr_amp != 0:
+        # SegmentFailerOrientedExpWeight, oriented_weight.py:73-83; sr_loss_functions.py:58-71
+        w = torch.exp(cfg.sfo_sr_amp * (seg.detach() - seg_t).abs())
+        hr_l = w * hr_l
+        lr_l = F.interpolate(w, scale_factor=1 / cfg.scale, mode="bilinear") * lr_l
+    loss = cfg.sr_w[0] * hr_l.mean((1, 2, 3)) + cfg.sr_w[1] * lr_l.mean((1, 2, 3)) + cfg.sr_w[2] * k_l.mean((1, 2, 3))
+    return loss, kpred
+
+
+def edt_exact(mask: np.ndarray) -> np.ndarray:
+    """Exact Euclidean distance of every non-zero pixel to the nearest zero pixel (0 for zero pixels):
+    what scipy.ndimage.distance_transform_edt computes.  Two-pass lower envelope (Felzenszwalb &
+    Huttenlocher) in float64; tests cross-check it against scipy on the golden masks."""
+    H, W = mask.shape
+    INF = 1e20
+    f = np.where(mask != 0, INF, 0.0)
+
+    def dt1d(f):
+        n = f.shape[0]
+        d = np.empty(n)
+        v = np.zeros(n, dtype=np.int64)
+        z = np.empty(n + 1)
+        k = 0
+        z[0], z[1] = -INF, INF
+        for q in range(1, n):
+            while True:
+                s = ((f[q] + q * q) - (f[v[k]] + v[k] * v[k])) / (2.0 * q - 2.0 * v[k])
+                if s <= z[k]:
+                    k -= 1
+                else:
+                    break
+            k += 1
+            v[k] = q
+            z[k], z[k + 1] = s, INF
+        k = 0
+        for q in range(n):
+            while z[k + 1] < q:
+                k += 1
+            d[q] = (q - v[k]) ** 2 + f[v[k]]
+        return d
+    g = np.empty_like(f)
+    for x in range(W):
+        g[:, x] = dt1d(f[:, x])
+    for y in range(H):
+        g[y, :] = dt1d(g[y, :])
+    g = np.where(g >= INF / 2, 0.0, g)  # no zero pixel anywhere: scipy returns... (never hit: guarded by any())
+    return np.sqrt(g)
+
+
+def inner_boundary(pos: np.ndarray) -> np.ndarray:
+    """skimage.segmentation.find_boundaries(mode='inner', connectivity=1) on a bool image: foreground
+    pixels whose 4-neighbourhood (reflecting nothing: grey dilation/erosion use 'reflect' borders, so
+    image edges never create a boundary) contains background.  boundary_loss.py:62."""
+    p = pos.astype(bool)
+    pad = np.pad(p, 1, mode="edge")
+    nb_all = pad[:-2, 1:-1] & pad[2:, 1:-1] & pad[1:-1, :-2] & pad[1:-1, 2:]
+    return p & ~nb_all
+
+
+def compute_sdf(mask: np.ndarray, use_scipy=True) -> np.ndarray:
+    """compute_sdf1_1, boundary_loss.py:40-67, for a (B,1,H,W) {0,1} array -> float64 (B,1,H,W)."""
+    B = mask.shape[0]
+    out = np.zeros(mask.shape, dtype=np.float64)
+    if use_scipy:
+        from scipy.ndimage import distance_transform_edt as edt
+    else:
+        edt = edt_exact
+    for b in range(B):
+        pos = mask[b, 0].astype(np.uint8).astype(bool)
+        if pos.any():
+            neg = ~pos
+            posdis, negdis = edt(pos), edt(neg)
+            bd = inner_boundary(pos)
+            sdf = (negdis - negdis.min()) / (negdis.max() - negdis.min()) - (posdis - posdis.min()) / (posdis.max() - posdis.min())
+            sdf[bd] = 0
+            out[b, 0] = sdf
+    return out
+
+
+def boundary_combo_loss(pred, target, alpha, cfg, sdf=None):
+    """BoundaryComboLoss.forward, loss_functions.py:49-75 with BCE_DiceLoss (:317-345),
+    WeightedBCELoss (:189-210), BinaryDiceLoss (:258-314) and BoundaryLoss (boundary_loss.py:26-38)."""
+    sm = 1e-8
+    p = pred.clamp(min=sm)
+    pw = cfg.bce_w
+    # WeightedBCELoss clamps again (no-op) and adds smooth inside the logs
+    bce = -(pw[0] * target * torch.log(p + sm) + pw[1] * (1 - target) * torch.log(1 - p + sm)) / sum(pw)
+    bce = bce.mean(dim=(1, 2, 3))
+    pf, tf = p.reshape(p.shape[0], -1), target.reshape(target.shape[0], -1)
+    num = 2 * (pf * tf).sum(1) + 1e-6
+    den = (pf.pow(2) + tf.pow(2)).sum(1) + 1e-6
+    dice = 1 - num / den
+    lw = cfg.wbd_w
+    wbd = (lw[0] * bce + lw[1] * dice) / sum(lw)
+    if sdf is None:
+        sdf = torch.from_numpy(compute_sdf(target.detach().cpu().numpy())).float()
+    bd = (p * sdf).mean(dim=(1, 2, 3))
+    return alpha * wbd + (1 - alpha) * bd
+
+
+# ----------------------------------------------------------------------------- joint forward
+
+def joint_forward(P, cfg, it, x, hr, mask, kernel_gt, alpha=1.0, drop=None, training=True, taps=None):
+    """JointModelWithLoss.forward (KBPN + PSPNet branch), build_model.py:402-416."""
+    sr, kvec = kbpn_forward(P, x, it, kernel_gt, cfg, taps)
+    bn = BNState(P, training)
+    seg, aux = pspnet_forward(P, norm_sr(sr, cfg), bn, drop)
+    sr_loss, kpred = kbpn_loss(sr, hr, x, kvec, kernel_gt, cfg, seg, mask, it)
+    sdf = torch.from_numpy(compute_sdf(mask.cpu().numpy())).float()
+    seg_loss = cfg.main_w * boundary_combo_loss(seg, mask, alpha, cfg, sdf) + \
+        cfg.aux_w * boundary_combo_loss(aux, mask, alpha, cfg, sdf)
+    return {"segment_loss": seg_loss, "sr_loss": sr_loss, "segment_preds": seg, "sr_preds": sr,
+            "kernel_preds": kpred, "aux_preds": aux, "bn_buffers": bn.new}
+
+
+def calc_loss(seg_loss, sr_loss, it, cfg):
+    """trainer.py:406-438 (JOINT_LEARNING, fixed TASK_LOSS_WEIGHT)."""
+    seg_l, sr_l = seg_loss.mean(), sr_loss.mean()
+    loss = (1 - cfg.beta) * sr_l + cfg.beta * seg_l
+    if cfg.joint_pretrain[0] <= it < cfg.joint_pretrain[1]:
+        loss = sr_l
+    return loss
+
+
+def iou(output, target, th=0.5, smooth=1e-5):
+    """estimate_metrics.py:64-84."""
+    o, t = output > th, target > th
+    inter = (o & t).sum(dim=(2, 3)).double()
+    union = (o | t).sum(dim=(2, 3)).double()
+    return (inter + smooth) / (union + smooth)

@@ -1,0 +1,152 @@
+"""Generate golden vectors from the REFERENCE itself (imported from /root/reference with the shims in
+ref_shims.py), run on CPU in the build container.  The reference has no tests/fixtures of its own for
+this path, so these files are what pins the oracle (oracle/csbsr_oracle.py).
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+
+Weights: csbsr_amd.utils.detfill (closed form, keyed on state_dict name+shape); inputs:
+csbsr_amd.data.synthetic.make_batch.  Only data is written: inputs, outputs, per-parameter gradient
+L2 norms and a few sampled gradient elements.  torch version recorded in each file.
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+from csbsr_amd.utils.detfill import deterministic_fill  # noqa: E402
+from csbsr_amd.data.synthetic import make_batch  # noqa: E402
+
+
+def grad_digest(model):
+    names, norms, samples = [], [], []
+    for n, p in model.named_parameters():
+        names.append(n)
+        if p.grad is None:
+            norms.append(-1.0)
+            samples.append(np.zeros(4, np.float32))
+            continue
+        g = p.grad.detach().reshape(-1)
+        norms.append(float(g.double().norm()))
+        idx = [(zlib.crc32((n + str(j)).encode()) % g.numel()) for j in range(4)]
+        samples.append(g[idx].numpy().astype(np.float32))
+    return names, np.array(norms), np.stack(samples)
+
+
+class DropCapture:
+    """Replace nn.Dropout2d.forward by a recorded/seeded channel mask (order of calls = keys)."""
+    KEYS = ("drop_1", "drop_2a", "drop_2b", "drop_2c", "aux_drop")
+
+    def __init__(self, enabled, seed=7):
+        self.enabled, self.gen, self.masks, self.i = enabled, torch.Generator().manual_seed(seed), {}, 0
+
+    def __call__(self, mod, x):
+        key = self.KEYS[self.i]
+        self.i += 1
+        if not self.enabled or not mod.training:
+            self.masks[key] = None
+            return x
+        keep = (torch.rand(x.shape[0], x.shape[1], generator=self.gen) >= mod.p).float() / (1 - mod.p)
+        self.masks[key] = keep
+        return x * keep[:, :, None, None]
+
+
+def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha=None, taps=False, overrides=(), seed=1121):
+    ref_shims.ANTIALIAS = antialias
+    cfg, JM, J, FR = ref_shims.build_reference(scale=scale, overrides=overrides)
+    model = JM(cfg, 1000, 0, FR(scale, "bicubic"))
+    deterministic_fill(model)
+    model.train()
+    if alpha is not None:
+        model.ss_loss_fn.alpha = alpha
+    cap = DropCapture(dropout)
+    orig = nn.Dropout2d.forward
+    # PSPNet calls: drop_1, drop_2 x3 (main path) then aux dropout (pspnet.py:105-120)
+    nn.Dropout2d.forward = lambda self, x: cap(self, x)
+    tapd = {}
+    hooks = []
+    if taps:
+        sm = model.sr_model
+
+        def tap(key, pick=lambda o: o):
+            def hook(mod, inp, out):
+                tapd[key] = pick(out).detach()
+            return hook
+        hooks.append(sm.feat.register_forward_hook(tap("init_f")))
+        for s, st in enumerate(sm.back_projection_stages, 1):
+            hooks.append(st.kb.sr_reconst.register_forward_hook(tap(f"s{s}.sr_t")))
+            hooks.append(st.kb.register_forward_hook(tap(f"s{s}.h", lambda o: o[0])))
+            hooks.append(st.kb.register_forward_hook(tap(f"s{s}.kvec", lambda o: o[1][:, :, 0, 0])))
+            if hasattr(st, "sft"):
+                hooks.append(st.sft.register_forward_hook(tap(f"s{s}.low")))
+    x, hr, mask, k = make_batch(B, lr, scale=scale, ksize=cfg.BLUR.KERNEL_SIZE_OUTPUT, seed=seed, antialias=antialias)
+    try:
+        seg_loss, sr_loss, seg, sr, kpred = model(it, x, sr_targets=hr, segment_targets=mask, kernel_targets=k)
+        from model.engine.trainer import calc_loss
+        import argparse
+        loss, _, _ = calc_loss(seg_loss, 0.0, sr_loss, 0.0, it, cfg, argparse.Namespace())
+        model.zero_grad()
+        loss.backward()
+    finally:
+        nn.Dropout2d.forward = orig
+        for h in hooks:
+            h.remove()
+    names, norms, samples = grad_digest(model)
+    bufs = {n: b.detach().numpy() for n, b in model.named_buffers()
+            if n in ("segmentation_model.feats.bn1.running_mean", "segmentation_model.feats.bn1.running_var",
+                     "segmentation_model.up_3.conv.1.running_var", "segmentation_model.aux.1.running_mean")}
+    out = dict(x=x.numpy(), hr=hr.numpy(), mask=mask.numpy(), kernel=k.numpy(), it=np.int64(it),
+               segment_loss=seg_loss.detach().numpy(), sr_loss=sr_loss.detach().numpy(), loss=np.float64(loss.item()),
+               segment_preds=seg.detach().numpy(), sr_preds=sr.detach().numpy(), kernel_preds=kpred.detach().numpy(),
+               grad_names=np.array(names), grad_norms=norms, grad_samples=samples,
+               alpha=np.float64(model.ss_loss_fn.alpha), antialias=np.bool_(antialias), scale=np.int64(scale),
+               torch_version=np.array(torch.__version__))
+    for kname, v in cap.masks.items():
+        if v is not None:
+            out["dropmask." + kname] = v.numpy()
+    for kname, v in bufs.items():
+        out["buf." + kname] = v
+    for kname, v in tapd.items():
+        v = v.numpy()
+        out["tap." + kname] = v if v.size <= 70000 else v[:, :8]          # first 8 channels of big maps
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: loss={loss.item():.6f} seg={seg_loss.tolist()} sr={sr_loss.tolist()} -> {os.path.getsize(path)/1e3:.0f} kB")
+
+
+def sdf_case():
+    from model.utils.boundary_loss import compute_sdf1_1
+    m = np.zeros((3, 1, 40, 56), np.uint8)
+    m[0, 0, 5:9, 3:50] = 1
+    m[0, 0, 9:30, 20:23] = 1
+    m[0, 0, 0:3, 53:56] = 1                      # touches the image corner
+    m[1, 0, 17, 11] = 1                          # single pixel
+    yy, xx = np.mgrid[:40, :56]
+    m[2, 0] = ((yy - 20) ** 2 + (xx - 30) ** 2 < 90).astype(np.uint8)
+    m[2, 0, 18:22, 28:32] = 0                    # hole
+    sdf = compute_sdf1_1(m.astype(np.float32), m.shape)
+    np.savez_compressed(os.path.join(HERE, "sdf_handdrawn.npz"), mask=m, sdf=sdf)
+    print("sdf_handdrawn written")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    sdf_case()
+    run_case("e2e_pspnet_it40000", 40000, taps=True, alpha=0.7)
+    run_case("e2e_pspnet_it40000_dropout", 40000, dropout=True, alpha=0.7)
+    run_case("e2e_pspnet_it1", 1)
+    run_case("e2e_pspnet_it10001", 10001)
+    run_case("e2e_pspnet_it20001", 20001)
+    run_case("e2e_pspnet_it40000_noaa", 40000, antialias=False, alpha=0.7)
+    run_case("e2e_pspnet_it40000_lr24", 40000, lr=24, B=1, alpha=0.9, seed=5)

@@ -1,0 +1,46 @@
+"""Helpers shared by the parity tests: load a golden fixture, rebuild the deterministic weights, run
+the oracle with autograd and digest gradients the same way tests/golden/make_golden.py did."""
+import os
+import sys
+import zlib
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+from csbsr_amd.utils.detfill import det_state_dict  # noqa: E402
+from csbsr_amd.modeling.shapes import joint_state_shapes  # noqa: E402
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def det_params(scale=4, num_stages=4, detector="PSPNet", requires_grad=True):
+    shapes = joint_state_shapes(scale=scale, num_stages=num_stages, detector=detector)
+    sd = det_state_dict(shapes)
+    if requires_grad:
+        for k, v in sd.items():
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+    return sd
+
+
+def sample_idx(name, numel):
+    return [(zlib.crc32((name + str(j)).encode()) % numel) for j in range(4)]
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(np.asarray(a)).double().reshape(-1)
+    b = torch.as_tensor(np.asarray(b)).double().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def max_rel_to_scale(a, b):
+    a = torch.as_tensor(np.asarray(a)).double().reshape(-1)
+    b = torch.as_tensor(np.asarray(b)).double().reshape(-1)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))

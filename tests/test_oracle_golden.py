@@ -1,0 +1,94 @@
+"""Pin the oracle (oracle/csbsr_oracle.py) against golden vectors produced by the REFERENCE itself
+(tests/golden/make_golden.py, run in the build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from golden_utils import load_golden, det_params, rel_err, sample_idx
+from oracle import csbsr_oracle as O
+
+CASES = ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "e2e_pspnet_it10001",
+         "e2e_pspnet_it20001", "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24"]
+
+# fp32 CPU vs fp32 CPU, same torch build: differences come only from op ordering (grouped conv vs the
+# reference's per-sample loop, vector kernel vs expanded map)
+TOL_OUT = 2e-5
+TOL_GRAD = 1e-2   # fp32-vs-fp32 evaluation-order noise reaches 4e-3 on some conv weights (7e-3 vs fp64)
+
+
+def run_oracle(g, grads=True):
+    P = det_params(requires_grad=grads)
+    cfg = O.PathCfg(antialias=bool(g["antialias"]), scale=int(g["scale"]))
+    t = lambda k: torch.from_numpy(g[k])
+    drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
+    taps = {}
+    out = O.joint_forward(P, cfg, int(g["it"]), t("x"), t("hr"), t("mask"), t("kernel"),
+                          alpha=float(g["alpha"]), drop=drop or None, taps=taps)
+    loss = O.calc_loss(out["segment_loss"], out["sr_loss"], int(g["it"]), cfg)
+    if grads:
+        loss.backward()
+    return P, out, loss, taps
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference_outputs_and_grads(case):
+    g = load_golden(case)
+    P, out, loss, taps = run_oracle(g)
+    for k in ("segment_loss", "sr_loss", "segment_preds", "sr_preds", "kernel_preds"):
+        assert rel_err(out[k].detach(), g[k]) < TOL_OUT, k
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    for k, v in g.items():
+        if k.startswith("tap."):
+            mine = taps[k[4:]].detach()
+            if tuple(mine.shape) != v.shape:
+                mine = mine[:, :8]
+            assert rel_err(mine, v) < TOL_OUT, k
+        if k.startswith("buf."):
+            assert rel_err(out["bn_buffers"][k[4:]], v) < TOL_OUT, k
+    # gradients: per-parameter L2 norm + 4 sampled elements, and the frozen/unused set must agree
+    names = [str(n) for n in g["grad_names"]]
+    n_checked = 0
+    for n, ref_norm, ref_s in zip(names, g["grad_norms"], g["grad_samples"]):
+        gr = P[n].grad
+        mine_norm = 0.0 if gr is None else float(gr.double().norm())
+        if ref_norm < 0:          # reference: grad is None (parameter unused or frozen in this phase)
+            assert mine_norm == 0.0 or _frozen_in_phase(n, int(g["it"])), n
+            continue
+        if ref_norm < 1e-7:       # exact zero, or the mathematically-zero grad of a conv bias feeding train-mode BN
+            assert mine_norm < 1e-6, n
+            continue
+        # PReLU slopes are one scalar = a signed sum over ~1e6 products with heavy cancellation: two fp32
+        # evaluation orders of the same math differ by 7e-3 typically and by up to 60% of a near-zero value vs fp64 (measured), so they get
+        # their own bound
+        tol, atol = (0.1, 1e-3) if gr.numel() == 1 else (TOL_GRAD, 1e-12)
+        assert abs(mine_norm - ref_norm) <= tol * ref_norm + atol, (n, mine_norm, ref_norm)
+        if gr.numel() == 1:
+            n_checked += 1
+            continue
+        idx = sample_idx(n, gr.numel())
+        assert np.allclose(gr.reshape(-1)[idx].numpy(), ref_s, rtol=1e-2, atol=0.25 * ref_norm / np.sqrt(gr.numel()) + 1e-9), n
+        n_checked += 1
+    assert n_checked >= (150 if int(g["it"]) >= 30001 else 20)
+
+
+def _frozen_in_phase(name, it):
+    """requires_grad=False phases of the reference (kbpn.py:118-142, 414-447): the oracle computes the
+    gradient anyway; the harness (csbsr_amd) masks it.  Only used to excuse a non-zero oracle grad."""
+    if 1 <= it < 10001:
+        return "kernel_predictor" in name or ".predictor." in name
+    if 10001 <= it < 20001:
+        return "kernel_predictor" not in name and ".predictor." not in name and name.startswith("sr_model")
+    return False
+
+
+def test_sdf_matches_reference_and_own_edt():
+    g = load_golden("sdf_handdrawn")
+    s1 = O.compute_sdf(g["mask"], use_scipy=True)
+    s2 = O.compute_sdf(g["mask"], use_scipy=False)
+    assert np.abs(s1 - g["sdf"]).max() < 1e-12
+    assert np.abs(s2 - g["sdf"]).max() < 1e-9
+
+
+def test_iou_identity():
+    a = torch.rand(2, 1, 8, 8)
+    assert torch.allclose(O.iou(a, a), torch.ones(2, 1, dtype=torch.double))
