@@ -1,0 +1,132 @@
+"""ctypes binding of libcsbsr_hip.so (the C ABI declared in include/csbsr_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a kernel reports an error this
+module raises.  PyTorch-ROCm is used only for device memory (tensors) and streams; every pointer that
+crosses this boundary is a raw ``data_ptr()``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsbsr_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
+RES_NONE, RES_ADD, RES_SUB, RES_MUL, RES_FMA = 0, 1, 2, 3, 4
+STAT_NONE, STAT_BN, STAT_SAMPLE_SUM = 0, 1, 2
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class Seg(C.Structure):
+    _fields_ = [("ptr", vp), ("sn", i64), ("sy", i64), ("sx", i64), ("c", i32), ("_pad", i32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("inp", Seg * 2), ("N", i32), ("H", i32), ("W", i32), ("OH", i32), ("OW", i32),
+                ("transposed", i32), ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32), ("dil", i32),
+                ("wt", vp), ("cout", i32), ("coutp", i32),
+                ("out16", vp), ("o_sn", i64), ("o_sy", i64), ("o_sx", i64),
+                ("out32", vp), ("o32_sn", i64), ("o32_sy", i64), ("o32_sx", i64), ("o32_sc", i64),
+                ("bias", vp), ("act", i32), ("act_slope", f32), ("prelu", vp),
+                ("res_mode", i32), ("res", vp), ("r_sn", i64), ("r_sy", i64), ("r_sx", i64),
+                ("res2", vp), ("r2_sn", i64), ("r2_sy", i64), ("r2_sx", i64),
+                ("accumulate", i32), ("stat_mode", i32), ("stat", vp), ("out_scale", f32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("a", vp), ("a_sn", i64), ("a_sy", i64), ("a_sx", i64), ("ca", i32), ("_pad0", i32),
+                ("b", Seg * 2), ("N", i32), ("AH", i32), ("AW", i32), ("BH", i32), ("BW", i32),
+                ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32), ("dil", i32),
+                ("g", vp), ("splits", i32), ("_pad1", i32)]
+
+
+class EpiBwdDesc(C.Structure):
+    _fields_ = [("npix", i64), ("c", i32), ("creal", i32),
+                ("dout", vp), ("dout_ld", i64), ("out", vp), ("out_ld", i64),
+                ("res", vp), ("res_ld", i64), ("res2", vp), ("res2_ld", i64),
+                ("act", i32), ("act_slope", f32), ("prelu", vp), ("res_mode", i32), ("_pad", i32),
+                ("dpre", vp), ("dpre_ld", i64),
+                ("dres", vp), ("dres_ld", i64), ("dres_accumulate", i32), ("_pad1", i32),
+                ("dres2", vp), ("dres2_ld", i64), ("dres2_accumulate", i32), ("_pad2", i32),
+                ("dbias", vp), ("dprelu", vp)]
+
+
+class BnDesc(C.Structure):
+    _fields_ = [("npix", i64), ("hw", i64), ("c", i32), ("creal", i32),
+                ("x", vp), ("x_ld", i64), ("mean", vp), ("invstd", vp), ("gamma", vp), ("beta", vp),
+                ("res", vp), ("res_ld", i64), ("act", i32), ("_pad", i32), ("prelu", vp), ("drop", vp),
+                ("y", vp), ("y_ld", i64), ("dy", vp), ("dy_ld", i64), ("red", vp), ("dprelu", vp),
+                ("dx", vp), ("dx_ld", i64), ("dres", vp), ("dres_ld", i64), ("dres_accumulate", i32), ("_pad1", i32),
+                ("dgamma", vp), ("dbeta", vp)]
+
+
+# name -> (restype, argtypes): every symbol include/csbsr_hip.h declares
+SIGNATURES = {
+    "csbsr_version": (i32, []),
+    "csbsr_last_error": (C.c_char_p, []),
+    "csbsr_conv_forward": (i32, [C.POINTER(ConvDesc), vp]),
+    "csbsr_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp]),
+    "csbsr_debug_set_wgrad_tr": (None, [i32]),
+    "csbsr_packed_weight_elems": (i64, [i32] * 9),
+    "csbsr_pack_weights": (i32, [vp, vp] + [i32] * 11 + [vp]),
+    "csbsr_unpack_wgrad": (i32, [vp, vp] + [i32] * 9 + [f32, vp]),
+    "csbsr_epilogue_backward": (i32, [C.POINTER(EpiBwdDesc), vp]),
+    "csbsr_axpby": (i32, [i64, i32, vp, i64, f32, vp, i64, f32, vp, i64, vp]),
+    "csbsr_fill_f16": (i32, [vp, i64, i32, i64, f32, vp]),
+    "csbsr_nchw32_to_nhwc16": (i32, [vp, vp, i32, i32, i32, i32, i32, i64, vp, vp, vp]),
+    "csbsr_nhwc16_to_nchw32": (i32, [vp, i64, vp, i32, i32, i32, i32, f32, f32, vp]),
+    "csbsr_plane_reduce": (i32, [vp, vp, i32, i64, vp, vp]),
+    "csbsr_instnorm_bwd": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, i32, i64, vp, vp]),
+    "csbsr_bn_finalize": (i32, [vp, i64, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
+    "csbsr_bn_apply": (i32, [C.POINTER(BnDesc), vp]),
+    "csbsr_bn_backward": (i32, [C.POINTER(BnDesc), vp]),
+    "csbsr_maxpool3x3s2_fwd": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "csbsr_maxpool3x3s2_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "csbsr_adaptive_avgpool_fwd": (i32, [vp, i64, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "csbsr_adaptive_avgpool_bwd": (i32, [vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "csbsr_bilinear_fwd": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "csbsr_bilinear_bwd": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "csbsr_bilinear32_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "csbsr_bilinear32_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "csbsr_bicubic_up_add": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "csbsr_aa_bicubic_down_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "csbsr_aa_bicubic_down_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "csbsr_blur_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp]),
+    "csbsr_blur_bwd_input": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "csbsr_blur_bwd_kernel": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "csbsr_sdf": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "csbsr_segloss_reduce": (i32, [vp, vp, vp, i32, i64, vp, f32, f32, vp]),
+    "csbsr_segloss_finish": (i32, [vp, vp, vp, i32, i64, vp, f32, f32, f32, f32, f32, f32, vp, vp, vp, i32, vp]),
+    "csbsr_l1_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i64, vp, f32, vp, i32, vp]),
+    "csbsr_sigmoid_bwd_to_nhwc8": (i32, [vp, vp, vp, i64, f32, vp]),
+}
+
+_lib = None
+
+
+class CsbsrHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it is not built -- there is no CPU / torch fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CsbsrHipError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            f"(or `make -C csbsr_amd/csrc`).  csbsr_amd has no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise CsbsrHipError(f"{name} failed ({rc}): {lib.csbsr_last_error().decode()}")

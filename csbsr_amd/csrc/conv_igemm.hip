@@ -1,0 +1,380 @@
+// Implicit-GEMM convolution / transposed convolution for gfx950.
+//
+//   D[cout][pixel] = sum_k  Wp[cout][k] * X[pixel @ k]      k = tap * Ctot + channel
+//
+// MFMA v_mfma_f32_32x32x16_f16: "A" = packed weights (rows = output channels), "B" = gathered input patches
+// (columns = output pixels), fp32 accumulators.  One 256-thread workgroup (4 wave64) owns a 128-pixel x BN-channel
+// tile; K is walked in 32-wide slices, register-staged global->LDS with double buffering; both LDS tiles are
+// [row][32 + 8 pad] halves so the 16-byte fragment reads are bank-conflict free.  The epilogue stages the fp32
+// tile through LDS so that every global store / residual load is a full 16-byte, channel-contiguous access.
+//
+// A transposed convolution (stride s) is run in its gather form: blockIdx.z selects one of the s*s output
+// residues ("phases"); within a phase it is an ordinary convolution with ceil(K/s)^2 taps walking the input
+// backwards, so conv, deconv and every dgrad share this one kernel (weights re-packed by pack.hip).
+//
+// Reference call sites this stands in for: F.conv2d / F.conv_transpose2d in
+// /root/reference/model/modeling/kbpn.py:241,273-277,513-517 and pspnet_pytorch/{extractors.py:36-38,pspnet.py:30-86}.
+#include "common.h"
+
+#define BM 128
+#define BK 32
+#define LDS_LD 40  // halves per LDS row: 32 + 8 pad (80 B)
+
+struct ConvK {
+  csbsr_seg_t in[2];
+  int N, H, W, OH, OW;
+  int transposed, KHt, KWt;  // taps per phase
+  int stride, pad, dil;
+  int ctot, c0;              // padded channels: total, segment 0
+  int Kp;                    // padded K of the packed weights
+  int rows_p;                // padded weight rows per phase (multiple of 32)
+  const half_t* wt;
+  int cout, coutp;
+  half_t* out16; long o_sn, o_sy, o_sx;
+  float* out32; long o32_sn, o32_sy, o32_sx, o32_sc;
+  const float* bias;
+  int act; float act_slope; const float* prelu;
+  int res_mode; const half_t* res; long r_sn, r_sy, r_sx;
+  const half_t* res2; long r2_sn, r2_sy, r2_sx;
+  int accumulate;
+  int stat_mode; float* stat;
+  float out_scale;
+  unsigned tiles_m, tiles_n;
+};
+
+template <int BN, int WP, int WC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
+  constexpr int PW = BM / WP;      // pixels per wave
+  constexpr int CW = BN / WC;      // couts per wave
+  constexpr int TP = PW / 32;
+  constexpr int TC = CW / 32;
+  constexpr int OUT_LD = BN + 4;   // fp32 staging row
+  constexpr int MAIN_BYTES = 2 * (BN + BM) * LDS_LD * 2;
+  constexpr int EPI_BYTES = BM * OUT_LD * 4;
+  constexpr int SM_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  char* smem = smem_dyn;
+  half_t* sW = reinterpret_cast<half_t*>(smem);                       // [2][BN][LDS_LD]
+  half_t* sX = sW + 2 * BN * LDS_LD;                                  // [2][BM][LDS_LD]
+  int* sRow = reinterpret_cast<int*>(smem + SM_BYTES);                // [BM][3]  n, oy, ox  (n = -1: invalid)
+  float* sStat = reinterpret_cast<float*>(smem + SM_BYTES + BM * 3 * 4);  // [2][BN]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wp = wid / WC, wc = wid % WC;
+
+  // ---- tile coordinates (XCD-aware: one XCD walks consecutive tiles, cout tiles fastest)
+  const unsigned ntile = p.tiles_m * p.tiles_n;
+  const unsigned lt = xcd_remap(blockIdx.x, ntile);
+  const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
+  const int cout0 = tile_n * BN;
+
+  // ---- phase geometry
+  int py = 0, px = 0, OHp = p.OH, OWp = p.OW, in_step = p.stride, tap_step = p.dil, base_y = -p.pad, base_x = -p.pad;
+  int o_step = 1;
+  if (p.transposed) {
+    py = blockIdx.z / p.stride; px = blockIdx.z % p.stride;
+    OHp = (p.OH - py + p.stride - 1) / p.stride;
+    OWp = (p.OW - px + p.stride - 1) / p.stride;
+    in_step = 1; tap_step = -1; o_step = p.stride;
+    base_y = (py + p.pad) / p.stride; base_x = (px + p.pad) / p.stride;
+  }
+  const long M = (long)p.N * OHp * OWp;
+  const long m0 = (long)tile_m * BM;
+  if (m0 >= M) return;
+  const half_t* wt = p.wt + (size_t)blockIdx.z * p.rows_p * p.Kp;
+
+  if (tid < BM) {
+    long m = m0 + tid;
+    int n = -1, oy = 0, ox = 0;
+    if (m < M) {
+      n = (int)(m / ((long)OHp * OWp));
+      int rem = (int)(m - (long)n * OHp * OWp);
+      oy = rem / OWp; ox = rem - oy * OWp;
+    }
+    sRow[tid * 3 + 0] = n; sRow[tid * 3 + 1] = oy; sRow[tid * 3 + 2] = ox;
+  }
+  if (tid < 2 * BN) sStat[tid] = 0.f;
+  __syncthreads();
+
+  // ---- per-thread gather state: rows r0 = tid/4, r0+64 ; 16-byte k-segment seg = tid%4
+  const int seg = tid & 3;
+  int rn[2], riy[2], rix[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (tid >> 2) + 64 * j;
+    rn[j] = sRow[r * 3];
+    riy[j] = sRow[r * 3 + 1] * in_step + base_y;
+    rix[j] = sRow[r * 3 + 2] * in_step + base_x;
+  }
+  // running (tap, channel) of this thread's segment
+  int kc = seg * 8, ky = 0, kx = 0;
+  while (kc >= p.ctot) { kc -= p.ctot; if (++kx == p.KWt) { kx = 0; ++ky; } }
+
+  constexpr int WCH = (BN * 4 + 255) / 256;  // weight chunks per thread
+  h8 gx[2], gw[WCH];
+
+  auto load_tile = [&](int kt) {
+    // weights
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 2, sg = c & 3;
+      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (row < BN && cout0 + row < p.rows_p)
+        v = *reinterpret_cast<const h8*>(wt + (size_t)(cout0 + row) * p.Kp + kt * BK + sg * 8);
+      gw[i] = v;
+    }
+    // patches
+    const bool kvalid = ky < p.KHt;
+    const csbsr_seg_t& sgm = (kc < p.c0) ? p.in[0] : p.in[1];
+    const int cc = (kc < p.c0) ? kc : kc - p.c0;
+    const half_t* base = reinterpret_cast<const half_t*>(sgm.ptr) + cc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int iy = riy[j] + ky * tap_step, ix = rix[j] + kx * tap_step;
+      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (kvalid && rn[j] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        v = *reinterpret_cast<const h8*>(base + rn[j] * sgm.sn + iy * sgm.sy + ix * sgm.sx);
+      gx[j] = v;
+    }
+    // advance by one K slice
+    kc += BK;
+    while (kc >= p.ctot) { kc -= p.ctot; if (++kx == p.KWt) { kx = 0; ++ky; } }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 2, sg = c & 3;
+      if (row < BN) *reinterpret_cast<h8*>(sW + (buf * BN + row) * LDS_LD + sg * 8) = gw[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (tid >> 2) + 64 * j;
+      *reinterpret_cast<h8*>(sX + (buf * BM + r) * LDS_LD + seg * 8) = gx[j];
+    }
+  };
+
+  f16v acc[TC][TP];
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nkt = p.Kp / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    const half_t* w_base = sW + (buf * BN + wc * CW + (lane & 31)) * LDS_LD + (lane >> 5) * 8;
+    const half_t* x_base = sX + (buf * BM + wp * PW + (lane & 31)) * LDS_LD + (lane >> 5) * 8;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      h8 af[TC], bf[TP];
+#pragma unroll
+      for (int a = 0; a < TC; ++a) af[a] = *reinterpret_cast<const h8*>(w_base + a * 32 * LDS_LD + ks * 16);
+#pragma unroll
+      for (int b = 0; b < TP; ++b) bf[b] = *reinterpret_cast<const h8*>(x_base + b * 32 * LDS_LD + ks * 16);
+#pragma unroll
+      for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: fp32 tile -> LDS [pixel][cout], then channel-contiguous 8-wide processing
+  float* sO = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int a = 0; a < TC; ++a)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+      const int pix = wp * PW + b * 32 + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = wc * CW + a * 32 + 8 * q + 4 * (lane >> 5);
+        f4 v = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        *reinterpret_cast<f4*>(sO + pix * OUT_LD + co) = v;
+      }
+    }
+  __syncthreads();
+
+  const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
+  constexpr int CPR = BN / 8;                 // 8-channel chunks per row
+  const int cc8 = tid % CPR;                  // fixed per thread (256 % CPR == 0)
+  const int co = cout0 + cc8 * 8;
+  float bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f;
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
+  const int n_first = sRow[0];
+  int n_last = n_first;
+  {
+    long ml = (m0 + BM - 1 < M - 1) ? m0 + BM - 1 : M - 1;
+    n_last = (int)(ml / ((long)OHp * OWp));
+  }
+  const bool uniform_n = (n_first == n_last);
+  int cur_n = -1;
+
+  for (int row = tid / CPR; row < BM; row += 256 / CPR) {
+    const int n = sRow[row * 3];
+    if (n < 0 || co >= p.coutp) continue;
+    const int oy = py + sRow[row * 3 + 1] * o_step, ox = px + sRow[row * 3 + 2] * o_step;
+    float v[8];
+    const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
+    const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
+    v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = v[e] * p.out_scale + bias[e];
+      t = apply_act(t, p.act, slope);
+      v[e] = (co + e < p.cout) ? t : 0.f;
+    }
+    if (p.stat_mode == CSBSR_STAT_BN) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+    } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM) {
+      if (!uniform_n && n != cur_n) {
+        if (cur_n >= 0)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { atomicAdd(p.stat + (size_t)cur_n * p.coutp + co + e, ssum[e]); ssum[e] = 0.f; }
+        cur_n = n;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ssum[e] += v[e];
+    }
+    if (p.res_mode != CSBSR_RES_NONE) {
+      const h8 r = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
+      h8 r2 = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (p.res_mode == CSBSR_RES_FMA) r2 = *reinterpret_cast<const h8*>(p.res2 + n * p.r2_sn + oy * p.r2_sy + ox * p.r2_sx + co);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float rv = (float)r[e];
+        switch (p.res_mode) {
+          case CSBSR_RES_ADD: v[e] += rv; break;
+          case CSBSR_RES_SUB: v[e] -= rv; break;
+          case CSBSR_RES_MUL: v[e] *= rv; break;
+          default: v[e] += rv * (float)r2[e]; break;
+        }
+      }
+    }
+    if (p.out16) {
+      half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
+      if (p.accumulate) {
+        const h8 old = *reinterpret_cast<const h8*>(o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+      }
+      h8 hv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
+      *reinterpret_cast<h8*>(o) = hv;
+    }
+    if (p.out32) {
+      float* o = p.out32 + n * p.o32_sn + oy * p.o32_sy + ox * p.o32_sx;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (co + e < p.cout) {
+          float* q = o + (co + e) * p.o32_sc;
+          *q = (p.accumulate && !p.out16) ? *q + v[e] : v[e];
+        }
+    }
+  }
+
+  if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
+    if (co < p.coutp) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(&sStat[cc8 * 8 + e], ssum[e]);
+        if (p.stat_mode == CSBSR_STAT_BN) atomicAdd(&sStat[BN + cc8 * 8 + e], ssq[e]);
+      }
+    }
+    __syncthreads();
+    if (tid < BN && cout0 + tid < p.coutp) {
+      if (p.stat_mode == CSBSR_STAT_BN) {
+        atomicAdd(p.stat + cout0 + tid, sStat[tid]);
+        atomicAdd(p.stat + p.coutp + cout0 + tid, sStat[BN + tid]);
+      } else if (n_first >= 0) {
+        atomicAdd(p.stat + (size_t)n_first * p.coutp + cout0 + tid, sStat[tid]);
+      }
+    }
+  } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && cur_n >= 0 && co < p.coutp) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(p.stat + (size_t)cur_n * p.coutp + co + e, ssum[e]);
+  }
+}
+
+template <int BN, int WP, int WC>
+static int launch_conv(const ConvK& k, int nphase, long maxM, hipStream_t st) {
+  ConvK p = k;
+  p.tiles_m = (unsigned)((maxM + BM - 1) / BM);
+  p.tiles_n = (unsigned)((k.coutp + BN - 1) / BN);
+  constexpr int OUT_LD = BN + 4;
+  constexpr int MAIN_BYTES = 2 * (BN + BM) * LDS_LD * 2;
+  constexpr int EPI_BYTES = BM * OUT_LD * 4;
+  constexpr int SM_BYTES = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + BM * 3 * 4 + 2 * BN * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BN, WP, WC>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, 1, nphase);
+  hipLaunchKernelGGL((conv_igemm_kernel<BN, WP, WC>), grid, dim3(256), SM_BYTES, st, p);
+  CSBSR_LAUNCH_CHECK("csbsr_conv_forward");
+  return 0;
+}
+
+extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) {
+  CSBSR_CHECK(d && d->in[0].ptr && d->wt, "conv: null pointer");
+  CSBSR_CHECK(d->in[0].c > 0 && d->in[0].c % 8 == 0 && d->in[1].c % 8 == 0, "conv: segment channels must be multiples of 8");
+  CSBSR_CHECK(d->coutp % 8 == 0 && d->cout <= d->coutp && d->cout > 0, "conv: bad cout/coutp");
+  CSBSR_CHECK(d->out16 || d->out32 || d->stat_mode != CSBSR_STAT_NONE, "conv: no output requested");
+  CSBSR_CHECK(d->stride >= 1 && d->KH >= 1 && d->KW >= 1, "conv: bad geometry");
+  CSBSR_CHECK(!d->transposed || d->dil == 1, "conv: transposed conv supports dilation 1 only");
+  CSBSR_CHECK(d->act != CSBSR_ACT_PRELU || d->prelu, "conv: PReLU needs a slope pointer");
+  CSBSR_CHECK(d->res_mode == CSBSR_RES_NONE || d->res, "conv: res_mode set without res");
+  ConvK k;
+  k.in[0] = d->in[0]; k.in[1] = d->in[1];
+  if (k.in[1].c == 0) k.in[1] = k.in[0];
+  k.N = d->N; k.H = d->H; k.W = d->W; k.OH = d->OH; k.OW = d->OW;
+  k.transposed = d->transposed;
+  k.stride = d->stride; k.pad = d->pad; k.dil = d->dil;
+  k.KHt = d->transposed ? (d->KH + d->stride - 1) / d->stride : d->KH;
+  k.KWt = d->transposed ? (d->KW + d->stride - 1) / d->stride : d->KW;
+  k.c0 = d->in[0].c; k.ctot = d->in[0].c + d->in[1].c;
+  k.Kp = round_up(k.KHt * k.KWt * k.ctot, BK);
+  k.rows_p = round_up(d->cout, 32);
+  k.wt = reinterpret_cast<const half_t*>(d->wt);
+  k.cout = d->cout; k.coutp = d->coutp;
+  k.out16 = reinterpret_cast<half_t*>(d->out16); k.o_sn = d->o_sn; k.o_sy = d->o_sy; k.o_sx = d->o_sx;
+  k.out32 = d->out32; k.o32_sn = d->o32_sn; k.o32_sy = d->o32_sy; k.o32_sx = d->o32_sx; k.o32_sc = d->o32_sc;
+  k.bias = d->bias; k.act = d->act; k.act_slope = d->act_slope; k.prelu = d->prelu;
+  k.res_mode = d->res_mode; k.res = reinterpret_cast<const half_t*>(d->res);
+  k.r_sn = d->r_sn; k.r_sy = d->r_sy; k.r_sx = d->r_sx;
+  k.res2 = reinterpret_cast<const half_t*>(d->res2); k.r2_sn = d->r2_sn; k.r2_sy = d->r2_sy; k.r2_sx = d->r2_sx;
+  CSBSR_CHECK(d->res_mode != CSBSR_RES_FMA || d->res2, "conv: FMA needs res2");
+  k.accumulate = d->accumulate; k.stat_mode = d->stat_mode; k.stat = d->stat;
+  k.out_scale = d->out_scale;
+  CSBSR_CHECK(d->stat_mode == CSBSR_STAT_NONE || d->stat, "conv: stat_mode set without stat buffer");
+  int nphase = 1;
+  long maxM;
+  if (d->transposed) {
+    nphase = d->stride * d->stride;
+    maxM = (long)d->N * ((d->OH + d->stride - 1) / d->stride) * ((d->OW + d->stride - 1) / d->stride);
+  } else {
+    maxM = (long)d->N * d->OH * d->OW;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  if (k.coutp > 64) return launch_conv<128, 2, 2>(k, nphase, maxM, st);
+  if (k.coutp > 32) return launch_conv<64, 2, 2>(k, nphase, maxM, st);
+  return launch_conv<32, 4, 1>(k, nphase, maxM, st);
+}

@@ -1,0 +1,237 @@
+// Weight-gradient GEMM for gfx950:   G[a][tap][b] = sum over pixels  A[pix][a] * B[pix @ tap][b]
+//
+// Both operands are channels-last, so the reduction dimension (pixels) is the strided one.  Tiles are staged
+// to LDS exactly as loaded ([pixel][channel], 16-byte channel chunks) and the MFMA fragments -- which want 8
+// consecutive *pixels* per lane -- are fetched with the gfx950 hardware transpose read ds_read_b64_tr_b16
+// (two per fragment), so no shuffle / scalar-LDS transposition is needed.  fp32 accumulate; the pixel range is
+// split across grid.z and combined with fp32 atomics.
+//
+// Autograd wgrad of F.conv2d / F.conv_transpose2d at the call sites listed in conv_igemm.hip.
+#include "common.h"
+
+#define WG_BP 32     // pixels per reduction step
+#define WG_BN 128    // columns (tap,channel) per tile
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+struct WgradK {
+  const half_t* a; long a_sn, a_sy, a_sx; int ca;
+  csbsr_seg_t b[2]; int cb0, cbtot;
+  int N, AH, AW, BH, BW;
+  int KH, KW, stride, pad, dil;
+  float* g; int ktot;        // row length of G
+  long M;                    // N*AH*AW
+  long per_split;            // pixels per split (multiple of 32)
+  unsigned tiles_a, tiles_b;
+};
+
+template <bool USE_TR>
+__device__ __forceinline__ h8 frag_T(const half_t* tile, int ld, int pix0, int ch) {
+  // returns {tile[pix0+0..7][ch]}  for the calling lane
+  if constexpr (USE_TR) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15;
+    // lane supplies the address of 4 contiguous halves: row (i/4), columns 4*(i%4).. of its group's 4x16 block;
+    // the group's block starts at channel (ch - i)
+    const half_t* p0 = tile + (pix0 + (i >> 2)) * ld + (ch - i) + 4 * (i & 3);
+    fp16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p0));
+    fp16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(p0 + 4 * ld));
+    h8 v;
+    v[0] = r0[0]; v[1] = r0[1]; v[2] = r0[2]; v[3] = r0[3]; v[4] = r1[0]; v[5] = r1[1]; v[6] = r1[2]; v[7] = r1[3];
+    return v;
+  } else {
+    h8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[(pix0 + e) * ld + ch];
+    return v;
+  }
+}
+
+template <int BA, int WA, int WB, bool USE_TR>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
+  constexpr int AW_ = BA / WA;          // a-rows per wave
+  constexpr int BW_ = WG_BN / WB;       // cols per wave
+  constexpr int TA = AW_ / 32, TB = BW_ / 32;
+  constexpr int LDA = BA + 8, LDB = WG_BN + 8;
+  __shared__ __attribute__((aligned(16))) half_t sA[WG_BP * LDA];
+  __shared__ __attribute__((aligned(16))) half_t sB[WG_BP * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wa = wid / WB, wb = wid % WB;
+  const unsigned ntile = p.tiles_a * p.tiles_b;
+  const unsigned lt = xcd_remap(blockIdx.x, ntile);
+  const int a0 = (lt % p.tiles_a) * BA;
+  const int col0 = (lt / p.tiles_a) * WG_BN;
+  const long mbeg = (long)blockIdx.z * p.per_split;
+  long mend = mbeg + p.per_split;
+  if (mend > p.M) mend = p.M;
+  if (mbeg >= mend) return;
+
+  // ---- B staging role: chunk ids tid, tid+256 : pixel = id/16, col chunk = id%16
+  int b_pix[2], b_ky[2], b_kx[2];
+  const half_t* b_ptr[2];
+  long b_sn[2], b_sy[2], b_sx[2];
+  bool b_ok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int id = tid + 256 * j;
+    b_pix[j] = id >> 4;
+    const int col = col0 + (id & 15) * 8;
+    b_ok[j] = col < p.ktot;
+    const int tap = b_ok[j] ? col / p.cbtot : 0;
+    const int c = b_ok[j] ? col - tap * p.cbtot : 0;
+    b_ky[j] = (tap / p.KW) * p.dil - p.pad;
+    b_kx[j] = (tap % p.KW) * p.dil - p.pad;
+    const csbsr_seg_t& sg = c < p.cb0 ? p.b[0] : p.b[1];
+    b_ptr[j] = reinterpret_cast<const half_t*>(sg.ptr) + (c < p.cb0 ? c : c - p.cb0);
+    b_sn[j] = sg.sn; b_sy[j] = sg.sy; b_sx[j] = sg.sx;
+  }
+  // ---- A staging role: BA/8 chunks per pixel
+  constexpr int ACH = BA / 8;
+  constexpr int A_ITERS = (WG_BP * ACH + 255) / 256;
+
+  // running pixel coordinate of local pixel 0 of the current step
+  int n0 = (int)(mbeg / ((long)p.AH * p.AW));
+  int rem0 = (int)(mbeg - (long)n0 * p.AH * p.AW);
+  int y0 = rem0 / p.AW, x0 = rem0 - y0 * p.AW;
+
+  f16v acc[TA][TB];
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  auto coord = [&](int dp, int& n, int& y, int& x) {
+    // (n0,y0,x0) + dp pixels
+    long xx = (long)x0 + dp;
+    long yy = y0 + xx / p.AW;
+    x = (int)(xx % p.AW);
+    n = n0 + (int)(yy / p.AH);
+    y = (int)(yy % p.AH);
+  };
+
+  for (long m = mbeg; m < mend; m += WG_BP) {
+    // global -> registers
+    h8 gb[2], ga[A_ITERS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (b_ok[j] && m + b_pix[j] < mend) {
+        int n, y, x; coord(b_pix[j], n, y, x);
+        const int by = y * p.stride + b_ky[j], bx = x * p.stride + b_kx[j];
+        if ((unsigned)by < (unsigned)p.BH && (unsigned)bx < (unsigned)p.BW)
+          v = *reinterpret_cast<const h8*>(b_ptr[j] + n * b_sn[j] + by * b_sy[j] + bx * b_sx[j]);
+      }
+      gb[j] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int id = tid + 256 * i;
+      const int pix = id / ACH, ch = (id % ACH) * 8;
+      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (pix < WG_BP && m + pix < mend && a0 + ch < p.ca) {
+        int n, y, x; coord(pix, n, y, x);
+        v = *reinterpret_cast<const h8*>(p.a + n * p.a_sn + y * p.a_sy + x * p.a_sx + a0 + ch);
+      }
+      ga[i] = v;
+    }
+    __syncthreads();   // previous step's fragment reads done
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int id = tid + 256 * j;
+      *reinterpret_cast<h8*>(sB + (id >> 4) * LDB + (id & 15) * 8) = gb[j];
+    }
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int id = tid + 256 * i;
+      const int pix = id / ACH, ch = (id % ACH) * 8;
+      if (pix < WG_BP) *reinterpret_cast<h8*>(sA + pix * LDA + ch) = ga[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < WG_BP / 16; ++ks) {
+      const int pix0 = ks * 16 + (lane >> 5) * 8;
+      h8 af[TA], bf[TB];
+#pragma unroll
+      for (int a = 0; a < TA; ++a) af[a] = frag_T<USE_TR>(sA, LDA, pix0, wa * AW_ + a * 32 + (lane & 31));
+#pragma unroll
+      for (int b = 0; b < TB; ++b) bf[b] = frag_T<USE_TR>(sB, LDB, pix0, wb * BW_ + b * 32 + (lane & 31));
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    // advance running coordinate
+    {
+      long xx = (long)x0 + WG_BP;
+      long yy = y0 + xx / p.AW;
+      x0 = (int)(xx % p.AW);
+      n0 += (int)(yy / p.AH);
+      y0 = (int)(yy % p.AH);
+    }
+  }
+
+  // ---- epilogue: D[a][col], lane: col = lane%32, rows (r&3)+8*(r>>2)+4*(lane>>5)
+  const bool single = gridDim.z == 1;
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      const int col = col0 + wb * BW_ + b * 32 + (lane & 31);
+      if (col >= p.ktot) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = a0 + wa * AW_ + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= p.ca) continue;
+        float* dst = p.g + (size_t)row * p.ktot + col;
+        if (single) *dst += acc[a][b][r];
+        else atomicAdd(dst, acc[a][b][r]);
+      }
+    }
+}
+
+static int g_wgrad_use_tr = 1;
+extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v; }
+
+template <int BA, int WA, int WB>
+static int launch_wgrad(const WgradK& k, int splits, hipStream_t st) {
+  WgradK p = k;
+  p.tiles_a = (unsigned)((k.ca + BA - 1) / BA);
+  p.tiles_b = (unsigned)((k.ktot + WG_BN - 1) / WG_BN);
+  const unsigned ntile = p.tiles_a * p.tiles_b;
+  if (splits <= 0) {
+    long want = (2048 + ntile - 1) / ntile;
+    long maxs = (k.M + 32 * 16 - 1) / (32 * 16);
+    splits = (int)(want < maxs ? want : maxs);
+    if (splits < 1) splits = 1;
+    if (splits > 1024) splits = 1024;
+  }
+  p.per_split = ((k.M + splits - 1) / splits + WG_BP - 1) / WG_BP * WG_BP;
+  splits = (int)((k.M + p.per_split - 1) / p.per_split);
+  dim3 grid(ntile, 1, splits);
+  if (g_wgrad_use_tr)
+    hipLaunchKernelGGL((conv_wgrad_kernel<BA, WA, WB, true>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<BA, WA, WB, false>), grid, dim3(256), 0, st, p);
+  CSBSR_LAUNCH_CHECK("csbsr_conv_wgrad");
+  return 0;
+}
+
+extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
+  CSBSR_CHECK(d && d->a && d->b[0].ptr && d->g, "wgrad: null pointer");
+  CSBSR_CHECK(d->ca % 8 == 0 && d->b[0].c % 8 == 0 && d->b[1].c % 8 == 0 && d->b[0].c > 0, "wgrad: channels must be multiples of 8");
+  WgradK k;
+  k.a = reinterpret_cast<const half_t*>(d->a); k.a_sn = d->a_sn; k.a_sy = d->a_sy; k.a_sx = d->a_sx; k.ca = d->ca;
+  k.b[0] = d->b[0]; k.b[1] = d->b[1];
+  if (k.b[1].c == 0) k.b[1] = k.b[0];
+  k.cb0 = d->b[0].c; k.cbtot = d->b[0].c + d->b[1].c;
+  k.N = d->N; k.AH = d->AH; k.AW = d->AW; k.BH = d->BH; k.BW = d->BW;
+  k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.dil = d->dil;
+  k.g = d->g; k.ktot = d->KH * d->KW * k.cbtot;
+  k.M = (long)d->N * d->AH * d->AW;
+  hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  if (d->ca > 64) return launch_wgrad<128, 2, 2>(k, d->splits, st);
+  if (d->ca > 32) return launch_wgrad<64, 2, 2>(k, d->splits, st);
+  return launch_wgrad<32, 1, 4>(k, d->splits, st);
+}

@@ -1,0 +1,781 @@
+// HBM-bound kernels on fp16 channels-last activations: epilogue backward, batch-norm, pooling, bilinear resize,
+// layout converters.  Every thread moves 16 bytes (8 channels) per access; reductions go wave-shuffle ->
+// LDS -> one atomic per workgroup.  Reference call sites are cited per entry point in include/csbsr_hip.h.
+#include "common.h"
+
+static inline int grid_for(long work, int block = 256, int cap = 8192) {
+  long b = (work + block - 1) / block;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+// ------------------------------------------------------------------------------------------- epilogue backward
+struct EpiK {
+  long npix; int c8, creal;
+  const half_t* dout; long dout_ld;
+  const half_t* out; long out_ld;
+  const half_t* res; long res_ld;
+  const half_t* res2; long res2_ld;
+  int act; float slope; const float* prelu; int res_mode;
+  half_t* dpre; long dpre_ld;
+  half_t* dres; long dres_ld; int dres_acc;
+  half_t* dres2; long dres2_ld; int dres2_acc;
+  float* dbias; float* dprelu;
+};
+
+// block = 256 threads = 32 pixel-lanes x 8? no: thread -> (pixel group, channel chunk): chunk = tid % c8 when c8 <= 256
+__global__ __launch_bounds__(256) void epilogue_bwd_kernel(const EpiK p) {
+  __shared__ float sRed[256 * 8];
+  __shared__ float sPre[256];
+  const int tid = threadIdx.x;
+  const int cpb = p.c8 < 256 ? p.c8 : 256;           // chunks handled per block column sweep
+  const int ppb = 256 / cpb;                         // pixels per block iteration (>=1)
+  const int ch = tid % cpb, pl = tid / cpb;
+  const float slope = p.act == CSBSR_ACT_PRELU ? *p.prelu : p.slope;
+  float dpr = 0.f;
+  for (int cbase = 0; cbase < p.c8; cbase += cpb) {
+    const int c8i = cbase + ch;
+    float db[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) db[e] = 0.f;
+    if (c8i < p.c8 && pl < ppb) {
+      const int c0 = c8i * 8;
+      for (long px = (long)blockIdx.x * ppb + pl; px < p.npix; px += (long)gridDim.x * ppb) {
+        const h8 go = *reinterpret_cast<const h8*>(p.dout + px * p.dout_ld + c0);
+        h8 o = {0, 0, 0, 0, 0, 0, 0, 0}, r = {0, 0, 0, 0, 0, 0, 0, 0}, r2 = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.out) o = *reinterpret_cast<const h8*>(p.out + px * p.out_ld + c0);
+        if (p.res) r = *reinterpret_cast<const h8*>(p.res + px * p.res_ld + c0);
+        if (p.res2) r2 = *reinterpret_cast<const h8*>(p.res2 + px * p.res2_ld + c0);
+        h8 dp, dr, dr2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float g = (float)go[e];
+          float y, gy, gr = 0.f, gr2 = 0.f;   // y = act(pre): rebuilt from the saved output
+          const float ov = (float)o[e], rv = (float)r[e], r2v = (float)r2[e];
+          switch (p.res_mode) {
+            case CSBSR_RES_ADD: y = ov - rv; gy = g; gr = g; break;
+            case CSBSR_RES_SUB: y = ov + rv; gy = g; gr = -g; break;
+            case CSBSR_RES_MUL: y = 0.f; gy = g * rv; gr = 0.f; break;   // y not recoverable: only act NONE allowed
+            case 4 /*FMA: out = y + res*res2*/: y = ov - rv * r2v; gy = g; gr = g * r2v; gr2 = g * rv; break;
+            default: y = ov; gy = g; break;
+          }
+          float d;
+          switch (p.act) {
+            case CSBSR_ACT_RELU: d = y > 0.f ? gy : 0.f; break;
+            case CSBSR_ACT_LRELU: d = y > 0.f ? gy : gy * slope; break;
+            case CSBSR_ACT_PRELU:
+              d = y > 0.f ? gy : gy * slope;
+              if (!(y > 0.f)) dpr += gy * (y / slope);          // pre-activation x = y / slope for x <= 0
+              break;
+            case CSBSR_ACT_SIGMOID: d = gy * y * (1.f - y); break;
+            default: d = gy; break;
+          }
+          if (c0 + e >= p.creal) d = 0.f;
+          dp[e] = (half_t)d; db[e] += d;
+          dr[e] = (half_t)gr; dr2[e] = (half_t)gr2;
+        }
+        if (p.dpre) *reinterpret_cast<h8*>(p.dpre + px * p.dpre_ld + c0) = dp;
+        if (p.dres) {
+          half_t* q = p.dres + px * p.dres_ld + c0;
+          if (p.dres_acc) { const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dr[e] = (half_t)((float)dr[e] + (float)old[e]); }
+          *reinterpret_cast<h8*>(q) = dr;
+        }
+        if (p.dres2) {
+          half_t* q = p.dres2 + px * p.dres2_ld + c0;
+          if (p.dres2_acc) { const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dr2[e] = (half_t)((float)dr2[e] + (float)old[e]); }
+          *reinterpret_cast<h8*>(q) = dr2;
+        }
+      }
+    }
+    if (p.dbias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sRed[tid * 8 + e] = db[e];
+      __syncthreads();
+      if (tid < cpb && cbase + tid < p.c8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float s = 0.f;
+          for (int q = 0; q < ppb; ++q) s += sRed[(q * cpb + tid) * 8 + e];
+          if ((cbase + tid) * 8 + e < p.creal) atomicAdd(p.dbias + (cbase + tid) * 8 + e, s);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (p.dprelu) {
+    dpr = wave_sum(dpr);
+    if ((tid & 63) == 0) sPre[tid >> 6] = dpr;
+    __syncthreads();
+    if (tid == 0) atomicAdd(p.dprelu, sPre[0] + sPre[1] + sPre[2] + sPre[3]);
+  }
+}
+
+extern "C" int csbsr_epilogue_backward(const csbsr_epi_bwd_desc_t* d, csbsr_stream_t s) {
+  CSBSR_CHECK(d && d->dout, "epilogue_bwd: null dout");
+  CSBSR_CHECK(d->c % 8 == 0, "epilogue_bwd: channels must be a multiple of 8");
+  CSBSR_CHECK(d->act == CSBSR_ACT_NONE || d->out, "epilogue_bwd: activation backward needs the saved output");
+  CSBSR_CHECK(!(d->res_mode == CSBSR_RES_MUL && d->act != CSBSR_ACT_NONE), "epilogue_bwd: MUL with activation unsupported");
+  EpiK k;
+  k.npix = d->npix; k.c8 = d->c / 8; k.creal = d->creal;
+  k.dout = (const half_t*)d->dout; k.dout_ld = d->dout_ld;
+  k.out = (const half_t*)d->out; k.out_ld = d->out_ld;
+  k.res = (const half_t*)d->res; k.res_ld = d->res_ld;
+  k.res2 = (const half_t*)d->res2; k.res2_ld = d->res2_ld;
+  k.act = d->act; k.slope = d->act_slope; k.prelu = d->prelu; k.res_mode = d->res_mode;
+  k.dpre = (half_t*)d->dpre; k.dpre_ld = d->dpre_ld;
+  k.dres = (half_t*)d->dres; k.dres_ld = d->dres_ld; k.dres_acc = d->dres_accumulate;
+  k.dres2 = (half_t*)d->dres2; k.dres2_ld = d->dres2_ld; k.dres2_acc = d->dres2_accumulate;
+  k.dbias = d->dbias; k.dprelu = d->dprelu;
+  const int cpb = k.c8 < 256 ? k.c8 : 256;
+  const int ppb = 256 / cpb;
+  int blocks = grid_for(d->npix, ppb * 8, 2048);
+  hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(blocks), dim3(256), 0, ST(s), k);
+  CSBSR_LAUNCH_CHECK("csbsr_epilogue_backward");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- axpby / fill / casts
+__global__ void axpby_kernel(long npix, int c8, const half_t* x, long x_ld, float a, const half_t* z, long z_ld, float b,
+                             half_t* y, long y_ld) {
+  const long total = npix * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long px = i / c8; const int c0 = (int)(i % c8) * 8;
+    const h8 xv = *reinterpret_cast<const h8*>(x + px * x_ld + c0);
+    h8 zv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (z) zv = *reinterpret_cast<const h8*>(z + px * z_ld + c0);
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)(a * (float)xv[e] + b * (float)zv[e]);
+    *reinterpret_cast<h8*>(y + px * y_ld + c0) = o;
+  }
+}
+extern "C" int csbsr_axpby(int64_t npix, int32_t c, const void* x, int64_t x_ld, float a, const void* z, int64_t z_ld,
+                           float b, void* y, int64_t y_ld, csbsr_stream_t s) {
+  CSBSR_CHECK(c % 8 == 0 && x && y, "axpby: bad args");
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(npix * (c / 8))), dim3(256), 0, ST(s), npix, c / 8, (const half_t*)x, x_ld,
+                     a, (const half_t*)z, z_ld, b, (half_t*)y, y_ld);
+  CSBSR_LAUNCH_CHECK("csbsr_axpby");
+  return 0;
+}
+__global__ void fill16_kernel(half_t* p, long npix, int c8, long ld, float v) {
+  const long total = npix * c8;
+  h8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (half_t)v;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    *reinterpret_cast<h8*>(p + (i / c8) * ld + (i % c8) * 8) = o;
+}
+extern "C" int csbsr_fill_f16(void* p, int64_t npix, int32_t c, int64_t ld, float v, csbsr_stream_t s) {
+  CSBSR_CHECK(c % 8 == 0 && p, "fill: bad args");
+  hipLaunchKernelGGL(fill16_kernel, dim3(grid_for(npix * (c / 8))), dim3(256), 0, ST(s), (half_t*)p, npix, c / 8, ld, v);
+  CSBSR_LAUNCH_CHECK("csbsr_fill_f16");
+  return 0;
+}
+
+// fp32 NCHW (optionally normalised per (n,c): (x-mean)*invstd) -> fp16 NHWC, channels padded with zeros
+__global__ void nchw32_to_nhwc16_kernel(const float* src, half_t* dst, int N, int C, long hw, int cp, long d_ld,
+                                        const float* mean, const float* invstd) {
+  const int c8 = cp / 8;
+  const long total = (long)N * hw * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8); const long px = i / c8;
+    const long n = px / hw, r = px - n * hw;
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cc * 8 + e;
+      float v = 0.f;
+      if (c < C) {
+        v = src[(n * C + c) * hw + r];
+        if (mean) v = (v - mean[n * C + c]) * invstd[n * C + c];
+      }
+      o[e] = (half_t)v;
+    }
+    *reinterpret_cast<h8*>(dst + px * d_ld + cc * 8) = o;
+  }
+}
+extern "C" int csbsr_nchw32_to_nhwc16(const float* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t cp,
+                                      int64_t dst_ld, const float* mean, const float* invstd, csbsr_stream_t s) {
+  CSBSR_CHECK(src && dst && cp % 8 == 0 && cp >= C, "nchw32_to_nhwc16: bad args");
+  const long hw = (long)H * W;
+  hipLaunchKernelGGL(nchw32_to_nhwc16_kernel, dim3(grid_for((long)N * hw * (cp / 8))), dim3(256), 0, ST(s), src, (half_t*)dst, N,
+                     C, hw, cp, dst_ld, mean, invstd);
+  CSBSR_LAUNCH_CHECK("csbsr_nchw32_to_nhwc16");
+  return 0;
+}
+// fp16 NHWC (first C channels) -> fp32 NCHW, dst = beta*dst + alpha*src
+__global__ void nhwc16_to_nchw32_kernel(const half_t* src, long s_ld, float* dst, int N, int C, long hw, float alpha, float beta) {
+  const long total = (long)N * hw;
+  for (long px = (long)blockIdx.x * blockDim.x + threadIdx.x; px < total; px += (long)gridDim.x * blockDim.x) {
+    const long n = px / hw, r = px - n * hw;
+    const h8 v = *reinterpret_cast<const h8*>(src + px * s_ld);
+    for (int c = 0; c < C && c < 8; ++c) {
+      float* q = dst + (n * C + c) * hw + r;
+      *q = (beta != 0.f ? beta * *q : 0.f) + alpha * (float)v[c];
+    }
+  }
+}
+extern "C" int csbsr_nhwc16_to_nchw32(const void* src, int64_t src_ld, float* dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                                      float alpha, float beta, csbsr_stream_t s) {
+  CSBSR_CHECK(src && dst && C <= 8, "nhwc16_to_nchw32: supports up to 8 channels");
+  const long hw = (long)H * W;
+  hipLaunchKernelGGL(nhwc16_to_nchw32_kernel, dim3(grid_for((long)N * hw)), dim3(256), 0, ST(s), (const half_t*)src, src_ld, dst,
+                     N, C, hw, alpha, beta);
+  CSBSR_LAUNCH_CHECK("csbsr_nhwc16_to_nchw32");
+  return 0;
+}
+
+// per-plane reductions of fp32 NCHW planes: out[plane][0] = sum a, [1] = sum a*a (b==NULL) or sum a*b
+__global__ __launch_bounds__(256) void plane_reduce_kernel(const float* a, const float* b, long hw, float* out, int chunks) {
+  __shared__ float s0[4], s1[4];
+  const int plane = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const long per = (hw + chunks - 1) / chunks;
+  const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;
+  const float* pa = a + (long)plane * hw;
+  const float* pb = b ? b + (long)plane * hw : nullptr;
+  float x0 = 0.f, x1 = 0.f;
+  for (long i = beg + threadIdx.x; i < end; i += 256) {
+    const float v = pa[i];
+    x0 += v; x1 += pb ? v * pb[i] : v * v;
+  }
+  x0 = wave_sum(x0); x1 = wave_sum(x1);
+  if ((threadIdx.x & 63) == 0) { s0[threadIdx.x >> 6] = x0; s1[threadIdx.x >> 6] = x1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(out + plane * 2, s0[0] + s0[1] + s0[2] + s0[3]);
+    atomicAdd(out + plane * 2 + 1, s1[0] + s1[1] + s1[2] + s1[3]);
+  }
+}
+extern "C" int csbsr_plane_reduce(const float* a, const float* b, int32_t planes, int64_t hw, float* out /*[planes][2] zeroed*/,
+                                  csbsr_stream_t s) {
+  CSBSR_CHECK(a && out, "plane_reduce: null");
+  int chunks = (int)((hw + 65535) / 65536);
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(plane_reduce_kernel, dim3(planes * chunks), dim3(256), 0, ST(s), a, b, hw, out, chunks);
+  CSBSR_LAUNCH_CHECK("csbsr_plane_reduce");
+  return 0;
+}
+
+// InstanceNorm2d backward on planes: dx (+)= invstd*(dy - mean(dy) - xhat*mean(dy*xhat)), dy given as fp16 NHWC8
+__global__ void instnorm_bwd_reduce_kernel(const half_t* dy, long dy_ld, const float* x, const float* mean, const float* invstd,
+                                           int C, long hw, float* red /*[N*C][2]*/, int chunks) {
+  __shared__ float sm[4][8][2];
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const long per = (hw + chunks - 1) / chunks;
+  const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;
+  float a0[8], a1[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) a0[c] = a1[c] = 0.f;
+  for (long i = beg + threadIdx.x; i < end; i += 256) {
+    const h8 g = *reinterpret_cast<const h8*>(dy + ((long)n * hw + i) * dy_ld);
+    for (int c = 0; c < C; ++c) {
+      const float xh = (x[((long)n * C + c) * hw + i] - mean[n * C + c]) * invstd[n * C + c];
+      a0[c] += (float)g[c]; a1[c] += (float)g[c] * xh;
+    }
+  }
+  for (int c = 0; c < C; ++c) {
+    const float v0 = wave_sum(a0[c]), v1 = wave_sum(a1[c]);
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][c][0] = v0; sm[threadIdx.x >> 6][c][1] = v1; }
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x;
+    atomicAdd(red + (n * C + c) * 2, sm[0][c][0] + sm[1][c][0] + sm[2][c][0] + sm[3][c][0]);
+    atomicAdd(red + (n * C + c) * 2 + 1, sm[0][c][1] + sm[1][c][1] + sm[2][c][1] + sm[3][c][1]);
+  }
+}
+__global__ void instnorm_bwd_apply_kernel(const half_t* dy, long dy_ld, const float* x, const float* mean, const float* invstd,
+                                          const float* red, int N, int C, long hw, float* dx, int accumulate) {
+  const long total = (long)N * hw;
+  for (long px = (long)blockIdx.x * blockDim.x + threadIdx.x; px < total; px += (long)gridDim.x * blockDim.x) {
+    const long n = px / hw, r = px - n * hw;
+    const h8 g = *reinterpret_cast<const h8*>(dy + px * dy_ld);
+    for (int c = 0; c < C; ++c) {
+      const long pi = n * C + c;
+      const float is = invstd[pi];
+      const float xh = (x[pi * hw + r] - mean[pi]) * is;
+      const float v = is * ((float)g[c] - red[pi * 2] / hw - xh * red[pi * 2 + 1] / hw);
+      float* q = dx + pi * hw + r;
+      *q = accumulate ? *q + v : v;
+    }
+  }
+}
+extern "C" int csbsr_instnorm_bwd(const void* dy, int64_t dy_ld, const float* x, const float* mean, const float* invstd,
+                                  float* dx, int32_t accumulate, int32_t N, int32_t C, int64_t hw, float* red /*[N*C][2] zeroed*/,
+                                  csbsr_stream_t s) {
+  CSBSR_CHECK(dy && x && dx && red && C <= 8, "instnorm_bwd: bad args");
+  int chunks = (int)((hw + 65535) / 65536);
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(instnorm_bwd_reduce_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)dy, dy_ld, x, mean, invstd, C,
+                     hw, red, chunks);
+  hipLaunchKernelGGL(instnorm_bwd_apply_kernel, dim3(grid_for((long)N * hw)), dim3(256), 0, ST(s), (const half_t*)dy, dy_ld, x, mean,
+                     invstd, red, N, C, hw, dx, accumulate);
+  CSBSR_LAUNCH_CHECK("csbsr_instnorm_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- batch norm (train)
+__global__ void bn_finalize_kernel(const float* stat, long count, int c, int cstride, float eps, float momentum, float* mean,
+                                   float* invstd, float* rmean, float* rvar) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const double m = (double)stat[i] / count;
+  double var = (double)stat[cstride + i] / count - m * m;
+  if (var < 0) var = 0;
+  mean[i] = (float)m;
+  invstd[i] = (float)(1.0 / sqrt(var + eps));
+  if (rmean) {
+    const double unb = count > 1 ? var * count / (count - 1) : var;
+    rmean[i] = (1.f - momentum) * rmean[i] + momentum * (float)m;
+    rvar[i] = (1.f - momentum) * rvar[i] + momentum * (float)unb;
+  }
+}
+extern "C" int csbsr_bn_finalize(const float* stat, int64_t count, int32_t c, int32_t cstride, float eps, float momentum,
+                                 float* mean, float* invstd, float* running_mean, float* running_var, csbsr_stream_t s) {
+  CSBSR_CHECK(stat && mean && invstd, "bn_finalize: null");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, ST(s), stat, (long)count, c, cstride, eps, momentum, mean,
+                     invstd, running_mean, running_var);
+  CSBSR_LAUNCH_CHECK("csbsr_bn_finalize");
+  return 0;
+}
+
+struct BnK {
+  long npix, hw; int c8;
+  const half_t* x; long x_ld;
+  const float *mean, *invstd, *gamma, *beta;
+  const half_t* res; long res_ld;
+  int act; const float* prelu; const float* drop;
+  half_t* y; long y_ld;
+  // backward
+  const half_t* dy; long dy_ld;
+  float* red; float* dprelu;
+  half_t* dx; long dx_ld;
+  half_t* dres; long dres_ld; int dres_acc;
+  float *dgamma, *dbeta;
+  int cp;
+};
+
+__global__ void bn_apply_kernel(const BnK p) {
+  const long total = p.npix * p.c8;
+  const float slope = p.act == CSBSR_ACT_PRELU ? *p.prelu : 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long px = i / p.c8; const int c0 = (int)(i % p.c8) * 8;
+    const h8 xv = *reinterpret_cast<const h8*>(p.x + px * p.x_ld + c0);
+    h8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p.res) rv = *reinterpret_cast<const h8*>(p.res + px * p.res_ld + c0);
+    const long n = px / p.hw;
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      float v = ((float)xv[e] - p.mean[c]) * p.invstd[c] * p.gamma[c] + p.beta[c] + (float)rv[e];
+      v = apply_act(v, p.act, slope);
+      if (p.drop) v *= p.drop[n * p.cp + c];
+      o[e] = (half_t)v;
+    }
+    *reinterpret_cast<h8*>(p.y + px * p.y_ld + c0) = o;
+  }
+}
+
+// z = gamma*xhat + beta + res ; y = drop * act(z).  dz = dy * drop * act'(z)
+__device__ __forceinline__ float bn_dz(const BnK& p, float dy, float xh, float r, int c, long n, float slope, float& dslope) {
+  const float z = xh * p.gamma[c] + p.beta[c] + r;
+  float g = dy;
+  if (p.drop) g *= p.drop[n * p.cp + c];
+  switch (p.act) {
+    case CSBSR_ACT_RELU: return z > 0.f ? g : 0.f;
+    case CSBSR_ACT_PRELU:
+      if (!(z > 0.f)) { dslope += g * z; return g * slope; }
+      return g;
+    default: return g;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnK p) {
+  __shared__ float sRed[256 * 16];
+  __shared__ float sPre[4];
+  const int tid = threadIdx.x;
+  const int cpb = p.c8 < 256 ? p.c8 : 256;
+  const int ppb = 256 / cpb;
+  const int ch = tid % cpb, pl = tid / cpb;
+  const float slope = p.act == CSBSR_ACT_PRELU ? *p.prelu : 0.f;
+  float dsl = 0.f;
+  for (int cbase = 0; cbase < p.c8; cbase += cpb) {
+    float s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+    const int c8i = cbase + ch;
+    if (c8i < p.c8 && pl < ppb) {
+      const int c0 = c8i * 8;
+      for (long px = (long)blockIdx.x * ppb + pl; px < p.npix; px += (long)gridDim.x * ppb) {
+        const h8 g = *reinterpret_cast<const h8*>(p.dy + px * p.dy_ld + c0);
+        const h8 xv = *reinterpret_cast<const h8*>(p.x + px * p.x_ld + c0);
+        h8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.res) rv = *reinterpret_cast<const h8*>(p.res + px * p.res_ld + c0);
+        const long n = px / p.hw;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = c0 + e;
+          const float xh = ((float)xv[e] - p.mean[c]) * p.invstd[c];
+          const float dz = bn_dz(p, (float)g[e], xh, (float)rv[e], c, n, slope, dsl);
+          s0[e] += dz; s1[e] += dz * xh;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sRed[tid * 16 + e] = s0[e]; sRed[tid * 16 + 8 + e] = s1[e]; }
+    __syncthreads();
+    if (tid < cpb && cbase + tid < p.c8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = 0.f, b = 0.f;
+        for (int q = 0; q < ppb; ++q) { a += sRed[(q * cpb + tid) * 16 + e]; b += sRed[(q * cpb + tid) * 16 + 8 + e]; }
+        atomicAdd(p.red + (cbase + tid) * 8 + e, a);
+        atomicAdd(p.red + p.cp + (cbase + tid) * 8 + e, b);
+      }
+    }
+    __syncthreads();
+  }
+  if (p.dprelu) {
+    dsl = wave_sum(dsl);
+    if ((tid & 63) == 0) sPre[tid >> 6] = dsl;
+    __syncthreads();
+    if (tid == 0) atomicAdd(p.dprelu, sPre[0] + sPre[1] + sPre[2] + sPre[3]);
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(const BnK p) {
+  const long total = p.npix * p.c8;
+  const float slope = p.act == CSBSR_ACT_PRELU ? *p.prelu : 0.f;
+  const float inv_cnt = 1.f / (float)p.npix;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long px = i / p.c8; const int c0 = (int)(i % p.c8) * 8;
+    const h8 g = *reinterpret_cast<const h8*>(p.dy + px * p.dy_ld + c0);
+    const h8 xv = *reinterpret_cast<const h8*>(p.x + px * p.x_ld + c0);
+    h8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p.res) rv = *reinterpret_cast<const h8*>(p.res + px * p.res_ld + c0);
+    const long n = px / p.hw;
+    h8 o, dr;
+    float dummy = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e;
+      const float xh = ((float)xv[e] - p.mean[c]) * p.invstd[c];
+      const float dz = bn_dz(p, (float)g[e], xh, (float)rv[e], c, n, slope, dummy);
+      const float v = p.gamma[c] * p.invstd[c] * (dz - p.red[c] * inv_cnt - xh * p.red[p.cp + c] * inv_cnt);
+      o[e] = (half_t)v; dr[e] = (half_t)dz;
+    }
+    *reinterpret_cast<h8*>(p.dx + px * p.dx_ld + c0) = o;
+    if (p.dres) {
+      half_t* q = p.dres + px * p.dres_ld + c0;
+      if (p.dres_acc) { const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dr[e] = (half_t)((float)dr[e] + (float)old[e]); }
+      *reinterpret_cast<h8*>(q) = dr;
+    }
+  }
+}
+__global__ void bn_param_grad_kernel(const float* red, int c, int cp, float* dgamma, float* dbeta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  dbeta[i] += red[i];
+  dgamma[i] += red[cp + i];
+}
+
+static void fill_bnk(BnK& k, const csbsr_bn_desc_t* d) {
+  k.npix = d->npix; k.hw = d->hw; k.c8 = d->c / 8; k.cp = d->c;
+  k.x = (const half_t*)d->x; k.x_ld = d->x_ld;
+  k.mean = d->mean; k.invstd = d->invstd; k.gamma = d->gamma; k.beta = d->beta;
+  k.res = (const half_t*)d->res; k.res_ld = d->res_ld;
+  k.act = d->act; k.prelu = d->prelu; k.drop = d->drop;
+  k.y = (half_t*)d->y; k.y_ld = d->y_ld;
+  k.dy = (const half_t*)d->dy; k.dy_ld = d->dy_ld;
+  k.red = d->red; k.dprelu = d->dprelu;
+  k.dx = (half_t*)d->dx; k.dx_ld = d->dx_ld;
+  k.dres = (half_t*)d->dres; k.dres_ld = d->dres_ld; k.dres_acc = d->dres_accumulate;
+  k.dgamma = d->dgamma; k.dbeta = d->dbeta;
+}
+extern "C" int csbsr_bn_apply(const csbsr_bn_desc_t* d, csbsr_stream_t s) {
+  CSBSR_CHECK(d && d->x && d->y && d->c % 8 == 0, "bn_apply: bad args");
+  BnK k; fill_bnk(k, d);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(k.npix * k.c8)), dim3(256), 0, ST(s), k);
+  CSBSR_LAUNCH_CHECK("csbsr_bn_apply");
+  return 0;
+}
+extern "C" int csbsr_bn_backward(const csbsr_bn_desc_t* d, csbsr_stream_t s) {
+  CSBSR_CHECK(d && d->x && d->dy && d->dx && d->red && d->c % 8 == 0, "bn_backward: bad args");
+  BnK k; fill_bnk(k, d);
+  const int cpb = k.c8 < 256 ? k.c8 : 256;
+  const int ppb = 256 / cpb;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(k.npix, ppb * 8, 1024)), dim3(256), 0, ST(s), k);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(k.npix * k.c8)), dim3(256), 0, ST(s), k);
+  if (d->dgamma)
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3((d->creal + 255) / 256), dim3(256), 0, ST(s), d->red, d->creal, d->c, d->dgamma, d->dbeta);
+  CSBSR_LAUNCH_CHECK("csbsr_bn_backward");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- max pool 3x3 s2 p1
+__global__ void maxpool_fwd_kernel(const half_t* x, half_t* y, int N, int H, int W, int c8, int OH, int OW) {
+  const long total = (long)N * OH * OW * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8); long t = i / c8;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH); const int n = (int)(t / OH);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -65504.f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky; if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx; if ((unsigned)ix >= (unsigned)W) continue;
+        const h8 v = *reinterpret_cast<const h8*>(x + (((long)n * H + iy) * W + ix) * c8 * 8 + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+      }
+    }
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
+    *reinterpret_cast<h8*>(y + i * 8) = o;
+  }
+}
+// gather form: dx[iy,ix] = sum over windows containing it whose argmax (first max in scan order) is (iy,ix)
+__global__ void maxpool_bwd_kernel(const half_t* x, const half_t* y, const half_t* dy, half_t* dx, int N, int H, int W, int c8,
+                                   int OH, int OW) {
+  const long total = (long)N * H * W * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8); long t = i / c8;
+    const int ix = (int)(t % W); t /= W;
+    const int iy = (int)(t % H); const int n = (int)(t / H);
+    const h8 xv = *reinterpret_cast<const h8*>(x + i * 8);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int oy = iy / 2 > 0 ? iy / 2 - 1 : 0; oy <= (iy + 1) / 2 && oy < OH; ++oy) {
+      if (oy * 2 - 1 > iy || oy * 2 + 1 < iy) continue;
+      for (int ox = ix / 2 > 0 ? ix / 2 - 1 : 0; ox <= (ix + 1) / 2 && ox < OW; ++ox) {
+        if (ox * 2 - 1 > ix || ox * 2 + 1 < ix) continue;
+        const long oi = (((long)n * OH + oy) * OW + ox) * c8 + cc;
+        const h8 yv = *reinterpret_cast<const h8*>(y + oi * 8);
+        const h8 gv = *reinterpret_cast<const h8*>(dy + oi * 8);
+        // is (iy,ix) the FIRST position in the window attaining the max?
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (xv[e] != yv[e]) continue;
+          bool first = true;
+          for (int ky = 0; ky < 3 && first; ++ky) {
+            const int jy = oy * 2 - 1 + ky; if ((unsigned)jy >= (unsigned)H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+              const int jx = ox * 2 - 1 + kx; if ((unsigned)jx >= (unsigned)W) continue;
+              if (jy == iy && jx == ix) { ky = 3; break; }
+              if (x[((((long)n * H + jy) * W + jx) * c8 + cc) * 8 + e] == yv[e]) { first = false; break; }
+            }
+          }
+          if (first) acc[e] += (float)gv[e];
+        }
+      }
+    }
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+    *reinterpret_cast<h8*>(dx + i * 8) = o;
+  }
+}
+extern "C" int csbsr_maxpool3x3s2_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
+  CSBSR_CHECK(x && y && c % 8 == 0, "maxpool: bad args");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long)N * OH * OW * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x, (half_t*)y, N,
+                     H, W, c / 8, OH, OW);
+  CSBSR_LAUNCH_CHECK("csbsr_maxpool3x3s2_fwd");
+  return 0;
+}
+extern "C" int csbsr_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
+                                      int32_t c, csbsr_stream_t s) {
+  CSBSR_CHECK(x && y && dy && dx && c % 8 == 0, "maxpool_bwd: bad args");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x,
+                     (const half_t*)y, (const half_t*)dy, (half_t*)dx, N, H, W, c / 8, OH, OW);
+  CSBSR_LAUNCH_CHECK("csbsr_maxpool3x3s2_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- adaptive avg pool
+__global__ void aap_fwd_kernel(const half_t* x, long x_ld, half_t* y, int N, int H, int W, int c8, int OH, int OW) {
+  const long total = (long)N * OH * OW * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8); long t = i / c8;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH); const int n = (int)(t / OH);
+    const int y0 = (oy * H) / OH, y1 = ((oy + 1) * H + OH - 1) / OH;
+    const int x0 = (ox * W) / OW, x1 = ((ox + 1) * W + OW - 1) / OW;
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    for (int iy = y0; iy < y1; ++iy)
+      for (int ix = x0; ix < x1; ++ix) {
+        const h8 v = *reinterpret_cast<const h8*>(x + (((long)n * H + iy) * W + ix) * x_ld + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+      }
+    const float inv = 1.f / ((y1 - y0) * (x1 - x0));
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)(a[e] * inv);
+    *reinterpret_cast<h8*>(y + i * 8) = o;
+  }
+}
+__global__ void aap_bwd_kernel(const half_t* dy, half_t* dx, long dx_ld, int accumulate, int N, int H, int W, int c8, int OH, int OW) {
+  const long total = (long)N * H * W * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8); long t = i / c8;
+    const int ix = (int)(t % W); t /= W;
+    const int iy = (int)(t % H); const int n = (int)(t / H);
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    for (int oy = 0; oy < OH; ++oy) {
+      const int y0 = (oy * H) / OH, y1 = ((oy + 1) * H + OH - 1) / OH;
+      if (iy < y0 || iy >= y1) continue;
+      for (int ox = 0; ox < OW; ++ox) {
+        const int x0 = (ox * W) / OW, x1 = ((ox + 1) * W + OW - 1) / OW;
+        if (ix < x0 || ix >= x1) continue;
+        const h8 g = *reinterpret_cast<const h8*>(dy + ((((long)n * OH + oy) * OW + ox) * c8 + cc) * 8);
+        const float inv = 1.f / ((y1 - y0) * (x1 - x0));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += (float)g[e] * inv;
+      }
+    }
+    half_t* q = dx + (((long)n * H + iy) * W + ix) * dx_ld + cc * 8;
+    h8 o;
+    if (accumulate) { const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += (float)old[e]; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)a[e];
+    *reinterpret_cast<h8*>(q) = o;
+  }
+}
+extern "C" int csbsr_adaptive_avgpool_fwd(const void* x, int64_t x_ld, void* y, int32_t N, int32_t H, int32_t W, int32_t c,
+                                          int32_t OH, int32_t OW, csbsr_stream_t s) {
+  CSBSR_CHECK(x && y && c % 8 == 0, "aap_fwd: bad args");
+  hipLaunchKernelGGL(aap_fwd_kernel, dim3(grid_for((long)N * OH * OW * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x, x_ld, (half_t*)y,
+                     N, H, W, c / 8, OH, OW);
+  CSBSR_LAUNCH_CHECK("csbsr_adaptive_avgpool_fwd");
+  return 0;
+}
+extern "C" int csbsr_adaptive_avgpool_bwd(const void* dy, void* dx, int64_t dx_ld, int32_t accumulate, int32_t N, int32_t H,
+                                          int32_t W, int32_t c, int32_t OH, int32_t OW, csbsr_stream_t s) {
+  CSBSR_CHECK(dy && dx && c % 8 == 0, "aap_bwd: bad args");
+  hipLaunchKernelGGL(aap_bwd_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), (const half_t*)dy, (half_t*)dx,
+                     dx_ld, accumulate, N, H, W, c / 8, OH, OW);
+  CSBSR_LAUNCH_CHECK("csbsr_adaptive_avgpool_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- bilinear resize
+__device__ __forceinline__ void bil_src(int o, int in, int out, int align, int& i0, int& i1, float& w1) {
+  float src;
+  if (align) src = out > 1 ? o * (float)(in - 1) / (float)(out - 1) : 0.f;
+  else { src = (o + 0.5f) * ((float)in / (float)out) - 0.5f; if (src < 0.f) src = 0.f; }
+  i0 = (int)src; if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + 1 < in ? i0 + 1 : in - 1;
+  w1 = src - i0;
+}
+__global__ void bilinear_fwd_kernel(const half_t* x, long x_ld, half_t* y, long y_ld, int N, int H, int W, int c8, int OH, int OW,
+                                    int align, const float* drop, int cp) {
+  const long total = (long)N * OH * OW * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8); long t = i / c8;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH); const int n = (int)(t / OH);
+    int y0, y1, x0, x1; float wy, wx;
+    bil_src(oy, H, OH, align, y0, y1, wy); bil_src(ox, W, OW, align, x0, x1, wx);
+    const half_t* b = x + (long)n * H * W * x_ld + cc * 8;
+    const h8 v00 = *reinterpret_cast<const h8*>(b + ((long)y0 * W + x0) * x_ld);
+    const h8 v01 = *reinterpret_cast<const h8*>(b + ((long)y0 * W + x1) * x_ld);
+    const h8 v10 = *reinterpret_cast<const h8*>(b + ((long)y1 * W + x0) * x_ld);
+    const h8 v11 = *reinterpret_cast<const h8*>(b + ((long)y1 * W + x1) * x_ld);
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = (1.f - wy) * ((1.f - wx) * (float)v00[e] + wx * (float)v01[e]) + wy * ((1.f - wx) * (float)v10[e] + wx * (float)v11[e]);
+      if (drop) v *= drop[n * cp + cc * 8 + e];
+      o[e] = (half_t)v;
+    }
+    *reinterpret_cast<h8*>(y + (((long)n * OH + oy) * OW + ox) * y_ld + cc * 8) = o;
+  }
+}
+// gather-form adjoint: each input pixel sums the output pixels that reference it (scan of a bounded output window)
+__global__ void bilinear_bwd_kernel(const half_t* dy, long dy_ld, half_t* dx, long dx_ld, int accumulate, int N, int H, int W, int c8,
+                                    int OH, int OW, int align, const float* drop, int cp) {
+  const long total = (long)N * H * W * c8;
+  const float ry = (float)OH / H, rx = (float)OW / W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8); long t = i / c8;
+    const int ix = (int)(t % W); t /= W;
+    const int iy = (int)(t % H); const int n = (int)(t / H);
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    int oy_lo = (int)floorf((iy - 1) * ry) - 2, oy_hi = (int)ceilf((iy + 1) * ry) + 2;
+    int ox_lo = (int)floorf((ix - 1) * rx) - 2, ox_hi = (int)ceilf((ix + 1) * rx) + 2;
+    if (iy == 0) oy_lo = 0;
+    if (ix == 0) ox_lo = 0;
+    if (iy == H - 1) oy_hi = OH - 1;
+    if (ix == W - 1) ox_hi = OW - 1;
+    oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+    oy_hi = oy_hi > OH - 1 ? OH - 1 : oy_hi; ox_hi = ox_hi > OW - 1 ? OW - 1 : ox_hi;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float wy; bil_src(oy, H, OH, align, y0, y1, wy);
+      float cy = 0.f;
+      if (y0 == iy) cy += 1.f - wy;
+      if (y1 == iy) cy += wy;
+      if (cy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float wx; bil_src(ox, W, OW, align, x0, x1, wx);
+        float cx = 0.f;
+        if (x0 == ix) cx += 1.f - wx;
+        if (x1 == ix) cx += wx;
+        if (cx == 0.f) continue;
+        const h8 g = *reinterpret_cast<const h8*>(dy + (((long)n * OH + oy) * OW + ox) * dy_ld + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += cy * cx * (float)g[e];
+      }
+    }
+    if (drop) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] *= drop[n * cp + cc * 8 + e];
+    }
+    half_t* q = dx + (((long)n * H + iy) * W + ix) * dx_ld + cc * 8;
+    if (accumulate) { const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += (float)old[e]; }
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)a[e];
+    *reinterpret_cast<h8*>(q) = o;
+  }
+}
+extern "C" int csbsr_bilinear_fwd(const void* x, int64_t x_ld, void* y, int64_t y_ld, int32_t N, int32_t H, int32_t W, int32_t c,
+                                  int32_t OH, int32_t OW, int32_t align_corners, const float* drop, csbsr_stream_t s) {
+  CSBSR_CHECK(x && y && c % 8 == 0, "bilinear_fwd: bad args");
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for((long)N * OH * OW * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x, x_ld,
+                     (half_t*)y, y_ld, N, H, W, c / 8, OH, OW, align_corners, drop, c);
+  CSBSR_LAUNCH_CHECK("csbsr_bilinear_fwd");
+  return 0;
+}
+extern "C" int csbsr_bilinear_bwd(const void* dy, int64_t dy_ld, void* dx, int64_t dx_ld, int32_t accumulate, int32_t N, int32_t H,
+                                  int32_t W, int32_t c, int32_t OH, int32_t OW, int32_t align_corners, const float* drop,
+                                  csbsr_stream_t s) {
+  CSBSR_CHECK(dy && dx && c % 8 == 0, "bilinear_bwd: bad args");
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), (const half_t*)dy, dy_ld,
+                     (half_t*)dx, dx_ld, accumulate, N, H, W, c / 8, OH, OW, align_corners, drop, c);
+  CSBSR_LAUNCH_CHECK("csbsr_bilinear_bwd");
+  return 0;
+}

@@ -1,0 +1,595 @@
+// fp32 planar (NCHW) image kernels of the path: per-sample blur (pseudo-LR), bicubic resizes, L1 terms,
+// exact EDT -> normalised signed distance map, fused boundary-combo segmentation loss.  All HBM-bound
+// (3-channel images, 1-channel maps); fp32 throughout because these feed log / division / small differences.
+#include "common.h"
+
+static inline int grid_for(long work, int block = 256, int cap = 8192) {
+  long b = (work + block - 1) / block;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+// ------------------------------------------------------------------------------------------- depthwise blur
+// y[n,c,oy,ox] = sum_{ky,kx} x[n,c,oy*s-P+ky, ox*s-P+kx] * k[n][ky*K+kx]  (- sub[n,c,oy,ox])
+// one workgroup = 16x16 outputs of one (n,c) plane; the input window is staged in LDS.
+template <int K>
+__global__ __launch_bounds__(256) void blur_fwd_kernel(const float* x, const float* kvec, int C, int H, int W, int OH, int OW,
+                                                       int stride, const float* sub, float* y32, half_t* y16, long y16_ld) {
+  extern __shared__ float sm[];
+  const int P = (K - 1) / 2;
+  const int TW = 15 * stride + K;          // staged window side
+  float* sK = sm;                          // K*K
+  float* sX = sm + K * K;                  // TW*TW
+  const int plane = blockIdx.z, n = plane / C, c = plane % C;
+  const int oy0 = blockIdx.y * 16, ox0 = blockIdx.x * 16;
+  for (int i = threadIdx.x; i < K * K; i += 256) sK[i] = kvec[(long)n * K * K + i];
+  const float* xp = x + (long)plane * H * W;
+  const int iy0 = oy0 * stride - P, ix0 = ox0 * stride - P;
+  for (int i = threadIdx.x; i < TW * TW; i += 256) {
+    const int ty = i / TW, tx = i % TW;
+    const int iy = iy0 + ty, ix = ix0 + tx;
+    sX[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? xp[(long)iy * W + ix] : 0.f;
+  }
+  __syncthreads();
+  const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+  const int oy = oy0 + ty, ox = ox0 + tx;
+  if (oy >= OH || ox >= OW) return;
+  float acc = 0.f;
+  for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) acc += sX[(ty * stride + ky) * TW + tx * stride + kx] * sK[ky * K + kx];
+  const long oi = (long)plane * OH * OW + (long)oy * OW + ox;
+  if (sub) acc -= sub[oi];
+  if (y32) y32[oi] = acc;
+  if (y16) y16[(((long)n * OH + oy) * OW + ox) * y16_ld + c] = (half_t)acc;
+}
+
+// dx[n,c,iy,ix] (+)= sum_{oy,ox} dy[n,c,oy,ox] * k[n][iy - oy*s + P][ix - ox*s + P]
+template <int K>
+__global__ void blur_bwd_input_kernel(const float* dy, const float* kvec, float* dx, int accumulate, int N, int C, int H, int W, int OH,
+                                      int OW, int stride) {
+  const int P = (K - 1) / 2;
+  const long total = (long)N * C * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % W); long t = i / W;
+    const int iy = (int)(t % H); const long plane = t / H;
+    const int n = (int)(plane / C);
+    const float* kp = kvec + (long)n * K * K;
+    const float* dyp = dy + plane * OH * OW;
+    float acc = 0.f;
+    // oy*s in [iy+P-K+1, iy+P]
+    int oy_lo = (iy + P - K + 1 + stride - 1); oy_lo = oy_lo < 0 ? 0 : oy_lo / stride;
+    int oy_hi = (iy + P) / stride; if (oy_hi > OH - 1) oy_hi = OH - 1;
+    int ox_lo = (ix + P - K + 1 + stride - 1); ox_lo = ox_lo < 0 ? 0 : ox_lo / stride;
+    int ox_hi = (ix + P) / stride; if (ox_hi > OW - 1) ox_hi = OW - 1;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const int ky = iy - oy * stride + P;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const int kx = ix - ox * stride + P;
+        acc += dyp[(long)oy * OW + ox] * kp[ky * K + kx];
+      }
+    }
+    dx[i] = accumulate ? dx[i] + acc : acc;
+  }
+}
+
+// dk[n][ky*K+kx] += sum_{c,oy,ox} dy[n,c,oy,ox] * x[n,c,oy*s-P+ky, ox*s-P+kx]
+// grid: (K*K taps, chunks, N); block reduces over its chunk of (c,oy,ox)
+template <int K>
+__global__ __launch_bounds__(256) void blur_bwd_kernel_kernel(const float* dy, const float* x, float* dk, int C, int H, int W, int OH,
+                                                              int OW, int stride, int chunks) {
+  __shared__ float sred[4];
+  const int P = (K - 1) / 2;
+  const int tap = blockIdx.x, ky = tap / K, kx = tap % K;
+  const int n = blockIdx.z;
+  const long total = (long)C * OH * OW;
+  const long per = (total + chunks - 1) / chunks;
+  const long beg = blockIdx.y * per, end = beg + per < total ? beg + per : total;
+  float acc = 0.f;
+  for (long i = beg + threadIdx.x; i < end; i += 256) {
+    const int ox = (int)(i % OW); long t = i / OW;
+    const int oy = (int)(t % OH); const int c = (int)(t / OH);
+    const int iy = oy * stride - P + ky, ix = ox * stride - P + kx;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+      acc += dy[((long)n * C + c) * OH * OW + (long)oy * OW + ox] * x[((long)n * C + c) * H * W + (long)iy * W + ix];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dk + (long)n * K * K + tap, sred[0] + sred[1] + sred[2] + sred[3]);
+}
+
+#define BLUR_DISPATCH(K, CALL) \
+  switch (K) {                 \
+    case 21: { constexpr int KK = 21; CALL; break; } \
+    case 7: { constexpr int KK = 7; CALL; break; }   \
+    case 5: { constexpr int KK = 5; CALL; break; }   \
+    default: csbsr_set_error("blur: unsupported kernel size %d", K); return 1; }
+
+extern "C" int csbsr_blur_fwd(const float* x, const float* kvec, int32_t N, int32_t C, int32_t H, int32_t W, int32_t K, int32_t stride,
+                              const float* sub, float* y32, void* y16, int64_t y16_ld, csbsr_stream_t s) {
+  CSBSR_CHECK(x && kvec && (y32 || y16), "blur_fwd: null");
+  const int P = (K - 1) / 2;
+  const int OH = (H + 2 * P - K) / stride + 1, OW = (W + 2 * P - K) / stride + 1;
+  const int TW = 15 * stride + K;
+  const size_t smem = (size_t)(K * K + TW * TW) * 4;
+  dim3 grid((OW + 15) / 16, (OH + 15) / 16, N * C);
+  BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_fwd_kernel<KK>), grid, dim3(256), smem, ST(s), x, kvec, C, H, W, OH, OW, stride, sub, y32,
+                                      (half_t*)y16, y16_ld));
+  CSBSR_LAUNCH_CHECK("csbsr_blur_fwd");
+  return 0;
+}
+extern "C" int csbsr_blur_bwd_input(const float* dy, const float* kvec, float* dx, int32_t accumulate, int32_t N, int32_t C, int32_t H,
+                                    int32_t W, int32_t K, int32_t stride, csbsr_stream_t s) {
+  CSBSR_CHECK(dy && kvec && dx, "blur_bwd_input: null");
+  const int P = (K - 1) / 2;
+  const int OH = (H + 2 * P - K) / stride + 1, OW = (W + 2 * P - K) / stride + 1;
+  BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_bwd_input_kernel<KK>), dim3(grid_for((long)N * C * H * W)), dim3(256), 0, ST(s), dy, kvec, dx,
+                                      accumulate, N, C, H, W, OH, OW, stride));
+  CSBSR_LAUNCH_CHECK("csbsr_blur_bwd_input");
+  return 0;
+}
+extern "C" int csbsr_blur_bwd_kernel(const float* dy, const float* x, float* dk, int32_t N, int32_t C, int32_t H, int32_t W, int32_t K,
+                                     int32_t stride, csbsr_stream_t s) {
+  CSBSR_CHECK(dy && x && dk, "blur_bwd_kernel: null");
+  const int P = (K - 1) / 2;
+  const int OH = (H + 2 * P - K) / stride + 1, OW = (W + 2 * P - K) / stride + 1;
+  long total = (long)C * OH * OW;
+  int chunks = (int)((total + 32767) / 32768);
+  if (chunks < 1) chunks = 1;
+  if (chunks > 64) chunks = 64;
+  dim3 grid(K * K, chunks, N);
+  BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_bwd_kernel_kernel<KK>), grid, dim3(256), 0, ST(s), dy, x, dk, C, H, W, OH, OW, stride, chunks));
+  CSBSR_LAUNCH_CHECK("csbsr_blur_bwd_kernel");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- bicubic
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+// out[n,c,oy,ox] += bicubic upsample (align_corners=False, A=-0.75, border-clamped taps) of x
+__global__ void bicubic_up_add_kernel(const float* x, float* out, int planes, int H, int W, int scale) {
+  const int OH = H * scale, OW = W * scale;
+  const long total = (long)planes * OH * OW;
+  const float A = -0.75f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW); long t = i / OW;
+    const int oy = (int)(t % OH); const long pl = t / OH;
+    const float sy = (oy + 0.5f) / scale - 0.5f, sx = (ox + 0.5f) / scale - 0.5f;
+    const int iy = (int)floorf(sy), ix = (int)floorf(sx);
+    const float ty = sy - iy, tx = sx - ix;
+    float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+    float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+    const float* xp = x + pl * H * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int yy = iy - 1 + a; yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+      float r = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        int xx = ix - 1 + b; xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+        r += wx[b] * xp[(long)yy * W + xx];
+      }
+      acc += wy[a] * r;
+    }
+    out[i] += acc;
+  }
+}
+extern "C" int csbsr_bicubic_up_add(const float* x, float* out, int32_t planes, int32_t H, int32_t W, int32_t scale, csbsr_stream_t s) {
+  CSBSR_CHECK(x && out, "bicubic_up_add: null");
+  hipLaunchKernelGGL(bicubic_up_add_kernel, dim3(grid_for((long)planes * H * W * scale * scale)), dim3(256), 0, ST(s), x, out, planes, H, W,
+                     scale);
+  CSBSR_LAUNCH_CHECK("csbsr_bicubic_up_add");
+  return 0;
+}
+
+// antialiased bicubic down-scale by integer factor f (torch _upsample_bicubic2d_aa): separable, A=-0.5,
+// support 2f, weights normalised over the in-image taps.  antialias==0: 4-tap A=-0.75 rule with clamped taps.
+__device__ __forceinline__ float aa_filter(float x) {
+  const float A = -0.5f;
+  x = fabsf(x);
+  if (x < 1.f) return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * A;
+  return 0.f;
+}
+// computes tap range [lo,hi) and normalisation for output index o
+__device__ __forceinline__ void aa_range(int o, int in, int f, int& lo, int& hi, float& center, float& norm) {
+  const float scale = (float)f;
+  center = scale * (o + 0.5f);
+  const float support = 2.f * scale;
+  lo = (int)(center - support + 0.5f); if (lo < 0) lo = 0;
+  hi = (int)(center + support + 0.5f); if (hi > in) hi = in;
+  float tot = 0.f;
+  for (int k = lo; k < hi; ++k) tot += aa_filter((k - center + 0.5f) / scale);
+  norm = 1.f / tot;
+}
+__global__ void aa_down_fwd_kernel(const float* x, float* y, int planes, int H, int W, int f, int antialias) {
+  const int OH = H / f, OW = W / f;
+  const long total = (long)planes * OH * OW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW); long t = i / OW;
+    const int oy = (int)(t % OH); const long pl = t / OH;
+    const float* xp = x + pl * H * W;
+    float acc = 0.f;
+    if (antialias) {
+      int ylo, yhi, xlo, xhi; float cy, cx, ny, nx;
+      aa_range(oy, H, f, ylo, yhi, cy, ny); aa_range(ox, W, f, xlo, xhi, cx, nx);
+      for (int yy = ylo; yy < yhi; ++yy) {
+        const float wy = aa_filter((yy - cy + 0.5f) / f) * ny;
+        float r = 0.f;
+        for (int xx = xlo; xx < xhi; ++xx) r += aa_filter((xx - cx + 0.5f) / f) * nx * xp[(long)yy * W + xx];
+        acc += wy * r;
+      }
+    } else {
+      const float A = -0.75f;
+      const float sy = (oy + 0.5f) * f - 0.5f, sx = (ox + 0.5f) * f - 0.5f;
+      const int iy = (int)floorf(sy), ix = (int)floorf(sx);
+      const float ty = sy - iy, tx = sx - ix;
+      float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+      float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+      for (int a = 0; a < 4; ++a) {
+        int yy = iy - 1 + a; yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+        float r = 0.f;
+        for (int b = 0; b < 4; ++b) { int xx = ix - 1 + b; xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx); r += wx[b] * xp[(long)yy * W + xx]; }
+        acc += wy[a] * r;
+      }
+    }
+    y[i] = acc;
+  }
+}
+// adjoint (gather over the outputs whose footprint covers the input pixel)
+__global__ void aa_down_bwd_kernel(const float* dy, float* dx, int accumulate, int planes, int H, int W, int f, int antialias) {
+  const int OH = H / f, OW = W / f;
+  const long total = (long)planes * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % W); long t = i / W;
+    const int iy = (int)(t % H); const long pl = t / H;
+    const float* gp = dy + pl * OH * OW;
+    float acc = 0.f;
+    int oy_lo = iy / f - 3, oy_hi = iy / f + 3, ox_lo = ix / f - 3, ox_hi = ix / f + 3;
+    if (!antialias) {   // clamped taps: border input pixels collect from every output that clamps onto them
+      if (iy == 0) oy_lo = 0;
+      if (ix == 0) ox_lo = 0;
+      if (iy == H - 1) oy_hi = OH - 1;
+      if (ix == W - 1) ox_hi = OW - 1;
+    }
+    oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+    oy_hi = oy_hi > OH - 1 ? OH - 1 : oy_hi; ox_hi = ox_hi > OW - 1 ? OW - 1 : ox_hi;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      float wy = 0.f;
+      if (antialias) {
+        int lo, hi; float c, nrm; aa_range(oy, H, f, lo, hi, c, nrm);
+        if (iy >= lo && iy < hi) wy = aa_filter((iy - c + 0.5f) / f) * nrm;
+      } else {
+        const float A = -0.75f; const float sy = (oy + 0.5f) * f - 0.5f; const int by = (int)floorf(sy); const float ty = sy - by;
+        const float w4[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+        for (int a = 0; a < 4; ++a) { int yy = by - 1 + a; yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy); if (yy == iy) wy += w4[a]; }
+      }
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        float wx = 0.f;
+        if (antialias) {
+          int lo, hi; float c, nrm; aa_range(ox, W, f, lo, hi, c, nrm);
+          if (ix >= lo && ix < hi) wx = aa_filter((ix - c + 0.5f) / f) * nrm;
+        } else {
+          const float A = -0.75f; const float sx = (ox + 0.5f) * f - 0.5f; const int bx = (int)floorf(sx); const float tx = sx - bx;
+          const float w4[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+          for (int b = 0; b < 4; ++b) { int xx = bx - 1 + b; xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx); if (xx == ix) wx += w4[b]; }
+        }
+        if (wx != 0.f) acc += wy * wx * gp[(long)oy * OW + ox];
+      }
+    }
+    dx[i] = accumulate ? dx[i] + acc : acc;
+  }
+}
+extern "C" int csbsr_aa_bicubic_down_fwd(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t f, int32_t antialias,
+                                         csbsr_stream_t s) {
+  CSBSR_CHECK(x && y && f >= 1, "aa_down_fwd: bad args");
+  hipLaunchKernelGGL(aa_down_fwd_kernel, dim3(grid_for((long)planes * (H / f) * (W / f))), dim3(256), 0, ST(s), x, y, planes, H, W, f, antialias);
+  CSBSR_LAUNCH_CHECK("csbsr_aa_bicubic_down_fwd");
+  return 0;
+}
+extern "C" int csbsr_aa_bicubic_down_bwd(const float* dy, float* dx, int32_t accumulate, int32_t planes, int32_t H, int32_t W, int32_t f,
+                                         int32_t antialias, csbsr_stream_t s) {
+  CSBSR_CHECK(dy && dx && f >= 1, "aa_down_bwd: bad args");
+  hipLaunchKernelGGL(aa_down_bwd_kernel, dim3(grid_for((long)planes * H * W)), dim3(256), 0, ST(s), dy, dx, accumulate, planes, H, W, f, antialias);
+  CSBSR_LAUNCH_CHECK("csbsr_aa_bicubic_down_bwd");
+  return 0;
+}
+
+// fp32 single-plane bilinear resize (aux head, align_corners=True: pspnet.py:122) and its adjoint
+__device__ __forceinline__ void bil_src32(int o, int in, int out, int align, int& i0, int& i1, float& w1) {
+  float src;
+  if (align) src = out > 1 ? o * (float)(in - 1) / (float)(out - 1) : 0.f;
+  else { src = (o + 0.5f) * ((float)in / (float)out) - 0.5f; if (src < 0.f) src = 0.f; }
+  i0 = (int)src; if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + 1 < in ? i0 + 1 : in - 1;
+  w1 = src - i0;
+}
+__global__ void bilinear32_fwd_kernel(const float* x, float* y, int planes, int H, int W, int OH, int OW, int align) {
+  const long total = (long)planes * OH * OW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW); long t = i / OW;
+    const int oy = (int)(t % OH); const long pl = t / OH;
+    int y0, y1, x0, x1; float wy, wx;
+    bil_src32(oy, H, OH, align, y0, y1, wy); bil_src32(ox, W, OW, align, x0, x1, wx);
+    const float* xp = x + pl * H * W;
+    y[i] = (1.f - wy) * ((1.f - wx) * xp[(long)y0 * W + x0] + wx * xp[(long)y0 * W + x1]) +
+           wy * ((1.f - wx) * xp[(long)y1 * W + x0] + wx * xp[(long)y1 * W + x1]);
+  }
+}
+__global__ void bilinear32_bwd_kernel(const float* dy, float* dx, int planes, int H, int W, int OH, int OW, int align) {
+  const long total = (long)planes * H * W;
+  const float ry = (float)OH / H, rx = (float)OW / W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % W); long t = i / W;
+    const int iy = (int)(t % H); const long pl = t / H;
+    int oy_lo = (int)floorf((iy - 1) * ry) - 2, oy_hi = (int)ceilf((iy + 1) * ry) + 2;
+    int ox_lo = (int)floorf((ix - 1) * rx) - 2, ox_hi = (int)ceilf((ix + 1) * rx) + 2;
+    if (iy == 0) oy_lo = 0;
+    if (ix == 0) ox_lo = 0;
+    if (iy == H - 1) oy_hi = OH - 1;
+    if (ix == W - 1) ox_hi = OW - 1;
+    oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+    oy_hi = oy_hi > OH - 1 ? OH - 1 : oy_hi; ox_hi = ox_hi > OW - 1 ? OW - 1 : ox_hi;
+    const float* gp = dy + pl * OH * OW;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float wy; bil_src32(oy, H, OH, align, y0, y1, wy);
+      float cy = 0.f;
+      if (y0 == iy) cy += 1.f - wy;
+      if (y1 == iy) cy += wy;
+      if (cy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float wx; bil_src32(ox, W, OW, align, x0, x1, wx);
+        float cx = 0.f;
+        if (x0 == ix) cx += 1.f - wx;
+        if (x1 == ix) cx += wx;
+        if (cx != 0.f) acc += cy * cx * gp[(long)oy * OW + ox];
+      }
+    }
+    dx[i] = acc;
+  }
+}
+extern "C" int csbsr_bilinear32_fwd(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t align,
+                                    csbsr_stream_t s) {
+  CSBSR_CHECK(x && y, "bilinear32_fwd: null");
+  hipLaunchKernelGGL(bilinear32_fwd_kernel, dim3(grid_for((long)planes * OH * OW)), dim3(256), 0, ST(s), x, y, planes, H, W, OH, OW, align);
+  CSBSR_LAUNCH_CHECK("csbsr_bilinear32_fwd");
+  return 0;
+}
+extern "C" int csbsr_bilinear32_bwd(const float* dy, float* dx, int32_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW, int32_t align,
+                                    csbsr_stream_t s) {
+  CSBSR_CHECK(dy && dx, "bilinear32_bwd: null");
+  hipLaunchKernelGGL(bilinear32_bwd_kernel, dim3(grid_for((long)planes * H * W)), dim3(256), 0, ST(s), dy, dx, planes, H, W, OH, OW, align);
+  CSBSR_LAUNCH_CHECK("csbsr_bilinear32_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- L1 terms
+// sums[n] += sum_{c,h,w} w(n,h,w) |a-b| ;  da (+)= gscale * w * sign(a-b)      (planes of one sample contiguous)
+__global__ __launch_bounds__(256) void l1_kernel(const float* a, const float* b, const float* wmap, int C, long hw, float* sums,
+                                                 float gscale, float* da, int da_acc, int chunks) {
+  __shared__ float sred[4];
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const long total = (long)C * hw;
+  const long per = (total + chunks - 1) / chunks;
+  const long beg = chunk * per, end = beg + per < total ? beg + per : total;
+  float acc = 0.f;
+  for (long i = beg + threadIdx.x; i < end; i += 256) {
+    const long gi = (long)n * total + i;
+    const float d = a[gi] - b[gi];
+    const float w = wmap ? wmap[(long)n * hw + i % hw] : 1.f;
+    acc += w * fabsf(d);
+    if (da) {
+      const float g = gscale * w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+      da[gi] = da_acc ? da[gi] + g : g;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && sums) atomicAdd(sums + n, sred[0] + sred[1] + sred[2] + sred[3]);
+}
+extern "C" int csbsr_l1_fwd_bwd(const float* a, const float* b, const float* wmap, int32_t N, int32_t C, int64_t hw, float* sums,
+                                float gscale, float* da, int32_t da_accumulate, csbsr_stream_t s) {
+  CSBSR_CHECK(a && b, "l1: null");
+  long total = (long)C * hw;
+  int chunks = (int)((total + 65535) / 65536);
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(l1_kernel, dim3(N * chunks), dim3(256), 0, ST(s), a, b, wmap, C, hw, sums, gscale, da, da_accumulate, chunks);
+  CSBSR_LAUNCH_CHECK("csbsr_l1_fwd_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- segmentation loss
+// sums[n][0..5] = sum bce_elem, sum p*t, sum p*p, sum t*t, sum p*sdf, (unused)
+__global__ __launch_bounds__(256) void segloss_reduce_kernel(const float* p, const float* t, const float* sdf, long hw, float* sums,
+                                                             float pw0, float pw1, int chunks) {
+  __shared__ float sred[4][5];
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const long per = (hw + chunks - 1) / chunks;
+  const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;
+  float a[5] = {0, 0, 0, 0, 0};
+  const float sm = 1e-8f;
+  for (long i = beg + threadIdx.x; i < end; i += 256) {
+    const long gi = (long)n * hw + i;
+    const float pc = fmaxf(p[gi], sm), tv = t[gi];
+    a[0] += -(pw0 * tv * logf(pc + sm) + pw1 * (1.f - tv) * logf(1.f - pc + sm));
+    a[1] += pc * tv; a[2] += pc * pc; a[3] += tv * tv; a[4] += pc * sdf[gi];
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const float v = wave_sum(a[k]);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) atomicAdd(sums + n * 8 + threadIdx.x, sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+}
+// loss[n] += weight * L ;  dp = gscale[n] * weight * dL/dp   where
+// L = alpha * (lw0*bce_mean + lw1*dice)/(lw0+lw1) + (1-alpha) * mean(p*sdf)
+__global__ void segloss_finish_kernel(const float* p, const float* t, const float* sdf, int N, long hw, const float* sums, float alpha,
+                                      float pw0, float pw1, float lw0, float lw1, float weight, const float* gscale, float* loss,
+                                      float* dp, int dp_acc) {
+  const float sm = 1e-8f, dsm = 1e-6f;
+  const float pws = pw0 + pw1, lws = lw0 + lw1;
+  const long total = (long)N * hw;
+  for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(gi / hw);
+    const float* S = sums + n * 8;
+    const float num = 2.f * S[1] + dsm, den = S[2] + S[3] + dsm;
+    if (gi % hw == 0 && loss) {
+      const float bce = S[0] / pws / hw;
+      const float dice = 1.f - num / den;
+      const float L = alpha * (lw0 * bce + lw1 * dice) / lws + (1.f - alpha) * S[4] / hw;
+      atomicAdd(loss + n, weight * L);
+    }
+    if (dp) {
+      const float praw = p[gi], tv = t[gi];
+      float g = 0.f;
+      if (praw >= sm) {   // clamp(min=smooth) passes gradient only where p >= smooth
+        const float pc = praw;
+        const float dbce = -(pw0 * tv / (pc + sm) - pw1 * (1.f - tv) / (1.f - pc + sm)) / pws / hw;
+        const float ddice = -(2.f * tv * den - num * 2.f * pc) / (den * den);
+        g = alpha * (lw0 * dbce + lw1 * ddice) / lws + (1.f - alpha) * sdf[gi] / hw;
+      }
+      g *= weight * (gscale ? gscale[n] : 1.f);
+      dp[gi] = dp_acc ? dp[gi] + g : g;
+    }
+  }
+}
+extern "C" int csbsr_segloss_reduce(const float* p, const float* t, const float* sdf, int32_t N, int64_t hw, float* sums, float pw0,
+                                    float pw1, csbsr_stream_t s) {
+  CSBSR_CHECK(p && t && sdf && sums, "segloss_reduce: null");
+  int chunks = (int)((hw + 65535) / 65536);
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(segloss_reduce_kernel, dim3(N * chunks), dim3(256), 0, ST(s), p, t, sdf, (long)hw, sums, pw0, pw1, chunks);
+  CSBSR_LAUNCH_CHECK("csbsr_segloss_reduce");
+  return 0;
+}
+extern "C" int csbsr_segloss_finish(const float* p, const float* t, const float* sdf, int32_t N, int64_t hw, const float* sums, float alpha,
+                                    float pw0, float pw1, float lw0, float lw1, float weight, const float* gscale, float* loss, float* dp,
+                                    int32_t dp_accumulate, csbsr_stream_t s) {
+  CSBSR_CHECK(p && t && sdf && sums, "segloss_finish: null");
+  hipLaunchKernelGGL(segloss_finish_kernel, dim3(grid_for((long)N * hw)), dim3(256), 0, ST(s), p, t, sdf, N, (long)hw, sums, alpha, pw0, pw1,
+                     lw0, lw1, weight, gscale, loss, dp, dp_accumulate);
+  CSBSR_LAUNCH_CHECK("csbsr_segloss_finish");
+  return 0;
+}
+
+// d(pre-sigmoid) = dp * p * (1-p) as channel 0 of an fp16 NHWC8 tensor (other channels zero)
+__global__ void sigmoid_bwd_to_nhwc8_kernel(const float* dp, const float* p, half_t* out, long npix, float scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    h8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float pv = p[i];
+    o[0] = (half_t)(dp[i] * pv * (1.f - pv) * scale);
+    *reinterpret_cast<h8*>(out + i * 8) = o;
+  }
+}
+extern "C" int csbsr_sigmoid_bwd_to_nhwc8(const float* dp, const float* p, void* out, int64_t npix, float scale, csbsr_stream_t s) {
+  CSBSR_CHECK(dp && p && out, "sigmoid_bwd: null");
+  hipLaunchKernelGGL(sigmoid_bwd_to_nhwc8_kernel, dim3(grid_for(npix)), dim3(256), 0, ST(s), dp, p, (half_t*)out, (long)npix, scale);
+  CSBSR_LAUNCH_CHECK("csbsr_sigmoid_bwd_to_nhwc8");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------- exact EDT / SDF
+// Squared Euclidean distance to the nearest zero pixel of `img` (distance_transform_edt semantics) by the exact
+// two-pass method: (1) per column, nearest zero above/below (1-D scan); (2) per row, lower envelope of parabolas
+// evaluated by brute force over the row held in LDS (W <= 4096).  inv = 1 computes it for the complement.
+__global__ void edt_cols_kernel(const float* mask, float* g, int N, int H, int W, int inv) {
+  const long total = (long)N * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W); const long n = i / W;
+    const float* mp = mask + n * H * W + x;
+    float* gp = g + n * H * W + x;
+    const float BIG = 1e9f;
+    float d = BIG;
+    for (int y = 0; y < H; ++y) {
+      const bool fg = (mp[(long)y * W] != 0.f) != (inv != 0);
+      d = fg ? d + 1.f : 0.f;
+      gp[(long)y * W] = d;
+    }
+    d = BIG;
+    for (int y = H - 1; y >= 0; --y) {
+      const bool fg = (mp[(long)y * W] != 0.f) != (inv != 0);
+      d = fg ? d + 1.f : 0.f;
+      const float cur = gp[(long)y * W];
+      gp[(long)y * W] = cur < d ? cur : d;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void edt_rows_kernel(const float* g, float* dist, int H, int W, float* minmax /*[N][2] as ordered ints*/) {
+  extern __shared__ float srow[];
+  __shared__ float smx[4];
+  const long row = blockIdx.x;       // n*H + y
+  const float* gp = g + row * W;
+  for (int x = threadIdx.x; x < W; x += 256) { const float v = gp[x]; srow[x] = v >= 1e8f ? 1e18f : v * v; }
+  __syncthreads();
+  float mx = 0.f;
+  for (int x = threadIdx.x; x < W; x += 256) {
+    float best = srow[x];
+    // candidates farther than sqrt(best) along the row cannot improve: expand outwards
+    for (int r = 1; r < W; ++r) {
+      const float rr = (float)r * r;
+      if (rr >= best) break;
+      if (x - r >= 0) best = fminf(best, srow[x - r] + rr);
+      if (x + r < W) best = fminf(best, srow[x + r] + rr);
+    }
+    const float dv = sqrtf(best);
+    dist[row * W + x] = dv;
+    mx = fmaxf(mx, dv);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    atomicMax(reinterpret_cast<int*>(minmax + (row / H)), __float_as_int(mx));   // non-negative floats order as ints
+  }
+}
+// sdf = negdis/max(negdis) - posdis/max(posdis), inner boundary -> 0, all-background sample -> 0
+// (min of each distance map is 0 whenever the mask has both classes; compute_sdf1_1 only runs if posmask.any())
+__global__ void sdf_combine_kernel(const float* mask, const float* posdis, const float* negdis, const float* pmax, const float* nmax,
+                                   float* sdf, int N, int H, int W) {
+  const long total = (long)N * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W); long t = i / W;
+    const int y = (int)(t % H); const long n = t / H;
+    const float pm = pmax[n], nm = nmax[n];
+    float v = 0.f;
+    if (pm > 0.f) {     // posmask.any()
+      const float* mp = mask + n * H * W;
+      const bool fg = mp[(long)y * W + x] != 0.f;
+      // nm == 0: mask is all foreground -> negdis == 0 everywhere and the reference divides 0/0 (NaN); mirror with 0
+      const float nterm = nm > 0.f ? negdis[i] / nm : 0.f;
+      v = nterm - posdis[i] / pm;
+      if (fg) {
+        const bool up = mp[(long)(y > 0 ? y - 1 : y) * W + x] != 0.f, dn = mp[(long)(y < H - 1 ? y + 1 : y) * W + x] != 0.f;
+        const bool lf = mp[(long)y * W + (x > 0 ? x - 1 : x)] != 0.f, rt = mp[(long)y * W + (x < W - 1 ? x + 1 : x)] != 0.f;
+        if (!(up && dn && lf && rt)) v = 0.f;
+      }
+    }
+    sdf[i] = v;
+  }
+}
+extern "C" int csbsr_sdf(const float* mask, float* sdf, float* scratch /*3*N*H*W + 2*N floats*/, int32_t N, int32_t H, int32_t W,
+                         csbsr_stream_t s) {
+  CSBSR_CHECK(mask && sdf && scratch, "sdf: null");
+  CSBSR_CHECK(W <= 8192, "sdf: row longer than 8192 not supported");
+  const long npx = (long)N * H * W;
+  float* g = scratch; float* posdis = scratch + npx; float* negdis = scratch + 2 * npx; float* mm = scratch + 3 * npx;
+  hipStream_t st = ST(s);
+  hipMemsetAsync(mm, 0, 2 * N * sizeof(float), st);
+  hipLaunchKernelGGL(edt_cols_kernel, dim3(grid_for((long)N * W, 64)), dim3(64), 0, st, mask, g, N, H, W, 0);
+  hipLaunchKernelGGL(edt_rows_kernel, dim3(N * H), dim3(256), W * sizeof(float), st, g, posdis, H, W, mm);
+  hipLaunchKernelGGL(edt_cols_kernel, dim3(grid_for((long)N * W, 64)), dim3(64), 0, st, mask, g, N, H, W, 1);
+  hipLaunchKernelGGL(edt_rows_kernel, dim3(N * H), dim3(256), W * sizeof(float), st, g, negdis, H, W, mm + N);
+  hipLaunchKernelGGL(sdf_combine_kernel, dim3(grid_for(npx)), dim3(256), 0, st, mask, posdis, negdis, mm, mm + N, sdf, N, H, W);
+  CSBSR_LAUNCH_CHECK("csbsr_sdf");
+  return 0;
+}

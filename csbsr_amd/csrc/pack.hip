@@ -1,0 +1,122 @@
+// Weight re-layout kernels: fp32 master weights (the reference's OIHW / IOHW parameter tensors, whose
+// state_dict layout is part of the drop-in boundary) -> packed fp16 MFMA operands, and packed fp32 weight
+// gradients -> += fp32 OIHW / IOHW .grad.   HBM-bound index shuffles, run once per step per layer.
+#include "common.h"
+
+struct PackK {
+  const float* w; half_t* dst;
+  int kind;            // 0 conv  1 conv flipped+swapped (dgrad of stride-1 conv)  2 transposed (phases)
+  int D0, D1, KH, KW, stride, pad;
+  int seg0_real, seg0_p, segtot_p, chan_real;
+  int row_off, nrows, rows_p, Kp, KHt, KWt, nphase;
+};
+
+__global__ void pack_weights_kernel(const PackK p) {
+  const long total = (long)p.nphase * p.rows_p * p.Kp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % p.Kp);
+    const long t = i / p.Kp;
+    const int r = (int)(t % p.rows_p);
+    const int ph = (int)(t / p.rows_p);
+    float v = 0.f;
+    const int tap = k / p.segtot_p;
+    const int cp = k - tap * p.segtot_p;
+    // padded channel -> real channel of the K side
+    int c = -1;
+    if (cp < p.seg0_p) { if (cp < p.seg0_real) c = cp; }
+    else { const int c1 = cp - p.seg0_p; if (p.seg0_real + c1 < p.chan_real) c = p.seg0_real + c1; }
+    if (r < p.nrows && c >= 0 && tap < p.KHt * p.KWt) {
+      const int jy = tap / p.KWt, jx = tap % p.KWt;
+      const int rr = p.row_off + r;
+      if (p.kind == 0) {
+        v = p.w[(((long)rr * p.D1 + c) * p.KH + jy) * p.KW + jx];
+      } else if (p.kind == 1) {
+        v = p.w[(((long)c * p.D1 + rr) * p.KH + (p.KH - 1 - jy)) * p.KW + (p.KW - 1 - jx)];
+      } else {
+        const int py = ph / p.stride, px = ph % p.stride;
+        const int kh = (py + p.pad) % p.stride + p.stride * jy;
+        const int kw = (px + p.pad) % p.stride + p.stride * jx;
+        if (kh < p.KH && kw < p.KW) v = p.w[(((long)c * p.D1 + rr) * p.KH + kh) * p.KW + kw];
+      }
+    }
+    p.dst[i] = (half_t)v;
+  }
+}
+
+static void pack_geometry(int kind, int D0, int D1, int KH, int KW, int stride, int seg0_real, int seg1_real,
+                          int nrows, PackK& p) {
+  p.kind = kind; p.D0 = D0; p.D1 = D1; p.KH = KH; p.KW = KW; p.stride = stride;
+  p.seg0_real = seg0_real;
+  p.seg0_p = round_up(seg0_real, 8);
+  p.segtot_p = p.seg0_p + (seg1_real > 0 ? round_up(seg1_real, 8) : 0);
+  p.chan_real = seg0_real + seg1_real;
+  p.nrows = nrows;
+  p.rows_p = round_up(nrows, 32);
+  p.KHt = kind == 2 ? (KH + stride - 1) / stride : KH;
+  p.KWt = kind == 2 ? (KW + stride - 1) / stride : KW;
+  p.nphase = kind == 2 ? stride * stride : 1;
+  p.Kp = round_up(p.KHt * p.KWt * p.segtot_p, 32);
+}
+
+extern "C" int64_t csbsr_packed_weight_elems(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,
+                                             int32_t stride, int32_t seg0_real, int32_t seg1_real, int32_t nrows) {
+  PackK p;
+  pack_geometry(kind, D0, D1, KH, KW, stride, seg0_real, seg1_real, nrows, p);
+  return (int64_t)p.nphase * p.rows_p * p.Kp;
+}
+
+extern "C" int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH,
+                                  int32_t KW, int32_t stride, int32_t pad, int32_t seg0_real, int32_t seg1_real,
+                                  int32_t row_off, int32_t nrows, csbsr_stream_t s) {
+  CSBSR_CHECK(w && dst, "pack: null pointer");
+  CSBSR_CHECK(kind >= 0 && kind <= 2, "pack: bad kind");
+  const int kdim = kind == 0 ? D1 : D0;       // which weight dim the K-side channels index
+  const int rdim = kind == 0 ? D0 : D1;
+  CSBSR_CHECK(seg0_real + seg1_real == kdim, "pack: segments (%d+%d) must cover the contracted dim (%d)", seg0_real, seg1_real, kdim);
+  CSBSR_CHECK(row_off >= 0 && row_off + nrows <= rdim, "pack: row range out of bounds");
+  PackK p;
+  pack_geometry(kind, D0, D1, KH, KW, stride, seg0_real, seg1_real, nrows, p);
+  p.w = w; p.dst = reinterpret_cast<half_t*>(dst); p.pad = pad; p.row_off = row_off;
+  const long total = (long)p.nphase * p.rows_p * p.Kp;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(s), p);
+  CSBSR_LAUNCH_CHECK("csbsr_pack_weights");
+  return 0;
+}
+
+// G[a][tap][bpad]  ->  grad[a_off + a][b][kh][kw] += ...   (grad is [D0][D1][KH][KW]; a indexes D0 unless
+// transpose_ab, in which case a indexes D1 and b indexes D0)
+__global__ void unpack_wgrad_kernel(const float* g, float* grad, int A, int Breal, int KH, int KW, int seg0_real,
+                                    int seg0_p, int segtot_p, int D0, int D1, int transpose_ab, int b_off, float scale) {
+  const long total = (long)A * Breal * KH * KW;
+  const int ktot = KH * KW * segtot_p;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int kw = (int)(i % KW);
+    long t = i / KW;
+    const int kh = (int)(t % KH); t /= KH;
+    const int b = (int)(t % Breal);
+    const int a = (int)(t / Breal);
+    const int bp = b < seg0_real ? b : seg0_p + (b - seg0_real);
+    const float v = g[(long)a * ktot + (kh * KW + kw) * segtot_p + bp] * scale;
+    const int bb = b + b_off;
+    const long di = transpose_ab ? ((((long)bb * D1 + a) * KH + kh) * KW + kw) : ((((long)a * D1 + bb) * KH + kh) * KW + kw);
+    grad[di] += v;
+  }
+}
+
+extern "C" int csbsr_unpack_wgrad(const float* g, float* grad, int32_t A, int32_t KH, int32_t KW, int32_t seg0_real,
+                                  int32_t seg1_real, int32_t D0, int32_t D1, int32_t transpose_ab, int32_t b_off,
+                                  float scale, csbsr_stream_t s) {
+  CSBSR_CHECK(g && grad, "unpack: null pointer");
+  const int seg0_p = round_up(seg0_real, 8);
+  const int segtot_p = seg0_p + (seg1_real > 0 ? round_up(seg1_real, 8) : 0);
+  const int Breal = seg0_real + seg1_real;
+  const long total = (long)A * Breal * KH * KW;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(s), g, grad, A,
+                     Breal, KH, KW, seg0_real, seg0_p, segtot_p, D0, D1, transpose_ab, b_off, scale);
+  CSBSR_LAUNCH_CHECK("csbsr_unpack_wgrad");
+  return 0;
+}

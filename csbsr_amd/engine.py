@@ -1,0 +1,363 @@
+"""Host-side runtime for the HIP hot path: feature-map views, layer objects that own packed weights
+and launch the C-ABI kernels (include/csbsr_hip.h), and explicit backward passes.
+
+Design (MI355X-first):
+  * feature maps are fp16 NHWC with channels padded to 8 and an explicit pixel stride, so ``torch.cat``
+    of the reference (kbpn.py:174,179,187; pspnet.py:40) becomes writing into channel slices of one buffer
+    and two-segment convolutions -- no concat copies;
+  * spatially constant operands (blur-kernel code maps, kbpn.py:405,513,565) are never materialised: they
+    enter the convolution as a stride-0 segment;
+  * backward is explicit (no autograd tape): every dgrad kernel either overwrites or accumulates into the
+    gradient buffer of its input, activation gradients carry a power-of-two loss scale (fp16 range), weight
+    gradients accumulate in fp32.
+PyTorch is used for device memory and the current HIP stream only.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class FM:
+    """fp16 channels-last feature map view: tensor [N,H,W,Cp] (last stride 1), ``c`` real channels.
+    ``bcast``: tensor is [N,1,1,Cp] and stands for a spatially constant map of logical size (H, W)."""
+    __slots__ = ("t", "c", "bcast", "H", "W")
+
+    def __init__(self, t, c, bcast=False, H=None, W=None):
+        assert t.dtype == torch.float16 and t.dim() == 4 and t.stride(3) == 1 and t.shape[3] % 8 == 0
+        self.t, self.c, self.bcast = t, c, bcast
+        self.H = t.shape[1] if H is None else H
+        self.W = t.shape[2] if W is None else W
+
+    @property
+    def N(self):
+        return self.t.shape[0]
+
+    @property
+    def cp(self):
+        return self.t.shape[3]
+
+    @property
+    def ld(self):
+        return self.t.stride(2)
+
+    def strides(self):
+        if self.bcast:
+            return self.t.stride(0), 0, 0
+        return self.t.stride(0), self.t.stride(1), self.t.stride(2)
+
+    def seg(self):
+        sn, sy, sx = self.strides()
+        return L.Seg(_ptr(self.t), sn, sy, sx, self.cp, 0)
+
+    def slice(self, c0, c1, creal=None):
+        return FM(self.t[..., c0:c1], (c1 - c0) if creal is None else creal, self.bcast, self.H, self.W)
+
+    @property
+    def npix(self):
+        return self.N * self.H * self.W
+
+    def flat_ok(self):
+        """True when pixels are laid out with one constant stride (needed by the elementwise kernels)."""
+        t = self.t
+        return (not self.bcast) and t.stride(1) == t.shape[2] * t.stride(2) and t.stride(0) == t.shape[1] * t.stride(1)
+
+
+class Engine:
+    def __init__(self, device="cuda:0", grad_scale=1.0):
+        L.load()
+        self.device = torch.device(device)
+        self.grad_scale = float(grad_scale)
+        self._ws = None
+        self.training = True
+
+    @property
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def new(self, N, H, W, c, zero=False):
+        f = torch.zeros if zero else torch.empty
+        return FM(f((N, H, W, pad8(c)), dtype=torch.float16, device=self.device), c)
+
+    def f32(self, *shape, zero=True):
+        f = torch.zeros if zero else torch.empty
+        return f(shape, dtype=torch.float32, device=self.device)
+
+    def workspace(self, nfloat):
+        if self._ws is None or self._ws.numel() < nfloat:
+            self._ws = torch.empty(int(nfloat * 1.25) + 1024, dtype=torch.float32, device=self.device)
+        return self._ws
+
+    # ------------------------------------------------------------------ elementwise wrappers
+    def epilogue_bwd(self, dout, out=None, act=L.ACT_NONE, slope=0.0, prelu=None, res=None, res2=None, res_mode=L.RES_NONE,
+                     dpre=None, dres=None, dres_acc=False, dres2=None, dres2_acc=False, dbias=None, dprelu=None, creal=None):
+        assert dout.flat_ok()
+        for f in (out, res, res2, dpre, dres, dres2):
+            assert f is None or f.flat_ok()
+        d = L.EpiBwdDesc()
+        d.npix, d.c, d.creal = dout.npix, dout.cp, dout.c if creal is None else creal
+        d.dout, d.dout_ld = _ptr(dout.t), dout.ld
+        if out is not None:
+            d.out, d.out_ld = _ptr(out.t), out.ld
+        if res is not None:
+            d.res, d.res_ld = _ptr(res.t), res.ld
+        if res2 is not None:
+            d.res2, d.res2_ld = _ptr(res2.t), res2.ld
+        d.act, d.act_slope, d.prelu, d.res_mode = act, slope, _ptr(prelu), res_mode
+        if dpre is not None:
+            d.dpre, d.dpre_ld = _ptr(dpre.t), dpre.ld
+        if dres is not None:
+            d.dres, d.dres_ld, d.dres_accumulate = _ptr(dres.t), dres.ld, int(dres_acc)
+        if dres2 is not None:
+            d.dres2, d.dres2_ld, d.dres2_accumulate = _ptr(dres2.t), dres2.ld, int(dres2_acc)
+        d.dbias, d.dprelu = _ptr(dbias), _ptr(dprelu)
+        L.call("csbsr_epilogue_backward", C.byref(d), self.stream)
+
+    def nchw32_to_fm(self, src, cp=None, mean=None, invstd=None, out=None):
+        N, Cc, H, W = src.shape
+        assert src.is_contiguous() and src.dtype == torch.float32
+        if out is None:
+            out = self.new(N, H, W, Cc if cp is None else cp)
+            out.c = Cc
+        L.call("csbsr_nchw32_to_nhwc16", _ptr(src), _ptr(out.t), N, Cc, H, W, out.cp, out.ld, _ptr(mean), _ptr(invstd), self.stream)
+        return out
+
+    def fm_to_nchw32(self, fm, dst, C_, alpha=1.0, beta=0.0):
+        assert fm.flat_ok() and dst.is_contiguous()
+        L.call("csbsr_nhwc16_to_nchw32", _ptr(fm.t), fm.ld, _ptr(dst), fm.N, C_, fm.H, fm.W, alpha, beta, self.stream)
+
+    def bilinear(self, x, OH, OW, align, out=None, drop=None):
+        if out is None:
+            out = self.new(x.N, OH, OW, x.c)
+        assert x.flat_ok() and out.flat_ok()
+        L.call("csbsr_bilinear_fwd", _ptr(x.t), x.ld, _ptr(out.t), out.ld, x.N, x.H, x.W, x.cp, OH, OW, int(align), _ptr(drop), self.stream)
+        return out
+
+    def bilinear_bwd(self, dy, dx, acc, align, drop=None):
+        L.call("csbsr_bilinear_bwd", _ptr(dy.t), dy.ld, _ptr(dx.t), dx.ld, int(acc), dx.N, dx.H, dx.W, dx.cp, dy.H, dy.W, int(align),
+               _ptr(drop), self.stream)
+
+
+# ---------------------------------------------------------------------------------------------- conv layer
+
+class Conv:
+    """One Conv2d / ConvTranspose2d of the reference bound to its fp32 master parameters.
+
+    ``w``: OIHW (conv) or IOHW (transposed) fp32 parameter; gradients accumulate (scaled by the engine's
+    grad_scale) into ``w.gacc`` fp32 tensors created on first use and read out by the model.
+    ``split``: real channel counts of the (up to two) input segments.
+    """
+
+    def __init__(self, eng, name, params, k, stride=1, pad=0, dil=1, transposed=False, bias=True, act=L.ACT_NONE, slope=0.0,
+                 prelu=False, split=None):
+        self.eng, self.name = eng, name
+        self.w = params[name + ".weight"]
+        self.b = params.get(name + ".bias") if bias else None
+        self.k, self.stride, self.pad, self.dil, self.transposed = k, stride, pad, dil, transposed
+        if transposed:
+            self.cin, self.cout = self.w.shape[0], self.w.shape[1]
+        else:
+            self.cout, self.cin = self.w.shape[0], self.w.shape[1]
+        self.split = (self.cin, 0) if split is None else tuple(split)
+        assert sum(self.split) == self.cin
+        self.act, self.slope = act, slope
+        self.prelu = params[prelu] if prelu else None
+        self._packed = {}
+
+    # -- packed operand cache (invalidated by the model at every optimiser step)
+    def invalidate(self):
+        self._packed.clear()
+
+    def _pack(self, key, kind, seg0, seg1, row_off, nrows, stride, pad):
+        if key in self._packed:
+            return self._packed[key]
+        D0, D1 = self.w.shape[0], self.w.shape[1]
+        n = L.load().csbsr_packed_weight_elems(kind, D0, D1, self.k, self.k, stride, seg0, seg1, nrows)
+        dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
+        L.call("csbsr_pack_weights", _ptr(self.w), _ptr(dst), kind, D0, D1, self.k, self.k, stride, pad, seg0, seg1, row_off, nrows,
+               self.eng.stream)
+        self._packed[key] = dst
+        return dst
+
+    def out_size(self, H, W):
+        k, s, p, d = self.k, self.stride, self.pad, self.dil
+        if self.transposed:
+            return (H - 1) * s - 2 * p + k, (W - 1) * s - 2 * p + k
+        return (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
+
+    def _launch(self, xs, wt, transposed, k, stride, pad, dil, H, W, OH, OW, cout, out, out32, bias, act, slope, prelu, res, res2,
+                res_mode, accumulate, stat, stat_mode, out_scale):
+        d = L.ConvDesc()
+        x0 = xs[0]
+        d.inp[0] = x0.seg()
+        if len(xs) > 1:
+            d.inp[1] = xs[1].seg()
+        d.N, d.H, d.W, d.OH, d.OW = x0.N, H, W, OH, OW
+        d.transposed, d.KH, d.KW, d.stride, d.pad, d.dil = int(transposed), k, k, stride, pad, dil
+        d.wt, d.cout = _ptr(wt), cout
+        d.coutp = pad8(cout)
+        if out is not None:
+            assert out.cp == d.coutp and (out.H, out.W) == (OH, OW), (out.cp, d.coutp, out.H, OH)
+            sn, sy, sx = out.strides()
+            d.out16, d.o_sn, d.o_sy, d.o_sx = _ptr(out.t), sn, sy, sx
+        if out32 is not None:           # fp32 NCHW planar [N, cout, OH, OW]
+            assert out32.is_contiguous() and tuple(out32.shape) == (x0.N, cout, OH, OW)
+            d.out32, d.o32_sn, d.o32_sy, d.o32_sx, d.o32_sc = _ptr(out32), cout * OH * OW, OW, 1, OH * OW
+        d.bias, d.act, d.act_slope, d.prelu = _ptr(bias), act, slope, _ptr(prelu)
+        d.res_mode = res_mode
+        if res is not None:
+            sn, sy, sx = res.strides()
+            d.res, d.r_sn, d.r_sy, d.r_sx = _ptr(res.t), sn, sy, sx
+        if res2 is not None:
+            sn, sy, sx = res2.strides()
+            d.res2, d.r2_sn, d.r2_sy, d.r2_sx = _ptr(res2.t), sn, sy, sx
+        d.accumulate, d.stat_mode, d.stat, d.out_scale = int(accumulate), stat_mode, _ptr(stat), out_scale
+        L.call("csbsr_conv_forward", C.byref(d), self.eng.stream)
+
+    def fwd(self, x, out=None, out32=None, res=None, res2=None, res_mode=L.RES_NONE, stat=None, stat_mode=L.STAT_NONE, store=True):
+        xs = x if isinstance(x, (tuple, list)) else (x,)
+        assert tuple(f.c for f in xs) == tuple(c for c in self.split if c > 0), (self.name, [f.c for f in xs], self.split)
+        H, W = xs[0].H, xs[0].W
+        OH, OW = self.out_size(H, W)
+        if out is None and store and out32 is None:
+            out = self.eng.new(xs[0].N, OH, OW, self.cout)
+        if self.transposed:
+            wt = self._pack("fwd", 2, self.split[0], self.split[1], 0, self.cout, self.stride, self.pad)
+        else:
+            wt = self._pack("fwd", 0, self.split[0], self.split[1], 0, self.cout, self.stride, self.pad)
+        self._launch(xs, wt, self.transposed, self.k, self.stride, self.pad, self.dil, H, W, OH, OW, self.cout, out, out32, self.b,
+                     self.act, self.slope, self.prelu, res, res2, res_mode, False, stat, stat_mode, 1.0)
+        return out
+
+    def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None):
+        """dgrad wrt input segment ``seg``; dpre: gradient wrt the pre-activation output (FM, may be bcast)."""
+        c_seg = self.split[seg]
+        row_off = 0 if seg == 0 else self.split[0]
+        k, s, p, d = self.k, self.stride, self.pad, self.dil
+        H, W = dpre.H, dpre.W
+        if self.transposed:                      # dgrad of a transposed conv = strided conv on dOut
+            wt = self._pack(("dg", seg), 0, self.cout, 0, row_off, c_seg, s, p)
+            OH, OW = in_hw if in_hw else ((H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1)
+            tr, ps, pp, dd = False, s, p, 1
+        elif s == 1:                             # flipped kernel, pad' = d(k-1) - p
+            wt = self._pack(("dg", seg), 1, self.cout, 0, row_off, c_seg, 1, p)
+            OH, OW = in_hw if in_hw else (H + 2 * (d * (k - 1) - p) - d * (k - 1), W + 2 * (d * (k - 1) - p) - d * (k - 1))
+            tr, ps, pp, dd = False, 1, d * (k - 1) - p, d
+        else:                                    # strided conv: gather-form transposed conv on dOut
+            assert d == 1 and in_hw is not None
+            wt = self._pack(("dg", seg), 2, self.cout, 0, row_off, c_seg, s, p)
+            OH, OW = in_hw
+            tr, ps, pp, dd = True, s, p, 1
+        if out is None and out32 is None and stat is None:
+            out = self.eng.new(dpre.N, OH, OW, c_seg)
+        self._launch((dpre,), wt, tr, k, ps, pp, dd, H, W, OH, OW, c_seg, out, out32, None, L.ACT_NONE, 0.0, None, None, None,
+                     L.RES_NONE, accumulate, stat, L.STAT_SAMPLE_SUM if stat is not None else L.STAT_NONE, 1.0)
+        return out
+
+    def bwd_weights(self, dpre, x):
+        """wgrad; accumulates (scaled) into self.w.gacc [same shape as w] fp32."""
+        xs = x if isinstance(x, (tuple, list)) else (x,)
+        d = L.WgradDesc()
+        if self.transposed:                      # A = input (LR), B = dOut (HR)
+            assert len(xs) == 1
+            a, bs = xs[0], (dpre,)
+            seg0, seg1 = self.cout, 0
+        else:
+            a, bs = dpre, xs
+            seg0, seg1 = self.split
+        sn, sy, sx = a.strides()
+        d.a, d.a_sn, d.a_sy, d.a_sx, d.ca = _ptr(a.t), sn, sy, sx, a.cp
+        d.b[0] = bs[0].seg()
+        if len(bs) > 1:
+            d.b[1] = bs[1].seg()
+        d.N, d.AH, d.AW, d.BH, d.BW = a.N, a.H, a.W, bs[0].H, bs[0].W
+        d.KH, d.KW, d.stride, d.pad, d.dil = self.k, self.k, self.stride, self.pad, self.dil
+        cbtot = sum(f.cp for f in bs)
+        ng = a.cp * self.k * self.k * cbtot
+        g = self.eng.workspace(ng)[:ng]
+        g.zero_()
+        d.g, d.splits = _ptr(g), 0
+        L.call("csbsr_conv_wgrad", C.byref(d), self.eng.stream)
+        gacc = grad_acc(self.w)
+        A_real = self.w.shape[0]
+        L.call("csbsr_unpack_wgrad", _ptr(g), _ptr(gacc), A_real, self.k, self.k, seg0, seg1, self.w.shape[0], self.w.shape[1], 0, 0,
+               1.0, self.eng.stream)
+
+
+def grad_acc(p):
+    """fp32 gradient accumulator attached to a master parameter tensor."""
+    g = getattr(p, "gacc", None)
+    if g is None:
+        g = torch.zeros_like(p, dtype=torch.float32)
+        p.gacc = g
+    return g
+
+
+# ---------------------------------------------------------------------------------------------- batch norm
+
+class BatchNorm:
+    """Train-mode BatchNorm2d fed by the conv epilogue's per-channel sum / sumsq."""
+
+    def __init__(self, eng, name, params, c):
+        self.eng, self.name, self.c = eng, name, c
+        self.gamma, self.beta = params[name + ".weight"], params[name + ".bias"]
+        self.rmean, self.rvar = params[name + ".running_mean"], params[name + ".running_var"]
+        self.nbt = params[name + ".num_batches_tracked"]
+
+    def new_stat(self):
+        return self.eng.f32(2, pad8(self.c))
+
+    def finalize(self, stat, count, update_running=True):
+        cp = pad8(self.c)
+        mean, invstd = self.eng.f32(cp), self.eng.f32(cp)
+        L.call("csbsr_bn_finalize", _ptr(stat), count, self.c, cp, 1e-5, 0.1, _ptr(mean), _ptr(invstd),
+               _ptr(self.rmean) if update_running else None, _ptr(self.rvar) if update_running else None, self.eng.stream)
+        if update_running:
+            self.nbt += 1
+        return mean, invstd
+
+    def _desc(self, x, mean, invstd, res, act, prelu, drop):
+        d = L.BnDesc()
+        d.npix, d.hw, d.c, d.creal = x.npix, x.H * x.W, x.cp, self.c
+        d.x, d.x_ld = _ptr(x.t), x.ld
+        cp = x.cp
+        if self.gamma.numel() != cp:            # pad per-channel params once (channels here are always multiples of 8)
+            raise L.CsbsrHipError("BatchNorm channel count must be a multiple of 8")
+        d.mean, d.invstd, d.gamma, d.beta = _ptr(mean), _ptr(invstd), _ptr(self.gamma), _ptr(self.beta)
+        if res is not None:
+            d.res, d.res_ld = _ptr(res.t), res.ld
+        d.act, d.prelu, d.drop = act, _ptr(prelu), _ptr(drop)
+        return d
+
+    def apply(self, x, mean, invstd, act=L.ACT_NONE, prelu=None, res=None, drop=None, out=None):
+        if out is None:
+            out = self.eng.new(x.N, x.H, x.W, x.c)
+        assert x.flat_ok() and out.flat_ok() and (res is None or res.flat_ok())
+        d = self._desc(x, mean, invstd, res, act, prelu, drop)
+        d.y, d.y_ld = _ptr(out.t), out.ld
+        L.call("csbsr_bn_apply", C.byref(d), self.eng.stream)
+        return out
+
+    def backward(self, dy, x, mean, invstd, act=L.ACT_NONE, prelu=None, res=None, drop=None, dres=None, dres_acc=False, dprelu=None):
+        """returns dx (gradient wrt the conv output); accumulates gamma/beta grads."""
+        dx = self.eng.new(x.N, x.H, x.W, x.c)
+        d = self._desc(x, mean, invstd, res, act, prelu, drop)
+        d.dy, d.dy_ld = _ptr(dy.t), dy.ld
+        red = self.eng.f32(2, x.cp)
+        d.red, d.dprelu = _ptr(red), _ptr(dprelu)
+        d.dx, d.dx_ld = _ptr(dx.t), dx.ld
+        if dres is not None:
+            d.dres, d.dres_ld, d.dres_accumulate = _ptr(dres.t), dres.ld, int(dres_acc)
+        d.dgamma, d.dbeta = _ptr(grad_acc(self.gamma)), _ptr(grad_acc(self.beta))
+        L.call("csbsr_bn_backward", C.byref(d), self.eng.stream)
+        return dx

@@ -1,0 +1,244 @@
+/*
+ * csbsr_hip.h -- C ABI of libcsbsr_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the CSBSR joint
+ * blind-SR + segmentation training hot path.
+ *
+ * The reference (Yuki-11/CSBSR) has no FFI / plugin registry: its "operator API" for this path is the set
+ * of torch.nn.functional calls made by JointModelWithLoss.forward + autograd
+ * (/root/reference/model/modeling/build_model.py:370-416).  Each entry point below replaces one family of
+ * those calls; the cited lines are the reference call sites it stands in for.  The Python host
+ * (csbsr_amd/) binds these with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - raw device pointers + explicit sizes/strides (in ELEMENTS), a hipStream_t passed as void*;
+ *  - feature maps are fp16, channels-last (N,H,W,C) with C padded to a multiple of 8 and an explicit pixel
+ *    stride ("ld") so channel slices of a wider buffer can be read / written in place (concat-free);
+ *  - 3-channel images, probability maps, losses and everything that feeds a log / division / small difference
+ *    are fp32 planar NCHW -- the layout the reference's loader delivers and its callers read back;
+ *  - every function is asynchronous on the given stream, never allocates, never synchronises, never throws;
+ *  - return 0 on success, non-zero on a bad argument / launch failure (text via csbsr_last_error()).
+ */
+#ifndef CSBSR_HIP_H
+#define CSBSR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* csbsr_stream_t; /* hipStream_t */
+
+int csbsr_version(void);
+const char* csbsr_last_error(void);
+
+/* ------------------------------------------------------------------------------------------- convolution */
+enum { CSBSR_ACT_NONE = 0, CSBSR_ACT_RELU = 1, CSBSR_ACT_LRELU = 2, CSBSR_ACT_PRELU = 3, CSBSR_ACT_SIGMOID = 4 };
+/* epilogue combine:  out = act(conv+bias)  (+ res | - res | * res | + res*res2) */
+enum { CSBSR_RES_NONE = 0, CSBSR_RES_ADD = 1, CSBSR_RES_SUB = 2, CSBSR_RES_MUL = 3, CSBSR_RES_FMA = 4 };
+/* per-channel reductions fused into the conv epilogue (computed on act(conv+bias), before res) */
+enum { CSBSR_STAT_NONE = 0, CSBSR_STAT_BN = 1 /* sum, sumsq per channel: fp32[2][coutp] */,
+       CSBSR_STAT_SAMPLE_SUM = 2 /* sum per (sample, channel): fp32[N][coutp]  (global average pool) */ };
+
+/* One input segment of a convolution: NHWC fp16 view with element strides.  A spatially constant operand
+ * (the blur-kernel code expanded over the image: kbpn.py:405,513,565-567) is passed with sy = sx = 0. */
+typedef struct {
+  const void* ptr;
+  int64_t sn, sy, sx; /* element strides of sample / row / pixel */
+  int32_t c;          /* channels in this segment, multiple of 8 (zero-padded) */
+  int32_t _pad;
+} csbsr_seg_t;
+
+/* Implicit-GEMM convolution / transposed convolution, MFMA fp16 -> fp32 accumulate.
+ * Replaces F.conv2d (kbpn.py:241 via ConvBlock, kbpn.py:513-517, extractors.py:36-38, pspnet.py:30-41,47,72-86)
+ * and F.conv_transpose2d (kbpn.py:273-277) and, with re-packed weights, their autograd dgrads. */
+typedef struct {
+  csbsr_seg_t in[2];       /* input = channel-concat of up to two segments (in[1].c == 0: unused) */
+  int32_t N, H, W;         /* input spatial size */
+  int32_t OH, OW;          /* output spatial size */
+  int32_t transposed;      /* 0: conv   1: transposed conv (gather form, one phase per output residue) */
+  int32_t KH, KW;          /* full kernel size */
+  int32_t stride, pad, dil;
+  const void* wt;          /* packed fp16 weights from csbsr_pack_weights */
+  int32_t cout;            /* real output channels */
+  int32_t coutp;           /* padded (multiple of 8) channel count of out16 / res / res2 */
+  void* out16;             /* fp16 NHWC output or NULL */
+  int64_t o_sn, o_sy, o_sx;
+  float* out32;            /* optional fp32 output with arbitrary strides (planar NCHW: sc = H*W) or NULL */
+  int64_t o32_sn, o32_sy, o32_sx, o32_sc;
+  const float* bias;       /* fp32[cout] or NULL */
+  int32_t act;             /* CSBSR_ACT_* */
+  float act_slope;         /* LRELU slope */
+  const float* prelu;      /* device scalar for CSBSR_ACT_PRELU */
+  int32_t res_mode;        /* CSBSR_RES_* */
+  const void* res;         /* fp16 NHWC */
+  int64_t r_sn, r_sy, r_sx;
+  const void* res2;        /* second operand of CSBSR_RES_FMA */
+  int64_t r2_sn, r2_sy, r2_sx;
+  int32_t accumulate;      /* 1: out += result (gradient fan-in) */
+  int32_t stat_mode;       /* CSBSR_STAT_* */
+  float* stat;
+  float out_scale;         /* accumulator multiplied by this first (1.0 default) */
+} csbsr_conv_desc_t;
+
+int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
+
+/* Weight-gradient GEMM: G[a][tap][b] = sum over pixels of A[pix][a] * B[pix @ tap][b]  (fp32, accumulated with
+ * atomics across pixel splits; caller zeroes G).  Conv: A = dPre (output side), B = input.  Transposed conv:
+ * A = its input (LR side), B = dOut (HR side).  Autograd wgrad of the calls above. */
+typedef struct {
+  const void* a;           /* fp16 NHWC [N, AH, AW, ca] ungathered side */
+  int64_t a_sn, a_sy, a_sx;
+  int32_t ca;              /* channels (multiple of 8) */
+  int32_t _pad0;
+  csbsr_seg_t b[2];        /* gathered side, up to two segments */
+  int32_t N, AH, AW;       /* grid the reduction runs over */
+  int32_t BH, BW;          /* spatial size of the gathered side */
+  int32_t KH, KW, stride, pad, dil;
+  float* g;                /* fp32 [ca][KH*KW*(cb0+cb1)] */
+  int32_t splits;          /* pixel-range splits (grid.z); 0 = auto */
+  int32_t _pad1;
+} csbsr_wgrad_desc_t;
+
+int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s);
+void csbsr_debug_set_wgrad_tr(int use_hw_transpose_read); /* test hook: 0 = scalar LDS transposition */
+
+/* fp32 master weights W[D0][D1][KH][KW] (the reference's OIHW conv / IOHW deconv parameters, whose state_dict
+ * layout is part of the drop-in boundary) -> packed fp16 operand [phase][rows_p][Kp] of csbsr_conv_forward.
+ *  kind 0  rows = D0, contracted channels = D1:            forward conv (W is OIHW) and dgrad of a transposed conv (W is IOHW)
+ *  kind 1  rows = D1, contracted = D0, taps flipped:       dgrad of a stride-1 conv
+ *  kind 2  rows = D1, contracted = D0, phase decomposed:   forward transposed conv (IOHW) and dgrad of a strided conv (OIHW)
+ * seg0_real + seg1_real = size of the contracted dim (two-segment inputs, each zero-padded to a multiple of 8);
+ * rows [row_off, row_off+nrows) of the row dim are emitted (dgrad wrt one input segment). */
+int64_t csbsr_packed_weight_elems(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t stride,
+                                  int32_t seg0_real, int32_t seg1_real, int32_t nrows);
+int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,
+                       int32_t stride, int32_t pad, int32_t seg0_real, int32_t seg1_real, int32_t row_off,
+                       int32_t nrows, csbsr_stream_t s);
+/* packed fp32 wgrad G[a][tap][b(padded segments)] -> grad[a][b_off + b][kh][kw] += scale * G   (grad is [D0][D1][KH][KW];
+ * transpose_ab: a indexes D1 and b indexes D0) */
+int csbsr_unpack_wgrad(const float* g, float* grad, int32_t A, int32_t KH, int32_t KW, int32_t seg0_real,
+                       int32_t seg1_real, int32_t D0, int32_t D1, int32_t transpose_ab, int32_t b_off, float scale,
+                       csbsr_stream_t s);
+
+/* ------------------------------------------------------------------------------------------- elementwise */
+/* Backward of the conv epilogue out = act(pre) (+|-|*|fma) res: writes dPre, optionally dRes / dRes2, the bias
+ * gradient (column sums of dPre) and the PReLU slope gradient.  Autograd of F.prelu / relu / leaky_relu /
+ * sigmoid / add / sub / mul (kbpn.py:236-247, 459-469, 480-489, 513-518). */
+typedef struct {
+  int64_t npix;
+  int32_t c, creal;
+  const void* dout; int64_t dout_ld;
+  const void* out;  int64_t out_ld;    /* saved epilogue output (post res) */
+  const void* res;  int64_t res_ld;
+  const void* res2; int64_t res2_ld;
+  int32_t act; float act_slope; const float* prelu;
+  int32_t res_mode; int32_t _pad;
+  void* dpre; int64_t dpre_ld;         /* may alias dout */
+  void* dres; int64_t dres_ld; int32_t dres_accumulate; int32_t _pad1;
+  void* dres2; int64_t dres2_ld; int32_t dres2_accumulate; int32_t _pad2;
+  float* dbias;                        /* fp32[c] += or NULL */
+  float* dprelu;                       /* fp32 scalar += or NULL */
+} csbsr_epi_bwd_desc_t;
+int csbsr_epilogue_backward(const csbsr_epi_bwd_desc_t* d, csbsr_stream_t s);
+
+int csbsr_axpby(int64_t npix, int32_t c, const void* x, int64_t x_ld, float a, const void* z, int64_t z_ld,
+                float b, void* y, int64_t y_ld, csbsr_stream_t s);
+int csbsr_fill_f16(void* p, int64_t npix, int32_t c, int64_t ld, float v, csbsr_stream_t s);
+
+/* boundary layout converters: fp32 NCHW (what the reference's loader hands over, crack_dataset.py:40-64;
+ * optionally normalised per (n,c) -- InstanceNorm2d(3) apply, build_model.py:136) -> fp16 NHWC, and back */
+int csbsr_nchw32_to_nhwc16(const float* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t cp,
+                           int64_t dst_ld, const float* mean, const float* invstd, csbsr_stream_t s);
+int csbsr_nhwc16_to_nchw32(const void* src, int64_t src_ld, float* dst, int32_t N, int32_t C, int32_t H, int32_t W,
+                           float alpha, float beta, csbsr_stream_t s);
+/* out[plane] = {sum a, sum a*a (b NULL) | sum a*b} over fp32 planes (instance-norm statistics) */
+int csbsr_plane_reduce(const float* a, const float* b, int32_t planes, int64_t hw, float* out, csbsr_stream_t s);
+int csbsr_instnorm_bwd(const void* dy, int64_t dy_ld, const float* x, const float* mean, const float* invstd,
+                       float* dx, int32_t accumulate, int32_t N, int32_t C, int64_t hw, float* red,
+                       csbsr_stream_t s);
+
+/* ------------------------------------------------------------------------------------------- batch norm */
+/* Train-mode BatchNorm2d (extractors.py:47-66, pspnet.py:48-49,83); sum / sumsq come from the conv epilogue. */
+int csbsr_bn_finalize(const float* stat, int64_t count, int32_t c, int32_t cstride, float eps, float momentum,
+                      float* mean, float* invstd, float* running_mean, float* running_var, csbsr_stream_t s);
+/* y = drop[n][c] * act( (x-mean)*invstd*gamma + beta + res ) ; backward = reduce + apply */
+typedef struct {
+  int64_t npix, hw;
+  int32_t c, creal;
+  const void* x; int64_t x_ld;         /* conv output (pre-BN) */
+  const float *mean, *invstd, *gamma, *beta;
+  const void* res; int64_t res_ld;
+  int32_t act; int32_t _pad;
+  const float* prelu;
+  const float* drop;                   /* fp32 [N][c] keep-mask / (1-p), or NULL */
+  void* y; int64_t y_ld;
+  const void* dy; int64_t dy_ld;       /* backward only from here */
+  float* red;                          /* fp32 [2][c], zeroed by caller */
+  float* dprelu;
+  void* dx; int64_t dx_ld;
+  void* dres; int64_t dres_ld; int32_t dres_accumulate; int32_t _pad1;
+  float *dgamma, *dbeta;
+} csbsr_bn_desc_t;
+int csbsr_bn_apply(const csbsr_bn_desc_t* d, csbsr_stream_t s);
+int csbsr_bn_backward(const csbsr_bn_desc_t* d, csbsr_stream_t s);
+
+/* ------------------------------------------------------------------------------------------- pooling / resize */
+int csbsr_maxpool3x3s2_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s);
+int csbsr_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
+                           int32_t c, csbsr_stream_t s);
+/* F.adaptive_avg_pool2d (pspnet.py:32), bins floor/ceil */
+int csbsr_adaptive_avgpool_fwd(const void* x, int64_t x_ld, void* y, int32_t N, int32_t H, int32_t W, int32_t c,
+                               int32_t OH, int32_t OW, csbsr_stream_t s);
+int csbsr_adaptive_avgpool_bwd(const void* dy, void* dx, int64_t dx_ld, int32_t accumulate, int32_t N, int32_t H,
+                               int32_t W, int32_t c, int32_t OH, int32_t OW, csbsr_stream_t s);
+/* F.interpolate(mode='bilinear'), both align_corners modes (pspnet.py:39,56,122); optional Dropout2d channel
+ * scale applied to the input side (pspnet.py:105-114) */
+int csbsr_bilinear_fwd(const void* x, int64_t x_ld, void* y, int64_t y_ld, int32_t N, int32_t H, int32_t W,
+                       int32_t c, int32_t OH, int32_t OW, int32_t align_corners, const float* drop, csbsr_stream_t s);
+int csbsr_bilinear_bwd(const void* dy, int64_t dy_ld, void* dx, int64_t dx_ld, int32_t accumulate, int32_t N,
+                       int32_t H, int32_t W, int32_t c, int32_t OH, int32_t OW, int32_t align_corners,
+                       const float* drop, csbsr_stream_t s);
+int csbsr_bilinear32_fwd(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                         int32_t align_corners, csbsr_stream_t s);
+int csbsr_bilinear32_bwd(const float* dy, float* dx, int32_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                         int32_t align_corners, csbsr_stream_t s);
+/* nn.Upsample(scale_factor, 'bicubic') of the LR input added to the SR residual (kbpn.py:110-114) */
+int csbsr_bicubic_up_add(const float* x, float* out, int32_t planes, int32_t H, int32_t W, int32_t scale,
+                         csbsr_stream_t s);
+/* FactorResize('bicubic') = F.interpolate(bicubic, antialias) by an integer factor (transforms.py:505-531) */
+int csbsr_aa_bicubic_down_fwd(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t f,
+                              int32_t antialias, csbsr_stream_t s);
+int csbsr_aa_bicubic_down_bwd(const float* dy, float* dx, int32_t accumulate, int32_t planes, int32_t H, int32_t W,
+                              int32_t f, int32_t antialias, csbsr_stream_t s);
+
+/* ------------------------------------------------------------------------------------------- blur kernels */
+/* Per-sample depthwise KxK cross-correlation (kbpn.py:394-402 stride = scale; sr_loss_functions.py:89-94
+ * stride 1) of fp32 NCHW images with kvec fp32 [N][K*K]:  y = blur(x) - sub.  y16: optional fp16 NHWC copy. */
+int csbsr_blur_fwd(const float* x, const float* kvec, int32_t N, int32_t C, int32_t H, int32_t W, int32_t K,
+                   int32_t stride, const float* sub, float* y32, void* y16, int64_t y16_ld, csbsr_stream_t s);
+int csbsr_blur_bwd_input(const float* dy, const float* kvec, float* dx, int32_t accumulate, int32_t N, int32_t C,
+                         int32_t H, int32_t W, int32_t K, int32_t stride, csbsr_stream_t s);
+int csbsr_blur_bwd_kernel(const float* dy, const float* x, float* dk, int32_t N, int32_t C, int32_t H, int32_t W,
+                          int32_t K, int32_t stride, csbsr_stream_t s);
+
+/* ------------------------------------------------------------------------------------------- losses */
+/* Exact Euclidean distance transform + normalised signed distance map of compute_sdf1_1
+ * (boundary_loss.py:40-67): mask fp32 [N][H][W] in {0,1} -> sdf.  scratch: 3*N*H*W + 2*N floats. */
+int csbsr_sdf(const float* mask, float* sdf, float* scratch, int32_t N, int32_t H, int32_t W, csbsr_stream_t s);
+/* BoundaryComboLoss = alpha*(lw0*WBCE + lw1*Dice)/(lw0+lw1) + (1-alpha)*mean(p*sdf)
+ * (loss_functions.py:49-75,189-210,258-345; boundary_loss.py:26-38) on probability maps fp32 [N][HW]:
+ * reduce -> sums[N][8];  finish -> loss[n] += weight*L, dp (+)= gscale[n]*weight*dL/dp */
+int csbsr_segloss_reduce(const float* p, const float* t, const float* sdf, int32_t N, int64_t hw, float* sums,
+                         float pw0, float pw1, csbsr_stream_t s);
+int csbsr_segloss_finish(const float* p, const float* t, const float* sdf, int32_t N, int64_t hw, const float* sums,
+                         float alpha, float pw0, float pw1, float lw0, float lw1, float weight, const float* gscale,
+                         float* loss, float* dp, int32_t dp_accumulate, csbsr_stream_t s);
+/* L1 terms of KBPNLoss (sr_loss_functions.py:41-54): sums[n] += sum w|a-b| ; da (+)= gscale*w*sign(a-b) */
+int csbsr_l1_fwd_bwd(const float* a, const float* b, const float* wmap, int32_t N, int32_t C, int64_t hw,
+                     float* sums, float gscale, float* da, int32_t da_accumulate, csbsr_stream_t s);
+/* d(pre-sigmoid) of a 1-channel head as channel 0 of an fp16 NHWC8 tensor */
+int csbsr_sigmoid_bwd_to_nhwc8(const float* dp, const float* p, void* out, int64_t npix, float scale,
+                               csbsr_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

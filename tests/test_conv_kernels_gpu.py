@@ -1,0 +1,130 @@
+"""GPU parity of the MFMA convolution kernels (forward, dgrad, wgrad) through the C ABI against
+torch fp32 CPU ops on the same fp16-rounded operands.  Tolerance: fp16 output rounding (2^-11) plus fp32
+accumulation-order noise -> 2e-3 relative to the tensor's max magnitude."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng():
+    from csbsr_amd.engine import Engine
+    return Engine("cuda:0")
+
+
+def to_fm(eng, x):        # NCHW fp32 cpu -> FM
+    from csbsr_amd.engine import FM, pad8
+    N, C, H, W = x.shape
+    t = torch.zeros(N, H, W, pad8(C), dtype=torch.float16)
+    t[..., :C] = x.permute(0, 2, 3, 1).half()
+    return FM(t.cuda(), C)
+
+
+def from_fm(fm):
+    return fm.t[..., :fm.c].float().cpu().permute(0, 3, 1, 2)
+
+
+def relmax(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+CASES = [
+    # cin, cout, k, stride, pad, dil, transposed, H, W
+    (16, 32, 3, 1, 1, 1, False, 9, 11),
+    (3, 49, 3, 1, 1, 1, False, 12, 12),
+    (128, 128, 3, 1, 1, 1, False, 16, 16),
+    (64, 128, 3, 1, 2, 2, False, 14, 10),
+    (40, 24, 1, 1, 0, 1, False, 10, 10),
+    (3, 64, 7, 2, 3, 1, False, 32, 32),
+    (64, 128, 3, 2, 1, 1, False, 16, 16),
+    (128, 128, 8, 4, 2, 1, False, 32, 32),
+    (128, 128, 8, 4, 2, 1, True, 8, 8),
+    (3, 128, 8, 4, 2, 1, True, 8, 8),
+    (24, 16, 12, 8, 2, 1, True, 4, 4),
+    (24, 16, 12, 8, 2, 1, False, 32, 32),
+    (200, 136, 3, 1, 1, 1, False, 8, 8),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("use_tr", [1, 0])
+def test_conv_fwd_dgrad_wgrad(case, use_tr):
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    cin, cout, k, s, p, d, tr, H, W = case
+    L.load().csbsr_debug_set_wgrad_tr(use_tr)
+    torch.manual_seed(hash(case) % 1000)
+    eng = _eng()
+    N = 2
+    x = torch.randn(N, cin, H, W).half().float()
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = (torch.randn(wshape) / (cin * k * k) ** 0.5).half().float()
+    b = torch.randn(cout) * 0.1
+    params = {"l.weight": w.cuda(), "l.bias": b.cuda()}
+    conv = Conv(eng, "l", params, k, s, p, d, transposed=tr, bias=True, act=L.ACT_LRELU, slope=0.1)
+    y = conv.fwd(to_fm(eng, x))
+    if tr:
+        ref_pre = F.conv_transpose2d(x, w, b, s, p)
+    else:
+        ref_pre = F.conv2d(x, w, b, s, p, d)
+    ref = F.leaky_relu(ref_pre, 0.1)
+    torch.cuda.synchronize()
+    assert tuple(from_fm(y).shape) == tuple(ref.shape)
+    assert relmax(from_fm(y), ref) < 2e-3
+    # dgrad / wgrad for a random dPre
+    dpre = torch.randn_like(ref_pre).half().float()
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    out = F.conv_transpose2d(xr, wr, None, s, p) if tr else F.conv2d(xr, wr, None, s, p, d)
+    out.backward(dpre)
+    dfm = to_fm(eng, dpre)
+    dx = conv.bwd_input(dfm, in_hw=(H, W))
+    conv.bwd_weights(dfm, to_fm(eng, x))
+    torch.cuda.synchronize()
+    assert relmax(from_fm(dx), xr.grad) < 2e-3
+    assert relmax(params["l.weight"].gacc.cpu(), wr.grad) < 2e-3
+    L.load().csbsr_debug_set_wgrad_tr(1)
+
+
+def test_two_segment_broadcast_and_epilogue():
+    """cat(features, spatially-constant code) conv with FMA epilogue, fp32 planar side output and GAP stat."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv, FM, pad8
+    eng = _eng()
+    torch.manual_seed(3)
+    N, H, W, c0, c1, cout = 2, 10, 12, 24, 441, 40
+    x0 = torch.randn(N, c0, H, W).half().float()
+    kv = (torch.rand(N, c1) / c1).half().float()
+    w = (torch.randn(cout, c0 + c1, 3, 3) / 30).half().float()
+    b = torch.randn(cout) * 0.1
+    r1 = torch.randn(N, cout, H, W).half().float()
+    r2 = torch.randn(N, cout, H, W).half().float()
+    params = {"l.weight": w.cuda(), "l.bias": b.cuda()}
+    conv = Conv(eng, "l", params, 3, 1, 1, act=L.ACT_NONE, split=(c0, c1))
+    kt = torch.zeros(N, 1, 1, pad8(c1), dtype=torch.float16)
+    kt[:, 0, 0, :c1] = kv.half()
+    kfm = FM(kt.cuda(), c1, bcast=True, H=H, W=W)
+    stat = torch.zeros(N, pad8(cout), device="cuda")
+    y = conv.fwd((to_fm(eng, x0), kfm), res=to_fm(eng, r1), res2=to_fm(eng, r2), res_mode=L.RES_FMA, stat=stat,
+                 stat_mode=L.STAT_SAMPLE_SUM)
+    cat = torch.cat((x0, kv[:, :, None, None].expand(N, c1, H, W)), 1)
+    pre = F.conv2d(cat, w, b, 1, 1)
+    ref = pre + r1 * r2
+    torch.cuda.synchronize()
+    assert relmax(from_fm(y), ref) < 2e-3
+    assert relmax(stat[:, :cout].cpu(), pre.sum((2, 3))) < 2e-3
+    # dgrad wrt the broadcast segment = per-sample sum over pixels
+    dpre = torch.randn_like(pre).half().float()
+    catr = cat.clone().requires_grad_(True)
+    F.conv2d(catr, w, None, 1, 1).backward(dpre)
+    dk = torch.zeros(N, pad8(c1), device="cuda")
+    conv.bwd_input(to_fm(eng, dpre), seg=1, stat=dk)
+    d0 = conv.bwd_input(to_fm(eng, dpre), seg=0)
+    conv.bwd_weights(to_fm(eng, dpre), (to_fm(eng, x0), kfm))
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(cat, wr, None, 1, 1).backward(dpre)
+    torch.cuda.synchronize()
+    assert relmax(dk[:, :c1].cpu(), catr.grad[:, c0:].sum((2, 3))) < 2e-3
+    assert relmax(from_fm(d0), catr.grad[:, :c0]) < 2e-3
+    assert relmax(params["l.weight"].gacc.cpu(), wr.grad) < 3e-3
