@@ -1,0 +1,178 @@
+"""bench.py -- training imgs/s of the CSBSR joint SR+segmentation hot path on N MI355X GPUs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8] [--lr-size 448] [--micro-batch 1]
+    python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...          (driver, N > 1)
+
+One step = one pass of the hot path over one synthetic minibatch already resident in HBM: KBPN (x4) + PSPNet
+forward, fused losses, explicit HIP backward, gradient all-reduce over RCCL (N > 1), Adam -- BASELINE.json config 2
+(B=8 per GPU, LR 448 -> HR 1792, iter 40000 = joint phase, beta = 0.3); weak scaling (per-GPU batch fixed).
+Prints ONE JSON line (rank 0).  See DESIGN.md section "Measurement" for the algorithmic FLOP / byte figures.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# as-executed algorithmic work per image, fwd+bwd, x4 / LR 448 / PSPNet
+ALG_TFLOP_PER_IMG_448 = 108.3
+ALG_GB_PER_IMG_448 = 249.0
+MFMA_PEAK_TFLOPS = 2500.0     # dense fp16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference path, fp32 torch ops) timed on this host's cores on a bounded
+    sample: B=2, LR 32 -> HR 128, forward+backward, repeated until ~the budget; imgs/s scaled to LR 448 by pixels."""
+    from oracle import csbsr_oracle as O
+    from csbsr_amd.utils.detfill import det_state_dict
+    from csbsr_amd.modeling.shapes import joint_state_shapes
+    from csbsr_amd.data.synthetic import make_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = det_state_dict(joint_state_shapes())
+    for k, v in P.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    cfg = O.PathCfg()
+    lr = 32
+    x, hr, mask, k = make_batch(2, lr, seed=1)
+    n, t0 = 0, time.time()
+    while True:
+        out = O.joint_forward(P, cfg, 40000, x, hr, mask, k, alpha=0.9)
+        O.calc_loss(out["segment_loss"], out["sr_loss"], 40000, cfg).backward()
+        n += 1
+        if time.time() - t0 > seconds_budget or n >= 3:
+            break
+    dt = time.time() - t0
+    ips = 2 * n / dt
+    scale = (448.0 / lr) ** 2
+    return {"value": ips / scale, "unit": "imgs/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+bwd, B=2, LR {lr}->HR {lr * 4}, {n} steps in {dt:.1f}s = {ips:.4f} img/s at LR {lr}; "
+                      f"divided by (448/{lr})^2 = {scale:.0f} (conv work linear in pixels) to quote it at LR 448"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--lr-size", type=int, default=448)
+    ap.add_argument("--micro-batch", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from csbsr_amd.config import cfg as base_cfg
+    from csbsr_amd.modeling.build_model import JointModelWithLoss
+    from csbsr_amd.data.synthetic import make_batch
+    from csbsr_amd.parallel import GradBucketReducer
+    from csbsr_amd.parallel.reducer import broadcast_parameters
+
+    cfg = base_cfg.clone()
+    model = JointModelWithLoss(cfg, 9000, 40000, None, device=str(dev))
+    model.micro_batch = args.micro_batch
+    model.train()
+    rt = model._runtime()
+    if world > 1:
+        broadcast_parameters(model)
+        model.reducer = GradBucketReducer(side_stream=torch.cuda.Stream(dev))
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.SOLVER.LR, betas=(0.9, 0.999), eps=1e-8)    # train.py:91
+
+    B, lr = args.batch, args.lr_size
+    # synthetic minibatch (seed differs per rank: each GPU gets its own shard of the global batch), resident in HBM
+    gen_lr = min(lr, 112)           # generate at <=112 and tile: the CPU-side generator is plumbing, not the bench
+    x, hr, mask, k = make_batch(B, gen_lr, seed=1121 + rank)
+    rep = lr // gen_lr
+    if rep > 1:
+        x, hr, mask = x.repeat(1, 1, rep, rep), hr.repeat(1, 1, rep, rep), mask.repeat(1, 1, rep, rep)
+    x, hr, mask, k = (t.to(dev).contiguous() for t in (x, hr, mask, k))
+    it = 40000
+    beta = cfg.SOLVER.TASK_LOSS_WEIGHT
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        seg_l, sr_l, seg, sr, kp = model(it, x, sr_targets=hr, segment_targets=mask, kernel_targets=k)
+        loss = (1 - beta) * sr_l.mean() + beta * seg_l.mean()          # trainer.py:406-438, iter >= 30001
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    for _ in range(args.warmup):
+        step()
+    eng = rt["eng"]
+    if not args.no_kernel_timing:
+        eng.timing = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = 0.0
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    ms = dt / args.steps * 1e3
+    imgs = B * world * args.steps / dt
+
+    roof = None
+    if eng.timing:
+        conv = [(f, b, e0.elapsed_time(e1)) for kind, f, b, e0, e1 in eng.timing if kind == "conv"]
+        wg = [(f, b, e0.elapsed_time(e1)) for kind, f, b, e0, e1 in eng.timing if kind == "wgrad"]
+        cf, ct = sum(c[0] for c in conv), sum(c[2] for c in conv) * 1e-3
+        wf, wt = sum(c[0] for c in wg), sum(c[2] for c in wg) * 1e-3
+        ach = cf / ct / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (forward conv / deconv / dgrad)", "achieved": round(ach, 1),
+                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": len(conv), "avg_launch_ms": round(ct * 1e3 / max(len(conv), 1), 3),
+                "share_of_step_time": round(ct / dt, 3),
+                "wgrad_kernel": {"achieved": round(wf / wt / 1e12, 1), "frac": round(wf / wt / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                 "share_of_step_time": round(wt / dt, 3), "launches": len(wg)}}
+    out = None
+    if rank == 0:
+        pix = (lr / 448.0) ** 2
+        per_img_s = dt / (B * args.steps)
+        out = {"metric": "training imgs/s (448->1792 x4, PSPNet)", "value": round(imgs, 4), "unit": "imgs/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 1), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "fp16 storage / fp32 accumulate", "data": "synthetic",
+               "config": {"workload": f"CSBSR KBPN x4 + PSPNet, beta=0.3, joint phase (iter 40000), per-GPU batch {B}, "
+                                      f"LR {lr}x{lr} -> HR {lr * 4}x{lr * 4}, fwd+loss+bwd+Adam", "global_batch": B * world,
+                          "micro_batch": args.micro_batch, "parallelism": f"dp{world}"},
+               "loss": round(last, 5),
+               "step_roofline": {"hbm_frac": round(ALG_GB_PER_IMG_448 * pix / per_img_s / HBM_PEAK_GBS, 4),
+                                 "mfma_frac": round(ALG_TFLOP_PER_IMG_448 * pix / per_img_s / MFMA_PEAK_TFLOPS, 4),
+                                 "note": "as-executed algorithmic work of SURVEY.md 8(d): 108.3 TFLOP and 249 GB per image at LR 448"},
+               "roofline": roof,
+               "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

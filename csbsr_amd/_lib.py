@@ -97,7 +97,7 @@ SIGNATURES = {
     "csbsr_sdf": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "csbsr_segloss_reduce": (i32, [vp, vp, vp, i32, i64, vp, f32, f32, vp]),
     "csbsr_segloss_finish": (i32, [vp, vp, vp, i32, i64, vp, f32, f32, f32, f32, f32, f32, vp, vp, vp, i32, vp]),
-    "csbsr_l1_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i64, vp, f32, vp, i32, vp]),
+    "csbsr_l1_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i64, vp, f32, vp, vp, i32, vp]),
     "csbsr_sigmoid_bwd_to_nhwc8": (i32, [vp, vp, vp, i64, f32, vp]),
 }
 

@@ -715,7 +715,8 @@ __global__ void bilinear_fwd_kernel(const half_t* x, long x_ld, half_t* y, long 
 __global__ void bilinear_bwd_kernel(const half_t* dy, long dy_ld, half_t* dx, long dx_ld, int accumulate, int N, int H, int W, int c8,
                                     int OH, int OW, int align, const float* drop, int cp) {
   const long total = (long)N * H * W * c8;
-  const float ry = (float)OH / H, rx = (float)OW / W;
+  // output-per-input ratio of the source mapping (align_corners: (out-1)/(in-1))
+  const float ry = (align && H > 1) ? (float)(OH - 1) / (H - 1) : (float)OH / H, rx = (align && W > 1) ? (float)(OW - 1) / (W - 1) : (float)OW / W;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cc = (int)(i % c8); long t = i / c8;
     const int ix = (int)(t % W); t /= W;
@@ -723,8 +724,8 @@ __global__ void bilinear_bwd_kernel(const half_t* dy, long dy_ld, half_t* dx, lo
     float a[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[e] = 0.f;
-    int oy_lo = (int)floorf((iy - 1) * ry) - 2, oy_hi = (int)ceilf((iy + 1) * ry) + 2;
-    int ox_lo = (int)floorf((ix - 1) * rx) - 2, ox_hi = (int)ceilf((ix + 1) * rx) + 2;
+    int oy_lo = (int)floorf((iy - 1.5f) * ry) - 2, oy_hi = (int)ceilf((iy + 1.5f) * ry) + 2;
+    int ox_lo = (int)floorf((ix - 1.5f) * rx) - 2, ox_hi = (int)ceilf((ix + 1.5f) * rx) + 2;
     if (iy == 0) oy_lo = 0;
     if (ix == 0) ox_lo = 0;
     if (iy == H - 1) oy_hi = OH - 1;

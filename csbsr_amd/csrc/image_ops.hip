@@ -323,12 +323,13 @@ __global__ void bilinear32_fwd_kernel(const float* x, float* y, int planes, int 
 }
 __global__ void bilinear32_bwd_kernel(const float* dy, float* dx, int planes, int H, int W, int OH, int OW, int align) {
   const long total = (long)planes * H * W;
-  const float ry = (float)OH / H, rx = (float)OW / W;
+  // output-per-input ratio of the source mapping (align_corners: (out-1)/(in-1))
+  const float ry = (align && H > 1) ? (float)(OH - 1) / (H - 1) : (float)OH / H, rx = (align && W > 1) ? (float)(OW - 1) / (W - 1) : (float)OW / W;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int ix = (int)(i % W); long t = i / W;
     const int iy = (int)(t % H); const long pl = t / H;
-    int oy_lo = (int)floorf((iy - 1) * ry) - 2, oy_hi = (int)ceilf((iy + 1) * ry) + 2;
-    int ox_lo = (int)floorf((ix - 1) * rx) - 2, ox_hi = (int)ceilf((ix + 1) * rx) + 2;
+    int oy_lo = (int)floorf((iy - 1.5f) * ry) - 2, oy_hi = (int)ceilf((iy + 1.5f) * ry) + 2;
+    int ox_lo = (int)floorf((ix - 1.5f) * rx) - 2, ox_hi = (int)ceilf((ix + 1.5f) * rx) + 2;
     if (iy == 0) oy_lo = 0;
     if (ix == 0) ox_lo = 0;
     if (iy == H - 1) oy_hi = OH - 1;
@@ -372,7 +373,7 @@ extern "C" int csbsr_bilinear32_bwd(const float* dy, float* dx, int32_t planes, 
 // ------------------------------------------------------------------------------------------- L1 terms
 // sums[n] += sum_{c,h,w} w(n,h,w) |a-b| ;  da (+)= gscale * w * sign(a-b)      (planes of one sample contiguous)
 __global__ __launch_bounds__(256) void l1_kernel(const float* a, const float* b, const float* wmap, int C, long hw, float* sums,
-                                                 float gscale, float* da, int da_acc, int chunks) {
+                                                 float gscale, const float* gs_n, float* da, int da_acc, int chunks) {
   __shared__ float sred[4];
   const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const long total = (long)C * hw;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* a, const float* b,
     const float w = wmap ? wmap[(long)n * hw + i % hw] : 1.f;
     acc += w * fabsf(d);
     if (da) {
-      const float g = gscale * w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+      const float g = gscale * (gs_n ? gs_n[n] : 1.f) * w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
       da[gi] = da_acc ? da[gi] + g : g;
     }
   }
@@ -395,12 +396,12 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* a, const float* b,
   if (threadIdx.x == 0 && sums) atomicAdd(sums + n, sred[0] + sred[1] + sred[2] + sred[3]);
 }
 extern "C" int csbsr_l1_fwd_bwd(const float* a, const float* b, const float* wmap, int32_t N, int32_t C, int64_t hw, float* sums,
-                                float gscale, float* da, int32_t da_accumulate, csbsr_stream_t s) {
+                                float gscale, const float* gs_n, float* da, int32_t da_accumulate, csbsr_stream_t s) {
   CSBSR_CHECK(a && b, "l1: null");
   long total = (long)C * hw;
   int chunks = (int)((total + 65535) / 65536);
   if (chunks < 1) chunks = 1;
-  hipLaunchKernelGGL(l1_kernel, dim3(N * chunks), dim3(256), 0, ST(s), a, b, wmap, C, hw, sums, gscale, da, da_accumulate, chunks);
+  hipLaunchKernelGGL(l1_kernel, dim3(N * chunks), dim3(256), 0, ST(s), a, b, wmap, C, hw, sums, gscale, gs_n, da, da_accumulate, chunks);
   CSBSR_LAUNCH_CHECK("csbsr_l1_fwd_bwd");
   return 0;
 }

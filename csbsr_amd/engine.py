@@ -80,6 +80,7 @@ class Engine:
         self.grad_scale = float(grad_scale)
         self._ws = None
         self.training = True
+        self.timing = None              # list of (kind, flops, bytes, start_event, end_event) when profiling is on
 
     @property
     def stream(self):
@@ -222,7 +223,19 @@ class Conv:
             sn, sy, sx = res2.strides()
             d.res2, d.r2_sn, d.r2_sy, d.r2_sx = _ptr(res2.t), sn, sy, sx
         d.accumulate, d.stat_mode, d.stat, d.out_scale = int(accumulate), stat_mode, _ptr(stat), out_scale
+        tm = self.eng.timing
+        if tm is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         L.call("csbsr_conv_forward", C.byref(d), self.eng.stream)
+        if tm is not None:
+            ev1.record()
+            ctot = sum(f.c for f in xs)
+            npx = x0.N * OH * OW
+            taps = k * k if not transposed else ((k + stride - 1) // stride) ** 2
+            flops = 2.0 * npx * cout * ctot * taps
+            nbytes = 2.0 * (sum(0 if f.bcast else f.N * f.H * f.W * f.c for f in xs) + (npx * cout if out is not None else 0))
+            tm.append(("conv", flops, nbytes, ev0, ev1))
 
     def fwd(self, x, out=None, out32=None, res=None, res2=None, res_mode=L.RES_NONE, stat=None, stat_mode=L.STAT_NONE, store=True):
         xs = x if isinstance(x, (tuple, list)) else (x,)
@@ -287,7 +300,16 @@ class Conv:
         g = self.eng.workspace(ng)[:ng]
         g.zero_()
         d.g, d.splits = _ptr(g), 0
+        tm = self.eng.timing
+        if tm is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         L.call("csbsr_conv_wgrad", C.byref(d), self.eng.stream)
+        if tm is not None:
+            ev1.record()
+            flops = 2.0 * a.N * a.H * a.W * a.c * sum(f.c for f in bs) * self.k * self.k
+            nbytes = 2.0 * (a.N * a.H * a.W * a.c + sum(0 if f.bcast else f.N * f.H * f.W * f.c for f in bs))
+            tm.append(("wgrad", flops, nbytes, ev0, ev1))
         gacc = grad_acc(self.w)
         A_real = self.w.shape[0]
         L.call("csbsr_unpack_wgrad", _ptr(g), _ptr(gacc), A_real, self.k, self.k, seg0, seg1, self.w.shape[0], self.w.shape[1], 0, 0,
@@ -300,6 +322,7 @@ def grad_acc(p):
     if g is None:
         g = torch.zeros_like(p, dtype=torch.float32)
         p.gacc = g
+    p.gacc_touched = True
     return g
 
 

@@ -1,0 +1,386 @@
+"""Drop-in counterparts of the reference's ``model.modeling.build_model`` classes for the KBPN + PSPNet path:
+
+    JointModelWithLoss(cfg, num_train_ds, resume_iter, sr_transforms)
+        .forward(iter, x, sr_targets=None, segment_targets=None, kernel_targets=None)
+            -> (segment_loss[B], sr_loss[B], segment_preds, sr_preds, kernel_preds[B,1,K,K])
+    JointModel(cfg).forward(x, damy_kernel, sr_targets=None) -> (sr_preds, segment_preds, kernel_preds)
+
+(/root/reference/model/modeling/build_model.py:323-416, 441-500).  Same constructor / forward signatures,
+same state_dict keys, same attributes the trainer touches (``sr_model``, ``segmentation_model``,
+``ss_loss_fn.{alpha,fix_alpha,iter,update_alpha()}``, ``iter_cnt``), same per-sample unreduced losses, so
+``loss = calc_loss(...); loss.backward(); optimizer.step()`` from trainer.py:67-71 runs unchanged.
+
+Underneath nothing is torch.nn: the forward hands raw device pointers to libcsbsr_hip.so (csbsr_amd/engine.py)
+and the two loss vectors are outputs of one torch.autograd.Function whose backward runs the hand-written HIP
+backward pass; PyTorch only owns memory, streams and the optimizer.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..config import path_config
+from ..engine import Engine, FM, grad_acc, _ptr
+from .kbpn import KBPN
+from .pspnet import PSPNet
+from .shapes import joint_state_shapes
+
+
+class BoundaryComboState:
+    """alpha schedule of BoundaryComboLoss (loss_functions.py:27-41, 76-81); the loss itself is fused in HIP."""
+
+    def __init__(self, per_epoch, resume_iter=0, alpha_min=0.01, decrease_ratio=1.0):
+        self.per_epoch, self.alpha_min, self.decrease_ratio = per_epoch, alpha_min, decrease_ratio
+        self.fix_alpha = False
+        self.iter = resume_iter % per_epoch
+        self.alpha = 1.0 - (resume_iter // per_epoch) * 0.01 * decrease_ratio
+        self.alpha = alpha_min if self.alpha <= alpha_min else self.alpha
+
+    def update_alpha(self):
+        if self.iter % self.per_epoch == 0 and self.alpha > self.alpha_min and not self.fix_alpha:
+            self.alpha -= 0.01 * self.decrease_ratio
+            self.iter = 1
+        else:
+            self.iter += 1
+
+
+class _ParamGroup(nn.Module):
+    """Holds parameters / buffers under the reference's dotted names (``sr_model.feat.0.weight`` ...)."""
+
+    def __init__(self, shapes, prefix):
+        super().__init__()
+        self._names = {}
+        for full, shp in shapes.items():
+            if not full.startswith(prefix + "."):
+                continue
+            local = full[len(prefix) + 1:]
+            key = local.replace(".", "__")
+            self._names[local] = key
+            if full.endswith(("running_mean", "running_var")):
+                self.register_buffer(key, torch.zeros(shp) if full.endswith("mean") else torch.ones(shp))
+            elif full.endswith("num_batches_tracked"):
+                self.register_buffer(key, torch.zeros((), dtype=torch.long))
+            else:
+                self.register_parameter(key, nn.Parameter(torch.zeros(shp)))
+
+    def named_local(self):
+        for local, key in self._names.items():
+            yield local, getattr(self, key)
+
+
+def _init_reference_style(name, t, gen):
+    """Random init with the reference's distributions (kbpn.py:73-82 kaiming-normal convs / zero biases, PReLU 0.01;
+    extractors.py:124-130 normal(0, sqrt(2/n)) convs, BN gamma=1 beta=0; pspnet PReLU 0.25, default Conv2d init elsewhere)."""
+    with torch.no_grad():
+        if t.dim() == 4:
+            if name.startswith("sr_model"):
+                fan_in = t.shape[1] * t.shape[2] * t.shape[3]
+                t.normal_(0, math.sqrt(2.0 / fan_in), generator=gen)
+            elif ".feats." in name:
+                n = t.shape[2] * t.shape[3] * t.shape[0]
+                t.normal_(0, math.sqrt(2.0 / n), generator=gen)
+            else:
+                fan_in = t.shape[1] * t.shape[2] * t.shape[3]
+                bound = 1.0 / math.sqrt(fan_in)
+                t.uniform_(-bound, bound, generator=gen)
+        elif name.endswith("act.weight"):
+            t.fill_(0.01)
+        elif name.endswith("conv.2.weight"):
+            t.fill_(0.25)
+        elif name.endswith(".weight"):
+            t.fill_(1.0)
+        else:
+            t.zero_()
+
+
+class _JointBase(nn.Module):
+    def __init__(self, cfg, antialias=True, device="cuda:0", seed=None):
+        super().__init__()
+        if cfg.MODEL.SR != "KBPN" or cfg.MODEL.DETECTOR_TYPE != "PSPNet":
+            raise NotImplementedError(f"csbsr_amd builds KBPN + PSPNet; got SR={cfg.MODEL.SR} DETECTOR_TYPE={cfg.MODEL.DETECTOR_TYPE}")
+        if cfg.MODEL.SR_PIXEL_SHUFFLE or cfg.MODEL.SUM_LR_ERROR_POS != "HR" or not cfg.MODEL.KBPN_KERNEL_SFT:
+            raise NotImplementedError("only the default KBPN variant (deconv up-sampling, HR error sum, kernel SFT) is built")
+        self.cfg = cfg
+        self.pc = path_config(cfg, antialias)
+        self.scale_factor = cfg.MODEL.SCALE_FACTOR
+        self.norm_method = cfg.SOLVER.NORM_SR_OUTPUT
+        self.seg_model_name = "PSPNet"
+        self._device = torch.device(device)
+        shapes = joint_state_shapes(self.pc.scale, self.pc.num_stages, self.pc.ksize, self.pc.ksize_out)
+        # registration order = reference state_dict order: segmentation_model.* then sr_model.*
+        self.segmentation_model = _ParamGroup(shapes, "segmentation_model")
+        self.sr_model = _ParamGroup(shapes, "sr_model")
+        gen = torch.Generator().manual_seed(cfg.SEED if seed is None else seed)
+        for full, t in self._named_full():
+            if t.is_floating_point() and not full.endswith(("running_mean", "running_var")):
+                _init_reference_style(full, t.data, gen)
+        self._rt = None
+        self.micro_batch = 1
+        self.dropout_enabled = True
+        self.dropout_masks = None     # tests may inject {name: [B,C] fp32} keep-masks
+
+    # ---- naming: state_dict keys are the reference's dotted names
+    def _named_full(self):
+        for grp in ("segmentation_model", "sr_model"):
+            for local, t in getattr(self, grp).named_local():
+                yield f"{grp}.{local}", t
+
+    def state_dict(self, *a, **kw):
+        from collections import OrderedDict
+        return OrderedDict((k, v.detach() if isinstance(v, nn.Parameter) else v) for k, v in self._named_full())
+
+    def load_state_dict(self, sd, strict=True):
+        own = dict(self._named_full())
+        missing = [k for k in own if k not in sd]
+        unexpected = [k for k in sd if k not in own]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}")
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k in own:
+                    own[k].copy_(v)
+        if self._rt is not None:
+            self._invalidate()
+        return missing, unexpected
+
+    # ---- runtime (engine + layer objects) is built lazily on the device
+    def _runtime(self):
+        if self._rt is None:
+            if not torch.cuda.is_available():
+                raise L.CsbsrHipError("csbsr_amd needs an MI355X (no CPU fallback)")
+            self.to(self._device)
+            eng = Engine(self._device)
+            P = {k: (v.data if isinstance(v, nn.Parameter) else v) for k, v in self._named_full()}
+            self._rt = {"eng": eng, "P": P, "kbpn": KBPN(eng, P, self.pc), "psp": PSPNet(eng, P)}
+        return self._rt
+
+    def _invalidate(self):
+        rt = self._rt
+        rt["kbpn"].invalidate()
+        rt["psp"].invalidate()
+
+    # ---- shared forward pieces
+    def _mount(self, t):
+        return None if t is None else t.to(self._device, torch.float32).contiguous()
+
+    def _instnorm_stats(self, sr32):
+        eng = self._rt["eng"]
+        B, Cc, H, W = sr32.shape
+        red = eng.f32(B * Cc, 2)
+        L.call("csbsr_plane_reduce", _ptr(sr32), None, B * Cc, H * W, _ptr(red), eng.stream)
+        mean = red[:, 0] / (H * W)
+        var = (red[:, 1] / (H * W) - mean * mean).clamp_min(0)
+        return mean.contiguous(), torch.rsqrt(var + 1e-5).contiguous()
+
+    def _norm_sr(self, sr32):
+        """build_model.py:125-141 -> FM fp16 NHWC8 for the segmentation net, plus what the backward needs."""
+        eng = self._rt["eng"]
+        B = sr32.shape[0]
+        if self.norm_method == "instance":
+            mean, invstd = self._instnorm_stats(sr32)
+        elif self.norm_method == "all":
+            mean = torch.tensor(self.pc.mean, device=self._device).repeat(B).contiguous()
+            invstd = (1.0 / torch.tensor(self.pc.std, device=self._device)).repeat(B).contiguous()
+        else:
+            mean = invstd = None
+        return eng.nchw32_to_fm(sr32, mean=mean, invstd=invstd), mean, invstd
+
+
+class _JointFn(torch.autograd.Function):
+    """(segment_loss[B], sr_loss[B]) = f(parameters); backward = the HIP backward pass."""
+
+    @staticmethod
+    def forward(ctx, model, seg_loss, sr_loss, *params):
+        ctx.model = model
+        return seg_loss.clone(), sr_loss.clone()
+
+    @staticmethod
+    def backward(ctx, dseg, dsr):
+        grads = ctx.model._hip_backward(dseg, dsr)
+        return (None, None, None) + tuple(grads)
+
+
+class JointModelWithLoss(_JointBase):
+    def __init__(self, cfg, num_train_ds, resume_iter, sr_transforms=None, antialias=True, device="cuda:0", seed=None):
+        super().__init__(cfg, antialias, device, seed)
+        if cfg.SOLVER.SEG_LOSS_FUNC != "BoundaryCombo" or cfg.SOLVER.SR_LOSS_FUNC != "KBPN":
+            raise NotImplementedError("csbsr_amd builds SEG_LOSS_FUNC=BoundaryCombo with SR_LOSS_FUNC=KBPN")
+        if cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SS_AMP != 0 or cfg.SOLVER.CRACK_ORIENTED_WEIGHT4SR_AMP != 0 or cfg.SOLVER.INTERM_SSLOSSWEGHT4SR:
+            raise NotImplementedError("oriented loss weights other than SEG_FAIL_ORIENTED_WEIGHT4SR are not built")
+        seg_rsm = resume_iter - (cfg.SOLVER.SR_PRETRAIN_ITER[1] - 1) if resume_iter > (cfg.SOLVER.SR_PRETRAIN_ITER[1] - 1) else 0
+        per_epoch = num_train_ds // cfg.SOLVER.BATCH_SIZE + 1
+        self.ss_loss_fn = BoundaryComboState(per_epoch, seg_rsm, decrease_ratio=cfg.SOLVER.BOUNDARY_DEC_RATIO)
+        self.sr_loss_fn = "KBPNLoss"
+        self.aux_weight, self.main_weight = cfg.SOLVER.SEG_AUX_LOSS_WEIGHT, cfg.SOLVER.SEG_MAIN_LOSS_WEIGHT
+        self.iter_cnt = True
+        self.grad_scale = None          # None: chosen per call as 2^round(log2(B*H*W))
+        self._st = None
+        self.reducer = None             # csbsr_amd.parallel.GradBucketReducer when data-parallel
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, iter, x, sr_targets=None, segment_targets=None, kernel_targets=None):
+        rt = self._runtime()
+        eng, kbpn, psp, pc = rt["eng"], rt["kbpn"], rt["psp"], self.pc
+        self._invalidate()              # master weights may have been stepped by the optimiser
+        x, hr, mask, kgt = self._mount(x), self._mount(sr_targets), self._mount(segment_targets), self._mount(kernel_targets)
+        B, _, h, w = x.shape
+        H, W = h * pc.scale, w * pc.scale
+        mb = max(1, min(self.micro_batch, B))
+        single = mb >= B
+        sr32 = eng.f32(B, 3, H, W, zero=False)
+        kvec = eng.f32(B, pc.ksize_out ** 2, zero=False)
+        training = self.training
+        for b0 in range(0, B, mb):
+            s_, k_ = kbpn.forward(x[b0:b0 + mb], iter, kgt[b0:b0 + mb], save=single and training)
+            sr32[b0:b0 + mb] = s_
+            kvec[b0:b0 + mb] = k_
+        xin, mean, invstd = self._norm_sr(sr32)
+        drop = self.dropout_masks if self.dropout_masks is not None else psp.make_dropout(B, training, self.dropout_enabled)
+        drop = {k: (None if v is None else v.to(self._device, torch.float32).contiguous()) for k, v in drop.items()}
+        seg32, aux32 = psp.forward(xin, drop, training)
+        # ---- losses (forward sums only; gradients are produced in _hip_backward)
+        hw = H * W
+        sdf = eng.f32(B, 1, H, W, zero=False)
+        scratch = eng.f32(3 * B * hw + 2 * B, zero=False)
+        L.call("csbsr_sdf", _ptr(mask), _ptr(sdf), _ptr(scratch), B, H, W, eng.stream)
+        del scratch
+        alpha = float(self.ss_loss_fn.alpha)
+        seg_loss = eng.f32(B)
+        sums_m, sums_a = eng.f32(B, 8), eng.f32(B, 8)
+        pw, lw = pc.bce_w, pc.wbd_w
+        for p_, sums, wgt in ((seg32, sums_m, self.main_weight), (aux32, sums_a, self.aux_weight)):
+            L.call("csbsr_segloss_reduce", _ptr(p_), _ptr(mask), _ptr(sdf), B, hw, _ptr(sums), pw[0], pw[1], eng.stream)
+            L.call("csbsr_segloss_finish", _ptr(p_), _ptr(mask), _ptr(sdf), B, hw, _ptr(sums), alpha, pw[0], pw[1], lw[0], lw[1], wgt,
+                   None, _ptr(seg_loss), None, 0, eng.stream)
+        # KBPNLoss: L1(sr, hr), L1(down(blur(sr)), x), MSE(kernel) * 0
+        ksum = kvec.sum(1, keepdim=True)
+        vec = (kvec / ksum).contiguous()
+        K = pc.ksize_out
+        wmap = None
+        if iter > pc.oriented_w_iter and pc.oriented_w_iter != -1 and pc.sfo_sr_amp != 0:
+            wmap = torch.exp(pc.sfo_sr_amp * (seg32 - mask).abs()).contiguous()      # oriented_weight.py:73-83 (detached)
+        wmap_lr = None
+        if wmap is not None:
+            wmap_lr = eng.f32(B, 1, h, w, zero=False)
+            L.call("csbsr_bilinear32_fwd", _ptr(wmap), _ptr(wmap_lr), B, H, W, h, w, 0, eng.stream)
+        blurred = eng.f32(B, 3, H, W, zero=False)
+        L.call("csbsr_blur_fwd", _ptr(sr32), _ptr(vec), B, 3, H, W, K, 1, None, _ptr(blurred), None, 0, eng.stream)
+        lr_pred = eng.f32(B, 3, h, w, zero=False)
+        L.call("csbsr_aa_bicubic_down_fwd", _ptr(blurred), _ptr(lr_pred), B * 3, H, W, pc.scale, int(pc.antialias), eng.stream)
+        s_hr, s_lr = eng.f32(B), eng.f32(B)
+        L.call("csbsr_l1_fwd_bwd", _ptr(sr32), _ptr(hr), _ptr(wmap), B, 3, hw, _ptr(s_hr), 0.0, None, None, 0, eng.stream)
+        L.call("csbsr_l1_fwd_bwd", _ptr(lr_pred), _ptr(x), _ptr(wmap_lr), B, 3, h * w, _ptr(s_lr), 0.0, None, None, 0, eng.stream)
+        kpred = vec.reshape(B, 1, K, K)
+        k_l = ((kpred - kgt) ** 2).mean((1, 2, 3))
+        sr_loss = pc.sr_w[0] * s_hr / (3 * hw) + pc.sr_w[1] * s_lr / (3 * h * w) + pc.sr_w[2] * k_l
+        self._st = dict(iter=iter, x=x, hr=hr, mask=mask, kgt=kgt, sr32=sr32, kvec=kvec, ksum=ksum, vec=vec, mean=mean, invstd=invstd,
+                        seg32=seg32, aux32=aux32, sdf=sdf, sums_m=sums_m, sums_a=sums_a, alpha=alpha, lr_pred=lr_pred, blurred=None,
+                        wmap=wmap, wmap_lr=wmap_lr, single=single, mb=mb, B=B, h=h, w=w)
+        del blurred
+        if torch.is_grad_enabled() and training:
+            params = [p for p in self.parameters()]
+            seg_loss, sr_loss = _JointFn.apply(self, seg_loss, sr_loss, *params)
+        return seg_loss, sr_loss, seg32, sr32, kpred
+
+    # ------------------------------------------------------------------ backward
+    def _hip_backward(self, dseg_loss, dsr_loss):
+        rt, st, pc = self._rt, self._st, self.pc
+        eng, kbpn, psp = rt["eng"], rt["kbpn"], rt["psp"]
+        B, h, w = st["B"], st["h"], st["w"]
+        H, W = h * pc.scale, w * pc.scale
+        hw = H * W
+        gs = self.grad_scale or float(2 ** round(math.log2(B * hw)))
+        eng.grad_scale = gs
+        pnames = [k for k, v in self._named_full() if isinstance(v, nn.Parameter)]     # == self.parameters() order
+        for k in pnames:                    # fresh fp32 accumulators for this backward
+            t = rt["P"][k]
+            if getattr(t, "gacc", None) is not None:
+                t.gacc.zero_()
+            t.gacc_touched = False
+        dsr32 = eng.f32(B, 3, H, W)
+        seg_active = dseg_loss is not None and bool((dseg_loss != 0).any())
+        if seg_active:
+            gsc = (dseg_loss.to(torch.float32) * gs).contiguous()
+            dseg32, daux32 = eng.f32(B, 1, H, W, zero=False), eng.f32(B, 1, H, W, zero=False)
+            pw, lw = pc.bce_w, pc.wbd_w
+            for p_, sums, wgt, dp in ((st["seg32"], st["sums_m"], self.main_weight, dseg32), (st["aux32"], st["sums_a"], self.aux_weight, daux32)):
+                L.call("csbsr_segloss_finish", _ptr(p_), _ptr(st["mask"]), _ptr(st["sdf"]), B, hw, _ptr(sums), st["alpha"], pw[0], pw[1],
+                       lw[0], lw[1], wgt, _ptr(gsc), None, _ptr(dp), 0, eng.stream)
+            dxin = psp.backward(dseg32, daux32)
+            if self.reducer is not None:        # segmentation gradients are final: exchange them under the KBPN backward
+                self.reducer.launch([rt["P"][k].gacc if getattr(rt["P"][k], "gacc_touched", False) else None
+                                     for k in pnames if k.startswith("segmentation_model")])
+            if st["mean"] is not None and self.norm_method == "instance":
+                red = eng.f32(B * 3, 2)
+                L.call("csbsr_instnorm_bwd", _ptr(dxin.t), dxin.ld, _ptr(st["sr32"]), _ptr(st["mean"]), _ptr(st["invstd"]), _ptr(dsr32), 0,
+                       B, 3, hw, _ptr(red), eng.stream)
+            else:
+                eng.fm_to_nchw32(dxin, dsr32, 3)
+                if st["invstd"] is not None:
+                    dsr32 *= st["invstd"].reshape(B, 3, 1, 1)
+            del dxin, dseg32, daux32
+        else:
+            psp.saved = None
+        # ---- SR loss gradients
+        dkvec = eng.f32(B, pc.ksize_out ** 2)
+        if dsr_loss is not None and bool((dsr_loss != 0).any()):
+            g = (dsr_loss.to(torch.float32) * gs)
+            K = pc.ksize_out
+            g_hr = (g * pc.sr_w[0] / (3 * hw)).contiguous()
+            g_lr = (g * pc.sr_w[1] / (3 * h * w)).contiguous()
+            L.call("csbsr_l1_fwd_bwd", _ptr(st["sr32"]), _ptr(st["hr"]), _ptr(st["wmap"]), B, 3, hw, None, 1.0, _ptr(g_hr), _ptr(dsr32), 1,
+                   eng.stream)
+            dlr = eng.f32(B, 3, h, w, zero=False)
+            L.call("csbsr_l1_fwd_bwd", _ptr(st["lr_pred"]), _ptr(st["x"]), _ptr(st["wmap_lr"]), B, 3, h * w, None, 1.0, _ptr(g_lr), _ptr(dlr), 0,
+                   eng.stream)
+            dbl = eng.f32(B, 3, H, W, zero=False)
+            L.call("csbsr_aa_bicubic_down_bwd", _ptr(dlr), _ptr(dbl), 0, B * 3, H, W, pc.scale, int(pc.antialias), eng.stream)
+            L.call("csbsr_blur_bwd_input", _ptr(dbl), _ptr(st["vec"]), _ptr(dsr32), 1, B, 3, H, W, K, 1, eng.stream)
+            dvec = eng.f32(B, K * K)
+            L.call("csbsr_blur_bwd_kernel", _ptr(dbl), _ptr(st["sr32"]), _ptr(dvec), B, 3, H, W, K, 1, eng.stream)
+            if pc.sr_w[2] != 0:
+                dvec += (g * pc.sr_w[2] / (K * K)).reshape(B, 1) * 2 * (st["vec"] - st["kgt"].reshape(B, -1))
+            dkvec = (dvec - (dvec * st["vec"]).sum(1, keepdim=True)) / st["ksum"]
+            del dbl, dlr
+        # ---- KBPN backward (per micro-batch; recompute the forward when it was not kept)
+        mb = st["mb"]
+        for b0 in range(0, B, mb):
+            if not st["single"]:
+                kbpn.forward(st["x"][b0:b0 + mb], st["iter"], st["kgt"][b0:b0 + mb], save=True)
+            kbpn.backward(dsr32[b0:b0 + mb].contiguous(), dkvec[b0:b0 + mb].contiguous())
+        self._st = None
+        if self.reducer is not None:
+            self.reducer.launch([rt["P"][k].gacc if getattr(rt["P"][k], "gacc_touched", False) else None
+                                 for k in pnames if k.startswith("sr_model")])
+            self.reducer.finish()
+        inv = 1.0 / gs
+        out = []
+        for k in pnames:                    # parameters no kernel touched (frozen phase / unused) keep grad None
+            t = rt["P"][k]
+            out.append(t.gacc * inv if getattr(t, "gacc_touched", False) else None)
+        return out
+
+
+class JointModel(_JointBase):
+    """Inference counterpart (build_model.py:441-500): SR clipped to [0,1] before segmentation, kernel normalised."""
+
+    def __init__(self, cfg, antialias=True, device="cuda:0", seed=None):
+        super().__init__(cfg, antialias, device, seed)
+        self.ksize = cfg.BLUR.KERNEL_SIZE_OUTPUT
+
+    @torch.no_grad()
+    def forward(self, x, damy_kernel, sr_targets=None):
+        rt = self._runtime()
+        eng, kbpn, psp = rt["eng"], rt["kbpn"], rt["psp"]
+        self._invalidate()
+        x, kgt = self._mount(x), self._mount(damy_kernel)
+        B = x.shape[0]
+        sr32, kvec = kbpn.forward(x, -1, kgt, save=False)
+        sr32.clamp_(0, 1)
+        xin, _, _ = self._norm_sr(sr32)
+        seg32, _ = psp.forward(xin, {k: None for k in ("drop_1", "drop_2a", "drop_2b", "drop_2c", "aux_drop")}, training=self.training)
+        psp.saved = None
+        kvec = kvec / kvec.sum(1, keepdim=True)
+        return sr32, seg32, kvec.reshape(B, 1, self.ksize, self.ksize)

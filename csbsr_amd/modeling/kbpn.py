@@ -1,0 +1,426 @@
+"""KBPN blind-SR network on the HIP engine: explicit forward and backward.
+
+Mirrors the reference module tree (parameter names, phase behaviour) of
+/root/reference/model/modeling/kbpn.py -- KBPN.forward :84-116, KernelBackProjectionStageWithSFT.forward
+:172-189, UpBlock :450-469, DownBlock :472-489, KBlock :380-409, KernelPredictorLikeIKC :562-578,
+SFTlayer :509-518, predictor_withGAP :322-341 -- but none of its structure: concat buffers are written in
+place, the kernel-code maps are stride-0 convolution segments, every conv epilogue is fused, and the
+backward pass is hand-scheduled (gradient fan-in by accumulate flags, no autograd tape).
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib as L
+from ..engine import FM, Conv, grad_acc, pad8, _ptr
+from .shapes import CONV_SETTING
+
+A_NONE, A_RELU, A_LRELU, A_PRELU, A_SIG = L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU, L.ACT_PRELU, L.ACT_SIGMOID
+
+
+class _Stage:
+    pass
+
+
+class KBPN:
+    def __init__(self, eng, params, cfg, prefix="sr_model"):
+        self.eng, self.P, self.cfg, self.prefix = eng, params, cfg, prefix
+        self.scale = cfg.scale
+        self.S = cfg.num_stages
+        self.K = cfg.ksize_out
+        self.kk = self.K * self.K
+        k, s, p = CONV_SETTING[self.scale]
+        md = 128
+        kc = cfg.ksize * cfg.ksize
+        e, P = eng, params
+        self.layers = []
+
+        def mk(name, *a, **kw):
+            c = Conv(e, name, P, *a, **kw)
+            self.layers.append(c)
+            return c
+
+        def block(name, kk_, st, pd, act, transposed=False, bias=False, slope=0.01, split=None):
+            return mk(name + ".layer", kk_, st, pd, 1, transposed=transposed, bias=bias, act=act, slope=slope,
+                      prelu=(name + ".act.weight") if act == A_PRELU else False, split=split)
+
+        self.feat = [mk(f"{prefix}.feat.{i}", 3, 1, 1, act=A_RELU) for i in (0, 2, 4, 6)]
+        self.pred = [block(f"{prefix}.predictor.feat_ext.{i}", 3, 1, 1, A_PRELU) for i in range(3)]
+        self.stages = []
+        for st in range(1, self.S + 1):
+            sp = f"{prefix}.back_projection_stages.{st - 1}"
+            o = _Stage()
+            o.up_conv = block(sp + ".up.conv", 1, 1, 0, A_PRELU, bias=True)
+            o.up1 = block(sp + ".up.up_conv1", k, s, p, A_PRELU, transposed=True)
+            o.up2 = block(sp + ".up.up_conv2", k, s, p, A_PRELU)
+            o.up3 = block(sp + ".up.up_conv3", k, s, p, A_PRELU, transposed=True)
+            o.sr_reconst = block(sp + ".kb.sr_reconst", 3, 1, 1, A_NONE, split=(md * (st - 1), md) if st > 1 else None)
+            kp = sp + ".kb.kernel_predictor"
+            o.fe_sr = [block(kp + ".fe_SR.0", 3, 1, 1, A_RELU), block(kp + ".fe_SR.1", 1, 1, 0, A_LRELU),
+                       block(kp + ".fe_SR.2", 3, 1, 1, A_LRELU), block(kp + ".fe_SR.3", 3, 1, 1, A_LRELU),
+                       block(kp + ".fe_SR.4", 3, 1, 1, A_LRELU)]
+            o.fe_k = [block(kp + ".fe_kernel.0", 3, 1, 1, A_LRELU), block(kp + ".fe_kernel.1", 3, 1, 1, A_LRELU)]
+            o.fe_cat = [block(kp + ".fe_cat.0", 1, 1, 0, A_LRELU, split=(kc, kc)), block(kp + ".fe_cat.1", 3, 1, 1, A_LRELU),
+                        block(kp + ".fe_cat.2", 3, 1, 1, A_NONE)]
+            o.kb_up = block(sp + ".kb.up_conv1", k, s, p, A_PRELU, transposed=True)
+            if st < self.S:
+                o.down_conv = block(sp + ".down.conv", 1, 1, 0, A_PRELU, bias=True)
+                o.down1 = block(sp + ".down.down_conv1", k, s, p, A_PRELU)
+                o.down2 = block(sp + ".down.down_conv2", k, s, p, A_PRELU, transposed=True)
+                o.down3 = block(sp + ".down.down_conv3", k, s, p, A_PRELU)
+                sf = sp + ".sft"
+                o.sc0 = mk(sf + ".SFT_scale_conv0", 3, 1, 1, act=A_LRELU, slope=0.1, split=(md * st, self.kk))
+                o.sc1 = mk(sf + ".SFT_scale_conv1", 3, 1, 1, act=A_SIG)
+                o.sh0 = mk(sf + ".SFT_shift_conv0", 3, 1, 1, act=A_LRELU, slope=0.1, split=(md * st, self.kk))
+                o.sh1 = mk(sf + ".SFT_shift_conv1", 3, 1, 1, act=A_NONE)
+            self.stages.append(o)
+        self.output_conv = block(f"{prefix}.output_conv", 3, 1, 1, A_NONE)
+        # bicubic 7x7 -> 21x21 as a fixed linear map U [kk, kc] (nn.Upsample(size, 'bicubic'), kbpn.py:317,558)
+        eye = torch.eye(kc).reshape(kc, 1, cfg.ksize, cfg.ksize)
+        up = F.interpolate(eye, size=(self.K, self.K), mode="bicubic", align_corners=False) if cfg.ksize != self.K else eye
+        self.U = up.reshape(kc, self.kk).t().contiguous().to(eng.device)       # [kk, kc]
+        self.kc = kc
+        self.saved = None
+
+    # ------------------------------------------------------------------ phase logic (kbpn.py:118-142, 414-447)
+    def set_phase(self, it):
+        c = self.cfg
+        sr_pre = c.sr_pretrain[0] <= it < c.sr_pretrain[1]
+        k_pre = c.kernel_pretrain[0] <= it < c.kernel_pretrain[1]
+        self.use_predictor = not sr_pre
+        for l in self.layers:
+            n = l.name
+            is_kernel = ("kernel_predictor" in n) or (".predictor." in n)
+            if sr_pre:
+                l.frozen = is_kernel
+            elif k_pre:
+                l.frozen = not is_kernel
+            else:
+                l.frozen = False
+
+    def invalidate(self):
+        for l in self.layers:
+            l.invalidate()
+
+    # ------------------------------------------------------------------ helpers
+    def _kfm(self, vec, H, W):
+        t = torch.zeros(vec.shape[0], 1, 1, pad8(self.kk), dtype=torch.float16, device=vec.device)
+        t[:, 0, 0, :self.kk] = vec.to(torch.float16)
+        return FM(t, self.kk, bcast=True, H=H, W=W)
+
+    def _bcast_grad(self, g, H, W):
+        """[B, c] fp32 (already scaled) -> stride-0 FM used as dPre of a GAP'ed conv output."""
+        t = torch.zeros(g.shape[0], 1, 1, pad8(g.shape[1]), dtype=torch.float16, device=g.device)
+        t[:, 0, 0, :g.shape[1]] = g.to(torch.float16)
+        return FM(t, g.shape[1], bcast=True, H=H, W=W)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x32, it, kernel_gt, save=True):
+        """x32: fp32 NCHW LR batch on device.  Returns (sr32 [B,3,H,W] fp32, kvec [B,kk] fp32 normalised)."""
+        e = self.eng
+        self.set_phase(it)
+        B, _, h, w = x32.shape
+        H, W = h * self.scale, w * self.scale
+        sv = {"x32": x32, "B": B, "h": h, "w": w}
+        x16 = e.nchw32_to_fm(x32)
+        f = x16
+        feats = [x16]
+        for c in self.feat:
+            f = c.fwd(f)
+            feats.append(f)
+        sv["feats"] = feats
+        init_f = f
+        if self.use_predictor:
+            z = init_f
+            zs = [z]
+            for c in self.pred[:2]:
+                z = c.fwd(z)
+                zs.append(z)
+            gap = e.f32(B, pad8(self.kc))
+            z3 = self.pred[2].fwd(z, stat=gap, stat_mode=L.STAT_SAMPLE_SUM)
+            zs.append(z3)
+            v49 = gap[:, :self.kc] / float(h * w)
+            k441 = v49 @ self.U.t()
+            ksum = k441.sum(1, keepdim=True)
+            kvec = k441 / ksum
+            sv["pred"] = (zs, k441, ksum)
+        else:
+            kvec = kernel_gt.reshape(B, -1).to(torch.float32)
+        concat_h = e.new(B, H, W, 128 * self.S)
+        concat_l = e.new(B, h, w, 128 * (self.S - 1)) if self.S > 1 else None
+        sv["concat_h"], sv["concat_l"] = concat_h, concat_l
+        low = init_f
+        stg = []
+        for s in range(1, self.S + 1):
+            st = self.stages[s - 1]
+            q = {}
+            q["low_in"] = low
+            xu = st.up_conv.fwd(low)
+            h0 = st.up1.fwd(xu)
+            d = st.up2.fwd(h0, res=xu, res_mode=L.RES_SUB)
+            hh = st.up3.fwd(d, res=h0, res_mode=L.RES_ADD)
+            q.update(xu=xu, h0=h0, d=d, h=hh)
+            segs = (concat_h.slice(0, 128 * (s - 1)), hh) if s > 1 else (hh,)
+            sr_t32 = e.f32(B, 3, H, W, zero=False)
+            sr_t16 = e.new(B, H, W, 3)
+            st.sr_reconst.fwd(segs, out=sr_t16, out32=sr_t32)
+            q.update(sr_t32=sr_t32, sr_t16=sr_t16, kvec_in=kvec)
+            if self.use_predictor:
+                kvec2 = self._kernel_predictor_fwd(st, q, sr_t16, kvec, H, W)
+            else:
+                kvec2 = kvec
+            ksum = kvec2.sum(1, keepdim=True)
+            vec = kvec2 / ksum
+            q.update(kvec2=kvec2, ksum=ksum, vec=vec)
+            err16 = e.new(B, h, w, 3, zero=True)
+            L.call("csbsr_blur_fwd", _ptr(sr_t32), _ptr(vec.contiguous()), B, 3, H, W, self.K, self.scale, _ptr(x32), None,
+                   _ptr(err16.t), err16.ld, e.stream)
+            q["err16"] = err16
+            hs = concat_h.slice(128 * (s - 1), 128 * s)
+            st.kb_up.fwd(err16, out=hs, res=hh, res_mode=L.RES_ADD)
+            kvec = vec
+            if s < self.S:
+                chp = concat_h.slice(0, 128 * s)
+                xd = st.down_conv.fwd(chp)
+                l0 = st.down1.fwd(xd)
+                dd = st.down2.fwd(l0, res=xd, res_mode=L.RES_SUB)
+                lows = concat_l.slice(128 * (s - 1), 128 * s)
+                st.down3.fwd(dd, out=lows, res=l0, res_mode=L.RES_ADD)
+                fpre = concat_l.slice(0, 128 * s)
+                kfm = self._kfm(vec, h, w)
+                t1 = st.sc0.fwd((fpre, kfm))
+                sc = st.sc1.fwd(t1)
+                t2 = st.sh0.fwd((fpre, kfm))
+                lowp = st.sh1.fwd(t2, res=fpre, res2=sc, res_mode=L.RES_FMA)
+                q.update(xd=xd, l0=l0, dd=dd, kfm=kfm, t1=t1, sc=sc, t2=t2, lowp=lowp)
+                low = lowp
+            stg.append(q if save else None)
+            if not save:
+                del q
+        sr32 = e.f32(B, 3, H, W, zero=False)
+        self.output_conv.fwd(concat_h, out32=sr32)
+        L.call("csbsr_bicubic_up_add", _ptr(x32), _ptr(sr32), B * 3, h, w, self.scale, e.stream)
+        sv["stages"] = stg
+        self.saved = sv if save else None
+        return sr32, kvec
+
+    def _kernel_predictor_fwd(self, st, q, sr_t16, kvec, H, W):
+        e = self.eng
+        B = sr_t16.N
+        a = [sr_t16]
+        x = sr_t16
+        for c in st.fe_sr:
+            x = c.fwd(x)
+            a.append(x)
+        kfm = self._kfm(kvec, H, W)
+        b1 = st.fe_k[0].fwd(kfm)
+        b2 = st.fe_k[1].fwd(b1)
+        c1 = st.fe_cat[0].fwd((a[-1], b2))
+        c2 = st.fe_cat[1].fwd(c1)
+        gap = e.f32(B, pad8(self.kc))
+        st.fe_cat[2].fwd(c2, stat=gap, stat_mode=L.STAT_SAMPLE_SUM, store=False)
+        d49 = gap[:, :self.kc] / float(H * W)
+        q["kp"] = (a, kfm, b1, b2, c1, c2)
+        return kvec + d49 @ self.U.t()
+
+    # ------------------------------------------------------------------ backward
+    def _act_bwd(self, conv, dout, out, res=None, res2=None, res_mode=L.RES_NONE, dres=None, dres_acc=False, dres2=None,
+                 dres2_acc=False):
+        """in-place dOut -> dPre for a fused conv epilogue; accumulates bias / PReLU-slope grads."""
+        fz = conv.frozen
+        self.eng.epilogue_bwd(dout, out=out, act=conv.act, slope=conv.slope, prelu=conv.prelu, res=res, res2=res2, res_mode=res_mode,
+                              dpre=dout, dres=dres, dres_acc=dres_acc, dres2=dres2, dres2_acc=dres2_acc,
+                              dbias=None if (conv.b is None or fz) else grad_acc(conv.b),
+                              dprelu=None if (conv.prelu is None or fz) else grad_acc(conv.prelu), creal=conv.cout)
+        return dout
+
+    def _wg(self, conv, dpre, x):
+        if not conv.frozen:
+            conv.bwd_weights(dpre, x)
+
+    def backward(self, dsr32, dkvec_final):
+        """dsr32: fp32 [B,3,H,W] gradient wrt sr (scaled by eng.grad_scale); dkvec_final: [B,kk] fp32 gradient wrt
+        the returned normalised kernel vector (scaled).  Accumulates parameter gradients (scaled)."""
+        e, sv = self.eng, self.saved
+        B, h, w = sv["B"], sv["h"], sv["w"]
+        H, W = h * self.scale, w * self.scale
+        concat_h, concat_l = sv["concat_h"], sv["concat_l"]
+        dch = e.new(B, H, W, 128 * self.S, zero=True)
+        dcl = e.new(B, h, w, 128 * (self.S - 1), zero=True) if self.S > 1 else None
+        # output conv
+        dpre = e.nchw32_to_fm(dsr32)
+        self._wg(self.output_conv, dpre, concat_h)
+        self.output_conv.bwd_input(dpre, out=dch, accumulate=True)
+        del dpre
+        dvec_next = dkvec_final.clone()     # gradient wrt the normalised kernel vector leaving stage s
+        dlowp = None
+        for s in range(self.S, 0, -1):
+            st, q = self.stages[s - 1], sv["stages"][s - 1]
+            if s < self.S:
+                # ---- SFT backward
+                fpre = concat_l.slice(0, 128 * s)
+                dfpre = dcl.slice(0, 128 * s)
+                dsc = e.new(B, h, w, 128 * s)
+                e.epilogue_bwd(dlowp, out=q["lowp"], res=fpre, res2=q["sc"], res_mode=L.RES_FMA, dpre=dlowp, dres=dfpre, dres_acc=True,
+                               dres2=dsc, dbias=None if st.sh1.frozen else grad_acc(st.sh1.b), creal=st.sh1.cout)
+                dk = e.f32(B, pad8(self.kk))
+                for c1, c0, t, dz in ((st.sh1, st.sh0, q["t2"], dlowp), (st.sc1, st.sc0, q["t1"], None)):
+                    if dz is None:
+                        dz = self._act_bwd(c1, dsc, q["sc"])
+                    self._wg(c1, dz, t)
+                    dt = c1.bwd_input(dz)
+                    self._act_bwd(c0, dt, t)
+                    self._wg(c0, dt, (fpre, q["kfm"]))
+                    c0.bwd_input(dt, seg=0, out=dfpre, accumulate=True)
+                    c0.bwd_input(dt, seg=1, stat=dk)
+                    del dt
+                dvec_next = dvec_next + dk[:, :self.kk]
+                del dsc, dlowp
+                # ---- DownBlock backward
+                dlow_s = dcl.slice(128 * (s - 1), 128 * s)
+                lows = concat_l.slice(128 * (s - 1), 128 * s)
+                dl0 = e.new(B, h, w, 128)
+                self._act_bwd(st.down3, dlow_s, lows, res=q["l0"], res_mode=L.RES_ADD, dres=dl0)
+                self._wg(st.down3, dlow_s, q["dd"])
+                ddd = st.down3.bwd_input(dlow_s, in_hw=(H, W))
+                dxd = e.new(B, H, W, 128)
+                self._act_bwd(st.down2, ddd, q["dd"], res=q["xd"], res_mode=L.RES_SUB, dres=dxd)
+                self._wg(st.down2, ddd, q["l0"])
+                st.down2.bwd_input(ddd, out=dl0, accumulate=True, in_hw=(h, w))
+                del ddd
+                self._act_bwd(st.down1, dl0, q["l0"])
+                self._wg(st.down1, dl0, q["xd"])
+                st.down1.bwd_input(dl0, out=dxd, accumulate=True, in_hw=(H, W))
+                del dl0
+                self._act_bwd(st.down_conv, dxd, q["xd"])
+                chp = concat_h.slice(0, 128 * s)
+                self._wg(st.down_conv, dxd, chp)
+                st.down_conv.bwd_input(dxd, out=dch.slice(0, 128 * s), accumulate=True)
+                del dxd
+            # ---- KBlock backward
+            hs = concat_h.slice(128 * (s - 1), 128 * s)
+            dhs = dch.slice(128 * (s - 1), 128 * s)
+            dh = e.new(B, H, W, 128)
+            self._act_bwd(st.kb_up, dhs, hs, res=q["h"], res_mode=L.RES_ADD, dres=dh)
+            self._wg(st.kb_up, dhs, q["err16"])
+            derr = e.f32(B, 3, h, w, zero=False)
+            st.kb_up.bwd_input(dhs, out32=derr, in_hw=(h, w))
+            dsr_t = e.f32(B, 3, H, W, zero=False)
+            vec = q["vec"].contiguous()
+            L.call("csbsr_blur_bwd_input", _ptr(derr), _ptr(vec), _ptr(dsr_t), 0, B, 3, H, W, self.K, self.scale, e.stream)
+            dvec = e.f32(B, self.kk)
+            L.call("csbsr_blur_bwd_kernel", _ptr(derr), _ptr(q["sr_t32"]), _ptr(dvec), B, 3, H, W, self.K, self.scale, e.stream)
+            dvec = dvec + dvec_next
+            # vec = kvec2 / sum(kvec2)
+            dk2 = (dvec - (dvec * q["vec"]).sum(1, keepdim=True)) / q["ksum"]
+            if self.use_predictor:
+                dkin = self._kernel_predictor_bwd(st, q, dk2, dsr_t, H, W)
+            else:
+                dkin = dk2
+            dvec_next = dkin
+            # sr_t = sr_reconst(cat(concat_h[:128(s-1)], h))
+            dpre = e.nchw32_to_fm(dsr_t)
+            segs = (concat_h.slice(0, 128 * (s - 1)), q["h"]) if s > 1 else (q["h"],)
+            self._wg(st.sr_reconst, dpre, segs)
+            if s > 1:
+                st.sr_reconst.bwd_input(dpre, seg=0, out=dch.slice(0, 128 * (s - 1)), accumulate=True)
+                st.sr_reconst.bwd_input(dpre, seg=1, out=dh, accumulate=True)
+            else:
+                st.sr_reconst.bwd_input(dpre, seg=0, out=dh, accumulate=True)
+            del dpre, dsr_t, derr
+            # ---- UpBlock backward
+            dh0 = e.new(B, H, W, 128)
+            self._act_bwd(st.up3, dh, q["h"], res=q["h0"], res_mode=L.RES_ADD, dres=dh0)
+            self._wg(st.up3, dh, q["d"])
+            dd_ = st.up3.bwd_input(dh, in_hw=(h, w))
+            del dh
+            dxu = e.new(B, h, w, 128)
+            self._act_bwd(st.up2, dd_, q["d"], res=q["xu"], res_mode=L.RES_SUB, dres=dxu)
+            self._wg(st.up2, dd_, q["h0"])
+            st.up2.bwd_input(dd_, out=dh0, accumulate=True, in_hw=(H, W))
+            del dd_
+            self._act_bwd(st.up1, dh0, q["h0"])
+            self._wg(st.up1, dh0, q["xu"])
+            st.up1.bwd_input(dh0, out=dxu, accumulate=True, in_hw=(h, w))
+            del dh0
+            self._act_bwd(st.up_conv, dxu, q["xu"])
+            self._wg(st.up_conv, dxu, q["low_in"])
+            dlowp = st.up_conv.bwd_input(dxu)        # gradient wrt this stage's `low` input
+            del dxu
+            sv["stages"][s - 1] = None
+        # ---- initial kernel predictor + VGG head
+        dinit = dlowp
+        feats = sv["feats"]
+        if self.use_predictor:
+            zs, k441, ksum = sv["pred"]
+            dk = dvec_next
+            kv = k441 / ksum
+            dk441 = (dk - (dk * kv).sum(1, keepdim=True)) / ksum
+            d49 = (dk441 @ self.U) / float(h * w)
+            z3 = zs[3]
+            dz = e.new(B, h, w, self.kc)
+            for b in range(B):      # GAP backward: every pixel of sample b receives d49[b]
+                gb = self._bcast_grad(d49[b:b + 1], h, w)
+                zb = FM(z3.t[b:b + 1], z3.c)
+                db = FM(dz.t[b:b + 1], dz.c)
+                c = self.pred[2]
+                e.epilogue_bwd(FM(gb.t.expand(1, h, w, gb.cp).contiguous(), gb.c), out=zb, act=c.act, prelu=c.prelu, dpre=db,
+                               dprelu=None if c.frozen else grad_acc(c.prelu), creal=c.cout)
+            for i in (2, 1, 0):
+                c = self.pred[i]
+                if i < 2:
+                    self._act_bwd(c, dz, zs[i + 1])
+                self._wg(c, dz, zs[i])
+                if i > 0:
+                    dz = c.bwd_input(dz)
+                else:
+                    c.bwd_input(dz, out=dinit, accumulate=True)
+        d = dinit
+        for i in (3, 2, 1, 0):
+            c = self.feat[i]
+            self._act_bwd(c, d, feats[i + 1])
+            self._wg(c, d, feats[i])
+            if i > 0:
+                d = c.bwd_input(d)
+        self.saved = None
+
+    def _kernel_predictor_bwd(self, st, q, dk2, dsr_t, H, W):
+        """backward of kvec2 = kvec_in + U @ GAP(fe_cat(...)); adds the fe_SR path into dsr_t (fp32 planar)."""
+        e = self.eng
+        a, kfm, b1, b2, c1, c2 = q["kp"]
+        B = dk2.shape[0]
+        d49 = (dk2 @ self.U) / float(H * W)
+        g = self._bcast_grad(d49, H, W)
+        cat2, cat1, cat0 = st.fe_cat[2], st.fe_cat[1], st.fe_cat[0]
+        self._wg(cat2, g, c2)
+        dc2 = cat2.bwd_input(g)
+        self._act_bwd(cat1, dc2, c2)
+        self._wg(cat1, dc2, c1)
+        dc1 = cat1.bwd_input(dc2)
+        del dc2
+        self._act_bwd(cat0, dc1, c1)
+        self._wg(cat0, dc1, (a[-1], b2))
+        da = cat0.bwd_input(dc1, seg=0)
+        db2 = cat0.bwd_input(dc1, seg=1)
+        del dc1
+        # fe_kernel chain
+        self._act_bwd(st.fe_k[1], db2, b2)
+        self._wg(st.fe_k[1], db2, b1)
+        db1 = st.fe_k[1].bwd_input(db2)
+        del db2
+        self._act_bwd(st.fe_k[0], db1, b1)
+        self._wg(st.fe_k[0], db1, kfm)
+        dkin = e.f32(B, pad8(self.kk))
+        st.fe_k[0].bwd_input(db1, stat=dkin)
+        del db1
+        # fe_SR chain
+        for i in (4, 3, 2, 1, 0):
+            c = st.fe_sr[i]
+            self._act_bwd(c, da, a[i + 1])
+            self._wg(c, da, a[i])
+            if i > 0:
+                da = c.bwd_input(da)
+            else:
+                c.bwd_input(da, out32=dsr_t, accumulate=True)
+        return dk2 + dkin[:, :self.kk]

@@ -1,0 +1,241 @@
+"""PSPNet (dilated ResNet-34 + pyramid pooling + 3 upsample stages + aux head) on the HIP engine.
+
+Counterpart of /root/reference/model/modeling/pspnet_pytorch/pspnet.py:23-123 and extractors.py:41-70,
+112-161 with the reference's parameter names; train-mode BatchNorm statistics come from the conv
+epilogue, Dropout2d channel masks are fused into the following resize / BN-apply, the PSP concat buffer is
+written in place by its producers.  Explicit backward.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib as L
+from ..engine import FM, Conv, BatchNorm, grad_acc, pad8, _ptr
+from .shapes import RESNET34
+
+DROP_P = {"drop_1": 0.3, "drop_2a": 0.15, "drop_2b": 0.15, "drop_2c": 0.15, "aux_drop": 0.1}   # pspnet.py:67,73,83
+DROP_C = {"drop_1": 1024, "drop_2a": 256, "drop_2b": 64, "drop_2c": 64, "aux_drop": 256}
+
+
+class ConvBN:
+    def __init__(self, eng, P, conv_name, bn_name, cin, cout, k, stride, pad, dil=1, bias=False):
+        self.conv = Conv(eng, conv_name, P, k, stride, pad, dil, bias=bias, act=L.ACT_NONE)
+        self.bn = BatchNorm(eng, bn_name, P, cout)
+        self.eng = eng
+
+    def fwd(self, x, training=True):
+        if not training:                # eval: running statistics (F.batch_norm(training=False))
+            raw = self.conv.fwd(x)
+            return raw, self.bn.rmean, torch.rsqrt(self.bn.rvar + 1e-5)
+        stat = self.bn.new_stat()
+        raw = self.conv.fwd(x, stat=stat, stat_mode=L.STAT_BN)
+        mean, invstd = self.bn.finalize(stat, raw.npix, update_running=training)
+        return raw, mean, invstd
+
+
+class PSPNet:
+    def __init__(self, eng, params, prefix="segmentation_model"):
+        self.eng, self.P, self.prefix = eng, params, prefix
+        e, P, f = eng, params, prefix + ".feats"
+        self.stem = ConvBN(e, P, f + ".conv1", f + ".bn1", 3, 64, 7, 2, 3)
+        self.blocks = []
+        inpl = 64
+        for li, (planes, nblk, stride, dil) in enumerate(RESNET34, 1):
+            for b in range(nblk):
+                bp = f"{f}.layer{li}.{b}"
+                first = b == 0
+                s_, d_ = (stride, 1) if first else (1, dil)
+                blk = {"c1": ConvBN(e, P, bp + ".conv1", bp + ".bn1", inpl if first else planes, planes, 3, s_, d_, d_),
+                       "c2": ConvBN(e, P, bp + ".conv2", bp + ".bn2", planes, planes, 3, 1, d_, d_),
+                       "down": None, "layer": li}
+                if first and (stride != 1 or inpl != planes):
+                    blk["down"] = ConvBN(e, P, bp + ".downsample.0", bp + ".downsample.1", inpl, planes, 1, stride, 0)
+                self.blocks.append(blk)
+            inpl = planes
+        self.psp_convs = [Conv(e, f"{prefix}.psp.stages.{i}.1", P, 1, bias=False) for i in range(4)]
+        self.bottleneck = Conv(e, prefix + ".psp.bottleneck", P, 1, bias=True, act=L.ACT_RELU)
+        self.ups = [ConvBN(e, P, f"{prefix}.{n}.conv.0", f"{prefix}.{n}.conv.1", ci, co, 3, 1, 1, bias=True)
+                    for n, ci, co in (("up_1", 1024, 256), ("up_2", 256, 64), ("up_3", 64, 64))]
+        self.up_prelu = [P[f"{prefix}.{n}.conv.2.weight"] for n in ("up_1", "up_2", "up_3")]
+        self.final = Conv(e, prefix + ".final.0", P, 1, bias=True, act=L.ACT_SIGMOID)
+        self.aux0 = ConvBN(e, P, prefix + ".aux.0", prefix + ".aux.1", 256, 256, 3, 1, 1)
+        self.aux4 = Conv(e, prefix + ".aux.4", P, 1, bias=True, act=L.ACT_SIGMOID)
+        self.saved = None
+
+    def all_convs(self):
+        cs = [self.stem.conv] + [b[k].conv for b in self.blocks for k in ("c1", "c2", "down") if b[k] is not None]
+        cs += self.psp_convs + [self.bottleneck] + [u.conv for u in self.ups] + [self.final, self.aux0.conv, self.aux4]
+        return cs
+
+    def invalidate(self):
+        for c in self.all_convs():
+            c.invalidate()
+
+    def make_dropout(self, B, training, enabled=True):
+        if not training or not enabled:
+            return {k: None for k in DROP_P}
+        out = {}
+        for k, p in DROP_P.items():
+            keep = (torch.rand(B, DROP_C[k], device=self.eng.device) >= p).to(torch.float32) / (1.0 - p)
+            out[k] = keep.contiguous()
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, xin, drop, training=True):
+        """xin: FM [B,H,W,8] (3 real channels, already normalised).  Returns (seg32, aux32) fp32 [B,1,H,W]."""
+        e = self.eng
+        B, H, W = xin.N, xin.H, xin.W
+        sv = {"xin": xin, "drop": drop}
+        raw, m, iv = self.stem.fwd(xin, training)
+        a = self.stem.bn.apply(raw, m, iv, act=L.ACT_RELU)
+        PH, PW = (a.H + 2 - 3) // 2 + 1, (a.W + 2 - 3) // 2 + 1
+        p = e.new(B, PH, PW, 64)
+        L.call("csbsr_maxpool3x3s2_fwd", _ptr(a.t), _ptr(p.t), B, a.H, a.W, 64, e.stream)
+        sv["stem"] = (raw, m, iv, a, p)
+        x = p
+        bsv = []
+        x3 = None
+        nb = len(self.blocks)
+        for bi, blk in enumerate(self.blocks):
+            r1, m1, i1 = blk["c1"].fwd(x, training)
+            a1 = blk["c1"].bn.apply(r1, m1, i1, act=L.ACT_RELU)
+            r2, m2, i2 = blk["c2"].fwd(a1, training)
+            if blk["down"] is not None:
+                rd, md, idv = blk["down"].fwd(x, training)
+                res = blk["down"].bn.apply(rd, md, idv, act=L.ACT_NONE)
+                dsv = (rd, md, idv)
+            else:
+                res, dsv = x, None
+            out = None
+            if bi == nb - 1:    # last block writes straight into the PSP concat buffer (channels 2048:2560)
+                cat = e.new(B, r2.H, r2.W, 2560)
+                out = cat.slice(2048, 2560)
+            y = blk["c2"].bn.apply(r2, m2, i2, act=L.ACT_RELU, res=res, out=out)
+            bsv.append((x, r1, m1, i1, a1, r2, m2, i2, res, dsv, y))
+            x = y
+            if blk["layer"] == 3 and (bi + 1 == nb or self.blocks[bi + 1]["layer"] == 4):
+                x3 = y
+        sv["blocks"] = bsv
+        fH, fW = x.H, x.W
+        # pyramid pooling
+        psp = []
+        for i, size in enumerate((1, 2, 3, 6)):
+            pooled = e.new(B, size, size, 512)
+            L.call("csbsr_adaptive_avgpool_fwd", _ptr(x.t), x.ld, _ptr(pooled.t), B, fH, fW, 512, size, size, e.stream)
+            pc = self.psp_convs[i].fwd(pooled)
+            e.bilinear(pc, fH, fW, False, out=cat.slice(512 * i, 512 * (i + 1)))
+            psp.append((pooled, pc))
+        bott = self.bottleneck.fwd(cat)
+        sv["psp"] = (cat, psp, bott)
+        # upsample stages; the dropout that follows stage j is fused into stage j+1's resize (or the last BN apply)
+        cur, cur_drop = bott, drop["drop_1"]
+        usv = []
+        names = ("drop_2a", "drop_2b", "drop_2c")
+        for j, up in enumerate(self.ups):
+            u = e.bilinear(cur, cur.H * 2, cur.W * 2, False, drop=cur_drop)
+            raw, m, iv = up.fwd(u, training)
+            last = j == 2
+            y = up.bn.apply(raw, m, iv, act=L.ACT_PRELU, prelu=self.up_prelu[j], drop=drop[names[j]] if last else None)
+            usv.append((cur, cur_drop, u, raw, m, iv, y))
+            cur, cur_drop = y, drop[names[j]]
+        sv["ups"] = usv
+        seg32 = e.f32(B, 1, H, W, zero=False)
+        self.final.fwd(cur, out32=seg32)
+        # aux head on layer3 output
+        ra, ma, ia = self.aux0.fwd(x3, training)
+        aa = self.aux0.bn.apply(ra, ma, ia, act=L.ACT_RELU, drop=drop["aux_drop"])
+        aux_lo = e.f32(B, 1, x3.H, x3.W, zero=False)
+        self.aux4.fwd(aa, out32=aux_lo)
+        aux32 = e.f32(B, 1, H, W, zero=False)
+        L.call("csbsr_bilinear32_fwd", _ptr(aux_lo), _ptr(aux32), B, x3.H, x3.W, H, W, 1, e.stream)
+        sv["aux"] = (x3, ra, ma, ia, aa, aux_lo)
+        sv["seg32"], sv["p3"] = seg32, cur
+        self.saved = sv
+        return seg32, aux32
+
+    # ------------------------------------------------------------------ backward
+    def _sigmoid_head_bwd(self, conv, dprob32, prob32, x):
+        """1-channel sigmoid head: returns dgrad wrt x; accumulates weight / bias grads."""
+        e = self.eng
+        B, _, H, W = prob32.shape
+        dpre = e.new(B, H, W, 1)
+        L.call("csbsr_sigmoid_bwd_to_nhwc8", _ptr(dprob32), _ptr(prob32), _ptr(dpre.t), B * H * W, 1.0, e.stream)
+        e.epilogue_bwd(dpre, dbias=grad_acc(conv.b), creal=1)
+        conv.bwd_weights(dpre, x)
+        return conv.bwd_input(dpre)
+
+    def backward(self, dseg32, daux32):
+        """Gradients (scaled) wrt the two probability maps -> returns FM gradient wrt xin [B,H,W,8]."""
+        e, sv = self.eng, self.saved
+        drop = sv["drop"]
+        xin = sv["xin"]
+        B, H, W = xin.N, xin.H, xin.W
+        # aux head
+        x3, ra, ma, ia, aa, aux_lo = sv["aux"]
+        daux_lo = e.f32(B, 1, x3.H, x3.W, zero=False)
+        L.call("csbsr_bilinear32_bwd", _ptr(daux32), _ptr(daux_lo), B, x3.H, x3.W, H, W, 1, e.stream)
+        daa = self._sigmoid_head_bwd(self.aux4, daux_lo, aux_lo, aa)
+        dra = self.aux0.bn.backward(daa, ra, ma, ia, act=L.ACT_RELU, drop=drop["aux_drop"])
+        self.aux0.conv.bwd_weights(dra, x3)
+        dx3_aux = self.aux0.conv.bwd_input(dra)
+        del daa, dra
+        # main head
+        d = self._sigmoid_head_bwd(self.final, dseg32, sv["seg32"], sv["p3"])
+        names = ("drop_2a", "drop_2b", "drop_2c")
+        for j in (2, 1, 0):
+            cur, cur_drop, u, raw, m, iv, y = sv["ups"][j]
+            up = self.ups[j]
+            draw = up.bn.backward(d, raw, m, iv, act=L.ACT_PRELU, prelu=self.up_prelu[j], drop=drop[names[j]] if j == 2 else None,
+                                  dprelu=grad_acc(self.up_prelu[j]))
+            up.conv.bwd_weights(draw, u)
+            du = up.conv.bwd_input(draw)
+            d = e.new(B, cur.H, cur.W, cur.c)
+            e.bilinear_bwd(du, d, False, False, drop=cur_drop)
+            del draw, du
+        cat, psp, bott = sv["psp"]
+        self.eng.epilogue_bwd(d, out=bott, act=L.ACT_RELU, dpre=d, dbias=grad_acc(self.bottleneck.b), creal=1024)
+        self.bottleneck.bwd_weights(d, cat)
+        dcat = self.bottleneck.bwd_input(d)
+        del d
+        fH, fW = cat.H, cat.W
+        df = dcat.slice(2048, 2560)
+        for i, size in enumerate((1, 2, 3, 6)):
+            pooled, pc = psp[i]
+            dpc = e.new(B, size, size, 512)
+            e.bilinear_bwd(dcat.slice(512 * i, 512 * (i + 1)), dpc, False, False)
+            self.psp_convs[i].bwd_weights(dpc, pooled)
+            dpool = self.psp_convs[i].bwd_input(dpc)
+            L.call("csbsr_adaptive_avgpool_bwd", _ptr(dpool.t), _ptr(df.t), df.ld, 1, B, fH, fW, 512, size, size, e.stream)
+        dy = df
+        nb = len(self.blocks)
+        for bi in range(nb - 1, -1, -1):
+            blk = self.blocks[bi]
+            x, r1, m1, i1, a1, r2, m2, i2, res, dsv, y = sv["blocks"][bi]
+            if blk["layer"] == 3 and (bi + 1 == nb or self.blocks[bi + 1]["layer"] == 4):
+                L.call("csbsr_axpby", dy.npix, dy.cp, _ptr(dy.t), dy.ld, 1.0, _ptr(dx3_aux.t), dx3_aux.ld, 1.0, _ptr(dy.t), dy.ld, e.stream)
+            dres = e.new(B, res.H, res.W, res.c)
+            dr2 = blk["c2"].bn.backward(dy, r2, m2, i2, act=L.ACT_RELU, res=res, dres=dres)
+            blk["c2"].conv.bwd_weights(dr2, a1)
+            da1 = blk["c2"].conv.bwd_input(dr2)
+            dr1 = blk["c1"].bn.backward(da1, r1, m1, i1, act=L.ACT_RELU)
+            blk["c1"].conv.bwd_weights(dr1, x)
+            del dr2, da1
+            if blk["down"] is not None:
+                rd, md, idv = dsv
+                drd = blk["down"].bn.backward(dres, rd, md, idv, act=L.ACT_NONE)
+                blk["down"].conv.bwd_weights(drd, x)
+                dx = blk["down"].conv.bwd_input(drd, in_hw=(x.H, x.W))
+                blk["c1"].conv.bwd_input(dr1, out=dx, accumulate=True, in_hw=(x.H, x.W))
+            else:
+                dx = dres
+                blk["c1"].conv.bwd_input(dr1, out=dx, accumulate=True, in_hw=(x.H, x.W))
+            dy = dx
+            sv["blocks"][bi] = None
+        raw, m, iv, a, p = sv["stem"]
+        da = e.new(B, a.H, a.W, 64)
+        L.call("csbsr_maxpool3x3s2_bwd", _ptr(a.t), _ptr(p.t), _ptr(dy.t), _ptr(da.t), B, a.H, a.W, 64, e.stream)
+        draw = self.stem.bn.backward(da, raw, m, iv, act=L.ACT_RELU)
+        self.stem.conv.bwd_weights(draw, xin)
+        dxin = self.stem.conv.bwd_input(draw, in_hw=(H, W))
+        self.saved = None
+        return dxin

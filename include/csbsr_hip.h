@@ -231,9 +231,9 @@ int csbsr_segloss_reduce(const float* p, const float* t, const float* sdf, int32
 int csbsr_segloss_finish(const float* p, const float* t, const float* sdf, int32_t N, int64_t hw, const float* sums,
                          float alpha, float pw0, float pw1, float lw0, float lw1, float weight, const float* gscale,
                          float* loss, float* dp, int32_t dp_accumulate, csbsr_stream_t s);
-/* L1 terms of KBPNLoss (sr_loss_functions.py:41-54): sums[n] += sum w|a-b| ; da (+)= gscale*w*sign(a-b) */
+/* L1 terms of KBPNLoss (sr_loss_functions.py:41-54): sums[n] += sum w|a-b| ; da (+)= gscale*gs_n[n]*w*sign(a-b) */
 int csbsr_l1_fwd_bwd(const float* a, const float* b, const float* wmap, int32_t N, int32_t C, int64_t hw,
-                     float* sums, float gscale, float* da, int32_t da_accumulate, csbsr_stream_t s);
+                     float* sums, float gscale, const float* gs_n, float* da, int32_t da_accumulate, csbsr_stream_t s);
 /* d(pre-sigmoid) of a 1-channel head as channel 0 of an fp16 NHWC8 tensor */
 int csbsr_sigmoid_bwd_to_nhwc8(const float* dp, const float* p, void* out, int64_t npix, float scale,
                                csbsr_stream_t s);

@@ -44,3 +44,34 @@ def max_rel_to_scale(a, b):
     a = torch.as_tensor(np.asarray(a)).double().reshape(-1)
     b = torch.as_tensor(np.asarray(b)).double().reshape(-1)
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+class fp16_storage_sim:
+    """Context manager: run the oracle with the build's precision plan emulated on CPU -- operands of every
+    conv / deconv and the outputs of conv, deconv and batch-norm rounded to fp16, fp32 accumulation.  Used to
+    derive how far ANY fp16-storage implementation of the reference arithmetic sits from the fp32 reference on
+    a given input, so the GPU tolerances for the 40-layer BN segmentation net are measured, not guessed."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.F = F
+        self.saved = (F.conv2d, F.conv_transpose2d, F.batch_norm)
+        oc, ot, ob = self.saved
+        r16 = lambda t: t if t is None else t.half().float()
+
+        def conv2d(x, w, b=None, *a, **k):
+            if k.get("groups", 1) != 1 or (len(a) >= 4 and a[3] != 1):      # depthwise blur stays fp32 (as in the build)
+                return oc(x, w, b, *a, **k)
+            return r16(oc(r16(x), r16(w), b, *a, **k))
+
+        def conv_t(x, w, b=None, *a, **k):
+            return r16(ot(r16(x), r16(w), b, *a, **k))
+
+        def bnorm(x, *a, **k):
+            return r16(ob(x, *a, **k))
+        F.conv2d, F.conv_transpose2d, F.batch_norm = conv2d, conv_t, bnorm
+        return self
+
+    def __exit__(self, *exc):
+        self.F.conv2d, self.F.conv_transpose2d, self.F.batch_norm = self.saved
+        return False

@@ -1,0 +1,345 @@
+"""GPU parity of the HBM-bound kernels (BN, pooling, resizes, blur, losses, EDT, epilogue backward) through
+the C ABI against torch fp32 CPU ops / the oracle.  fp16-storage kernels: 2e-3 of the tensor's max magnitude;
+fp32 kernels: 1e-5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _eng():
+    from csbsr_amd.engine import Engine
+    return Engine("cuda:0")
+
+
+def to_fm(x):
+    from csbsr_amd.engine import FM, pad8
+    N, Cc, H, W = x.shape
+    t = torch.zeros(N, H, W, pad8(Cc), dtype=torch.float16)
+    t[..., :Cc] = x.permute(0, 2, 3, 1).half()
+    return FM(t.cuda(), Cc)
+
+
+def from_fm(fm):
+    return fm.t[..., :fm.c].float().cpu().permute(0, 3, 1, 2)
+
+
+def relmax(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+def r16(x):
+    return x.half().float()
+
+
+_KEEP = []
+
+
+def P(t):
+    """device pointer of a tensor; the tensor is kept alive until the test module is torn down (a temporary such as
+    ``x.cuda()`` would otherwise be freed -- and its block reused -- before the asynchronous kernel runs)."""
+    from csbsr_amd.engine import _ptr
+    if t is not None:
+        _KEEP.append(t)
+        if len(_KEEP) > 256:
+            torch.cuda.synchronize()
+            del _KEEP[:128]
+    return _ptr(t)
+
+
+@pytest.mark.parametrize("act,res_mode", [("relu", 0), ("prelu", 1), ("prelu", 2), ("lrelu", 0), ("sigmoid", 0), ("none", 4)])
+def test_epilogue_backward(act, res_mode):
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    torch.manual_seed(1)
+    N, Cc, H, W = 2, 20, 7, 9
+    pre = torch.randn(N, Cc, H, W).requires_grad_(True)
+    res = r16(torch.randn(N, Cc, H, W)).requires_grad_(True)
+    res2 = r16(torch.randn(N, Cc, H, W)).requires_grad_(True)
+    slope = torch.tensor([0.2], requires_grad=True)
+    bias = torch.zeros(Cc, requires_grad=True)
+    z = pre + bias.view(1, -1, 1, 1)
+    y = {"relu": F.relu, "prelu": lambda v: F.prelu(v, slope), "lrelu": lambda v: F.leaky_relu(v, 0.1), "sigmoid": torch.sigmoid,
+         "none": lambda v: v}[act](z)
+    out = {0: y, 1: y + res, 2: y - res, 4: y + res * res2}[res_mode]
+    out16 = r16(out.detach())
+    dout = r16(torch.randn_like(out))
+    # reference on the fp16-rounded saved output (what the kernel sees)
+    out.backward(dout)
+    actc = {"relu": L.ACT_RELU, "prelu": L.ACT_PRELU, "lrelu": L.ACT_LRELU, "sigmoid": L.ACT_SIGMOID, "none": L.ACT_NONE}[act]
+    d = to_fm(dout)
+    dres, dres2 = eng.new(N, H, W, Cc), eng.new(N, H, W, Cc)
+    dbias = torch.zeros(24, device="cuda")
+    dpr = torch.zeros(1, device="cuda")
+    sl = slope.detach().cuda()
+    eng.epilogue_bwd(d, out=to_fm(out16), act=actc, slope=0.1, prelu=sl if act == "prelu" else None,
+                     res=to_fm(res.detach()) if res_mode else None, res2=to_fm(res2.detach()) if res_mode == 4 else None, res_mode=res_mode,
+                     dpre=d, dres=dres if res_mode else None, dres2=dres2 if res_mode == 4 else None, dbias=dbias,
+                     dprelu=dpr if act == "prelu" else None)
+    torch.cuda.synchronize()
+    assert relmax(from_fm(d), pre.grad) < 4e-3
+    assert relmax(dbias[:Cc].cpu(), bias.grad) < 4e-3
+    if res_mode:
+        assert relmax(from_fm(dres), res.grad) < 2e-3
+    if res_mode == 4:
+        assert relmax(from_fm(dres2), res2.grad) < 2e-3
+    if act == "prelu":
+        assert abs(float(dpr) - float(slope.grad)) < 5e-3 * float(pre.grad.abs().sum())
+
+
+@pytest.mark.parametrize("act,with_res,with_drop", [("relu", False, False), ("relu", True, False), ("prelu", False, True), ("none", False, False)])
+def test_batchnorm_train_fwd_bwd(act, with_res, with_drop):
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import BatchNorm, Conv
+    eng = _eng()
+    torch.manual_seed(2)
+    N, Cc, H, W = 3, 16, 9, 10
+    x = r16(torch.randn(N, 8, H, W))
+    w = r16(torch.randn(Cc, 8, 3, 3) / 8)
+    gamma = (1 + 0.2 * torch.randn(Cc)).requires_grad_(True)
+    beta = (0.1 * torch.randn(Cc)).requires_grad_(True)
+    res = r16(torch.randn(N, Cc, H, W)).requires_grad_(True)
+    slope = torch.tensor([0.25], requires_grad=True)
+    drop = ((torch.rand(N, Cc) > 0.3).float() / 0.7) if with_drop else None
+    params = {"c.weight": w.cuda(), "b.weight": gamma.detach().cuda(), "b.bias": beta.detach().cuda(),
+              "b.running_mean": torch.zeros(Cc).cuda(), "b.running_var": torch.ones(Cc).cuda(),
+              "b.num_batches_tracked": torch.zeros((), dtype=torch.long).cuda()}
+    conv = Conv(eng, "c", params, 3, 1, 1, bias=False)
+    bn = BatchNorm(eng, "b", params, Cc)
+    stat = bn.new_stat()
+    raw = conv.fwd(to_fm(x), stat=stat, stat_mode=L.STAT_BN)
+    mean, invstd = bn.finalize(stat, raw.npix)
+    actc = {"relu": L.ACT_RELU, "prelu": L.ACT_PRELU, "none": L.ACT_NONE}[act]
+    sl = slope.detach().cuda()
+    dr = drop.cuda() if with_drop else None
+    y = bn.apply(raw, mean, invstd, act=actc, prelu=sl if act == "prelu" else None, res=to_fm(res.detach()) if with_res else None, drop=dr)
+    # reference
+    rawr = F.conv2d(x, w, None, 1, 1).requires_grad_(True)
+    rm, rv = torch.zeros(Cc), torch.ones(Cc)
+    z = F.batch_norm(rawr, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    if with_res:
+        z = z + res
+    yr = {"relu": F.relu, "prelu": lambda v: F.prelu(v, slope), "none": lambda v: v}[act](z)
+    if with_drop:
+        yr = yr * drop[:, :, None, None]
+    torch.cuda.synchronize()
+    assert relmax(from_fm(y), yr) < 3e-3
+    assert relmax(params["b.running_mean"].cpu(), rm) < 1e-3 and relmax(params["b.running_var"].cpu(), rv) < 1e-3
+    dy = r16(torch.randn_like(yr))
+    yr.backward(dy)
+    dres = eng.new(N, H, W, Cc)
+    dpr = torch.zeros(1, device="cuda")
+    dx = bn.backward(to_fm(dy), raw, mean, invstd, act=actc, prelu=sl if act == "prelu" else None, res=to_fm(res.detach()) if with_res else None,
+                     drop=dr, dres=dres if with_res else None, dprelu=dpr if act == "prelu" else None)
+    torch.cuda.synchronize()
+    assert relmax(from_fm(dx), rawr.grad) < 5e-3
+    assert relmax(params["b.weight"].gacc.cpu(), gamma.grad) < 5e-3
+    assert relmax(params["b.bias"].gacc.cpu(), beta.grad) < 5e-3
+    if with_res:
+        assert relmax(from_fm(dres), res.grad) < 3e-3
+    if act == "prelu":
+        assert abs(float(dpr) - float(slope.grad)) < 1e-2 * abs(float(slope.grad)) + 1e-2
+
+
+def test_maxpool_and_adaptive_pool():
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    torch.manual_seed(3)
+    x = r16(torch.relu(torch.randn(2, 16, 11, 14))).requires_grad_(True)     # relu: ties at 0 exercise the argmax rule
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = r16(torch.randn_like(y))
+    y.backward(dy)
+    fx = to_fm(x.detach())
+    fy = eng.new(2, y.shape[2], y.shape[3], 16)
+    L.call("csbsr_maxpool3x3s2_fwd", P(fx.t), P(fy.t), 2, 11, 14, 16, eng.stream)
+    fdx = eng.new(2, 11, 14, 16)
+    L.call("csbsr_maxpool3x3s2_bwd", P(fx.t), P(fy.t), P(to_fm(dy).t), P(fdx.t), 2, 11, 14, 16, eng.stream)
+    torch.cuda.synchronize()
+    assert relmax(from_fm(fy), y.detach()) == 0.0
+    assert relmax(from_fm(fdx), x.grad) < 2e-3
+    for size in (1, 2, 3, 6):
+        x2 = r16(torch.randn(2, 24, 8, 8)).requires_grad_(True)
+        y2 = F.adaptive_avg_pool2d(x2, size)
+        dy2 = r16(torch.randn_like(y2))
+        y2.backward(dy2)
+        f2 = to_fm(x2.detach())
+        o2 = eng.new(2, size, size, 24)
+        L.call("csbsr_adaptive_avgpool_fwd", P(f2.t), f2.ld, P(o2.t), 2, 8, 8, 24, size, size, eng.stream)
+        d2 = eng.new(2, 8, 8, 24, zero=True)
+        L.call("csbsr_adaptive_avgpool_bwd", P(to_fm(dy2).t), P(d2.t), d2.ld, 1, 2, 8, 8, 24, size, size, eng.stream)
+        torch.cuda.synchronize()
+        assert relmax(from_fm(o2), y2.detach()) < 2e-3
+        assert relmax(from_fm(d2), x2.grad) < 2e-3
+
+
+@pytest.mark.parametrize("align", [False, True])
+@pytest.mark.parametrize("shape", [(8, 8, 16, 16), (1, 1, 8, 8), (3, 3, 8, 8), (6, 6, 8, 8), (8, 8, 64, 64), (5, 7, 20, 21)])
+def test_bilinear_fwd_bwd(align, shape):
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    H, W, OH, OW = shape
+    torch.manual_seed(4)
+    x = r16(torch.randn(2, 8, H, W)).requires_grad_(True)
+    y = F.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=align)
+    dy = r16(torch.randn_like(y))
+    y.backward(dy)
+    fy = eng.bilinear(to_fm(x.detach()), OH, OW, align)
+    dx = eng.new(2, H, W, 8)
+    eng.bilinear_bwd(to_fm(dy), dx, False, align)
+    torch.cuda.synchronize()
+    assert relmax(from_fm(fy), y.detach()) < 2e-3
+    assert relmax(from_fm(dx), x.grad) < 2e-3
+    # fp32 single-plane variant
+    x1 = torch.randn(2, 1, H, W).requires_grad_(True)
+    y1 = F.interpolate(x1, size=(OH, OW), mode="bilinear", align_corners=align)
+    d1 = torch.randn_like(y1)
+    y1.backward(d1)
+    o = torch.empty(2, 1, OH, OW, device="cuda")
+    L.call("csbsr_bilinear32_fwd", P(x1.detach().cuda()), P(o), 2, H, W, OH, OW, int(align), eng.stream)
+    g = torch.empty(2, 1, H, W, device="cuda")
+    L.call("csbsr_bilinear32_bwd", P(d1.cuda()), P(g), 2, H, W, OH, OW, int(align), eng.stream)
+    torch.cuda.synchronize()
+    assert relmax(o.cpu(), y1.detach()) < 1e-5
+    assert relmax(g.cpu(), x1.grad) < 1e-5
+
+
+@pytest.mark.parametrize("stride", [4, 1])
+def test_blur_fwd_bwd(stride):
+    from csbsr_amd import _lib as L
+    from oracle import csbsr_oracle as O
+    eng = _eng()
+    torch.manual_seed(5)
+    N, H, W, K = 2, 36, 40, 21
+    x = torch.rand(N, 3, H, W).requires_grad_(True)
+    k = torch.rand(N, K * K)
+    k = (k / k.sum(1, keepdim=True)).requires_grad_(True)
+    y = O.blur_down(x, k, K, stride)
+    sub = torch.rand_like(y)
+    dy = torch.randn_like(y)
+    (y - sub).backward(dy)
+    xc, kc = x.detach().cuda(), k.detach().cuda()
+    o = torch.empty_like(y, device="cuda")
+    L.call("csbsr_blur_fwd", P(xc), P(kc), N, 3, H, W, K, stride, P(sub.cuda()), P(o), None, 0, eng.stream)
+    dx = torch.empty(N, 3, H, W, device="cuda")
+    L.call("csbsr_blur_bwd_input", P(dy.cuda()), P(kc), P(dx), 0, N, 3, H, W, K, stride, eng.stream)
+    dk = torch.zeros(N, K * K, device="cuda")
+    L.call("csbsr_blur_bwd_kernel", P(dy.cuda()), P(xc), P(dk), N, 3, H, W, K, stride, eng.stream)
+    torch.cuda.synchronize()
+    assert relmax(o.cpu(), (y - sub).detach()) < 1e-5
+    assert relmax(dx.cpu(), x.grad) < 1e-5
+    assert relmax(dk.cpu(), k.grad) < 1e-4
+
+
+@pytest.mark.parametrize("aa", [1, 0])
+def test_bicubic_resizes(aa):
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    torch.manual_seed(6)
+    x = torch.rand(2, 3, 32, 40).requires_grad_(True)
+    y = F.interpolate(x, size=(8, 10), mode="bicubic", align_corners=False, antialias=bool(aa))
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    o = torch.empty(2, 3, 8, 10, device="cuda")
+    L.call("csbsr_aa_bicubic_down_fwd", P(x.detach().cuda()), P(o), 6, 32, 40, 4, aa, eng.stream)
+    dx = torch.empty(2, 3, 32, 40, device="cuda")
+    L.call("csbsr_aa_bicubic_down_bwd", P(dy.cuda()), P(dx), 0, 6, 32, 40, 4, aa, eng.stream)
+    torch.cuda.synchronize()
+    assert relmax(o.cpu(), y.detach()) < 1e-5
+    assert relmax(dx.cpu(), x.grad) < 1e-5
+    xl = torch.rand(2, 3, 9, 7)
+    up = F.interpolate(xl, scale_factor=4, mode="bicubic", align_corners=False)
+    acc = torch.ones(2, 3, 36, 28, device="cuda")
+    L.call("csbsr_bicubic_up_add", P(xl.cuda()), P(acc), 6, 9, 7, 4, eng.stream)
+    torch.cuda.synchronize()
+    assert relmax(acc.cpu() - 1, up) < 1e-5
+
+
+def test_sdf_matches_reference_fixture_and_oracle():
+    from csbsr_amd import _lib as L
+    from golden_utils import load_golden
+    from oracle import csbsr_oracle as O
+    from csbsr_amd.data.synthetic import crack_masks
+    eng = _eng()
+    g = load_golden("sdf_handdrawn")
+    m = torch.from_numpy(g["mask"].astype(np.float32)).cuda()
+    N, _, H, W = m.shape
+    sdf = torch.empty(N, 1, H, W, device="cuda")
+    scratch = torch.empty(3 * N * H * W + 2 * N, device="cuda")
+    L.call("csbsr_sdf", P(m), P(sdf), P(scratch), N, H, W, eng.stream)
+    torch.cuda.synchronize()
+    assert np.abs(sdf.cpu().numpy() - g["sdf"]).max() < 2e-6
+    m2 = crack_masks(2, 160, 192, torch.Generator().manual_seed(3))
+    m2 = m2[:, :, :160, :192].contiguous()
+    ref = O.compute_sdf(m2.numpy())
+    s2 = torch.empty(2, 1, 160, 192, device="cuda")
+    sc2 = torch.empty(3 * 2 * 160 * 192 + 4, device="cuda")
+    L.call("csbsr_sdf", P(m2.cuda()), P(s2), P(sc2), 2, 160, 192, eng.stream)
+    torch.cuda.synchronize()
+    assert np.abs(s2.cpu().numpy() - ref).max() < 2e-6
+
+
+def test_segloss_and_l1():
+    from csbsr_amd import _lib as L
+    from oracle import csbsr_oracle as O
+    eng = _eng()
+    torch.manual_seed(7)
+    N, H, W = 2, 24, 20
+    p = torch.rand(N, 1, H, W)
+    p[0, 0, 0, :4] = 0.0                       # exercises clamp(min=1e-8)
+    p = p.requires_grad_(True)
+    t = (torch.rand(N, 1, H, W) > 0.8).float()
+    sdf = torch.from_numpy(O.compute_sdf(t.numpy())).float()
+    cfg = O.PathCfg(bce_w=(20.0, 1.0), wbd_w=(1.0, 2.0))
+    alpha = 0.6
+    loss = O.boundary_combo_loss(p, t, alpha, cfg, sdf)
+    gsc = torch.tensor([0.5, 2.0])
+    (loss * gsc * 0.4).sum().backward()
+    pc, tc, sc = p.detach().cuda(), t.cuda(), sdf.cuda()
+    sums = torch.zeros(N, 8, device="cuda")
+    lo = torch.zeros(N, device="cuda")
+    dp = torch.empty(N, 1, H, W, device="cuda")
+    L.call("csbsr_segloss_reduce", P(pc), P(tc), P(sc), N, H * W, P(sums), 20.0, 1.0, eng.stream)
+    L.call("csbsr_segloss_finish", P(pc), P(tc), P(sc), N, H * W, P(sums), alpha, 20.0, 1.0, 1.0, 2.0, 0.4, P(gsc.cuda()), P(lo), P(dp), 0,
+           eng.stream)
+    torch.cuda.synchronize()
+    assert relmax(lo.cpu(), 0.4 * loss.detach()) < 1e-5
+    assert relmax(dp.cpu(), p.grad) < 1e-4
+    a = torch.rand(N, 3, H, W).requires_grad_(True)
+    b = torch.rand(N, 3, H, W)
+    wm = torch.rand(N, 1, H, W) + 0.5
+    l1 = (wm * (a - b).abs()).sum((1, 2, 3))
+    (l1 * gsc).sum().backward()
+    s = torch.zeros(N, device="cuda")
+    da = torch.empty(N, 3, H, W, device="cuda")
+    L.call("csbsr_l1_fwd_bwd", P(a.detach().cuda()), P(b.cuda()), P(wm.cuda()), N, 3, H * W, P(s), 1.0, P(gsc.cuda()), P(da), 0, eng.stream)
+    torch.cuda.synchronize()
+    assert relmax(s.cpu(), l1.detach()) < 1e-5
+    assert relmax(da.cpu(), a.grad) < 1e-6
+
+
+def test_instance_norm_fwd_bwd():
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    torch.manual_seed(8)
+    N, H, W = 2, 20, 24
+    x = torch.rand(N, 3, H, W).requires_grad_(True)
+    y = F.instance_norm(x, eps=1e-5)
+    dy = r16(torch.randn(N, 3, H, W))
+    y.backward(dy)
+    xc = x.detach().cuda()
+    red = torch.zeros(N * 3, 2, device="cuda")
+    L.call("csbsr_plane_reduce", P(xc), None, N * 3, H * W, P(red), eng.stream)
+    mean = (red[:, 0] / (H * W)).contiguous()
+    invstd = torch.rsqrt(red[:, 1] / (H * W) - mean * mean + 1e-5).contiguous()
+    fm = eng.nchw32_to_fm(xc, mean=mean, invstd=invstd)
+    dx = torch.empty(N, 3, H, W, device="cuda")
+    red2 = torch.zeros(N * 3, 2, device="cuda")
+    dfm = to_fm(dy)
+    L.call("csbsr_instnorm_bwd", P(dfm.t), dfm.ld, P(xc), P(mean), P(invstd), P(dx), 0, N, 3, H * W, P(red2), eng.stream)
+    torch.cuda.synchronize()
+    assert relmax(from_fm(fm), y.detach()) < 2e-3
+    assert relmax(dx.cpu(), x.grad) < 1e-4

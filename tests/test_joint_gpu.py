@@ -1,0 +1,163 @@
+"""GPU parity of the full hot path (JointModelWithLoss forward + backward through the C ABI) against
+(a) the golden vectors produced by the reference and (b) the oracle run on the same inputs.
+
+Tolerances (north_star: 1e-3 relative, fp16 storage / fp32 accumulate):
+  outputs (sr, seg, kernel, losses): max |a-b| / max|b| <= 2e-3 per tensor  (measured ~3e-4 .. 1e-3)
+  gradients: relative L2 per parameter tensor vs the fp32 oracle.  The oracle's own fp32 evaluation-order noise
+  reaches 1e-2 on a few tensors and 60 % on near-zero PReLU-slope sums (tests/test_oracle_golden.py), so the
+  bound is 3e-2 for tensors and a cancellation-aware absolute bound for scalars; the median is reported.
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_utils import load_golden, det_params, rel_err, max_rel_to_scale, fp16_storage_sim
+from oracle import csbsr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def build_model(g, micro_batch=8):
+    from csbsr_amd.config import cfg as base_cfg
+    from csbsr_amd.modeling.build_model import JointModelWithLoss
+    from csbsr_amd.utils.detfill import deterministic_fill
+    cfg = base_cfg.clone()
+    cfg.MODEL.SCALE_FACTOR = int(g["scale"])
+    m = JointModelWithLoss(cfg, 1000, 0, None, antialias=bool(g["antialias"]))
+    deterministic_fill(m.state_dict())
+    m.ss_loss_fn.alpha = float(g["alpha"])
+    m.micro_batch = micro_batch
+    m.train()
+    drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
+    m.dropout_masks = drop if drop else {k: None for k in ("drop_1", "drop_2a", "drop_2b", "drop_2c", "aux_drop")}
+    return m, cfg
+
+
+def run_hip(g, micro_batch=8):
+    m, cfg = build_model(g, micro_batch)
+    t = lambda k: torch.from_numpy(g[k])
+    it = int(g["it"])
+    seg_l, sr_l, seg, sr, kp = m(it, t("x"), sr_targets=t("hr"), segment_targets=t("mask"), kernel_targets=t("kernel"))
+    pc = m.pc
+    loss = (1 - pc.beta) * sr_l.mean() + pc.beta * seg_l.mean()
+    if pc.joint_pretrain[0] <= it < pc.joint_pretrain[1]:
+        loss = sr_l.mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {k: (None if v.grad is None else v.grad.detach().cpu()) for k, v in m._named_full() if isinstance(v, torch.nn.Parameter)}
+    outs = dict(segment_loss=seg_l.detach().cpu(), sr_loss=sr_l.detach().cpu(), segment_preds=seg.cpu(), sr_preds=sr.cpu(),
+                kernel_preds=kp.cpu(), loss=float(loss))
+    bufs = {k: v.detach().cpu() for k, v in m.state_dict().items() if "running" in k}
+    return outs, grads, bufs
+
+
+def run_oracle(g):
+    P = det_params()
+    cfg = O.PathCfg(antialias=bool(g["antialias"]), scale=int(g["scale"]))
+    t = lambda k: torch.from_numpy(g[k])
+    drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
+    out = O.joint_forward(P, cfg, int(g["it"]), t("x"), t("hr"), t("mask"), t("kernel"), alpha=float(g["alpha"]), drop=drop or None)
+    loss = O.calc_loss(out["segment_loss"], out["sr_loss"], int(g["it"]), cfg)
+    loss.backward()
+    return P, out, loss
+
+
+@pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "e2e_pspnet_it10001",
+                                  "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24"])
+def test_forward_matches_golden_and_oracle(case):
+    g = load_golden(case)
+    outs, grads, bufs = run_hip(g)
+    # what fp16 storage of the reference arithmetic costs on this input (CPU emulation, see golden_utils)
+    with fp16_storage_sim(), torch.no_grad():
+        P = det_params(requires_grad=False)
+        cfg = O.PathCfg(antialias=bool(g["antialias"]), scale=int(g["scale"]))
+        t = lambda k: torch.from_numpy(g[k])
+        drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
+        sim = O.joint_forward(P, cfg, int(g["it"]), t("x"), t("hr"), t("mask"), t("kernel"), alpha=float(g["alpha"]), drop=drop or None)
+    worst = {}
+    for k in ("segment_preds", "sr_preds", "kernel_preds", "segment_loss", "sr_loss"):
+        worst[k] = max_rel_to_scale(outs[k], g[k])
+        bound = 2e-3 + 2.0 * max_rel_to_scale(sim[k], g[k]) if k.startswith("segment") else 2e-3
+        assert worst[k] < bound, (k, worst[k], bound)
+    assert abs(outs["loss"] - float(g["loss"])) < 1e-2 * abs(float(g["loss"]))
+    for k, v in g.items():
+        if k.startswith("buf."):
+            assert max_rel_to_scale(bufs[k[4:]], v) < 1e-2, k
+    iou = O.iou(outs["segment_preds"], torch.from_numpy(g["segment_preds"]))
+    # random-weight probabilities sit close to the 0.5 threshold, so IoU is judged against what the fp16 emulation loses
+    iou_sim = O.iou(sim["segment_preds"], torch.from_numpy(g["segment_preds"]))
+    assert float(iou.min()) > min(0.99, float(iou_sim.min()) - 0.02), (iou, iou_sim)
+    print(case, {k: f"{v:.1e}" for k, v in worst.items()}, "IoU vs ref", float(iou.min()))
+
+
+def run_oracle_fp16_sim(g):
+    with fp16_storage_sim():
+        return run_oracle(g)
+
+
+@pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_pspnet_it1", "e2e_pspnet_it10001", "e2e_pspnet_it40000_dropout"])
+def test_gradients_match_oracle(case):
+    """Per-parameter relative L2 error of the HIP gradients vs the fp32 oracle.
+
+    SR-only phases (iter < 30001): direct bound.  Joint phase: at this fixture size (HR 64x64, B=2: BatchNorm over
+    128..8192 values, random weights) the segmentation gradient is chaotic -- ANY fp16-storage evaluation of the
+    reference arithmetic lands 5 % (last layers) to 35 % (first layers, KBPN) away from fp32, which the CPU emulation
+    in golden_utils.fp16_storage_sim reproduces layer by layer (measured: emulation median 0.30, HIP median 0.28).
+    So there the HIP error is bounded by the emulation's error per tensor, and the backward kernels themselves are
+    pinned tightly in test_conv_kernels_gpu.py / test_elementwise_gpu.py."""
+    g = load_golden(case)
+    outs, grads, _ = run_hip(g)
+    P, out, loss = run_oracle(g)
+    it = int(g["it"])
+    joint = it >= 30001
+    Ps = run_oracle_fp16_sim(g)[0] if joint else None
+    errs, sims, bad = [], [], []
+    names = [str(n) for n in g["grad_names"]]
+    for n, ref_norm in zip(names, g["grad_norms"]):
+        hip = grads[n]
+        if ref_norm < 0:                       # reference: grad None (frozen / unused in this phase)
+            assert hip is None or float(hip.abs().max()) == 0.0, n
+            continue
+        og = P[n].grad
+        if ref_norm < 1e-7:
+            assert hip is None or float(hip.norm()) < 1e-5, n
+            continue
+        assert hip is not None, n
+        if og.numel() == 1:
+            # PReLU slope = signed sum over ~1e6 products; fp32 orders already differ by 10 % (test_oracle_golden.py)
+            tol = 0.1 * abs(float(og)) + 2e-3
+            if joint:
+                tol += 2.0 * abs(float(Ps[n].grad) - float(og)) + 0.3 * abs(float(og)) + 5e-3
+            assert abs(float(hip) - float(og)) <= tol, (n, float(hip), float(og))
+            continue
+        e = rel_err(hip, og)
+        errs.append(e)
+        if joint:
+            es = rel_err(Ps[n].grad, og)
+            sims.append(es)
+            if e > 2.0 * es + 3e-2:
+                bad.append((n, e, es))
+        elif e > 3e-2:
+            bad.append((n, e))
+    errs = np.array(errs)
+    print(case, "grad rel-L2 vs fp32 oracle: median %.2e  p90 %.2e  max %.2e  (n=%d)" % (np.median(errs), np.percentile(errs, 90), errs.max(), len(errs)))
+    assert not bad, bad[:10]
+    if joint:
+        sims = np.array(sims)
+        print(case, "fp16-storage emulation of the oracle: median %.2e  p90 %.2e  max %.2e" % (np.median(sims), np.percentile(sims, 90), sims.max()))
+        assert np.median(errs) < 1.5 * np.median(sims) + 5e-3
+    else:
+        assert np.median(errs) < 5e-3
+
+
+def test_micro_batching_is_exact():
+    """KBPN has no batch-coupled op: micro-batch 1 (forward recomputed inside backward) == whole batch resident.
+    The SR output is identical up to fp32 atomics order in the GAP sums; everything downstream of the fp16 BatchNorm
+    stack moves within the fp16 noise floor (see above)."""
+    g = load_golden("e2e_pspnet_it1")
+    o1, g1, _ = run_hip(g, micro_batch=1)
+    o2, g2, _ = run_hip(g, micro_batch=8)
+    assert max_rel_to_scale(o1["sr_preds"], o2["sr_preds"]) < 1e-4
+    assert max_rel_to_scale(o1["sr_loss"], o2["sr_loss"]) < 1e-4
+    worst = max(rel_err(g1[k], g2[k]) for k in g1 if g1[k] is not None and g1[k].numel() > 1)
+    assert worst < 5e-3, worst
