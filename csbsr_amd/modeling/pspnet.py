@@ -188,6 +188,7 @@ class PSPNet:
             draw = up.bn.backward(d, raw, m, iv, act=L.ACT_PRELU, prelu=self.up_prelu[j], drop=drop[names[j]] if j == 2 else None,
                                   dprelu=grad_acc(self.up_prelu[j]))
             up.conv.bwd_weights(draw, u)
+            grad_acc(up.conv.b)          # a conv bias feeding train-mode BN has an identically zero gradient (not None)
             du = up.conv.bwd_input(draw)
             d = e.new(B, cur.H, cur.W, cur.c)
             e.bilinear_bwd(du, d, False, False, drop=cur_drop)
