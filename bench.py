@@ -140,8 +140,8 @@ def main():
 
     roof = None
     if eng.timing:
-        conv = [(f, b, e0.elapsed_time(e1)) for kind, f, b, e0, e1 in eng.timing if kind == "conv"]
-        wg = [(f, b, e0.elapsed_time(e1)) for kind, f, b, e0, e1 in eng.timing if kind == "wgrad"]
+        conv = [(t[1], t[2], t[3].elapsed_time(t[4])) for t in eng.timing if t[0] == "conv"]
+        wg = [(t[1], t[2], t[3].elapsed_time(t[4])) for t in eng.timing if t[0] == "wgrad"]
         cf, ct = sum(c[0] for c in conv), sum(c[2] for c in conv) * 1e-3
         wf, wt = sum(c[0] for c in wg), sum(c[2] for c in wg) * 1e-3
         ach = cf / ct / 1e12

@@ -235,7 +235,7 @@ class Conv:
             taps = k * k if not transposed else ((k + stride - 1) // stride) ** 2
             flops = 2.0 * npx * cout * ctot * taps
             nbytes = 2.0 * (sum(0 if f.bcast else f.N * f.H * f.W * f.c for f in xs) + (npx * cout if out is not None else 0))
-            tm.append(("conv", flops, nbytes, ev0, ev1))
+            tm.append(("conv", flops, nbytes, ev0, ev1, self.name, (x0.N, H, W, ctot, cout, k, stride, int(transposed))))
 
     def fwd(self, x, out=None, out32=None, res=None, res2=None, res_mode=L.RES_NONE, stat=None, stat_mode=L.STAT_NONE, store=True):
         xs = x if isinstance(x, (tuple, list)) else (x,)
@@ -309,7 +309,7 @@ class Conv:
             ev1.record()
             flops = 2.0 * a.N * a.H * a.W * a.c * sum(f.c for f in bs) * self.k * self.k
             nbytes = 2.0 * (a.N * a.H * a.W * a.c + sum(0 if f.bcast else f.N * f.H * f.W * f.c for f in bs))
-            tm.append(("wgrad", flops, nbytes, ev0, ev1))
+            tm.append(("wgrad", flops, nbytes, ev0, ev1, self.name, (a.N, a.H, a.W, a.c, sum(f.c for f in bs), self.k, self.stride, int(self.transposed))))
         gacc = grad_acc(self.w)
         A_real = self.w.shape[0]
         L.call("csbsr_unpack_wgrad", _ptr(g), _ptr(gacc), A_real, self.k, self.k, seg0, seg1, self.w.shape[0], self.w.shape[1], 0, 0,
