@@ -69,7 +69,8 @@ SIGNATURES = {
     "csbsr_debug_set_wgrad_tr": (None, [i32]),
     "csbsr_packed_weight_elems": (i64, [i32] * 9),
     "csbsr_pack_weights": (i32, [vp, vp] + [i32] * 11 + [vp]),
-    "csbsr_unpack_wgrad": (i32, [vp, vp] + [i32] * 9 + [f32, vp]),
+    "csbsr_unpack_wgrad": (i32, [vp, vp] + [i32] * 9 + [f32, i32, i32, vp]),
+    "csbsr_wgrad_splits": (i32, [i32, i32, i64]),
     "csbsr_epilogue_backward": (i32, [C.POINTER(EpiBwdDesc), vp]),
     "csbsr_axpby": (i32, [i64, i32, vp, i64, f32, vp, i64, f32, vp, i64, vp]),
     "csbsr_fill_f16": (i32, [vp, i64, i32, i64, f32, vp]),

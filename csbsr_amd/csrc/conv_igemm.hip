@@ -17,8 +17,8 @@
 #include "common.h"
 
 #define BM 128
-#define BK 32
-#define LDS_LD 40  // halves per LDS row: 32 + 8 pad (80 B)
+#define BK 64
+#define LDS_LD 72  // halves per LDS row: 64 + 8 pad (144 B): conflict-free 16-byte fragment reads
 
 struct ConvK {
   csbsr_seg_t in[2];
@@ -48,14 +48,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   constexpr int CW = BN / WC;      // couts per wave
   constexpr int TP = PW / 32;
   constexpr int TC = CW / 32;
-  constexpr int OUT_LD = BN + 4;   // fp32 staging row
-  constexpr int MAIN_BYTES = 2 * (BN + BM) * LDS_LD * 2;
+  constexpr int NH = BN == 128 ? 2 : 1;   // epilogue staged in NH halves of HB couts
+  constexpr int HB = BN / NH;
+  constexpr int OUT_LD = HB + 4;   // fp32 staging row
+  constexpr int MAIN_BYTES = (BN + BM) * LDS_LD * 2;
   constexpr int EPI_BYTES = BM * OUT_LD * 4;
   constexpr int SM_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   char* smem = smem_dyn;
-  half_t* sW = reinterpret_cast<half_t*>(smem);                       // [2][BN][LDS_LD]
-  half_t* sX = sW + 2 * BN * LDS_LD;                                  // [2][BM][LDS_LD]
+  half_t* sW = reinterpret_cast<half_t*>(smem);                       // [BN][LDS_LD]
+  half_t* sX = sW + BN * LDS_LD;                                      // [BM][LDS_LD]
   int* sRow = reinterpret_cast<int*>(smem + SM_BYTES);                // [BM][3]  n, oy, ox  (n = -1: invalid)
   float* sStat = reinterpret_cast<float*>(smem + SM_BYTES + BM * 3 * 4);  // [2][BN]
 
@@ -97,12 +99,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   if (tid < 2 * BN) sStat[tid] = 0.f;
   __syncthreads();
 
-  // ---- per-thread gather state: rows r0 = tid/4, r0+64 ; 16-byte k-segment seg = tid%4
-  const int seg = tid & 3;
-  int rn[2], riy[2], rix[2];
+  // ---- per-thread gather state: rows tid/8 + 32 j (j < 4); 16-byte k-segment seg = tid%8 (one K slice = 64 channels of one
+  // tap = a full 128-byte line per pixel)
+  constexpr int SEGS = BK / 8;                // 8
+  constexpr int RPP = 256 / SEGS;             // rows per pass: 32
+  constexpr int XCH = BM / RPP;               // 4 patch chunks per thread
+  const int seg = tid % SEGS;
+  int rn[XCH], riy[XCH], rix[XCH];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = (tid >> 2) + 64 * j;
+  for (int j = 0; j < XCH; ++j) {
+    const int r = tid / SEGS + RPP * j;
     rn[j] = sRow[r * 3];
     riy[j] = sRow[r * 3 + 1] * in_step + base_y;
     rix[j] = sRow[r * 3 + 2] * in_step + base_x;
@@ -111,15 +117,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   int kc = seg * 8, ky = 0, kx = 0;
   while (kc >= p.ctot) { kc -= p.ctot; if (++kx == p.KWt) { kx = 0; ++ky; } }
 
-  constexpr int WCH = (BN * 4 + 255) / 256;  // weight chunks per thread
-  h8 gx[2], gw[WCH];
+  constexpr int WCH = (BN * SEGS + 255) / 256;  // weight chunks per thread
+  h8 gx[XCH], gw[WCH];
 
   auto load_tile = [&](int kt) {
     // weights
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
       const int c = tid + 256 * i;
-      const int row = c >> 2, sg = c & 3;
+      const int row = c / SEGS, sg = c % SEGS;
       h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       if (row < BN && cout0 + row < p.rows_p)
         v = *reinterpret_cast<const h8*>(wt + (size_t)(cout0 + row) * p.Kp + kt * BK + sg * 8);
@@ -130,9 +136,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     const csbsr_seg_t& sgm = (kc < p.c0) ? p.in[0] : p.in[1];
     const int cc = (kc < p.c0) ? kc : kc - p.c0;
     const half_t* base = reinterpret_cast<const half_t*>(sgm.ptr) + cc;
+    const int dy = ky * tap_step, dx = kx * tap_step;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int iy = riy[j] + ky * tap_step, ix = rix[j] + kx * tap_step;
+    for (int j = 0; j < XCH; ++j) {
+      const int iy = riy[j] + dy, ix = rix[j] + dx;
       h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       if (kvalid && rn[j] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
         v = *reinterpret_cast<const h8*>(base + rn[j] * sgm.sn + iy * sgm.sy + ix * sgm.sx);
@@ -142,18 +149,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     kc += BK;
     while (kc >= p.ctot) { kc -= p.ctot; if (++kx == p.KWt) { kx = 0; ++ky; } }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
       const int c = tid + 256 * i;
-      const int row = c >> 2, sg = c & 3;
-      if (row < BN) *reinterpret_cast<h8*>(sW + (buf * BN + row) * LDS_LD + sg * 8) = gw[i];
+      const int row = c / SEGS, sg = c % SEGS;
+      if (row < BN) *reinterpret_cast<h8*>(sW + row * LDS_LD + sg * 8) = gw[i];
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = (tid >> 2) + 64 * j;
-      *reinterpret_cast<h8*>(sX + (buf * BM + r) * LDS_LD + seg * 8) = gx[j];
-    }
+    for (int j = 0; j < XCH; ++j) *reinterpret_cast<h8*>(sX + (tid / SEGS + RPP * j) * LDS_LD + seg * 8) = gx[j];
   };
 
   f16v acc[TC][TP];
@@ -164,15 +168,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  // single LDS buffer + register prefetch: the next slice's HBM loads fly under this slice's 16 MFMAs per wave
   const int nkt = p.Kp / BK;
+  const half_t* w_base = sW + (wc * CW + (lane & 31)) * LDS_LD + (lane >> 5) * 8;
+  const half_t* x_base = sX + (wp * PW + (lane & 31)) * LDS_LD + (lane >> 5) * 8;
   load_tile(0);
-  store_tile(0);
-  __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
+    if (kt > 0) __syncthreads();              // previous slice's fragment reads done
+    store_tile();
+    __syncthreads();
     if (kt + 1 < nkt) load_tile(kt + 1);
-    const half_t* w_base = sW + (buf * BN + wc * CW + (lane & 31)) * LDS_LD + (lane >> 5) * 8;
-    const half_t* x_base = sX + (buf * BM + wp * PW + (lane & 31)) * LDS_LD + (lane >> 5) * 8;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       h8 af[TC], bf[TP];
@@ -185,36 +190,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
         for (int b = 0; b < TP; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
-    __syncthreads();
   }
-
-  // ---- epilogue: fp32 tile -> LDS [pixel][cout], then channel-contiguous 8-wide processing
-  float* sO = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int a = 0; a < TC; ++a)
-#pragma unroll
-    for (int b = 0; b < TP; ++b) {
-      const int pix = wp * PW + b * 32 + (lane & 31);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = wc * CW + a * 32 + 8 * q + 4 * (lane >> 5);
-        f4 v = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-        *reinterpret_cast<f4*>(sO + pix * OUT_LD + co) = v;
-      }
-    }
   __syncthreads();
 
+  // ---- epilogue: fp32 tile -> LDS [pixel][cout] in halves of HB couts (keeps LDS <= the main-loop footprint so three
+  // workgroups fit per CU), then channel-contiguous 8-wide processing
+  float* sO = reinterpret_cast<float*>(smem);
   const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
-  constexpr int CPR = BN / 8;                 // 8-channel chunks per row
-  const int cc8 = tid % CPR;                  // fixed per thread (256 % CPR == 0)
-  const int co = cout0 + cc8 * 8;
-  float bias[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f;
-  float ssum[8], ssq[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
   const int n_first = sRow[0];
   int n_last = n_first;
   {
@@ -222,81 +204,118 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     n_last = (int)(ml / ((long)OHp * OWp));
   }
   const bool uniform_n = (n_first == n_last);
-  int cur_n = -1;
+  constexpr int CPR = HB / 8;                 // 8-channel chunks per staged row
+  const int cc8 = tid % CPR;                  // fixed per thread (256 % CPR == 0)
 
-  for (int row = tid / CPR; row < BM; row += 256 / CPR) {
-    const int n = sRow[row * 3];
-    if (n < 0 || co >= p.coutp) continue;
-    const int oy = py + sRow[row * 3 + 1] * o_step, ox = px + sRow[row * 3 + 2] * o_step;
-    float v[8];
-    const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
-    const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
-    v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+#pragma unroll 1
+  for (int hh = 0; hh < NH; ++hh) {
+    if (hh > 0) __syncthreads();              // previous half fully consumed
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t = v[e] * p.out_scale + bias[e];
-      t = apply_act(t, p.act, slope);
-      v[e] = (co + e < p.cout) ? t : 0.f;
-    }
-    if (p.stat_mode == CSBSR_STAT_BN) {
+    for (int a = 0; a < TC; ++a) {
+      const int cbase = wc * CW + a * 32;     // wave-uniform
+      if (cbase / HB != hh) continue;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
-    } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM) {
-      if (!uniform_n && n != cur_n) {
-        if (cur_n >= 0)
+      for (int b = 0; b < TP; ++b) {
+        const int pix = wp * PW + b * 32 + (lane & 31);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { atomicAdd(p.stat + (size_t)cur_n * p.coutp + co + e, ssum[e]); ssum[e] = 0.f; }
-        cur_n = n;
+        for (int q = 0; q < 4; ++q) {
+          const int cl = cbase - hh * HB + 8 * q + 4 * (lane >> 5);
+          f4 v = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+          *reinterpret_cast<f4*>(sO + pix * OUT_LD + cl) = v;
+        }
       }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ssum[e] += v[e];
     }
-    if (p.res_mode != CSBSR_RES_NONE) {
-      const h8 r = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
-      h8 r2 = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (p.res_mode == CSBSR_RES_FMA) r2 = *reinterpret_cast<const h8*>(p.res2 + n * p.r2_sn + oy * p.r2_sy + ox * p.r2_sx + co);
+    __syncthreads();
+
+    const int co = cout0 + hh * HB + cc8 * 8;
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f;
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
+    int cur_n = -1;
+
+    for (int row = tid / CPR; row < BM; row += 256 / CPR) {
+      const int n = sRow[row * 3];
+      if (n < 0 || co >= p.coutp) continue;
+      const int oy = py + sRow[row * 3 + 1] * o_step, ox = px + sRow[row * 3 + 2] * o_step;
+      float v[8];
+      const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
+      const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
+      v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float rv = (float)r[e];
-        switch (p.res_mode) {
-          case CSBSR_RES_ADD: v[e] += rv; break;
-          case CSBSR_RES_SUB: v[e] -= rv; break;
-          case CSBSR_RES_MUL: v[e] *= rv; break;
-          default: v[e] += rv * (float)r2[e]; break;
+        float t = v[e] * p.out_scale + bias[e];
+        t = apply_act(t, p.act, slope);
+        v[e] = (co + e < p.cout) ? t : 0.f;
+      }
+      if (p.stat_mode == CSBSR_STAT_BN) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+      } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM) {
+        if (!uniform_n && n != cur_n) {
+          if (cur_n >= 0)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { atomicAdd(p.stat + (size_t)cur_n * p.coutp + co + e, ssum[e]); ssum[e] = 0.f; }
+          cur_n = n;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ssum[e] += v[e];
+      }
+      if (p.res_mode != CSBSR_RES_NONE) {
+        const h8 r = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
+        h8 r2 = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.res_mode == CSBSR_RES_FMA) r2 = *reinterpret_cast<const h8*>(p.res2 + n * p.r2_sn + oy * p.r2_sy + ox * p.r2_sx + co);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float rv = (float)r[e];
+          switch (p.res_mode) {
+            case CSBSR_RES_ADD: v[e] += rv; break;
+            case CSBSR_RES_SUB: v[e] -= rv; break;
+            case CSBSR_RES_MUL: v[e] *= rv; break;
+            default: v[e] += rv * (float)r2[e]; break;
+          }
         }
       }
-    }
-    if (p.out16) {
-      half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
-      if (p.accumulate) {
-        const h8 old = *reinterpret_cast<const h8*>(o);
+      if (p.out16) {
+        half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
+        if (p.accumulate) {
+          const h8 old = *reinterpret_cast<const h8*>(o);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
-      }
-      h8 hv;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-      *reinterpret_cast<h8*>(o) = hv;
-    }
-    if (p.out32) {
-      float* o = p.out32 + n * p.o32_sn + oy * p.o32_sy + ox * p.o32_sx;
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (co + e < p.cout) {
-          float* q = o + (co + e) * p.o32_sc;
-          *q = (p.accumulate && !p.out16) ? *q + v[e] : v[e];
+          for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
         }
+        h8 hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
+        *reinterpret_cast<h8*>(o) = hv;
+      }
+      if (p.out32) {
+        float* o = p.out32 + n * p.o32_sn + oy * p.o32_sy + ox * p.o32_sx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (co + e < p.cout) {
+            float* q = o + (co + e) * p.o32_sc;
+            *q = (p.accumulate && !p.out16) ? *q + v[e] : v[e];
+          }
+      }
+    }
+
+    if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
+      if (co < p.coutp) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          atomicAdd(&sStat[hh * HB + cc8 * 8 + e], ssum[e]);
+          if (p.stat_mode == CSBSR_STAT_BN) atomicAdd(&sStat[BN + hh * HB + cc8 * 8 + e], ssq[e]);
+        }
+      }
+    } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && cur_n >= 0 && co < p.coutp) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(p.stat + (size_t)cur_n * p.coutp + co + e, ssum[e]);
     }
   }
 
   if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
-    if (co < p.coutp) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(&sStat[cc8 * 8 + e], ssum[e]);
-        if (p.stat_mode == CSBSR_STAT_BN) atomicAdd(&sStat[BN + cc8 * 8 + e], ssq[e]);
-      }
-    }
     __syncthreads();
     if (tid < BN && cout0 + tid < p.coutp) {
       if (p.stat_mode == CSBSR_STAT_BN) {
@@ -306,9 +325,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         atomicAdd(p.stat + (size_t)n_first * p.coutp + cout0 + tid, sStat[tid]);
       }
     }
-  } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && cur_n >= 0 && co < p.coutp) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(p.stat + (size_t)cur_n * p.coutp + co + e, ssum[e]);
   }
 }
 
@@ -317,8 +333,8 @@ static int launch_conv(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   ConvK p = k;
   p.tiles_m = (unsigned)((maxM + BM - 1) / BM);
   p.tiles_n = (unsigned)((k.coutp + BN - 1) / BN);
-  constexpr int OUT_LD = BN + 4;
-  constexpr int MAIN_BYTES = 2 * (BN + BM) * LDS_LD * 2;
+  constexpr int OUT_LD = (BN == 128 ? 64 : BN) + 4;
+  constexpr int MAIN_BYTES = (BN + BM) * LDS_LD * 2;
   constexpr int EPI_BYTES = BM * OUT_LD * 4;
   constexpr int SM_BYTES = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + BM * 3 * 4 + 2 * BN * 4;
   static bool attr_set = false;

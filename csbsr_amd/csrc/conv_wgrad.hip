@@ -9,7 +9,7 @@
 // Autograd wgrad of F.conv2d / F.conv_transpose2d at the call sites listed in conv_igemm.hip.
 #include "common.h"
 
-#define WG_BP 32     // pixels per reduction step
+#define WG_BP 64     // pixels per reduction step
 #define WG_BN 128    // columns (tap,channel) per tile
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   constexpr int AW_ = BA / WA;          // a-rows per wave
   constexpr int BW_ = WG_BN / WB;       // cols per wave
   constexpr int TA = AW_ / 32, TB = BW_ / 32;
-  constexpr int LDA = BA + 8, LDB = WG_BN + 8;
+  constexpr int LDA = BA + 32, LDB = WG_BN + 32;   // row stride = 16 dwords mod 64: conflict-free ds_read_b64_tr_b16
   __shared__ __attribute__((aligned(16))) half_t sA[WG_BP * LDA];
   __shared__ __attribute__((aligned(16))) half_t sB[WG_BP * LDB];
 
@@ -66,33 +66,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   if (mend > p.M) mend = p.M;
   if (mbeg >= mend) return;
 
-  // ---- B staging role: chunk ids tid, tid+256 : pixel = id/16, col chunk = id%16
-  int b_pix[2], b_ky[2], b_kx[2];
-  const half_t* b_ptr[2];
-  long b_sn[2], b_sy[2], b_sx[2];
-  bool b_ok[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int id = tid + 256 * j;
-    b_pix[j] = id >> 4;
-    const int col = col0 + (id & 15) * 8;
-    b_ok[j] = col < p.ktot;
-    const int tap = b_ok[j] ? col / p.cbtot : 0;
-    const int c = b_ok[j] ? col - tap * p.cbtot : 0;
-    b_ky[j] = (tap / p.KW) * p.dil - p.pad;
-    b_kx[j] = (tap % p.KW) * p.dil - p.pad;
+  // ---- B staging role: chunk ids tid + 256*j : pixel = id/16, col chunk = id%16
+  constexpr int B_ITERS = WG_BP * 16 / 256;
+  int b_ky, b_kx;
+  const half_t* b_ptr;
+  long b_sn, b_sy, b_sx;
+  bool b_ok;
+  {
+    const int col = col0 + (tid & 15) * 8;      // the column chunk is the same for every j (256 % 16 == 0)
+    b_ok = col < p.ktot;
+    const int tap = b_ok ? col / p.cbtot : 0;
+    const int c = b_ok ? col - tap * p.cbtot : 0;
+    b_ky = (tap / p.KW) * p.dil - p.pad;
+    b_kx = (tap % p.KW) * p.dil - p.pad;
     const csbsr_seg_t& sg = c < p.cb0 ? p.b[0] : p.b[1];
-    b_ptr[j] = reinterpret_cast<const half_t*>(sg.ptr) + (c < p.cb0 ? c : c - p.cb0);
-    b_sn[j] = sg.sn; b_sy[j] = sg.sy; b_sx[j] = sg.sx;
+    b_ptr = reinterpret_cast<const half_t*>(sg.ptr) + (c < p.cb0 ? c : c - p.cb0);
+    b_sn = sg.sn; b_sy = sg.sy; b_sx = sg.sx;
   }
   // ---- A staging role: BA/8 chunks per pixel
   constexpr int ACH = BA / 8;
-  constexpr int A_ITERS = (WG_BP * ACH + 255) / 256;
+  constexpr int A_ITERS = WG_BP * ACH / 256;
 
-  // running pixel coordinate of local pixel 0 of the current step
-  int n0 = (int)(mbeg / ((long)p.AH * p.AW));
-  int rem0 = (int)(mbeg - (long)n0 * p.AH * p.AW);
-  int y0 = rem0 / p.AW, x0 = rem0 - y0 * p.AW;
+  // per-thread running pixel coordinates (no integer division in the loop): B chunk j covers pixel (tid>>4) + 16 j,
+  // A chunk i covers pixel tid/ACH + (256/ACH) i of the step being LOADED
+  struct Pix { int n, y, x; };
+  auto init_pix = [&](long m) {
+    Pix c;
+    c.n = (int)(m / ((long)p.AH * p.AW));
+    const int rem = (int)(m - (long)c.n * p.AH * p.AW);
+    c.y = rem / p.AW; c.x = rem - c.y * p.AW;
+    return c;
+  };
+  auto advance = [&](Pix& c, int d) {
+    c.x += d;
+    while (c.x >= p.AW) { c.x -= p.AW; if (++c.y == p.AH) { c.y = 0; ++c.n; } }
+  };
+  constexpr int A_DELTA = 256 / ACH;
+  Pix cb = init_pix(mbeg + (tid >> 4));
+  Pix ca_ = init_pix(mbeg + tid / ACH);
 
   f16v acc[TA][TB];
 #pragma unroll
@@ -102,53 +113,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  auto coord = [&](int dp, int& n, int& y, int& x) {
-    // (n0,y0,x0) + dp pixels
-    long xx = (long)x0 + dp;
-    long yy = y0 + xx / p.AW;
-    x = (int)(xx % p.AW);
-    n = n0 + (int)(yy / p.AH);
-    y = (int)(yy % p.AH);
-  };
-
-  for (long m = mbeg; m < mend; m += WG_BP) {
-    // global -> registers
-    h8 gb[2], ga[A_ITERS];
+  h8 gb[B_ITERS], ga[A_ITERS];
+  const int a_ch = (tid % ACH) * 8;
+  auto issue_loads = [&](long m) {     // global -> registers for the step starting at pixel m, then advance the coordinates
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < B_ITERS; ++j) {
+      const int pix = (tid >> 4) + 16 * j;
       h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (b_ok[j] && m + b_pix[j] < mend) {
-        int n, y, x; coord(b_pix[j], n, y, x);
-        const int by = y * p.stride + b_ky[j], bx = x * p.stride + b_kx[j];
+      if (b_ok && m + pix < mend) {
+        const int by = cb.y * p.stride + b_ky, bx = cb.x * p.stride + b_kx;
         if ((unsigned)by < (unsigned)p.BH && (unsigned)bx < (unsigned)p.BW)
-          v = *reinterpret_cast<const h8*>(b_ptr[j] + n * b_sn[j] + by * b_sy[j] + bx * b_sx[j]);
+          v = *reinterpret_cast<const h8*>(b_ptr + cb.n * b_sn + by * b_sy + bx * b_sx);
       }
       gb[j] = v;
+      advance(cb, 16);
     }
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
-      const int id = tid + 256 * i;
-      const int pix = id / ACH, ch = (id % ACH) * 8;
+      const int pix = tid / ACH + A_DELTA * i;
       h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (pix < WG_BP && m + pix < mend && a0 + ch < p.ca) {
-        int n, y, x; coord(pix, n, y, x);
-        v = *reinterpret_cast<const h8*>(p.a + n * p.a_sn + y * p.a_sy + x * p.a_sx + a0 + ch);
-      }
+      if (m + pix < mend && a0 + a_ch < p.ca)
+        v = *reinterpret_cast<const h8*>(p.a + ca_.n * p.a_sn + ca_.y * p.a_sy + ca_.x * p.a_sx + a0 + a_ch);
       ga[i] = v;
+      advance(ca_, A_DELTA);
     }
+  };
+
+  issue_loads(mbeg);
+  for (long m = mbeg; m < mend; m += WG_BP) {
     __syncthreads();   // previous step's fragment reads done
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < B_ITERS; ++j) {
       const int id = tid + 256 * j;
       *reinterpret_cast<h8*>(sB + (id >> 4) * LDB + (id & 15) * 8) = gb[j];
     }
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i) {
-      const int id = tid + 256 * i;
-      const int pix = id / ACH, ch = (id % ACH) * 8;
-      if (pix < WG_BP) *reinterpret_cast<h8*>(sA + pix * LDA + ch) = ga[i];
-    }
+    for (int i = 0; i < A_ITERS; ++i) *reinterpret_cast<h8*>(sA + (tid / ACH + A_DELTA * i) * LDA + a_ch) = ga[i];
     __syncthreads();
+    if (m + WG_BP < mend) issue_loads(m + WG_BP);     // next step's HBM loads fly under this step's MFMAs
 #pragma unroll
     for (int ks = 0; ks < WG_BP / 16; ++ks) {
       const int pix0 = ks * 16 + (lane >> 5) * 8;
@@ -162,18 +164,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
 #pragma unroll
         for (int b = 0; b < TB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
-    // advance running coordinate
-    {
-      long xx = (long)x0 + WG_BP;
-      long yy = y0 + xx / p.AW;
-      x0 = (int)(xx % p.AW);
-      n0 += (int)(yy / p.AH);
-      y0 = (int)(yy % p.AH);
-    }
   }
 
   // ---- epilogue: D[a][col], lane: col = lane%32, rows (r&3)+8*(r>>2)+4*(lane>>5)
-  const bool single = gridDim.z == 1;
+  // every (row < ca, col < ktot) element of this split's slab is written exactly once: no atomics, no zero-fill;
+  // csbsr_unpack_wgrad sums the slabs
+  float* slab = p.g + (size_t)blockIdx.z * p.ca * p.ktot;
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -184,9 +180,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
       for (int r = 0; r < 16; ++r) {
         const int row = a0 + wa * AW_ + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= p.ca) continue;
-        float* dst = p.g + (size_t)row * p.ktot + col;
-        if (single) *dst += acc[a][b][r];
-        else atomicAdd(dst, acc[a][b][r]);
+        slab[(size_t)row * p.ktot + col] = acc[a][b][r];
       }
     }
 }
@@ -194,21 +188,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
 static int g_wgrad_use_tr = 1;
 extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v; }
 
+static int wgrad_tile_a(int ca) { return ca > 64 ? 128 : (ca > 32 ? 64 : 32); }
+
+// number of pixel-range splits (= fp32 slabs the caller must provide) for a problem
+extern "C" int32_t csbsr_wgrad_splits(int32_t ca, int32_t ktot, int64_t M) {
+  const int BA = wgrad_tile_a(ca);
+  const long ntile = (long)((ca + BA - 1) / BA) * ((ktot + WG_BN - 1) / WG_BN);
+  long want = (1536 + ntile - 1) / ntile;
+  long maxs = (M + WG_BP * 8 - 1) / (WG_BP * 8);
+  long splits = want < maxs ? want : maxs;
+  const long slab_bytes = (long)ca * ktot * 4;
+  const long cap = (192L << 20) / (slab_bytes > 0 ? slab_bytes : 1);      // keep the slab workspace under 192 MiB
+  if (splits > cap) splits = cap;
+  if (splits > 1024) splits = 1024;
+  if (splits < 1) splits = 1;
+  const long per_split = ((M + splits - 1) / splits + WG_BP - 1) / WG_BP * WG_BP;
+  return (int32_t)((M + per_split - 1) / per_split);
+}
+
 template <int BA, int WA, int WB>
 static int launch_wgrad(const WgradK& k, int splits, hipStream_t st) {
   WgradK p = k;
   p.tiles_a = (unsigned)((k.ca + BA - 1) / BA);
   p.tiles_b = (unsigned)((k.ktot + WG_BN - 1) / WG_BN);
   const unsigned ntile = p.tiles_a * p.tiles_b;
-  if (splits <= 0) {
-    long want = (2048 + ntile - 1) / ntile;
-    long maxs = (k.M + 32 * 16 - 1) / (32 * 16);
-    splits = (int)(want < maxs ? want : maxs);
-    if (splits < 1) splits = 1;
-    if (splits > 1024) splits = 1024;
-  }
   p.per_split = ((k.M + splits - 1) / splits + WG_BP - 1) / WG_BP * WG_BP;
-  splits = (int)((k.M + p.per_split - 1) / p.per_split);
+  if ((int)((k.M + p.per_split - 1) / p.per_split) != splits) {
+    csbsr_set_error("wgrad: splits=%d leaves an empty slab; use csbsr_wgrad_splits()", splits);
+    return 1;
+  }
   dim3 grid(ntile, 1, splits);
   if (g_wgrad_use_tr)
     hipLaunchKernelGGL((conv_wgrad_kernel<BA, WA, WB, true>), grid, dim3(256), 0, st, p);
@@ -231,6 +239,7 @@ extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
   k.g = d->g; k.ktot = d->KH * d->KW * k.cbtot;
   k.M = (long)d->N * d->AH * d->AW;
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  CSBSR_CHECK(d->splits >= 1, "wgrad: splits must come from csbsr_wgrad_splits()");
   if (d->ca > 64) return launch_wgrad<128, 2, 2>(k, d->splits, st);
   if (d->ca > 32) return launch_wgrad<64, 2, 2>(k, d->splits, st);
   return launch_wgrad<32, 1, 4>(k, d->splits, st);

@@ -661,11 +661,55 @@ __global__ void aap_bwd_kernel(const half_t* dy, half_t* dx, long dx_ld, int acc
     *reinterpret_cast<h8*>(q) = o;
   }
 }
+// large bins (PSP priors 1,2,3,6 over a 224^2 map): one workgroup per (sample, bin, 64-channel group);
+// 8 channel-chunk lanes x 32 pixel lanes, LDS tree over the pixel lanes
+__global__ __launch_bounds__(256) void aap_fwd_block_kernel(const half_t* x, long x_ld, half_t* y, int N, int H, int W, int c8, int OH, int OW) {
+  __shared__ float sred[32][8][8];
+  const int groups = (c8 + 7) / 8;
+  int b = blockIdx.x;
+  const int g = b % groups; b /= groups;
+  const int ox = b % OW; b /= OW;
+  const int oy = b % OH; const int n = b / OH;
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int cc = g * 8 + cl;
+  const int y0 = (oy * H) / OH, y1 = ((oy + 1) * H + OH - 1) / OH;
+  const int x0 = (ox * W) / OW, x1 = ((ox + 1) * W + OW - 1) / OW;
+  const int bw = x1 - x0, cnt = (y1 - y0) * bw;
+  float a[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = 0.f;
+  if (cc < c8)
+    for (int i = pl; i < cnt; i += 32) {
+      const int iy = y0 + i / bw, ix = x0 + i % bw;
+      const h8 v = *reinterpret_cast<const h8*>(x + (((long)n * H + iy) * W + ix) * x_ld + cc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sred[pl][cl][e] = a[e];
+  __syncthreads();
+  if (pl == 0 && cc < c8) {
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s_ = 0.f;
+      for (int q = 0; q < 32; ++q) s_ += sred[q][cl][e];
+      o[e] = (half_t)(s_ / cnt);
+    }
+    *reinterpret_cast<h8*>(y + ((((long)n * OH + oy) * OW + ox) * c8 + cc) * 8) = o;
+  }
+}
 extern "C" int csbsr_adaptive_avgpool_fwd(const void* x, int64_t x_ld, void* y, int32_t N, int32_t H, int32_t W, int32_t c,
                                           int32_t OH, int32_t OW, csbsr_stream_t s) {
   CSBSR_CHECK(x && y && c % 8 == 0, "aap_fwd: bad args");
-  hipLaunchKernelGGL(aap_fwd_kernel, dim3(grid_for((long)N * OH * OW * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x, x_ld, (half_t*)y,
-                     N, H, W, c / 8, OH, OW);
+  if ((long)(H / OH) * (W / OW) >= 64) {
+    const int groups = (c / 8 + 7) / 8;
+    hipLaunchKernelGGL(aap_fwd_block_kernel, dim3(N * OH * OW * groups), dim3(256), 0, ST(s), (const half_t*)x, x_ld, (half_t*)y, N, H, W,
+                       c / 8, OH, OW);
+  } else {
+    hipLaunchKernelGGL(aap_fwd_kernel, dim3(grid_for((long)N * OH * OW * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x, x_ld, (half_t*)y,
+                       N, H, W, c / 8, OH, OW);
+  }
   CSBSR_LAUNCH_CHECK("csbsr_adaptive_avgpool_fwd");
   return 0;
 }
@@ -771,12 +815,77 @@ extern "C" int csbsr_bilinear_fwd(const void* x, int64_t x_ld, void* y, int64_t 
   CSBSR_LAUNCH_CHECK("csbsr_bilinear_fwd");
   return 0;
 }
+// large up-sampling ratios (PSP priors): the adjoint window of one input pixel spans thousands of outputs --
+// one workgroup per (sample, input pixel, 64-channel group), 32 window lanes, LDS tree
+__global__ __launch_bounds__(256) void bilinear_bwd_block_kernel(const half_t* dy, long dy_ld, half_t* dx, long dx_ld, int accumulate, int N,
+                                                                 int H, int W, int c8, int OH, int OW, int align, const float* drop, int cp) {
+  __shared__ float sred[32][8][8];
+  const int groups = (c8 + 7) / 8;
+  int b = blockIdx.x;
+  const int g = b % groups; b /= groups;
+  const int ix = b % W; b /= W;
+  const int iy = b % H; const int n = b / H;
+  const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int cc = g * 8 + cl;
+  const float ry = (align && H > 1) ? (float)(OH - 1) / (H - 1) : (float)OH / H, rx = (align && W > 1) ? (float)(OW - 1) / (W - 1) : (float)OW / W;
+  int oy_lo = (int)floorf((iy - 1.5f) * ry) - 2, oy_hi = (int)ceilf((iy + 1.5f) * ry) + 2;
+  int ox_lo = (int)floorf((ix - 1.5f) * rx) - 2, ox_hi = (int)ceilf((ix + 1.5f) * rx) + 2;
+  if (iy == 0) oy_lo = 0;
+  if (ix == 0) ox_lo = 0;
+  if (iy == H - 1) oy_hi = OH - 1;
+  if (ix == W - 1) ox_hi = OW - 1;
+  oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+  oy_hi = oy_hi > OH - 1 ? OH - 1 : oy_hi; ox_hi = ox_hi > OW - 1 ? OW - 1 : ox_hi;
+  const int ww = ox_hi - ox_lo + 1, cnt = (oy_hi - oy_lo + 1) * ww;
+  float a[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = 0.f;
+  if (cc < c8)
+    for (int i = pl; i < cnt; i += 32) {
+      const int oy = oy_lo + i / ww, ox = ox_lo + i % ww;
+      int y0, y1, x0, x1; float wy, wx;
+      bil_src(oy, H, OH, align, y0, y1, wy); bil_src(ox, W, OW, align, x0, x1, wx);
+      float cy = 0.f, cx = 0.f;
+      if (y0 == iy) cy += 1.f - wy;
+      if (y1 == iy) cy += wy;
+      if (x0 == ix) cx += 1.f - wx;
+      if (x1 == ix) cx += wx;
+      const float w_ = cy * cx;
+      if (w_ == 0.f) continue;
+      const h8 gv = *reinterpret_cast<const h8*>(dy + (((long)n * OH + oy) * OW + ox) * dy_ld + cc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += w_ * (float)gv[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sred[pl][cl][e] = a[e];
+  __syncthreads();
+  if (pl == 0 && cc < c8) {
+    half_t* q = dx + (((long)n * H + iy) * W + ix) * dx_ld + cc * 8;
+    h8 old = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (accumulate) old = *reinterpret_cast<const h8*>(q);
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s_ = 0.f;
+      for (int k = 0; k < 32; ++k) s_ += sred[k][cl][e];
+      if (drop) s_ *= drop[n * cp + cc * 8 + e];
+      o[e] = (half_t)(s_ + (float)old[e]);
+    }
+    *reinterpret_cast<h8*>(q) = o;
+  }
+}
 extern "C" int csbsr_bilinear_bwd(const void* dy, int64_t dy_ld, void* dx, int64_t dx_ld, int32_t accumulate, int32_t N, int32_t H,
                                   int32_t W, int32_t c, int32_t OH, int32_t OW, int32_t align_corners, const float* drop,
                                   csbsr_stream_t s) {
   CSBSR_CHECK(dy && dx && c % 8 == 0, "bilinear_bwd: bad args");
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), (const half_t*)dy, dy_ld,
-                     (half_t*)dx, dx_ld, accumulate, N, H, W, c / 8, OH, OW, align_corners, drop, c);
+  if ((long)(OH / H) * (OW / W) >= 64) {
+    const int groups = (c / 8 + 7) / 8;
+    hipLaunchKernelGGL(bilinear_bwd_block_kernel, dim3(N * H * W * groups), dim3(256), 0, ST(s), (const half_t*)dy, dy_ld, (half_t*)dx, dx_ld,
+                       accumulate, N, H, W, c / 8, OH, OW, align_corners, drop, c);
+  } else {
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), (const half_t*)dy, dy_ld,
+                       (half_t*)dx, dx_ld, accumulate, N, H, W, c / 8, OH, OW, align_corners, drop, c);
+  }
   CSBSR_LAUNCH_CHECK("csbsr_bilinear_bwd");
   return 0;
 }

@@ -55,7 +55,7 @@ static void pack_geometry(int kind, int D0, int D1, int KH, int KW, int stride, 
   p.KHt = kind == 2 ? (KH + stride - 1) / stride : KH;
   p.KWt = kind == 2 ? (KW + stride - 1) / stride : KW;
   p.nphase = kind == 2 ? stride * stride : 1;
-  p.Kp = round_up(p.KHt * p.KWt * p.segtot_p, 32);
+  p.Kp = round_up(p.KHt * p.KWt * p.segtot_p, 64);   // = BK of conv_igemm.hip
 }
 
 extern "C" int64_t csbsr_packed_weight_elems(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,
@@ -88,7 +88,8 @@ extern "C" int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32
 // G[a][tap][bpad]  ->  grad[a_off + a][b][kh][kw] += ...   (grad is [D0][D1][KH][KW]; a indexes D0 unless
 // transpose_ab, in which case a indexes D1 and b indexes D0)
 __global__ void unpack_wgrad_kernel(const float* g, float* grad, int A, int Breal, int KH, int KW, int seg0_real,
-                                    int seg0_p, int segtot_p, int D0, int D1, int transpose_ab, int b_off, float scale) {
+                                    int seg0_p, int segtot_p, int D0, int D1, int transpose_ab, int b_off, float scale, int splits,
+                                    long slab) {
   const long total = (long)A * Breal * KH * KW;
   const int ktot = KH * KW * segtot_p;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -98,7 +99,10 @@ __global__ void unpack_wgrad_kernel(const float* g, float* grad, int A, int Brea
     const int b = (int)(t % Breal);
     const int a = (int)(t / Breal);
     const int bp = b < seg0_real ? b : seg0_p + (b - seg0_real);
-    const float v = g[(long)a * ktot + (kh * KW + kw) * segtot_p + bp] * scale;
+    const long gi = (long)a * ktot + (kh * KW + kw) * segtot_p + bp;
+    float v = 0.f;
+    for (int sp = 0; sp < splits; ++sp) v += g[sp * slab + gi];     // sum the pixel-range slabs of csbsr_conv_wgrad
+    v *= scale;
     const int bb = b + b_off;
     const long di = transpose_ab ? ((((long)bb * D1 + a) * KH + kh) * KW + kw) : ((((long)a * D1 + bb) * KH + kh) * KW + kw);
     grad[di] += v;
@@ -107,7 +111,7 @@ __global__ void unpack_wgrad_kernel(const float* g, float* grad, int A, int Brea
 
 extern "C" int csbsr_unpack_wgrad(const float* g, float* grad, int32_t A, int32_t KH, int32_t KW, int32_t seg0_real,
                                   int32_t seg1_real, int32_t D0, int32_t D1, int32_t transpose_ab, int32_t b_off,
-                                  float scale, csbsr_stream_t s) {
+                                  float scale, int32_t splits, int32_t ca_padded, csbsr_stream_t s) {
   CSBSR_CHECK(g && grad, "unpack: null pointer");
   const int seg0_p = round_up(seg0_real, 8);
   const int segtot_p = seg0_p + (seg1_real > 0 ? round_up(seg1_real, 8) : 0);
@@ -116,7 +120,8 @@ extern "C" int csbsr_unpack_wgrad(const float* g, float* grad, int32_t A, int32_
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(s), g, grad, A,
-                     Breal, KH, KW, seg0_real, seg0_p, segtot_p, D0, D1, transpose_ab, b_off, scale);
+                     Breal, KH, KW, seg0_real, seg0_p, segtot_p, D0, D1, transpose_ab, b_off, scale, splits,
+                     (long)ca_padded * KH * KW * segtot_p);
   CSBSR_LAUNCH_CHECK("csbsr_unpack_wgrad");
   return 0;
 }

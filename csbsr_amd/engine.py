@@ -296,10 +296,10 @@ class Conv:
         d.N, d.AH, d.AW, d.BH, d.BW = a.N, a.H, a.W, bs[0].H, bs[0].W
         d.KH, d.KW, d.stride, d.pad, d.dil = self.k, self.k, self.stride, self.pad, self.dil
         cbtot = sum(f.cp for f in bs)
-        ng = a.cp * self.k * self.k * cbtot
-        g = self.eng.workspace(ng)[:ng]
-        g.zero_()
-        d.g, d.splits = _ptr(g), 0
+        ktot = self.k * self.k * cbtot
+        splits = L.load().csbsr_wgrad_splits(a.cp, ktot, a.N * a.H * a.W)
+        g = self.eng.workspace(splits * a.cp * ktot)
+        d.g, d.splits = _ptr(g), splits
         tm = self.eng.timing
         if tm is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -313,7 +313,7 @@ class Conv:
         gacc = grad_acc(self.w)
         A_real = self.w.shape[0]
         L.call("csbsr_unpack_wgrad", _ptr(g), _ptr(gacc), A_real, self.k, self.k, seg0, seg1, self.w.shape[0], self.w.shape[1], 0, 0,
-               1.0, self.eng.stream)
+               1.0, splits, a.cp, self.eng.stream)
 
 
 def grad_acc(p):

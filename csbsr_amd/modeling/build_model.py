@@ -118,6 +118,7 @@ class _JointBase(nn.Module):
                 _init_reference_style(full, t.data, gen)
         self._rt = None
         self.micro_batch = 1
+        self.max_resident = 5           # micro-batches whose KBPN activations stay in HBM for the backward (~30 GB each at LR 448)
         self.dropout_enabled = True
         self.dropout_masks = None     # tests may inject {name: [B,C] fp32} keep-masks
 
@@ -232,8 +233,13 @@ class JointModelWithLoss(_JointBase):
         sr32 = eng.f32(B, 3, H, W, zero=False)
         kvec = eng.f32(B, pc.ksize_out ** 2, zero=False)
         training = self.training
-        for b0 in range(0, B, mb):
-            s_, k_ = kbpn.forward(x[b0:b0 + mb], iter, kgt[b0:b0 + mb], save=single and training)
+        keep = training and torch.is_grad_enabled()
+        saves = []
+        for i, b0 in enumerate(range(0, B, mb)):
+            resident = keep and i < self.max_resident
+            s_, k_ = kbpn.forward(x[b0:b0 + mb], iter, kgt[b0:b0 + mb], save=resident)
+            saves.append(kbpn.saved if resident else None)
+            kbpn.saved = None
             sr32[b0:b0 + mb] = s_
             kvec[b0:b0 + mb] = k_
         xin, mean, invstd = self._norm_sr(sr32)
@@ -277,7 +283,7 @@ class JointModelWithLoss(_JointBase):
         sr_loss = pc.sr_w[0] * s_hr / (3 * hw) + pc.sr_w[1] * s_lr / (3 * h * w) + pc.sr_w[2] * k_l
         self._st = dict(iter=iter, x=x, hr=hr, mask=mask, kgt=kgt, sr32=sr32, kvec=kvec, ksum=ksum, vec=vec, mean=mean, invstd=invstd,
                         seg32=seg32, aux32=aux32, sdf=sdf, sums_m=sums_m, sums_a=sums_a, alpha=alpha, lr_pred=lr_pred, blurred=None,
-                        wmap=wmap, wmap_lr=wmap_lr, single=single, mb=mb, B=B, h=h, w=w)
+                        wmap=wmap, wmap_lr=wmap_lr, saves=saves, mb=mb, B=B, h=h, w=w)
         del blurred
         if torch.is_grad_enabled() and training:
             params = [p for p in self.parameters()]
@@ -346,9 +352,17 @@ class JointModelWithLoss(_JointBase):
             del dbl, dlr
         # ---- KBPN backward (per micro-batch; recompute the forward when it was not kept)
         mb = st["mb"]
-        for b0 in range(0, B, mb):
-            if not st["single"]:
-                kbpn.forward(st["x"][b0:b0 + mb], st["iter"], st["kgt"][b0:b0 + mb], save=True)
+        saves = st["saves"]
+        order = list(enumerate(range(0, B, mb)))
+        for i, b0 in reversed(order):         # resident micro-batches last-in first-out: frees HBM before the recomputed ones run
+            if saves[i] is None:
+                continue
+            kbpn.saved, saves[i] = saves[i], None
+            kbpn.backward(dsr32[b0:b0 + mb].contiguous(), dkvec[b0:b0 + mb].contiguous())
+        for i, b0 in order:                   # the rest: forward recomputed here (KBPN has no batch-coupled op: exact)
+            if i < self.max_resident:
+                continue
+            kbpn.forward(st["x"][b0:b0 + mb], st["iter"], st["kgt"][b0:b0 + mb], save=True)
             kbpn.backward(dsr32[b0:b0 + mb].contiguous(), dkvec[b0:b0 + mb].contiguous())
         self._st = None
         if self.reducer is not None:

