@@ -889,3 +889,79 @@ extern "C" int csbsr_bilinear_bwd(const void* dy, int64_t dy_ld, void* dx, int64
   CSBSR_LAUNCH_CHECK("csbsr_bilinear_bwd");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------- constant-operand folding
+// A zero-padded 3x3 convolution of a spatially constant map (kbpn.py:565-567: fe_kernel.0 applied to GAP(kernel).expand(HR))
+// takes only 16 distinct values per (sample, channel): one per border class (first/last row) x (first/last column).
+// class id = (y==0)*8 + (y==H-1)*4 + (x==0)*2 + (x==W-1).  fill: out[n,y,x,:] = V[n][class][:]
+__global__ void border_class_fill_kernel(const float* V, half_t* out, long ld, int N, int H, int W, int c8) {
+  const long total = (long)N * H * W * c8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8); long t = i / c8;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H); const int n = (int)(t / H);
+    const int cls = (y == 0) * 8 + (y == H - 1) * 4 + (x == 0) * 2 + (x == W - 1);
+    const float* v = V + ((long)n * 16 + cls) * c8 * 8 + cc * 8;
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+    *reinterpret_cast<h8*>(out + (((long)n * H + y) * W + x) * ld + cc * 8) = o;
+  }
+}
+// adjoint: sums[n][class][:] += sum over the pixels of that class of x[n,y,x,:]   (interior reduced per block, the
+// O(perimeter) border pixels go straight to atomics)
+__global__ __launch_bounds__(256) void border_class_sums_kernel(const half_t* x, long ld, float* sums, int H, int W, int c8, int chunks) {
+  __shared__ float sred[256][8];
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const int cpb = c8 < 256 ? c8 : 256, ppb = 256 / cpb;
+  const int ch = threadIdx.x % cpb, pl = threadIdx.x / cpb;
+  const long hw = (long)H * W;
+  const long per = (hw + chunks - 1) / chunks;
+  const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;
+  for (int cbase = 0; cbase < c8; cbase += cpb) {
+    const int cc = cbase + ch;
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    if (cc < c8 && pl < ppb)
+      for (long px = beg + pl; px < end; px += ppb) {
+        const int y = (int)(px / W), xx = (int)(px - (long)y * W);
+        const h8 v = *reinterpret_cast<const h8*>(x + ((long)n * hw + px) * ld + cc * 8);
+        const int cls = (y == 0) * 8 + (y == H - 1) * 4 + (xx == 0) * 2 + (xx == W - 1);
+        if (cls == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) atomicAdd(sums + ((long)n * 16 + cls) * c8 * 8 + cc * 8 + e, (float)v[e]);
+        }
+      }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sred[threadIdx.x][e] = a[e];
+    __syncthreads();
+    if (threadIdx.x < cpb && cbase + threadIdx.x < c8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float s_ = 0.f;
+        for (int q = 0; q < ppb; ++q) s_ += sred[q * cpb + threadIdx.x][e];
+        atomicAdd(sums + (long)n * 16 * c8 * 8 + (cbase + threadIdx.x) * 8 + e, s_);
+      }
+    }
+    __syncthreads();
+  }
+}
+extern "C" int csbsr_border_class_fill(const float* V, void* out, int64_t ld, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
+  CSBSR_CHECK(V && out && c % 8 == 0, "border_class_fill: bad args");
+  hipLaunchKernelGGL(border_class_fill_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), V, (half_t*)out, (long)ld, N, H, W, c / 8);
+  CSBSR_LAUNCH_CHECK("csbsr_border_class_fill");
+  return 0;
+}
+extern "C" int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
+  CSBSR_CHECK(x && sums && c % 8 == 0, "border_class_sums: bad args");
+  int chunks = (int)(((long)H * W + 16383) / 16384);
+  if (chunks < 1) chunks = 1;
+  if (chunks > 512) chunks = 512;
+  hipLaunchKernelGGL(border_class_sums_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, H, W, c / 8, chunks);
+  CSBSR_LAUNCH_CHECK("csbsr_border_class_sums");
+  return 0;
+}

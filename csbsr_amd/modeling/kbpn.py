@@ -82,6 +82,11 @@ class KBPN:
         self.U = up.reshape(kc, self.kk).t().contiguous().to(eng.device)       # [kk, kc]
         self.kc = kc
         self.saved = None
+        # border-class tap masks for the folded constant-operand conv: index = first*2 + last, entry [ky]
+        m = torch.ones(4, 3)
+        m[2, 0] = m[3, 0] = 0.0          # first row/col: tap 0 reads outside
+        m[1, 2] = m[3, 2] = 0.0          # last row/col: tap 2 reads outside
+        self.Mtap = m.to(eng.device)
 
     # ------------------------------------------------------------------ phase logic (kbpn.py:118-142, 414-447)
     def set_phase(self, it):
@@ -213,8 +218,7 @@ class KBPN:
         for c in st.fe_sr:
             x = c.fwd(x)
             a.append(x)
-        kfm = self._kfm(kvec, H, W)
-        b1 = st.fe_k[0].fwd(kfm)
+        b1, kfm = self._fold_const_conv_fwd(st.fe_k[0], kvec, H, W)
         b2 = st.fe_k[1].fwd(b1)
         c1 = st.fe_cat[0].fwd((a[-1], b2))
         c2 = st.fe_cat[1].fwd(c1)
@@ -410,9 +414,7 @@ class KBPN:
         db1 = st.fe_k[1].bwd_input(db2)
         del db2
         self._act_bwd(st.fe_k[0], db1, b1)
-        self._wg(st.fe_k[0], db1, kfm)
-        dkin = e.f32(B, pad8(self.kk))
-        st.fe_k[0].bwd_input(db1, stat=dkin)
+        dkin = self._fold_const_conv_bwd(st.fe_k[0], db1, kfm, H, W)
         del db1
         # fe_SR chain
         for i in (4, 3, 2, 1, 0):
@@ -423,4 +425,36 @@ class KBPN:
                 da = c.bwd_input(da)
             else:
                 c.bwd_input(da, out32=dsr_t, accumulate=True)
-        return dk2 + dkin[:, :self.kk]
+        return dk2 + dkin
+
+    # ------------------------------------------------------------------ constant-operand folding (exact)
+    def _fold_const_conv_fwd(self, conv, kvec, H, W):
+        """3x3 zero-padded conv of the spatially constant kernel-code map (fe_kernel.0, kbpn.py:565-567): the output takes
+        one value per border class, so it is T = W . k (a [cout, 9] mat-vec per sample), 16 masked tap sums, the activation,
+        and a class fill of the map -- instead of 2*H*W*441*49*9 FLOP on the MFMA."""
+        e = self.eng
+        B = kvec.shape[0]
+        w16 = conv.w.to(torch.float16).float()                      # same operand rounding as the MFMA path
+        k16 = kvec.to(torch.float16).float()
+        T = torch.einsum("ocyx,nc->noyx", w16, k16)                  # [B, cout, 3, 3]
+        V = torch.einsum("noyx,ay,bx->nabo", T, self.Mtap, self.Mtap)   # [B, 4, 4, cout]
+        V = torch.where(V > 0, V, V * conv.slope) if conv.act == A_LRELU else V
+        cp = pad8(conv.cout)
+        Vp = e.f32(B, 16, cp)
+        Vp[:, :, :conv.cout] = V.reshape(B, 16, conv.cout)
+        out = e.new(B, H, W, conv.cout)
+        L.call("csbsr_border_class_fill", _ptr(Vp), _ptr(out.t), out.ld, B, H, W, cp, e.stream)
+        return out, (w16, k16)
+
+    def _fold_const_conv_bwd(self, conv, dpre, saved, H, W):
+        """adjoint of the above: 16 class sums of dPre -> per-tap sums S, dW += S (x) k, dk = W^T S."""
+        e = self.eng
+        w16, k16 = saved
+        B = dpre.N
+        sums = e.f32(B, 16, dpre.cp)
+        L.call("csbsr_border_class_sums", _ptr(dpre.t), dpre.ld, _ptr(sums), B, H, W, dpre.cp, e.stream)
+        C_ = sums[:, :, :conv.cout].reshape(B, 4, 4, conv.cout)
+        S = torch.einsum("nabo,ay,bx->noyx", C_, self.Mtap, self.Mtap)     # [B, cout, 3, 3]
+        if not conv.frozen:
+            grad_acc(conv.w).add_(torch.einsum("noyx,nc->ocyx", S, k16))
+        return torch.einsum("ocyx,noyx->nc", w16, S)

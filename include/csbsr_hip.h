@@ -157,6 +157,14 @@ int csbsr_instnorm_bwd(const void* dy, int64_t dy_ld, const float* x, const floa
                        float* dx, int32_t accumulate, int32_t N, int32_t C, int64_t hw, float* red,
                        csbsr_stream_t s);
 
+/* Constant-operand folding (exact): a zero-padded 3x3 conv of a spatially constant map (fe_kernel.0 applied to the
+ * expanded kernel code, kbpn.py:565-567) takes one value per border class ((y==0)*8 + (y==H-1)*4 + (x==0)*2 + (x==W-1)).
+ * fill: out[n,y,x,:] = V[n][class][:] (fp32 [N][16][c] -> fp16 NHWC);  sums: its adjoint (sums zeroed by the caller). */
+int csbsr_border_class_fill(const float* V, void* out, int64_t ld, int32_t N, int32_t H, int32_t W, int32_t c,
+                            csbsr_stream_t s);
+int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, int32_t N, int32_t H, int32_t W, int32_t c,
+                            csbsr_stream_t s);
+
 /* ------------------------------------------------------------------------------------------- batch norm */
 /* Train-mode BatchNorm2d (extractors.py:47-66, pspnet.py:48-49,83); sum / sumsq come from the conv epilogue. */
 int csbsr_bn_finalize(const float* stat, int64_t count, int32_t c, int32_t cstride, float eps, float momentum,
