@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
     ap.add_argument("--lr-size", type=int, default=448)
     ap.add_argument("--micro-batch", type=int, default=1)
+    ap.add_argument("--max-resident", type=int, default=5, help="micro-batches whose KBPN activations stay resident for backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -92,6 +93,7 @@ def main():
     cfg = base_cfg.clone()
     model = JointModelWithLoss(cfg, 9000, 40000, None, device=str(dev))
     model.micro_batch = args.micro_batch
+    model.max_resident = args.max_resident
     model.train()
     rt = model._runtime()
     if world > 1:

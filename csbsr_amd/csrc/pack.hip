@@ -90,19 +90,21 @@ extern "C" int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32
 __global__ void unpack_wgrad_kernel(const float* g, float* grad, int A, int Breal, int KH, int KW, int seg0_real,
                                     int seg0_p, int segtot_p, int D0, int D1, int transpose_ab, int b_off, float scale, int splits,
                                     long slab) {
-  const long total = (long)A * Breal * KH * KW;
+  // one thread per element of the packed layout [a][tap][b_padded]: the loop over slabs reads consecutive addresses across
+  // the wave; the single write per element goes to the OIHW / IOHW gradient
   const int ktot = KH * KW * segtot_p;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int kw = (int)(i % KW);
-    long t = i / KW;
-    const int kh = (int)(t % KH); t /= KH;
-    const int b = (int)(t % Breal);
-    const int a = (int)(t / Breal);
-    const int bp = b < seg0_real ? b : seg0_p + (b - seg0_real);
-    const long gi = (long)a * ktot + (kh * KW + kw) * segtot_p + bp;
+  const long total = (long)A * ktot;
+  for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(gi / ktot);
+    const int r = (int)(gi - (long)a * ktot);
+    const int tap = r / segtot_p, bp = r - tap * segtot_p;
+    int b;
+    if (bp < seg0_p) { if (bp >= seg0_real) continue; b = bp; }
+    else { b = seg0_real + (bp - seg0_p); if (b >= Breal) continue; }
     float v = 0.f;
-    for (int sp = 0; sp < splits; ++sp) v += g[sp * slab + gi];     // sum the pixel-range slabs of csbsr_conv_wgrad
+    for (int sp = 0; sp < splits; ++sp) v += g[sp * slab + gi];
     v *= scale;
+    const int kh = tap / KW, kw = tap - kh * KW;
     const int bb = b + b_off;
     const long di = transpose_ab ? ((((long)bb * D1 + a) * KH + kh) * KW + kw) : ((((long)a * D1 + bb) * KH + kh) * KW + kw);
     grad[di] += v;
@@ -116,7 +118,7 @@ extern "C" int csbsr_unpack_wgrad(const float* g, float* grad, int32_t A, int32_
   const int seg0_p = round_up(seg0_real, 8);
   const int segtot_p = seg0_p + (seg1_real > 0 ? round_up(seg1_real, 8) : 0);
   const int Breal = seg0_real + seg1_real;
-  const long total = (long)A * Breal * KH * KW;
+  const long total = (long)A * KH * KW * segtot_p;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(s), g, grad, A,
