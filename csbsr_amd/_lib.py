@@ -27,7 +27,7 @@ class ConvDesc(C.Structure):
                 ("wt", vp), ("cout", i32), ("coutp", i32),
                 ("out16", vp), ("o_sn", i64), ("o_sy", i64), ("o_sx", i64),
                 ("out32", vp), ("o32_sn", i64), ("o32_sy", i64), ("o32_sx", i64), ("o32_sc", i64),
-                ("bias", vp), ("act", i32), ("act_slope", f32), ("prelu", vp),
+                ("bias", vp), ("cbias", vp), ("act", i32), ("act_slope", f32), ("prelu", vp),
                 ("res_mode", i32), ("res", vp), ("r_sn", i64), ("r_sy", i64), ("r_sx", i64),
                 ("res2", vp), ("r2_sn", i64), ("r2_sy", i64), ("r2_sx", i64),
                 ("accumulate", i32), ("stat_mode", i32), ("stat", vp), ("out_scale", f32)]
@@ -67,8 +67,9 @@ SIGNATURES = {
     "csbsr_conv_forward": (i32, [C.POINTER(ConvDesc), vp]),
     "csbsr_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp]),
     "csbsr_debug_set_wgrad_tr": (None, [i32]),
+    "csbsr_debug_set_conv_glds": (None, [i32]),
     "csbsr_packed_weight_elems": (i64, [i32] * 9),
-    "csbsr_pack_weights": (i32, [vp, vp] + [i32] * 11 + [vp]),
+    "csbsr_pack_weights": (i32, [vp, vp] + [i32] * 12 + [vp]),
     "csbsr_unpack_wgrad": (i32, [vp, vp] + [i32] * 9 + [f32, i32, i32, vp]),
     "csbsr_wgrad_splits": (i32, [i32, i32, i64]),
     "csbsr_epilogue_backward": (i32, [C.POINTER(EpiBwdDesc), vp]),
@@ -124,6 +125,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
     _lib = lib
+    if os.environ.get("CSBSR_CONV_GLDS"):          # A/B hook for kernel selection experiments
+        lib.csbsr_debug_set_conv_glds(int(os.environ["CSBSR_CONV_GLDS"]))
     return lib
 
 

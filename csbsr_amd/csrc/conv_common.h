@@ -1,0 +1,145 @@
+// Kernel-argument block and the fused epilogue shared by the two implicit-GEMM convolution kernels
+// (conv_igemm.hip: register-staged, any channel count; conv_igemm_glds.hip: LDS-DMA, MFMA-bound shapes).
+#pragma once
+#include "common.h"
+
+struct ConvK {
+  csbsr_seg_t in[2];
+  int N, H, W, OH, OW;
+  int transposed, KHt, KWt;  // taps per phase
+  int stride, pad, dil;
+  int ctot, c0;              // padded channels: total, segment 0
+  int Kp;                    // padded K of the packed weights
+  int rows_p;                // padded weight rows per phase
+  const half_t* wt;
+  int cout, coutp;
+  half_t* out16; long o_sn, o_sy, o_sx;
+  float* out32; long o32_sn, o32_sy, o32_sx, o32_sc;
+  const float* bias;
+  const float* cbias;        // optional [N][16][coutp]: bias per (sample, border class of the output pixel) -- folded constant segment
+  int act; float act_slope; const float* prelu;
+  int res_mode; const half_t* res; long r_sn, r_sy, r_sx;
+  const half_t* res2; long r2_sn, r2_sy, r2_sx;
+  int accumulate;
+  int stat_mode; float* stat;
+  float out_scale;
+  unsigned tiles_m, tiles_n;
+};
+
+// weight rows are padded so that a 128-row tile never reads past the buffer when the wide tile is used
+static inline int conv_rows_padded(int nrows) { return round_up(nrows, nrows > 64 ? 128 : 32); }
+
+// one output pixel x 8 consecutive channels: scale + bias + activation, fused statistics, residual combine, stores
+__device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8], const float (&bias)[8], float slope, int co, int n, int oy,
+                                                  int ox, bool uniform_n, int& cur_n, float (&ssum)[8], float (&ssq)[8]) {
+  const float* cb = nullptr;
+  if (p.cbias) {
+    const int cls = (oy == 0) * 8 + (oy == p.OH - 1) * 4 + (ox == 0) * 2 + (ox == p.OW - 1);
+    cb = p.cbias + ((size_t)n * 16 + cls) * p.coutp + co;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float t = v[e] * p.out_scale + bias[e];
+    if (cb) t += cb[e];
+    t = apply_act(t, p.act, slope);
+    v[e] = (co + e < p.cout) ? t : 0.f;
+  }
+  if (p.stat_mode == CSBSR_STAT_BN) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+  } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM) {
+    if (!uniform_n && n != cur_n) {
+      if (cur_n >= 0)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { atomicAdd(p.stat + (size_t)cur_n * p.coutp + co + e, ssum[e]); ssum[e] = 0.f; }
+      cur_n = n;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ssum[e] += v[e];
+  }
+  if (p.res_mode != CSBSR_RES_NONE) {
+    const h8 r = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
+    h8 r2 = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p.res_mode == CSBSR_RES_FMA) r2 = *reinterpret_cast<const h8*>(p.res2 + n * p.r2_sn + oy * p.r2_sy + ox * p.r2_sx + co);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float rv = (float)r[e];
+      switch (p.res_mode) {
+        case CSBSR_RES_ADD: v[e] += rv; break;
+        case CSBSR_RES_SUB: v[e] -= rv; break;
+        case CSBSR_RES_MUL: v[e] *= rv; break;
+        default: v[e] += rv * (float)r2[e]; break;
+      }
+    }
+  }
+  if (p.out16) {
+    half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
+    if (p.accumulate) {
+      const h8 old = *reinterpret_cast<const h8*>(o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+    }
+    h8 hv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
+    *reinterpret_cast<h8*>(o) = hv;
+  }
+  if (p.out32) {
+    float* o = p.out32 + n * p.o32_sn + oy * p.o32_sy + ox * p.o32_sx;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (co + e < p.cout) {
+        float* q = o + (co + e) * p.o32_sc;
+        *q = (p.accumulate && !p.out16) ? *q + v[e] : v[e];
+      }
+  }
+}
+
+// per-thread partial statistics -> LDS bins (uniform sample per tile) or straight to global (tile straddles samples)
+__device__ __forceinline__ void conv_epilogue_flush_stats(const ConvK& p, float* sStat, int BN, int local_col, int co, bool uniform_n, int cur_n,
+                                                          float (&ssum)[8], float (&ssq)[8]) {
+  if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
+    if (co < p.coutp) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(&sStat[local_col + e], ssum[e]);
+        if (p.stat_mode == CSBSR_STAT_BN) atomicAdd(&sStat[BN + local_col + e], ssq[e]);
+      }
+    }
+  } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && cur_n >= 0 && co < p.coutp) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(p.stat + (size_t)cur_n * p.coutp + co + e, ssum[e]);
+  }
+}
+
+// Register-direct epilogue for one 32x32 accumulator tile (no statistics requested): v_permlane32_swap pairs turn the MFMA
+// layout (lane l / l+32 hold couts 8q..8q+3 / 8q+4..8q+7 of pixel l%32) into 8 consecutive couts per lane, so every lane issues
+// 16-byte stores / residual loads for its own pixel -- no LDS round trip, no barriers, one address computation per pixel.
+__device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const f16v& acc, int cbase /*first cout of the 32-wide tile*/,
+                                                          float slope, int n, int oy, int ox) {
+  if (n < 0) return;
+  const int hi = (threadIdx.x & 63) >> 5;
+#pragma unroll
+  for (int pair = 0; pair < 2; ++pair) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned a = __float_as_uint(acc[8 * pair + j]), b = __float_as_uint(acc[8 * pair + 4 + j]);
+      auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+      // lower lanes: r[0] = own group 2*pair, r[1] = partner's group 2*pair ; upper lanes: r[0] = partner's group 2*pair+1, r[1] = own
+      v[j] = __uint_as_float(r[0]);
+      v[4 + j] = __uint_as_float(r[1]);
+    }
+    const int co = cbase + 16 * pair + 8 * hi;
+    if (co >= p.coutp) continue;
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f;
+    float s0[8], s1[8];
+    int cur_n = -1;
+    conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, true, cur_n, s0, s1);
+  }
+}
+
+bool conv_glds_eligible(const ConvK& k);
+int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st);

@@ -15,32 +15,11 @@
 // Reference call sites this stands in for: F.conv2d / F.conv_transpose2d in
 // /root/reference/model/modeling/kbpn.py:241,273-277,513-517 and pspnet_pytorch/{extractors.py:36-38,pspnet.py:30-86}.
 #include "common.h"
+#include "conv_common.h"
 
 #define BM 128
 #define BK 64
 #define LDS_LD 72  // halves per LDS row: 64 + 8 pad (144 B): conflict-free 16-byte fragment reads
-
-struct ConvK {
-  csbsr_seg_t in[2];
-  int N, H, W, OH, OW;
-  int transposed, KHt, KWt;  // taps per phase
-  int stride, pad, dil;
-  int ctot, c0;              // padded channels: total, segment 0
-  int Kp;                    // padded K of the packed weights
-  int rows_p;                // padded weight rows per phase (multiple of 32)
-  const half_t* wt;
-  int cout, coutp;
-  half_t* out16; long o_sn, o_sy, o_sx;
-  float* out32; long o32_sn, o32_sy, o32_sx, o32_sc;
-  const float* bias;
-  int act; float act_slope; const float* prelu;
-  int res_mode; const half_t* res; long r_sn, r_sy, r_sx;
-  const half_t* res2; long r2_sn, r2_sy, r2_sx;
-  int accumulate;
-  int stat_mode; float* stat;
-  float out_scale;
-  unsigned tiles_m, tiles_n;
-};
 
 template <int BN, int WP, int WC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
@@ -195,8 +174,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
   // ---- epilogue: fp32 tile -> LDS [pixel][cout] in halves of HB couts (keeps LDS <= the main-loop footprint so three
   // workgroups fit per CU), then channel-contiguous 8-wide processing
-  float* sO = reinterpret_cast<float*>(smem);
   const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
+  if (p.stat_mode == CSBSR_STAT_NONE) {       // register-direct epilogue (conv_common.h)
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+      const int row = wp * PW + b * 32 + (lane & 31);
+      const int n = sRow[row * 3], oy = py + sRow[row * 3 + 1] * o_step, ox = px + sRow[row * 3 + 2] * o_step;
+#pragma unroll
+      for (int a = 0; a < TC; ++a) conv_epilogue_direct_tile(p, acc[a][b], cout0 + wc * CW + a * 32, slope, n, oy, ox);
+    }
+    return;
+  }
+  float* sO = reinterpret_cast<float*>(smem);
   const int n_first = sRow[0];
   int n_last = n_first;
   {
@@ -244,75 +233,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
       const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
       const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
       v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = v[e] * p.out_scale + bias[e];
-        t = apply_act(t, p.act, slope);
-        v[e] = (co + e < p.cout) ? t : 0.f;
-      }
-      if (p.stat_mode == CSBSR_STAT_BN) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
-      } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM) {
-        if (!uniform_n && n != cur_n) {
-          if (cur_n >= 0)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { atomicAdd(p.stat + (size_t)cur_n * p.coutp + co + e, ssum[e]); ssum[e] = 0.f; }
-          cur_n = n;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ssum[e] += v[e];
-      }
-      if (p.res_mode != CSBSR_RES_NONE) {
-        const h8 r = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
-        h8 r2 = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (p.res_mode == CSBSR_RES_FMA) r2 = *reinterpret_cast<const h8*>(p.res2 + n * p.r2_sn + oy * p.r2_sy + ox * p.r2_sx + co);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float rv = (float)r[e];
-          switch (p.res_mode) {
-            case CSBSR_RES_ADD: v[e] += rv; break;
-            case CSBSR_RES_SUB: v[e] -= rv; break;
-            case CSBSR_RES_MUL: v[e] *= rv; break;
-            default: v[e] += rv * (float)r2[e]; break;
-          }
-        }
-      }
-      if (p.out16) {
-        half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
-        if (p.accumulate) {
-          const h8 old = *reinterpret_cast<const h8*>(o);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
-        }
-        h8 hv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-        *reinterpret_cast<h8*>(o) = hv;
-      }
-      if (p.out32) {
-        float* o = p.out32 + n * p.o32_sn + oy * p.o32_sy + ox * p.o32_sx;
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (co + e < p.cout) {
-            float* q = o + (co + e) * p.o32_sc;
-            *q = (p.accumulate && !p.out16) ? *q + v[e] : v[e];
-          }
-      }
+      conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, uniform_n, cur_n, ssum, ssq);
     }
 
-    if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
-      if (co < p.coutp) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          atomicAdd(&sStat[hh * HB + cc8 * 8 + e], ssum[e]);
-          if (p.stat_mode == CSBSR_STAT_BN) atomicAdd(&sStat[BN + hh * HB + cc8 * 8 + e], ssq[e]);
-        }
-      }
-    } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && cur_n >= 0 && co < p.coutp) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) atomicAdd(p.stat + (size_t)cur_n * p.coutp + co + e, ssum[e]);
-    }
+    conv_epilogue_flush_stats(p, sStat, BN, hh * HB + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
   }
 
   if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
@@ -356,6 +280,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   CSBSR_CHECK(d->out16 || d->out32 || d->stat_mode != CSBSR_STAT_NONE, "conv: no output requested");
   CSBSR_CHECK(d->stride >= 1 && d->KH >= 1 && d->KW >= 1, "conv: bad geometry");
   CSBSR_CHECK(!d->transposed || d->dil == 1, "conv: transposed conv supports dilation 1 only");
+  CSBSR_CHECK(!d->cbias || (!d->transposed && d->stride == 1), "conv: border-class bias needs a stride-1 convolution");
   CSBSR_CHECK(d->act != CSBSR_ACT_PRELU || d->prelu, "conv: PReLU needs a slope pointer");
   CSBSR_CHECK(d->res_mode == CSBSR_RES_NONE || d->res, "conv: res_mode set without res");
   ConvK k;
@@ -368,12 +293,12 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   k.KWt = d->transposed ? (d->KW + d->stride - 1) / d->stride : d->KW;
   k.c0 = d->in[0].c; k.ctot = d->in[0].c + d->in[1].c;
   k.Kp = round_up(k.KHt * k.KWt * k.ctot, BK);
-  k.rows_p = round_up(d->cout, 32);
+  k.rows_p = conv_rows_padded(d->cout);
   k.wt = reinterpret_cast<const half_t*>(d->wt);
   k.cout = d->cout; k.coutp = d->coutp;
   k.out16 = reinterpret_cast<half_t*>(d->out16); k.o_sn = d->o_sn; k.o_sy = d->o_sy; k.o_sx = d->o_sx;
   k.out32 = d->out32; k.o32_sn = d->o32_sn; k.o32_sy = d->o32_sy; k.o32_sx = d->o32_sx; k.o32_sc = d->o32_sc;
-  k.bias = d->bias; k.act = d->act; k.act_slope = d->act_slope; k.prelu = d->prelu;
+  k.bias = d->bias; k.cbias = d->cbias; k.act = d->act; k.act_slope = d->act_slope; k.prelu = d->prelu;
   k.res_mode = d->res_mode; k.res = reinterpret_cast<const half_t*>(d->res);
   k.r_sn = d->r_sn; k.r_sy = d->r_sy; k.r_sx = d->r_sx;
   k.res2 = reinterpret_cast<const half_t*>(d->res2); k.r2_sn = d->r2_sn; k.r2_sy = d->r2_sy; k.r2_sx = d->r2_sx;
@@ -390,6 +315,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
     maxM = (long)d->N * d->OH * d->OW;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  if (conv_glds_eligible(k)) return conv_glds_launch(k, nphase, maxM, st);
   if (k.coutp > 64) return launch_conv<128, 2, 2>(k, nphase, maxM, st);
   if (k.coutp > 32) return launch_conv<64, 2, 2>(k, nphase, maxM, st);
   return launch_conv<32, 4, 1>(k, nphase, maxM, st);

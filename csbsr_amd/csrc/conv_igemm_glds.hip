@@ -1,0 +1,305 @@
+// Implicit-GEMM convolution, LDS-DMA variant for the MFMA-bound layers (>= 128 output channels, channel counts that are
+// multiples of 64): same math and epilogue as conv_igemm.hip, different data movement.
+//
+//  * one K slice = 64 channels of ONE tap of ONE input segment, i.e. a full 128-byte line per pixel / per weight row;
+//  * both tiles go HBM -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no ds_write pass -- the register-staged
+//    kernel is bound by the ~79 B/clk ds_write_b128 path);
+//  * the LDS image is lane-linear (1 KiB per wave instruction), so bank conflicts are removed by permuting the SOURCE
+//    chunk a lane fetches: position (row, c') holds channel chunk c' ^ ((row >> 1) & 7); fragment reads apply the same XOR
+//    (cdna guide rule 21) -> conflict-free ds_read_b128;
+//  * NSTAGE-deep ring (3 x 48 KiB for the 256x128 tile, one workgroup of 8 waves per CU = 2 waves per SIMD; 2 x 32 KiB for
+//    128x128, two workgroups per CU), counted s_waitcnt vmcnt(N) + raw s_barrier so DMAs stay in flight across barriers;
+//  * halo / padding / tile-overhang lanes fetch from a 256-byte zero page instead of branching.
+#include "common.h"
+#include "conv_common.h"
+
+template <int BM, int NWM, int NSTAGE>
+__global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK p, const half_t* __restrict__ zero_page) {
+  constexpr int BN = 128, BKG = 64;
+  constexpr int NW = NWM * 2, NT = NW * 64;
+  constexpr int XI = BM / 8, WI = BN / 8;            // wave-instructions per stage for the X / W tile
+  constexpr int NI = (XI + WI) / NW;                 // per wave
+  constexpr int NXI = XI / NW;                       // X instructions per wave (the first NXI of its NI)
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
+  constexpr int OUT_LD = 64 + 4;
+  constexpr int EPI_BYTES = 128 * OUT_LD * 4;
+  constexpr int SM_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
+  static_assert(XI % NW == 0 && WI % NW == 0, "tile rows must split evenly over the waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* sRow = reinterpret_cast<int*>(smem + SM_BYTES);                      // [BM][3]
+  float* sStat = reinterpret_cast<float*>(smem + SM_BYTES + BM * 3 * 4);    // [2][BN]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const unsigned ntile = p.tiles_m * p.tiles_n;
+  const unsigned lt = xcd_remap(blockIdx.x, ntile);
+  const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
+  const int cout0 = tile_n * BN;
+
+  int py = 0, px = 0, OHp = p.OH, OWp = p.OW, in_step = p.stride, tap_step = p.dil, base_y = -p.pad, base_x = -p.pad, o_step = 1;
+  if (p.transposed) {
+    py = blockIdx.z / p.stride; px = blockIdx.z % p.stride;
+    OHp = (p.OH - py + p.stride - 1) / p.stride;
+    OWp = (p.OW - px + p.stride - 1) / p.stride;
+    in_step = 1; tap_step = -1; o_step = p.stride;
+    base_y = (py + p.pad) / p.stride; base_x = (px + p.pad) / p.stride;
+  }
+  const long M = (long)p.N * OHp * OWp;
+  const long m0 = (long)tile_m * BM;
+  if (m0 >= M) return;
+  const half_t* wt = p.wt + (size_t)blockIdx.z * p.rows_p * p.Kp;
+
+  if (tid < BM) {
+    long m = m0 + tid;
+    int n = -1, oy = 0, ox = 0;
+    if (m < M) {
+      n = (int)(m / ((long)OHp * OWp));
+      int rem = (int)(m - (long)n * OHp * OWp);
+      oy = rem / OWp; ox = rem - oy * OWp;
+    }
+    sRow[tid * 3 + 0] = n; sRow[tid * 3 + 1] = oy; sRow[tid * 3 + 2] = ox;
+  }
+  if (tid < 2 * BN) sStat[tid] = 0.f;
+  __syncthreads();
+
+  // ---- per-lane DMA roles.  Instruction j = wid + NW*i of a stage covers tile rows 8j .. 8j+7, lane -> row 8j + lane/8,
+  // LDS chunk position c' = lane%8, channel chunk c = c' ^ ((row>>1)&7) = c' ^ ((4*(wid&1) + lane/16) & 7) for every i.
+  const int cch = ((lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7)) * 8;          // halves
+  // Everything that does not change from slice to slice is hoisted out of the K loop (the loop is VALU-bound on address
+  // generation otherwise): per row a 64-bit element offset for tap (0,0) in each input segment, and a bit per tap saying
+  // whether that tap lands inside the image.  Per slice only a wave-uniform base pointer changes.
+  long off0[NXI], off1[NXI];
+  unsigned long long tapmask[NXI];
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) {
+    const int r = 8 * (wid + NW * i) + (lane >> 3);
+    const int n = sRow[r * 3];
+    const int iy0 = sRow[r * 3 + 1] * in_step + base_y, ix0 = sRow[r * 3 + 2] * in_step + base_x;
+    off0[i] = n * p.in[0].sn + iy0 * p.in[0].sy + ix0 * p.in[0].sx + cch;
+    off1[i] = n * p.in[1].sn + iy0 * p.in[1].sy + ix0 * p.in[1].sx + cch;
+    unsigned long long m = 0;
+    if (n >= 0) {
+      for (int t = 0; t < p.KHt * p.KWt; ++t) {
+        const int iy = iy0 + (t / p.KWt) * tap_step, ix = ix0 + (t % p.KWt) * tap_step;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) m |= 1ull << t;
+      }
+    }
+    tapmask[i] = m;
+  }
+  const half_t* wrow[NI - NXI];
+#pragma unroll
+  for (int i = 0; i < NI - NXI; ++i) {
+    const int r = 8 * (wid + NW * (NXI + i) - XI) + (lane >> 3);      // weight-tile row
+    wrow[i] = wt + (size_t)(cout0 + r) * p.Kp + cch;                  // rows_p is padded to the tile: always in bounds
+  }
+  const half_t* zp = zero_page + (lane & 7) * 8;
+  // scalar running position of the slice being ISSUED: tap index (ky,kx), channel offset cs within the concatenated input
+  int cs = 0, ky = 0, kx = 0, tap = 0;
+
+  auto issue = [&](int kt) {
+    char* sbase = smem + (kt % NSTAGE) * STAGE_BYTES;
+    const bool s0 = cs < p.c0;
+    const long sy = s0 ? p.in[0].sy : p.in[1].sy, sx = s0 ? p.in[0].sx : p.in[1].sx;
+    const half_t* xb = reinterpret_cast<const half_t*>(s0 ? p.in[0].ptr : p.in[1].ptr) + (s0 ? cs : cs - p.c0) +
+                       (long)(ky * tap_step) * sy + (long)(kx * tap_step) * sx;            // wave-uniform
+    const unsigned long long bit = tap < 64 ? (1ull << tap) : 0ull;                        // beyond the last tap: K padding
+#pragma unroll
+    for (int i = 0; i < NXI; ++i) {
+      const half_t* src = (tapmask[i] & bit) ? xb + (s0 ? off0[i] : off1[i]) : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sbase + (wid + NW * i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NI - NXI; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + kt * BKG),
+                                       (__attribute__((address_space(3))) void*)(sbase + BM * 128 + (wid + NW * (NXI + i) - XI) * 1024), 16, 0, 0);
+    }
+    cs += BKG;
+    if (cs >= p.ctot) { cs = 0; ++tap; if (++kx == p.KWt) { kx = 0; ++ky; } }
+  };
+
+  f16v acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nkt = p.Kp / BKG;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nkt) issue(s);
+
+  // fragment addressing: tile row R, channel chunk c -> byte R*128 + ((c ^ ((R>>1)&7)) << 4)
+  const int xr0 = wm * 64 + (lane & 31), wr0 = wn * 64 + (lane & 31);
+  for (int kt = 0; kt < nkt; ++kt) {
+    // stage kt landed (this wave's DMAs), then everyone's
+    const int ahead = (nkt - 1 - kt) < (NSTAGE - 2) ? (nkt - 1 - kt) : (NSTAGE - 2);   // stages still allowed in flight
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1);      // refills the buffer read in iteration kt-1
+    const char* xs = smem + (kt % NSTAGE) * STAGE_BYTES;
+    const char* ws = xs + BM * 128;
+    // fragment double-buffering: the reads of sub-step ks+1 are in flight while the 4 MFMAs of sub-step ks issue
+    auto load_frags = [&](int ks, h8 (&af)[2], h8 (&bf)[2]) {
+      const int c = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int R = wr0 + a * 32;
+        af[a] = *reinterpret_cast<const h8*>(ws + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int R = xr0 + b * 32;
+        bf[b] = *reinterpret_cast<const h8*>(xs + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+      }
+    };
+    h8 af0[2], bf0[2], af1[2], bf1[2];
+    load_frags(0, af0, bf0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks += 2) {
+      load_frags(ks + 1, af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0[a], bf0[b], acc[a][b], 0, 0, 0);
+      if (ks + 2 < 4) load_frags(ks + 2, af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1[a], bf1[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
+  if (p.stat_mode == CSBSR_STAT_NONE) {       // register-direct epilogue
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int row = wm * 64 + b * 32 + (lane & 31);
+      const int n = sRow[row * 3], oy = py + sRow[row * 3 + 1] * o_step, ox = px + sRow[row * 3 + 2] * o_step;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) conv_epilogue_direct_tile(p, acc[a][b], cout0 + wn * 64 + a * 32, slope, n, oy, ox);
+    }
+    return;
+  }
+  // ---- statistics requested: epilogue staged through LDS in passes of 128 pixels x 64 couts (same as conv_igemm.hip)
+  float* sO = reinterpret_cast<float*>(smem);
+  const int n_first = sRow[0];
+  int n_last;
+  {
+    long ml = (m0 + BM - 1 < M - 1) ? m0 + BM - 1 : M - 1;
+    n_last = (int)(ml / ((long)OHp * OWp));
+  }
+  const bool uniform_n = (n_first == n_last);
+  constexpr int CPR = 8;                      // 8-channel chunks per staged row (64 couts)
+  const int cc8 = tid % CPR;
+  constexpr int RSTEP = NT / CPR;
+
+#pragma unroll 1
+  for (int pass = 0; pass < (BM / 128) * 2; ++pass) {
+    const int rh = pass >> 1, hh = pass & 1;
+    if (pass > 0) __syncthreads();
+    if ((wm * 64) / 128 == rh && wn == hh) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int pix = wm * 64 - rh * 128 + b * 32 + (lane & 31);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int cl = a * 32 + 8 * q + 4 * (lane >> 5);
+            f4 v = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+            *reinterpret_cast<f4*>(sO + pix * OUT_LD + cl) = v;
+          }
+        }
+    }
+    __syncthreads();
+    const int co = cout0 + hh * 64 + cc8 * 8;
+    float bias[8], ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f; ssum[e] = ssq[e] = 0.f; }
+    int cur_n = -1;
+    for (int row = tid / CPR; row < 128; row += RSTEP) {
+      const int grow = rh * 128 + row;
+      const int n = sRow[grow * 3];
+      if (n < 0 || co >= p.coutp) continue;
+      const int oy = py + sRow[grow * 3 + 1] * o_step, ox = px + sRow[grow * 3 + 2] * o_step;
+      float v[8];
+      const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
+      const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
+      v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+      conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, uniform_n, cur_n, ssum, ssq);
+    }
+    conv_epilogue_flush_stats(p, sStat, BN, hh * 64 + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
+  }
+  if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
+    __syncthreads();
+    if (tid < BN && cout0 + tid < p.coutp) {
+      if (p.stat_mode == CSBSR_STAT_BN) {
+        atomicAdd(p.stat + cout0 + tid, sStat[tid]);
+        atomicAdd(p.stat + p.coutp + cout0 + tid, sStat[BN + tid]);
+      } else if (n_first >= 0) {
+        atomicAdd(p.stat + (size_t)n_first * p.coutp + cout0 + tid, sStat[tid]);
+      }
+    }
+  }
+}
+
+static half_t* g_zero_page = nullptr;
+
+template <int BM, int NWM, int NSTAGE>
+static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
+  ConvK p = k;
+  constexpr int BN = 128;
+  p.tiles_m = (unsigned)((maxM + BM - 1) / BM);
+  p.tiles_n = (unsigned)((k.coutp + BN - 1) / BN);
+  constexpr int RING = NSTAGE * (BM + BN) * 128;
+  constexpr int EPI = 128 * 68 * 4;
+  constexpr int SM_BYTES = (RING > EPI ? RING : EPI) + BM * 3 * 4 + 2 * BN * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_glds_kernel<BM, NWM, NSTAGE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES) != hipSuccess) {
+      csbsr_set_error("conv(glds): cannot reserve %d bytes of LDS", SM_BYTES);
+      return 2;
+    }
+    attr_set = true;
+  }
+  if (!g_zero_page) {
+    if (hipMalloc(reinterpret_cast<void**>(&g_zero_page), 256) != hipSuccess) { csbsr_set_error("conv(glds): zero page alloc failed"); return 2; }
+    (void)hipMemset(g_zero_page, 0, 256);
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, 1, nphase);
+  hipLaunchKernelGGL((conv_igemm_glds_kernel<BM, NWM, NSTAGE>), grid, dim3(NWM * 128), SM_BYTES, st, p, g_zero_page);
+  CSBSR_LAUNCH_CHECK("csbsr_conv_forward(glds)");
+  return 0;
+}
+
+static int g_glds_mode = 2;      // 0: off, 1: 128x128 x2 stages only, 2: + 256x128 x3 stages for long-K stride-1 layers
+extern "C" void csbsr_debug_set_conv_glds(int mode) { g_glds_mode = mode; }
+
+// eligibility: MFMA-bound shapes only
+bool conv_glds_eligible(const ConvK& k) {
+  if (g_glds_mode == 0) return false;
+  if (k.coutp <= 64) return false;
+  if (k.ctot % 64 != 0) return false;
+  if (k.c0 != k.ctot && k.c0 % 64 != 0) return false;
+  if (k.rows_p % 128 != 0) return false;      // packed weights padded to the 128-row tile (csbsr_pack_weights does)
+  if (k.KHt * k.KWt > 64) return false;       // one validity bit per tap in a 64-bit mask
+  return true;
+}
+
+int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st) {
+  // measured (scripts/bench_conv.py): the 8-wave 256x128 tile only pays for long-K stride-1 layers (SFT 3x3, ResNet 3x3);
+  // strided / transposed / short-K layers run faster with two 128x128 workgroups per CU
+  const bool big = g_glds_mode == 2 && !k.transposed && k.stride == 1 && k.Kp >= 2304 && maxM >= 256 * 256;
+  if (!big) return launch_glds<128, 2, 2>(k, nphase, maxM, st);
+  return launch_glds<256, 4, 3>(k, nphase, maxM, st);
+}

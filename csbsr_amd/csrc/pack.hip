@@ -8,7 +8,7 @@ struct PackK {
   int kind;            // 0 conv  1 conv flipped+swapped (dgrad of stride-1 conv)  2 transposed (phases)
   int D0, D1, KH, KW, stride, pad;
   int seg0_real, seg0_p, segtot_p, chan_real;
-  int row_off, nrows, rows_p, Kp, KHt, KWt, nphase;
+  int row_off, nrows, rows_p, Kp, KHt, KWt, nphase, k_off;
 };
 
 __global__ void pack_weights_kernel(const PackK p) {
@@ -25,6 +25,7 @@ __global__ void pack_weights_kernel(const PackK p) {
     int c = -1;
     if (cp < p.seg0_p) { if (cp < p.seg0_real) c = cp; }
     else { const int c1 = cp - p.seg0_p; if (p.seg0_real + c1 < p.chan_real) c = p.seg0_real + c1; }
+    if (c >= 0) c += p.k_off;
     if (r < p.nrows && c >= 0 && tap < p.KHt * p.KWt) {
       const int jy = tap / p.KWt, jx = tap % p.KWt;
       const int rr = p.row_off + r;
@@ -51,7 +52,7 @@ static void pack_geometry(int kind, int D0, int D1, int KH, int KW, int stride, 
   p.segtot_p = p.seg0_p + (seg1_real > 0 ? round_up(seg1_real, 8) : 0);
   p.chan_real = seg0_real + seg1_real;
   p.nrows = nrows;
-  p.rows_p = round_up(nrows, 32);
+  p.rows_p = round_up(nrows, nrows > 64 ? 128 : 32);   // = conv_rows_padded() of conv_common.h
   p.KHt = kind == 2 ? (KH + stride - 1) / stride : KH;
   p.KWt = kind == 2 ? (KW + stride - 1) / stride : KW;
   p.nphase = kind == 2 ? stride * stride : 1;
@@ -67,16 +68,16 @@ extern "C" int64_t csbsr_packed_weight_elems(int32_t kind, int32_t D0, int32_t D
 
 extern "C" int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH,
                                   int32_t KW, int32_t stride, int32_t pad, int32_t seg0_real, int32_t seg1_real,
-                                  int32_t row_off, int32_t nrows, csbsr_stream_t s) {
+                                  int32_t row_off, int32_t nrows, int32_t k_off, csbsr_stream_t s) {
   CSBSR_CHECK(w && dst, "pack: null pointer");
   CSBSR_CHECK(kind >= 0 && kind <= 2, "pack: bad kind");
   const int kdim = kind == 0 ? D1 : D0;       // which weight dim the K-side channels index
   const int rdim = kind == 0 ? D0 : D1;
-  CSBSR_CHECK(seg0_real + seg1_real == kdim, "pack: segments (%d+%d) must cover the contracted dim (%d)", seg0_real, seg1_real, kdim);
+  CSBSR_CHECK(k_off >= 0 && k_off + seg0_real + seg1_real <= kdim, "pack: segments (%d+%d at %d) exceed the contracted dim (%d)", seg0_real, seg1_real, k_off, kdim);
   CSBSR_CHECK(row_off >= 0 && row_off + nrows <= rdim, "pack: row range out of bounds");
   PackK p;
   pack_geometry(kind, D0, D1, KH, KW, stride, seg0_real, seg1_real, nrows, p);
-  p.w = w; p.dst = reinterpret_cast<half_t*>(dst); p.pad = pad; p.row_off = row_off;
+  p.w = w; p.dst = reinterpret_cast<half_t*>(dst); p.pad = pad; p.row_off = row_off; p.k_off = k_off;
   const long total = (long)p.nphase * p.rows_p * p.Kp;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;

@@ -179,14 +179,14 @@ class Conv:
     def invalidate(self):
         self._packed.clear()
 
-    def _pack(self, key, kind, seg0, seg1, row_off, nrows, stride, pad):
+    def _pack(self, key, kind, seg0, seg1, row_off, nrows, stride, pad, k_off=0):
         if key in self._packed:
             return self._packed[key]
         D0, D1 = self.w.shape[0], self.w.shape[1]
         n = L.load().csbsr_packed_weight_elems(kind, D0, D1, self.k, self.k, stride, seg0, seg1, nrows)
         dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
         L.call("csbsr_pack_weights", _ptr(self.w), _ptr(dst), kind, D0, D1, self.k, self.k, stride, pad, seg0, seg1, row_off, nrows,
-               self.eng.stream)
+               k_off, self.eng.stream)
         self._packed[key] = dst
         return dst
 
@@ -197,7 +197,7 @@ class Conv:
         return (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
 
     def _launch(self, xs, wt, transposed, k, stride, pad, dil, H, W, OH, OW, cout, out, out32, bias, act, slope, prelu, res, res2,
-                res_mode, accumulate, stat, stat_mode, out_scale):
+                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None):
         d = L.ConvDesc()
         x0 = xs[0]
         d.inp[0] = x0.seg()
@@ -214,7 +214,7 @@ class Conv:
         if out32 is not None:           # fp32 NCHW planar [N, cout, OH, OW]
             assert out32.is_contiguous() and tuple(out32.shape) == (x0.N, cout, OH, OW)
             d.out32, d.o32_sn, d.o32_sy, d.o32_sx, d.o32_sc = _ptr(out32), cout * OH * OW, OW, 1, OH * OW
-        d.bias, d.act, d.act_slope, d.prelu = _ptr(bias), act, slope, _ptr(prelu)
+        d.bias, d.cbias, d.act, d.act_slope, d.prelu = _ptr(bias), _ptr(cbias), act, slope, _ptr(prelu)
         d.res_mode = res_mode
         if res is not None:
             sn, sy, sx = res.strides()
@@ -277,7 +277,42 @@ class Conv:
                      L.RES_NONE, accumulate, stat, L.STAT_SAMPLE_SUM if stat is not None else L.STAT_NONE, 1.0)
         return out
 
-    def bwd_weights(self, dpre, x):
+    # -- exact folding of a spatially constant second input segment (SFT conv0: cat(features, kernel code), kbpn.py:513)
+    def fwd_folded(self, x, kvec, mtap, out=None):
+        """conv over the feature segment only; the constant segment enters as a per-(sample, border class) bias
+        T = W_const . k, 16 masked tap sums (see csbsr_border_class_fill)."""
+        assert not self.transposed and self.stride == 1 and self.k == 3 and self.split[1] > 0
+        cf = self.split[0]
+        B = x.N
+        wt = self._pack("fwd_feat", 0, cf, 0, 0, self.cout, 1, self.pad, 0)
+        w16c = self.w[:, cf:].to(torch.float16).float()
+        k16 = kvec.to(torch.float16).float()
+        T = torch.einsum("ocyx,nc->noyx", w16c, k16)
+        V = torch.einsum("noyx,ay,bx->nabo", T, mtap, mtap).reshape(B, 16, self.cout)
+        cb = self.eng.f32(B, 16, pad8(self.cout))
+        cb[:, :, :self.cout] = V
+        H, W = x.H, x.W
+        if out is None:
+            out = self.eng.new(B, H, W, self.cout)
+        self._launch((x,), wt, False, 3, 1, self.pad, self.dil, H, W, H, W, self.cout, out, None, self.b, self.act, self.slope, self.prelu,
+                     None, None, L.RES_NONE, False, None, L.STAT_NONE, 1.0, cbias=cb)
+        return out, (w16c, k16)
+
+    def bwd_weights_folded(self, dpre, x, saved, mtap, frozen=False):
+        """wgrad of the feature part on the MFMA, of the constant part from 16 border-class sums of dPre; returns dL/dk [B, c_const]."""
+        w16c, k16 = saved
+        cf = self.split[0]
+        if not frozen:
+            self.bwd_weights(dpre, x, split_override=(cf, 0))
+        B = dpre.N
+        sums = self.eng.f32(B, 16, dpre.cp)
+        L.call("csbsr_border_class_sums", _ptr(dpre.t), dpre.ld, _ptr(sums), B, dpre.H, dpre.W, dpre.cp, self.eng.stream)
+        S = torch.einsum("nabo,ay,bx->noyx", sums[:, :, :self.cout].reshape(B, 4, 4, self.cout), mtap, mtap)
+        if not frozen:
+            grad_acc(self.w)[:, cf:].add_(torch.einsum("noyx,nc->ocyx", S, k16))
+        return torch.einsum("ocyx,noyx->nc", w16c, S)
+
+    def bwd_weights(self, dpre, x, split_override=None):
         """wgrad; accumulates (scaled) into self.w.gacc [same shape as w] fp32."""
         xs = x if isinstance(x, (tuple, list)) else (x,)
         d = L.WgradDesc()
@@ -287,7 +322,7 @@ class Conv:
             seg0, seg1 = self.cout, 0
         else:
             a, bs = dpre, xs
-            seg0, seg1 = self.split
+            seg0, seg1 = split_override if split_override is not None else self.split
         sn, sy, sx = a.strides()
         d.a, d.a_sn, d.a_sy, d.a_sx, d.ca = _ptr(a.t), sn, sy, sx, a.cp
         d.b[0] = bs[0].seg()

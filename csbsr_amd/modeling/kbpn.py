@@ -193,12 +193,12 @@ class KBPN:
                 lows = concat_l.slice(128 * (s - 1), 128 * s)
                 st.down3.fwd(dd, out=lows, res=l0, res_mode=L.RES_ADD)
                 fpre = concat_l.slice(0, 128 * s)
-                kfm = self._kfm(vec, h, w)
-                t1 = st.sc0.fwd((fpre, kfm))
+                # the 441 kernel-code channels of the SFT input are spatially constant: folded exactly into a class bias
+                t1, fold1 = st.sc0.fwd_folded(fpre, vec, self.Mtap)
                 sc = st.sc1.fwd(t1)
-                t2 = st.sh0.fwd((fpre, kfm))
+                t2, fold2 = st.sh0.fwd_folded(fpre, vec, self.Mtap)
                 lowp = st.sh1.fwd(t2, res=fpre, res2=sc, res_mode=L.RES_FMA)
-                q.update(xd=xd, l0=l0, dd=dd, kfm=kfm, t1=t1, sc=sc, t2=t2, lowp=lowp)
+                q.update(xd=xd, l0=l0, dd=dd, fold1=fold1, fold2=fold2, t1=t1, sc=sc, t2=t2, lowp=lowp)
                 low = lowp
             stg.append(q if save else None)
             if not save:
@@ -268,18 +268,15 @@ class KBPN:
                 dsc = e.new(B, h, w, 128 * s)
                 e.epilogue_bwd(dlowp, out=q["lowp"], res=fpre, res2=q["sc"], res_mode=L.RES_FMA, dpre=dlowp, dres=dfpre, dres_acc=True,
                                dres2=dsc, dbias=None if st.sh1.frozen else grad_acc(st.sh1.b), creal=st.sh1.cout)
-                dk = e.f32(B, pad8(self.kk))
-                for c1, c0, t, dz in ((st.sh1, st.sh0, q["t2"], dlowp), (st.sc1, st.sc0, q["t1"], None)):
+                for c1, c0, t, dz, fold in ((st.sh1, st.sh0, q["t2"], dlowp, q["fold2"]), (st.sc1, st.sc0, q["t1"], None, q["fold1"])):
                     if dz is None:
                         dz = self._act_bwd(c1, dsc, q["sc"])
                     self._wg(c1, dz, t)
                     dt = c1.bwd_input(dz)
                     self._act_bwd(c0, dt, t)
-                    self._wg(c0, dt, (fpre, q["kfm"]))
+                    dvec_next = dvec_next + c0.bwd_weights_folded(dt, fpre, fold, self.Mtap, frozen=c0.frozen)
                     c0.bwd_input(dt, seg=0, out=dfpre, accumulate=True)
-                    c0.bwd_input(dt, seg=1, stat=dk)
                     del dt
-                dvec_next = dvec_next + dk[:, :self.kk]
                 del dsc, dlowp
                 # ---- DownBlock backward
                 dlow_s = dcl.slice(128 * (s - 1), 128 * s)

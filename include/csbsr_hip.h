@@ -64,6 +64,8 @@ typedef struct {
   float* out32;            /* optional fp32 output with arbitrary strides (planar NCHW: sc = H*W) or NULL */
   int64_t o32_sn, o32_sy, o32_sx, o32_sc;
   const float* bias;       /* fp32[cout] or NULL */
+  const float* cbias;      /* fp32 [N][16][coutp] or NULL: extra bias per (sample, border class of the output pixel) = the exact
+                              contribution of a folded spatially-constant input segment (see csbsr_border_class_fill) */
   int32_t act;             /* CSBSR_ACT_* */
   float act_slope;         /* LRELU slope */
   const float* prelu;      /* device scalar for CSBSR_ACT_PRELU */
@@ -101,6 +103,7 @@ typedef struct {
 int32_t csbsr_wgrad_splits(int32_t ca, int32_t ktot, int64_t npix);
 int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s);
 void csbsr_debug_set_wgrad_tr(int use_hw_transpose_read); /* test hook: 0 = scalar LDS transposition */
+void csbsr_debug_set_conv_glds(int mode);                 /* test hook: 0 = register-staged kernel only, 1 = 128x128 LDS-DMA, 2 = 256x128 */
 
 /* fp32 master weights W[D0][D1][KH][KW] (the reference's OIHW conv / IOHW deconv parameters, whose state_dict
  * layout is part of the drop-in boundary) -> packed fp16 operand [phase][rows_p][Kp] of csbsr_conv_forward.
@@ -113,7 +116,7 @@ int64_t csbsr_packed_weight_elems(int32_t kind, int32_t D0, int32_t D1, int32_t 
                                   int32_t seg0_real, int32_t seg1_real, int32_t nrows);
 int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,
                        int32_t stride, int32_t pad, int32_t seg0_real, int32_t seg1_real, int32_t row_off,
-                       int32_t nrows, csbsr_stream_t s);
+                       int32_t nrows, int32_t k_off, csbsr_stream_t s);   /* k_off: first contracted channel (sub-range packing) */
 /* packed fp32 wgrad slabs G[split][ca_padded][tap][b(padded segments)] -> grad[a][b_off + b][kh][kw] += scale * sum_split G
  * (grad is [D0][D1][KH][KW]; transpose_ab: a indexes D1 and b indexes D0) */
 int csbsr_unpack_wgrad(const float* g, float* grad, int32_t A, int32_t KH, int32_t KW, int32_t seg0_real,

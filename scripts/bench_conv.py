@@ -1,0 +1,49 @@
+"""Micro-benchmark of one convolution shape through the C ABI (GPU): TF/s of forward / dgrad / wgrad."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from csbsr_amd import _lib as L
+from csbsr_amd.engine import Engine, Conv, FM, pad8
+
+def run(name, N, H, W, cin, cout, k, s, p, d=1, tr=False, iters=10, what=("fwd", "fwd_noepi")):
+    eng = Engine()
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    params = {"l.weight": (torch.randn(wshape, device="cuda") / (cin * k * k) ** 0.5), "l.bias": torch.zeros(cout, device="cuda")}
+    conv = Conv(eng, "l", params, k, s, p, d, transposed=tr, bias=True, act=L.ACT_LRELU, slope=0.1)
+    x = FM(torch.randn(N, H, W, pad8(cin), device="cuda", dtype=torch.float16), cin)
+    OH, OW = conv.out_size(H, W)
+    y = eng.new(N, OH, OW, cout)
+    dy = FM(torch.randn(N, OH, OW, pad8(cout), device="cuda", dtype=torch.float16), cout)
+    dx = eng.new(N, H, W, cin)
+    taps = k * k if not tr else ((k + s - 1) // s) ** 2
+    flops = 2.0 * N * OH * OW * cout * cin * taps
+    if tr: flops = 2.0 * N * OH * OW * cout * cin * taps
+    res = {}
+    for w_ in what:
+        fn = {"fwd": lambda: conv.fwd(x, out=y), "fwd_noepi": lambda: conv._launch((x,), conv._pack("fwd", 2 if tr else 0, cin, 0, 0, cout, s, p), tr, k, s, p, d, H, W, OH, OW, cout, y, None, None, 0, 0.0, None, None, None, 0, False, None, 0, -12345.0), "dgrad": lambda: conv.bwd_input(dy, out=dx, in_hw=(H, W)), "wgrad": lambda: conv.bwd_weights(dy, x)}[w_]
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        res[w_] = (ms, flops / ms / 1e9)
+    print(f"{name:28s} " + "  ".join(f"{k_}: {v[0]:7.3f} ms {v[1]:7.1f} TF/s" for k_, v in res.items()))
+
+if __name__ == "__main__":
+    sel = sys.argv[1] if len(sys.argv) > 1 else "all"
+    it = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    if len(sys.argv) > 3:
+        L.load().csbsr_debug_set_conv_glds(int(sys.argv[3]))
+    shapes = {
+        "sft825": (1, 448, 448, 825, 825, 3, 1, 1),
+        "conv8s4": (1, 1792, 1792, 128, 128, 8, 4, 2),
+        "deconv8s4": (1, 448, 448, 128, 128, 8, 4, 2, 1, True),
+        "res512": (8, 224, 224, 512, 512, 3, 1, 1),
+        "hr32": (1, 1792, 1792, 32, 32, 3, 1, 1),
+        "gemm1x1": (1, 1792, 1792, 128, 128, 1, 1, 0),
+    }
+    for n, sh in shapes.items():
+        if sel in ("all", n):
+            run(n, *sh, iters=it)

@@ -44,6 +44,8 @@ CASES = [
     (24, 16, 12, 8, 2, 1, True, 4, 4),
     (24, 16, 12, 8, 2, 1, False, 32, 32),
     (200, 136, 3, 1, 1, 1, False, 8, 8),
+    (64, 128, 3, 1, 1, 1, False, 192, 190),        # > 65536 pixels: the 256x128 LDS-DMA kernel, ragged last tile
+    (128, 192, 8, 4, 2, 1, True, 96, 96),          # LDS-DMA kernel, transposed, two cout tiles (second one half empty)
 ]
 
 
