@@ -20,11 +20,12 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-# as-executed algorithmic work per image, fwd+bwd, x4 / LR 448 / PSPNet is 108.3 TFLOP / 249 GB.
-# This build folds ONE constant-operand convolution exactly (fe_kernel.0 on the expanded kernel code: 4 x 4.996 TFLOP
-# forward, x3 for fwd+dgrad+wgrad = 15.0 TFLOP; 37.8 GB of conv I/O replaced by 2.5 GB for the class-filled map), so
-# the reduced figures are the denominator (never divide folded run time into unfolded work).
-ALG_TFLOP_PER_IMG_448 = 108.3 - 15.0
+# Algorithmic work per image, fwd+bwd, x4 / LR 448 / PSPNet.  SURVEY.md section 8(d): 108.3 TFLOP / 249 GB as executed by the
+# reference.  This build folds the convolutions over spatially constant operands exactly (fe_kernel.0: 4 x 4.996 TFLOP forward;
+# the 441 kernel-code input channels of the six SFT conv0's: 6.66 TFLOP forward; x3 for fwd + dgrad + wgrad = 35.0 TFLOP), so
+# the reduced figures are the denominator (never divide folded run time into unfolded work).  Bytes: the folded
+# fe_kernel.0 conv I/O (37.8 GB) is replaced by the class-filled map (2.5 GB); the SFT code channels were never read from HBM.
+ALG_TFLOP_PER_IMG_448 = 108.3 - 35.0
 ALG_GB_PER_IMG_448 = 249.0 - 37.8 + 2.5
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
@@ -69,7 +70,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
     ap.add_argument("--lr-size", type=int, default=448)
     ap.add_argument("--micro-batch", type=int, default=1)
-    ap.add_argument("--max-resident", type=int, default=5, help="micro-batches whose KBPN activations stay resident for backward")
+    ap.add_argument("--max-resident", type=int, default=6, help="micro-batches whose KBPN activations stay resident for backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -169,7 +170,7 @@ def main():
                "loss": round(last, 5),
                "step_roofline": {"hbm_frac": round(ALG_GB_PER_IMG_448 * pix / per_img_s / HBM_PEAK_GBS, 4),
                                  "mfma_frac": round(ALG_TFLOP_PER_IMG_448 * pix / per_img_s / MFMA_PEAK_TFLOPS, 4),
-                                 "note": "algorithmic work per image at LR 448: SURVEY.md 8(d) as-executed 108.3 TFLOP / 249 GB minus the one folded constant-operand conv (fe_kernel.0) = 93.3 TFLOP / 213.7 GB"},
+                                 "note": "algorithmic work per image at LR 448 after exact constant-operand folding (fe_kernel.0 + SFT code channels): 73.3 TFLOP / 213.7 GB (SURVEY.md 8(d) as-executed: 108.3 TFLOP / 249 GB)"},
                "roofline": roof,
                "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
         if not args.no_cpu_baseline and world == 1:

@@ -24,6 +24,7 @@ struct ConvK {
   int stat_mode; float* stat;
   float out_scale;
   unsigned tiles_m, tiles_n;
+  int direct_epi;            // 1: register-direct epilogue when no statistics are requested
 };
 
 // weight rows are padded so that a 128-row tile never reads past the buffer when the wide tile is used
@@ -141,5 +142,6 @@ __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const 
   }
 }
 
+extern int g_conv_direct_epi;
 bool conv_glds_eligible(const ConvK& k);
 int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st);

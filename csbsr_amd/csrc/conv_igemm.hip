@@ -84,6 +84,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   constexpr int RPP = 256 / SEGS;             // rows per pass: 32
   constexpr int XCH = BM / RPP;               // 4 patch chunks per thread
   const int seg = tid % SEGS;
+  // hoisted out of the K loop: per row a 64-bit element offset for tap (0,0) in each segment and one validity bit per tap;
+  // per slice only the thread's (tap, channel) cursor and two running tap displacements change
+  long off0[XCH], off1[XCH];
+  unsigned long long tapmask[XCH];
+  const int ntaps = p.KHt * p.KWt;
+  const bool use_mask = ntaps <= 64 && p.Kp >= 12 * BK;     // short-K layers: the precompute costs more than it saves (measured)
   int rn[XCH], riy[XCH], rix[XCH];
 #pragma unroll
   for (int j = 0; j < XCH; ++j) {
@@ -91,10 +97,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     rn[j] = sRow[r * 3];
     riy[j] = sRow[r * 3 + 1] * in_step + base_y;
     rix[j] = sRow[r * 3 + 2] * in_step + base_x;
+    off0[j] = rn[j] * p.in[0].sn + riy[j] * p.in[0].sy + rix[j] * p.in[0].sx;
+    off1[j] = rn[j] * p.in[1].sn + riy[j] * p.in[1].sy + rix[j] * p.in[1].sx;
+    unsigned long long m = 0;
+    if (rn[j] >= 0 && use_mask) {
+      int iy = riy[j], ix = rix[j], tkx = 0;          // walk the taps without integer division
+      for (int t = 0; t < ntaps; ++t) {
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) m |= 1ull << t;
+        ix += tap_step;
+        if (++tkx == p.KWt) { tkx = 0; ix = rix[j]; iy += tap_step; }
+      }
+    }
+    tapmask[j] = m;
   }
-  // running (tap, channel) of this thread's segment
-  int kc = seg * 8, ky = 0, kx = 0;
-  while (kc >= p.ctot) { kc -= p.ctot; if (++kx == p.KWt) { kx = 0; ++ky; } }
+  // running (tap, channel) cursor of this thread's 16-byte segment, and the tap displacement in each segment's strides
+  int kc = seg * 8, ky = 0, kx = 0, tapi = 0;
+  long td0 = 0, td1 = 0;
+  auto next_tap = [&]() {
+    ++tapi;
+    if (++kx == p.KWt) {
+      kx = 0; ++ky;
+      td0 += tap_step * (p.in[0].sy - (long)(p.KWt - 1) * p.in[0].sx);
+      td1 += tap_step * (p.in[1].sy - (long)(p.KWt - 1) * p.in[1].sx);
+    } else {
+      td0 += tap_step * p.in[0].sx;
+      td1 += tap_step * p.in[1].sx;
+    }
+  };
+  while (kc >= p.ctot) { kc -= p.ctot; next_tap(); }
 
   constexpr int WCH = (BN * SEGS + 255) / 256;  // weight chunks per thread
   h8 gx[XCH], gw[WCH];
@@ -112,21 +142,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     }
     // patches
     const bool kvalid = ky < p.KHt;
-    const csbsr_seg_t& sgm = (kc < p.c0) ? p.in[0] : p.in[1];
-    const int cc = (kc < p.c0) ? kc : kc - p.c0;
-    const half_t* base = reinterpret_cast<const half_t*>(sgm.ptr) + cc;
-    const int dy = ky * tap_step, dx = kx * tap_step;
+    const bool s0 = kc < p.c0;
+    const half_t* base = s0 ? reinterpret_cast<const half_t*>(p.in[0].ptr) + kc + td0
+                            : reinterpret_cast<const half_t*>(p.in[1].ptr) + (kc - p.c0) + td1;
+    const unsigned long long bit = (use_mask && tapi < 64) ? (1ull << tapi) : 0ull;
 #pragma unroll
     for (int j = 0; j < XCH; ++j) {
-      const int iy = riy[j] + dy, ix = rix[j] + dx;
+      bool ok;
+      if (use_mask) ok = kvalid && (tapmask[j] & bit);
+      else {
+        const int iy = riy[j] + ky * tap_step, ix = rix[j] + kx * tap_step;
+        ok = kvalid && rn[j] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      }
       h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (kvalid && rn[j] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-        v = *reinterpret_cast<const h8*>(base + rn[j] * sgm.sn + iy * sgm.sy + ix * sgm.sx);
+      if (ok) v = *reinterpret_cast<const h8*>(base + (s0 ? off0[j] : off1[j]));
       gx[j] = v;
     }
     // advance by one K slice
     kc += BK;
-    while (kc >= p.ctot) { kc -= p.ctot; if (++kx == p.KWt) { kx = 0; ++ky; } }
+    while (kc >= p.ctot) { kc -= p.ctot; next_tap(); }
   };
   auto store_tile = [&]() {
 #pragma unroll
@@ -175,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   // ---- epilogue: fp32 tile -> LDS [pixel][cout] in halves of HB couts (keeps LDS <= the main-loop footprint so three
   // workgroups fit per CU), then channel-contiguous 8-wide processing
   const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
-  if (p.stat_mode == CSBSR_STAT_NONE) {       // register-direct epilogue (conv_common.h)
+  if (p.stat_mode == CSBSR_STAT_NONE && p.direct_epi) {       // register-direct epilogue (conv_common.h)
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
       const int row = wp * PW + b * 32 + (lane & 31);
@@ -305,6 +339,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   CSBSR_CHECK(d->res_mode != CSBSR_RES_FMA || d->res2, "conv: FMA needs res2");
   k.accumulate = d->accumulate; k.stat_mode = d->stat_mode; k.stat = d->stat;
   k.out_scale = d->out_scale;
+  k.direct_epi = g_conv_direct_epi;
   CSBSR_CHECK(d->stat_mode == CSBSR_STAT_NONE || d->stat, "conv: stat_mode set without stat buffer");
   int nphase = 1;
   long maxM;

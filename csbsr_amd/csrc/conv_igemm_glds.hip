@@ -80,9 +80,11 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     off1[i] = n * p.in[1].sn + iy0 * p.in[1].sy + ix0 * p.in[1].sx + cch;
     unsigned long long m = 0;
     if (n >= 0) {
+      int iy = iy0, ix = ix0, tkx = 0;                // walk the taps without integer division
       for (int t = 0; t < p.KHt * p.KWt; ++t) {
-        const int iy = iy0 + (t / p.KWt) * tap_step, ix = ix0 + (t % p.KWt) * tap_step;
         if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) m |= 1ull << t;
+        ix += tap_step;
+        if (++tkx == p.KWt) { tkx = 0; ix = ix0; iy += tap_step; }
       }
     }
     tapmask[i] = m;
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   __syncthreads();
 
   const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
-  if (p.stat_mode == CSBSR_STAT_NONE) {       // register-direct epilogue
+  if (p.stat_mode == CSBSR_STAT_NONE && p.direct_epi) {       // register-direct epilogue
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int row = wm * 64 + b * 32 + (lane & 31);
@@ -283,7 +285,8 @@ static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
 }
 
 static int g_glds_mode = 2;      // 0: off, 1: 128x128 x2 stages only, 2: + 256x128 x3 stages for long-K stride-1 layers
-extern "C" void csbsr_debug_set_conv_glds(int mode) { g_glds_mode = mode; }
+int g_conv_direct_epi = 0;      // measured: 32-byte store segments lose to the LDS-staged 128-byte ones on the tile kernels
+extern "C" void csbsr_debug_set_conv_glds(int mode) { g_glds_mode = mode & 7; g_conv_direct_epi = (mode & 8) ? 1 : 0; }
 
 // eligibility: MFMA-bound shapes only
 bool conv_glds_eligible(const ConvK& k) {

@@ -956,8 +956,106 @@ extern "C" int csbsr_border_class_fill(const float* V, void* out, int64_t ld, in
   CSBSR_LAUNCH_CHECK("csbsr_border_class_fill");
   return 0;
 }
+// fast path for real image sizes: (1) plain total over all pixels, (2) the O(perimeter) border pixels binned per class in LDS by one
+// workgroup per (sample, edge), (3) interior = total - sum of the border classes.  No contended global atomics.
+__global__ __launch_bounds__(256) void bcs_total_kernel(const half_t* x, long ld, float* sums, long hw, int c8, int chunks) {
+  __shared__ float sred[256][8];
+  const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  const int cpb = c8 < 256 ? c8 : 256, ppb = 256 / cpb;
+  const int ch = threadIdx.x % cpb, pl = threadIdx.x / cpb;
+  const long per = (hw + chunks - 1) / chunks;
+  const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;
+  for (int cbase = 0; cbase < c8; cbase += cpb) {
+    const int cc = cbase + ch;
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    if (cc < c8 && pl < ppb)
+      for (long px = beg + pl; px < end; px += ppb) {
+        const h8 v = *reinterpret_cast<const h8*>(x + ((long)n * hw + px) * ld + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+      }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sred[threadIdx.x][e] = a[e];
+    __syncthreads();
+    if (threadIdx.x < cpb && cbase + threadIdx.x < c8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float s_ = 0.f;
+        for (int q = 0; q < ppb; ++q) s_ += sred[q * cpb + threadIdx.x][e];
+        atomicAdd(sums + (long)n * 16 * c8 * 8 + (cbase + threadIdx.x) * 8 + e, s_);
+      }
+    }
+    __syncthreads();
+  }
+}
+// grid = N * 4 edges * groups of 32 channel chunks; block: 32 chunk lanes x 8 pixel lanes
+__global__ __launch_bounds__(256) void bcs_edges_kernel(const half_t* x, long ld, float* sums, int H, int W, int c8) {
+  __shared__ float sbin[3][32][8];           // this edge touches at most 3 classes: edge, its two corners
+  const int groups = (c8 + 31) / 32;
+  int b = blockIdx.x;
+  const int g = b % groups; b /= groups;
+  const int edge = b % 4; const int n = b / 4;
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int cc = g * 32 + cl;
+  for (int i = threadIdx.x; i < 3 * 32 * 8; i += 256) (&sbin[0][0][0])[i] = 0.f;
+  __syncthreads();
+  // edges: 0 top row, 1 bottom row (full rows incl. corners), 2 left col, 3 right col (rows 1..H-2 only: corners belong to the rows)
+  const int len = edge < 2 ? W : H - 2;
+  float a[3][8];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[k][e] = 0.f;
+  if (cc < c8)
+    for (int i = pl; i < len; i += 8) {
+      int y, xx;
+      if (edge == 0) { y = 0; xx = i; } else if (edge == 1) { y = H - 1; xx = i; } else if (edge == 2) { y = i + 1; xx = 0; } else { y = i + 1; xx = W - 1; }
+      const h8 v = *reinterpret_cast<const h8*>(x + (((long)n * H + y) * W + xx) * ld + cc * 8);
+      const int k = (edge < 2) ? (xx == 0 ? 1 : (xx == W - 1 ? 2 : 0)) : 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[k][e] += (float)v[e];
+    }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (a[k][e] != 0.f) atomicAdd(&sbin[k][cl][e], a[k][e]);
+  __syncthreads();
+  if (pl == 0 && cc < c8) {
+    const int base_cls = edge == 0 ? 8 : (edge == 1 ? 4 : (edge == 2 ? 2 : 1));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (edge >= 2 && k > 0) break;
+      const int cls = base_cls + (k == 1 ? 2 : (k == 2 ? 1 : 0));
+      float* dst = sums + ((long)n * 16 + cls) * c8 * 8 + cc * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e] = sbin[k][cl][e];       // exactly one block owns each (n, class, channel)
+    }
+  }
+}
+__global__ void bcs_fixup_kernel(float* sums, int N, int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * c) return;
+  const int n = i / c, ch = i % c;
+  float* s_ = sums + (long)n * 16 * c + ch;
+  float border = 0.f;
+  for (int k = 1; k < 16; ++k) border += s_[(long)k * c];
+  s_[0] -= border;
+}
 extern "C" int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
   CSBSR_CHECK(x && sums && c % 8 == 0, "border_class_sums: bad args");
+  if (H >= 3 && W >= 3 && (long)H * W >= 4096) {
+    const long hw = (long)H * W;
+    int chunks = (int)((hw + 4095) / 4096);
+    if (chunks > 2048) chunks = 2048;
+    hipLaunchKernelGGL(bcs_total_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks);
+    hipLaunchKernelGGL(bcs_edges_kernel, dim3(N * 4 * ((c / 8 + 31) / 32)), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, H, W, c / 8);
+    hipLaunchKernelGGL(bcs_fixup_kernel, dim3((N * c + 255) / 256), dim3(256), 0, ST(s), sums, N, c);
+    CSBSR_LAUNCH_CHECK("csbsr_border_class_sums");
+    return 0;
+  }
   int chunks = (int)(((long)H * W + 16383) / 16384);
   if (chunks < 1) chunks = 1;
   if (chunks > 512) chunks = 512;

@@ -118,7 +118,7 @@ class _JointBase(nn.Module):
                 _init_reference_style(full, t.data, gen)
         self._rt = None
         self.micro_batch = 1
-        self.max_resident = 5           # micro-batches whose KBPN activations stay in HBM for the backward (~30 GB each at LR 448)
+        self.max_resident = 6           # micro-batches whose KBPN activations stay in HBM for the backward (~30 GB each at LR 448)
         self.dropout_enabled = True
         self.dropout_masks = None     # tests may inject {name: [B,C] fp32} keep-masks
 

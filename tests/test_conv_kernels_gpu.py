@@ -44,6 +44,9 @@ CASES = [
     (24, 16, 12, 8, 2, 1, True, 4, 4),
     (24, 16, 12, 8, 2, 1, False, 32, 32),
     (200, 136, 3, 1, 1, 1, False, 8, 8),
+    (32, 32, 3, 1, 1, 1, False, 40, 70),           # streaming small-channel kernel, ragged 64-pixel strips
+    (49, 49, 3, 1, 1, 1, False, 17, 64),           # two cout tiles, channel padding 49 -> 56
+    (56, 32, 1, 1, 0, 1, False, 12, 128),          # 1x1
     (64, 128, 3, 1, 1, 1, False, 192, 190),        # > 65536 pixels: the 256x128 LDS-DMA kernel, ragged last tile
     (128, 192, 8, 4, 2, 1, True, 96, 96),          # LDS-DMA kernel, transposed, two cout tiles (second one half empty)
 ]

@@ -343,3 +343,27 @@ def test_instance_norm_fwd_bwd():
     torch.cuda.synchronize()
     assert relmax(from_fm(fm), y.detach()) < 2e-3
     assert relmax(dx.cpu(), x.grad) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 11, 24), (1, 70, 66, 56), (2, 64, 64, 136)])
+def test_border_class_fill_and_sums(shape):
+    """constant-operand folding helpers: class fill and its adjoint (small-image atomics path and the large-image path)."""
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    N, H, W, Cc = shape
+    torch.manual_seed(9)
+    V = torch.randn(N, 16, Cc)
+    out = eng.new(N, H, W, Cc)
+    L.call("csbsr_border_class_fill", P(V.cuda()), P(out.t), out.ld, N, H, W, Cc, eng.stream)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    cls = (yy == 0) * 8 + (yy == H - 1) * 4 + (xx == 0) * 2 + (xx == W - 1) * 1
+    ref = V[:, cls.reshape(-1)].reshape(N, H, W, Cc).permute(0, 3, 1, 2)
+    x = r16(torch.randn(N, Cc, H, W))
+    sums = torch.zeros(N, 16, Cc, device="cuda")
+    fx = to_fm(x)
+    L.call("csbsr_border_class_sums", P(fx.t), fx.ld, P(sums), N, H, W, Cc, eng.stream)
+    torch.cuda.synchronize()
+    assert relmax(from_fm(out), r16(ref)) < 1e-6
+    onehot = torch.nn.functional.one_hot(cls.reshape(-1), 16).float()          # [HW, 16]
+    ref_s = torch.einsum("nchw,hwk->nkc", x, onehot.reshape(H, W, 16))
+    assert relmax(sums.cpu(), ref_s) < 2e-4
