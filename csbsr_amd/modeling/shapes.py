@@ -70,7 +70,8 @@ def kbpn_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, md=128, prefix="sr
     return d
 
 
-def pspnet_shapes(prefix="segmentation_model", n_classes=1):
+def pspnet_shapes(prefix="segmentation_model", n_classes=1, blur_dim=None, n_layer_blurskip=2):
+    """blur_dim: PSPNet_BlurSkip (pspnet.py:127-159): SFTLikeBlock(blur_dim+64 -> 64) + ConvBlock(64, 64, BN, ReLU), x n_layer."""
     d = OrderedDict()
     f = prefix + ".feats"
     d[f + ".conv1.weight"] = (64, 3, 7, 7)
@@ -96,6 +97,19 @@ def pspnet_shapes(prefix="segmentation_model", n_classes=1):
         d[f"{prefix}.{nm}.conv.0.bias"] = (co,)
         _bn(d, f"{prefix}.{nm}.conv.1", co)
         d[f"{prefix}.{nm}.conv.2.weight"] = (1,)
+    if blur_dim is not None:
+        cc = blur_dim + 64
+        for i in range(n_layer_blurskip):
+            sp = f"{prefix}.blur_skip.{2 * i}"
+            for br, last_act in (("conv_scale", None), ("conv_shift", None)):
+                d[f"{sp}.{br}.0.layer.weight"] = (cc, cc, 3, 3)
+                d[f"{sp}.{br}.0.layer.bias"] = (cc,)
+                d[f"{sp}.{br}.0.act.weight"] = (1,)
+                d[f"{sp}.{br}.1.layer.weight"] = (64, cc, 3, 3)
+                d[f"{sp}.{br}.1.layer.bias"] = (64,)
+            cp = f"{prefix}.blur_skip.{2 * i + 1}"
+            d[cp + ".layer.weight"] = (64, 64, 3, 3)
+            _bn(d, cp + ".norm", 64)
     d[prefix + ".final.0.weight"] = (n_classes, 64, 1, 1)
     d[prefix + ".final.0.bias"] = (n_classes,)
     d[prefix + ".aux.0.weight"] = (256, 256, 3, 3)
@@ -109,8 +123,11 @@ def joint_state_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, detector="P
     """state_dict order of JointModelWithLoss: segmentation_model.* first, then sr_model.*
     (MetaSSModel.__init__ runs before MetaSRModel's body, build_model.py:52-60,191-197)."""
     d = OrderedDict()
-    if detector != "PSPNet":
+    if detector == "PSPNet":
+        d.update(pspnet_shapes())
+    elif detector == "PSPNet_BlurSkip":
+        d.update(pspnet_shapes(blur_dim=ksize_out * ksize_out))
+    else:
         raise NotImplementedError(detector)
-    d.update(pspnet_shapes())
     d.update(kbpn_shapes(scale, num_stages, ksize, ksize_out))
     return d

@@ -55,6 +55,7 @@ class PathCfg:
         self.antialias = True                # torchvision>=0.17 Resize default on tensors
         self.oriented_w_iter = -1            # SOLVER.ORIENTED_WEIGHT_ITER
         self.sfo_sr_amp = 0.0                # SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP
+        self.detector = "PSPNet"             # MODEL.DETECTOR_TYPE: "PSPNet" | "PSPNet_BlurSkip"
         self.__dict__.update(kw)
 
     @property
@@ -319,14 +320,40 @@ def psp_upsample(P, bn, pre, x):
     return F.prelu(bn(pre + ".conv.1", p), P[pre + ".conv.2.weight"])
 
 
-def pspnet_forward(P, x, bn, drop=None):
-    """PSPNet.forward, pspnet.py:95-123 -> (main prob map, aux prob map)."""
+def sft_like_block(P, pre, feats, kvec):
+    """SFTLikeBlock.forward, blocks.py:105-120: cat(features, expanded kernel code) -> scale / shift branches."""
+    B, _, H, W = feats.shape
+    cond = kvec.reshape(B, -1, 1, 1).expand(B, kvec.shape[1], H, W)
+    cat = torch.cat((feats, cond), 1)
+
+    def cb(name, x, act):
+        y = F.conv2d(x, P[f"{pre}.{name}.layer.weight"], P[f"{pre}.{name}.layer.bias"], 1, 1)
+        if act == "prelu":
+            return F.prelu(y, P[f"{pre}.{name}.act.weight"])
+        return torch.sigmoid(y) if act == "sigmoid" else y
+    scale = cb("conv_scale.1", cb("conv_scale.0", cat, "prelu"), "sigmoid")
+    shift = cb("conv_shift.1", cb("conv_shift.0", cat, "prelu"), None)
+    return feats * scale + shift
+
+
+def pspnet_forward(P, x, bn, drop=None, kvec=None):
+    """PSPNet.forward, pspnet.py:95-123, and PSPNet_BlurSkip.forward, pspnet.py:173-207 when ``kvec`` (the GAP of the kernel
+    prediction, [B, K*K]) is given -> (main prob map, aux prob map)."""
     h, w = x.shape[2:]
     f, x3 = resnet34_dilated(P, bn, x)
     p = _drop(psp_module(P, f), drop, "drop_1")
     p = _drop(psp_upsample(P, bn, "segmentation_model.up_1", p), drop, "drop_2a")
     p = _drop(psp_upsample(P, bn, "segmentation_model.up_2", p), drop, "drop_2b")
     p = _drop(psp_upsample(P, bn, "segmentation_model.up_3", p), drop, "drop_2c")
+    if kvec is not None:
+        q = p
+        for i in range(4):
+            pre = f"segmentation_model.blur_skip.{i}"
+            if i % 2 == 0:
+                q = sft_like_block(P, pre, q, kvec)
+            else:       # blocks.ConvBlock(64, 64): conv (no bias) + BatchNorm2d + ReLU
+                q = F.relu(bn(pre + ".norm", F.conv2d(q, P[pre + ".layer.weight"], None, 1, 1)))
+        p = p + q
     a = F.conv2d(x3, P["segmentation_model.aux.0.weight"], None, 1, 1)
     a = _drop(F.relu(bn("segmentation_model.aux.1", a)), drop, "aux_drop")
     a = torch.sigmoid(F.conv2d(a, P["segmentation_model.aux.4.weight"], P["segmentation_model.aux.4.bias"]))
@@ -471,7 +498,7 @@ def joint_forward(P, cfg, it, x, hr, mask, kernel_gt, alpha=1.0, drop=None, trai
     """JointModelWithLoss.forward (KBPN + PSPNet branch), build_model.py:402-416."""
     sr, kvec = kbpn_forward(P, x, it, kernel_gt, cfg, taps)
     bn = BNState(P, training)
-    seg, aux = pspnet_forward(P, norm_sr(sr, cfg), bn, drop)
+    seg, aux = pspnet_forward(P, norm_sr(sr, cfg), bn, drop, kvec if cfg.detector == "PSPNet_BlurSkip" else None)
     sr_loss, kpred = kbpn_loss(sr, hr, x, kvec, kernel_gt, cfg, seg, mask, it)
     sdf = torch.from_numpy(compute_sdf(mask.cpu().numpy())).float()
     seg_loss = cfg.main_w * boundary_combo_loss(seg, mask, alpha, cfg, sdf) + \

@@ -61,9 +61,10 @@ class DropCapture:
         return x * keep[:, :, None, None]
 
 
-def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha=None, taps=False, overrides=(), seed=1121):
+def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha=None, taps=False, overrides=(), seed=1121,
+             detector="PSPNet"):
     ref_shims.ANTIALIAS = antialias
-    cfg, JM, J, FR = ref_shims.build_reference(scale=scale, overrides=overrides)
+    cfg, JM, J, FR = ref_shims.build_reference(detector=detector, scale=scale, overrides=overrides)
     model = JM(cfg, 1000, 0, FR(scale, "bicubic"))
     deterministic_fill(model)
     model.train()
@@ -110,6 +111,8 @@ def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha
                segment_preds=seg.detach().numpy(), sr_preds=sr.detach().numpy(), kernel_preds=kpred.detach().numpy(),
                grad_names=np.array(names), grad_norms=norms, grad_samples=samples,
                alpha=np.float64(model.ss_loss_fn.alpha), antialias=np.bool_(antialias), scale=np.int64(scale),
+               detector=np.array(detector), sfo_sr_amp=np.float64(cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP),
+               oriented_w_iter=np.int64(cfg.SOLVER.ORIENTED_WEIGHT_ITER),
                torch_version=np.array(torch.__version__))
     for kname, v in cap.masks.items():
         if v is not None:
@@ -142,7 +145,14 @@ def sdf_case():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    sdf_case()
+    if "--only-new" in sys.argv:        # keep the committed fixtures, add the missing ones
+        _rc = run_case
+
+        def run_case(name, *a, **k):     # noqa: F811
+            if not os.path.exists(os.path.join(HERE, name + ".npz")):
+                _rc(name, *a, **k)
+    else:
+        sdf_case()
     run_case("e2e_pspnet_it40000", 40000, taps=True, alpha=0.7)
     run_case("e2e_pspnet_it40000_dropout", 40000, dropout=True, alpha=0.7)
     run_case("e2e_pspnet_it1", 1)
@@ -150,3 +160,9 @@ if __name__ == "__main__":
     run_case("e2e_pspnet_it20001", 20001)
     run_case("e2e_pspnet_it40000_noaa", 40000, antialias=False, alpha=0.7)
     run_case("e2e_pspnet_it40000_lr24", 40000, lr=24, B=1, alpha=0.9, seed=5)
+    # BASELINE config 5: x8, PSPNet_BlurSkip, w^F (m^F = 1) on the SR loss, only blur_skip trainable
+    run_case("e2e_blurskip_x8_it40000", 40000, lr=8, scale=8, alpha=0.8, detector="PSPNet_BlurSkip", seed=9,
+             overrides=("SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP", 1.0, "SOLVER.ORIENTED_WEIGHT_ITER", 0))
+    # config 2 with the w^F weight on (README row 'CSBSR w/ PSPNet + w^F')
+    run_case("e2e_pspnet_wf_it40000", 40000, alpha=0.7, seed=11,
+             overrides=("SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP", 1.0, "SOLVER.ORIENTED_WEIGHT_ITER", 0))
