@@ -115,6 +115,11 @@ extern "C" int csbsr_blur_fwd(const float* x, const float* kvec, int32_t N, int3
   const int TW = 15 * stride + K;
   const size_t smem = (size_t)(K * K + TW * TW) * 4;
   dim3 grid((OW + 15) / 16, (OH + 15) / 16, N * C);
+  if (smem > 48 * 1024) {      // stride-8 windows (141^2 floats) need the opt-in above the default dynamic LDS limit
+    CSBSR_CHECK(smem <= 160 * 1024, "blur_fwd: window does not fit LDS");
+    BLUR_DISPATCH(K, hipFuncSetAttribute(reinterpret_cast<const void*>(blur_fwd_kernel<KK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)smem));
+  }
   BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_fwd_kernel<KK>), grid, dim3(256), smem, ST(s), x, kvec, C, H, W, OH, OW, stride, sub, y32,
                                       (half_t*)y16, y16_ld));
   CSBSR_LAUNCH_CHECK("csbsr_blur_fwd");

@@ -75,7 +75,7 @@ def _init_reference_style(name, t, gen):
     extractors.py:124-130 normal(0, sqrt(2/n)) convs, BN gamma=1 beta=0; pspnet PReLU 0.25, default Conv2d init elsewhere)."""
     with torch.no_grad():
         if t.dim() == 4:
-            if name.startswith("sr_model"):
+            if name.startswith("sr_model") or ".blur_skip." in name:      # blocks.py:53-61 (kaiming / xavier normal)
                 fan_in = t.shape[1] * t.shape[2] * t.shape[3]
                 t.normal_(0, math.sqrt(2.0 / fan_in), generator=gen)
             elif ".feats." in name:
@@ -98,17 +98,19 @@ def _init_reference_style(name, t, gen):
 class _JointBase(nn.Module):
     def __init__(self, cfg, antialias=True, device="cuda:0", seed=None):
         super().__init__()
-        if cfg.MODEL.SR != "KBPN" or cfg.MODEL.DETECTOR_TYPE != "PSPNet":
-            raise NotImplementedError(f"csbsr_amd builds KBPN + PSPNet; got SR={cfg.MODEL.SR} DETECTOR_TYPE={cfg.MODEL.DETECTOR_TYPE}")
+        if cfg.MODEL.SR != "KBPN" or cfg.MODEL.DETECTOR_TYPE not in ("PSPNet", "PSPNet_BlurSkip"):
+            raise NotImplementedError(f"csbsr_amd builds KBPN + PSPNet / PSPNet_BlurSkip; got SR={cfg.MODEL.SR} "
+                                      f"DETECTOR_TYPE={cfg.MODEL.DETECTOR_TYPE}")
         if cfg.MODEL.SR_PIXEL_SHUFFLE or cfg.MODEL.SUM_LR_ERROR_POS != "HR" or not cfg.MODEL.KBPN_KERNEL_SFT:
             raise NotImplementedError("only the default KBPN variant (deconv up-sampling, HR error sum, kernel SFT) is built")
         self.cfg = cfg
         self.pc = path_config(cfg, antialias)
         self.scale_factor = cfg.MODEL.SCALE_FACTOR
         self.norm_method = cfg.SOLVER.NORM_SR_OUTPUT
-        self.seg_model_name = "PSPNet"
+        self.seg_model_name = cfg.MODEL.DETECTOR_TYPE
+        self.blur_skip = self.seg_model_name == "PSPNet_BlurSkip"
         self._device = torch.device(device)
-        shapes = joint_state_shapes(self.pc.scale, self.pc.num_stages, self.pc.ksize, self.pc.ksize_out)
+        shapes = joint_state_shapes(self.pc.scale, self.pc.num_stages, self.pc.ksize, self.pc.ksize_out, self.seg_model_name)
         # registration order = reference state_dict order: segmentation_model.* then sr_model.*
         self.segmentation_model = _ParamGroup(shapes, "segmentation_model")
         self.sr_model = _ParamGroup(shapes, "sr_model")
@@ -116,6 +118,10 @@ class _JointBase(nn.Module):
         for full, t in self._named_full():
             if t.is_floating_point() and not full.endswith(("running_mean", "running_var")):
                 _init_reference_style(full, t.data, gen)
+        if self.blur_skip:        # build_model.py:352-368: everything but blur_skip.* is fixed
+            for full, t in self._named_full():
+                if isinstance(t, nn.Parameter):
+                    t.requires_grad = ".blur_skip." in full
         self._rt = None
         self.micro_batch = 1
         self.max_resident = 6           # micro-batches whose KBPN activations stay in HBM for the backward (~30 GB each at LR 448)
@@ -154,7 +160,7 @@ class _JointBase(nn.Module):
             self.to(self._device)
             eng = Engine(self._device)
             P = {k: (v.data if isinstance(v, nn.Parameter) else v) for k, v in self._named_full()}
-            self._rt = {"eng": eng, "P": P, "kbpn": KBPN(eng, P, self.pc), "psp": PSPNet(eng, P)}
+            self._rt = {"eng": eng, "P": P, "kbpn": KBPN(eng, P, self.pc), "psp": PSPNet(eng, P, blur_dim=self.pc.ksize_out ** 2 if self.blur_skip else None)}
         return self._rt
 
     def _invalidate(self):
@@ -236,7 +242,7 @@ class JointModelWithLoss(_JointBase):
         keep = training and torch.is_grad_enabled()
         saves = []
         for i, b0 in enumerate(range(0, B, mb)):
-            resident = keep and i < self.max_resident
+            resident = keep and i < self.max_resident and not self.blur_skip     # BlurSkip: KBPN is frozen, no backward through it
             s_, k_ = kbpn.forward(x[b0:b0 + mb], iter, kgt[b0:b0 + mb], save=resident)
             saves.append(kbpn.saved if resident else None)
             kbpn.saved = None
@@ -245,7 +251,7 @@ class JointModelWithLoss(_JointBase):
         xin, mean, invstd = self._norm_sr(sr32)
         drop = self.dropout_masks if self.dropout_masks is not None else psp.make_dropout(B, training, self.dropout_enabled)
         drop = {k: (None if v is None else v.to(self._device, torch.float32).contiguous()) for k, v in drop.items()}
-        seg32, aux32 = psp.forward(xin, drop, training)
+        seg32, aux32 = psp.forward(xin, drop, training, kvec=kvec if self.blur_skip else None)
         # ---- losses (forward sums only; gradients are produced in _hip_backward)
         hw = H * W
         sdf = eng.f32(B, 1, H, W, zero=False)
@@ -315,6 +321,8 @@ class JointModelWithLoss(_JointBase):
                 L.call("csbsr_segloss_finish", _ptr(p_), _ptr(st["mask"]), _ptr(st["sdf"]), B, hw, _ptr(sums), st["alpha"], pw[0], pw[1],
                        lw[0], lw[1], wgt, _ptr(gsc), None, _ptr(dp), 0, eng.stream)
             dxin = psp.backward(dseg32, daux32)
+            if self.blur_skip:                  # only blur_skip.* trains: no gradient leaves the segmentation net
+                return self._finish_backward(pnames, gs, ("segmentation_model",))
             if self.reducer is not None:        # segmentation gradients are final: exchange them under the KBPN backward
                 self.reducer.launch([rt["P"][k].gacc if getattr(rt["P"][k], "gacc_touched", False) else None
                                      for k in pnames if k.startswith("segmentation_model")])
@@ -329,6 +337,8 @@ class JointModelWithLoss(_JointBase):
             del dxin, dseg32, daux32
         else:
             psp.saved = None
+            if self.blur_skip:
+                return self._finish_backward(pnames, gs, ())
         # ---- SR loss gradients
         dkvec = eng.f32(B, pc.ksize_out ** 2)
         if dsr_loss is not None and bool((dsr_loss != 0).any()):
@@ -364,10 +374,15 @@ class JointModelWithLoss(_JointBase):
                 continue
             kbpn.forward(st["x"][b0:b0 + mb], st["iter"], st["kgt"][b0:b0 + mb], save=True)
             kbpn.backward(dsr32[b0:b0 + mb].contiguous(), dkvec[b0:b0 + mb].contiguous())
+        return self._finish_backward(pnames, gs, ("sr_model",))
+
+    def _finish_backward(self, pnames, gs, reduce_groups):
+        rt = self._rt
         self._st = None
         if self.reducer is not None:
-            self.reducer.launch([rt["P"][k].gacc if getattr(rt["P"][k], "gacc_touched", False) else None
-                                 for k in pnames if k.startswith("sr_model")])
+            for grp in reduce_groups:
+                self.reducer.launch([rt["P"][k].gacc if getattr(rt["P"][k], "gacc_touched", False) else None
+                                     for k in pnames if k.startswith(grp)])
             self.reducer.finish()
         inv = 1.0 / gs
         out = []
@@ -394,7 +409,8 @@ class JointModel(_JointBase):
         sr32, kvec = kbpn.forward(x, -1, kgt, save=False)
         sr32.clamp_(0, 1)
         xin, _, _ = self._norm_sr(sr32)
-        seg32, _ = psp.forward(xin, {k: None for k in ("drop_1", "drop_2a", "drop_2b", "drop_2c", "aux_drop")}, training=self.training)
+        seg32, _ = psp.forward(xin, {k: None for k in ("drop_1", "drop_2a", "drop_2b", "drop_2c", "aux_drop")}, training=self.training,
+                               kvec=kvec if self.blur_skip else None)
         psp.saved = None
         kvec = kvec / kvec.sum(1, keepdim=True)
         return sr32, seg32, kvec.reshape(B, 1, self.ksize, self.ksize)

@@ -33,9 +33,37 @@ class ConvBN:
         return raw, mean, invstd
 
 
+class _SFTLike:
+    """SFTLikeBlock (blocks.py:86-120): features * sigmoid(conv(prelu(conv(cat)))) + conv(prelu(conv(cat))), cat = features ++ the
+    spatially constant kernel code -- the constant 441 channels are folded into border-class biases (Conv.fwd_folded)."""
+
+    def __init__(self, eng, P, pre, cf, cconst):
+        def mk(name, act, prelu):
+            return Conv(eng, f"{pre}.{name}.layer", P, 3, 1, 1, bias=True, act=act, prelu=f"{pre}.{name}.act.weight" if prelu else False,
+                        split=(cf, cconst) if prelu else None)
+        self.sc0, self.sc1 = mk("conv_scale.0", L.ACT_PRELU, True), mk("conv_scale.1", L.ACT_SIGMOID, False)
+        self.sh0, self.sh1 = mk("conv_shift.0", L.ACT_PRELU, True), mk("conv_shift.1", L.ACT_NONE, False)
+
+    def convs(self):
+        return [self.sc0, self.sc1, self.sh0, self.sh1]
+
+
 class PSPNet:
-    def __init__(self, eng, params, prefix="segmentation_model"):
+    def __init__(self, eng, params, prefix="segmentation_model", blur_dim=None):
+        """blur_dim: build PSPNet_BlurSkip (pspnet.py:127-207) whose forward also takes the kernel code [B, blur_dim]; in that
+        variant only blur_skip.* is trainable (build_model.py:352-368), so the backward stops there."""
         self.eng, self.P, self.prefix = eng, params, prefix
+        self.blur_dim = blur_dim
+        self.blur_skip = []
+        if blur_dim is not None:
+            for i in range(2):
+                self.blur_skip.append((_SFTLike(eng, params, f"{prefix}.blur_skip.{2 * i}", 64, blur_dim),
+                                       ConvBN(eng, params, f"{prefix}.blur_skip.{2 * i + 1}.layer", f"{prefix}.blur_skip.{2 * i + 1}.norm",
+                                              64, 64, 3, 1, 1)))
+            m = torch.ones(4, 3)
+            m[2, 0] = m[3, 0] = 0.0          # first row/col: tap 0 reads outside
+            m[1, 2] = m[3, 2] = 0.0          # last row/col: tap 2 reads outside
+            self.Mtap = m.to(eng.device)
         e, P, f = eng, params, prefix + ".feats"
         self.stem = ConvBN(e, P, f + ".conv1", f + ".bn1", 3, 64, 7, 2, 3)
         self.blocks = []
@@ -65,6 +93,8 @@ class PSPNet:
     def all_convs(self):
         cs = [self.stem.conv] + [b[k].conv for b in self.blocks for k in ("c1", "c2", "down") if b[k] is not None]
         cs += self.psp_convs + [self.bottleneck] + [u.conv for u in self.ups] + [self.final, self.aux0.conv, self.aux4]
+        for sft, cb in self.blur_skip:
+            cs += sft.convs() + [cb.conv]
         return cs
 
     def invalidate(self):
@@ -81,11 +111,13 @@ class PSPNet:
         return out
 
     # ------------------------------------------------------------------ forward
-    def forward(self, xin, drop, training=True):
-        """xin: FM [B,H,W,8] (3 real channels, already normalised).  Returns (seg32, aux32) fp32 [B,1,H,W]."""
+    def forward(self, xin, drop, training=True, kvec=None):
+        """xin: FM [B,H,W,8] (3 real channels, already normalised); kvec [B, blur_dim] fp32 for the BlurSkip variant.
+        Returns (seg32, aux32) fp32 [B,1,H,W]."""
         e = self.eng
         B, H, W = xin.N, xin.H, xin.W
         sv = {"xin": xin, "drop": drop}
+        keep_trunk = self.blur_dim is None      # BlurSkip: the trunk is frozen, nothing of it is needed by the backward
         raw, m, iv = self.stem.fwd(xin, training)
         a = self.stem.bn.apply(raw, m, iv, act=L.ACT_RELU)
         PH, PW = (a.H + 2 - 3) // 2 + 1, (a.W + 2 - 3) // 2 + 1
@@ -111,7 +143,7 @@ class PSPNet:
                 cat = e.new(B, r2.H, r2.W, 2560)
                 out = cat.slice(2048, 2560)
             y = blk["c2"].bn.apply(r2, m2, i2, act=L.ACT_RELU, res=res, out=out)
-            bsv.append((x, r1, m1, i1, a1, r2, m2, i2, res, dsv, y))
+            bsv.append((x, r1, m1, i1, a1, r2, m2, i2, res, dsv, y) if keep_trunk else None)
             x = y
             if blk["layer"] == 3 and (bi + 1 == nb or self.blocks[bi + 1]["layer"] == 4):
                 x3 = y
@@ -136,9 +168,11 @@ class PSPNet:
             raw, m, iv = up.fwd(u, training)
             last = j == 2
             y = up.bn.apply(raw, m, iv, act=L.ACT_PRELU, prelu=self.up_prelu[j], drop=drop[names[j]] if last else None)
-            usv.append((cur, cur_drop, u, raw, m, iv, y))
+            usv.append((cur, cur_drop, u, raw, m, iv, y) if keep_trunk else None)
             cur, cur_drop = y, drop[names[j]]
         sv["ups"] = usv
+        if self.blur_dim is not None:
+            cur = self._blur_skip_fwd(cur, kvec, training, sv)
         seg32 = e.f32(B, 1, H, W, zero=False)
         self.final.fwd(cur, out32=seg32)
         # aux head on layer3 output
@@ -150,18 +184,75 @@ class PSPNet:
         L.call("csbsr_bilinear32_fwd", _ptr(aux_lo), _ptr(aux32), B, x3.H, x3.W, H, W, 1, e.stream)
         sv["aux"] = (x3, ra, ma, ia, aa, aux_lo)
         sv["seg32"], sv["p3"] = seg32, cur
+        if not keep_trunk:
+            sv["stem"] = sv["psp"] = sv["aux"] = None
         self.saved = sv
         return seg32, aux32
 
+    # ------------------------------------------------------------------ BlurSkip branch (pspnet.py:191-198)
+    def _blur_skip_fwd(self, p, kvec, training, sv):
+        e = self.eng
+        q, bsv = p, []
+        for sft, cb in self.blur_skip:
+            t1, f1 = sft.sc0.fwd_folded(q, kvec, self.Mtap)
+            sc = sft.sc1.fwd(t1)
+            t2, f2 = sft.sh0.fwd_folded(q, kvec, self.Mtap)
+            y = sft.sh1.fwd(t2, res=q, res2=sc, res_mode=L.RES_FMA)              # q * scale + shift
+            raw, m, iv = cb.fwd(y, training)
+            z = cb.bn.apply(raw, m, iv, act=L.ACT_RELU)
+            bsv.append((q, t1, f1, sc, t2, f2, y, raw, m, iv, z))
+            q = z
+        out = e.new(p.N, p.H, p.W, p.c)
+        L.call("csbsr_axpby", p.npix, p.cp, _ptr(p.t), p.ld, 1.0, _ptr(q.t), q.ld, 1.0, _ptr(out.t), out.ld, e.stream)    # p + _p
+        sv["blur_skip"] = bsv
+        return out
+
+    def _blur_skip_bwd(self, d):
+        """d: gradient wrt (p + _p).  Accumulates the blur_skip.* gradients; nothing upstream of it is trainable."""
+        e = self.eng
+        bsv = self.saved["blur_skip"]
+
+        def act_bwd(conv, dout, out):
+            e.epilogue_bwd(dout, out=out, act=conv.act, slope=conv.slope, prelu=conv.prelu, dpre=dout, dbias=grad_acc(conv.b),
+                           dprelu=None if conv.prelu is None else grad_acc(conv.prelu), creal=conv.cout)
+            return dout
+
+        for i in (1, 0):
+            sft, cb = self.blur_skip[i]
+            q, t1, f1, sc, t2, f2, y, raw, m, iv, z = bsv[i]
+            bsv[i] = None
+            draw = cb.bn.backward(d, raw, m, iv, act=L.ACT_RELU)
+            cb.conv.bwd_weights(draw, y)
+            dy = cb.conv.bwd_input(draw)
+            del draw, d
+            need_dq = i > 0                   # block 0's input is the frozen trunk's output
+            dq = e.new(q.N, q.H, q.W, q.c) if need_dq else None
+            dsc = e.new(q.N, q.H, q.W, q.c)
+            e.epilogue_bwd(dy, out=y, res=q, res2=sc, res_mode=L.RES_FMA, dpre=dy, dres=dq, dres2=dsc, dbias=grad_acc(sft.sh1.b),
+                           creal=sft.sh1.cout)
+            for c1, c0, t, dz, fold in ((sft.sh1, sft.sh0, t2, dy, f2), (sft.sc1, sft.sc0, t1, None, f1)):
+                if dz is None:
+                    dz = act_bwd(c1, dsc, sc)
+                c1.bwd_weights(dz, t)
+                dt = c1.bwd_input(dz)
+                act_bwd(c0, dt, t)
+                c0.bwd_weights_folded(dt, q, fold, self.Mtap)
+                if need_dq:
+                    c0.bwd_input(dt, seg=0, out=dq, accumulate=True)
+                del dt
+            del dy, dsc
+            d = dq
+
     # ------------------------------------------------------------------ backward
-    def _sigmoid_head_bwd(self, conv, dprob32, prob32, x):
+    def _sigmoid_head_bwd(self, conv, dprob32, prob32, x, frozen=False):
         """1-channel sigmoid head: returns dgrad wrt x; accumulates weight / bias grads."""
         e = self.eng
         B, _, H, W = prob32.shape
         dpre = e.new(B, H, W, 1)
         L.call("csbsr_sigmoid_bwd_to_nhwc8", _ptr(dprob32), _ptr(prob32), _ptr(dpre.t), B * H * W, 1.0, e.stream)
-        e.epilogue_bwd(dpre, dbias=grad_acc(conv.b), creal=1)
-        conv.bwd_weights(dpre, x)
+        if not frozen:
+            e.epilogue_bwd(dpre, dbias=grad_acc(conv.b), creal=1)
+            conv.bwd_weights(dpre, x)
         return conv.bwd_input(dpre)
 
     def backward(self, dseg32, daux32):
@@ -170,6 +261,10 @@ class PSPNet:
         drop = sv["drop"]
         xin = sv["xin"]
         B, H, W = xin.N, xin.H, xin.W
+        if self.blur_dim is not None:
+            self._blur_skip_bwd(self._sigmoid_head_bwd(self.final, dseg32, sv["seg32"], sv["p3"], frozen=True))
+            self.saved = None
+            return None
         # aux head
         x3, ra, ma, ia, aa, aux_lo = sv["aux"]
         daux_lo = e.f32(B, 1, x3.H, x3.W, zero=False)

@@ -20,6 +20,15 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
 
+def golden_cfg(g):
+    """oracle PathCfg of a fixture (fixtures made before config 5 existed carry no detector / w^F keys)."""
+    from oracle import csbsr_oracle as O
+    kw = dict(antialias=bool(g["antialias"]), scale=int(g["scale"]))
+    if "detector" in g:
+        kw.update(detector=str(g["detector"]), sfo_sr_amp=float(g["sfo_sr_amp"]), oriented_w_iter=int(g["oriented_w_iter"]))
+    return O.PathCfg(**kw)
+
+
 def det_params(scale=4, num_stages=4, detector="PSPNet", requires_grad=True):
     shapes = joint_state_shapes(scale=scale, num_stages=num_stages, detector=detector)
     sd = det_state_dict(shapes)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_utils import load_golden, det_params, rel_err, max_rel_to_scale, fp16_storage_sim
+from golden_utils import load_golden, det_params, rel_err, max_rel_to_scale, fp16_storage_sim, golden_cfg
 from oracle import csbsr_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -23,6 +23,10 @@ def build_model(g, micro_batch=8):
     from csbsr_amd.utils.detfill import deterministic_fill
     cfg = base_cfg.clone()
     cfg.MODEL.SCALE_FACTOR = int(g["scale"])
+    if "detector" in g:
+        cfg.MODEL.DETECTOR_TYPE = str(g["detector"])
+        cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP = float(g["sfo_sr_amp"])
+        cfg.SOLVER.ORIENTED_WEIGHT_ITER = int(g["oriented_w_iter"])
     m = JointModelWithLoss(cfg, 1000, 0, None, antialias=bool(g["antialias"]))
     deterministic_fill(m.state_dict())
     m.ss_loss_fn.alpha = float(g["alpha"])
@@ -53,8 +57,8 @@ def run_hip(g, micro_batch=8):
 
 
 def run_oracle(g):
-    P = det_params()
-    cfg = O.PathCfg(antialias=bool(g["antialias"]), scale=int(g["scale"]))
+    cfg = golden_cfg(g)
+    P = det_params(scale=cfg.scale, detector=cfg.detector)
     t = lambda k: torch.from_numpy(g[k])
     drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
     out = O.joint_forward(P, cfg, int(g["it"]), t("x"), t("hr"), t("mask"), t("kernel"), alpha=float(g["alpha"]), drop=drop or None)
@@ -64,14 +68,15 @@ def run_oracle(g):
 
 
 @pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "e2e_pspnet_it10001",
-                                  "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24"])
+                                  "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24", "e2e_blurskip_x8_it40000",
+                                  "e2e_pspnet_wf_it40000"])
 def test_forward_matches_golden_and_oracle(case):
     g = load_golden(case)
     outs, grads, bufs = run_hip(g)
     # what fp16 storage of the reference arithmetic costs on this input (CPU emulation, see golden_utils)
     with fp16_storage_sim(), torch.no_grad():
-        P = det_params(requires_grad=False)
-        cfg = O.PathCfg(antialias=bool(g["antialias"]), scale=int(g["scale"]))
+        cfg = golden_cfg(g)
+        P = det_params(scale=cfg.scale, detector=cfg.detector, requires_grad=False)
         t = lambda k: torch.from_numpy(g[k])
         drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
         sim = O.joint_forward(P, cfg, int(g["it"]), t("x"), t("hr"), t("mask"), t("kernel"), alpha=float(g["alpha"]), drop=drop or None)
@@ -96,7 +101,8 @@ def run_oracle_fp16_sim(g):
         return run_oracle(g)
 
 
-@pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_pspnet_it1", "e2e_pspnet_it10001", "e2e_pspnet_it40000_dropout"])
+@pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_pspnet_it1", "e2e_pspnet_it10001", "e2e_pspnet_it40000_dropout",
+                                  "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000"])
 def test_gradients_match_oracle(case):
     """Per-parameter relative L2 error of the HIP gradients vs the fp32 oracle.
 
@@ -105,7 +111,9 @@ def test_gradients_match_oracle(case):
     reference arithmetic lands 5 % (last layers) to 35 % (first layers, KBPN) away from fp32, which the CPU emulation
     in golden_utils.fp16_storage_sim reproduces layer by layer (measured: emulation median 0.30, HIP median 0.28).
     So there the HIP error is bounded by the emulation's error per tensor, and the backward kernels themselves are
-    pinned tightly in test_conv_kernels_gpu.py / test_elementwise_gpu.py."""
+    pinned tightly in test_conv_kernels_gpu.py / test_elementwise_gpu.py.  (Per-tensor ratio HIP/emulation: 0.6 .. 2.2 measured -- two
+    realisations of the same noise -- hence the 2.5x; the medians agree within 5 %.)  The non-chaotic half of the joint gradient is
+    pinned directly by test_sr_loss_gradients_match_oracle."""
     g = load_golden(case)
     outs, grads, _ = run_hip(g)
     P, out, loss = run_oracle(g)
@@ -142,13 +150,45 @@ def test_gradients_match_oracle(case):
             bad.append((n, e))
     errs = np.array(errs)
     print(case, "grad rel-L2 vs fp32 oracle: median %.2e  p90 %.2e  max %.2e  (n=%d)" % (np.median(errs), np.percentile(errs, 90), errs.max(), len(errs)))
-    assert not bad, bad[:10]
     if joint:
         sims = np.array(sims)
         print(case, "fp16-storage emulation of the oracle: median %.2e  p90 %.2e  max %.2e" % (np.median(sims), np.percentile(sims, 90), sims.max()))
+    assert not bad, (len(bad), bad[:10])
+    if joint:
         assert np.median(errs) < 1.5 * np.median(sims) + 5e-3
     else:
         assert np.median(errs) < 5e-3
+
+
+@pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_pspnet_wf_it40000"])
+def test_sr_loss_gradients_match_oracle(case):
+    """d(mean sr_loss)/d(parameters) in the joint phase, with and without the w^F weight (a14): no BatchNorm stack in this path, so the
+    bound is direct.  The w^F map exp(|seg - mask|) is a detached function of the fp16 segmentation output (1.5e-2 off fp32 at this size),
+    which moves the weighted gradients by about that much: measured median 2.9e-3, max 1.5e-2."""
+    g = load_golden(case)
+    m, cfg = build_model(g)
+    t = lambda k: torch.from_numpy(g[k])
+    it = int(g["it"])
+    seg_l, sr_l, seg, sr, kp = m(it, t("x"), sr_targets=t("hr"), segment_targets=t("mask"), kernel_targets=t("kernel"))
+    sr_l.mean().backward()
+    grads = {k: v.grad for k, v in m._named_full() if isinstance(v, torch.nn.Parameter)}
+    oc = golden_cfg(g)
+    P = det_params(scale=oc.scale, detector=oc.detector)
+    out = O.joint_forward(P, oc, it, t("x"), t("hr"), t("mask"), t("kernel"), alpha=float(g["alpha"]))
+    out["sr_loss"].mean().backward()
+    errs = []
+    for n, p in P.items():
+        og = getattr(p, "grad", None)
+        if n.startswith("segmentation_model"):
+            assert grads.get(n) is None or float(grads[n].abs().max()) == 0.0, n
+            continue
+        if og is None or og.numel() == 1 or float(og.norm()) < 1e-9:
+            continue
+        assert grads[n] is not None, n
+        errs.append(rel_err(grads[n].cpu(), og))
+    errs = np.array(errs)
+    print(case, "SR-loss grads: median %.2e max %.2e (n=%d)" % (np.median(errs), errs.max(), len(errs)))
+    assert len(errs) > 100 and np.median(errs) < 5e-3 and errs.max() < 3e-2
 
 
 def test_micro_batching_is_exact():

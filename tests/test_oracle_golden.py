@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_utils import load_golden, det_params, rel_err, sample_idx
+from golden_utils import load_golden, det_params, rel_err, sample_idx, golden_cfg
 from oracle import csbsr_oracle as O
 
 CASES = ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "e2e_pspnet_it10001",
@@ -15,14 +15,6 @@ CASES = ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "
 # reference's per-sample loop, vector kernel vs expanded map)
 TOL_OUT = 2e-5
 TOL_GRAD = 3e-2   # fp32 evaluation-order noise: up to 1.1e-2 on kb.sr_reconst weights (7e-3 vs an fp64 run of the oracle), <3e-4 elsewhere
-
-
-def golden_cfg(g):
-    """PathCfg of a fixture (the fixtures made before config 5 existed carry no detector / w^F keys)."""
-    kw = dict(antialias=bool(g["antialias"]), scale=int(g["scale"]))
-    if "detector" in g:
-        kw.update(detector=str(g["detector"]), sfo_sr_amp=float(g["sfo_sr_amp"]), oriented_w_iter=int(g["oriented_w_iter"]))
-    return O.PathCfg(**kw)
 
 
 def run_oracle(g, grads=True):
