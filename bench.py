@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--lr-size", type=int, default=448)
     ap.add_argument("--micro-batch", type=int, default=1)
     ap.add_argument("--max-resident", type=int, default=6, help="micro-batches whose KBPN activations stay resident for backward")
+    ap.add_argument("--workload", default="pspnet_x4", choices=("pspnet_x4", "blurskip_x8"),
+                    help="pspnet_x4 = BASELINE config 2 (the bench line); blurskip_x8 = config 5 (x8, PSPNet_BlurSkip, w^F; use --lr-size 224 "
+                         "--batch 4) -- a coverage timing, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -92,6 +95,11 @@ def main():
     from csbsr_amd.parallel.reducer import broadcast_parameters
 
     cfg = base_cfg.clone()
+    x8 = args.workload == "blurskip_x8"
+    if x8:
+        cfg.MODEL.SCALE_FACTOR, cfg.MODEL.DETECTOR_TYPE = 8, "PSPNet_BlurSkip"
+        cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP, cfg.SOLVER.ORIENTED_WEIGHT_ITER = 1.0, 0
+    scale = cfg.MODEL.SCALE_FACTOR
     model = JointModelWithLoss(cfg, 9000, 40000, None, device=str(dev))
     model.micro_batch = args.micro_batch
     model.max_resident = args.max_resident
@@ -100,12 +108,12 @@ def main():
     if world > 1:
         broadcast_parameters(model)
         model.reducer = GradBucketReducer(side_stream=torch.cuda.Stream(dev))
-    opt = torch.optim.Adam(model.parameters(), lr=cfg.SOLVER.LR, betas=(0.9, 0.999), eps=1e-8)    # train.py:91
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.SOLVER.LR, betas=(0.9, 0.999), eps=1e-8)    # train.py:91
 
     B, lr = args.batch, args.lr_size
     # synthetic minibatch (seed differs per rank: each GPU gets its own shard of the global batch), resident in HBM
     gen_lr = min(lr, 112)           # generate at <=112 and tile: the CPU-side generator is plumbing, not the bench
-    x, hr, mask, k = make_batch(B, gen_lr, seed=1121 + rank)
+    x, hr, mask, k = make_batch(B, gen_lr, scale=scale, seed=1121 + rank)
     rep = lr // gen_lr
     if rep > 1:
         x, hr, mask = x.repeat(1, 1, rep, rep), hr.repeat(1, 1, rep, rep), mask.repeat(1, 1, rep, rep)
@@ -161,11 +169,11 @@ def main():
     if rank == 0:
         pix = (lr / 448.0) ** 2
         per_img_s = dt / (B * args.steps)
-        out = {"metric": "training imgs/s (448->1792 x4, PSPNet)", "value": round(imgs, 4), "unit": "imgs/s", "n_gpus": world,
+        out = {"metric": "training imgs/s (448->1792 x4, PSPNet)" if not x8 else "training imgs/s (x8, PSPNet_BlurSkip, w^F)", "value": round(imgs, 4), "unit": "imgs/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 1), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "fp16 storage / fp32 accumulate", "data": "synthetic",
-               "config": {"workload": f"CSBSR KBPN x4 + PSPNet, beta=0.3, joint phase (iter 40000), per-GPU batch {B}, "
-                                      f"LR {lr}x{lr} -> HR {lr * 4}x{lr * 4}, fwd+loss+bwd+Adam", "global_batch": B * world,
+               "config": {"workload": f"CSBSR KBPN x{scale} + {cfg.MODEL.DETECTOR_TYPE}, beta=0.3, joint phase (iter 40000), per-GPU batch {B}, "
+                                      f"LR {lr}x{lr} -> HR {lr * scale}x{lr * scale}, fwd+loss+bwd+Adam", "global_batch": B * world,
                           "micro_batch": args.micro_batch, "parallelism": f"dp{world}"},
                "loss": round(last, 5),
                "step_roofline": {"hbm_frac": round(ALG_GB_PER_IMG_448 * pix / per_img_s / HBM_PEAK_GBS, 4),
@@ -173,7 +181,9 @@ def main():
                                  "note": "algorithmic work per image at LR 448 after exact constant-operand folding (fe_kernel.0 + SFT code channels): 73.3 TFLOP / 213.7 GB (SURVEY.md 8(d) as-executed: 108.3 TFLOP / 249 GB)"},
                "roofline": roof,
                "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
-        if not args.no_cpu_baseline and world == 1:
+        if x8:
+            out["step_roofline"] = None          # the folded-work figures above are config 2's
+        if not args.no_cpu_baseline and world == 1 and not x8:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
