@@ -119,6 +119,70 @@ def pspnet_shapes(prefix="segmentation_model", n_classes=1, blur_dim=None, n_lay
     return d
 
 
+HRNET_W48 = (("stage2", 1, (48, 96)), ("stage3", 4, (48, 96, 192)), ("stage4", 3, (48, 96, 192, 384)))   # hrnet_config.py:46-73
+
+
+def hrnet_ocr_shapes(prefix="segmentation_model", n_classes=1):
+    """HRNet_W48_OCR (nets/hrnet.py:101-137) over HighResolutionNet hrnet48 (hrnet_backbone.py:295-503), registration order."""
+    d = OrderedDict()
+    b = prefix + ".backbone"
+
+    def cb(conv, norm, cin, cout, k, bias=False):
+        d[conv + ".weight"] = (cout, cin, k, k)
+        if bias:
+            d[conv + ".bias"] = (cout,)
+        _bn(d, norm, cout)
+    cb(b + ".conv1", b + ".bn1", 3, 64, 3)
+    cb(b + ".conv2", b + ".bn2", 64, 64, 3)
+    for i in range(4):
+        bp = f"{b}.layer1.{i}"
+        cb(bp + ".conv1", bp + ".bn1", 64 if i == 0 else 256, 64, 1)
+        cb(bp + ".conv2", bp + ".bn2", 64, 64, 3)
+        cb(bp + ".conv3", bp + ".bn3", 64, 256, 1)
+        if i == 0:
+            cb(bp + ".downsample.0", bp + ".downsample.1", 64, 256, 1)
+    prev = (256,)
+    for si, (stage, nmod, chans) in enumerate(HRNET_W48, 1):
+        tp = f"{b}.transition{si}"
+        for i, c in enumerate(chans):
+            if i < len(prev):
+                if prev[i] != c:
+                    cb(f"{tp}.{i}.0", f"{tp}.{i}.1", prev[i], c, 3)
+            else:
+                cb(f"{tp}.{i}.0.0", f"{tp}.{i}.0.1", prev[-1], c, 3)
+        for m in range(nmod):
+            mp = f"{b}.{stage}.{m}"
+            for i, c in enumerate(chans):
+                for blk in range(4):
+                    bp = f"{mp}.branches.{i}.{blk}"
+                    cb(bp + ".conv1", bp + ".bn1", c, c, 3)
+                    cb(bp + ".conv2", bp + ".bn2", c, c, 3)
+            for i, ci in enumerate(chans):
+                for j, cj in enumerate(chans):
+                    fp = f"{mp}.fuse_layers.{i}.{j}"
+                    if j > i:
+                        cb(fp + ".0", fp + ".1", cj, ci, 1)
+                    elif j < i:
+                        for k in range(i - j):
+                            cb(f"{fp}.{k}.0", f"{fp}.{k}.1", cj, ci if k == i - j - 1 else cj, 3)
+        prev = chans
+    cb(prefix + ".conv3x3.0", prefix + ".conv3x3.1.0", 720, 512, 3, bias=True)
+    ob = prefix + ".ocr_distri_head.object_context_block"
+    cb(ob + ".f_pixel.0", ob + ".f_pixel.1.0", 512, 256, 1, bias=True)
+    cb(ob + ".f_pixel.2", ob + ".f_pixel.3.0", 256, 256, 1, bias=True)
+    cb(ob + ".f_object.0", ob + ".f_object.1.0", 512, 256, 1, bias=True)
+    cb(ob + ".f_object.2", ob + ".f_object.3.0", 256, 256, 1, bias=True)
+    cb(ob + ".f_down.0", ob + ".f_down.1.0", 512, 256, 1, bias=True)
+    cb(ob + ".f_up.0", ob + ".f_up.1.0", 256, 512, 1, bias=True)
+    cb(prefix + ".ocr_distri_head.conv_bn_dropout.0", prefix + ".ocr_distri_head.conv_bn_dropout.1.0", 1024, 512, 1, bias=True)
+    d[prefix + ".cls_head.weight"] = (n_classes, 512, 1, 1)
+    d[prefix + ".cls_head.bias"] = (n_classes,)
+    cb(prefix + ".aux_head.0", prefix + ".aux_head.1.0", 720, 720, 3, bias=True)
+    d[prefix + ".aux_head.2.weight"] = (n_classes, 720, 1, 1)
+    d[prefix + ".aux_head.2.bias"] = (n_classes,)
+    return d
+
+
 def joint_state_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, detector="PSPNet"):
     """state_dict order of JointModelWithLoss: segmentation_model.* first, then sr_model.*
     (MetaSSModel.__init__ runs before MetaSRModel's body, build_model.py:52-60,191-197)."""
@@ -127,6 +191,8 @@ def joint_state_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, detector="P
         d.update(pspnet_shapes())
     elif detector == "PSPNet_BlurSkip":
         d.update(pspnet_shapes(blur_dim=ksize_out * ksize_out))
+    elif detector == "HRNet_OCR":
+        d.update(hrnet_ocr_shapes())
     else:
         raise NotImplementedError(detector)
     d.update(kbpn_shapes(scale, num_stages, ksize, ksize_out))

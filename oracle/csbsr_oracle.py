@@ -55,7 +55,7 @@ class PathCfg:
         self.antialias = True                # torchvision>=0.17 Resize default on tensors
         self.oriented_w_iter = -1            # SOLVER.ORIENTED_WEIGHT_ITER
         self.sfo_sr_amp = 0.0                # SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP
-        self.detector = "PSPNet"             # MODEL.DETECTOR_TYPE: "PSPNet" | "PSPNet_BlurSkip"
+        self.detector = "PSPNet"             # MODEL.DETECTOR_TYPE: "PSPNet" | "PSPNet_BlurSkip" | "HRNet_OCR"
         self.__dict__.update(kw)
 
     @property
@@ -364,6 +364,120 @@ def pspnet_forward(P, x, bn, drop=None, kvec=None):
 
 # ----------------------------------------------------------------------------- losses
 
+# ----------------------------------------------------------------------------- HRNet-W48 + OCR (BASELINE config 4)
+
+HRNET_W48 = (("stage2", 1, (48, 96)), ("stage3", 4, (48, 96, 192)), ("stage4", 3, (48, 96, 192, 384)))   # hrnet_config.py:46-73
+
+
+def _conv_bn(P, bn, conv, norm, x, stride=1, pad=1, relu=True):
+    y = bn(norm, F.conv2d(x, P[conv + ".weight"], P.get(conv + ".bias"), stride, pad))
+    return F.relu(y) if relu else y
+
+
+def hr_basic_block(P, bn, pre, x):
+    """hrnet_backbone.py:36-63 (no downsample inside the HRNet branches: in == out channels)."""
+    out = _conv_bn(P, bn, pre + ".conv1", pre + ".bn1", x)
+    out = _conv_bn(P, bn, pre + ".conv2", pre + ".bn2", out, relu=False)
+    return F.relu(out + x)
+
+
+def hr_bottleneck(P, bn, pre, x):
+    """hrnet_backbone.py:66-106."""
+    out = _conv_bn(P, bn, pre + ".conv1", pre + ".bn1", x, pad=0)
+    out = _conv_bn(P, bn, pre + ".conv2", pre + ".bn2", out)
+    out = _conv_bn(P, bn, pre + ".conv3", pre + ".bn3", out, pad=0, relu=False)
+    res = x
+    if (pre + ".downsample.0.weight") in P:
+        res = _conv_bn(P, bn, pre + ".downsample.0", pre + ".downsample.1", x, pad=0, relu=False)
+    return F.relu(out + res)
+
+
+def hr_module(P, bn, pre, xs):
+    """HighResolutionModule.forward, hrnet_backbone.py:271-297: 4 BasicBlocks per branch, then every output resolution i sums all
+    branches j (1x1 conv + BN + bilinear(align_corners=True) up for j > i, a chain of i-j stride-2 3x3 conv + BN (+ReLU between) for j < i)."""
+    nb = len(xs)
+    xs = list(xs)
+    for i in range(nb):
+        for b in range(4):
+            xs[i] = hr_basic_block(P, bn, f"{pre}.branches.{i}.{b}", xs[i])
+    outs = []
+    for i in range(nb):
+        y = None
+        for j in range(nb):
+            fp = f"{pre}.fuse_layers.{i}.{j}"
+            if j == i:
+                t = xs[j]
+            elif j > i:
+                t = _conv_bn(P, bn, fp + ".0", fp + ".1", xs[j], pad=0, relu=False)
+                t = F.interpolate(t, size=xs[i].shape[-2:], mode="bilinear", align_corners=True)
+            else:
+                t = xs[j]
+                for k in range(i - j):
+                    t = _conv_bn(P, bn, f"{fp}.{k}.0", f"{fp}.{k}.1", t, stride=2, relu=k != i - j - 1)
+            y = t if y is None else y + t
+        outs.append(F.relu(y))
+    return outs
+
+
+def hrnet_backbone(P, bn, pre, x):
+    """HighResolutionNet.forward, hrnet_backbone.py:505-545 (hrnet48; stem = two stride-2 3x3 convs)."""
+    x = _conv_bn(P, bn, pre + ".conv1", pre + ".bn1", x, stride=2)
+    x = _conv_bn(P, bn, pre + ".conv2", pre + ".bn2", x, stride=2)
+    for b in range(4):
+        x = hr_bottleneck(P, bn, f"{pre}.layer1.{b}", x)
+    ys = [x]
+    for si, (stage, nmod, chans) in enumerate(HRNET_W48, 1):
+        tp = f"{pre}.transition{si}"
+        xs = []
+        for i in range(len(chans)):
+            if i < len(ys):
+                if (f"{tp}.{i}.0.weight") in P:      # only transition1.0 (256 -> 48): channel counts match afterwards
+                    xs.append(_conv_bn(P, bn, f"{tp}.{i}.0", f"{tp}.{i}.1", ys[i]))
+                else:
+                    xs.append(ys[i])
+            else:                                   # new lowest-resolution branch from the previous lowest one
+                xs.append(_conv_bn(P, bn, f"{tp}.{i}.0.0", f"{tp}.{i}.0.1", ys[-1], stride=2))
+        for m in range(nmod):
+            xs = hr_module(P, bn, f"{pre}.{stage}.{m}", xs)
+        ys = xs
+    return ys
+
+
+def hrnet_ocr_forward(P, x, bn, drop=None):
+    """HRNet_W48_OCR.forward, nets/hrnet.py:139-158, with SpatialGather_Module (spatial_ocr_block.py:37-66) and
+    SpatialOCR_Module / _ObjectAttentionBlock (:114-305) for num_classes = 1 -> (main prob map, aux prob map)."""
+    pre = "segmentation_model"
+    H, W = x.shape[-2:]
+    ys = hrnet_backbone(P, bn, pre + ".backbone", x)
+    h, w = ys[0].shape[-2:]
+    feats = torch.cat([ys[0]] + [F.interpolate(t, size=(h, w), mode="bilinear", align_corners=True) for t in ys[1:]], 1)
+    a = _conv_bn(P, bn, pre + ".aux_head.0", pre + ".aux_head.1.0", feats)
+    out_aux = F.conv2d(a, P[pre + ".aux_head.2.weight"], P[pre + ".aux_head.2.bias"])
+    f = _conv_bn(P, bn, pre + ".conv3x3.0", pre + ".conv3x3.1.0", feats)
+    B, C = f.shape[:2]
+    # soft object region = softmax over pixels of the (single-class) aux logits; context = region-weighted mean feature
+    probs = F.softmax(out_aux.reshape(B, 1, -1), dim=2)
+    ctx = torch.matmul(probs, f.reshape(B, C, -1).permute(0, 2, 1)).permute(0, 2, 1).unsqueeze(3)          # [B, C, 1, 1]
+    ob = pre + ".ocr_distri_head.object_context_block"
+
+    def seq(name, t, n):
+        for i in range(n):
+            t = _conv_bn(P, bn, f"{ob}.{name}.{2 * i}", f"{ob}.{name}.{2 * i + 1}.0", t, pad=0)
+        return t
+    query = seq("f_pixel", f, 2).reshape(B, 256, -1).permute(0, 2, 1)
+    key = seq("f_object", ctx, 2).reshape(B, 256, -1)
+    value = seq("f_down", ctx, 1).reshape(B, 256, -1).permute(0, 2, 1)
+    sim = F.softmax((256 ** -0.5) * torch.matmul(query, key), dim=-1)            # [B, hw, 1]: one object region -> all ones
+    context = torch.matmul(sim, value).permute(0, 2, 1).reshape(B, 256, h, w)
+    context = seq("f_up", context, 1)
+    o = _conv_bn(P, bn, pre + ".ocr_distri_head.conv_bn_dropout.0", pre + ".ocr_distri_head.conv_bn_dropout.1.0",
+                 torch.cat([context, f], 1), pad=0)
+    o = _drop(o, drop, "ocr_drop")
+    out = F.conv2d(o, P[pre + ".cls_head.weight"], P[pre + ".cls_head.bias"])
+    up = lambda t: torch.sigmoid(F.interpolate(t, size=(H, W), mode="bilinear", align_corners=True))
+    return up(out), up(out_aux)
+
+
 def norm_sr(sr, cfg):
     """build_model.py:125-141."""
     if cfg.norm_sr == "instance":
@@ -498,7 +612,10 @@ def joint_forward(P, cfg, it, x, hr, mask, kernel_gt, alpha=1.0, drop=None, trai
     """JointModelWithLoss.forward (KBPN + PSPNet branch), build_model.py:402-416."""
     sr, kvec = kbpn_forward(P, x, it, kernel_gt, cfg, taps)
     bn = BNState(P, training)
-    seg, aux = pspnet_forward(P, norm_sr(sr, cfg), bn, drop, kvec if cfg.detector == "PSPNet_BlurSkip" else None)
+    if cfg.detector == "HRNet_OCR":
+        seg, aux = hrnet_ocr_forward(P, norm_sr(sr, cfg), bn, drop)
+    else:
+        seg, aux = pspnet_forward(P, norm_sr(sr, cfg), bn, drop, kvec if cfg.detector == "PSPNet_BlurSkip" else None)
     sr_loss, kpred = kbpn_loss(sr, hr, x, kvec, kernel_gt, cfg, seg, mask, it)
     sdf = torch.from_numpy(compute_sdf(mask.cpu().numpy())).float()
     seg_loss = cfg.main_w * boundary_combo_loss(seg, mask, alpha, cfg, sdf) + \

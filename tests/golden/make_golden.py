@@ -47,7 +47,8 @@ class DropCapture:
     """Replace nn.Dropout2d.forward by a recorded/seeded channel mask (order of calls = keys)."""
     KEYS = ("drop_1", "drop_2a", "drop_2b", "drop_2c", "aux_drop")
 
-    def __init__(self, enabled, seed=7):
+    def __init__(self, enabled, seed=7, keys=None):
+        self.KEYS = keys or self.KEYS
         self.enabled, self.gen, self.masks, self.i = enabled, torch.Generator().manual_seed(seed), {}, 0
 
     def __call__(self, mod, x):
@@ -70,7 +71,7 @@ def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha
     model.train()
     if alpha is not None:
         model.ss_loss_fn.alpha = alpha
-    cap = DropCapture(dropout)
+    cap = DropCapture(dropout, keys=("ocr_drop",) if detector == "HRNet_OCR" else None)      # spatial_ocr_block.py:283
     orig = nn.Dropout2d.forward
     # PSPNet calls: drop_1, drop_2 x3 (main path) then aux dropout (pspnet.py:105-120)
     nn.Dropout2d.forward = lambda self, x: cap(self, x)
@@ -105,14 +106,20 @@ def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha
     names, norms, samples = grad_digest(model)
     bufs = {n: b.detach().numpy() for n, b in model.named_buffers()
             if n in ("segmentation_model.feats.bn1.running_mean", "segmentation_model.feats.bn1.running_var",
-                     "segmentation_model.up_3.conv.1.running_var", "segmentation_model.aux.1.running_mean")}
+                     "segmentation_model.up_3.conv.1.running_var", "segmentation_model.aux.1.running_mean",
+                     "segmentation_model.blur_skip.3.norm.running_var",
+                     "segmentation_model.backbone.bn1.running_mean", "segmentation_model.backbone.stage4.2.fuse_layers.3.2.0.1.running_var",
+                     "segmentation_model.ocr_distri_head.object_context_block.f_object.3.0.running_var",
+                     "segmentation_model.ocr_distri_head.object_context_block.f_pixel.3.0.running_mean",
+                     "segmentation_model.ocr_distri_head.object_context_block.f_up.1.0.running_var",
+                     "segmentation_model.aux_head.1.0.running_mean")}
     out = dict(x=x.numpy(), hr=hr.numpy(), mask=mask.numpy(), kernel=k.numpy(), it=np.int64(it),
                segment_loss=seg_loss.detach().numpy(), sr_loss=sr_loss.detach().numpy(), loss=np.float64(loss.item()),
                segment_preds=seg.detach().numpy(), sr_preds=sr.detach().numpy(), kernel_preds=kpred.detach().numpy(),
                grad_names=np.array(names), grad_norms=norms, grad_samples=samples,
                alpha=np.float64(model.ss_loss_fn.alpha), antialias=np.bool_(antialias), scale=np.int64(scale),
                detector=np.array(detector), sfo_sr_amp=np.float64(cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP),
-               oriented_w_iter=np.int64(cfg.SOLVER.ORIENTED_WEIGHT_ITER),
+               oriented_w_iter=np.int64(cfg.SOLVER.ORIENTED_WEIGHT_ITER), beta=np.float64(cfg.SOLVER.TASK_LOSS_WEIGHT),
                torch_version=np.array(torch.__version__))
     for kname, v in cap.masks.items():
         if v is not None:
@@ -163,6 +170,9 @@ if __name__ == "__main__":
     # BASELINE config 5: x8, PSPNet_BlurSkip, w^F (m^F = 1) on the SR loss, only blur_skip trainable
     run_case("e2e_blurskip_x8_it40000", 40000, lr=8, scale=8, alpha=0.8, detector="PSPNet_BlurSkip", seed=9,
              overrides=("SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP", 1.0, "SOLVER.ORIENTED_WEIGHT_ITER", 0))
+    # BASELINE config 4: HRNet-W48 + OCR detector, beta = 0.9, batch 4 (BatchNorm over the 4 object-context vectors)
+    run_case("e2e_hrnet_ocr_it40000", 40000, B=4, alpha=0.8, detector="HRNet_OCR", seed=13, dropout=True,
+             overrides=("SOLVER.TASK_LOSS_WEIGHT", 0.9))
     # config 2 with the w^F weight on (README row 'CSBSR w/ PSPNet + w^F')
     run_case("e2e_pspnet_wf_it40000", 40000, alpha=0.7, seed=11,
              overrides=("SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP", 1.0, "SOLVER.ORIENTED_WEIGHT_ITER", 0))

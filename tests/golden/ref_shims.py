@@ -189,6 +189,10 @@ def build_reference(detector="PSPNet", scale=4, overrides=()):
     cfg.merge_from_list(list(overrides))
     from model.modeling.pspnet_pytorch import extractors
     extractors.resnet34 = lambda pretrained=True: extractors.ResNet(extractors.BasicBlock, [3, 4, 6, 3])
+    # HRNet backbone: the ImageNet checkpoint is not in the container (no network); keep the random init, weights are
+    # overwritten by the deterministic fill anyway
+    from model.modeling.hrnet_ocr.tools.module_helper import ModuleHelper
+    ModuleHelper.load_model = staticmethod(lambda model, pretrained=None, all_match=True, network=None: model)
     from model.modeling.build_model import JointModelWithLoss, JointModel
     from model.data.transforms.transforms import FactorResize
     return cfg, JointModelWithLoss, JointModel, FactorResize

