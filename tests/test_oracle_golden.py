@@ -66,6 +66,11 @@ def test_oracle_matches_reference_outputs_and_grads(case):
         # evaluation orders of the same math differ by 7e-3 typically and by up to 60% of a near-zero value vs fp64 (measured), so they get
         # their own bound (w^F case: reference 2.4e-4, fp64 oracle 3.4e-4, fp32 oracle 1.3e-3 on stage-0 down.conv's slope)
         tol, atol = (0.1, 2e-3) if gr.numel() == 1 else (TOL_GRAD, 1e-12)
+        if hrnet and n.startswith("sr_model"):
+            # beta = 0.9 pushes the segmentation gradient, back-propagated through ~300 BatchNorm layers, into KBPN: there the
+            # reference's own fp32 result is noise-limited (measured against an fp64 run of the oracle: PReLU slopes 0.0083 (ref) /
+            # 0.027 (fp32 oracle) / 0.021 (fp64); kb.sr_reconst weights 7 %; median over all tensors 5e-4)
+            tol, atol = (1.0, 3e-2) if gr.numel() == 1 else (0.1, 1e-12)
         assert abs(mine_norm - ref_norm) <= tol * ref_norm + atol, (n, mine_norm, ref_norm)
         if gr.numel() == 1:
             n_checked += 1
