@@ -75,6 +75,9 @@ SIGNATURES = {
     "csbsr_epilogue_backward": (i32, [C.POINTER(EpiBwdDesc), vp]),
     "csbsr_axpby": (i32, [i64, i32, vp, i64, f32, vp, i64, f32, vp, i64, vp]),
     "csbsr_fill_f16": (i32, [vp, i64, i32, i64, f32, vp]),
+    "csbsr_sum_act": (i32, [i64, i32, i32, vp, vp, vp, i64, i32, vp]),
+    "csbsr_weighted_pool_fwd": (i32, [vp, i64, vp, vp, i32, i64, i32, vp]),
+    "csbsr_weighted_pool_bwd": (i32, [vp, i64, vp, vp, vp, i64, vp, i32, i64, i32, vp]),
     "csbsr_nchw32_to_nhwc16": (i32, [vp, vp, i32, i32, i32, i32, i32, i64, vp, vp, vp]),
     "csbsr_nhwc16_to_nchw32": (i32, [vp, i64, vp, i32, i32, i32, i32, f32, f32, vp]),
     "csbsr_plane_reduce": (i32, [vp, vp, i32, i64, vp, vp]),

@@ -25,6 +25,7 @@ from ..config import path_config
 from ..engine import Engine, FM, grad_acc, _ptr
 from .kbpn import KBPN
 from .pspnet import PSPNet
+from .hrnet_ocr import HRNetOCR
 from .shapes import joint_state_shapes
 
 
@@ -98,8 +99,8 @@ def _init_reference_style(name, t, gen):
 class _JointBase(nn.Module):
     def __init__(self, cfg, antialias=True, device="cuda:0", seed=None):
         super().__init__()
-        if cfg.MODEL.SR != "KBPN" or cfg.MODEL.DETECTOR_TYPE not in ("PSPNet", "PSPNet_BlurSkip"):
-            raise NotImplementedError(f"csbsr_amd builds KBPN + PSPNet / PSPNet_BlurSkip; got SR={cfg.MODEL.SR} "
+        if cfg.MODEL.SR != "KBPN" or cfg.MODEL.DETECTOR_TYPE not in ("PSPNet", "PSPNet_BlurSkip", "HRNet_OCR"):
+            raise NotImplementedError(f"csbsr_amd builds KBPN + PSPNet / PSPNet_BlurSkip / HRNet_OCR; got SR={cfg.MODEL.SR} "
                                       f"DETECTOR_TYPE={cfg.MODEL.DETECTOR_TYPE}")
         if cfg.MODEL.SR_PIXEL_SHUFFLE or cfg.MODEL.SUM_LR_ERROR_POS != "HR" or not cfg.MODEL.KBPN_KERNEL_SFT:
             raise NotImplementedError("only the default KBPN variant (deconv up-sampling, HR error sum, kernel SFT) is built")
@@ -160,7 +161,8 @@ class _JointBase(nn.Module):
             self.to(self._device)
             eng = Engine(self._device)
             P = {k: (v.data if isinstance(v, nn.Parameter) else v) for k, v in self._named_full()}
-            self._rt = {"eng": eng, "P": P, "kbpn": KBPN(eng, P, self.pc), "psp": PSPNet(eng, P, blur_dim=self.pc.ksize_out ** 2 if self.blur_skip else None)}
+            self._rt = {"eng": eng, "P": P, "kbpn": KBPN(eng, P, self.pc), "psp": HRNetOCR(eng, P) if self.seg_model_name == "HRNet_OCR"
+                        else PSPNet(eng, P, blur_dim=self.pc.ksize_out ** 2 if self.blur_skip else None)}
         return self._rt
 
     def _invalidate(self):
@@ -249,7 +251,8 @@ class JointModelWithLoss(_JointBase):
             sr32[b0:b0 + mb] = s_
             kvec[b0:b0 + mb] = k_
         xin, mean, invstd = self._norm_sr(sr32)
-        drop = self.dropout_masks if self.dropout_masks is not None else psp.make_dropout(B, training, self.dropout_enabled)
+        drop = psp.make_dropout(B, training, self.dropout_enabled) if self.dropout_masks is None else \
+            {k: self.dropout_masks.get(k) for k in psp.drop_keys}
         drop = {k: (None if v is None else v.to(self._device, torch.float32).contiguous()) for k, v in drop.items()}
         seg32, aux32 = psp.forward(xin, drop, training, kvec=kvec if self.blur_skip else None)
         # ---- losses (forward sums only; gradients are produced in _hip_backward)
@@ -409,7 +412,7 @@ class JointModel(_JointBase):
         sr32, kvec = kbpn.forward(x, -1, kgt, save=False)
         sr32.clamp_(0, 1)
         xin, _, _ = self._norm_sr(sr32)
-        seg32, _ = psp.forward(xin, {k: None for k in ("drop_1", "drop_2a", "drop_2b", "drop_2c", "aux_drop")}, training=self.training,
+        seg32, _ = psp.forward(xin, {k: None for k in psp.drop_keys}, training=self.training,
                                kvec=kvec if self.blur_skip else None)
         psp.saved = None
         kvec = kvec / kvec.sum(1, keepdim=True)

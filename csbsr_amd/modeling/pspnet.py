@@ -49,6 +49,8 @@ class _SFTLike:
 
 
 class PSPNet:
+    drop_keys = tuple(DROP_P)
+
     def __init__(self, eng, params, prefix="segmentation_model", blur_dim=None):
         """blur_dim: build PSPNet_BlurSkip (pspnet.py:127-207) whose forward also takes the kernel code [B, blur_dim]; in that
         variant only blur_skip.* is trainable (build_model.py:352-368), so the backward stops there."""

@@ -148,6 +148,19 @@ int csbsr_axpby(int64_t npix, int32_t c, const void* x, int64_t x_ld, float a, c
                 float b, void* y, int64_t y_ld, csbsr_stream_t s);
 int csbsr_fill_f16(void* p, int64_t npix, int32_t c, int64_t ld, float v, csbsr_stream_t s);
 
+/* HRNet-W48 + OCR detector (BASELINE config 4).
+ * csbsr_sum_act: y = relu?(x_0 + ... + x_{n-1}), n <= 4 fp16 NHWC maps -- the fuse sum of HighResolutionModule.forward
+ * (model/modeling/hrnet_ocr/backbones/hrnet/hrnet_backbone.py:276-296).
+ * csbsr_weighted_pool_{fwd,bwd}: out[n][c] = sum_p w[n][p] * x[n][p][c] and its adjoint (dx +=, dw =) -- the soft object-region
+ * pooling torch.matmul(softmax(probs), feats) of SpatialGather_Module.forward (modules/spatial_ocr_block.py:58-66).  out is
+ * accumulated into (zero it first); c <= 2048. */
+int csbsr_sum_act(int64_t npix, int32_t c, int32_t n, const void* const* xs, const int64_t* x_lds, void* y, int64_t y_ld,
+                  int32_t relu, csbsr_stream_t s);
+int csbsr_weighted_pool_fwd(const void* x, int64_t x_ld, const float* w, float* out, int32_t N, int64_t hw, int32_t c,
+                            csbsr_stream_t s);
+int csbsr_weighted_pool_bwd(const void* x, int64_t x_ld, const float* w, const float* dout, void* dx, int64_t dx_ld, float* dw,
+                            int32_t N, int64_t hw, int32_t c, csbsr_stream_t s);
+
 /* boundary layout converters: fp32 NCHW (what the reference's loader hands over, crack_dataset.py:40-64;
  * optionally normalised per (n,c) -- InstanceNorm2d(3) apply, build_model.py:136) -> fp16 NHWC, and back */
 int csbsr_nchw32_to_nhwc16(const float* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t cp,

@@ -446,11 +446,17 @@ def hrnet_backbone(P, bn, pre, x):
 def hrnet_ocr_forward(P, x, bn, drop=None):
     """HRNet_W48_OCR.forward, nets/hrnet.py:139-158, with SpatialGather_Module (spatial_ocr_block.py:37-66) and
     SpatialOCR_Module / _ObjectAttentionBlock (:114-305) for num_classes = 1 -> (main prob map, aux prob map)."""
-    pre = "segmentation_model"
-    H, W = x.shape[-2:]
-    ys = hrnet_backbone(P, bn, pre + ".backbone", x)
+    ys = hrnet_backbone(P, bn, "segmentation_model.backbone", x)
     h, w = ys[0].shape[-2:]
     feats = torch.cat([ys[0]] + [F.interpolate(t, size=(h, w), mode="bilinear", align_corners=True) for t in ys[1:]], 1)
+    return hrnet_ocr_head(P, feats, bn, drop, x.shape[-2:])
+
+
+def hrnet_ocr_head(P, feats, bn, drop, out_hw):
+    """nets/hrnet.py:150-158: everything after the 720-channel concat."""
+    pre = "segmentation_model"
+    H, W = out_hw
+    h, w = feats.shape[-2:]
     a = _conv_bn(P, bn, pre + ".aux_head.0", pre + ".aux_head.1.0", feats)
     out_aux = F.conv2d(a, P[pre + ".aux_head.2.weight"], P[pre + ".aux_head.2.bias"])
     f = _conv_bn(P, bn, pre + ".conv3x3.0", pre + ".conv3x3.1.0", feats)

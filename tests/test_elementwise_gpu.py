@@ -367,3 +367,46 @@ def test_border_class_fill_and_sums(shape):
     onehot = torch.nn.functional.one_hot(cls.reshape(-1), 16).float()          # [HW, 16]
     ref_s = torch.einsum("nchw,hwk->nkc", x, onehot.reshape(H, W, 16))
     assert relmax(sums.cpu(), ref_s) < 2e-4
+
+
+@pytest.mark.parametrize("n,relu", [(1, True), (3, True), (4, False)])
+def test_sum_act(n, relu):
+    """n-ary fuse sum of an HRNet module (csbsr_sum_act) vs torch."""
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    torch.manual_seed(3)
+    xs = [r16(torch.randn(2, 48, 9, 11)) for _ in range(n)]
+    fms = [to_fm(x) for x in xs]
+    out = eng.new(2, 9, 11, 48)
+    ptrs = (C.c_void_p * 4)(*[P(f.t) for f in fms], *([None] * (4 - n)))
+    lds = (C.c_int64 * 4)(*[f.ld for f in fms], *([0] * (4 - n)))
+    L.call("csbsr_sum_act", out.npix, out.cp, n, ptrs, lds, P(out.t), out.ld, int(relu), eng.stream)
+    ref = sum(xs)
+    ref = F.relu(ref) if relu else ref
+    assert relmax(from_fm(out), ref) < 2e-3
+
+
+def test_weighted_pool_fwd_bwd():
+    """soft object-region pooling of the OCR head (SpatialGather_Module for one class) and its adjoint vs torch autograd."""
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    torch.manual_seed(4)
+    N, Cc, H, W = 3, 512, 37, 41                  # hw = 1517: two 1024-pixel chunks, ragged
+    x = r16(torch.randn(N, Cc, H, W)).requires_grad_(True)
+    logits = torch.randn(N, H * W)
+    w = torch.softmax(logits, 1).requires_grad_(True)
+    ref = torch.einsum("np,ncp->nc", w, x.reshape(N, Cc, -1))
+    g = torch.randn(N, Cc)
+    ref.backward(g)
+    fx = to_fm(x.detach())
+    out = torch.zeros(N, Cc, device="cuda")
+    wd = w.detach().cuda().contiguous()
+    L.call("csbsr_weighted_pool_fwd", P(fx.t), fx.ld, P(wd), P(out), N, H * W, Cc, eng.stream)
+    assert relmax(out.cpu(), ref.detach()) < 1e-4
+    base = r16(torch.randn(N, Cc, H, W))          # dx is accumulated into
+    dx = to_fm(base)
+    dw = torch.empty(N, H * W, device="cuda")
+    gd = g.cuda().contiguous()
+    L.call("csbsr_weighted_pool_bwd", P(fx.t), fx.ld, P(wd), P(gd), P(dx.t), dx.ld, P(dw), N, H * W, Cc, eng.stream)
+    assert relmax(dw.cpu(), w.grad) < 1e-4
+    assert relmax(from_fm(dx), base + x.grad) < 2e-3
