@@ -71,9 +71,9 @@ def main():
     ap.add_argument("--lr-size", type=int, default=448)
     ap.add_argument("--micro-batch", type=int, default=1)
     ap.add_argument("--max-resident", type=int, default=6, help="micro-batches whose KBPN activations stay resident for backward")
-    ap.add_argument("--workload", default="pspnet_x4", choices=("pspnet_x4", "blurskip_x8"),
+    ap.add_argument("--workload", default="pspnet_x4", choices=("pspnet_x4", "blurskip_x8", "hrnet_x4"),
                     help="pspnet_x4 = BASELINE config 2 (the bench line); blurskip_x8 = config 5 (x8, PSPNet_BlurSkip, w^F; use --lr-size 224 "
-                         "--batch 4) -- a coverage timing, not the headline")
+                         "--batch 4); hrnet_x4 = config 4 (HRNet-W48 + OCR, beta 0.9; use --batch 4) -- coverage timings, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -99,6 +99,9 @@ def main():
     if x8:
         cfg.MODEL.SCALE_FACTOR, cfg.MODEL.DETECTOR_TYPE = 8, "PSPNet_BlurSkip"
         cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP, cfg.SOLVER.ORIENTED_WEIGHT_ITER = 1.0, 0
+    if args.workload == "hrnet_x4":
+        cfg.MODEL.DETECTOR_TYPE, cfg.SOLVER.TASK_LOSS_WEIGHT = "HRNet_OCR", 0.9
+    other = args.workload != "pspnet_x4"
     scale = cfg.MODEL.SCALE_FACTOR
     model = JointModelWithLoss(cfg, 9000, 40000, None, device=str(dev))
     model.micro_batch = args.micro_batch
@@ -169,10 +172,10 @@ def main():
     if rank == 0:
         pix = (lr / 448.0) ** 2
         per_img_s = dt / (B * args.steps)
-        out = {"metric": "training imgs/s (448->1792 x4, PSPNet)" if not x8 else "training imgs/s (x8, PSPNet_BlurSkip, w^F)", "value": round(imgs, 4), "unit": "imgs/s", "n_gpus": world,
+        out = {"metric": "training imgs/s (448->1792 x4, PSPNet)" if not other else f"training imgs/s ({args.workload})", "value": round(imgs, 4), "unit": "imgs/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 1), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "fp16 storage / fp32 accumulate", "data": "synthetic",
-               "config": {"workload": f"CSBSR KBPN x{scale} + {cfg.MODEL.DETECTOR_TYPE}, beta=0.3, joint phase (iter 40000), per-GPU batch {B}, "
+               "config": {"workload": f"CSBSR KBPN x{scale} + {cfg.MODEL.DETECTOR_TYPE}, beta={beta}, joint phase (iter 40000), per-GPU batch {B}, "
                                       f"LR {lr}x{lr} -> HR {lr * scale}x{lr * scale}, fwd+loss+bwd+Adam", "global_batch": B * world,
                           "micro_batch": args.micro_batch, "parallelism": f"dp{world}"},
                "loss": round(last, 5),
@@ -181,9 +184,9 @@ def main():
                                  "note": "algorithmic work per image at LR 448 after exact constant-operand folding (fe_kernel.0 + SFT code channels): 73.3 TFLOP / 213.7 GB (SURVEY.md 8(d) as-executed: 108.3 TFLOP / 249 GB)"},
                "roofline": roof,
                "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
-        if x8:
+        if other:
             out["step_roofline"] = None          # the folded-work figures above are config 2's
-        if not args.no_cpu_baseline and world == 1 and not x8:
+        if not args.no_cpu_baseline and world == 1 and not other:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

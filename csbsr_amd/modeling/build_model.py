@@ -224,7 +224,9 @@ class JointModelWithLoss(_JointBase):
         self.sr_loss_fn = "KBPNLoss"
         self.aux_weight, self.main_weight = cfg.SOLVER.SEG_AUX_LOSS_WEIGHT, cfg.SOLVER.SEG_MAIN_LOSS_WEIGHT
         self.iter_cnt = True
-        self.grad_scale = None          # None: chosen per call as 2^round(log2(B*H*W))
+        self.grad_scale = None          # None: chosen per call as 2^round(log2(B*H*W)) (see _hip_backward)
+        self.scale_backoff = 0          # log2 reduction of the automatic scale after overflowed steps
+        self.overflow_steps = 0
         self._st = None
         self.reducer = None             # csbsr_amd.parallel.GradBucketReducer when data-parallel
 
@@ -306,7 +308,11 @@ class JointModelWithLoss(_JointBase):
         B, h, w = st["B"], st["h"], st["w"]
         H, W = h * pc.scale, w * pc.scale
         hw = H * W
-        gs = self.grad_scale or float(2 ** round(math.log2(B * hw)))
+        # loss scale of the fp16 activation gradients: the per-pixel loss gradient is O(1/(B*H*W)); PSPNet keeps that magnitude down
+        # to the input, HRNet-OCR grows it ~1e5x towards the stem (measured, reference-style init), so it starts 2^8 lower.
+        # ``scale_backoff`` is the dynamic part (GradScaler semantics): a backward that overflowed returns zero gradients for that
+        # step and lowers the scale for the following ones.
+        gs = self.grad_scale or float(2 ** (round(math.log2(B * hw)) - (8 if self.seg_model_name == "HRNet_OCR" else 0) - self.scale_backoff))
         eng.grad_scale = gs
         pnames = [k for k, v in self._named_full() if isinstance(v, nn.Parameter)]     # == self.parameters() order
         for k in pnames:                    # fresh fp32 accumulators for this backward
@@ -388,10 +394,23 @@ class JointModelWithLoss(_JointBase):
                                      for k in pnames if k.startswith(grp)])
             self.reducer.finish()
         inv = 1.0 / gs
+        touched = [rt["P"][k] for k in pnames if getattr(rt["P"][k], "gacc_touched", False)]
+        # overflow check on the (already all-reduced, so rank-consistent) accumulators: one scalar read back per step
+        finite = bool(torch.isfinite(torch.stack([t.gacc.sum() for t in touched]).sum())) if touched else True
+        if not finite:
+            self.overflow_steps += 1
+            if self.grad_scale is None:
+                self.scale_backoff += 4
+            import warnings
+            warnings.warn(f"csbsr_amd: fp16 gradient overflow at loss scale {gs:g}; this step's gradients are zeroed"
+                          + ("" if self.grad_scale is not None else f", next scale {gs / 16:g}"))
         out = []
         for k in pnames:                    # parameters no kernel touched (frozen phase / unused) keep grad None
             t = rt["P"][k]
-            out.append(t.gacc * inv if getattr(t, "gacc_touched", False) else None)
+            if not getattr(t, "gacc_touched", False):
+                out.append(None)
+            else:
+                out.append(t.gacc * inv if finite else torch.zeros_like(t.gacc))
         return out
 
 

@@ -216,3 +216,27 @@ def test_micro_batching_is_exact():
     assert max_rel_to_scale(o1["sr_loss"], o2["sr_loss"]) < 1e-4
     worst = max(rel_err(g1[k], g2[k]) for k in g1 if g1[k] is not None and g1[k].numel() > 1)
     assert worst < 5e-3, worst
+
+
+def test_loss_scale_overflow_backoff():
+    """fp16 gradient overflow follows GradScaler semantics: that step's gradients are zeros (never inf/nan), the automatic loss scale
+    drops by 2^4 for the next step, which then succeeds."""
+    import warnings
+    g = load_golden("e2e_pspnet_it40000")
+    m, cfg = build_model(g)
+    t = lambda k: torch.from_numpy(g[k])
+    m.scale_backoff = -40                      # 2^40 x the automatic scale: certain overflow
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        seg_l, sr_l, *_ = m(40000, t("x"), sr_targets=t("hr"), segment_targets=t("mask"), kernel_targets=t("kernel"))
+        (0.7 * sr_l.mean() + 0.3 * seg_l.mean()).backward()
+    assert any("overflow" in str(x.message) for x in w)
+    assert m.overflow_steps == 1 and m.scale_backoff == -36
+    grads = [p.grad for p in m.parameters() if p.grad is not None]
+    assert len(grads) > 250 and all(float(x.abs().max()) == 0.0 for x in grads)
+    m.scale_backoff = 0
+    m.zero_grad()
+    seg_l, sr_l, *_ = m(40000, t("x"), sr_targets=t("hr"), segment_targets=t("mask"), kernel_targets=t("kernel"))
+    (0.7 * sr_l.mean() + 0.3 * seg_l.mean()).backward()
+    assert m.overflow_steps == 1 and all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+    assert sum(float(p.grad.abs().sum()) for p in m.parameters() if p.grad is not None) > 0
