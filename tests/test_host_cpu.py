@@ -79,6 +79,28 @@ def test_state_dict_matches_reference_layout():
         m.load_state_dict({"nope": torch.zeros(1)}, strict=True)
 
 
+@pytest.mark.parametrize("detector,scale,fixture,n_state,n_param,n_elem,n_train", [
+    ("PSPNet_BlurSkip", 8, "e2e_blurskip_x8_it40000", 442, 316, 127318388, 26),        # config 5: only blur_skip.* trains
+    ("HRNet_OCR", 4, "e2e_hrnet_ocr_it40000", 2051, 1109, 135658533, 1109),           # config 4
+])
+def test_state_dict_of_other_detectors(detector, scale, fixture, n_state, n_param, n_elem, n_train):
+    """state_dict layout / parameter order / trainable set of the config 4 and 5 models equal the reference's (the fixtures carry
+    the reference's own named_parameters() list; the counts are SURVEY.md section 8c's)."""
+    from csbsr_amd.config import cfg
+    from csbsr_amd.modeling.build_model import JointModelWithLoss
+    c = cfg.clone()
+    c.MODEL.DETECTOR_TYPE, c.MODEL.SCALE_FACTOR = detector, scale
+    m = JointModelWithLoss(c, 1000, 0, None)
+    assert len(m.state_dict()) == n_state
+    params = [(k, v) for k, v in m._named_full() if isinstance(v, torch.nn.Parameter)]
+    assert len(params) == n_param and sum(v.numel() for _, v in params) == n_elem
+    assert sum(v.requires_grad for _, v in params) == n_train
+    g = np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz"))
+    assert [k for k, _ in params] == [str(n) for n in g["grad_names"]]
+    trainable_ref = {str(n) for n, nrm in zip(g["grad_names"], g["grad_norms"]) if nrm >= 0}
+    assert {k for k, v in params if v.requires_grad} == trainable_ref
+
+
 def test_alpha_schedule_matches_reference_rule():
     """BoundaryComboLoss alpha bookkeeping (loss_functions.py:27-41, 76-81)."""
     from csbsr_amd.modeling.build_model import BoundaryComboState
