@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
 
 
 class WgradDesc(C.Structure):
-    _fields_ = [("a", vp), ("a_sn", i64), ("a_sy", i64), ("a_sx", i64), ("ca", i32), ("_pad0", i32),
+    _fields_ = [("a", vp), ("a_sn", i64), ("a_sy", i64), ("a_sx", i64), ("ca", i32), ("ca_real", i32),
                 ("b", Seg * 2), ("N", i32), ("AH", i32), ("AW", i32), ("BH", i32), ("BW", i32),
                 ("KH", i32), ("KW", i32), ("stride", i32), ("pad", i32), ("dil", i32),
                 ("g", vp), ("splits", i32), ("_pad1", i32)]
@@ -72,6 +72,7 @@ SIGNATURES = {
     "csbsr_pack_weights": (i32, [vp, vp] + [i32] * 12 + [vp]),
     "csbsr_unpack_wgrad": (i32, [vp, vp] + [i32] * 9 + [f32, i32, i32, vp]),
     "csbsr_wgrad_splits": (i32, [i32, i32, i64]),
+    "csbsr_wgrad_splits_desc": (i32, [vp]),
     "csbsr_epilogue_backward": (i32, [C.POINTER(EpiBwdDesc), vp]),
     "csbsr_axpby": (i32, [i64, i32, vp, i64, f32, vp, i64, f32, vp, i64, vp]),
     "csbsr_fill_f16": (i32, [vp, i64, i32, i64, f32, vp]),

@@ -22,6 +22,7 @@ struct WgradK {
   long M;                    // N*AH*AW
   long per_split;            // pixels per split (multiple of 32)
   unsigned tiles_a, tiles_b;
+  int ca_real;               // real channels of A (thin kernel: rows = (tap, channel))
 };
 
 template <bool USE_TR>
@@ -186,7 +187,128 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
 }
 
 static int g_wgrad_use_tr = 1;
-extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v; }
+static int g_wgrad_thin = 1;
+extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v & 1; g_wgrad_thin = !(v & 2); }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Thin-A variant: stride-1 "same" conv whose output has so few channels that KH*KW*ca_real <= 32 (the 3-channel image heads:
+// kb.sr_reconst, output_conv, the dgrad side of fe_SR.0).  The taps move from the column index into the ROW index,
+//     G[(tap, co)][ci] = sum over input pixels q  dPre[q - off(tap)][co] * X[q][ci]
+// so one 32-row MFMA tile holds all taps of all output channels (27 of 32 rows live instead of 3), the B operand is the
+// unshifted input -- read from HBM exactly once instead of once per tap -- and the A' tile is assembled from the (tiny,
+// L2-resident) dPre map.  Same slab layout as the kernel above, so csbsr_unpack_wgrad is unchanged.
+template <bool USE_TR>
+__global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradK p) {
+  constexpr int LDA = 32 + 32, LDB = WG_BN + 32;
+  __shared__ __attribute__((aligned(16))) half_t sA[WG_BP * LDA];
+  __shared__ __attribute__((aligned(16))) half_t sB[WG_BP * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col0 = blockIdx.x * WG_BN;                 // input-channel tile
+  const long mbeg = (long)blockIdx.z * p.per_split;
+  long mend = mbeg + p.per_split;
+  if (mend > p.M) mend = p.M;
+  if (mbeg >= mend) return;
+
+  // ---- B staging role (as above, no tap shift): chunk ids tid + 256*j : pixel = id/16, col chunk = id%16
+  constexpr int B_ITERS = WG_BP * 16 / 256;
+  const half_t* b_ptr;
+  long b_sn, b_sy, b_sx;
+  bool b_ok;
+  {
+    const int c = col0 + (tid & 15) * 8;
+    b_ok = c < p.cbtot;
+    const csbsr_seg_t& sg = (c < p.cb0 || !b_ok) ? p.b[0] : p.b[1];
+    b_ptr = reinterpret_cast<const half_t*>(sg.ptr) + (!b_ok ? 0 : (c < p.cb0 ? c : c - p.cb0));
+    b_sn = sg.sn; b_sy = sg.sy; b_sx = sg.sx;
+  }
+  // ---- A' staging role: pixel tid/4, rows 8*(tid%4) .. +7 ; row m = tap * ca_real + co
+  int a_dy[8], a_dx[8], a_co[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int m = (tid & 3) * 8 + e;
+    const int tap = m / p.ca_real;
+    a_co[e] = tap < p.KH * p.KW ? m - tap * p.ca_real : -1;
+    a_dy[e] = p.pad - (tap / p.KW) * p.dil;            // dPre pixel = input pixel + (pad - k*dil)
+    a_dx[e] = p.pad - (tap % p.KW) * p.dil;
+  }
+  struct Pix { int n, y, x; };
+  auto init_pix = [&](long m) {
+    Pix c;
+    c.n = (int)(m / ((long)p.BH * p.BW));
+    const int rem = (int)(m - (long)c.n * p.BH * p.BW);
+    c.y = rem / p.BW; c.x = rem - c.y * p.BW;
+    return c;
+  };
+  auto advance = [&](Pix& c, int d) {
+    c.x += d;
+    while (c.x >= p.BW) { c.x -= p.BW; if (++c.y == p.BH) { c.y = 0; ++c.n; } }
+  };
+  Pix cb = init_pix(mbeg + (tid >> 4));
+  Pix ca_ = init_pix(mbeg + (tid >> 2));
+
+  f16v acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  h8 gb[B_ITERS], ga;
+  auto issue_loads = [&](long m) {
+#pragma unroll
+    for (int j = 0; j < B_ITERS; ++j) {
+      const int pix = (tid >> 4) + 16 * j;
+      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (b_ok && m + pix < mend) v = *reinterpret_cast<const h8*>(b_ptr + cb.n * b_sn + cb.y * b_sy + cb.x * b_sx);
+      gb[j] = v;
+      advance(cb, 16);
+    }
+    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (m + (tid >> 2) < mend) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ay = ca_.y + a_dy[e], ax = ca_.x + a_dx[e];
+        if (a_co[e] >= 0 && (unsigned)ay < (unsigned)p.AH && (unsigned)ax < (unsigned)p.AW)
+          v[e] = p.a[ca_.n * p.a_sn + ay * p.a_sy + ax * p.a_sx + a_co[e]];
+      }
+    }
+    ga = v;
+    advance(ca_, 64);
+  };
+
+  issue_loads(mbeg);
+  for (long m = mbeg; m < mend; m += WG_BP) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < B_ITERS; ++j) {
+      const int id = tid + 256 * j;
+      *reinterpret_cast<h8*>(sB + (id >> 4) * LDB + (id & 15) * 8) = gb[j];
+    }
+    *reinterpret_cast<h8*>(sA + (tid >> 2) * LDA + (tid & 3) * 8) = ga;
+    __syncthreads();
+    if (m + WG_BP < mend) issue_loads(m + WG_BP);
+#pragma unroll
+    for (int ks = 0; ks < WG_BP / 16; ++ks) {
+      const int pix0 = ks * 16 + (lane >> 5) * 8;
+      const h8 af = frag_T<USE_TR>(sA, LDA, pix0, lane & 31);
+      const h8 bf = frag_T<USE_TR>(sB, LDB, pix0, wid * 32 + (lane & 31));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+    }
+  }
+  float* slab = p.g + (size_t)blockIdx.z * p.ca * p.ktot;
+  const int ci = col0 + wid * 32 + (lane & 31);
+  if (ci >= p.cbtot) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int tap = m / p.ca_real;
+    if (tap >= p.KH * p.KW) continue;
+    slab[(size_t)(m - tap * p.ca_real) * p.ktot + (size_t)tap * p.cbtot + ci] = acc[r];
+  }
+}
+
+static bool wgrad_is_thin(const csbsr_wgrad_desc_t* d) {
+  const int cr = d->ca_real > 0 ? d->ca_real : d->ca;
+  return g_wgrad_thin && d->stride == 1 && d->KH * d->KW * cr <= 32 && d->KH * d->KW > 1 && d->AH == d->BH && d->AW == d->BW &&
+         2 * d->pad == d->dil * (d->KH - 1) && d->KH == d->KW && d->b[0].sx != 0 && (d->b[1].c == 0 || d->b[1].sx != 0) &&
+         (d->b[0].c + d->b[1].c) >= 64;
+}
 
 static int wgrad_tile_a(int ca) { return ca > 64 ? 128 : (ca > 32 ? 64 : 32); }
 
@@ -204,6 +326,27 @@ extern "C" int32_t csbsr_wgrad_splits(int32_t ca, int32_t ktot, int64_t M) {
   if (splits < 1) splits = 1;
   const long per_split = ((M + splits - 1) / splits + WG_BP - 1) / WG_BP * WG_BP;
   return (int32_t)((M + per_split - 1) / per_split);
+}
+
+static long wgrad_splits_for(long ntile, long slab_elems, long M) {
+  long want = (1536 + ntile - 1) / ntile;
+  long maxs = (M + WG_BP * 8 - 1) / (WG_BP * 8);
+  long splits = want < maxs ? want : maxs;
+  const long cap = (192L << 20) / (slab_elems > 0 ? slab_elems * 4 : 1);      // keep the slab workspace under 192 MiB
+  if (splits > cap) splits = cap;
+  if (splits > 1024) splits = 1024;
+  if (splits < 1) splits = 1;
+  const long per_split = ((M + splits - 1) / splits + WG_BP - 1) / WG_BP * WG_BP;
+  return (M + per_split - 1) / per_split;
+}
+
+// splits for a full descriptor (knows about the thin-A kernel, whose grid has KH*KW times fewer column tiles)
+extern "C" int32_t csbsr_wgrad_splits_desc(const csbsr_wgrad_desc_t* d) {
+  const int cbtot = d->b[0].c + d->b[1].c;
+  const int ktot = d->KH * d->KW * cbtot;
+  if (wgrad_is_thin(d))
+    return (int32_t)wgrad_splits_for((cbtot + WG_BN - 1) / WG_BN, (long)d->ca * ktot, (long)d->N * d->BH * d->BW);
+  return csbsr_wgrad_splits(d->ca, ktot, (long)d->N * d->AH * d->AW);
 }
 
 template <int BA, int WA, int WB>
@@ -240,6 +383,20 @@ extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
   k.M = (long)d->N * d->AH * d->AW;
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   CSBSR_CHECK(d->splits >= 1, "wgrad: splits must come from csbsr_wgrad_splits()");
+  if (wgrad_is_thin(d)) {
+    k.ca_real = d->ca_real > 0 ? d->ca_real : d->ca;
+    k.M = (long)d->N * d->BH * d->BW;
+    k.per_split = ((k.M + d->splits - 1) / d->splits + WG_BP - 1) / WG_BP * WG_BP;
+    if ((int)((k.M + k.per_split - 1) / k.per_split) != d->splits) {
+      csbsr_set_error("wgrad(thin): splits=%d leaves an empty slab; use csbsr_wgrad_splits_desc()", d->splits);
+      return 1;
+    }
+    dim3 grid((k.cbtot + WG_BN - 1) / WG_BN, 1, d->splits);
+    if (g_wgrad_use_tr) hipLaunchKernelGGL((conv_wgrad_thin_kernel<true>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((conv_wgrad_thin_kernel<false>), grid, dim3(256), 0, st, k);
+    CSBSR_LAUNCH_CHECK("csbsr_conv_wgrad(thin)");
+    return 0;
+  }
   if (d->ca > 64) return launch_wgrad<128, 2, 2>(k, d->splits, st);
   if (d->ca > 32) return launch_wgrad<64, 2, 2>(k, d->splits, st);
   return launch_wgrad<32, 1, 4>(k, d->splits, st);

@@ -324,7 +324,7 @@ class Conv:
             a, bs = dpre, xs
             seg0, seg1 = split_override if split_override is not None else self.split
         sn, sy, sx = a.strides()
-        d.a, d.a_sn, d.a_sy, d.a_sx, d.ca = _ptr(a.t), sn, sy, sx, a.cp
+        d.a, d.a_sn, d.a_sy, d.a_sx, d.ca, d.ca_real = _ptr(a.t), sn, sy, sx, a.cp, a.c
         d.b[0] = bs[0].seg()
         if len(bs) > 1:
             d.b[1] = bs[1].seg()
@@ -332,7 +332,7 @@ class Conv:
         d.KH, d.KW, d.stride, d.pad, d.dil = self.k, self.k, self.stride, self.pad, self.dil
         cbtot = sum(f.cp for f in bs)
         ktot = self.k * self.k * cbtot
-        splits = L.load().csbsr_wgrad_splits(a.cp, ktot, a.N * a.H * a.W)
+        splits = L.load().csbsr_wgrad_splits_desc(C.byref(d))
         g = self.eng.workspace(splits * a.cp * ktot)
         d.g, d.splits = _ptr(g), splits
         tm = self.eng.timing

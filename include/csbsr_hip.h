@@ -90,7 +90,7 @@ typedef struct {
   const void* a;           /* fp16 NHWC [N, AH, AW, ca] ungathered side */
   int64_t a_sn, a_sy, a_sx;
   int32_t ca;              /* channels (multiple of 8) */
-  int32_t _pad0;
+  int32_t ca_real;         /* real (unpadded) channels of A, 0 = ca: lets 3-channel heads take the taps-in-rows kernel */
   csbsr_seg_t b[2];        /* gathered side, up to two segments */
   int32_t N, AH, AW;       /* grid the reduction runs over */
   int32_t BH, BW;          /* spatial size of the gathered side */
@@ -101,6 +101,7 @@ typedef struct {
 } csbsr_wgrad_desc_t;
 
 int32_t csbsr_wgrad_splits(int32_t ca, int32_t ktot, int64_t npix);
+int32_t csbsr_wgrad_splits_desc(const csbsr_wgrad_desc_t* d);   /* same, for a filled descriptor (d->splits ignored): use this one */
 int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s);
 void csbsr_debug_set_wgrad_tr(int use_hw_transpose_read); /* test hook: 0 = scalar LDS transposition */
 void csbsr_debug_set_conv_glds(int mode);                 /* test hook: 0 = register-staged kernel only, 1 = 128x128 LDS-DMA, 2 = 256x128 */
