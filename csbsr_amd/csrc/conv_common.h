@@ -143,5 +143,8 @@ __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const 
 }
 
 extern int g_conv_direct_epi;
+bool conv_thin_eligible(const ConvK& k);                  // conv_thin.hip: 3-channel image heads
+int conv_thin_launch(const ConvK& k, hipStream_t st);
+void conv_thin_enable(int on);
 bool conv_glds_eligible(const ConvK& k);
 int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st);

@@ -286,7 +286,11 @@ static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
 
 static int g_glds_mode = 2;      // 0: off, 1: 128x128 x2 stages only, 2: + 256x128 x3 stages for long-K stride-1 layers
 int g_conv_direct_epi = 0;      // measured: 32-byte store segments lose to the LDS-staged 128-byte ones on the tile kernels
-extern "C" void csbsr_debug_set_conv_glds(int mode) { g_glds_mode = mode & 7; g_conv_direct_epi = (mode & 8) ? 1 : 0; }
+extern "C" void csbsr_debug_set_conv_glds(int mode) {
+  g_glds_mode = mode & 7;
+  g_conv_direct_epi = (mode & 8) ? 1 : 0;
+  conv_thin_enable((mode & 16) ? 0 : 1);      // bit 4: route the 3-channel heads through the generic kernel (A/B timing)
+}
 
 // eligibility: MFMA-bound shapes only
 bool conv_glds_eligible(const ConvK& k) {

@@ -1,0 +1,161 @@
+// Thin-output 3x3 convolution for gfx950: the 3-channel image heads of the path (kb.sr_reconst 128s -> 3, output_conv 512 -> 3 and the
+// dgrad side of fe_SR.0, 49 -> 3) at HR resolution.  These layers are pure streaming -- 1 KB of input per pixel for 3 outputs -- but the
+// implicit-GEMM kernels gather the input once per tap (9x through L1/L2) and waste 29/32 of every MFMA column tile.
+//
+// Here the nine taps move into the GEMM's N dimension: one pass over the (halo-extended) input tile computes
+//     Y[q][(tap, co)] = sum_ci X[q][ci] * W[co][ci][tap]              (N = 9 * cout <= 32, one MFMA column tile, 27/32 live)
+// with the A operand streamed global -> VGPR exactly once, and the convolution output is the shift-and-add
+//     out[p][co] = sum_tap Y[p + off(tap)][(tap, co)]
+// done from LDS in the epilogue, followed by the common fused epilogue (conv_common.h).  Same packed weights as conv_igemm.hip.
+//
+// K ordering: the MFMA only needs A and B to agree on which channel sits at which k, so within each group of 32 channels lanes 0-31
+// take channels [0,16) and lanes 32-63 take [16,32) -- every lane issues one 32-byte global load per pixel per group (two k-steps),
+// and each 64-byte sector is used in full.
+#include "conv_common.h"
+
+#define TN_TH 8
+#define TN_TW 32
+#define TN_HW (TN_TW + 2)
+#define TN_HP ((TN_TH + 2) * TN_HW)        // 340 halo pixels
+#define TN_MB ((TN_HP + 31) / 32)          // 11 row blocks of 32
+#define TN_YLD 33
+
+__global__ __launch_bounds__(256) void conv_thin_cout_kernel(const ConvK p, int tiles_x, int tiles_y, int wld) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* sW = reinterpret_cast<half_t*>(smem);                                    // [32][wld]
+  float* sY = reinterpret_cast<float*>(smem + (size_t)32 * wld * sizeof(half_t));  // [TN_MB*32][TN_YLD]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y;
+  const int n = b / tiles_y;
+  const int CR = p.cout, ntap_rows = 9 * CR;
+
+  // ---- weights -> LDS: sW[(tap, co)][ci] = wt[co][tap * ctot + ci]; rows >= 9*cout and columns >= ctot are zero
+  {
+    const int chunks_per_row = wld / 8;
+    for (int id = tid; id < 32 * chunks_per_row; id += 256) {
+      const int row = id / chunks_per_row, ci = (id - row * chunks_per_row) * 8;
+      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (row < ntap_rows && ci < p.ctot) {
+        const int tap = row / CR, co = row - tap * CR;
+        v = *reinterpret_cast<const h8*>(p.wt + (size_t)co * p.Kp + (size_t)tap * p.ctot + ci);
+      }
+      *reinterpret_cast<h8*>(sW + row * wld + ci) = v;
+    }
+  }
+
+  // ---- per-lane pixel pointers of this wave's row blocks (wid, wid+4, wid+8)
+  const int hi = lane >> 5;
+  const half_t* base0[3];
+  const half_t* base1[3];
+  bool okp[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int q = (wid + 4 * i) * 32 + (lane & 31);
+    const int hy = q / TN_HW, hx = q - hy * TN_HW;
+    const int iy = ty * TN_TH + hy - 1, ix = tx * TN_TW + hx - 1;
+    okp[i] = (wid + 4 * i) < TN_MB && q < TN_HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const long o0 = okp[i] ? (long)n * p.in[0].sn + (long)iy * p.in[0].sy + (long)ix * p.in[0].sx : 0;
+    const long o1 = okp[i] ? (long)n * p.in[1].sn + (long)iy * p.in[1].sy + (long)ix * p.in[1].sx : 0;
+    base0[i] = reinterpret_cast<const half_t*>(p.in[0].ptr) + o0;
+    base1[i] = reinterpret_cast<const half_t*>(p.in[1].ptr) + o1 - p.c0;
+  }
+  f16v acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int npair = (p.ctot + 31) / 32;
+  h8 a[3][2], an[3][2];
+  auto load = [&](int j, h8 (&dst)[3][2]) {
+    const int ch = 32 * j + 16 * hi;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const half_t* bp = (ch < p.c0 ? base0[i] : base1[i]) + ch;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (okp[i] && ch + 8 * s + 8 <= p.ctot) v = *reinterpret_cast<const h8*>(bp + 8 * s);
+        dst[i][s] = v;
+      }
+    }
+  };
+  load(0, a);
+  __syncthreads();                      // sW complete
+  for (int j = 0; j < npair; ++j) {
+    if (j + 1 < npair) load(j + 1, an);
+    const half_t* wrow = sW + (lane & 31) * wld + 32 * j + 16 * hi;
+    const h8 b0 = *reinterpret_cast<const h8*>(wrow);
+    const h8 b1 = *reinterpret_cast<const h8*>(wrow + 8);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], b0, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], b1, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { a[i][0] = an[i][0]; a[i][1] = an[i][1]; }
+  }
+
+  // ---- Y tile -> LDS (D: col = lane & 31 = (tap, co); rows (r&3) + 8*(r>>2) + 4*(lane>>5))
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (wid + 4 * i >= TN_MB) continue;
+    float* yb = sY + (size_t)(wid + 4 * i) * 32 * TN_YLD + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yb[((r & 3) + 8 * (r >> 2) + 4 * hi) * TN_YLD] = acc[i][r];
+  }
+  __syncthreads();
+
+  // ---- shift-and-add + fused epilogue: one output pixel per thread
+  const int oyl = tid / TN_TW, oxl = tid % TN_TW;
+  const int oy = ty * TN_TH + oyl, ox = tx * TN_TW + oxl;
+  if (oy >= p.OH || ox >= p.OW) return;
+  float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const float* y = sY + (size_t)((oyl + ky) * TN_HW + oxl + kx) * TN_YLD + (ky * 3 + kx) * CR;
+      for (int co = 0; co < CR; ++co) v[co] += y[co];
+    }
+  if (p.bias)
+    for (int co = 0; co < CR; ++co) bias[co] = p.bias[co];
+  const float slope = p.act == CSBSR_ACT_PRELU ? p.prelu[0] : p.act_slope;
+  int cur_n = n;
+  float ssum[8], ssq[8];
+  conv_epilogue_row(p, v, bias, slope, 0, n, oy, ox, true, cur_n, ssum, ssq);
+}
+
+static int g_conv_thin = 1;
+void conv_thin_enable(int on) { g_conv_thin = on; }
+
+bool conv_thin_eligible(const ConvK& k) {
+  if (!g_conv_thin || k.transposed) return false;
+  if (k.KHt != 3 || k.KWt != 3 || k.stride != 1 || k.dil != 1 || k.pad != 1) return false;
+  if (k.cout * 9 > 32 || k.coutp != 8) return false;
+  if (k.stat_mode != CSBSR_STAT_NONE) return false;
+  if (k.OH != k.H || k.OW != k.W) return false;
+  if (k.in[0].sx == 0 || (k.c0 != k.ctot && (k.in[1].sx == 0 || k.c0 % 32 != 0))) return false;
+  if (k.ctot < 32 || k.ctot > 1024) return false;
+  return true;
+}
+
+int conv_thin_launch(const ConvK& k, hipStream_t st) {
+  const int tiles_x = (k.OW + TN_TW - 1) / TN_TW, tiles_y = (k.OH + TN_TH - 1) / TN_TH;
+  const int wld = round_up(k.ctot, 32) + 8;
+  const size_t smem = (size_t)32 * wld * sizeof(half_t) + (size_t)TN_MB * 32 * TN_YLD * sizeof(float);
+  static size_t configured = 0;
+  if (smem > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_cout_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+        hipSuccess) {
+      csbsr_set_error("conv(thin): cannot reserve %zu bytes of LDS", smem);
+      return 1;
+    }
+    configured = smem;
+  }
+  hipLaunchKernelGGL(conv_thin_cout_kernel, dim3((unsigned)(k.N * tiles_y * tiles_x)), dim3(256), smem, st, k, tiles_x, tiles_y, wld);
+  CSBSR_LAUNCH_CHECK("csbsr_conv_forward(thin)");
+  return 0;
+}
