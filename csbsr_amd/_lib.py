@@ -18,7 +18,7 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
 
 class Seg(C.Structure):
-    _fields_ = [("ptr", vp), ("sn", i64), ("sy", i64), ("sx", i64), ("c", i32), ("_pad", i32)]
+    _fields_ = [("ptr", vp), ("sn", i64), ("sy", i64), ("sx", i64), ("c", i32), ("creal", i32)]
 
 
 class ConvDesc(C.Structure):

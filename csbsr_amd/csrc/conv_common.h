@@ -146,5 +146,7 @@ extern int g_conv_direct_epi;
 bool conv_thin_eligible(const ConvK& k);                  // conv_thin.hip: 3-channel image heads
 int conv_thin_launch(const ConvK& k, hipStream_t st);
 void conv_thin_enable(int on);
+bool conv_thin_cin_eligible(const ConvK& k, int creal);   // 3-channel image in
+int conv_thin_cin_launch(const ConvK& k, int creal, hipStream_t st);
 bool conv_glds_eligible(const ConvK& k);
 int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st);

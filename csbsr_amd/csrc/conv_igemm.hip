@@ -351,6 +351,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   if (conv_thin_eligible(k)) return conv_thin_launch(k, st);
+  if (d->in[1].c == 0 && conv_thin_cin_eligible(k, d->in[0].creal)) return conv_thin_cin_launch(k, d->in[0].creal, st);
   if (conv_glds_eligible(k)) return conv_glds_launch(k, nphase, maxM, st);
   if (k.coutp > 64) return launch_conv<128, 2, 2>(k, nphase, maxM, st);
   if (k.coutp > 32) return launch_conv<64, 2, 2>(k, nphase, maxM, st);

@@ -20,6 +20,8 @@
 #define TN_MB ((TN_HP + 31) / 32)          // 11 row blocks of 32
 #define TN_YLD 33
 
+#define TN_TPW 1                           // tile rows per workgroup: the weight tile is staged once per workgroup
+
 __global__ __launch_bounds__(256) void conv_thin_cout_kernel(const ConvK p, int tiles_x, int tiles_y, int wld) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* sW = reinterpret_cast<half_t*>(smem);                                    // [32][wld]
@@ -27,8 +29,9 @@ __global__ __launch_bounds__(256) void conv_thin_cout_kernel(const ConvK p, int 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int b = blockIdx.x;
   const int tx = b % tiles_x; b /= tiles_x;
-  const int ty = b % tiles_y;
-  const int n = b / tiles_y;
+  const int tyg = (tiles_y + TN_TPW - 1) / TN_TPW;
+  const int ty0 = (b % tyg) * TN_TPW;
+  const int n = b / tyg;
   const int CR = p.cout, ntap_rows = 9 * CR;
 
   // ---- weights -> LDS: sW[(tap, co)][ci] = wt[co][tap * ctot + ci]; rows >= 9*cout and columns >= ctot are zero
@@ -45,8 +48,15 @@ __global__ __launch_bounds__(256) void conv_thin_cout_kernel(const ConvK p, int 
     }
   }
 
-  // ---- per-lane pixel pointers of this wave's row blocks (wid, wid+4, wid+8)
   const int hi = lane >> 5;
+  const float slope = p.act == CSBSR_ACT_PRELU ? p.prelu[0] : p.act_slope;
+  float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (p.bias)
+    for (int co = 0; co < CR; ++co) bias[co] = p.bias[co];
+  bool first = true;
+#pragma unroll 1
+  for (int ty = ty0; ty < ty0 + TN_TPW && ty < tiles_y; ++ty) {
+  // ---- per-lane pixel pointers of this wave's row blocks (wid, wid+4, wid+8)
   const half_t* base0[3];
   const half_t* base1[3];
   bool okp[3];
@@ -83,7 +93,8 @@ __global__ __launch_bounds__(256) void conv_thin_cout_kernel(const ConvK p, int 
     }
   };
   load(0, a);
-  __syncthreads();                      // sW complete
+  __syncthreads();                      // sW complete (first tile) / previous tile's sY reads done
+  first = false;
   for (int j = 0; j < npair; ++j) {
     if (j + 1 < npair) load(j + 1, an);
     const half_t* wrow = sW + (lane & 31) * wld + 32 * j + 16 * hi;
@@ -111,8 +122,8 @@ __global__ __launch_bounds__(256) void conv_thin_cout_kernel(const ConvK p, int 
   // ---- shift-and-add + fused epilogue: one output pixel per thread
   const int oyl = tid / TN_TW, oxl = tid % TN_TW;
   const int oy = ty * TN_TH + oyl, ox = tx * TN_TW + oxl;
-  if (oy >= p.OH || ox >= p.OW) return;
-  float v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (oy >= p.OH || ox >= p.OW) continue;
+  float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -120,12 +131,10 @@ __global__ __launch_bounds__(256) void conv_thin_cout_kernel(const ConvK p, int 
       const float* y = sY + (size_t)((oyl + ky) * TN_HW + oxl + kx) * TN_YLD + (ky * 3 + kx) * CR;
       for (int co = 0; co < CR; ++co) v[co] += y[co];
     }
-  if (p.bias)
-    for (int co = 0; co < CR; ++co) bias[co] = p.bias[co];
-  const float slope = p.act == CSBSR_ACT_PRELU ? p.prelu[0] : p.act_slope;
   int cur_n = n;
   float ssum[8], ssq[8];
   conv_epilogue_row(p, v, bias, slope, 0, n, oy, ox, true, cur_n, ssum, ssq);
+  }
 }
 
 static int g_conv_thin = 1;
@@ -155,7 +164,112 @@ int conv_thin_launch(const ConvK& k, hipStream_t st) {
     }
     configured = smem;
   }
-  hipLaunchKernelGGL(conv_thin_cout_kernel, dim3((unsigned)(k.N * tiles_y * tiles_x)), dim3(256), smem, st, k, tiles_x, tiles_y, wld);
+  const int tyg = (tiles_y + TN_TPW - 1) / TN_TPW;
+  hipLaunchKernelGGL(conv_thin_cout_kernel, dim3((unsigned)(k.N * tyg * tiles_x)), dim3(256), smem, st, k, tiles_x, tiles_y, wld);
   CSBSR_LAUNCH_CHECK("csbsr_conv_forward(thin)");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Thin-input 3x3 convolution: the mirror case (3-channel image in, 49..512 channels out: fe_SR.0 and the dgrad side of the
+// image heads).  The padded implicit GEMM runs K = 9 taps x 8 padded channels = 72 -> 128; here K is the dense (tap, channel)
+// index, 27 -> 32 = two MFMA k-steps, the pixel operand is gathered once per tile row from an LDS copy of the halo tile and
+// reused for every output-channel tile, and the kernel is bound by writing the output.  D[cout][pixel], register-direct epilogue.
+#define TK_WLD 40
+
+__global__ __launch_bounds__(256) void conv_thin_cin_kernel(const ConvK p, int tiles_x, int tiles_y, int CI) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nct = (p.cout + 31) / 32;
+  half_t* sWt = reinterpret_cast<half_t*>(smem);                     // [nct*32][TK_WLD], k = tap*CI + c
+  half_t* sIn = sWt + (size_t)nct * 32 * TK_WLD;                      // [TN_HP][4]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int tyg = (tiles_y + TN_TPW - 1) / TN_TPW;
+  const int ty0 = (b % tyg) * TN_TPW;
+  const int n = b / tyg;
+
+  for (int id = tid; id < nct * 32 * (TK_WLD / 8); id += 256) {
+    const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *reinterpret_cast<h8*>(sWt + id * 8) = z;
+  }
+  __syncthreads();
+  for (int id = tid; id < nct * 32 * 9; id += 256) {
+    const int co = id / 9, tap = id - co * 9;
+    const h8 v = *reinterpret_cast<const h8*>(p.wt + (size_t)co * p.Kp + tap * 8);
+    for (int c = 0; c < CI; ++c) sWt[co * TK_WLD + tap * CI + c] = v[c];
+  }
+  const float slope = p.act == CSBSR_ACT_PRELU ? p.prelu[0] : p.act_slope;
+#pragma unroll 1
+  for (int ty = ty0; ty < ty0 + TN_TPW && ty < tiles_y; ++ty) {
+  __syncthreads();                      // previous tile's sIn reads done
+  for (int id = tid; id < TN_HP; id += 256) {
+    const int hy = id / TN_HW, hx = id - hy * TN_HW;
+    const int iy = ty * TN_TH + hy - 1, ix = tx * TN_TW + hx - 1;
+    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+      v = *reinterpret_cast<const h8*>(reinterpret_cast<const half_t*>(p.in[0].ptr) + (long)n * p.in[0].sn + (long)iy * p.in[0].sy +
+                                       (long)ix * p.in[0].sx);
+    half_t* d = sIn + id * 4;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = 0;
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int rb = 0; rb < 2; ++rb) {
+    const int oyl = wid * 2 + rb, oxl = lane & 31;
+    const int oy = ty * TN_TH + oyl, ox = tx * TN_TW + oxl;
+    h8 pf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * s + 8 * hi + e;
+        const int tap = k / CI, c = k - tap * CI;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        pf[s][e] = tap < 9 ? sIn[((oyl + ky) * TN_HW + oxl + kx) * 4 + c] : (half_t)0;
+      }
+    const int nn = (oy < p.OH && ox < p.OW) ? n : -1;
+#pragma unroll 4
+    for (int ct = 0; ct < nct; ++ct) {
+      const half_t* wrow = sWt + (size_t)(ct * 32 + (lane & 31)) * TK_WLD + 8 * hi;
+      const h8 w0 = *reinterpret_cast<const h8*>(wrow);
+      const h8 w1 = *reinterpret_cast<const h8*>(wrow + 16);
+      f16v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, pf[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, pf[1], acc, 0, 0, 0);
+      conv_epilogue_direct_tile(p, acc, ct * 32, slope, nn, oy, ox);
+    }
+  }
+  }
+}
+
+bool conv_thin_cin_eligible(const ConvK& k, int creal) {
+  if (!g_conv_thin || k.transposed) return false;
+  if (k.KHt != 3 || k.KWt != 3 || k.stride != 1 || k.dil != 1 || k.pad != 1) return false;
+  if (k.ctot != 8 || k.c0 != 8 || creal < 1 || creal > 3 || k.in[0].sx == 0) return false;
+  if (k.stat_mode != CSBSR_STAT_NONE || k.cbias) return false;
+  if (k.OH != k.H || k.OW != k.W) return false;
+  if (k.cout < 32 || k.cout > 1024) return false;
+  return true;
+}
+
+int conv_thin_cin_launch(const ConvK& k, int creal, hipStream_t st) {
+  const int tiles_x = (k.OW + TN_TW - 1) / TN_TW, tiles_y = (k.OH + TN_TH - 1) / TN_TH;
+  const int nct = (k.cout + 31) / 32;
+  const size_t smem = ((size_t)nct * 32 * TK_WLD + (size_t)TN_HP * 4) * sizeof(half_t);
+  static size_t configured = 0;
+  if (smem > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_cin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+        hipSuccess) {
+      csbsr_set_error("conv(thin-in): cannot reserve %zu bytes of LDS", smem);
+      return 1;
+    }
+    configured = smem;
+  }
+  const int tyg = (tiles_y + TN_TPW - 1) / TN_TPW;
+  hipLaunchKernelGGL(conv_thin_cin_kernel, dim3((unsigned)(k.N * tyg * tiles_x)), dim3(256), smem, st, k, tiles_x, tiles_y, creal);
+  CSBSR_LAUNCH_CHECK("csbsr_conv_forward(thin-in)");
   return 0;
 }

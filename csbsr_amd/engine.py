@@ -58,7 +58,7 @@ class FM:
 
     def seg(self):
         sn, sy, sx = self.strides()
-        return L.Seg(_ptr(self.t), sn, sy, sx, self.cp, 0)
+        return L.Seg(_ptr(self.t), sn, sy, sx, self.cp, self.c)
 
     def slice(self, c0, c1, creal=None):
         return FM(self.t[..., c0:c1], (c1 - c0) if creal is None else creal, self.bcast, self.H, self.W)

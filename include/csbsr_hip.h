@@ -43,7 +43,7 @@ typedef struct {
   const void* ptr;
   int64_t sn, sy, sx; /* element strides of sample / row / pixel */
   int32_t c;          /* channels in this segment, multiple of 8 (zero-padded) */
-  int32_t _pad;
+  int32_t creal;      /* real (unpadded) channel count, 0 = unknown: lets 3-channel images take the dense-K kernel */
 } csbsr_seg_t;
 
 /* Implicit-GEMM convolution / transposed convolution, MFMA fp16 -> fp32 accumulate.

@@ -52,6 +52,8 @@ CASES = [
     (128, 3, 3, 1, 1, 1, False, 20, 24),           # 3-channel image head (kb.sr_reconst): taps-in-rows wgrad kernel
     (200, 3, 3, 1, 1, 1, False, 9, 70),            # same, two input-channel tiles, ragged
     (64, 2, 3, 1, 1, 1, False, 8, 8),
+    (3, 128, 3, 1, 1, 1, False, 20, 24),           # 3-channel image in (dgrad side of the heads): dense-K kernel
+    (2, 200, 3, 1, 1, 1, False, 9, 70),            # ragged tile, last cout tile partial
     (128, 128, 12, 8, 2, 1, True, 8, 8),           # x8 KBPN up-projection (config 5): 64 phases, 4 taps each
     (128, 128, 12, 8, 2, 1, False, 64, 64),        # x8 down-projection: 144 taps (> the 64-bit tap mask)
     (64, 505, 3, 1, 1, 1, False, 20, 24),          # blur_skip conv_scale.0 feature part (cout padded 505 -> 512)
