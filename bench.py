@@ -38,7 +38,9 @@ def cpu_baseline(seconds_budget=25.0):
     from csbsr_amd.utils.detfill import det_state_dict
     from csbsr_amd.modeling.shapes import joint_state_shapes
     from csbsr_amd.data.synthetic import make_batch
-    cores = os.cpu_count() or 1
+    # intra-op threads: the oracle's convolutions at this sample size stop scaling past ~16 threads (a 256-thread pool on the GPU
+    # box's host took 315 s for one step against ~20 s with 16), so the pool is capped and the count actually used is reported
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     P = det_state_dict(joint_state_shapes())
     for k, v in P.items():
@@ -157,17 +159,37 @@ def main():
 
     roof = None
     if eng.timing:
-        conv = [(t[1], t[2], t[3].elapsed_time(t[4])) for t in eng.timing if t[0] == "conv"]
-        wg = [(t[1], t[2], t[3].elapsed_time(t[4])) for t in eng.timing if t[0] == "wgrad"]
-        cf, ct = sum(c[0] for c in conv), sum(c[2] for c in conv) * 1e-3
-        wf, wt = sum(c[0] for c in wg), sum(c[2] for c in wg) * 1e-3
-        ach = cf / ct / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (forward conv / deconv / dgrad)", "achieved": round(ach, 1),
-                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "launches": len(conv), "avg_launch_ms": round(ct * 1e3 / max(len(conv), 1), 3),
-                "share_of_step_time": round(ct / dt, 3),
-                "wgrad_kernel": {"achieved": round(wf / wt / 1e12, 1), "frac": round(wf / wt / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                                 "share_of_step_time": round(wt / dt, 3), "launches": len(wg)}}
+        # one roofline block = ONE kernel: the conv kernel with the largest share of the timed region (csbsr_debug_last_conv_kernel tags
+        # every launch with the kernel it dispatched to).  achieved = algorithmic FLOPs of those launches / their HIP-event time.
+        names = {0: "conv_igemm_kernel<32,4,1>", 1: "conv_igemm_kernel<64,2,2>", 2: "conv_igemm_kernel<128,2,2>",
+                 3: "conv_igemm_glds_kernel<128,2,2>", 4: "conv_igemm_glds_kernel<256,4,3>", 5: "conv_thin_cout_kernel",
+                 6: "conv_thin_cin_kernel"}
+        per = {}
+        for t in eng.timing:
+            key = names.get(t[7], "conv?") if t[0] == "conv" else "conv_wgrad_kernel (all variants)"
+            a = per.setdefault(key, [0.0, 0.0, 0.0, 0])
+            a[0] += t[1]; a[1] += t[2]; a[2] += t[3].elapsed_time(t[4]) * 1e-3; a[3] += 1
+        conv_only = {k: v for k, v in per.items() if not k.startswith("conv_wgrad")}
+        dom = max(conv_only, key=lambda k: conv_only[k][2])
+        fl, by, tt, nl = per[dom]
+        ach = fl / tt / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and args.workload == "pspnet_x4":
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_traffic.json; "
+                                "FETCH_SIZE doubled per MI355X_MICROARCH.md), same command at --batch 1" if traffic else None,
+                "launches": nl, "avg_launch_ms": round(tt * 1e3 / max(nl, 1), 4),
+                "alg_flop_per_launch": round(fl / max(nl, 1) / 1e9, 2), "alg_flop_unit": "GFLOP",
+                "alg_bytes_per_launch": round(by / max(nl, 1)), "share_of_step_time": round(tt / dt, 3),
+                "other_kernels": {k: {"achieved": round(v[0] / v[2] / 1e12, 1), "share_of_step_time": round(v[2] / dt, 3), "launches": v[3],
+                                      "avg_launch_ms": round(v[2] * 1e3 / v[3], 4)} for k, v in per.items() if k != dom}}
     out = None
     if rank == 0:
         pix = (lr / 448.0) ** 2

@@ -71,6 +71,7 @@ SIGNATURES = {
     "csbsr_packed_weight_elems": (i64, [i32] * 9),
     "csbsr_pack_weights": (i32, [vp, vp] + [i32] * 12 + [vp]),
     "csbsr_unpack_wgrad": (i32, [vp, vp] + [i32] * 9 + [f32, i32, i32, vp]),
+    "csbsr_debug_last_conv_kernel": (i32, []),
     "csbsr_wgrad_splits": (i32, [i32, i32, i64]),
     "csbsr_wgrad_splits_desc": (i32, [vp]),
     "csbsr_epilogue_backward": (i32, [C.POINTER(EpiBwdDesc), vp]),

@@ -30,9 +30,21 @@ struct ConvK {
 // weight rows are padded so that a 128-row tile never reads past the buffer when the wide tile is used
 static inline int conv_rows_padded(int nrows) { return round_up(nrows, nrows > 64 ? 128 : 32); }
 
+// Operands the epilogue reads from HBM for one (pixel, 8 channels): residual(s) and, when accumulating, the old output.  Issued for
+// all of a thread's rows up front so their latencies overlap instead of serialising row by row (a 128x128 tile has only 8 MFMA
+// k-steps per 8 epilogue rows on the short-K layers: one exposed HBM round trip per row was most of the epilogue).
+struct EpiPre { h8 r, old; };
+__device__ __forceinline__ void conv_epilogue_prefetch(const ConvK& p, int co, int n, int oy, int ox, EpiPre& q) {
+  if (p.res_mode != CSBSR_RES_NONE) {
+    q.r = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
+  }
+  if (p.out16 && p.accumulate) q.old = *reinterpret_cast<const h8*>(p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co);
+}
+
 // one output pixel x 8 consecutive channels: scale + bias + activation, fused statistics, residual combine, stores
 __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8], const float (&bias)[8], float slope, int co, int n, int oy,
-                                                  int ox, bool uniform_n, int& cur_n, float (&ssum)[8], float (&ssq)[8]) {
+                                                  int ox, bool uniform_n, int& cur_n, float (&ssum)[8], float (&ssq)[8],
+                                                  const EpiPre* pre = nullptr) {
   const float* cb = nullptr;
   if (p.cbias) {
     const int cls = (oy == 0) * 8 + (oy == p.OH - 1) * 4 + (ox == 0) * 2 + (ox == p.OW - 1);
@@ -59,9 +71,10 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
     for (int e = 0; e < 8; ++e) ssum[e] += v[e];
   }
   if (p.res_mode != CSBSR_RES_NONE) {
-    const h8 r = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
+    const h8 r = pre ? pre->r : *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
     h8 r2 = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (p.res_mode == CSBSR_RES_FMA) r2 = *reinterpret_cast<const h8*>(p.res2 + n * p.r2_sn + oy * p.r2_sy + ox * p.r2_sx + co);
+    if (p.res_mode == CSBSR_RES_FMA)
+      r2 = *reinterpret_cast<const h8*>(p.res2 + n * p.r2_sn + oy * p.r2_sy + ox * p.r2_sx + co);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float rv = (float)r[e];
@@ -76,7 +89,7 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
   if (p.out16) {
     half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
     if (p.accumulate) {
-      const h8 old = *reinterpret_cast<const h8*>(o);
+      const h8 old = pre ? pre->old : *reinterpret_cast<const h8*>(o);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
     }
@@ -143,6 +156,10 @@ __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const 
 }
 
 extern int g_conv_direct_epi;
+// which kernel the last csbsr_conv_forward call of this thread dispatched to (csbsr_debug_last_conv_kernel): lets the host-side
+// timing attribute each launch to a kernel name, so bench.py's roofline block is about ONE kernel, the one rocprof lists
+enum { CONVK_IGEMM32 = 0, CONVK_IGEMM64, CONVK_IGEMM128, CONVK_GLDS128, CONVK_GLDS256, CONVK_THIN_COUT, CONVK_THIN_CIN };
+extern thread_local int g_last_conv_kernel;
 bool conv_thin_eligible(const ConvK& k);                  // conv_thin.hip: 3-channel image heads
 int conv_thin_launch(const ConvK& k, hipStream_t st);
 void conv_thin_enable(int on);

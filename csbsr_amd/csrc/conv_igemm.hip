@@ -259,15 +259,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
     int cur_n = -1;
 
-    for (int row = tid / CPR; row < BM; row += 256 / CPR) {
-      const int n = sRow[row * 3];
-      if (n < 0 || co >= p.coutp) continue;
-      const int oy = py + sRow[row * 3 + 1] * o_step, ox = px + sRow[row * 3 + 2] * o_step;
-      float v[8];
-      const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
-      const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
-      v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
-      conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, uniform_n, cur_n, ssum, ssq);
+    constexpr int RSTEP = 256 / CPR;
+    // rows in groups of EG: the group's residual / old-output loads are all issued before the first row is combined
+    constexpr int RPT = BM / RSTEP, EG = RPT >= 2 ? 2 : 1;
+#pragma unroll
+    for (int g = 0; g < RPT / EG; ++g) {
+      EpiPre pre[EG];
+      int rn[EG], roy[EG], rox[EG];
+#pragma unroll
+      for (int i = 0; i < EG; ++i) {
+        const int grow = tid / CPR + (g * EG + i) * RSTEP;
+        const int n = sRow[grow * 3];
+        rn[i] = (n < 0 || co >= p.coutp) ? -1 : n;
+        roy[i] = py + sRow[grow * 3 + 1] * o_step;
+        rox[i] = px + sRow[grow * 3 + 2] * o_step;
+        if (rn[i] >= 0) conv_epilogue_prefetch(p, co, rn[i], roy[i], rox[i], pre[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < EG; ++i) {
+        if (rn[i] < 0) continue;
+        const int row = tid / CPR + (g * EG + i) * RSTEP;
+        float v[8];
+        const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
+        const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
+        v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+        conv_epilogue_row(p, v, bias, slope, co, rn[i], roy[i], rox[i], uniform_n, cur_n, ssum, ssq, &pre[i]);
+      }
     }
 
     conv_epilogue_flush_stats(p, sStat, BN, hh * HB + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
@@ -350,10 +367,17 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
     maxM = (long)d->N * d->OH * d->OW;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  if (conv_thin_eligible(k)) return conv_thin_launch(k, st);
-  if (d->in[1].c == 0 && conv_thin_cin_eligible(k, d->in[0].creal)) return conv_thin_cin_launch(k, d->in[0].creal, st);
+  if (conv_thin_eligible(k)) { g_last_conv_kernel = CONVK_THIN_COUT; return conv_thin_launch(k, st); }
+  if (d->in[1].c == 0 && conv_thin_cin_eligible(k, d->in[0].creal)) {
+    g_last_conv_kernel = CONVK_THIN_CIN;
+    return conv_thin_cin_launch(k, d->in[0].creal, st);
+  }
   if (conv_glds_eligible(k)) return conv_glds_launch(k, nphase, maxM, st);
+  g_last_conv_kernel = k.coutp > 64 ? CONVK_IGEMM128 : (k.coutp > 32 ? CONVK_IGEMM64 : CONVK_IGEMM32);
   if (k.coutp > 64) return launch_conv<128, 2, 2>(k, nphase, maxM, st);
   if (k.coutp > 32) return launch_conv<64, 2, 2>(k, nphase, maxM, st);
   return launch_conv<32, 4, 1>(k, nphase, maxM, st);
 }
+
+thread_local int g_last_conv_kernel = -1;
+extern "C" int32_t csbsr_debug_last_conv_kernel(void) { return g_last_conv_kernel; }

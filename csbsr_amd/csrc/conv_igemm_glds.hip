@@ -228,17 +228,33 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f; ssum[e] = ssq[e] = 0.f; }
     int cur_n = -1;
-    for (int row = tid / CPR; row < 128; row += RSTEP) {
-      const int grow = rh * 128 + row;
-      const int n = sRow[grow * 3];
-      if (n < 0 || co >= p.coutp) continue;
-      const int oy = py + sRow[grow * 3 + 1] * o_step, ox = px + sRow[grow * 3 + 2] * o_step;
-      float v[8];
-      const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
-      const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
-      v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
-      conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, uniform_n, cur_n, ssum, ssq);
+    // rows in groups of EG: the group's residual / old-output loads are all issued before the first row is combined
+    constexpr int RPT = 128 / RSTEP, EG = RPT >= 2 ? 2 : 1;
+#pragma unroll
+    for (int g = 0; g < RPT / EG; ++g) {
+      EpiPre pre[EG];
+      int rn[EG], roy[EG], rox[EG];
+#pragma unroll
+      for (int i = 0; i < EG; ++i) {
+        const int grow = rh * 128 + tid / CPR + (g * EG + i) * RSTEP;
+        const int n = sRow[grow * 3];
+        rn[i] = (n < 0 || co >= p.coutp) ? -1 : n;
+        roy[i] = py + sRow[grow * 3 + 1] * o_step;
+        rox[i] = px + sRow[grow * 3 + 2] * o_step;
+        if (rn[i] >= 0) conv_epilogue_prefetch(p, co, rn[i], roy[i], rox[i], pre[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < EG; ++i) {
+        if (rn[i] < 0) continue;
+        const int row = tid / CPR + (g * EG + i) * RSTEP;
+        float v[8];
+        const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
+        const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
+        v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+        conv_epilogue_row(p, v, bias, slope, co, rn[i], roy[i], rox[i], uniform_n, cur_n, ssum, ssq, &pre[i]);
+      }
     }
+
     conv_epilogue_flush_stats(p, sStat, BN, hh * 64 + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
   }
   if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
@@ -307,6 +323,7 @@ int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   // measured (scripts/bench_conv.py): the 8-wave 256x128 tile only pays for long-K stride-1 layers (SFT 3x3, ResNet 3x3);
   // strided / transposed / short-K layers run faster with two 128x128 workgroups per CU
   const bool big = g_glds_mode == 2 && !k.transposed && k.stride == 1 && k.Kp >= 2304 && maxM >= 256 * 256;
+  g_last_conv_kernel = big ? CONVK_GLDS256 : CONVK_GLDS128;
   if (!big) return launch_glds<128, 2, 2>(k, nphase, maxM, st);
   return launch_glds<256, 4, 3>(k, nphase, maxM, st);
 }

@@ -235,7 +235,8 @@ class Conv:
             taps = k * k if not transposed else ((k + stride - 1) // stride) ** 2
             flops = 2.0 * npx * cout * ctot * taps
             nbytes = 2.0 * (sum(0 if f.bcast else f.N * f.H * f.W * f.c for f in xs) + (npx * cout if out is not None else 0))
-            tm.append(("conv", flops, nbytes, ev0, ev1, self.name, (x0.N, H, W, ctot, cout, k, stride, int(transposed))))
+            tm.append(("conv", flops, nbytes, ev0, ev1, self.name, (x0.N, H, W, ctot, cout, k, stride, int(transposed)),
+                       int(L.load().csbsr_debug_last_conv_kernel())))
 
     def fwd(self, x, out=None, out32=None, res=None, res2=None, res_mode=L.RES_NONE, stat=None, stat_mode=L.STAT_NONE, store=True):
         xs = x if isinstance(x, (tuple, list)) else (x,)

@@ -81,6 +81,9 @@ typedef struct {
 } csbsr_conv_desc_t;
 
 int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
+/* measurement aid: kernel the calling thread's last csbsr_conv_forward dispatched to -- 0/1/2 conv_igemm_kernel<32|64|128,..>,
+ * 3/4 conv_igemm_glds_kernel<128,2,2|256,4,3>, 5 conv_thin_cout_kernel, 6 conv_thin_cin_kernel (bench.py's roofline block) */
+int32_t csbsr_debug_last_conv_kernel(void);
 
 /* Weight-gradient GEMM: G[split][a][tap][b] = sum over the split's pixels of A[pix][a] * B[pix @ tap][b]  (fp32; the pixel
  * range is cut into csbsr_wgrad_splits() slabs, each written once -- no atomics, no zero-fill; csbsr_unpack_wgrad sums them).

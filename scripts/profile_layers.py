@@ -27,7 +27,7 @@ torch.cuda.synchronize()
 import time
 t0 = time.time(); step(); torch.cuda.synchronize(); dt = time.time() - t0
 agg = collections.OrderedDict()
-for kind, fl, by, e0, e1, name, shp in rt["eng"].timing:
+for kind, fl, by, e0, e1, name, shp, *_ in rt["eng"].timing:
     key = (kind, shp)
     a = agg.setdefault(key, [0, 0.0, 0.0, 0.0, name])
     a[0] += 1; a[1] += fl; a[2] += by; a[3] += e0.elapsed_time(e1)
