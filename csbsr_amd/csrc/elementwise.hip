@@ -448,22 +448,37 @@ struct BnK {
   int cp;
 };
 
+// Elementwise BN kernels: the launch has a multiple of c8 threads in total, so a thread keeps ONE channel octet for its whole
+// grid-stride loop -- per-channel parameters live in registers and the loop has no integer division (the first version spent
+// most of its time in two 64-bit divisions and 40 parameter loads per 48 bytes of traffic: ~1 TB/s).
+static inline int grid_for_c8(long work, int c8) {
+  int g = grid_for(work), a = 256, b = c8;
+  while (b) { const int t = a % b; a = b; b = t; }       // a = gcd(256, c8)
+  const int m = c8 / a;                                  // grid must be a multiple of m
+  g = (g + m - 1) / m * m;
+  return g;
+}
+
 __global__ void bn_apply_kernel(const BnK p) {
-  const long total = p.npix * p.c8;
+  const long T = (long)gridDim.x * blockDim.x;
+  const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = (int)(gt % p.c8) * 8;
+  const long pstep = T / p.c8;
   const float slope = p.act == CSBSR_ACT_PRELU ? *p.prelu : 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long px = i / p.c8; const int c0 = (int)(i % p.c8) * 8;
+  float mean[8], sc[8], be[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { mean[e] = p.mean[c0 + e]; sc[e] = p.invstd[c0 + e] * p.gamma[c0 + e]; be[e] = p.beta[c0 + e]; }
+  for (long px = gt / p.c8; px < p.npix; px += pstep) {
     const h8 xv = *reinterpret_cast<const h8*>(p.x + px * p.x_ld + c0);
     h8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
     if (p.res) rv = *reinterpret_cast<const h8*>(p.res + px * p.res_ld + c0);
-    const long n = px / p.hw;
+    const float* dr = p.drop ? p.drop + (long)((unsigned)px / (unsigned)p.hw) * p.cp + c0 : nullptr;
     h8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = c0 + e;
-      float v = ((float)xv[e] - p.mean[c]) * p.invstd[c] * p.gamma[c] + p.beta[c] + (float)rv[e];
+      float v = ((float)xv[e] - mean[e]) * sc[e] + be[e] + (float)rv[e];
       v = apply_act(v, p.act, slope);
-      if (p.drop) v *= p.drop[n * p.cp + c];
+      if (dr) v *= dr[e];
       o[e] = (half_t)v;
     }
     *reinterpret_cast<h8*>(p.y + px * p.y_ld + c0) = o;
@@ -500,17 +515,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnK p) {
     const int c8i = cbase + ch;
     if (c8i < p.c8 && pl < ppb) {
       const int c0 = c8i * 8;
+      float mean[8], istd[8], ga[8], be[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { mean[e] = p.mean[c0 + e]; istd[e] = p.invstd[c0 + e]; ga[e] = p.gamma[c0 + e]; be[e] = p.beta[c0 + e]; }
       for (long px = (long)blockIdx.x * ppb + pl; px < p.npix; px += (long)gridDim.x * ppb) {
         const h8 g = *reinterpret_cast<const h8*>(p.dy + px * p.dy_ld + c0);
         const h8 xv = *reinterpret_cast<const h8*>(p.x + px * p.x_ld + c0);
         h8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
         if (p.res) rv = *reinterpret_cast<const h8*>(p.res + px * p.res_ld + c0);
-        const long n = px / p.hw;
+        const float* dr = p.drop ? p.drop + (long)((unsigned)px / (unsigned)p.hw) * p.cp + c0 : nullptr;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int c = c0 + e;
-          const float xh = ((float)xv[e] - p.mean[c]) * p.invstd[c];
-          const float dz = bn_dz(p, (float)g[e], xh, (float)rv[e], c, n, slope, dsl);
+          const float xh = ((float)xv[e] - mean[e]) * istd[e];
+          const float z = xh * ga[e] + be[e] + (float)rv[e];
+          float gg = (float)g[e];
+          if (dr) gg *= dr[e];
+          float dz = gg;
+          if (p.act == CSBSR_ACT_RELU) dz = z > 0.f ? gg : 0.f;
+          else if (p.act == CSBSR_ACT_PRELU && !(z > 0.f)) { dsl += gg * z; dz = gg * slope; }
           s0[e] += dz; s1[e] += dz * xh;
         }
       }
@@ -538,34 +560,42 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnK p) {
 }
 
 __global__ void bn_bwd_apply_kernel(const BnK p) {
-  const long total = p.npix * p.c8;
+  const long T = (long)gridDim.x * blockDim.x;
+  const long gt = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = (int)(gt % p.c8) * 8;
+  const long pstep = T / p.c8;
   const float slope = p.act == CSBSR_ACT_PRELU ? *p.prelu : 0.f;
   const float inv_cnt = 1.f / (float)p.npix;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long px = i / p.c8; const int c0 = (int)(i % p.c8) * 8;
+  float mean[8], istd[8], ga[8], be[8], k1[8], k2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c0 + e;
+    mean[e] = p.mean[c]; istd[e] = p.invstd[c]; ga[e] = p.gamma[c]; be[e] = p.beta[c];
+    k1[e] = p.red[c] * inv_cnt; k2[e] = p.red[p.cp + c] * inv_cnt;
+  }
+  for (long px = gt / p.c8; px < p.npix; px += pstep) {
     const h8 g = *reinterpret_cast<const h8*>(p.dy + px * p.dy_ld + c0);
     const h8 xv = *reinterpret_cast<const h8*>(p.x + px * p.x_ld + c0);
     h8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
     if (p.res) rv = *reinterpret_cast<const h8*>(p.res + px * p.res_ld + c0);
-    const long n = px / p.hw;
-    h8 o, dr;
-    float dummy = 0.f;
+    const float* dr = p.drop ? p.drop + (long)((unsigned)px / (unsigned)p.hw) * p.cp + c0 : nullptr;
+    h8 old = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p.dres && p.dres_acc) old = *reinterpret_cast<const h8*>(p.dres + px * p.dres_ld + c0);
+    h8 o, drs;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = c0 + e;
-      const float xh = ((float)xv[e] - p.mean[c]) * p.invstd[c];
-      const float dz = bn_dz(p, (float)g[e], xh, (float)rv[e], c, n, slope, dummy);
-      const float v = p.gamma[c] * p.invstd[c] * (dz - p.red[c] * inv_cnt - xh * p.red[p.cp + c] * inv_cnt);
-      o[e] = (half_t)v; dr[e] = (half_t)dz;
+      const float xh = ((float)xv[e] - mean[e]) * istd[e];
+      const float z = xh * ga[e] + be[e] + (float)rv[e];
+      float gg = (float)g[e];
+      if (dr) gg *= dr[e];
+      float dz = gg;
+      if (p.act == CSBSR_ACT_RELU) dz = z > 0.f ? gg : 0.f;
+      else if (p.act == CSBSR_ACT_PRELU) dz = z > 0.f ? gg : gg * slope;
+      o[e] = (half_t)(ga[e] * istd[e] * (dz - k1[e] - xh * k2[e]));
+      drs[e] = (half_t)(dz + (float)old[e]);
     }
     *reinterpret_cast<h8*>(p.dx + px * p.dx_ld + c0) = o;
-    if (p.dres) {
-      half_t* q = p.dres + px * p.dres_ld + c0;
-      if (p.dres_acc) { const h8 old = *reinterpret_cast<const h8*>(q);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dr[e] = (half_t)((float)dr[e] + (float)old[e]); }
-      *reinterpret_cast<h8*>(q) = dr;
-    }
+    if (p.dres) *reinterpret_cast<h8*>(p.dres + px * p.dres_ld + c0) = drs;
   }
 }
 __global__ void bn_param_grad_kernel(const float* red, int c, int cp, float* dgamma, float* dbeta) {
@@ -591,7 +621,7 @@ static void fill_bnk(BnK& k, const csbsr_bn_desc_t* d) {
 extern "C" int csbsr_bn_apply(const csbsr_bn_desc_t* d, csbsr_stream_t s) {
   CSBSR_CHECK(d && d->x && d->y && d->c % 8 == 0, "bn_apply: bad args");
   BnK k; fill_bnk(k, d);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(k.npix * k.c8)), dim3(256), 0, ST(s), k);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for_c8(k.npix * k.c8, k.c8)), dim3(256), 0, ST(s), k);
   CSBSR_LAUNCH_CHECK("csbsr_bn_apply");
   return 0;
 }
@@ -601,7 +631,7 @@ extern "C" int csbsr_bn_backward(const csbsr_bn_desc_t* d, csbsr_stream_t s) {
   const int cpb = k.c8 < 256 ? k.c8 : 256;
   const int ppb = 256 / cpb;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(k.npix, ppb * 8, 1024)), dim3(256), 0, ST(s), k);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(k.npix * k.c8)), dim3(256), 0, ST(s), k);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_c8(k.npix * k.c8, k.c8)), dim3(256), 0, ST(s), k);
   if (d->dgamma)
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3((d->creal + 255) / 256), dim3(256), 0, ST(s), d->red, d->creal, d->c, d->dgamma, d->dbeta);
   CSBSR_LAUNCH_CHECK("csbsr_bn_backward");
