@@ -76,28 +76,60 @@ __global__ void blur_bwd_input_kernel(const float* dy, const float* kvec, float*
 
 // dk[n][ky*K+kx] += sum_{c,oy,ox} dy[n,c,oy,ox] * x[n,c,oy*s-P+ky, ox*s-P+kx]
 // grid: (K*K taps, chunks, N); block reduces over its chunk of (c,oy,ox)
+// dk[n][ky*K+kx] = sum_{c,oy,ox} dy[n,c,oy,ox] * x[n,c,oy*s-P+ky, ox*s-P+kx]
+// Tiled: a workgroup stages a TOxTO tile of dy and the matching x window in LDS, every thread owns up to two taps and sweeps the
+// tile (dy is a wave-wide broadcast read, the x reads of neighbouring taps are neighbouring words), and accumulates over
+// ``tiles_per_wg`` tiles before one atomic per tap.  (The first version walked the whole plane once per tap with two 64-bit
+// divisions per element: 2.1 ms per launch at HR.)
 template <int K>
 __global__ __launch_bounds__(256) void blur_bwd_kernel_kernel(const float* dy, const float* x, float* dk, int C, int H, int W, int OH,
-                                                              int OW, int stride, int chunks) {
-  __shared__ float sred[4];
+                                                              int OW, int stride, int TO, int lgTO, int tiles_x, int tiles_y,
+                                                              int tiles_per_wg) {
+  extern __shared__ float sm[];
   const int P = (K - 1) / 2;
-  const int tap = blockIdx.x, ky = tap / K, kx = tap % K;
-  const int n = blockIdx.z;
-  const long total = (long)C * OH * OW;
-  const long per = (total + chunks - 1) / chunks;
-  const long beg = blockIdx.y * per, end = beg + per < total ? beg + per : total;
-  float acc = 0.f;
-  for (long i = beg + threadIdx.x; i < end; i += 256) {
-    const int ox = (int)(i % OW); long t = i / OW;
-    const int oy = (int)(t % OH); const int c = (int)(t / OH);
-    const int iy = oy * stride - P + ky, ix = ox * stride - P + kx;
-    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-      acc += dy[((long)n * C + c) * OH * OW + (long)oy * OW + ox] * x[((long)n * C + c) * H * W + (long)iy * W + ix];
+  const int XW = (TO - 1) * stride + K;
+  float* sDy = sm;                 // TO*TO
+  float* sX = sm + TO * TO;        // XW*XW
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int t0 = tid, t1 = tid + 256;
+  const bool v1 = t1 < K * K, v0 = t0 < K * K;
+  const int off0 = v0 ? (t0 / K) * XW + (t0 % K) : 0;
+  const int off1 = v1 ? (t1 / K) * XW + (t1 % K) : 0;
+  float acc0 = 0.f, acc1 = 0.f;
+  const int total = C * tiles_y * tiles_x;
+  int tile = blockIdx.x * tiles_per_wg;
+  const int tend = tile + tiles_per_wg < total ? tile + tiles_per_wg : total;
+  for (; tile < tend; ++tile) {
+    const int c = tile / (tiles_y * tiles_x);
+    const int r = tile - c * tiles_y * tiles_x;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const float* dyp = dy + ((long)n * C + c) * OH * OW;
+    const float* xp = x + ((long)n * C + c) * H * W;
+    __syncthreads();
+    for (int i = tid; i < TO * TO; i += 256) {
+      const int oy = ty * TO + (i >> lgTO), ox = tx * TO + (i & (TO - 1));
+      sDy[i] = (oy < OH && ox < OW) ? dyp[(long)oy * OW + ox] : 0.f;
+    }
+    const int iy0 = ty * TO * stride - P, ix0 = tx * TO * stride - P;
+    for (int i = tid; i < XW * XW; i += 256) {
+      const int ry = i / XW, rx = i - ry * XW;
+      const int iy = iy0 + ry, ix = ix0 + rx;
+      sX[i] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? xp[(long)iy * W + ix] : 0.f;
+    }
+    __syncthreads();
+    for (int jy = 0; jy < TO; ++jy) {
+      const float* xr = sX + jy * stride * XW;
+      const float* dr = sDy + jy * TO;
+#pragma unroll 8
+      for (int jx = 0; jx < TO; ++jx) {
+        const float d = dr[jx];
+        acc0 += d * xr[jx * stride + off0];
+        acc1 += d * xr[jx * stride + off1];
+      }
+    }
   }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(dk + (long)n * K * K + tap, sred[0] + sred[1] + sred[2] + sred[3]);
+  if (v0) atomicAdd(dk + (long)n * K * K + t0, acc0);
+  if (v1) atomicAdd(dk + (long)n * K * K + t1, acc1);
 }
 
 #define BLUR_DISPATCH(K, CALL) \
@@ -140,12 +172,18 @@ extern "C" int csbsr_blur_bwd_kernel(const float* dy, const float* x, float* dk,
   CSBSR_CHECK(dy && x && dk, "blur_bwd_kernel: null");
   const int P = (K - 1) / 2;
   const int OH = (H + 2 * P - K) / stride + 1, OW = (W + 2 * P - K) / stride + 1;
-  long total = (long)C * OH * OW;
-  int chunks = (int)((total + 32767) / 32768);
-  if (chunks < 1) chunks = 1;
-  if (chunks > 64) chunks = 64;
-  dim3 grid(K * K, chunks, N);
-  BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_bwd_kernel_kernel<KK>), grid, dim3(256), 0, ST(s), dy, x, dk, C, H, W, OH, OW, stride, chunks));
+  CSBSR_CHECK(K * K <= 512, "blur_bwd_kernel: at most 512 taps");
+  const int TO = stride == 1 ? 32 : (stride <= 4 ? 16 : 8), lgTO = TO == 32 ? 5 : (TO == 16 ? 4 : 3);
+  const int XW = (TO - 1) * stride + K;
+  const size_t smem = (size_t)(TO * TO + XW * XW) * sizeof(float);
+  CSBSR_CHECK(smem <= 64 * 1024, "blur_bwd_kernel: window does not fit LDS");
+  const int tiles_x = (OW + TO - 1) / TO, tiles_y = (OH + TO - 1) / TO;
+  const int total = C * tiles_x * tiles_y;
+  int tpw = (total + 1023) / 1024;          // ~1024 workgroups per sample at most: bounds the atomics per tap
+  if (tpw < 1) tpw = 1;
+  dim3 grid((total + tpw - 1) / tpw, N);
+  BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_bwd_kernel_kernel<KK>), grid, dim3(256), smem, ST(s), dy, x, dk, C, H, W, OH, OW, stride, TO, lgTO,
+                                      tiles_x, tiles_y, tpw));
   CSBSR_LAUNCH_CHECK("csbsr_blur_bwd_kernel");
   return 0;
 }
