@@ -91,24 +91,34 @@ extern "C" int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32
 __global__ void unpack_wgrad_kernel(const float* g, float* grad, int A, int Breal, int KH, int KW, int seg0_real,
                                     int seg0_p, int segtot_p, int D0, int D1, int transpose_ab, int b_off, float scale, int splits,
                                     long slab) {
-  // one thread per element of the packed layout [a][tap][b_padded]: the loop over slabs reads consecutive addresses across
-  // the wave; the single write per element goes to the OIHW / IOHW gradient
+  // one thread per FOUR consecutive elements of the packed layout [a][tap][b_padded] (b_padded is a multiple of 8, so the four share
+  // row, tap and segment): 16-byte loads, the slab loop unrolled over independent accumulators; the writes go to OIHW / IOHW
   const int ktot = KH * KW * segtot_p;
-  const long total = (long)A * ktot;
-  for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (long)gridDim.x * blockDim.x) {
+  const long total4 = (long)A * ktot / 4;
+  const f4* g4 = reinterpret_cast<const f4*>(g);
+  const long slab4 = slab / 4;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (long)gridDim.x * blockDim.x) {
+    const long gi = q * 4;
     const int a = (int)(gi / ktot);
     const int r = (int)(gi - (long)a * ktot);
     const int tap = r / segtot_p, bp = r - tap * segtot_p;
     int b;
     if (bp < seg0_p) { if (bp >= seg0_real) continue; b = bp; }
     else { b = seg0_real + (bp - seg0_p); if (b >= Breal) continue; }
-    float v = 0.f;
-    for (int sp = 0; sp < splits; ++sp) v += g[sp * slab + gi];
-    v *= scale;
+    f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    int sp = 0;
+    for (; sp + 1 < splits; sp += 2) { v0 += g4[(long)sp * slab4 + q]; v1 += g4[(long)(sp + 1) * slab4 + q]; }
+    if (sp < splits) v0 += g4[(long)sp * slab4 + q];
+    v0 += v1;
     const int kh = tap / KW, kw = tap - kh * KW;
-    const int bb = b + b_off;
-    const long di = transpose_ab ? ((((long)bb * D1 + a) * KH + kh) * KW + kw) : ((((long)a * D1 + bb) * KH + kh) * KW + kw);
-    grad[di] += v;
+    const int lim = bp < seg0_p ? seg0_real : Breal;      // real channels end inside this group of four?
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (b + e >= lim) break;
+      const int bb = b + e + b_off;
+      const long di = transpose_ab ? ((((long)bb * D1 + a) * KH + kh) * KW + kw) : ((((long)a * D1 + bb) * KH + kh) * KW + kw);
+      grad[di] += v0[e] * scale;
+    }
   }
 }
 
@@ -120,8 +130,8 @@ extern "C" int csbsr_unpack_wgrad(const float* g, float* grad, int32_t A, int32_
   const int segtot_p = seg0_p + (seg1_real > 0 ? round_up(seg1_real, 8) : 0);
   const int Breal = seg0_real + seg1_real;
   const long total = (long)A * KH * KW * segtot_p;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = (int)((total / 4 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(s), g, grad, A,
                      Breal, KH, KW, seg0_real, seg0_p, segtot_p, D0, D1, transpose_ab, b_off, scale, splits,
                      (long)ca_padded * KH * KW * segtot_p);

@@ -207,7 +207,7 @@ def test_bilinear_fwd_bwd(align, shape):
     assert relmax(g.cpu(), x1.grad) < 1e-5
 
 
-@pytest.mark.parametrize("stride", [4, 1])
+@pytest.mark.parametrize("stride", [4, 1, 8])
 def test_blur_fwd_bwd(stride):
     from csbsr_amd import _lib as L
     from oracle import csbsr_oracle as O
