@@ -1166,7 +1166,7 @@ extern "C" int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, i
   CSBSR_CHECK(x && sums && c % 8 == 0, "border_class_sums: bad args");
   if (H >= 3 && W >= 3 && (long)H * W >= 4096) {
     const long hw = (long)H * W;
-    int chunks = (int)((hw + 4095) / 4096);
+    int chunks = (int)((hw + 511) / 512);     // >= 392 workgroups at LR 448^2: the 4096-pixel chunks left 4/5 of the CUs idle
     if (chunks > 2048) chunks = 2048;
     hipLaunchKernelGGL(bcs_total_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks);
     hipLaunchKernelGGL(bcs_edges_kernel, dim3(N * 4 * ((c / 8 + 31) / 32)), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, H, W, c / 8);
