@@ -125,7 +125,7 @@ class _JointBase(nn.Module):
                     t.requires_grad = ".blur_skip." in full
         self._rt = None
         self.micro_batch = 1
-        self.max_resident = 6           # micro-batches whose KBPN activations stay in HBM for the backward (~30 GB each at LR 448)
+        self.max_resident = 7           # micro-batches whose KBPN activations stay in HBM for the backward (~26.5 GB each at LR 448; 8 fit too: 263 GB peak at B=8)
         self.dropout_enabled = True
         self.dropout_masks = None     # tests may inject {name: [B,C] fp32} keep-masks
 
