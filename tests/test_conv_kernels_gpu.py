@@ -52,6 +52,10 @@ CASES = [
     (128, 3, 3, 1, 1, 1, False, 20, 24),           # 3-channel image head (kb.sr_reconst): taps-in-rows wgrad kernel
     (200, 3, 3, 1, 1, 1, False, 9, 70),            # same, two input-channel tiles, ragged
     (64, 2, 3, 1, 1, 1, False, 8, 8),
+    (32, 32, 3, 1, 1, 1, False, 130, 140),         # small-channel HR kernel (>= 128x128 pixels), ragged tiles
+    (49, 49, 3, 1, 1, 1, False, 129, 131),         # channel padding 49 -> 56: K steps straddle taps
+    (32, 49, 1, 1, 0, 1, False, 128, 160),         # 1x1
+    (56, 24, 3, 1, 1, 1, False, 128, 128),
     (3, 128, 3, 1, 1, 1, False, 20, 24),           # 3-channel image in (dgrad side of the heads): dense-K kernel
     (2, 200, 3, 1, 1, 1, False, 9, 70),            # ragged tile, last cout tile partial
     (128, 128, 12, 8, 2, 1, True, 8, 8),           # x8 KBPN up-projection (config 5): 64 phases, 4 taps each
