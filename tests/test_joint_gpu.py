@@ -164,9 +164,11 @@ def test_gradients_match_oracle(case):
     if joint:
         sims = np.array(sims)
         print(case, "fp16-storage emulation of the oracle: median %.2e  p90 %.2e  max %.2e" % (np.median(sims), np.percentile(sims, 90), sims.max()))
-        # a tensor fails only if it is worse than 2.5x its own emulated error AND than 1.2x the typical emulated error: the two
-        # runs are independent realisations of the same chaotic noise (run-to-run the HIP value itself moves by ~3 % of the norm)
-        bad = [b for b in bad if b[1] > max(2.5 * b[2], 1.2 * np.median(sims)) + 3e-2]
+        # the HIP run and the emulation are independent realisations of the same chaotic noise (run-to-run the HIP value itself moves
+        # by ~3 % of the norm through atomics order), so the per-tensor bound is loose -- worse than 2.5x the tensor's own emulated
+        # error AND than 1.5x the emulation's worst tensor -- and the distribution is compared instead (median and 90th percentile)
+        bad = [b for b in bad if b[1] > max(2.5 * b[2], 1.5 * sims.max()) + 3e-2]
+        assert np.percentile(errs, 90) < 1.5 * np.percentile(sims, 90) + 3e-2
     assert not bad, (len(bad), bad[:10])
     if joint:
         assert np.median(errs) < 1.5 * np.median(sims) + 5e-3
