@@ -31,7 +31,7 @@ MFMA_PEAK_TFLOPS = 2500.0     # dense fp16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=15.0):
     """The oracle (CPU restatement of the reference path, fp32 torch ops) timed on this host's cores on a bounded
     sample: B=2, LR 32 -> HR 128, forward+backward, repeated until ~the budget; imgs/s scaled to LR 448 by pixels."""
     from oracle import csbsr_oracle as O
@@ -54,7 +54,7 @@ def cpu_baseline(seconds_budget=25.0):
         out = O.joint_forward(P, cfg, 40000, x, hr, mask, k, alpha=0.9)
         O.calc_loss(out["segment_loss"], out["sr_loss"], 40000, cfg).backward()
         n += 1
-        if time.time() - t0 > seconds_budget or n >= 3:
+        if time.time() - t0 > seconds_budget or n >= 40:
             break
     dt = time.time() - t0
     ips = 2 * n / dt
