@@ -322,7 +322,8 @@ bool conv_glds_eligible(const ConvK& k) {
 int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   // measured (scripts/bench_conv.py): the 8-wave 256x128 tile only pays for long-K stride-1 layers (SFT 3x3, ResNet 3x3);
   // strided / transposed / short-K layers run faster with two 128x128 workgroups per CU
-  const bool big = g_glds_mode == 2 && !k.transposed && k.stride == 1 && k.Kp >= 2304 && maxM >= 256 * 256;
+  const bool big = (g_glds_mode == 2 && !k.transposed && k.stride == 1 && k.Kp >= 2304 && maxM >= 256 * 256) ||
+                   (g_glds_mode == 3 && maxM >= 256 * 256);     // mode 3 (A/B timing): the 256-row tile wherever it fits
   g_last_conv_kernel = big ? CONVK_GLDS256 : CONVK_GLDS128;
   if (!big) return launch_glds<128, 2, 2>(k, nphase, maxM, st);
   return launch_glds<256, 4, 3>(k, nphase, maxM, st);
