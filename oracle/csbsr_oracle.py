@@ -246,13 +246,13 @@ def kbpn_forward(P, x, it, kernel_gt, cfg, taps=None):
 class BNState:
     """Train-mode BatchNorm bookkeeping: collects updated running stats."""
 
-    def __init__(self, P, training=True):
-        self.P, self.training, self.new = P, training, {}
+    def __init__(self, P, training=True, momentum=0.1):
+        self.P, self.training, self.new, self.momentum = P, training, {}, momentum
 
     def __call__(self, pre, x):
         P = self.P
         rm, rv = P[pre + ".running_mean"].clone(), P[pre + ".running_var"].clone()
-        y = F.batch_norm(x, rm, rv, P[pre + ".weight"], P[pre + ".bias"], self.training, 0.1, 1e-5)
+        y = F.batch_norm(x, rm, rv, P[pre + ".weight"], P[pre + ".bias"], self.training, self.momentum, 1e-5)
         if self.training:
             self.new[pre + ".running_mean"], self.new[pre + ".running_var"] = rm, rv
             self.new[pre + ".num_batches_tracked"] = P[pre + ".num_batches_tracked"] + 1

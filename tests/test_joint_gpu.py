@@ -292,3 +292,61 @@ def test_three_step_training_trajectory_matches_oracle():
     assert abs(d_o) > 1e-4 and abs(d_h - d_o) < 0.05 * abs(d_o) + 1e-5, (d_o, d_h)
     for a, b in zip(lh, lo):          # Adam's first steps are sign-like (+-lr per weight): near-zero gradient entries may move the other way
         assert abs(a - b) < 4e-3 * b
+
+
+@pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_blurskip_x8_it40000", "e2e_hrnet_ocr_it40000"])
+def test_joint_model_inference_matches_oracle(case):
+    """JointModel.forward (build_model.py:466-496) in eval mode: iter = -1 (kernel predictor on), SR clipped to [0,1] before the
+    detector, running-statistics BatchNorm, no dropout, kernel normalised to sum 1 -- vs the oracle and its fp16-storage emulation."""
+    from csbsr_amd.config import cfg as base_cfg
+    from csbsr_amd.modeling.build_model import JointModel
+    from csbsr_amd.utils.detfill import deterministic_fill
+    g = load_golden(case)
+    oc = golden_cfg(g)
+    cfg = base_cfg.clone()
+    cfg.MODEL.SCALE_FACTOR, cfg.MODEL.DETECTOR_TYPE = oc.scale, oc.detector
+    m = JointModel(cfg, antialias=bool(g["antialias"]))
+    deterministic_fill(m.state_dict())
+    m.eval()
+    x, k = torch.from_numpy(g["x"]), torch.from_numpy(g["kernel"])
+    # the deterministic fill's running statistics are arbitrary numbers: calibrate them to this input with one train-mode pass of the
+    # oracle at momentum 1 (running := batch statistics), as a trained checkpoint's would be, and load them into both sides
+    P0 = det_params(scale=oc.scale, detector=oc.detector, requires_grad=False)
+    with torch.no_grad():
+        sr_c, kv_c = O.kbpn_forward(P0, x, -1, k, oc)
+        bn_c = O.BNState(P0, True, momentum=1.0)
+        xin_c = O.norm_sr(sr_c.clamp(0, 1), oc)
+        if oc.detector == "HRNet_OCR":
+            O.hrnet_ocr_forward(P0, xin_c, bn_c, None)
+        else:
+            O.pspnet_forward(P0, xin_c, bn_c, None, kv_c if oc.detector == "PSPNet_BlurSkip" else None)
+    calib = {k_: v for k_, v in bn_c.new.items() if "running" in k_}
+    sd = m.state_dict()
+    for k_, v in calib.items():
+        sd[k_].copy_(v)
+    sr, seg, kp = m(x, k)
+    torch.cuda.synchronize()
+
+    def oracle():
+        P = det_params(scale=oc.scale, detector=oc.detector, requires_grad=False)
+        P.update(calib)
+        with torch.no_grad():
+            sr_o, kvec = O.kbpn_forward(P, x, -1, k, oc)
+            sr_o = sr_o.clamp(0, 1)
+            bn = O.BNState(P, False)
+            xin = O.norm_sr(sr_o, oc)
+            if oc.detector == "HRNet_OCR":
+                seg_o, _ = O.hrnet_ocr_forward(P, xin, bn, None)
+            else:
+                seg_o, _ = O.pspnet_forward(P, xin, bn, None, kvec if oc.detector == "PSPNet_BlurSkip" else None)
+            kv = kvec / kvec.sum(1, keepdim=True)
+        return sr_o, seg_o, kv.reshape(kp.shape)
+    sr_o, seg_o, kp_o = oracle()
+    with fp16_storage_sim():
+        _, seg_s, _ = oracle()
+    assert max_rel_to_scale(sr.cpu(), sr_o) < 2e-3
+    assert max_rel_to_scale(kp.cpu(), kp_o) < 2e-3
+    assert abs(float(kp.sum(dim=(1, 2, 3)).mean()) - 1.0) < 1e-4
+    e, es = max_rel_to_scale(seg.cpu(), seg_o), max_rel_to_scale(seg_s, seg_o)
+    print(case, "inference seg: hip %.2e emulation %.2e" % (e, es))
+    assert e < 2e-3 + 3.0 * es
