@@ -75,6 +75,7 @@ SIGNATURES = {
     "csbsr_wgrad_splits": (i32, [i32, i32, i64]),
     "csbsr_wgrad_splits_desc": (i32, [vp]),
     "csbsr_epilogue_backward": (i32, [C.POINTER(EpiBwdDesc), vp]),
+    "csbsr_set_reduction_scratch": (i32, [vp, i64]),
     "csbsr_axpby": (i32, [i64, i32, vp, i64, f32, vp, i64, f32, vp, i64, vp]),
     "csbsr_fill_f16": (i32, [vp, i64, i32, i64, f32, vp]),
     "csbsr_sum_act": (i32, [i64, i32, i32, vp, vp, vp, i64, i32, vp]),

@@ -52,5 +52,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Caller-owned scratch for two-stage per-channel reductions (csbsr_set_reduction_scratch).  Device-scope fp32 atomics are
+// resolved at the memory side on this part (~190 ns each, serialised per address: 1500 workgroups x 128 channels of bias-gradient
+// atomics cost 290 us on top of a 36 us streaming pass), so the reducing kernels write per-workgroup partial rows here and
+// csbsr_sum_partials folds them; without a registered scratch they fall back to atomics.
+extern float* g_red_scratch;
+extern long g_red_scratch_elems;
+int csbsr_sum_partials(const float* part, int nblk, long ld, int count, float* dst, hipStream_t st);   // dst[j] += sum_b part[b*ld+j]
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

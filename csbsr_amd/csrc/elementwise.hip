@@ -10,6 +10,38 @@ static inline int grid_for(long work, int block = 256, int cap = 8192) {
 }
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
+// ------------------------------------------------------------------------------------------- two-stage reductions
+float* g_red_scratch = nullptr;
+long g_red_scratch_elems = 0;
+extern "C" int csbsr_set_reduction_scratch(float* buf, int64_t elems) {
+  g_red_scratch = buf;
+  g_red_scratch_elems = buf ? (long)elems : 0;
+  return 0;
+}
+// dst[j] += sum over the nblk partial rows; block = 32 columns x 8 row slices
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int nblk, long ld, int count, float* dst) {
+  __shared__ float sm[8][33];
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+  float a0 = 0.f, a1 = 0.f;
+  if (col < count) {
+    int b = sl;
+    for (; b + 8 < nblk; b += 16) { a0 += part[(long)b * ld + col]; a1 += part[(long)(b + 8) * ld + col]; }
+    if (b < nblk) a0 += part[(long)b * ld + col];
+  }
+  sm[sl][threadIdx.x & 31] = a0 + a1;
+  __syncthreads();
+  if (sl == 0 && col < count) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += sm[q][threadIdx.x & 31];
+    dst[col] += t;
+  }
+}
+int csbsr_sum_partials(const float* part, int nblk, long ld, int count, float* dst, hipStream_t st) {
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((count + 31) / 32), dim3(256), 0, st, part, nblk, ld, count, dst);
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------- epilogue backward
 struct EpiK {
   long npix; int c8, creal;
@@ -22,6 +54,7 @@ struct EpiK {
   half_t* dres; long dres_ld; int dres_acc;
   half_t* dres2; long dres2_ld; int dres2_acc;
   float* dbias; float* dprelu;
+  float* part; long part_ld;        // per-workgroup partial rows [gridDim.x][part_ld]: bias sums in [0,c), PReLU-slope sum at c
 };
 
 // block = 256 threads = 32 pixel-lanes x 8? no: thread -> (pixel group, channel chunk): chunk = tid % c8 when c8 <= 256
@@ -101,7 +134,8 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const EpiK p) {
         for (int e = 0; e < 8; ++e) {
           float s = 0.f;
           for (int q = 0; q < ppb; ++q) s += sRed[(q * cpb + tid) * 8 + e];
-          if ((cbase + tid) * 8 + e < p.creal) atomicAdd(p.dbias + (cbase + tid) * 8 + e, s);
+          if (p.part) p.part[(long)blockIdx.x * p.part_ld + (cbase + tid) * 8 + e] = s;
+          else if ((cbase + tid) * 8 + e < p.creal) atomicAdd(p.dbias + (cbase + tid) * 8 + e, s);
         }
       }
       __syncthreads();
@@ -111,7 +145,10 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const EpiK p) {
     dpr = wave_sum(dpr);
     if ((tid & 63) == 0) sPre[tid >> 6] = dpr;
     __syncthreads();
-    if (tid == 0) atomicAdd(p.dprelu, sPre[0] + sPre[1] + sPre[2] + sPre[3]);
+    if (tid == 0) {
+      if (p.part) p.part[(long)blockIdx.x * p.part_ld + p.c8 * 8] = sPre[0] + sPre[1] + sPre[2] + sPre[3];
+      else atomicAdd(p.dprelu, sPre[0] + sPre[1] + sPre[2] + sPre[3]);
+    }
   }
 }
 
@@ -134,7 +171,13 @@ extern "C" int csbsr_epilogue_backward(const csbsr_epi_bwd_desc_t* d, csbsr_stre
   const int cpb = k.c8 < 256 ? k.c8 : 256;
   const int ppb = 256 / cpb;
   int blocks = grid_for(d->npix, ppb * 8, 2048);
+  k.part = nullptr; k.part_ld = d->c + 8;
+  if ((k.dbias || k.dprelu) && g_red_scratch && (long)blocks * k.part_ld <= g_red_scratch_elems) k.part = g_red_scratch;
   hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(blocks), dim3(256), 0, ST(s), k);
+  if (k.part) {
+    if (k.dbias) csbsr_sum_partials(k.part, blocks, k.part_ld, d->creal, k.dbias, ST(s));
+    if (k.dprelu) csbsr_sum_partials(k.part + d->c, blocks, k.part_ld, 1, k.dprelu, ST(s));
+  }
   CSBSR_LAUNCH_CHECK("csbsr_epilogue_backward");
   return 0;
 }
@@ -446,6 +489,7 @@ struct BnK {
   half_t* dres; long dres_ld; int dres_acc;
   float *dgamma, *dbeta;
   int cp;
+  float* part; long part_ld;        // bn_bwd_reduce partial rows: [2*cp] sums, PReLU-slope sum at 2*cp
 };
 
 // Elementwise BN kernels: the launch has a multiple of c8 threads in total, so a thread keeps ONE channel octet for its whole
@@ -545,8 +589,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnK p) {
       for (int e = 0; e < 8; ++e) {
         float a = 0.f, b = 0.f;
         for (int q = 0; q < ppb; ++q) { a += sRed[(q * cpb + tid) * 16 + e]; b += sRed[(q * cpb + tid) * 16 + 8 + e]; }
-        atomicAdd(p.red + (cbase + tid) * 8 + e, a);
-        atomicAdd(p.red + p.cp + (cbase + tid) * 8 + e, b);
+        if (p.part) {
+          p.part[(long)blockIdx.x * p.part_ld + (cbase + tid) * 8 + e] = a;
+          p.part[(long)blockIdx.x * p.part_ld + p.cp + (cbase + tid) * 8 + e] = b;
+        } else {
+          atomicAdd(p.red + (cbase + tid) * 8 + e, a);
+          atomicAdd(p.red + p.cp + (cbase + tid) * 8 + e, b);
+        }
       }
     }
     __syncthreads();
@@ -630,7 +679,14 @@ extern "C" int csbsr_bn_backward(const csbsr_bn_desc_t* d, csbsr_stream_t s) {
   BnK k; fill_bnk(k, d);
   const int cpb = k.c8 < 256 ? k.c8 : 256;
   const int ppb = 256 / cpb;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid_for(k.npix, ppb * 8, 1024)), dim3(256), 0, ST(s), k);
+  const int rblocks = grid_for(k.npix, ppb * 8, 1024);
+  k.part = nullptr; k.part_ld = 2 * k.cp + 8;
+  if (g_red_scratch && (long)rblocks * k.part_ld <= g_red_scratch_elems) k.part = g_red_scratch;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rblocks), dim3(256), 0, ST(s), k);
+  if (k.part) {
+    csbsr_sum_partials(k.part, rblocks, k.part_ld, 2 * k.cp, k.red, ST(s));
+    if (k.dprelu) csbsr_sum_partials(k.part + 2 * k.cp, rblocks, k.part_ld, 1, k.dprelu, ST(s));
+  }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_c8(k.npix * k.c8, k.c8)), dim3(256), 0, ST(s), k);
   if (d->dgamma)
     hipLaunchKernelGGL(bn_param_grad_kernel, dim3((d->creal + 255) / 256), dim3(256), 0, ST(s), d->red, d->creal, d->c, d->dgamma, d->dbeta);

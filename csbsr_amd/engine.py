@@ -79,6 +79,10 @@ class Engine:
         self.device = torch.device(device)
         self.grad_scale = float(grad_scale)
         self._ws = None
+        # partial-row scratch of the two-stage reductions (see csbsr_set_reduction_scratch); owned here, registered with the library
+        self._red = torch.empty(16 << 20, dtype=torch.float32, device=self.device) if torch.cuda.is_available() else None
+        if self._red is not None:
+            L.call("csbsr_set_reduction_scratch", _ptr(self._red), self._red.numel())
         self.training = True
         self.timing = None              # list of (kind, flops, bytes, start_event, end_event) when profiling is on
 

@@ -147,6 +147,10 @@ typedef struct {
   float* dprelu;                       /* fp32 scalar += or NULL */
 } csbsr_epi_bwd_desc_t;
 int csbsr_epilogue_backward(const csbsr_epi_bwd_desc_t* d, csbsr_stream_t s);
+/* Caller-owned fp32 scratch for the two-stage per-channel reductions of csbsr_epilogue_backward / csbsr_bn_backward (one partial row
+ * per workgroup + a fold kernel instead of ~1e5 contended atomics per call).  Used by whatever stream the calls are issued on: one
+ * stream at a time per process.  16 Mi floats cover every shape of the path; NULL (the default) keeps the atomics path. */
+int csbsr_set_reduction_scratch(float* buf, int64_t elems);
 
 int csbsr_axpby(int64_t npix, int32_t c, const void* x, int64_t x_ld, float a, const void* z, int64_t z_ld,
                 float b, void* y, int64_t y_ld, csbsr_stream_t s);
