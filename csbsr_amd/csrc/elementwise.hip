@@ -18,27 +18,33 @@ extern "C" int csbsr_set_reduction_scratch(float* buf, int64_t elems) {
   g_red_scratch_elems = buf ? (long)elems : 0;
   return 0;
 }
-// dst[j] += sum over the nblk partial rows; block = 32 columns x 8 row slices
+// dst[j] += sum over the nblk partial rows; block = 32 columns x 8 row slices over a chunk of up to 1024 rows (grid.y chunks, one
+// atomic per column per chunk -- a handful per address)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int nblk, long ld, int count, float* dst) {
   __shared__ float sm[8][33];
   const int col = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
-  float a0 = 0.f, a1 = 0.f;
+  const int r0 = blockIdx.y * 1024, r1 = min(nblk, r0 + 1024);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (col < count) {
-    int b = sl;
-    for (; b + 8 < nblk; b += 16) { a0 += part[(long)b * ld + col]; a1 += part[(long)(b + 8) * ld + col]; }
-    if (b < nblk) a0 += part[(long)b * ld + col];
+    int b = r0 + sl;
+    for (; b + 24 < r1; b += 32) {
+      a0 += part[(long)b * ld + col]; a1 += part[(long)(b + 8) * ld + col];
+      a2 += part[(long)(b + 16) * ld + col]; a3 += part[(long)(b + 24) * ld + col];
+    }
+    for (; b < r1; b += 8) a0 += part[(long)b * ld + col];
   }
-  sm[sl][threadIdx.x & 31] = a0 + a1;
+  sm[sl][threadIdx.x & 31] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (sl == 0 && col < count) {
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) t += sm[q][threadIdx.x & 31];
-    dst[col] += t;
+    if (gridDim.y == 1) dst[col] += t;
+    else atomicAdd(dst + col, t);
   }
 }
 int csbsr_sum_partials(const float* part, int nblk, long ld, int count, float* dst, hipStream_t st) {
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((count + 31) / 32), dim3(256), 0, st, part, nblk, ld, count, dst);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((count + 31) / 32, (nblk + 1023) / 1024), dim3(256), 0, st, part, nblk, ld, count, dst);
   return 0;
 }
 
