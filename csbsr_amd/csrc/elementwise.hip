@@ -1138,7 +1138,7 @@ extern "C" int csbsr_border_class_fill(const float* V, void* out, int64_t ld, in
 }
 // fast path for real image sizes: (1) plain total over all pixels, (2) the O(perimeter) border pixels binned per class in LDS by one
 // workgroup per (sample, edge), (3) interior = total - sum of the border classes.  No contended global atomics.
-__global__ __launch_bounds__(256) void bcs_total_kernel(const half_t* x, long ld, float* sums, long hw, int c8, int chunks) {
+__global__ __launch_bounds__(256) void bcs_total_kernel(const half_t* x, long ld, float* sums, long hw, int c8, int chunks, float* part) {
   __shared__ float sred[256][8];
   const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const int cpb = c8 < 256 ? c8 : 256, ppb = 256 / cpb;
@@ -1164,7 +1164,8 @@ __global__ __launch_bounds__(256) void bcs_total_kernel(const half_t* x, long ld
       for (int e = 0; e < 8; ++e) {
         float s_ = 0.f;
         for (int q = 0; q < ppb; ++q) s_ += sred[q * cpb + threadIdx.x][e];
-        atomicAdd(sums + (long)n * 16 * c8 * 8 + (cbase + threadIdx.x) * 8 + e, s_);
+        if (part) part[(long)blockIdx.x * c8 * 8 + (cbase + threadIdx.x) * 8 + e] = s_;      // row per (sample, chunk): folded by csbsr_sum_partials
+        else atomicAdd(sums + (long)n * 16 * c8 * 8 + (cbase + threadIdx.x) * 8 + e, s_);
       }
     }
     __syncthreads();
@@ -1230,7 +1231,10 @@ extern "C" int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, i
     const long hw = (long)H * W;
     int chunks = (int)((hw + 511) / 512);     // >= 392 workgroups at LR 448^2: the 4096-pixel chunks left 4/5 of the CUs idle
     if (chunks > 2048) chunks = 2048;
-    hipLaunchKernelGGL(bcs_total_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks);
+    float* part = (g_red_scratch && (long)N * chunks * c <= g_red_scratch_elems) ? g_red_scratch : nullptr;
+    hipLaunchKernelGGL(bcs_total_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks, part);
+    if (part)
+      for (int n = 0; n < N; ++n) csbsr_sum_partials(part + (long)n * chunks * c, chunks, c, c, sums + (long)n * 16 * c, ST(s));
     hipLaunchKernelGGL(bcs_edges_kernel, dim3(N * 4 * ((c / 8 + 31) / 32)), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, H, W, c / 8);
     hipLaunchKernelGGL(bcs_fixup_kernel, dim3((N * c + 255) / 256), dim3(256), 0, ST(s), sums, N, c);
     CSBSR_LAUNCH_CHECK("csbsr_border_class_sums");

@@ -84,7 +84,7 @@ __global__ void blur_bwd_input_kernel(const float* dy, const float* kvec, float*
 template <int K>
 __global__ __launch_bounds__(256) void blur_bwd_kernel_kernel(const float* dy, const float* x, float* dk, int C, int H, int W, int OH,
                                                               int OW, int stride, int TO, int lgTO, int tiles_x, int tiles_y,
-                                                              int tiles_per_wg) {
+                                                              int tiles_per_wg, float* part) {
   extern __shared__ float sm[];
   const int P = (K - 1) / 2;
   const int XW = (TO - 1) * stride + K;
@@ -128,8 +128,13 @@ __global__ __launch_bounds__(256) void blur_bwd_kernel_kernel(const float* dy, c
       }
     }
   }
-  if (v0) atomicAdd(dk + (long)n * K * K + t0, acc0);
-  if (v1) atomicAdd(dk + (long)n * K * K + t1, acc1);
+  if (part) {           // row per (sample, workgroup), 512 floats: folded by csbsr_sum_partials
+    float* row = part + ((long)n * gridDim.x + blockIdx.x) * 512;
+    row[t0] = acc0; row[t1] = acc1;
+  } else {
+    if (v0) atomicAdd(dk + (long)n * K * K + t0, acc0);
+    if (v1) atomicAdd(dk + (long)n * K * K + t1, acc1);
+  }
 }
 
 #define BLUR_DISPATCH(K, CALL) \
@@ -182,8 +187,11 @@ extern "C" int csbsr_blur_bwd_kernel(const float* dy, const float* x, float* dk,
   int tpw = (total + 1023) / 1024;          // ~1024 workgroups per sample at most: bounds the atomics per tap
   if (tpw < 1) tpw = 1;
   dim3 grid((total + tpw - 1) / tpw, N);
+  float* part = (g_red_scratch && (long)N * grid.x * 512 <= g_red_scratch_elems) ? g_red_scratch : nullptr;
   BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_bwd_kernel_kernel<KK>), grid, dim3(256), smem, ST(s), dy, x, dk, C, H, W, OH, OW, stride, TO, lgTO,
-                                      tiles_x, tiles_y, tpw));
+                                      tiles_x, tiles_y, tpw, part));
+  if (part)
+    for (int n = 0; n < N; ++n) csbsr_sum_partials(part + (long)n * grid.x * 512, (int)grid.x, 512, K * K, dk + (long)n * K * K, ST(s));
   CSBSR_LAUNCH_CHECK("csbsr_blur_bwd_kernel");
   return 0;
 }
