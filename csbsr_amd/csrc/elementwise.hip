@@ -1175,7 +1175,9 @@ __global__ __launch_bounds__(256) void bcs_total_kernel(const half_t* x, long ld
 __global__ __launch_bounds__(256) void bcs_edges_kernel(const half_t* x, long ld, float* sums, int H, int W, int c8) {
   __shared__ float sbin[3][32][8];           // this edge touches at most 3 classes: edge, its two corners
   const int groups = (c8 + 31) / 32;
+  constexpr int SEG = 8;                      // an edge is cut into 8 segments: 8 atomics per address instead of 16 workgroups in total
   int b = blockIdx.x;
+  const int seg = b % SEG; b /= SEG;
   const int g = b % groups; b /= groups;
   const int edge = b % 4; const int n = b / 4;
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
@@ -1189,8 +1191,9 @@ __global__ __launch_bounds__(256) void bcs_edges_kernel(const half_t* x, long ld
   for (int k = 0; k < 3; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[k][e] = 0.f;
+  const int i0 = (int)((long)len * seg / SEG), i1 = (int)((long)len * (seg + 1) / SEG);
   if (cc < c8)
-    for (int i = pl; i < len; i += 8) {
+    for (int i = i0 + pl; i < i1; i += 8) {
       int y, xx;
       if (edge == 0) { y = 0; xx = i; } else if (edge == 1) { y = H - 1; xx = i; } else if (edge == 2) { y = i + 1; xx = 0; } else { y = i + 1; xx = W - 1; }
       const h8 v = *reinterpret_cast<const h8*>(x + (((long)n * H + y) * W + xx) * ld + cc * 8);
@@ -1212,7 +1215,8 @@ __global__ __launch_bounds__(256) void bcs_edges_kernel(const half_t* x, long ld
       const int cls = base_cls + (k == 1 ? 2 : (k == 2 ? 1 : 0));
       float* dst = sums + ((long)n * 16 + cls) * c8 * 8 + cc * 8;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dst[e] = sbin[k][cl][e];       // exactly one block owns each (n, class, channel)
+      for (int e = 0; e < 8; ++e)
+        if (sbin[k][cl][e] != 0.f) atomicAdd(dst + e, sbin[k][cl][e]);       // 8 segment blocks per (n, class, channel); sums is zeroed by the caller
     }
   }
 }
@@ -1235,7 +1239,7 @@ extern "C" int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, i
     hipLaunchKernelGGL(bcs_total_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks, part);
     if (part)
       for (int n = 0; n < N; ++n) csbsr_sum_partials(part + (long)n * chunks * c, chunks, c, c, sums + (long)n * 16 * c, ST(s));
-    hipLaunchKernelGGL(bcs_edges_kernel, dim3(N * 4 * ((c / 8 + 31) / 32)), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, H, W, c / 8);
+    hipLaunchKernelGGL(bcs_edges_kernel, dim3(N * 4 * ((c / 8 + 31) / 32) * 8), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, H, W, c / 8);
     hipLaunchKernelGGL(bcs_fixup_kernel, dim3((N * c + 255) / 256), dim3(256), 0, ST(s), sums, N, c);
     CSBSR_LAUNCH_CHECK("csbsr_border_class_sums");
     return 0;
