@@ -610,7 +610,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnK p) {
     dsl = wave_sum(dsl);
     if ((tid & 63) == 0) sPre[tid >> 6] = dsl;
     __syncthreads();
-    if (tid == 0) atomicAdd(p.dprelu, sPre[0] + sPre[1] + sPre[2] + sPre[3]);
+    if (tid == 0) {
+      if (p.part) p.part[(long)blockIdx.x * p.part_ld + 2 * p.cp] = sPre[0] + sPre[1] + sPre[2] + sPre[3];
+      else atomicAdd(p.dprelu, sPre[0] + sPre[1] + sPre[2] + sPre[3]);
+    }
   }
 }
 

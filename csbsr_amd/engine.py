@@ -80,7 +80,8 @@ class Engine:
         self.grad_scale = float(grad_scale)
         self._ws = None
         # partial-row scratch of the two-stage reductions (see csbsr_set_reduction_scratch); owned here, registered with the library
-        self._red = torch.empty(16 << 20, dtype=torch.float32, device=self.device) if torch.cuda.is_available() else None
+        # (poisoned with NaN once: a fold that reads a slot its producer did not write shows up immediately instead of adding garbage)
+        self._red = torch.full((16 << 20,), float("nan"), dtype=torch.float32, device=self.device) if torch.cuda.is_available() else None
         if self._red is not None:
             L.call("csbsr_set_reduction_scratch", _ptr(self._red), self._red.numel())
         self.training = True
