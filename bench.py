@@ -71,8 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
     ap.add_argument("--lr-size", type=int, default=448)
-    ap.add_argument("--micro-batch", type=int, default=1)
-    ap.add_argument("--max-resident", type=int, default=7, help="micro-batches whose KBPN activations stay resident for backward")
+    ap.add_argument("--micro-batch", type=int, default=4)
+    ap.add_argument("--max-resident", type=int, default=-1, help="micro-batches whose KBPN activations stay resident for backward")
     ap.add_argument("--workload", default="pspnet_x4", choices=("pspnet_x4", "blurskip_x8", "hrnet_x4"),
                     help="pspnet_x4 = BASELINE config 2 (the bench line); blurskip_x8 = config 5 (x8, PSPNet_BlurSkip, w^F; use --lr-size 224 "
                          "--batch 4); hrnet_x4 = config 4 (HRNet-W48 + OCR, beta 0.9; use --batch 4) -- coverage timings, not the headline")
@@ -107,7 +107,7 @@ def main():
     scale = cfg.MODEL.SCALE_FACTOR
     model = JointModelWithLoss(cfg, 9000, 40000, None, device=str(dev))
     model.micro_batch = args.micro_batch
-    model.max_resident = args.max_resident
+    model.max_resident = None if args.max_resident < 0 else args.max_resident     # None: as many as the free HBM allows
     model.train()
     rt = model._runtime()
     if world > 1:
