@@ -110,14 +110,25 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
 }
 
 // per-thread partial statistics -> LDS bins (uniform sample per tile) or straight to global (tile straddles samples)
+// CPR = channel chunks per staged row: lanes l, l+CPR, l+2CPR .. of a wave own the same 8 channels, so they are folded with
+// xor-shuffles first and only the first CPR lanes of each wave touch the LDS bins (4-way instead of 32-way same-address atomics)
+template <int CPR>
 __device__ __forceinline__ void conv_epilogue_flush_stats(const ConvK& p, float* sStat, int BN, int local_col, int co, bool uniform_n, int cur_n,
                                                           float (&ssum)[8], float (&ssq)[8]) {
   if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
-    if (co < p.coutp) {
+    const bool sq = p.stat_mode == CSBSR_STAT_BN;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = co < p.coutp ? ssum[e] : 0.f, b = (sq && co < p.coutp) ? ssq[e] : 0.f;
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); if (sq) b += __shfl_xor(b, o, 64); }
+      ssum[e] = a; ssq[e] = b;
+    }
+    if ((threadIdx.x & 63) < CPR && co < p.coutp) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         atomicAdd(&sStat[local_col + e], ssum[e]);
-        if (p.stat_mode == CSBSR_STAT_BN) atomicAdd(&sStat[BN + local_col + e], ssq[e]);
+        if (sq) atomicAdd(&sStat[BN + local_col + e], ssq[e]);
       }
     }
   } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && cur_n >= 0 && co < p.coutp) {

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
       }
     }
 
-    conv_epilogue_flush_stats(p, sStat, BN, hh * HB + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
+    conv_epilogue_flush_stats<CPR>(p, sStat, BN, hh * HB + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
   }
 
   if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {

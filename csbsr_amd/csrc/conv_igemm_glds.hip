@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
       }
     }
 
-    conv_epilogue_flush_stats(p, sStat, BN, hh * 64 + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
+    conv_epilogue_flush_stats<CPR>(p, sStat, BN, hh * 64 + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
   }
   if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
     __syncthreads();
