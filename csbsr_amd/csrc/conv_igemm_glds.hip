@@ -30,7 +30,8 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   int* sRow = reinterpret_cast<int*>(smem + SM_BYTES);                      // [BM][3]
   float* sStat = reinterpret_cast<float*>(smem + SM_BYTES + BM * 3 * 4);    // [2][BN]
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS destinations / m0 stay on the scalar unit
   const int wm = wid >> 1, wn = wid & 1;
   const unsigned ntile = p.tiles_m * p.tiles_n;
   const unsigned lt = xcd_remap(blockIdx.x, ntile);
@@ -96,19 +97,28 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     wrow[i] = wt + (size_t)(cout0 + r) * p.Kp + cch;                  // rows_p is padded to the tile: always in bounds
   }
   const half_t* zp = zero_page + (lane & 7) * 8;
-  // scalar running position of the slice being ISSUED: tap index (ky,kx), channel offset cs within the concatenated input
-  int cs = 0, ky = 0, kx = 0, tap = 0;
+  // Scalar running state of the slice being ISSUED.  Nothing here is recomputed per slice: the wave-uniform source pointer moves by
+  // BKG channels inside a tap and by precomputed row / pixel strides between taps (both input segments tracked, their strides may
+  // differ), the per-lane row offsets of the current segment sit in offc[], and the per-lane "tap inside the image" bit is
+  // refreshed only when the tap changes.  (The first version rebuilt all of it per slice: ~80 VALU + ~45 SALU instructions per 16
+  // MFMAs -- 5 + 5 per MFMA in the PMC counts.)
+  int cs = 0, kx = 0, tap = 0;
+  const long tsx0 = (long)tap_step * p.in[0].sx, tsy0 = (long)tap_step * p.in[0].sy - (long)p.KWt * tsx0;
+  const long tsx1 = (long)tap_step * p.in[1].sx, tsy1 = (long)tap_step * p.in[1].sy - (long)p.KWt * tsx1;
+  const half_t* xb0 = reinterpret_cast<const half_t*>(p.in[0].ptr);          // + tap displacement, channel 0 of segment 0
+  const half_t* xb1 = reinterpret_cast<const half_t*>(p.in[1].ptr) - p.c0;   // + tap displacement, indexed by the concatenated channel
+  bool seg0 = true;
+  long offc[NXI];
+  bool vok[NXI];
+#pragma unroll
+  for (int i = 0; i < NXI; ++i) { offc[i] = off0[i]; vok[i] = (tapmask[i] & 1ull) != 0; }
 
   auto issue = [&](int kt) {
     char* sbase = smem + (kt % NSTAGE) * STAGE_BYTES;
-    const bool s0 = cs < p.c0;
-    const long sy = s0 ? p.in[0].sy : p.in[1].sy, sx = s0 ? p.in[0].sx : p.in[1].sx;
-    const half_t* xb = reinterpret_cast<const half_t*>(s0 ? p.in[0].ptr : p.in[1].ptr) + (s0 ? cs : cs - p.c0) +
-                       (long)(ky * tap_step) * sy + (long)(kx * tap_step) * sx;            // wave-uniform
-    const unsigned long long bit = tap < 64 ? (1ull << tap) : 0ull;                        // beyond the last tap: K padding
+    const half_t* xb = (seg0 ? xb0 : xb1) + cs;                                              // wave-uniform
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
-      const half_t* src = (tapmask[i] & bit) ? xb + (s0 ? off0[i] : off1[i]) : zp;
+      const half_t* src = vok[i] ? xb + offc[i] : zp;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sbase + (wid + NW * i) * 1024), 16, 0, 0);
     }
@@ -118,7 +128,23 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
                                        (__attribute__((address_space(3))) void*)(sbase + BM * 128 + (wid + NW * (NXI + i) - XI) * 1024), 16, 0, 0);
     }
     cs += BKG;
-    if (cs >= p.ctot) { cs = 0; ++tap; if (++kx == p.KWt) { kx = 0; ++ky; } }
+    if (cs >= p.ctot) {                       // next tap (wave-uniform branch)
+      cs = 0; ++tap;
+      xb0 += tsx0; xb1 += tsx1;
+      if (++kx == p.KWt) { kx = 0; xb0 += tsy0; xb1 += tsy1; }
+      const unsigned long long bit = tap < 64 ? (1ull << tap) : 0ull;     // beyond the last tap: K padding -> zero page
+#pragma unroll
+      for (int i = 0; i < NXI; ++i) vok[i] = (tapmask[i] & bit) != 0;
+      if (!seg0) {
+        seg0 = true;
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) offc[i] = off0[i];
+      }
+    } else if (seg0 && cs >= p.c0) {          // crossed into the second input segment (c0 is a multiple of BKG here)
+      seg0 = false;
+#pragma unroll
+      for (int i = 0; i < NXI; ++i) offc[i] = off1[i];
+    }
   };
 
   f16v acc[2][2];
