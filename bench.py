@@ -184,7 +184,7 @@ def main():
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_traffic.json; "
-                                "FETCH_SIZE doubled per MI355X_MICROARCH.md), same command at --batch 1" if traffic else None,
+                                "FETCH_SIZE doubled per MI355X_MICROARCH.md), same command at --batch 4 (one KBPN micro-batch of 4, as in the default run)" if traffic else None,
                 "launches": nl, "avg_launch_ms": round(tt * 1e3 / max(nl, 1), 4),
                 "alg_flop_per_launch": round(fl / max(nl, 1) / 1e9, 2), "alg_flop_unit": "GFLOP",
                 "alg_bytes_per_launch": round(by / max(nl, 1)), "share_of_step_time": round(tt / dt, 3),

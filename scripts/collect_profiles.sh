@@ -8,8 +8,8 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch --output-format csv -- python3 $R/bench.py --batch 1 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write --output-format csv -- python3 $R/bench.py --batch 1 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch --output-format csv -- python3 $R/bench.py --batch 4 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write --output-format csv -- python3 $R/bench.py --batch 4 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
 rm -f $O/*/*kernel_trace.csv $O/*/*agent_info.csv 2>/dev/null     # large; the stats / counter files are what is summarised
 ls -la $O $O/* | head -40
 tail -c 600 $O/bench.json

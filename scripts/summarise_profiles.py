@@ -2,7 +2,7 @@
 
   profiles/r01_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `python bench.py` (default flags)
   profiles/r01_bench.json               the JSON line of the same command
-  profiles/r01_pmc_traffic.json         per-kernel HBM bytes per launch from the two --pmc passes (FETCH_SIZE, WRITE_SIZE), at --batch 1
+  profiles/r01_pmc_traffic.json         per-kernel HBM bytes per launch from the two --pmc passes (FETCH_SIZE, WRITE_SIZE), at --batch 4 (one micro-batch of 4, as in the bench)
 
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950
 FETCH_SIZE counts 128-byte requests as 64 bytes for wide coalesced reads, so it is doubled; WRITE_SIZE is taken as is (uncalibrated).
@@ -54,7 +54,7 @@ line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-
 json.dump(json.loads(line), open(os.path.join(DST, f"{TAG}_bench.json"), "w"), indent=1)
 fetch = pmc(os.path.join(SRC, "pmc_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE")
 write = pmc(os.path.join(SRC, "pmc_write", "write_counter_collection.csv"), "WRITE_SIZE")
-out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --batch 1 --steps 1 --warmup 1 --no-cpu-baseline "
+out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --batch 4 --steps 1 --warmup 1 --no-cpu-baseline "
                   "--no-kernel-timing (two separate passes)",
        "units": "bytes per launch; FETCH_SIZE(KiB) x 1024 x 2 (gfx950 correction), WRITE_SIZE(KiB) x 1024", "kernels": {}}
 for k in sorted(fetch, key=lambda k: -fetch[k][0]):
