@@ -35,7 +35,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   const int wm = wid >> 1, wn = wid & 1;
   const unsigned ntile = p.tiles_m * p.tiles_n;
   const unsigned lt = xcd_remap(blockIdx.x, ntile);
-  const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
+  const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;      // cout tile fastest (pixel-fastest: 2.6x less fabric traffic on SFT, 5 % slower)
   const int cout0 = tile_n * BN;
 
   int py = 0, px = 0, OHp = p.OH, OWp = p.OW, in_step = p.stride, tap_step = p.dil, base_y = -p.pad, base_x = -p.pad, o_step = 1;
@@ -97,53 +97,53 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     wrow[i] = wt + (size_t)(cout0 + r) * p.Kp + cch;                  // rows_p is padded to the tile: always in bounds
   }
   const half_t* zp = zero_page + (lane & 7) * 8;
-  // Scalar running state of the slice being ISSUED.  Nothing here is recomputed per slice: the wave-uniform source pointer moves by
-  // BKG channels inside a tap and by precomputed row / pixel strides between taps (both input segments tracked, their strides may
-  // differ), the per-lane row offsets of the current segment sit in offc[], and the per-lane "tap inside the image" bit is
-  // refreshed only when the tap changes.  (The first version rebuilt all of it per slice: ~80 VALU + ~45 SALU instructions per 16
-  // MFMAs -- 5 + 5 per MFMA in the PMC counts.)
+  // Scalar running state of the slice being ISSUED.  K is walked CHANNEL-SLICE OUTER, TAP INNER (the packed weights are indexed
+  // tap * ctot + channel, so only the order of the 64-wide slices changes): a tile's taps re-touch the same 64-channel planes of the
+  // same pixels back to back, so every tap after the first hits L2.  With the taps outer a workgroup streamed its whole pixels x ctot
+  // window (426 KB at 832 channels, x 32 workgroups per XCD >> the 4 MB L2) between two touches of a line and every tap went back
+  // to the fabric: PMC FETCH_SIZE 39 GB per launch for 1.3 GB of input on the SFT 825 -> 825 conv at N = 4.
+  // The wave-uniform source pointer moves by precomputed pixel / row strides between taps (both input segments tracked, their
+  // strides may differ); the per-lane row offsets of the current segment sit in offc[].
+  const int ntaps = p.KHt * p.KWt;
   int cs = 0, kx = 0, tap = 0;
   const long tsx0 = (long)tap_step * p.in[0].sx, tsy0 = (long)tap_step * p.in[0].sy - (long)p.KWt * tsx0;
   const long tsx1 = (long)tap_step * p.in[1].sx, tsy1 = (long)tap_step * p.in[1].sy - (long)p.KWt * tsx1;
-  const half_t* xb0 = reinterpret_cast<const half_t*>(p.in[0].ptr);          // + tap displacement, channel 0 of segment 0
-  const half_t* xb1 = reinterpret_cast<const half_t*>(p.in[1].ptr) - p.c0;   // + tap displacement, indexed by the concatenated channel
+  const half_t* const xb0_0 = reinterpret_cast<const half_t*>(p.in[0].ptr);          // tap 0, channel 0 of segment 0
+  const half_t* const xb1_0 = reinterpret_cast<const half_t*>(p.in[1].ptr) - p.c0;   // tap 0, indexed by the concatenated channel
+  const half_t* xb0 = xb0_0;
+  const half_t* xb1 = xb1_0;
   bool seg0 = true;
   long offc[NXI];
-  bool vok[NXI];
 #pragma unroll
-  for (int i = 0; i < NXI; ++i) { offc[i] = off0[i]; vok[i] = (tapmask[i] & 1ull) != 0; }
+  for (int i = 0; i < NXI; ++i) offc[i] = off0[i];
 
   auto issue = [&](int kt) {
     char* sbase = smem + (kt % NSTAGE) * STAGE_BYTES;
     const half_t* xb = (seg0 ? xb0 : xb1) + cs;                                              // wave-uniform
+    const unsigned long long bit = 1ull << tap;                                             // ntaps <= 64 (eligibility)
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
-      const half_t* src = vok[i] ? xb + offc[i] : zp;
+      const half_t* src = (tapmask[i] & bit) ? xb + offc[i] : zp;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sbase + (wid + NW * i) * 1024), 16, 0, 0);
     }
+    const int wk = tap * p.ctot + cs;                                                        // column of this slice in the packed weights
 #pragma unroll
     for (int i = 0; i < NI - NXI; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + kt * BKG),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + wk),
                                        (__attribute__((address_space(3))) void*)(sbase + BM * 128 + (wid + NW * (NXI + i) - XI) * 1024), 16, 0, 0);
     }
-    cs += BKG;
-    if (cs >= p.ctot) {                       // next tap (wave-uniform branch)
-      cs = 0; ++tap;
+    if (++tap == ntaps) {                     // next channel slice (wave-uniform branch)
+      tap = 0; kx = 0; xb0 = xb0_0; xb1 = xb1_0;
+      cs += BKG;
+      if (seg0 && cs >= p.c0 && cs < p.ctot) {          // crossed into the second input segment (c0 is a multiple of BKG here)
+        seg0 = false;
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) offc[i] = off1[i];
+      }
+    } else {
       xb0 += tsx0; xb1 += tsx1;
       if (++kx == p.KWt) { kx = 0; xb0 += tsy0; xb1 += tsy1; }
-      const unsigned long long bit = tap < 64 ? (1ull << tap) : 0ull;     // beyond the last tap: K padding -> zero page
-#pragma unroll
-      for (int i = 0; i < NXI; ++i) vok[i] = (tapmask[i] & bit) != 0;
-      if (!seg0) {
-        seg0 = true;
-#pragma unroll
-        for (int i = 0; i < NXI; ++i) offc[i] = off0[i];
-      }
-    } else if (seg0 && cs >= p.c0) {          // crossed into the second input segment (c0 is a multiple of BKG here)
-      seg0 = false;
-#pragma unroll
-      for (int i = 0; i < NXI; ++i) offc[i] = off1[i];
     }
   };
 

@@ -36,6 +36,8 @@ if __name__ == "__main__":
     it = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     if len(sys.argv) > 3:
         L.load().csbsr_debug_set_conv_glds(int(sys.argv[3]))
+    what = tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else ("fwd",)
+    nb = int(sys.argv[5]) if len(sys.argv) > 5 else None
     shapes = {
         "sft825": (1, 448, 448, 825, 825, 3, 1, 1),
         "conv8s4": (1, 1792, 1792, 128, 128, 8, 4, 2),
@@ -46,4 +48,6 @@ if __name__ == "__main__":
     }
     for n, sh in shapes.items():
         if sel in ("all", n):
-            run(n, *sh, iters=it)
+            if nb:
+                sh = (nb,) + tuple(sh[1:])
+            run(n, *sh, iters=it, what=what)
