@@ -23,6 +23,7 @@ struct WgradK {
   long per_split;            // pixels per split (multiple of 32)
   unsigned tiles_a, tiles_b;
   int ca_real;               // real channels of A (thin kernel: rows = (tap, channel))
+  int tap_perm;              // 1: XCD-aware tap order of the 8x8 stride-4 layers (see the kernel)
 };
 
 template <bool USE_TR>
@@ -61,7 +62,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   const unsigned ntile = p.tiles_a * p.tiles_b;
   const unsigned lt = xcd_remap(blockIdx.x, ntile);
   const int a0 = (lt % p.tiles_a) * BA;
-  const int col0 = (lt / p.tiles_a) * WG_BN;
+  int col0 = (lt / p.tiles_a) * WG_BN;
+  if (p.tap_perm) {
+    // 8x8 stride-4 layers with 128 gathered channels: one column tile per tap, 64 tiles = 8 per XCD.  Taps whose kernel offsets agree
+    // modulo the stride read the SAME strided pixel set of the gathered side (shifted by whole A-grid pixels), so XCD j takes the
+    // taps with ky = j%4 (+4) and kx in {2(j/4), 2(j/4)+1} (+4): each XCD's L2 then holds 1/8 of the gathered tensor, fetched once,
+    // instead of every row class being pulled in by two XCDs and every column by all of them (PMC: 9.2 GB per launch at N=4 for
+    // 3.5 GB of operands).
+    const int j = lt >> 3, r = lt & 7;
+    const int ky = (j & 3) + 4 * (r >> 2), kx = 2 * (j >> 2) + (r & 1) + 4 * ((r >> 1) & 1);
+    col0 = (ky * 8 + kx) * WG_BN;
+  }
   const long mbeg = (long)blockIdx.z * p.per_split;
   long mend = mbeg + p.per_split;
   if (mend > p.M) mend = p.M;
@@ -188,7 +199,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
 
 static int g_wgrad_use_tr = 1;
 static int g_wgrad_thin = 1;
-extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v & 1; g_wgrad_thin = !(v & 2); }
+static int g_wgrad_tap_perm = 1;
+extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v & 1; g_wgrad_thin = !(v & 2); g_wgrad_tap_perm = !(v & 4); }
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Thin-A variant: stride-1 "same" conv whose output has so few channels that KH*KW*ca_real <= 32 (the 3-channel image heads:
@@ -380,6 +392,7 @@ extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
   k.N = d->N; k.AH = d->AH; k.AW = d->AW; k.BH = d->BH; k.BW = d->BW;
   k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.dil = d->dil;
   k.g = d->g; k.ktot = d->KH * d->KW * k.cbtot;
+  k.tap_perm = (g_wgrad_tap_perm && d->KH == 8 && d->KW == 8 && d->stride == 4 && k.cbtot == WG_BN && d->ca <= 128) ? 1 : 0;
   k.M = (long)d->N * d->AH * d->AW;
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   CSBSR_CHECK(d->splits >= 1, "wgrad: splits must come from csbsr_wgrad_splits()");
