@@ -40,7 +40,7 @@ def test_hrnet_ocr_forward_backward_vs_oracle():
     drop = {"ocr_drop": keep}
     P, seg_o, aux_o, dx_o, bufs_o = _oracle(x, r1, r2, drop)
     with fp16_storage_sim():
-        Ps, seg_s, aux_s, dx_s, _ = _oracle(x, r1, r2, drop)
+        Ps, seg_s, aux_s, dx_s, bufs_s = _oracle(x, r1, r2, drop)
 
     cfg = base_cfg.clone()
     cfg.MODEL.DETECTOR_TYPE = "HRNet_OCR"
@@ -62,7 +62,7 @@ def test_hrnet_ocr_forward_backward_vs_oracle():
         assert e < 2e-3 + 2.0 * es, (name, e, es)
     for k, v in bufs_o.items():
         if "running" in k and ("stage4.2" in k or "f_up" in k or "f_object" in k or "f_pixel" in k or "conv_bn_dropout" in k):
-            assert max_rel_to_scale(rt["P"][k].cpu(), v) < 5e-2, k
+            assert max_rel_to_scale(rt["P"][k].cpu(), v) < 2e-2 + 3.0 * max_rel_to_scale(bufs_s[k], v), k
     # backward
     errs, sims, bad = [], [], []
     dx = dxin.t[..., :3].float().cpu().permute(0, 3, 1, 2) / gs
@@ -82,13 +82,15 @@ def test_hrnet_ocr_forward_backward_vs_oracle():
         e, es = rel_err(mine.reshape(ref.shape), ref), rel_err(sim, ref)
         errs.append(e)
         sims.append(es)
-        if e > max(2.5 * es, 1.2 * float(np.median(sims))) + 3e-2:
-            bad.append((k, e, es))
+        bad.append((k, e, es))
     errs, sims = np.array(errs), np.array(sims)
+    # independent realisations of the same chaotic noise (see tests/test_joint_gpu.py): loose per-tensor bound, distributions compared
+    bad = [b for b in bad if b[1] > max(2.5 * b[2], 1.5 * sims.max()) + 3e-2]
     print("HRNet-OCR grads vs fp32 oracle: median %.2e p90 %.2e max %.2e (n=%d, %d exact zeros); emulation median %.2e p90 %.2e max %.2e"
           % (np.median(errs), np.percentile(errs, 90), errs.max(), len(errs), zero, np.median(sims), np.percentile(sims, 90), sims.max()))
     assert len(errs) > 900 and not bad, bad[:10]
     assert np.median(errs) < 1.5 * np.median(sims) + 5e-3
+    assert np.percentile(errs, 90) < 1.5 * np.percentile(sims, 90) + 3e-2
 
 
 def _fm(x):
