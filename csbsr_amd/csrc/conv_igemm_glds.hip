@@ -29,6 +29,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* sRow = reinterpret_cast<int*>(smem + SM_BYTES);                      // [BM][3]
   float* sStat = reinterpret_cast<float*>(smem + SM_BYTES + BM * 3 * 4);    // [2][BN]
+  float* sBias = sStat + 2 * BN;                                             // [BN]: this tile's bias, fetched before the K loop
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS destinations / m0 stay on the scalar unit
@@ -62,6 +63,8 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     sRow[tid * 3 + 0] = n; sRow[tid * 3 + 1] = oy; sRow[tid * 3 + 2] = ox;
   }
   if (tid < 2 * BN) sStat[tid] = 0.f;
+  if (tid < BN) sBias[tid] = (p.bias && cout0 + tid < p.cout) ? p.bias[cout0 + tid] : 0.f;
+  const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;      // (both used to be loaded inside the epilogue passes)
   __syncthreads();
 
   // ---- per-lane DMA roles.  Instruction j = wid + NW*i of a stage covers tile rows 8j .. 8j+7, lane -> row 8j + lane/8,
@@ -206,7 +209,6 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   }
   __syncthreads();
 
-  const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
   if (p.stat_mode == CSBSR_STAT_NONE && p.direct_epi) {       // register-direct epilogue
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -217,7 +219,12 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     }
     return;
   }
-  // ---- statistics requested: epilogue staged through LDS in passes of 128 pixels x 64 couts (same as conv_igemm.hip)
+  // ---- epilogue staged through LDS in ONE pass: the whole BM x 128 fp32 tile goes into the (now dead) DMA ring -- unpadded rows
+  // of 32 16-byte slots with slot' = slot ^ (row & 15) instead of padding, so it fits exactly (64 KB for BM = 128) -- all waves
+  // stage at once, one LDS-only barrier, then every thread owns one 8-channel chunk of BM/RSTEP rows.  (Two 64-cout passes with
+  // three full barriers, each also draining the previous pass's stores, made the epilogue longer than the 8-slice K loop of the
+  // transposed conv.)
+  static_assert(BM * 128 * 4 <= RING_BYTES, "the staged tile must fit the ring");
   float* sO = reinterpret_cast<float*>(smem);
   const int n_first = sRow[0];
   int n_last;
@@ -226,43 +233,37 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     n_last = (int)(ml / ((long)OHp * OWp));
   }
   const bool uniform_n = (n_first == n_last);
-  constexpr int CPR = 8;                      // 8-channel chunks per staged row (64 couts)
+  constexpr int CPR = 16;                     // 8-channel chunks per staged row (128 couts)
   const int cc8 = tid % CPR;
   constexpr int RSTEP = NT / CPR;
-
-#pragma unroll 1
-  for (int pass = 0; pass < (BM / 128) * 2; ++pass) {
-    const int rh = pass >> 1, hh = pass & 1;
-    if (pass > 0) __syncthreads();
-    if ((wm * 64) / 128 == rh && wn == hh) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int pix = wm * 64 - rh * 128 + b * 32 + (lane & 31);
+    for (int b = 0; b < 2; ++b) {
+      const int pix = wm * 64 + b * 32 + (lane & 31);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int cl = a * 32 + 8 * q + 4 * (lane >> 5);
-            f4 v = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-            *reinterpret_cast<f4*>(sO + pix * OUT_LD + cl) = v;
-          }
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int slot = (wn * 64 + a * 32 + 8 * q + 4 * (lane >> 5)) >> 2;
+        f4 v = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        *reinterpret_cast<f4*>(sO + pix * 128 + ((slot ^ (pix & 15)) << 2)) = v;
+      }
     }
-    __syncthreads();
-    const int co = cout0 + hh * 64 + cc8 * 8;
-    float bias[8], ssum[8], ssq[8];
+  lds_barrier();
+  const int co = cout0 + cc8 * 8;
+  float bias[8], ssum[8], ssq[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f; ssum[e] = ssq[e] = 0.f; }
-    int cur_n = -1;
+  for (int e = 0; e < 8; ++e) { bias[e] = sBias[cc8 * 8 + e]; ssum[e] = ssq[e] = 0.f; }
+  int cur_n = -1;
+  {
     // rows in groups of EG: the group's residual / old-output loads are all issued before the first row is combined
-    constexpr int RPT = 128 / RSTEP, EG = RPT >= 2 ? 2 : 1;
+    constexpr int RPT = BM / RSTEP, EG = 2;
 #pragma unroll
     for (int g = 0; g < RPT / EG; ++g) {
       EpiPre pre[EG];
       int rn[EG], roy[EG], rox[EG];
 #pragma unroll
       for (int i = 0; i < EG; ++i) {
-        const int grow = rh * 128 + tid / CPR + (g * EG + i) * RSTEP;
+        const int grow = tid / CPR + (g * EG + i) * RSTEP;
         const int n = sRow[grow * 3];
         rn[i] = (n < 0 || co >= p.coutp) ? -1 : n;
         roy[i] = py + sRow[grow * 3 + 1] * o_step;
@@ -274,14 +275,13 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
         if (rn[i] < 0) continue;
         const int row = tid / CPR + (g * EG + i) * RSTEP;
         float v[8];
-        const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
-        const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
+        const f4 v0 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8) ^ (row & 15)) << 2));
+        const f4 v1 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8 + 1) ^ (row & 15)) << 2));
         v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
         conv_epilogue_row(p, v, bias, slope, co, rn[i], roy[i], rox[i], uniform_n, cur_n, ssum, ssq, &pre[i]);
       }
     }
-
-    conv_epilogue_flush_stats<CPR>(p, sStat, BN, hh * 64 + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
+    conv_epilogue_flush_stats<CPR>(p, sStat, BN, cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
   }
   if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
     __syncthreads();
@@ -306,7 +306,7 @@ static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   p.tiles_n = (unsigned)((k.coutp + BN - 1) / BN);
   constexpr int RING = NSTAGE * (BM + BN) * 128;
   constexpr int EPI = 128 * 68 * 4;
-  constexpr int SM_BYTES = (RING > EPI ? RING : EPI) + BM * 3 * 4 + 2 * BN * 4;
+  constexpr int SM_BYTES = (RING > EPI ? RING : EPI) + BM * 3 * 4 + 3 * BN * 4;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_glds_kernel<BM, NWM, NSTAGE>),
