@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   half_t* sX = sW + BN * LDS_LD;                                      // [BM][LDS_LD]
   int* sRow = reinterpret_cast<int*>(smem + SM_BYTES);                // [BM][3]  n, oy, ox  (n = -1: invalid)
   float* sStat = reinterpret_cast<float*>(smem + SM_BYTES + BM * 3 * 4);  // [2][BN]
+  float* sBias = sStat + 2 * BN;                                           // [BN]: fetched before the K loop, not inside the epilogue
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -76,6 +77,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     sRow[tid * 3 + 0] = n; sRow[tid * 3 + 1] = oy; sRow[tid * 3 + 2] = ox;
   }
   if (tid < 2 * BN) sStat[tid] = 0.f;
+  if (tid < BN) sBias[tid] = (p.bias && cout0 + tid < p.cout) ? p.bias[cout0 + tid] : 0.f;
+  const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
   __syncthreads();
 
   // ---- per-thread gather state: rows tid/8 + 32 j (j < 4); 16-byte k-segment seg = tid%8 (one K slice = 64 channels of one
@@ -208,7 +211,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
   // ---- epilogue: fp32 tile -> LDS [pixel][cout] in halves of HB couts (keeps LDS <= the main-loop footprint so three
   // workgroups fit per CU), then channel-contiguous 8-wide processing
-  const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
   if (p.stat_mode == CSBSR_STAT_NONE && p.direct_epi) {       // register-direct epilogue (conv_common.h)
 #pragma unroll
     for (int b = 0; b < TP; ++b) {
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 
 #pragma unroll 1
   for (int hh = 0; hh < NH; ++hh) {
-    if (hh > 0) __syncthreads();              // previous half fully consumed
+    if (hh > 0) lds_barrier();                // previous half fully consumed (LDS only: no wait for its global stores)
 #pragma unroll
     for (int a = 0; a < TC; ++a) {
       const int cbase = wc * CW + a * 32;     // wave-uniform
@@ -248,12 +250,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
 
     const int co = cout0 + hh * HB + cc8 * 8;
     float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bias[e] = sBias[hh * HB + cc8 * 8 + e];
     float ssum[8], ssq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
@@ -311,7 +313,7 @@ static int launch_conv(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   constexpr int OUT_LD = (BN == 128 ? 64 : BN) + 4;
   constexpr int MAIN_BYTES = (BN + BM) * LDS_LD * 2;
   constexpr int EPI_BYTES = BM * OUT_LD * 4;
-  constexpr int SM_BYTES = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + BM * 3 * 4 + 2 * BN * 4;
+  constexpr int SM_BYTES = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + BM * 3 * 4 + 3 * BN * 4;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BN, WP, WC>),
