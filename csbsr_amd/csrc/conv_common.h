@@ -148,8 +148,10 @@ __device__ __forceinline__ void conv_epilogue_flush_stats(const ConvK& p, float*
 // Register-direct epilogue for one 32x32 accumulator tile (no statistics requested): v_permlane32_swap pairs turn the MFMA
 // layout (lane l / l+32 hold couts 8q..8q+3 / 8q+4..8q+7 of pixel l%32) into 8 consecutive couts per lane, so every lane issues
 // 16-byte stores / residual loads for its own pixel -- no LDS round trip, no barriers, one address computation per pixel.
+// ``bias_tab``: per-cout bias already staged by the caller (LDS, indexed by absolute cout, zeros past p.cout), or nullptr to read p.bias
+// from global memory here -- 8 dependent L2 round trips per call, which is most of a short tile's epilogue.
 __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const f16v& acc, int cbase /*first cout of the 32-wide tile*/,
-                                                          float slope, int n, int oy, int ox) {
+                                                          float slope, int n, int oy, int ox, const float* bias_tab = nullptr) {
   if (n < 0) return;
   const int hi = (threadIdx.x & 63) >> 5;
 #pragma unroll
@@ -167,7 +169,7 @@ __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const 
     if (co >= p.coutp) continue;
     float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bias[e] = bias_tab ? bias_tab[co + e] : ((p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f);
     float s0[8], s1[8];
     int cur_n = -1;
     conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, true, cur_n, s0, s1);

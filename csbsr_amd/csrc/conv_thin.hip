@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256) void conv_thin_cin_kernel(const ConvK p, int t
   const int nct = (p.cout + 31) / 32;
   half_t* sWt = reinterpret_cast<half_t*>(smem);                     // [nct*32][TK_WLD], k = tap*CI + c
   half_t* sIn = sWt + (size_t)nct * 32 * TK_WLD;                      // [TN_HP][4]
+  float* sBias = reinterpret_cast<float*>(sIn + TN_HP * 4);           // [nct*32]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5;
   int b = blockIdx.x;
   const int tx = b % tiles_x; b /= tiles_x;
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256) void conv_thin_cin_kernel(const ConvK p, int t
     const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     *reinterpret_cast<h8*>(sWt + id * 8) = z;
   }
+  for (int id = tid; id < nct * 32; id += 256) sBias[id] = (p.bias && id < p.cout) ? p.bias[id] : 0.f;
   __syncthreads();
   for (int id = tid; id < nct * 32 * 9; id += 256) {
     const int co = id / 9, tap = id - co * 9;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_thin_cin_kernel(const ConvK p, int t
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, pf[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, pf[1], acc, 0, 0, 0);
-      conv_epilogue_direct_tile(p, acc, ct * 32, slope, nn, oy, ox);
+      conv_epilogue_direct_tile(p, acc, ct * 32, slope, nn, oy, ox, sBias);
     }
   }
   }
@@ -258,7 +260,7 @@ bool conv_thin_cin_eligible(const ConvK& k, int creal) {
 int conv_thin_cin_launch(const ConvK& k, int creal, hipStream_t st) {
   const int tiles_x = (k.OW + TN_TW - 1) / TN_TW, tiles_y = (k.OH + TN_TH - 1) / TN_TH;
   const int nct = (k.cout + 31) / 32;
-  const size_t smem = ((size_t)nct * 32 * TK_WLD + (size_t)TN_HP * 4) * sizeof(half_t);
+  const size_t smem = ((size_t)nct * 32 * TK_WLD + (size_t)TN_HP * 4) * sizeof(half_t) + (size_t)nct * 32 * sizeof(float);
   static size_t configured = 0;
   if (smem > configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_cin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
