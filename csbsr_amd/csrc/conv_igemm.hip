@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     constexpr int RSTEP = 256 / CPR;
     // rows in groups of EG: the group's residual / old-output loads are all issued before the first row is combined
     constexpr int RPT = BM / RSTEP, EG = RPT >= 2 ? 2 : 1;
-#pragma unroll
+#pragma unroll 1      // one copy of the (large, mode-rich) row code: fully unrolled the kernel was 23 K instructions
     for (int g = 0; g < RPT / EG; ++g) {
       EpiPre pre[EG];
       int rn[EG], roy[EG], rox[EG];

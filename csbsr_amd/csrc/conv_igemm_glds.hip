@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   {
     // rows in groups of EG: the group's residual / old-output loads are all issued before the first row is combined
     constexpr int RPT = BM / RSTEP, EG = 2;
-#pragma unroll
+#pragma unroll 1      // one copy of the (large, mode-rich) row code: fully unrolled the kernel was 23 K instructions
     for (int g = 0; g < RPT / EG; ++g) {
       EpiPre pre[EG];
       int rn[EG], roy[EG], rox[EG];
