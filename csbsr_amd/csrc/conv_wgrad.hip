@@ -99,23 +99,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   constexpr int ACH = BA / 8;
   constexpr int A_ITERS = WG_BP * ACH / 256;
 
-  // per-thread running pixel coordinates (no integer division in the loop): B chunk j covers pixel (tid>>4) + 16 j,
-  // A chunk i covers pixel tid/ACH + (256/ACH) i of the step being LOADED
-  struct Pix { int n, y, x; };
-  auto init_pix = [&](long m) {
+  // per-thread running pixel coordinates AND element offsets (no integer division, no 64-bit multiply in the loop: the offsets move by
+  // precomputed strides; rebuilding n*sn + y*sy + x*sx per chunk cost ~17 VALU instructions per MFMA in the PMC counts): B chunk j
+  // covers pixel (tid>>4) + 16 j, A chunk i covers pixel tid/ACH + (256/ACH) i of the step being LOADED
+  struct Pix { int n, y, x; long off; };
+  auto init_pix = [&](long m, long sn, long sy, long sx) {
     Pix c;
     c.n = (int)(m / ((long)p.AH * p.AW));
     const int rem = (int)(m - (long)c.n * p.AH * p.AW);
     c.y = rem / p.AW; c.x = rem - c.y * p.AW;
+    c.off = c.n * sn + c.y * sy + c.x * sx;
     return c;
   };
-  auto advance = [&](Pix& c, int d) {
-    c.x += d;
-    while (c.x >= p.AW) { c.x -= p.AW; if (++c.y == p.AH) { c.y = 0; ++c.n; } }
-  };
   constexpr int A_DELTA = 256 / ACH;
-  Pix cb = init_pix(mbeg + (tid >> 4));
-  Pix ca_ = init_pix(mbeg + tid / ACH);
+  // B: element offset of tap (0,0)'s source pixel = n*b_sn + (y*stride)*b_sy + (x*stride)*b_sx ; the tap displacement is a constant
+  const long bsx = (long)p.stride * b_sx, bsy = (long)p.stride * b_sy;
+  const long b_tap = (long)b_ky * b_sy + (long)b_kx * b_sx;
+  const long b_dx = 16 * bsx, b_rowfix = bsy - (long)p.AW * bsx, b_imgfix = b_sn - (long)p.AH * bsy;
+  const long a_dx = (long)A_DELTA * p.a_sx, a_rowfix = p.a_sy - (long)p.AW * p.a_sx, a_imgfix = p.a_sn - (long)p.AH * p.a_sy;
+  auto advance = [&](Pix& c, int d, long dxs, long rowfix, long imgfix) {
+    c.x += d; c.off += dxs;
+    while (c.x >= p.AW) { c.x -= p.AW; c.off += rowfix; if (++c.y == p.AH) { c.y = 0; ++c.n; c.off += imgfix; } }
+  };
+  Pix cb = init_pix(mbeg + (tid >> 4), b_sn, bsy, bsx);
+  Pix ca_ = init_pix(mbeg + tid / ACH, p.a_sn, p.a_sy, p.a_sx);
 
   f16v acc[TA][TB];
 #pragma unroll
@@ -127,6 +134,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
 
   h8 gb[B_ITERS], ga[A_ITERS];
   const int a_ch = (tid % ACH) * 8;
+  const half_t* a_base = p.a + a0 + a_ch;
+  const half_t* b_base = b_ptr + b_tap;
+  const bool a_ok = a0 + a_ch < p.ca;
   auto issue_loads = [&](long m) {     // global -> registers for the step starting at pixel m, then advance the coordinates
 #pragma unroll
     for (int j = 0; j < B_ITERS; ++j) {
@@ -134,20 +144,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
       h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       if (b_ok && m + pix < mend) {
         const int by = cb.y * p.stride + b_ky, bx = cb.x * p.stride + b_kx;
-        if ((unsigned)by < (unsigned)p.BH && (unsigned)bx < (unsigned)p.BW)
-          v = *reinterpret_cast<const h8*>(b_ptr + cb.n * b_sn + by * b_sy + bx * b_sx);
+        if ((unsigned)by < (unsigned)p.BH && (unsigned)bx < (unsigned)p.BW) v = *reinterpret_cast<const h8*>(b_base + cb.off);
       }
       gb[j] = v;
-      advance(cb, 16);
+      advance(cb, 16, b_dx, b_rowfix, b_imgfix);
     }
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       const int pix = tid / ACH + A_DELTA * i;
       h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (m + pix < mend && a0 + a_ch < p.ca)
-        v = *reinterpret_cast<const h8*>(p.a + ca_.n * p.a_sn + ca_.y * p.a_sy + ca_.x * p.a_sx + a0 + a_ch);
+      if (a_ok && m + pix < mend) v = *reinterpret_cast<const h8*>(a_base + ca_.off);
       ga[i] = v;
-      advance(ca_, A_DELTA);
+      advance(ca_, A_DELTA, a_dx, a_rowfix, a_imgfix);
     }
   };
 
