@@ -78,6 +78,7 @@ def main():
                          "--batch 4); hrnet_x4 = config 4 (HRNet-W48 + OCR, beta 0.9; use --batch 4) -- coverage timings, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dump-layers", default=None, help="write the per-launch conv / wgrad log of the timed region (layer, shape, kernel, ms) as JSON")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -158,6 +159,9 @@ def main():
     imgs = B * world * args.steps / dt
 
     roof = None
+    if eng.timing and args.dump_layers and rank == 0:
+        json.dump([{"kind": t[0], "flops": t[1], "bytes": t[2], "ms": t[3].elapsed_time(t[4]), "layer": t[5], "shape": list(t[6]),
+                    "kernel": (t[7] if len(t) > 7 else -1)} for t in eng.timing], open(args.dump_layers, "w"))
     if eng.timing:
         # one roofline block = ONE kernel: the conv kernel with the largest share of the timed region (csbsr_debug_last_conv_kernel tags
         # every launch with the kernel it dispatched to).  achieved = algorithmic FLOPs of those launches / their HIP-event time.

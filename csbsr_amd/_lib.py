@@ -131,6 +131,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
     _lib = lib
+    if os.environ.get("CSBSR_WGRAD_DBG"):          # A/B hook: bit0 transpose reads, 2 no thin, 4 no tap order, 8 no flat grid, 16 flat everywhere
+        lib.csbsr_debug_set_wgrad_tr(int(os.environ["CSBSR_WGRAD_DBG"]))
     if os.environ.get("CSBSR_CONV_GLDS"):          # A/B hook for kernel selection experiments
         lib.csbsr_debug_set_conv_glds(int(os.environ["CSBSR_CONV_GLDS"]))
     return lib

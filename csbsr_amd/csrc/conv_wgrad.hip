@@ -24,6 +24,8 @@ struct WgradK {
   unsigned tiles_a, tiles_b;
   int ca_real;               // real channels of A (thin kernel: rows = (tap, channel))
   int tap_perm;              // 1: XCD-aware tap order of the 8x8 stride-4 layers (see the kernel)
+  int flat;                  // 1: 1-D grid over (split, tile): all tiles of one pixel split run on ONE XCD (see the kernel)
+  int splits;
 };
 
 template <bool USE_TR>
@@ -60,7 +62,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wa = wid / WB, wb = wid % WB;
   const unsigned ntile = p.tiles_a * p.tiles_b;
-  const unsigned lt = xcd_remap(blockIdx.x, ntile);
+  unsigned lt, zsplit;
+  if (p.flat) {
+    // every tile of a split reads the same pixel range of both operands, so the whole split goes to one XCD (a contiguous chunk of
+    // the (split, tile) order): its L2 fetches the range once while the tiles stream through it in step.  With the tiles of a split
+    // dealt across the XCDs instead, each XCD pulled in every operand range itself (PMC: 4-15x the operand bytes per launch).
+    const unsigned w = xcd_remap(blockIdx.x, ntile * (unsigned)p.splits);
+    zsplit = w / ntile; lt = w - zsplit * ntile;
+  } else {
+    lt = xcd_remap(blockIdx.x, ntile); zsplit = blockIdx.z;
+  }
   const int a0 = (lt % p.tiles_a) * BA;
   int col0 = (lt / p.tiles_a) * WG_BN;
   if (p.tap_perm) {
@@ -73,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
     const int ky = (j & 3) + 4 * (r >> 2), kx = 2 * (j >> 2) + (r & 1) + 4 * ((r >> 1) & 1);
     col0 = (ky * 8 + kx) * WG_BN;
   }
-  const long mbeg = (long)blockIdx.z * p.per_split;
+  const long mbeg = (long)zsplit * p.per_split;
   long mend = mbeg + p.per_split;
   if (mend > p.M) mend = p.M;
   if (mbeg >= mend) return;
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   // ---- epilogue: D[a][col], lane: col = lane%32, rows (r&3)+8*(r>>2)+4*(lane>>5)
   // every (row < ca, col < ktot) element of this split's slab is written exactly once: no atomics, no zero-fill;
   // csbsr_unpack_wgrad sums the slabs
-  float* slab = p.g + (size_t)blockIdx.z * p.ca * p.ktot;
+  float* slab = p.g + (size_t)zsplit * p.ca * p.ktot;
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -208,7 +219,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
 static int g_wgrad_use_tr = 1;
 static int g_wgrad_thin = 1;
 static int g_wgrad_tap_perm = 1;
-extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v & 1; g_wgrad_thin = !(v & 2); g_wgrad_tap_perm = !(v & 4); }
+static int g_wgrad_flat = 1;     // 0 off, 1 every layer without the tap permutation, 2 every layer
+extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v & 1; g_wgrad_thin = !(v & 2); g_wgrad_tap_perm = !(v & 4); g_wgrad_flat = (v & 8) ? 0 : ((v & 16) ? 2 : 1); }
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Thin-A variant: stride-1 "same" conv whose output has so few channels that KH*KW*ca_real <= 32 (the 3-channel image heads:
@@ -380,7 +392,10 @@ static int launch_wgrad(const WgradK& k, int splits, hipStream_t st) {
     csbsr_set_error("wgrad: splits=%d leaves an empty slab; use csbsr_wgrad_splits()", splits);
     return 1;
   }
-  dim3 grid(ntile, 1, splits);
+  p.splits = splits;
+  if (g_wgrad_flat == 2) { p.flat = 1; p.tap_perm = 0; }
+  else p.flat = (g_wgrad_flat == 1 && !p.tap_perm && ntile <= 48) ? 1 : 0;   // measured: +5..25 % up to ~40 tiles, -1..2 % for the 100+ tile layers
+  dim3 grid(p.flat ? ntile * splits : ntile, 1, p.flat ? 1 : splits);
   if (g_wgrad_use_tr)
     hipLaunchKernelGGL((conv_wgrad_kernel<BA, WA, WB, true>), grid, dim3(256), 0, st, p);
   else

@@ -45,6 +45,10 @@ if __name__ == "__main__":
         "res512": (8, 224, 224, 512, 512, 3, 1, 1),
         "hr32": (1, 1792, 1792, 32, 32, 3, 1, 1),
         "gemm1x1": (1, 1792, 1792, 128, 128, 1, 1, 0),
+        "hr49": (1, 1792, 1792, 49, 49, 3, 1, 1),
+        "c128": (1, 448, 448, 128, 128, 3, 1, 1),
+        "res256": (8, 224, 224, 256, 256, 3, 1, 1),
+        "up1024": (1, 448, 448, 1024, 256, 3, 1, 1),
     }
     for n, sh in shapes.items():
         if sel in ("all", n):
