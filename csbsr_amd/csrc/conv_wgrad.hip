@@ -26,6 +26,7 @@ struct WgradK {
   int tap_perm;              // 1: XCD-aware tap order of the 8x8 stride-4 layers (see the kernel)
   int flat;                  // 1: 1-D grid over (split, tile): all tiles of one pixel split run on ONE XCD (see the kernel)
   int splits;
+  int row_shift;             // 1: per-tile pixel-range shift that aligns the gathered rows of taps a stride apart (see the kernel)
 };
 
 template <bool USE_TR>
@@ -84,9 +85,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
     const int ky = (j & 3) + 4 * (r >> 2), kx = 2 * (j >> 2) + (r & 1) + 4 * ((r >> 1) & 1);
     col0 = (ky * 8 + kx) * WG_BN;
   }
-  const long mbeg = (long)zsplit * p.per_split;
+  // Strided layers: the tap row ky reads gathered row y*stride + ky*dil - pad, so tiles whose taps differ by a whole stride in ky touch
+  // the same (16x larger) gathered rows one A-row apart in time -- 7 steps x every resident workgroup's traffic, far beyond the L2.
+  // Each tile's pixel ranges are therefore slid back by floor(ky*dil/stride) A-rows: all taps of a residue class then stream the same
+  // gathered rows in the same steps.  (The ranges still partition [0, M): the first split is shorter, the last one longer.)
+  long shift = 0;
+  if (p.row_shift) shift = (long)((((col0 / p.cbtot) / p.KW) * p.dil) / p.stride) * p.AW;
+  long mbeg = (long)zsplit * p.per_split - shift;
   long mend = mbeg + p.per_split;
-  if (mend > p.M) mend = p.M;
+  if (mbeg < 0) mbeg = 0;
+  if (mend > p.M || (int)zsplit == p.splits - 1) mend = p.M;
   if (mbeg >= mend) return;
 
   // ---- B staging role: chunk ids tid + 256*j : pixel = id/16, col chunk = id%16
@@ -219,8 +227,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
 static int g_wgrad_use_tr = 1;
 static int g_wgrad_thin = 1;
 static int g_wgrad_tap_perm = 1;
+static int g_wgrad_row_shift = 1;
+static int g_wgrad_extra_lds = 0;   // A/B: dynamic LDS bytes added to the launch to lower the occupancy
 static int g_wgrad_flat = 1;     // 0 off, 1 every layer without the tap permutation, 2 every layer
-extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v & 1; g_wgrad_thin = !(v & 2); g_wgrad_tap_perm = !(v & 4); g_wgrad_flat = (v & 8) ? 0 : ((v & 16) ? 2 : 1); }
+extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v & 1; g_wgrad_thin = !(v & 2); g_wgrad_tap_perm = !(v & 4); g_wgrad_flat = (v & 8) ? 0 : ((v & 16) ? 2 : 1); g_wgrad_row_shift = !(v & 32); g_wgrad_extra_lds = (v >> 8) * 1024; }
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Thin-A variant: stride-1 "same" conv whose output has so few channels that KH*KW*ca_real <= 32 (the 3-channel image heads:
@@ -393,11 +403,13 @@ static int launch_wgrad(const WgradK& k, int splits, hipStream_t st) {
     return 1;
   }
   p.splits = splits;
+  // the shift must leave the first split non-empty (slabs are written, not accumulated)
+  p.row_shift = (g_wgrad_row_shift && k.stride > 1 && (long)((k.KH - 1) * k.dil / k.stride) * k.AW < p.per_split) ? 1 : 0;
   if (g_wgrad_flat == 2) { p.flat = 1; p.tap_perm = 0; }
   else p.flat = (g_wgrad_flat == 1 && !p.tap_perm && ntile <= 48) ? 1 : 0;   // measured: +5..25 % up to ~40 tiles, -1..2 % for the 100+ tile layers
   dim3 grid(p.flat ? ntile * splits : ntile, 1, p.flat ? 1 : splits);
   if (g_wgrad_use_tr)
-    hipLaunchKernelGGL((conv_wgrad_kernel<BA, WA, WB, true>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<BA, WA, WB, true>), grid, dim3(256), g_wgrad_extra_lds, st, p);
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<BA, WA, WB, false>), grid, dim3(256), 0, st, p);
   CSBSR_LAUNCH_CHECK("csbsr_conv_wgrad");
