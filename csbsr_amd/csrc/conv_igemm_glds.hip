@@ -35,13 +35,23 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS destinations / m0 stay on the scalar unit
   const int wm = wid >> 1, wn = wid & 1;
   const unsigned ntile = p.tiles_m * p.tiles_n;
-  const unsigned lt = xcd_remap(blockIdx.x, ntile);
+  // Transposed layers: the stride^2 output phases of one pixel tile gather the SAME input pixels (and write interleaved pieces of the
+  // same output rows), so the phase is the FASTEST index of a 1-D grid: a tile's phases run side by side on one XCD, the input tile
+  // comes from HBM / Infinity Cache once instead of once per phase and the others hit L2.  (grid.z = phase put the phases a whole
+  // sweep of the image apart.)
+  unsigned lt, zph;
+  if (p.nphase_flat > 1) {
+    const unsigned w = xcd_remap(blockIdx.x, ntile * (unsigned)p.nphase_flat);
+    lt = w / (unsigned)p.nphase_flat; zph = w - lt * (unsigned)p.nphase_flat;
+  } else {
+    lt = xcd_remap(blockIdx.x, ntile); zph = blockIdx.z;
+  }
   const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;      // cout tile fastest (pixel-fastest: 2.6x less fabric traffic on SFT, 5 % slower)
   const int cout0 = tile_n * BN;
 
   int py = 0, px = 0, OHp = p.OH, OWp = p.OW, in_step = p.stride, tap_step = p.dil, base_y = -p.pad, base_x = -p.pad, o_step = 1;
   if (p.transposed) {
-    py = blockIdx.z / p.stride; px = blockIdx.z % p.stride;
+    py = zph / p.stride; px = zph % p.stride;
     OHp = (p.OH - py + p.stride - 1) / p.stride;
     OWp = (p.OW - px + p.stride - 1) / p.stride;
     in_step = 1; tap_step = -1; o_step = p.stride;
@@ -50,7 +60,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   const long M = (long)p.N * OHp * OWp;
   const long m0 = (long)tile_m * BM;
   if (m0 >= M) return;
-  const half_t* wt = p.wt + (size_t)blockIdx.z * p.rows_p * p.Kp;
+  const half_t* wt = p.wt + (size_t)zph * p.rows_p * p.Kp;
 
   if (tid < BM) {
     long m = m0 + tid;
@@ -297,6 +307,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 }
 
 static half_t* g_zero_page = nullptr;
+static int g_glds_phase_flat = 1;
 
 template <int BM, int NWM, int NSTAGE>
 static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
@@ -320,7 +331,8 @@ static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
     if (hipMalloc(reinterpret_cast<void**>(&g_zero_page), 256) != hipSuccess) { csbsr_set_error("conv(glds): zero page alloc failed"); return 2; }
     (void)hipMemset(g_zero_page, 0, 256);
   }
-  dim3 grid(p.tiles_m * p.tiles_n, 1, nphase);
+  p.nphase_flat = (g_glds_phase_flat && nphase > 1) ? nphase : 0;
+  dim3 grid(p.tiles_m * p.tiles_n * (p.nphase_flat ? nphase : 1), 1, p.nphase_flat ? 1 : nphase);
   hipLaunchKernelGGL((conv_igemm_glds_kernel<BM, NWM, NSTAGE>), grid, dim3(NWM * 128), SM_BYTES, st, p, g_zero_page);
   CSBSR_LAUNCH_CHECK("csbsr_conv_forward(glds)");
   return 0;
@@ -330,6 +342,7 @@ static int g_glds_mode = 2;      // 0: off, 1: 128x128 x2 stages only, 2: + 256x
 int g_conv_direct_epi = 0;      // measured: 32-byte store segments lose to the LDS-staged 128-byte ones on the tile kernels
 extern "C" void csbsr_debug_set_conv_glds(int mode) {
   g_glds_mode = mode & 7;
+  g_glds_phase_flat = (mode & 32) ? 0 : 1;     // bit 5: phases back on grid.z (A/B timing)
   g_conv_direct_epi = (mode & 8) ? 1 : 0;
   conv_thin_enable((mode & 16) ? 0 : 1);      // bit 4: route the 3-channel heads through the generic kernel (A/B timing)
 }
