@@ -12,7 +12,15 @@
 //  * halo / padding / tile-overhang lanes fetch from a 256-byte zero page instead of branching.
 #include "common.h"
 #include "conv_common.h"
+#include <type_traits>
 
+#ifdef CSBSR_TS
+__device__ unsigned long long g_ts[8 * 262144];
+#define TS(i) do { if (threadIdx.x == 0 && blockIdx.x < 262144) g_ts[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+extern "C" int csbsr_debug_read_ts(void* dst, long n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ts), n * 8); }
+#else
+#define TS(i)
+#endif
 template <int BM, int NWM, int NSTAGE>
 __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK p, const half_t* __restrict__ zero_page) {
   constexpr int BN = 128, BKG = 64;
@@ -27,10 +35,18 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   constexpr int SM_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
   static_assert(XI % NW == 0 && WI % NW == 0, "tile rows must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* sRow = reinterpret_cast<int*>(smem + SM_BYTES);                      // [BM][3]
-  float* sStat = reinterpret_cast<float*>(smem + SM_BYTES + BM * 3 * 4);    // [2][BN]
-  float* sBias = sStat + 2 * BN;                                             // [BN]: this tile's bias, fetched before the K loop
+  // per tile-row tables, filled by ONE thread per row in the prologue (each of the 8 lanes that DMA a row, and each of the 16 threads
+  // that later store it, used to redo the 64-bit address products and the tap walk: 26 us of a 200 us workgroup on the 64-tap layers,
+  // 2 us of 18 on the transposed ones)
+  long* sOff0 = reinterpret_cast<long*>(smem + SM_BYTES);                    // [BM] element offset of tap (0,0) in input segment 0
+  long* sOff1 = sOff0 + BM;                                                  // [BM] ... in segment 1
+  unsigned long long* sMask = reinterpret_cast<unsigned long long*>(sOff1 + BM);   // [BM] bit t: tap t lands inside the image
+  long* sOOff = reinterpret_cast<long*>(sMask + BM);                         // [BM] element offset of the output pixel in out16
+  int* sRow = reinterpret_cast<int*>(sOOff + BM);                            // [BM][3] (n, oy, ox) of the phase grid; n = -1: no pixel
+  float* sStat = reinterpret_cast<float*>(sRow + BM * 3);                    // [2][BN]
+  float* sBias = sStat + 2 * BN;                                             // [BN]: this tile's bias
 
+  TS(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: LDS destinations / m0 stay on the scalar unit
   const int wm = wid >> 1, wn = wid & 1;
@@ -62,6 +78,9 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   if (m0 >= M) return;
   const half_t* wt = p.wt + (size_t)zph * p.rows_p * p.Kp;
 
+  // the bias is fetched now and parked in LDS after the first DMA issue: its HBM round trip used to sit in front of the prologue barrier
+  float bias_reg = 0.f;
+  if (tid < BN && p.bias && cout0 + tid < p.cout) bias_reg = p.bias[cout0 + tid];
   if (tid < BM) {
     long m = m0 + tid;
     int n = -1, oy = 0, ox = 0;
@@ -71,37 +90,38 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
       oy = rem / OWp; ox = rem - oy * OWp;
     }
     sRow[tid * 3 + 0] = n; sRow[tid * 3 + 1] = oy; sRow[tid * 3 + 2] = ox;
+    const int iy0 = oy * in_step + base_y, ix0 = ox * in_step + base_x;
+    sOff0[tid] = n * p.in[0].sn + iy0 * p.in[0].sy + ix0 * p.in[0].sx;
+    sOff1[tid] = n * p.in[1].sn + iy0 * p.in[1].sy + ix0 * p.in[1].sx;
+    unsigned long long mk = 0;
+    if (n >= 0) {
+      // tap (ty, tx) is inside the image iff its row is and its column is: KHt + KWt tests, then one shifted OR per live tap row
+      unsigned xm = 0;
+      for (int tx = 0, ix = ix0; tx < p.KWt; ++tx, ix += tap_step)
+        if ((unsigned)ix < (unsigned)p.W) xm |= 1u << tx;
+      for (int ty = 0, iy = iy0, sh = 0; ty < p.KHt; ++ty, iy += tap_step, sh += p.KWt)
+        if ((unsigned)iy < (unsigned)p.H) mk |= (unsigned long long)xm << sh;
+    }
+    sMask[tid] = mk;
+    sOOff[tid] = n * p.o_sn + (long)(py + oy * o_step) * p.o_sy + (long)(px + ox * o_step) * p.o_sx;
   }
   if (tid < 2 * BN) sStat[tid] = 0.f;
-  if (tid < BN) sBias[tid] = (p.bias && cout0 + tid < p.cout) ? p.bias[cout0 + tid] : 0.f;
-  const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;      // (both used to be loaded inside the epilogue passes)
   __syncthreads();
+  TS(1);
 
   // ---- per-lane DMA roles.  Instruction j = wid + NW*i of a stage covers tile rows 8j .. 8j+7, lane -> row 8j + lane/8,
   // LDS chunk position c' = lane%8, channel chunk c = c' ^ ((row>>1)&7) = c' ^ ((4*(wid&1) + lane/16) & 7) for every i.
   const int cch = ((lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7)) * 8;          // halves
-  // Everything that does not change from slice to slice is hoisted out of the K loop (the loop is VALU-bound on address
-  // generation otherwise): per row a 64-bit element offset for tap (0,0) in each input segment, and a bit per tap saying
-  // whether that tap lands inside the image.  Per slice only a wave-uniform base pointer changes.
+  // Per row: the 64-bit element offset of tap (0,0) in each input segment and a bit per tap saying whether that tap lands inside
+  // the image (from the tables above).  Per slice only a wave-uniform base pointer changes.
   long off0[NXI], off1[NXI];
   unsigned long long tapmask[NXI];
 #pragma unroll
   for (int i = 0; i < NXI; ++i) {
     const int r = 8 * (wid + NW * i) + (lane >> 3);
-    const int n = sRow[r * 3];
-    const int iy0 = sRow[r * 3 + 1] * in_step + base_y, ix0 = sRow[r * 3 + 2] * in_step + base_x;
-    off0[i] = n * p.in[0].sn + iy0 * p.in[0].sy + ix0 * p.in[0].sx + cch;
-    off1[i] = n * p.in[1].sn + iy0 * p.in[1].sy + ix0 * p.in[1].sx + cch;
-    unsigned long long m = 0;
-    if (n >= 0) {
-      int iy = iy0, ix = ix0, tkx = 0;                // walk the taps without integer division
-      for (int t = 0; t < p.KHt * p.KWt; ++t) {
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) m |= 1ull << t;
-        ix += tap_step;
-        if (++tkx == p.KWt) { tkx = 0; ix = ix0; iy += tap_step; }
-      }
-    }
-    tapmask[i] = m;
+    off0[i] = sOff0[r] + cch;
+    off1[i] = sOff1[r] + cch;
+    tapmask[i] = sMask[r];
   }
   const half_t* wrow[NI - NXI];
 #pragma unroll
@@ -173,8 +193,11 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nkt) issue(s);
 
+  if (tid < BN) sBias[tid] = bias_reg;        // read in the epilogue, behind the K loop's barriers
+  const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
   // fragment addressing: tile row R, channel chunk c -> byte R*128 + ((c ^ ((R>>1)&7)) << 4)
   const int xr0 = wm * 64 + (lane & 31), wr0 = wn * 64 + (lane & 31);
+  TS(2);
   for (int kt = 0; kt < nkt; ++kt) {
     // stage kt landed (this wave's DMAs), then everyone's
     const int ahead = (nkt - 1 - kt) < (NSTAGE - 2) ? (nkt - 1 - kt) : (NSTAGE - 2);   // stages still allowed in flight
@@ -182,6 +205,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (kt == 0) TS(3);
     if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1);      // refills the buffer read in iteration kt-1
     const char* xs = smem + (kt % NSTAGE) * STAGE_BYTES;
     const char* ws = xs + BM * 128;
@@ -217,6 +241,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1[a], bf1[b], acc[a][b], 0, 0, 0);
     }
   }
+  TS(4);
   __syncthreads();
 
   if (p.stat_mode == CSBSR_STAT_NONE && p.direct_epi) {       // register-direct epilogue
@@ -259,12 +284,74 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
       }
     }
   lds_barrier();
+  TS(5);
   const int co = cout0 + cc8 * 8;
   float bias[8], ssum[8], ssq[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bias[e] = sBias[cc8 * 8 + e]; ssum[e] = ssq[e] = 0.f; }
   int cur_n = -1;
-  {
+  // Straight-line rows for the common fused epilogues (no statistics, fp16 output, whole channel octets, identity / ReLU / leaky
+  // activation, residual add or subtract, optional accumulate): the mode switches become two multipliers picked once per kernel.
+  // The general row below re-tests every mode per element -- ~100 scalar branches per row; its 8 rows took 7.7 us of an 18 us
+  // transposed-conv workgroup whose 8 K slices take 5.9 us.
+  const bool fast = p.stat_mode == CSBSR_STAT_NONE && !p.cbias && !p.out32 && p.out16 && (p.cout & 7) == 0 &&
+                    p.act != CSBSR_ACT_SIGMOID && !(slope > 1.f) && (p.res_mode == CSBSR_RES_NONE || p.res_mode == CSBSR_RES_ADD || p.res_mode == CSBSR_RES_SUB);
+  if (fast) {
+    // leaky / ReLU / identity as max(t, t*sneg) with sneg <= 1 (PReLU slopes above 1 take the general row)
+    const float sneg = p.act == CSBSR_ACT_NONE ? 1.f : (p.act == CSBSR_ACT_RELU ? 0.f : slope);
+    const float rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
+    const bool has_res = p.res_mode != CSBSR_RES_NONE, has_old = p.accumulate != 0;
+    const float osc = p.out_scale;
+    constexpr int RPT = BM / RSTEP, EG = 4;
+    static_assert(RPT % EG == 0, "rows per thread must split into groups");
+    auto rows = [&](auto EXTRA) {       // EXTRA: a residual and / or the old output is combined in
+#pragma unroll 1
+      for (int g = 0; g < RPT / EG; ++g) {
+        h8 rr[EG], oo[EG];
+        long ooff[EG];
+        bool live[EG];
+#pragma unroll
+        for (int i = 0; i < EG; ++i) {
+          const int grow = tid / CPR + (g * EG + i) * RSTEP;
+          const int n = sRow[grow * 3];
+          live[i] = n >= 0 && co < p.coutp;
+          ooff[i] = sOOff[grow] + co;
+          if constexpr (decltype(EXTRA)::value) {
+            rr[i] = h8{0, 0, 0, 0, 0, 0, 0, 0}; oo[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (live[i]) {
+              if (has_res) {
+                const int oyo = py + sRow[grow * 3 + 1] * o_step, oxo = px + sRow[grow * 3 + 2] * o_step;
+                rr[i] = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oyo * p.r_sy + oxo * p.r_sx + co);
+              }
+              if (has_old) oo[i] = *reinterpret_cast<const h8*>(p.out16 + ooff[i]);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < EG; ++i) {
+          if (!live[i]) continue;
+          const int row = tid / CPR + (g * EG + i) * RSTEP;
+          const f4 v0 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8) ^ (row & 15)) << 2));
+          const f4 v1 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8 + 1) ^ (row & 15)) << 2));
+          const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          h8 hv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = v[e] * osc + bias[e];
+            t = fmaxf(t, t * sneg);
+            if constexpr (decltype(EXTRA)::value) {
+              t += rsign * (float)rr[i][e];
+              t += (float)oo[i][e];
+            }
+            hv[e] = (half_t)t;
+          }
+          *reinterpret_cast<h8*>(p.out16 + ooff[i]) = hv;
+        }
+      }
+    };
+    if (has_res || has_old) rows(std::true_type{});
+    else rows(std::false_type{});
+  } else {
     // rows in groups of EG: the group's residual / old-output loads are all issued before the first row is combined
     constexpr int RPT = BM / RSTEP, EG = 2;
 #pragma unroll 1      // one copy of the (large, mode-rich) row code: fully unrolled the kernel was 23 K instructions
@@ -293,6 +380,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     }
     conv_epilogue_flush_stats<CPR>(p, sStat, BN, cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
   }
+  TS(6);
   if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
     __syncthreads();
     if (tid < BN && cout0 + tid < p.coutp) {
@@ -317,7 +405,8 @@ static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   p.tiles_n = (unsigned)((k.coutp + BN - 1) / BN);
   constexpr int RING = NSTAGE * (BM + BN) * 128;
   constexpr int EPI = 128 * 68 * 4;
-  constexpr int SM_BYTES = (RING > EPI ? RING : EPI) + BM * 3 * 4 + 3 * BN * 4;
+  constexpr int SM_BYTES = (RING > EPI ? RING : EPI) + BM * (4 * 8 + 3 * 4) + 3 * BN * 4;      // ring / staged tile + row tables + statistics + bias
+  static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_glds_kernel<BM, NWM, NSTAGE>),
@@ -359,9 +448,9 @@ bool conv_glds_eligible(const ConvK& k) {
 }
 
 int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st) {
-  // measured (scripts/bench_conv.py): the 8-wave 256x128 tile only pays for long-K stride-1 layers (SFT 3x3, ResNet 3x3);
-  // strided / transposed / short-K layers run faster with two 128x128 workgroups per CU
-  const bool big = (g_glds_mode == 2 && !k.transposed && k.stride == 1 && k.Kp >= 2304 && maxM >= 256 * 256) ||
+  // measured (scripts/bench_conv.py): the 8-wave 256x128 tile only pays for long-K layers (SFT 3x3, ResNet 3x3, the 8x8 stride-4
+  // gathers); transposed / short-K layers run faster with two 128x128 workgroups per CU
+  const bool big = (g_glds_mode == 2 && !k.transposed && k.Kp >= 2304 && maxM >= 256 * 256) ||
                    (g_glds_mode == 3 && maxM >= 256 * 256);     // mode 3 (A/B timing): the 256-row tile wherever it fits
   g_last_conv_kernel = big ? CONVK_GLDS256 : CONVK_GLDS128;
   if (!big) return launch_glds<128, 2, 2>(k, nphase, maxM, st);
