@@ -51,8 +51,20 @@ __device__ __forceinline__ h8 frag_T(const half_t* tile, int ld, int pix0, int c
   }
 }
 
+#ifdef CSBSR_TS
+__device__ unsigned long long g_wts[8 * 65536];
+extern "C" int csbsr_debug_read_wts(void* dst, long n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wts), n * 8); }
+#define WTS_DECL unsigned long long ts_prev = wall_clock64(), ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define WTS(i) do { const unsigned long long t_ = wall_clock64(); ts_acc[i] += t_ - ts_prev; ts_prev = t_; } while (0)
+#define WTS_FLUSH do { if (threadIdx.x == 0 && blockIdx.x + gridDim.x * blockIdx.z < 65536) for (int i_ = 0; i_ < 8; ++i_) g_wts[(size_t)(blockIdx.x + gridDim.x * blockIdx.z) * 8 + i_] = ts_acc[i_]; } while (0)
+#else
+#define WTS_DECL
+#define WTS(i)
+#define WTS_FLUSH
+#endif
 template <int BA, int WA, int WB, bool USE_TR>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
+  WTS_DECL;
   constexpr int AW_ = BA / WA;          // a-rows per wave
   constexpr int BW_ = WG_BN / WB;       // cols per wave
   constexpr int TA = AW_ / 32, TB = BW_ / 32;
@@ -178,9 +190,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
     }
   };
 
+  WTS(0);
   issue_loads(mbeg);
+  WTS(1);
   for (long m = mbeg; m < mend; m += WG_BP) {
     __syncthreads();   // previous step's fragment reads done
+    WTS(2);
 #pragma unroll
     for (int j = 0; j < B_ITERS; ++j) {
       const int id = tid + 256 * j;
@@ -188,8 +203,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
     }
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) *reinterpret_cast<h8*>(sA + (tid / ACH + A_DELTA * i) * LDA + a_ch) = ga[i];
+    WTS(3);
     __syncthreads();
+    WTS(4);
     if (m + WG_BP < mend) issue_loads(m + WG_BP);     // next step's HBM loads fly under this step's MFMAs
+    WTS(5);
 #pragma unroll
     for (int ks = 0; ks < WG_BP / 16; ++ks) {
       const int pix0 = ks * 16 + (lane >> 5) * 8;
@@ -203,6 +221,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
 #pragma unroll
         for (int b = 0; b < TB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
+    WTS(6);
   }
 
   // ---- epilogue: D[a][col], lane: col = lane%32, rows (r&3)+8*(r>>2)+4*(lane>>5)
@@ -222,6 +241,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
         slab[(size_t)row * p.ktot + col] = acc[a][b][r];
       }
     }
+  WTS(7);
+  WTS_FLUSH;
 }
 
 static int g_wgrad_use_tr = 1;
