@@ -62,13 +62,14 @@ extern "C" int csbsr_debug_read_wts(void* dst, long n) { return (int)hipMemcpyFr
 #define WTS(i)
 #define WTS_FLUSH
 #endif
-template <int BA, int WA, int WB, bool USE_TR>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
+template <int BA, int BN, int WA, int WB, bool USE_TR>
+__global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgradK p) {
   WTS_DECL;
+  constexpr int NT = 64 * WA * WB;      // threads: every wave owns a 64 x 64 (or smaller) piece of the BA x BN tile
   constexpr int AW_ = BA / WA;          // a-rows per wave
-  constexpr int BW_ = WG_BN / WB;       // cols per wave
+  constexpr int BW_ = BN / WB;          // cols per wave
   constexpr int TA = AW_ / 32, TB = BW_ / 32;
-  constexpr int LDA = BA + 32, LDB = WG_BN + 32;   // row stride = 16 dwords mod 64: conflict-free ds_read_b64_tr_b16
+  constexpr int LDA = BA + 32, LDB = BN + 32;      // row stride = 16 dwords mod 64: conflict-free ds_read_b64_tr_b16
   __shared__ __attribute__((aligned(16))) half_t sA[WG_BP * LDA];
   __shared__ __attribute__((aligned(16))) half_t sB[WG_BP * LDB];
 
@@ -86,16 +87,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
     lt = xcd_remap(blockIdx.x, ntile); zsplit = blockIdx.z;
   }
   const int a0 = (lt % p.tiles_a) * BA;
-  int col0 = (lt / p.tiles_a) * WG_BN;
+  int col0 = (lt / p.tiles_a) * BN;
   if (p.tap_perm) {
     // 8x8 stride-4 layers with 128 gathered channels: one column tile per tap, 64 tiles = 8 per XCD.  Taps whose kernel offsets agree
     // modulo the stride read the SAME strided pixel set of the gathered side (shifted by whole A-grid pixels), so XCD j takes the
     // taps with ky = j%4 (+4) and kx in {2(j/4), 2(j/4)+1} (+4): each XCD's L2 then holds 1/8 of the gathered tensor, fetched once,
     // instead of every row class being pulled in by two XCDs and every column by all of them (PMC: 9.2 GB per launch at N=4 for
     // 3.5 GB of operands).
-    const int j = lt >> 3, r = lt & 7;
-    const int ky = (j & 3) + 4 * (r >> 2), kx = 2 * (j >> 2) + (r & 1) + 4 * ((r >> 1) & 1);
-    col0 = (ky * 8 + kx) * WG_BN;
+    if constexpr (BN == 128) {
+      const int j = lt >> 3, r = lt & 7;
+      const int ky = (j & 3) + 4 * (r >> 2), kx = 2 * (j >> 2) + (r & 1) + 4 * ((r >> 1) & 1);
+      col0 = (ky * 8 + kx) * 128;
+    } else {      // 256-column tiles hold the tap pair (ky, kx0), (ky, kx0 + 1): 32 tiles, 4 per XCD
+      const int j = lt >> 2, r = lt & 3;
+      const int ky = (j & 3) + 4 * (r >> 1), kx0 = 2 * (j >> 2) + 4 * (r & 1);
+      col0 = (ky * 8 + kx0) * 128;
+    }
   }
   // Strided layers: the tap row ky reads gathered row y*stride + ky*dil - pad, so tiles whose taps differ by a whole stride in ky touch
   // the same (16x larger) gathered rows one A-row apart in time -- 7 steps x every resident workgroup's traffic, far beyond the L2.
@@ -109,14 +116,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   if (mend > p.M || (int)zsplit == p.splits - 1) mend = p.M;
   if (mbeg >= mend) return;
 
-  // ---- B staging role: chunk ids tid + 256*j : pixel = id/16, col chunk = id%16
-  constexpr int B_ITERS = WG_BP * 16 / 256;
+  // ---- B staging role: chunk ids tid + NT*j : pixel = id/BCH, col chunk = id%BCH
+  constexpr int BCH = BN / 8, B_DELTA = NT / BCH;
+  constexpr int B_ITERS = WG_BP * BCH / NT;
+  static_assert(NT % BCH == 0 && (WG_BP * BCH) % NT == 0, "B staging must tile evenly");
   int b_ky, b_kx;
   const half_t* b_ptr;
   long b_sn, b_sy, b_sx;
   bool b_ok;
   {
-    const int col = col0 + (tid & 15) * 8;      // the column chunk is the same for every j (256 % 16 == 0)
+    const int col = col0 + (tid % BCH) * 8;     // the column chunk is the same for every j (NT % BCH == 0)
     b_ok = col < p.ktot;
     const int tap = b_ok ? col / p.cbtot : 0;
     const int c = b_ok ? col - tap * p.cbtot : 0;
@@ -128,11 +137,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   }
   // ---- A staging role: BA/8 chunks per pixel
   constexpr int ACH = BA / 8;
-  constexpr int A_ITERS = WG_BP * ACH / 256;
+  constexpr int A_ITERS = WG_BP * ACH / NT;
+  static_assert(NT % ACH == 0 && (WG_BP * ACH) % NT == 0, "A staging must tile evenly");
 
   // per-thread running pixel coordinates AND element offsets (no integer division, no 64-bit multiply in the loop: the offsets move by
   // precomputed strides; rebuilding n*sn + y*sy + x*sx per chunk cost ~17 VALU instructions per MFMA in the PMC counts): B chunk j
-  // covers pixel (tid>>4) + 16 j, A chunk i covers pixel tid/ACH + (256/ACH) i of the step being LOADED
+  // covers pixel tid/BCH + (NT/BCH) j, A chunk i covers pixel tid/ACH + (NT/ACH) i of the step being LOADED
   struct Pix { int n, y, x; long off; };
   auto init_pix = [&](long m, long sn, long sy, long sx) {
     Pix c;
@@ -142,17 +152,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
     c.off = c.n * sn + c.y * sy + c.x * sx;
     return c;
   };
-  constexpr int A_DELTA = 256 / ACH;
+  constexpr int A_DELTA = NT / ACH;
   // B: element offset of tap (0,0)'s source pixel = n*b_sn + (y*stride)*b_sy + (x*stride)*b_sx ; the tap displacement is a constant
   const long bsx = (long)p.stride * b_sx, bsy = (long)p.stride * b_sy;
   const long b_tap = (long)b_ky * b_sy + (long)b_kx * b_sx;
-  const long b_dx = 16 * bsx, b_rowfix = bsy - (long)p.AW * bsx, b_imgfix = b_sn - (long)p.AH * bsy;
+  const long b_dx = B_DELTA * bsx, b_rowfix = bsy - (long)p.AW * bsx, b_imgfix = b_sn - (long)p.AH * bsy;
   const long a_dx = (long)A_DELTA * p.a_sx, a_rowfix = p.a_sy - (long)p.AW * p.a_sx, a_imgfix = p.a_sn - (long)p.AH * p.a_sy;
   auto advance = [&](Pix& c, int d, long dxs, long rowfix, long imgfix) {
     c.x += d; c.off += dxs;
     while (c.x >= p.AW) { c.x -= p.AW; c.off += rowfix; if (++c.y == p.AH) { c.y = 0; ++c.n; c.off += imgfix; } }
   };
-  Pix cb = init_pix(mbeg + (tid >> 4), b_sn, bsy, bsx);
+  Pix cb = init_pix(mbeg + tid / BCH, b_sn, bsy, bsx);
   Pix ca_ = init_pix(mbeg + tid / ACH, p.a_sn, p.a_sy, p.a_sx);
 
   f16v acc[TA][TB];
@@ -171,14 +181,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   auto issue_loads = [&](long m) {     // global -> registers for the step starting at pixel m, then advance the coordinates
 #pragma unroll
     for (int j = 0; j < B_ITERS; ++j) {
-      const int pix = (tid >> 4) + 16 * j;
+      const int pix = tid / BCH + B_DELTA * j;
       h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       if (b_ok && m + pix < mend) {
         const int by = cb.y * p.stride + b_ky, bx = cb.x * p.stride + b_kx;
         if ((unsigned)by < (unsigned)p.BH && (unsigned)bx < (unsigned)p.BW) v = *reinterpret_cast<const h8*>(b_base + cb.off);
       }
       gb[j] = v;
-      advance(cb, 16, b_dx, b_rowfix, b_imgfix);
+      advance(cb, B_DELTA, b_dx, b_rowfix, b_imgfix);
     }
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
@@ -198,8 +208,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
     WTS(2);
 #pragma unroll
     for (int j = 0; j < B_ITERS; ++j) {
-      const int id = tid + 256 * j;
-      *reinterpret_cast<h8*>(sB + (id >> 4) * LDB + (id & 15) * 8) = gb[j];
+      const int id = tid + NT * j;
+      *reinterpret_cast<h8*>(sB + (id / BCH) * LDB + (id % BCH) * 8) = gb[j];
     }
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) *reinterpret_cast<h8*>(sA + (tid / ACH + A_DELTA * i) * LDA + a_ch) = ga[i];
@@ -249,9 +259,10 @@ static int g_wgrad_use_tr = 1;
 static int g_wgrad_thin = 1;
 static int g_wgrad_tap_perm = 1;
 static int g_wgrad_row_shift = 1;
+static int g_wgrad_wide = 1;
 static int g_wgrad_extra_lds = 0;   // A/B: dynamic LDS bytes added to the launch to lower the occupancy
 static int g_wgrad_flat = 1;     // 0 off, 1 every layer without the tap permutation, 2 every layer
-extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v & 1; g_wgrad_thin = !(v & 2); g_wgrad_tap_perm = !(v & 4); g_wgrad_flat = (v & 8) ? 0 : ((v & 16) ? 2 : 1); g_wgrad_row_shift = !(v & 32); g_wgrad_extra_lds = (v >> 8) * 1024; }
+extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v & 1; g_wgrad_thin = !(v & 2); g_wgrad_tap_perm = !(v & 4); g_wgrad_flat = (v & 8) ? 0 : ((v & 16) ? 2 : 1); g_wgrad_row_shift = !(v & 32); g_wgrad_wide = !(v & 64); g_wgrad_extra_lds = (v >> 8) * 1024; }
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Thin-A variant: stride-1 "same" conv whose output has so few channels that KH*KW*ca_real <= 32 (the 3-channel image heads:
@@ -374,11 +385,16 @@ static bool wgrad_is_thin(const csbsr_wgrad_desc_t* d) {
 }
 
 static int wgrad_tile_a(int ca) { return ca > 64 ? 128 : (ca > 32 ? 64 : 32); }
+// 128 x 256 tiles on 8 waves (each wave still owns 64 x 64) for the layers with thousands of columns: the kernel is bound by what a CU
+// can load (~16 B/clk, scripts/ts_wgrad.py) and the wide tile moves 48 KB per 64-pixel step for twice the MFMAs of the 32 KB square
+// one.  One such workgroup fits per CU (158 VGPRs x 8 waves), so it only pays where the pixel loops are long: +10..16 % on the SFT and
+// decoder 3x3 layers, -20 % on a 9-tile 128-channel 3x3, -2 % on the tap-permuted 8x8 stride-4 layers (which keep the square tile).
+static int wgrad_tile_n(int ca, int ktot, bool perm8 = false) { return (g_wgrad_wide && ca > 64 && ktot >= 6144 && !perm8) ? 256 : 128; }
 
 // number of pixel-range splits (= fp32 slabs the caller must provide) for a problem
-extern "C" int32_t csbsr_wgrad_splits(int32_t ca, int32_t ktot, int64_t M) {
-  const int BA = wgrad_tile_a(ca);
-  const long ntile = (long)((ca + BA - 1) / BA) * ((ktot + WG_BN - 1) / WG_BN);
+static int32_t wgrad_splits_impl(int32_t ca, int32_t ktot, int64_t M, bool perm8) {
+  const int BA = wgrad_tile_a(ca), BN = wgrad_tile_n(ca, ktot, perm8);
+  const long ntile = (long)((ca + BA - 1) / BA) * ((ktot + BN - 1) / BN);
   long want = (1536 + ntile - 1) / ntile;
   long maxs = (M + WG_BP * 8 - 1) / (WG_BP * 8);
   long splits = want < maxs ? want : maxs;
@@ -390,6 +406,8 @@ extern "C" int32_t csbsr_wgrad_splits(int32_t ca, int32_t ktot, int64_t M) {
   const long per_split = ((M + splits - 1) / splits + WG_BP - 1) / WG_BP * WG_BP;
   return (int32_t)((M + per_split - 1) / per_split);
 }
+
+extern "C" int32_t csbsr_wgrad_splits(int32_t ca, int32_t ktot, int64_t M) { return wgrad_splits_impl(ca, ktot, M, false); }
 
 static long wgrad_splits_for(long ntile, long slab_elems, long M) {
   long want = (1536 + ntile - 1) / ntile;
@@ -409,14 +427,15 @@ extern "C" int32_t csbsr_wgrad_splits_desc(const csbsr_wgrad_desc_t* d) {
   const int ktot = d->KH * d->KW * cbtot;
   if (wgrad_is_thin(d))
     return (int32_t)wgrad_splits_for((cbtot + WG_BN - 1) / WG_BN, (long)d->ca * ktot, (long)d->N * d->BH * d->BW);
-  return csbsr_wgrad_splits(d->ca, ktot, (long)d->N * d->AH * d->AW);
+  const bool perm8 = g_wgrad_tap_perm && d->KH == 8 && d->KW == 8 && d->stride == 4 && cbtot == WG_BN && d->ca <= 128;
+  return wgrad_splits_impl(d->ca, ktot, (long)d->N * d->AH * d->AW, perm8);
 }
 
-template <int BA, int WA, int WB>
+template <int BA, int BN, int WA, int WB>
 static int launch_wgrad(const WgradK& k, int splits, hipStream_t st) {
   WgradK p = k;
   p.tiles_a = (unsigned)((k.ca + BA - 1) / BA);
-  p.tiles_b = (unsigned)((k.ktot + WG_BN - 1) / WG_BN);
+  p.tiles_b = (unsigned)((k.ktot + BN - 1) / BN);
   const unsigned ntile = p.tiles_a * p.tiles_b;
   p.per_split = ((k.M + splits - 1) / splits + WG_BP - 1) / WG_BP * WG_BP;
   if ((int)((k.M + p.per_split - 1) / p.per_split) != splits) {
@@ -430,9 +449,9 @@ static int launch_wgrad(const WgradK& k, int splits, hipStream_t st) {
   else p.flat = (g_wgrad_flat == 1 && !p.tap_perm && ntile <= 48) ? 1 : 0;   // measured: +5..25 % up to ~40 tiles, -1..2 % for the 100+ tile layers
   dim3 grid(p.flat ? ntile * splits : ntile, 1, p.flat ? 1 : splits);
   if (g_wgrad_use_tr)
-    hipLaunchKernelGGL((conv_wgrad_kernel<BA, WA, WB, true>), grid, dim3(256), g_wgrad_extra_lds, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<BA, BN, WA, WB, true>), grid, dim3(64 * WA * WB), g_wgrad_extra_lds, st, p);
   else
-    hipLaunchKernelGGL((conv_wgrad_kernel<BA, WA, WB, false>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<BA, BN, WA, WB, false>), grid, dim3(64 * WA * WB), 0, st, p);
   CSBSR_LAUNCH_CHECK("csbsr_conv_wgrad");
   return 0;
 }
@@ -466,7 +485,10 @@ extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
     CSBSR_LAUNCH_CHECK("csbsr_conv_wgrad(thin)");
     return 0;
   }
-  if (d->ca > 64) return launch_wgrad<128, 2, 2>(k, d->splits, st);
-  if (d->ca > 32) return launch_wgrad<64, 2, 2>(k, d->splits, st);
-  return launch_wgrad<32, 1, 4>(k, d->splits, st);
+  if (d->ca > 64) {
+    if (wgrad_tile_n(d->ca, k.ktot, k.tap_perm != 0) == 256) return launch_wgrad<128, 256, 2, 4>(k, d->splits, st);
+    return launch_wgrad<128, 128, 2, 2>(k, d->splits, st);
+  }
+  if (d->ca > 32) return launch_wgrad<64, 128, 2, 2>(k, d->splits, st);
+  return launch_wgrad<32, 128, 1, 4>(k, d->splits, st);
 }
