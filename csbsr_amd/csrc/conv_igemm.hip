@@ -16,13 +16,14 @@
 // /root/reference/model/modeling/kbpn.py:241,273-277,513-517 and pspnet_pytorch/{extractors.py:36-38,pspnet.py:30-86}.
 #include "common.h"
 #include "conv_common.h"
+#include <type_traits>
 
 #define BM 128
 #define BK 64
 #define LDS_LD 72  // halves per LDS row: 64 + 8 pad (144 B): conflict-free 16-byte fragment reads
 
 template <int BN, int WP, int WC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 2 : (BN == 64 ? 3 : 4)))) void conv_igemm_kernel(const ConvK p) {
   constexpr int PW = BM / WP;      // pixels per wave
   constexpr int CW = BN / WC;      // couts per wave
   constexpr int TP = PW / 32;
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   int* sRow = reinterpret_cast<int*>(smem + SM_BYTES);                // [BM][3]  n, oy, ox  (n = -1: invalid)
   float* sStat = reinterpret_cast<float*>(smem + SM_BYTES + BM * 3 * 4);  // [2][BN]
   float* sBias = sStat + 2 * BN;                                           // [BN]: fetched before the K loop, not inside the epilogue
+  long* sOOff = reinterpret_cast<long*>(sBias + BN);                       // [BM]: element offset of each tile row's output pixel in out16
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -75,6 +77,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
       oy = rem / OWp; ox = rem - oy * OWp;
     }
     sRow[tid * 3 + 0] = n; sRow[tid * 3 + 1] = oy; sRow[tid * 3 + 2] = ox;
+    sOOff[tid] = n * p.o_sn + (long)(py + oy * o_step) * p.o_sy + (long)(px + ox * o_step) * p.o_sx;
   }
   if (tid < 2 * BN) sStat[tid] = 0.f;
   if (tid < BN) sBias[tid] = (p.bias && cout0 + tid < p.cout) ? p.bias[cout0 + tid] : 0.f;
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     n_last = (int)(ml / ((long)OHp * OWp));
   }
   const bool uniform_n = (n_first == n_last);
+  const EpiFast fe = conv_epilogue_fast_setup(p, slope);
   constexpr int CPR = HB / 8;                 // 8-channel chunks per staged row
   const int cc8 = tid % CPR;                  // fixed per thread (256 % CPR == 0)
 
@@ -262,6 +266,49 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     int cur_n = -1;
 
     constexpr int RSTEP = 256 / CPR;
+    if (fe.ok) {          // straight-line rows (conv_common.h)
+      constexpr int RPT = BM / RSTEP, EG = RPT >= 2 ? 2 : RPT;      // (4 rows in flight cost the 64-cout kernel its third wave per SIMD)
+      static_assert(RPT % EG == 0, "rows per thread must split into groups");
+      auto rows = [&](auto EXTRA, auto BNSTAT) {
+#pragma unroll 1
+        for (int g = 0; g < RPT / EG; ++g) {
+          h8 rr[EG], oo[EG];
+          long ooff[EG];
+          bool live[EG];
+#pragma unroll
+          for (int i = 0; i < EG; ++i) {
+            const int grow = tid / CPR + (g * EG + i) * RSTEP;
+            const int n = sRow[grow * 3];
+            live[i] = n >= 0 && co < p.coutp;
+            ooff[i] = sOOff[grow] + co;
+            rr[i] = h8{0, 0, 0, 0, 0, 0, 0, 0}; oo[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (decltype(EXTRA)::value) {
+              if (live[i]) {
+                if (fe.has_res) {
+                  const int oyo = py + sRow[grow * 3 + 1] * o_step, oxo = px + sRow[grow * 3 + 2] * o_step;
+                  rr[i] = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oyo * p.r_sy + oxo * p.r_sx + co);
+                }
+                if (fe.has_old) oo[i] = *reinterpret_cast<const h8*>(p.out16 + ooff[i]);
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < EG; ++i) {
+            if (!live[i]) continue;
+            const int row = tid / CPR + (g * EG + i) * RSTEP;
+            const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
+            const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, bias, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq);
+          }
+        }
+      };
+      const bool extra = fe.has_res || fe.has_old;
+      if (fe.bn) { if (extra) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{}); }
+      else { if (extra) rows(std::true_type{}, std::false_type{}); else rows(std::false_type{}, std::false_type{}); }
+      if (fe.bn) conv_epilogue_flush_stats<CPR>(p, sStat, BN, hh * HB + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
+      continue;
+    }
     // rows in groups of EG: the group's residual / old-output loads are all issued before the first row is combined
     constexpr int RPT = BM / RSTEP, EG = RPT >= 2 ? 2 : 1;
 #pragma unroll 1      // one copy of the (large, mode-rich) row code: fully unrolled the kernel was 23 K instructions
@@ -313,7 +360,7 @@ static int launch_conv(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   constexpr int OUT_LD = (BN == 128 ? 64 : BN) + 4;
   constexpr int MAIN_BYTES = (BN + BM) * LDS_LD * 2;
   constexpr int EPI_BYTES = BM * OUT_LD * 4;
-  constexpr int SM_BYTES = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + BM * 3 * 4 + 3 * BN * 4;
+  constexpr int SM_BYTES = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + BM * 3 * 4 + 3 * BN * 4 + BM * 8;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BN, WP, WC>),

@@ -290,21 +290,11 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bias[e] = sBias[cc8 * 8 + e]; ssum[e] = ssq[e] = 0.f; }
   int cur_n = -1;
-  // Straight-line rows for the common fused epilogues (no statistics, fp16 output, whole channel octets, identity / ReLU / leaky
-  // activation, residual add or subtract, optional accumulate): the mode switches become two multipliers picked once per kernel.
-  // The general row below re-tests every mode per element -- ~100 scalar branches per row; its 8 rows took 7.7 us of an 18 us
-  // transposed-conv workgroup whose 8 K slices take 5.9 us.
-  const bool fast = p.stat_mode == CSBSR_STAT_NONE && !p.cbias && !p.out32 && p.out16 && (p.cout & 7) == 0 &&
-                    p.act != CSBSR_ACT_SIGMOID && !(slope > 1.f) && (p.res_mode == CSBSR_RES_NONE || p.res_mode == CSBSR_RES_ADD || p.res_mode == CSBSR_RES_SUB);
-  if (fast) {
-    // leaky / ReLU / identity as max(t, t*sneg) with sneg <= 1 (PReLU slopes above 1 take the general row)
-    const float sneg = p.act == CSBSR_ACT_NONE ? 1.f : (p.act == CSBSR_ACT_RELU ? 0.f : slope);
-    const float rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
-    const bool has_res = p.res_mode != CSBSR_RES_NONE, has_old = p.accumulate != 0;
-    const float osc = p.out_scale;
+  const EpiFast fe = conv_epilogue_fast_setup(p, slope);      // conv_common.h
+  if (fe.ok) {
     constexpr int RPT = BM / RSTEP, EG = 4;
     static_assert(RPT % EG == 0, "rows per thread must split into groups");
-    auto rows = [&](auto EXTRA) {       // EXTRA: a residual and / or the old output is combined in
+    auto rows = [&](auto EXTRA, auto BNSTAT) {       // EXTRA: a residual and / or the old output is combined in
 #pragma unroll 1
       for (int g = 0; g < RPT / EG; ++g) {
         h8 rr[EG], oo[EG];
@@ -316,14 +306,14 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
           const int n = sRow[grow * 3];
           live[i] = n >= 0 && co < p.coutp;
           ooff[i] = sOOff[grow] + co;
+          rr[i] = h8{0, 0, 0, 0, 0, 0, 0, 0}; oo[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
           if constexpr (decltype(EXTRA)::value) {
-            rr[i] = h8{0, 0, 0, 0, 0, 0, 0, 0}; oo[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
             if (live[i]) {
-              if (has_res) {
+              if (fe.has_res) {
                 const int oyo = py + sRow[grow * 3 + 1] * o_step, oxo = px + sRow[grow * 3 + 2] * o_step;
                 rr[i] = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oyo * p.r_sy + oxo * p.r_sx + co);
               }
-              if (has_old) oo[i] = *reinterpret_cast<const h8*>(p.out16 + ooff[i]);
+              if (fe.has_old) oo[i] = *reinterpret_cast<const h8*>(p.out16 + ooff[i]);
             }
           }
         }
@@ -334,23 +324,14 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
           const f4 v0 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8) ^ (row & 15)) << 2));
           const f4 v1 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8 + 1) ^ (row & 15)) << 2));
           const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          h8 hv;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float t = v[e] * osc + bias[e];
-            t = fmaxf(t, t * sneg);
-            if constexpr (decltype(EXTRA)::value) {
-              t += rsign * (float)rr[i][e];
-              t += (float)oo[i][e];
-            }
-            hv[e] = (half_t)t;
-          }
-          *reinterpret_cast<h8*>(p.out16 + ooff[i]) = hv;
+          conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, bias, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq);
         }
       }
     };
-    if (has_res || has_old) rows(std::true_type{});
-    else rows(std::false_type{});
+    const bool extra = fe.has_res || fe.has_old;
+    if (fe.bn) { if (extra) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{}); }
+    else { if (extra) rows(std::true_type{}, std::false_type{}); else rows(std::false_type{}, std::false_type{}); }
+    if (fe.bn) conv_epilogue_flush_stats<CPR>(p, sStat, BN, cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
   } else {
     // rows in groups of EG: the group's residual / old-output loads are all issued before the first row is combined
     constexpr int RPT = BM / RSTEP, EG = 2;
