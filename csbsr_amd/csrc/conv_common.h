@@ -123,33 +123,42 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
 // max(t, t*sneg), sneg <= 1), residual add or subtract, optional accumulate, optional BatchNorm sums: the mode switches of
 // conv_epilogue_row become two multipliers picked once per kernel.  The general row re-tests every mode per element (~100 scalar
 // branches per row): its 8 rows took 7.7 us of an 18 us transposed-conv workgroup whose 8 K slices take 5.9 us (CSBSR_TS build).
-struct EpiFast { bool ok, has_res, has_old, bn; float sneg, rsign, osc; };
+struct EpiFast { bool ok, has_res, has_old, bn, masked; float sneg, rsign, osc; int cout; };
 __device__ __forceinline__ EpiFast conv_epilogue_fast_setup(const ConvK& p, float slope) {
   EpiFast f;
-  f.ok = (p.stat_mode == CSBSR_STAT_NONE || p.stat_mode == CSBSR_STAT_BN) && !p.cbias && !p.out32 && p.out16 && (p.cout & 7) == 0 &&
+  f.ok = (p.stat_mode == CSBSR_STAT_NONE || p.stat_mode == CSBSR_STAT_BN) && !p.cbias && !p.out32 && p.out16 &&
          p.act != CSBSR_ACT_SIGMOID && !(p.act != CSBSR_ACT_NONE && p.act != CSBSR_ACT_RELU && slope > 1.f) &&
          (p.res_mode == CSBSR_RES_NONE || p.res_mode == CSBSR_RES_ADD || p.res_mode == CSBSR_RES_SUB);
   f.sneg = p.act == CSBSR_ACT_NONE ? 1.f : (p.act == CSBSR_ACT_RELU ? 0.f : slope);
   f.rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
   f.has_res = p.res_mode != CSBSR_RES_NONE; f.has_old = p.accumulate != 0; f.bn = p.stat_mode == CSBSR_STAT_BN;
-  f.osc = p.out_scale;
+  f.masked = (p.cout & 7) != 0;      // the last channel octet is partly padding: those lanes are forced to zero (one branch per row)
+  f.osc = p.out_scale; f.cout = p.cout;
   return f;
 }
-// one pixel x 8 channels; o = &out16[pixel][co]; rr / oo = residual / old output (zeros when absent; only read when EXTRA)
+// one pixel x 8 channels co..co+7; o = &out16[pixel][co]; rr / oo = residual / old output (zeros when absent; only read when EXTRA)
 template <bool EXTRA, bool BNSTAT>
-__device__ __forceinline__ void conv_epilogue_fast_row(const EpiFast& f, const float (&v)[8], const float (&bias)[8], half_t* o, const h8& rr,
-                                                       const h8& oo, float (&ssum)[8], float (&ssq)[8]) {
+__device__ __forceinline__ void conv_epilogue_fast_row(const EpiFast& f, const float (&v)[8], const float (&bias)[8], int co, half_t* o,
+                                                       const h8& rr, const h8& oo, float (&ssum)[8], float (&ssq)[8]) {
+  float t[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    t[e] = v[e] * f.osc + bias[e];
+    t[e] = fmaxf(t[e], t[e] * f.sneg);
+  }
+  if (f.masked) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (co + e < f.cout) ? t[e] : 0.f;
+  }
   h8 hv;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    float t = v[e] * f.osc + bias[e];
-    t = fmaxf(t, t * f.sneg);
-    if constexpr (BNSTAT) { ssum[e] += t; ssq[e] += t * t; }
+    if constexpr (BNSTAT) { ssum[e] += t[e]; ssq[e] += t[e] * t[e]; }
     if constexpr (EXTRA) {
-      t += f.rsign * (float)rr[e];
-      t += (float)oo[e];
+      t[e] += f.rsign * (float)rr[e];
+      t[e] += (float)oo[e];
     }
-    hv[e] = (half_t)t;
+    hv[e] = (half_t)t[e];
   }
   *reinterpret_cast<h8*>(o) = hv;
 }

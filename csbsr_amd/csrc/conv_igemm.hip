@@ -22,6 +22,13 @@
 #define BK 64
 #define LDS_LD 72  // halves per LDS row: 64 + 8 pad (144 B): conflict-free 16-byte fragment reads
 
+#ifdef CSBSR_TS
+__device__ unsigned long long g_its[8 * 262144];
+#define ITS(i) do { if (threadIdx.x == 0 && blockIdx.x < 262144) g_its[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+extern "C" int csbsr_debug_read_its(void* dst, long n) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_its), n * 8); }
+#else
+#define ITS(i)
+#endif
 template <int BN, int WP, int WC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ? 2 : (BN == 64 ? 3 : 4)))) void conv_igemm_kernel(const ConvK p) {
   constexpr int PW = BM / WP;      // pixels per wave
@@ -43,6 +50,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
   float* sBias = sStat + 2 * BN;                                           // [BN]: fetched before the K loop, not inside the epilogue
   long* sOOff = reinterpret_cast<long*>(sBias + BN);                       // [BM]: element offset of each tile row's output pixel in out16
 
+  ITS(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int wp = wid / WC, wc = wid % WC;
@@ -83,6 +91,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
   if (tid < BN) sBias[tid] = (p.bias && cout0 + tid < p.cout) ? p.bias[cout0 + tid] : 0.f;
   const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
   __syncthreads();
+  ITS(1);
 
   // ---- per-thread gather state: rows tid/8 + 32 j (j < 4); 16-byte k-segment seg = tid%8 (one K slice = 64 channels of one
   // tap = a full 128-byte line per pixel)
@@ -133,9 +142,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
   while (kc >= p.ctot) { kc -= p.ctot; next_tap(); }
 
   constexpr int WCH = (BN * SEGS + 255) / 256;  // weight chunks per thread
-  h8 gx[XCH], gw[WCH];
+  // register-staged slices: two sets in flight for the narrow tiles (a 32-cout slice is 4 MFMAs per wave -- 128 clocks -- against a
+  // ~1.3 us load round trip: CSBSR_TS showed the K loop of the HR 32-channel layers waiting one full round trip per slice)
+  constexpr bool DEEP = BN <= 32;
+  h8 gx0[XCH], gw0[WCH], gx1[DEEP ? XCH : 1], gw1[DEEP ? WCH : 1];
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, auto& gx, auto& gw) {
     // weights
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
     kc += BK;
     while (kc >= p.ctot) { kc -= p.ctot; next_tap(); }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](const auto& gx, const auto& gw) {
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
       const int c = tid + 256 * i;
@@ -191,12 +203,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
   const int nkt = p.Kp / BK;
   const half_t* w_base = sW + (wc * CW + (lane & 31)) * LDS_LD + (lane >> 5) * 8;
   const half_t* x_base = sX + (wp * PW + (lane & 31)) * LDS_LD + (lane >> 5) * 8;
-  load_tile(0);
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt > 0) __syncthreads();              // previous slice's fragment reads done
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < nkt) load_tile(kt + 1);
+  ITS(2);
+  auto compute = [&]() {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       h8 af[TC], bf[TP];
@@ -209,7 +217,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
 #pragma unroll
         for (int b = 0; b < TP; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
+  };
+  load_tile(0, gx0, gw0);
+  ITS(3);
+  if constexpr (DEEP) {
+    if (nkt > 1) load_tile(1, gx1, gw1);
+    for (int kt = 0; kt < nkt; kt += 2) {
+      if (kt > 0) __syncthreads();              // previous slice's fragment reads done
+      store_tile(gx0, gw0);
+      __syncthreads();
+      if (kt + 2 < nkt) load_tile(kt + 2, gx0, gw0);
+      compute();
+      if (kt + 1 < nkt) {
+        __syncthreads();
+        store_tile(gx1, gw1);
+        __syncthreads();
+        if (kt + 3 < nkt) load_tile(kt + 3, gx1, gw1);
+        compute();
+      }
+    }
+  } else {
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt > 0) __syncthreads();              // previous slice's fragment reads done
+      store_tile(gx0, gw0);
+      __syncthreads();
+      if (kt + 1 < nkt) load_tile(kt + 1, gx0, gw0);
+      compute();
+    }
   }
+  ITS(4);
   __syncthreads();
 
   // ---- epilogue: fp32 tile -> LDS [pixel][cout] in halves of HB couts (keeps LDS <= the main-loop footprint so three
@@ -255,6 +291,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
       }
     }
     lds_barrier();
+    if (hh == 0) ITS(5);
 
     const int co = cout0 + hh * HB + cc8 * 8;
     float bias[8];
@@ -299,7 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
             const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
             const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, bias, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq);
+            conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, bias, co, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq);
           }
         }
       };
@@ -339,6 +376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
     conv_epilogue_flush_stats<CPR>(p, sStat, BN, hh * HB + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
   }
 
+  ITS(6);
   if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
     __syncthreads();
     if (tid < BN && cout0 + tid < p.coutp) {

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
           const f4 v0 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8) ^ (row & 15)) << 2));
           const f4 v1 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8 + 1) ^ (row & 15)) << 2));
           const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, bias, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq);
+          conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, bias, co, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq);
         }
       }
     };

@@ -7,7 +7,8 @@ from csbsr_amd import _lib as L
 from csbsr_amd.engine import Engine, Conv, FM, pad8
 shape = sys.argv[1]; nb = int(sys.argv[2]); what = sys.argv[3]
 shapes = {"deconv8s4": (448, 448, 128, 128, 8, 4, 2, True), "conv8s4": (1792, 1792, 128, 128, 8, 4, 2, False), "c128": (448, 448, 128, 128, 3, 1, 1, False),
-          "gemm1x1": (1792, 1792, 128, 128, 1, 1, 0, False)}
+          "gemm1x1": (1792, 1792, 128, 128, 1, 1, 0, False), "hr32": (1792, 1792, 32, 32, 3, 1, 1, False), "hr49": (1792, 1792, 49, 49, 3, 1, 1, False),
+          "hr64": (1792, 1792, 64, 64, 3, 1, 1, False)}
 H, W, cin, cout, k, s, p, tr = shapes[shape]
 eng = Engine()
 wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
@@ -24,8 +25,9 @@ torch.cuda.synchronize()
 lib = L.load()
 n = 262144
 buf = np.zeros(n * 8, dtype=np.uint64)
-lib.csbsr_debug_read_ts.argtypes = [ctypes.c_void_p, ctypes.c_long]
-lib.csbsr_debug_read_ts(buf.ctypes.data, n * 8)
+rd = lib.csbsr_debug_read_its if (len(sys.argv) > 4 and sys.argv[4] == "generic") else lib.csbsr_debug_read_ts
+rd.argtypes = [ctypes.c_void_p, ctypes.c_long]
+rd(buf.ctypes.data, n * 8)
 t = buf.reshape(n, 8).astype(np.int64)
 live = t[:, 6] > t[:, 0]
 t = t[live]
