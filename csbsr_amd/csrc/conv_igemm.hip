@@ -80,9 +80,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
     long m = m0 + tid;
     int n = -1, oy = 0, ox = 0;
     if (m < M) {
-      n = (int)(m / ((long)OHp * OWp));
-      int rem = (int)(m - (long)n * OHp * OWp);
-      oy = rem / OWp; ox = rem - oy * OWp;
+      int rem;
+      if (M < (1l << 31)) {      // 32-bit divisions (the 64-bit one is a ~100-instruction routine in front of the prologue barrier)
+        const unsigned hw = (unsigned)(OHp * OWp);
+        n = (int)((unsigned)m / hw); rem = (int)((unsigned)m - (unsigned)n * hw);
+      } else {
+        n = (int)(m / ((long)OHp * OWp)); rem = (int)(m - (long)n * OHp * OWp);
+      }
+      oy = (int)((unsigned)rem / (unsigned)OWp); ox = rem - oy * OWp;
     }
     sRow[tid * 3 + 0] = n; sRow[tid * 3 + 1] = oy; sRow[tid * 3 + 2] = ox;
     sOOff[tid] = n * p.o_sn + (long)(py + oy * o_step) * p.o_sy + (long)(px + ox * o_step) * p.o_sx;
@@ -443,7 +448,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   CSBSR_CHECK(d->res_mode != CSBSR_RES_FMA || d->res2, "conv: FMA needs res2");
   k.accumulate = d->accumulate; k.stat_mode = d->stat_mode; k.stat = d->stat;
   k.out_scale = d->out_scale;
-  k.direct_epi = g_conv_direct_epi;
+  k.direct_epi = g_conv_direct_epi; k.tile2d = 0; k.nphase_flat = 0;
   CSBSR_CHECK(d->stat_mode == CSBSR_STAT_NONE || d->stat, "conv: stat_mode set without stat buffer");
   int nphase = 1;
   long maxM;

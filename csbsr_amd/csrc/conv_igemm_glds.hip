@@ -75,7 +75,18 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   }
   const long M = (long)p.N * OHp * OWp;
   const long m0 = (long)tile_m * BM;
-  if (m0 >= M) return;
+  // 2-D pixel tiles (16 wide, BM/16 high) for the spatial layers whose output divides evenly: a BM-pixel run of one output row needs
+  // KH input rows x (BM*stride + K) columns, the 2-D tile (BM/16*stride + K) x (16*stride + K) -- 2448 instead of 4128 input pixels
+  // per 128 outputs for the 8x8 stride-4 layers, 180 instead of 390 for a 3x3
+  constexpr int TW2 = 16, TH2 = BM / 16;
+  int t2_n = 0, t2_y0 = 0, t2_x0 = 0;
+  if (p.tile2d) {
+    const int tx_n = p.OW / TW2, ty_n = p.OH / TH2;
+    t2_n = tile_m / (tx_n * ty_n);
+    const int rem = tile_m - t2_n * (tx_n * ty_n);
+    t2_y0 = (rem / tx_n) * TH2; t2_x0 = (rem % tx_n) * TW2;
+    if (t2_n >= p.N) return;
+  } else if (m0 >= M) return;
   const half_t* wt = p.wt + (size_t)zph * p.rows_p * p.Kp;
 
   // the bias is fetched now and parked in LDS after the first DMA issue: its HBM round trip used to sit in front of the prologue barrier
@@ -84,10 +95,17 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   if (tid < BM) {
     long m = m0 + tid;
     int n = -1, oy = 0, ox = 0;
-    if (m < M) {
-      n = (int)(m / ((long)OHp * OWp));
-      int rem = (int)(m - (long)n * OHp * OWp);
-      oy = rem / OWp; ox = rem - oy * OWp;
+    if (p.tile2d) {
+      n = t2_n; oy = t2_y0 + tid / TW2; ox = t2_x0 + tid % TW2;
+    } else if (m < M) {
+      int rem;
+      if (M < (1l << 31)) {      // 32-bit divisions (the 64-bit one is a ~100-instruction routine in front of the prologue barrier)
+        const unsigned hw = (unsigned)(OHp * OWp);
+        n = (int)((unsigned)m / hw); rem = (int)((unsigned)m - (unsigned)n * hw);
+      } else {
+        n = (int)(m / ((long)OHp * OWp)); rem = (int)(m - (long)n * OHp * OWp);
+      }
+      oy = (int)((unsigned)rem / (unsigned)OWp); ox = rem - oy * OWp;
     }
     sRow[tid * 3 + 0] = n; sRow[tid * 3 + 1] = oy; sRow[tid * 3 + 2] = ox;
     const int iy0 = oy * in_step + base_y, ix0 = ox * in_step + base_x;
@@ -265,7 +283,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   int n_last;
   {
     long ml = (m0 + BM - 1 < M - 1) ? m0 + BM - 1 : M - 1;
-    n_last = (int)(ml / ((long)OHp * OWp));
+    n_last = p.tile2d ? n_first : (int)(ml / ((long)OHp * OWp));
   }
   const bool uniform_n = (n_first == n_last);
   constexpr int CPR = 16;                     // 8-channel chunks per staged row (128 couts)
@@ -377,12 +395,14 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 
 static half_t* g_zero_page = nullptr;
 static int g_glds_phase_flat = 1;
+static int g_glds_tile2d = 1;
 
 template <int BM, int NWM, int NSTAGE>
 static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   ConvK p = k;
   constexpr int BN = 128;
   p.tiles_m = (unsigned)((maxM + BM - 1) / BM);
+  p.tile2d = (g_glds_tile2d && !k.transposed && k.KHt * k.KWt > 1 && k.OW % 16 == 0 && k.OH % (BM / 16) == 0) ? 1 : 0;      // same tile count
   p.tiles_n = (unsigned)((k.coutp + BN - 1) / BN);
   constexpr int RING = NSTAGE * (BM + BN) * 128;
   constexpr int EPI = 128 * 68 * 4;
@@ -412,7 +432,8 @@ static int g_glds_mode = 2;      // 0: off, 1: 128x128 x2 stages only, 2: + 256x
 int g_conv_direct_epi = 0;      // measured: 32-byte store segments lose to the LDS-staged 128-byte ones on the tile kernels
 extern "C" void csbsr_debug_set_conv_glds(int mode) {
   g_glds_mode = mode & 7;
-  g_glds_phase_flat = (mode & 32) ? 0 : 1;     // bit 5: phases back on grid.z (A/B timing)
+  g_glds_phase_flat = (mode & 32) ? 0 : 1;
+  g_glds_tile2d = (mode & 64) ? 0 : 1;           // bit 6: linear pixel tiles everywhere (A/B timing)     // bit 5: phases back on grid.z (A/B timing)
   g_conv_direct_epi = (mode & 8) ? 1 : 0;
   conv_thin_enable((mode & 16) ? 0 : 1);      // bit 4: route the 3-channel heads through the generic kernel (A/B timing)
 }
