@@ -24,6 +24,7 @@ struct ConvK {
   int stat_mode; float* stat;
   float out_scale;
   unsigned tiles_m, tiles_n;
+  int tap_group;             // 1: strided layer, taps issued residue class by residue class (glds kernel, see issue())
   int tile2d;                // 1: 16-wide 2-D pixel tiles (glds kernel, see there)
   int nphase_flat;           // > 1: 1-D grid with the transposed conv's output phase as the fastest index (glds kernel)
   int direct_epi;            // 1: register-direct epilogue when no statistics are requested

@@ -448,7 +448,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   CSBSR_CHECK(d->res_mode != CSBSR_RES_FMA || d->res2, "conv: FMA needs res2");
   k.accumulate = d->accumulate; k.stat_mode = d->stat_mode; k.stat = d->stat;
   k.out_scale = d->out_scale;
-  k.direct_epi = g_conv_direct_epi; k.tile2d = 0; k.nphase_flat = 0;
+  k.direct_epi = g_conv_direct_epi; k.tile2d = 0; k.nphase_flat = 0; k.tap_group = 0;
   CSBSR_CHECK(d->stat_mode == CSBSR_STAT_NONE || d->stat, "conv: stat_mode set without stat buffer");
   int nphase = 1;
   long maxM;

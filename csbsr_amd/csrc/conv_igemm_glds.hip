@@ -156,7 +156,10 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   // The wave-uniform source pointer moves by precomputed pixel / row strides between taps (both input segments tracked, their
   // strides may differ); the per-lane row offsets of the current segment sit in offc[].
   const int ntaps = p.KHt * p.KWt;
-  int cs = 0, kx = 0, tap = 0;
+  int cs = 0, kx = 0, tap = 0, tcount = 0;
+  int g_ax = 0, g_ay = 0, g_rx = 0, g_ry = 0;                      // grouped tap order (see issue())
+  const int ggx = p.tap_group ? p.KWt / p.stride : 1, ggy = p.tap_group ? p.KHt / p.stride : 1;
+  const long rs0 = (long)tap_step * p.in[0].sy, rs1 = (long)tap_step * p.in[1].sy;
   const long tsx0 = (long)tap_step * p.in[0].sx, tsy0 = (long)tap_step * p.in[0].sy - (long)p.KWt * tsx0;
   const long tsx1 = (long)tap_step * p.in[1].sx, tsy1 = (long)tap_step * p.in[1].sy - (long)p.KWt * tsx1;
   const half_t* const xb0_0 = reinterpret_cast<const half_t*>(p.in[0].ptr);          // tap 0, channel 0 of segment 0
@@ -184,17 +187,29 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + wk),
                                        (__attribute__((address_space(3))) void*)(sbase + BM * 128 + (wid + NW * (NXI + i) - XI) * 1024), 16, 0, 0);
     }
-    if (++tap == ntaps) {                     // next channel slice (wave-uniform branch)
-      tap = 0; kx = 0; xb0 = xb0_0; xb1 = xb1_0;
+    if (++tcount == ntaps) {                  // next channel slice (wave-uniform branch)
+      tcount = 0; tap = 0; kx = 0; xb0 = xb0_0; xb1 = xb1_0;
+      g_ax = g_ay = g_rx = g_ry = 0;
       cs += BKG;
       if (seg0 && cs >= p.c0 && cs < p.ctot) {          // crossed into the second input segment (c0 is a multiple of BKG here)
         seg0 = false;
 #pragma unroll
         for (int i = 0; i < NXI; ++i) offc[i] = off1[i];
       }
-    } else {
+    } else if (!p.tap_group) {
+      ++tap;
       xb0 += tsx0; xb1 += tsx1;
       if (++kx == p.KWt) { kx = 0; xb0 += tsy0; xb1 += tsy1; }
+    } else {
+      // strided layers: taps that agree modulo the stride gather the SAME input pixels (for neighbouring outputs), so they are
+      // issued back to back -- (ky, kx) = (ry + s*ay, rx + s*ax), (ax, ay) fastest -- and the class's lines are still in L2 / L1
+      // when its next tap wants them.  In raster order the re-touches were 4 and 32 taps apart, a 256-pixel tile's 64-channel
+      // window (592 KB) x 32 workgroups per XCD in between: PMC fetch 10 GB per launch for 3.5 GB of input on the 8x8 stride-4
+      // layers at N = 4, at which point the layer ran at HBM speed.
+      if (++g_ax == ggx) { g_ax = 0; if (++g_ay == ggy) { g_ay = 0; if (++g_rx == p.stride) { g_rx = 0; ++g_ry; } } }
+      const int ky = g_ry + p.stride * g_ay, kxx = g_rx + p.stride * g_ax;
+      tap = ky * p.KWt + kxx;
+      xb0 = xb0_0 + ky * rs0 + kxx * tsx0; xb1 = xb1_0 + ky * rs1 + kxx * tsx1;
     }
   };
 
@@ -396,6 +411,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 static half_t* g_zero_page = nullptr;
 static int g_glds_phase_flat = 1;
 static int g_glds_tile2d = 1;
+static int g_glds_tap_group = 1;
 
 template <int BM, int NWM, int NSTAGE>
 static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
@@ -403,6 +419,8 @@ static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   constexpr int BN = 128;
   p.tiles_m = (unsigned)((maxM + BM - 1) / BM);
   p.tile2d = (g_glds_tile2d && !k.transposed && k.KHt * k.KWt > 1 && k.OW % 16 == 0 && k.OH % (BM / 16) == 0) ? 1 : 0;      // same tile count
+  p.tap_group = (g_glds_tap_group && !k.transposed && k.stride > 1 && k.dil == 1 && k.KHt > k.stride && k.KHt % k.stride == 0 &&
+                 k.KWt > k.stride && k.KWt % k.stride == 0) ? 1 : 0;
   p.tiles_n = (unsigned)((k.coutp + BN - 1) / BN);
   constexpr int RING = NSTAGE * (BM + BN) * 128;
   constexpr int EPI = 128 * 68 * 4;
@@ -433,6 +451,7 @@ int g_conv_direct_epi = 0;      // measured: 32-byte store segments lose to the 
 extern "C" void csbsr_debug_set_conv_glds(int mode) {
   g_glds_mode = mode & 7;
   g_glds_phase_flat = (mode & 32) ? 0 : 1;
+  g_glds_tap_group = (mode & 128) ? 0 : 1;       // bit 7: raster tap order on the strided layers (A/B timing)
   g_glds_tile2d = (mode & 64) ? 0 : 1;           // bit 6: linear pixel tiles everywhere (A/B timing)     // bit 5: phases back on grid.z (A/B timing)
   g_conv_direct_epi = (mode & 8) ? 1 : 0;
   conv_thin_enable((mode & 16) ? 0 : 1);      // bit 4: route the 3-channel heads through the generic kernel (A/B timing)
