@@ -62,6 +62,10 @@ CASES = [
     (128, 128, 12, 8, 2, 1, False, 64, 64),        # x8 down-projection: 144 taps (> the 64-bit tap mask)
     (64, 505, 3, 1, 1, 1, False, 20, 24),          # blur_skip conv_scale.0 feature part (cout padded 505 -> 512)
     (505, 64, 3, 1, 1, 1, False, 20, 24),          # blur_skip conv_scale.1 (cin padded 505 -> 512)
+    (128, 128, 8, 4, 2, 1, False, 256, 256),       # strided gather: 2-D pixel tiles, residue-grouped tap order; wgrad tap order + row shift
+    (256, 128, 3, 1, 1, 1, False, 192, 192),       # 256x128 LDS-DMA tile with 2-D (16 x 16) pixel tiles
+    (128, 128, 8, 4, 2, 1, False, 768, 768),       # the same strided gather on the 256x128 tile (> 65536 output pixels)
+    (768, 128, 3, 1, 1, 1, False, 24, 24),         # 6912 wgrad columns: the 128 x 256 eight-wave wgrad tile
 ]
 
 
