@@ -20,8 +20,10 @@
 
 #define BM 128
 #define BK 64
+#define NTAP_MAX 160   // taps per phase the tap tables hold (12 x 12 is the largest kernel on the path)
 #define LDS_LD 72  // halves per LDS row: 64 + 8 pad (144 B): conflict-free 16-byte fragment reads
 
+__device__ __attribute__((aligned(16))) const half_t g_zero_line[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // what out-of-image taps read
 #ifdef CSBSR_TS
 __device__ unsigned long long g_its[8 * 262144];
 #define ITS(i) do { if (threadIdx.x == 0 && blockIdx.x < 262144) g_its[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
@@ -49,6 +51,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
   float* sStat = reinterpret_cast<float*>(smem + SM_BYTES + BM * 3 * 4);  // [2][BN]
   float* sBias = sStat + 2 * BN;                                           // [BN]: fetched before the K loop, not inside the epilogue
   long* sOOff = reinterpret_cast<long*>(sBias + BN);                       // [BM]: element offset of each tile row's output pixel in out16
+  long* sTap0 = sOOff + BM;                                                // [NTAP_MAX] element displacement of tap t in input segment 0
+  long* sTap1 = sTap0 + NTAP_MAX;                                          // ... in segment 1
+  int* sTapYX = reinterpret_cast<int*>(sTap1 + NTAP_MAX);                  // [NTAP_MAX] (ty, tx) packed, -1 past the last tap (K padding)
 
   ITS(0);
   const int tid = threadIdx.x;
@@ -92,6 +97,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
     sRow[tid * 3 + 0] = n; sRow[tid * 3 + 1] = oy; sRow[tid * 3 + 2] = ox;
     sOOff[tid] = n * p.o_sn + (long)(py + oy * o_step) * p.o_sy + (long)(px + ox * o_step) * p.o_sx;
   }
+  if (tid < NTAP_MAX) {        // tap tables: the K loop looks a tap's displacement up instead of carrying 64-bit running sums per thread
+    const int ty = tid / p.KWt, tx = tid - ty * p.KWt;
+    const bool live = tid < p.KHt * p.KWt;
+    sTap0[tid] = live ? (long)tap_step * (ty * p.in[0].sy + tx * p.in[0].sx) : 0;
+    sTap1[tid] = live ? (long)tap_step * (ty * p.in[1].sy + tx * p.in[1].sx) : 0;
+    sTapYX[tid] = live ? (ty | (tx << 16)) : -1;
+  }
   if (tid < 2 * BN) sStat[tid] = 0.f;
   if (tid < BN) sBias[tid] = (p.bias && cout0 + tid < p.cout) ? p.bias[cout0 + tid] : 0.f;
   const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
@@ -130,21 +142,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
     }
     tapmask[j] = m;
   }
-  // running (tap, channel) cursor of this thread's 16-byte segment, and the tap displacement in each segment's strides
-  int kc = seg * 8, ky = 0, kx = 0, tapi = 0;
-  long td0 = 0, td1 = 0;
-  auto next_tap = [&]() {
-    ++tapi;
-    if (++kx == p.KWt) {
-      kx = 0; ++ky;
-      td0 += tap_step * (p.in[0].sy - (long)(p.KWt - 1) * p.in[0].sx);
-      td1 += tap_step * (p.in[1].sy - (long)(p.KWt - 1) * p.in[1].sx);
-    } else {
-      td0 += tap_step * p.in[0].sx;
-      td1 += tap_step * p.in[1].sx;
-    }
-  };
-  while (kc >= p.ctot) { kc -= p.ctot; next_tap(); }
+  // running (tap, channel) cursor of this thread's 16-byte segment.  Per slice the thread does: two table reads for the tap, one
+  // pointer select, then per chunk a validity test and a pointer select between the pixel and a zero line -- ~60 VALU instructions
+  // where the running-displacement version (branchy next-tap updates, predicated loads with zero-initialised destinations) had
+  // ~150, against 4 MFMAs per wave and slice on the 32-cout tile (the K loop of the HR 32-channel layers was VALU-bound).
+  int kc = seg * 8, tapi = 0;
+  while (kc >= p.ctot) { kc -= p.ctot; ++tapi; }
+  const half_t* const zline = g_zero_line;
 
   constexpr int WCH = (BN * SEGS + 255) / 256;  // weight chunks per thread
   // register-staged slices: two sets in flight for the narrow tiles (a 32-cout slice is 4 MFMAs per wave -- 128 clocks -- against a
@@ -152,38 +156,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
   constexpr bool DEEP = BN <= 32;
   h8 gx0[XCH], gw0[WCH], gx1[DEEP ? XCH : 1], gw1[DEEP ? WCH : 1];
 
-  auto load_tile = [&](int kt, auto& gx, auto& gw) {
-    // weights
+  // weight chunks: a running pointer per chunk (rows past the padded weight rows read the zero line and do not move)
+  const half_t* wsrc[WCH];
+  int wstep[WCH];
 #pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c / SEGS, sg = c % SEGS;
-      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (row < BN && cout0 + row < p.rows_p)
-        v = *reinterpret_cast<const h8*>(wt + (size_t)(cout0 + row) * p.Kp + kt * BK + sg * 8);
-      gw[i] = v;
-    }
+  for (int i = 0; i < WCH; ++i) {
+    const int c = tid + 256 * i;
+    const int row = c / SEGS, sg = c % SEGS;
+    const bool ok = row < BN && cout0 + row < p.rows_p;
+    wsrc[i] = ok ? wt + (size_t)(cout0 + row) * p.Kp + sg * 8 : zline;
+    wstep[i] = ok ? BK : 0;
+  }
+  const half_t* const in0 = reinterpret_cast<const half_t*>(p.in[0].ptr);
+  const half_t* const in1 = reinterpret_cast<const half_t*>(p.in[1].ptr) - p.c0;       // indexed by the concatenated channel
+  auto load_tile = [&](int kt, auto& gx, auto& gw) {
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) { gw[i] = *reinterpret_cast<const h8*>(wsrc[i]); wsrc[i] += wstep[i]; }
     // patches
-    const bool kvalid = ky < p.KHt;
+    const bool kvalid = tapi < ntaps;
+    const int tq = kvalid ? tapi : 0;
+    const int yx = sTapYX[tq];
     const bool s0 = kc < p.c0;
-    const half_t* base = s0 ? reinterpret_cast<const half_t*>(p.in[0].ptr) + kc + td0
-                            : reinterpret_cast<const half_t*>(p.in[1].ptr) + (kc - p.c0) + td1;
-    const unsigned long long bit = (use_mask && tapi < 64) ? (1ull << tapi) : 0ull;
+    const half_t* base = (s0 ? in0 + sTap0[tq] : in1 + sTap1[tq]) + kc;
+    const int ky = yx & 0xffff, kx = yx >> 16;
 #pragma unroll
     for (int j = 0; j < XCH; ++j) {
       bool ok;
-      if (use_mask) ok = kvalid && (tapmask[j] & bit);
+      if (use_mask) ok = kvalid && ((tapmask[j] >> (tapi & 63)) & 1ull);
       else {
         const int iy = riy[j] + ky * tap_step, ix = rix[j] + kx * tap_step;
         ok = kvalid && rn[j] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       }
-      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (ok) v = *reinterpret_cast<const h8*>(base + (s0 ? off0[j] : off1[j]));
-      gx[j] = v;
+      const half_t* src = ok ? base + (s0 ? off0[j] : off1[j]) : zline;
+      gx[j] = *reinterpret_cast<const h8*>(src);
     }
     // advance by one K slice
     kc += BK;
-    while (kc >= p.ctot) { kc -= p.ctot; next_tap(); }
+    while (kc >= p.ctot) { kc -= p.ctot; ++tapi; }
   };
   auto store_tile = [&](const auto& gx, const auto& gw) {
 #pragma unroll
@@ -403,7 +412,7 @@ static int launch_conv(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   constexpr int OUT_LD = (BN == 128 ? 64 : BN) + 4;
   constexpr int MAIN_BYTES = (BN + BM) * LDS_LD * 2;
   constexpr int EPI_BYTES = BM * OUT_LD * 4;
-  constexpr int SM_BYTES = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + BM * 3 * 4 + 3 * BN * 4 + BM * 8;
+  constexpr int SM_BYTES = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + BM * 3 * 4 + 3 * BN * 4 + BM * 8 + NTAP_MAX * 20;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BN, WP, WC>),
@@ -465,6 +474,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
     return conv_thin_cin_launch(k, d->in[0].creal, st);
   }
   if (conv_glds_eligible(k)) return conv_glds_launch(k, nphase, maxM, st);
+  CSBSR_CHECK(k.KHt * k.KWt <= NTAP_MAX, "conv: more taps per phase than the tap tables hold");
   g_last_conv_kernel = k.coutp > 64 ? CONVK_IGEMM128 : (k.coutp > 32 ? CONVK_IGEMM64 : CONVK_IGEMM32);
   if (k.coutp > 64) return launch_conv<128, 2, 2>(k, nphase, maxM, st);
   if (k.coutp > 32) return launch_conv<64, 2, 2>(k, nphase, maxM, st);
