@@ -199,7 +199,8 @@ __device__ __forceinline__ void conv_epilogue_flush_stats(const ConvK& p, float*
 // ``bias_tab``: per-cout bias already staged by the caller (LDS, indexed by absolute cout, zeros past p.cout), or nullptr to read p.bias
 // from global memory here -- 8 dependent L2 round trips per call, which is most of a short tile's epilogue.
 __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const f16v& acc, int cbase /*first cout of the 32-wide tile*/,
-                                                          float slope, int n, int oy, int ox, const float* bias_tab = nullptr) {
+                                                          float slope, int n, int oy, int ox, const float* bias_tab = nullptr,
+                                                          const EpiFast* fe = nullptr) {
   if (n < 0) return;
   const int hi = (threadIdx.x & 63) >> 5;
 #pragma unroll
@@ -219,6 +220,15 @@ __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const 
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = bias_tab ? bias_tab[co + e] : ((p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f);
     float s0[8], s1[8];
+    if (fe && fe->ok && !fe->bn) {          // straight-line row (the caller set fe up once per kernel)
+      half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
+      h8 rr = {0, 0, 0, 0, 0, 0, 0, 0}, oo = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (fe->has_res) rr = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
+      if (fe->has_old) oo = *reinterpret_cast<const h8*>(o);
+      if (fe->has_res || fe->has_old) conv_epilogue_fast_row<true, false>(*fe, v, bias, co, o, rr, oo, s0, s1);
+      else conv_epilogue_fast_row<false, false>(*fe, v, bias, co, o, rr, oo, s0, s1);
+      continue;
+    }
     int cur_n = -1;
     conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, true, cur_n, s0, s1);
   }

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void conv_thin_cin_kernel(const ConvK p, int t
     for (int c = 0; c < CI; ++c) sWt[co * TK_WLD + tap * CI + c] = v[c];
   }
   const float slope = p.act == CSBSR_ACT_PRELU ? p.prelu[0] : p.act_slope;
+  const EpiFast fe = conv_epilogue_fast_setup(p, slope);
 #pragma unroll 1
   for (int ty = ty0; ty < ty0 + TN_TPW && ty < tiles_y; ++ty) {
   __syncthreads();                      // previous tile's sIn reads done
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_thin_cin_kernel(const ConvK p, int t
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, pf[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, pf[1], acc, 0, 0, 0);
-      conv_epilogue_direct_tile(p, acc, ct * 32, slope, nn, oy, ox, sBias);
+      conv_epilogue_direct_tile(p, acc, ct * 32, slope, nn, oy, ox, sBias, &fe);
     }
   }
   }

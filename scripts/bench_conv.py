@@ -46,6 +46,8 @@ if __name__ == "__main__":
         "hr32": (1, 1792, 1792, 32, 32, 3, 1, 1),
         "gemm1x1": (1, 1792, 1792, 128, 128, 1, 1, 0),
         "hr49": (1, 1792, 1792, 49, 49, 3, 1, 1),
+        "thin3_128": (1, 1792, 1792, 3, 128, 3, 1, 1),
+        "thin3_512": (1, 1792, 1792, 3, 512, 3, 1, 1),
         "conv8s4_small": (1, 448, 448, 128, 128, 8, 4, 2),
         "c128_small": (1, 112, 112, 128, 128, 3, 1, 1),
         "c128": (1, 448, 448, 128, 128, 3, 1, 1),
