@@ -36,4 +36,5 @@ names = ["prologue(decode)", "tapmask+first issue", "first stage landed", "K loo
 d = np.diff(t[:, :7], axis=1) * 10.0   # ns
 for i, nm in enumerate(names):
     print(f"  {nm:22s} mean {d[:, i].mean():8.0f} ns   p50 {np.median(d[:, i]):8.0f}   p90 {np.percentile(d[:, i], 90):8.0f}")
+print(f"  entry -> decode start (TS7-TS0): mean {(t[:, 7] - t[:, 0]).mean() * 10:8.0f} ns")
 print(f"  total                  mean {(t[:, 6] - t[:, 0]).mean() * 10:8.0f} ns ; kernel span {(t[:, 6].max() - t[:, 0].min()) * 10 / 1e6:.3f} ms")
