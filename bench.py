@@ -85,11 +85,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
+    # test hooks (one-GPU smoke of the N > 1 path): CSBSR_DIST_BACKEND=gloo CSBSR_FORCE_DEVICE=0 puts every rank on one device
+    backend = os.environ.get("CSBSR_DIST_BACKEND", "nccl")
+    if "CSBSR_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["CSBSR_FORCE_DEVICE"])
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from csbsr_amd.config import cfg as base_cfg
     from csbsr_amd.modeling.build_model import JointModelWithLoss
