@@ -21,9 +21,10 @@ extern "C" int csbsr_debug_read_ts(void* dst, long n) { return (int)hipMemcpyFro
 #else
 #define TS(i)
 #endif
-template <int BM, int NWM, int NSTAGE>
+template <int BM, int NWM, int NSTAGE, int CT = 1>     // CT: 128-cout tiles per workgroup (2: a 256-cout tile, every wave 64 px x 128 couts)
 __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK p, const half_t* __restrict__ zero_page) {
-  constexpr int BN = 128, BKG = 64;
+  constexpr int BN = 128 * CT, BKG = 64;
+  constexpr int TA = 2 * CT;                         // 32-cout MFMA tiles per wave
   constexpr int NW = NWM * 2, NT = NW * 64;
   constexpr int XI = BM / 8, WI = BN / 8;            // wave-instructions per stage for the X / W tile
   constexpr int NI = (XI + WI) / NW;                 // per wave
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 #pragma unroll
   for (int i = 0; i < NI - NXI; ++i) {
     const int r = 8 * (wid + NW * (NXI + i) - XI) + (lane >> 3);      // weight-tile row
-    wrow[i] = wt + (size_t)(cout0 + r) * p.Kp + cch;                  // rows_p is padded to the tile: always in bounds
+    const int wr = cout0 + r < p.rows_p ? cout0 + r : p.rows_p - 1;   // rows_p is padded to 128: only the 256-cout tile can reach past it
+    wrow[i] = wt + (size_t)wr * p.Kp + cch;
   }
   const half_t* zp = zero_page + (lane & 7) * 8;
   // Scalar running state of the slice being ISSUED.  K is walked CHANNEL-SLICE OUTER, TAP INNER (the packed weights are indexed
@@ -214,9 +216,9 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     }
   };
 
-  f16v acc[2][2];
+  f16v acc[TA][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   if (tid < BN) sBias[tid] = bias_reg;        // read in the epilogue, behind the K loop's barriers
   const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
   // fragment addressing: tile row R, channel chunk c -> byte R*128 + ((c ^ ((R>>1)&7)) << 4)
-  const int xr0 = wm * 64 + (lane & 31), wr0 = wn * 64 + (lane & 31);
+  const int xr0 = wm * 64 + (lane & 31), wr0 = wn * (32 * TA) + (lane & 31);
   TS(2);
   for (int kt = 0; kt < nkt; ++kt) {
     // stage kt landed (this wave's DMAs), then everyone's
@@ -244,10 +246,10 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     const char* xs = smem + (kt % NSTAGE) * STAGE_BYTES;
     const char* ws = xs + BM * 128;
     // fragment double-buffering: the reads of sub-step ks+1 are in flight while the 4 MFMAs of sub-step ks issue
-    auto load_frags = [&](int ks, h8 (&af)[2], h8 (&bf)[2]) {
+    auto load_frags = [&](int ks, h8 (&af)[TA], h8 (&bf)[2]) {
       const int c = ks * 2 + (lane >> 5);
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
+      for (int a = 0; a < TA; ++a) {
         const int R = wr0 + a * 32;
         af[a] = *reinterpret_cast<const h8*>(ws + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
       }
@@ -257,20 +259,32 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
         bf[b] = *reinterpret_cast<const h8*>(xs + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
       }
     };
-    h8 af0[2], bf0[2], af1[2], bf1[2];
+    if constexpr (CT == 2) {      // 8 MFMAs per sub-step cover the next fragment reads; one fragment set keeps the wave inside 256 registers
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        h8 af[TA], bf[2];
+        load_frags(ks, af, bf);
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+      }
+      continue;
+    }
+    h8 af0[TA], bf0[2], af1[TA], bf1[2];
     load_frags(0, af0, bf0);
 #pragma unroll
     for (int ks = 0; ks < 4; ks += 2) {
       load_frags(ks + 1, af1, bf1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < TA; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0[a], bf0[b], acc[a][b], 0, 0, 0);
       if (ks + 2 < 4) load_frags(ks + 2, af0, bf0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < TA; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1[a], bf1[b], acc[a][b], 0, 0, 0);
     }
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
       const int row = wm * 64 + b * 32 + (lane & 31);
       const int n = sRow[row * 3], oy = py + sRow[row * 3 + 1] * o_step, ox = px + sRow[row * 3 + 2] * o_step;
 #pragma unroll
-      for (int a = 0; a < 2; ++a) conv_epilogue_direct_tile(p, acc[a][b], cout0 + wn * 64 + a * 32, slope, n, oy, ox);
+      for (int a = 0; a < TA; ++a) conv_epilogue_direct_tile(p, acc[a][b], cout0 + wn * (32 * TA) + a * 32, slope, n, oy, ox);
     }
     return;
   }
@@ -305,6 +319,14 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   constexpr int CPR = 16;                     // 8-channel chunks per staged row (128 couts)
   const int cc8 = tid % CPR;
   constexpr int RSTEP = NT / CPR;
+  const EpiFast fe = conv_epilogue_fast_setup(p, slope);      // conv_common.h
+  // CT == 2: the staged tile is BM x 128 couts at a time.  Pass h stages the two 32-cout MFMA tiles {2h, 2h+1} of EVERY wave (so no
+  // wave carries more than half its accumulators across a pass of row code): staged columns 0..63 are couts 64h.. of the waves
+  // with wn = 0, columns 64..127 couts 128 + 64h.. of the waves with wn = 1.  Each pass is a compile-time instance (static
+  // accumulator indices).
+  auto epi_pass = [&](auto HH) {
+  constexpr int hh = decltype(HH)::value;
+  if (hh > 0) lds_barrier();                 // the previous half's rows are read out
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -313,20 +335,21 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int slot = (wn * 64 + a * 32 + 8 * q + 4 * (lane >> 5)) >> 2;
-        f4 v = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+        const f16v& t = acc[2 * hh + a][b];
+        f4 v = {t[4 * q + 0], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
         *reinterpret_cast<f4*>(sO + pix * 128 + ((slot ^ (pix & 15)) << 2)) = v;
       }
     }
   lds_barrier();
-  TS(5);
-  const int co = cout0 + cc8 * 8;
+  if (hh == 0) TS(5);
+  const int lcol = CT == 1 ? cc8 * 8 : (cc8 >> 3) * 128 + hh * 64 + (cc8 & 7) * 8;      // this thread's 8 couts within the workgroup's BN
+  const int co = cout0 + lcol;
   float bias[8], ssum[8], ssq[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { bias[e] = sBias[cc8 * 8 + e]; ssum[e] = ssq[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { bias[e] = sBias[lcol + e]; ssum[e] = ssq[e] = 0.f; }
   int cur_n = -1;
-  const EpiFast fe = conv_epilogue_fast_setup(p, slope);      // conv_common.h
   if (fe.ok) {
-    constexpr int RPT = BM / RSTEP, EG = 4;
+    constexpr int RPT = BM / RSTEP, EG = CT == 2 ? 2 : 4;
     static_assert(RPT % EG == 0, "rows per thread must split into groups");
     auto rows = [&](auto EXTRA, auto BNSTAT) {       // EXTRA: a residual and / or the old output is combined in
 #pragma unroll 1
@@ -365,7 +388,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     const bool extra = fe.has_res || fe.has_old;
     if (fe.bn) { if (extra) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{}); }
     else { if (extra) rows(std::true_type{}, std::false_type{}); else rows(std::false_type{}, std::false_type{}); }
-    if (fe.bn) conv_epilogue_flush_stats<CPR>(p, sStat, BN, cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
+    if (fe.bn) conv_epilogue_flush_stats<CPR>(p, sStat, BN, lcol, co, uniform_n, cur_n, ssum, ssq);
   } else {
     // rows in groups of EG: the group's residual / old-output loads are all issued before the first row is combined
     constexpr int RPT = BM / RSTEP, EG = 2;
@@ -393,8 +416,11 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
         conv_epilogue_row(p, v, bias, slope, co, rn[i], roy[i], rox[i], uniform_n, cur_n, ssum, ssq, &pre[i]);
       }
     }
-    conv_epilogue_flush_stats<CPR>(p, sStat, BN, cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
+    conv_epilogue_flush_stats<CPR>(p, sStat, BN, lcol, co, uniform_n, cur_n, ssum, ssq);
   }
+  };      // epi_pass
+  epi_pass(std::integral_constant<int, 0>{});
+  if constexpr (CT == 2) epi_pass(std::integral_constant<int, 1>{});
   TS(6);
   if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
     __syncthreads();
@@ -413,23 +439,24 @@ static half_t* g_zero_page = nullptr;
 static int g_glds_phase_flat = 1;
 static int g_glds_tile2d = 1;
 static int g_glds_tap_group = 1;
+static int g_glds_wide = 1;
 
-template <int BM, int NWM, int NSTAGE>
+template <int BM, int NWM, int NSTAGE, int CT = 1>
 static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   ConvK p = k;
-  constexpr int BN = 128;
+  constexpr int BN = 128 * CT;
   p.tiles_m = (unsigned)((maxM + BM - 1) / BM);
   p.tile2d = (g_glds_tile2d && !k.transposed && k.KHt * k.KWt > 1 && k.OW % 16 == 0 && k.OH % (BM / 16) == 0) ? 1 : 0;      // same tile count
   p.tap_group = (g_glds_tap_group && !k.transposed && k.stride > 1 && k.dil == 1 && k.KHt > k.stride && k.KHt % k.stride == 0 &&
                  k.KWt > k.stride && k.KWt % k.stride == 0) ? 1 : 0;
   p.tiles_n = (unsigned)((k.coutp + BN - 1) / BN);
   constexpr int RING = NSTAGE * (BM + BN) * 128;
-  constexpr int EPI = 128 * 68 * 4;
+  constexpr int EPI = BM * 128 * 4;
   constexpr int SM_BYTES = (RING > EPI ? RING : EPI) + BM * (4 * 8 + 3 * 4) + 3 * BN * 4;      // ring / staged tile + row tables + statistics + bias
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_glds_kernel<BM, NWM, NSTAGE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES) != hipSuccess) {
       csbsr_set_error("conv(glds): cannot reserve %d bytes of LDS", SM_BYTES);
       return 2;
@@ -442,7 +469,7 @@ static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   }
   p.nphase_flat = (g_glds_phase_flat && nphase > 1) ? nphase : 0;
   dim3 grid(p.tiles_m * p.tiles_n * (p.nphase_flat ? nphase : 1), 1, p.nphase_flat ? 1 : nphase);
-  hipLaunchKernelGGL((conv_igemm_glds_kernel<BM, NWM, NSTAGE>), grid, dim3(NWM * 128), SM_BYTES, st, p, g_zero_page);
+  hipLaunchKernelGGL((conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT>), grid, dim3(NWM * 128), SM_BYTES, st, p, g_zero_page);
   CSBSR_LAUNCH_CHECK("csbsr_conv_forward(glds)");
   return 0;
 }
@@ -454,6 +481,7 @@ extern "C" void csbsr_debug_set_conv_glds(int mode) {
   g_glds_phase_flat = (mode & 32) ? 0 : 1;
   g_glds_tap_group = (mode & 128) ? 0 : 1;       // bit 7: raster tap order on the strided layers (A/B timing)
   g_glds_tile2d = (mode & 64) ? 0 : 1;           // bit 6: linear pixel tiles everywhere (A/B timing)     // bit 5: phases back on grid.z (A/B timing)
+  g_glds_wide = (mode & 256) ? 0 : 1;            // bit 8: no 256-cout tile (A/B timing)
   g_conv_direct_epi = (mode & 8) ? 1 : 0;
   conv_thin_enable((mode & 16) ? 0 : 1);      // bit 4: route the 3-channel heads through the generic kernel (A/B timing)
 }
@@ -474,7 +502,11 @@ int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   // gathers); transposed / short-K layers run faster with two 128x128 workgroups per CU
   const bool big = (g_glds_mode == 2 && !k.transposed && k.Kp >= 2304 && maxM >= 256 * 256) ||
                    (g_glds_mode == 3 && maxM >= 256 * 256);     // mode 3 (A/B timing): the 256-row tile wherever it fits
+  // 256 px x 256 couts (128 flop per staged byte instead of 85) where the couts fill 256-wide tiles about as well as 128-wide ones
+  const int pad128 = (k.coutp + 127) / 128 * 128, pad256 = (k.coutp + 255) / 256 * 256;
+  const bool wide = big && g_glds_wide && k.coutp >= 256 && pad256 * 8 <= pad128 * 9 + 64;
   g_last_conv_kernel = big ? CONVK_GLDS256 : CONVK_GLDS128;
   if (!big) return launch_glds<128, 2, 2>(k, nphase, maxM, st);
+  if (wide) return launch_glds<256, 4, 2, 2>(k, nphase, maxM, st);
   return launch_glds<256, 4, 3>(k, nphase, maxM, st);
 }

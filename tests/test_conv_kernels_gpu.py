@@ -66,6 +66,8 @@ CASES = [
     (256, 128, 3, 1, 1, 1, False, 192, 192),       # 256x128 LDS-DMA tile with 2-D (16 x 16) pixel tiles
     (128, 128, 8, 4, 2, 1, False, 768, 768),       # the same strided gather on the 256x128 tile (> 65536 output pixels)
     (768, 128, 3, 1, 1, 1, False, 24, 24),         # 6912 wgrad columns: the 128 x 256 eight-wave wgrad tile
+    (256, 256, 3, 1, 1, 1, False, 192, 192),       # 256 px x 256 cout LDS-DMA tile (two staged epilogue passes), 2-D pixel tiles
+    (264, 505, 3, 1, 1, 1, False, 190, 194),       # the same with a partly empty second cout tile, ragged pixel tiles, K padding
 ]
 
 
