@@ -230,14 +230,14 @@ class KBPN:
 
     # ------------------------------------------------------------------ backward
     def _act_bwd(self, conv, dout, out, res=None, res2=None, res_mode=L.RES_NONE, dres=None, dres_acc=False, dres2=None,
-                 dres2_acc=False):
-        """in-place dOut -> dPre for a fused conv epilogue; accumulates bias / PReLU-slope grads."""
+                 dres2_acc=False, dpre=None):
+        """dOut -> dPre for a fused conv epilogue (in place unless ``dpre`` is given); accumulates bias / PReLU-slope grads."""
         fz = conv.frozen
         self.eng.epilogue_bwd(dout, out=out, act=conv.act, slope=conv.slope, prelu=conv.prelu, res=res, res2=res2, res_mode=res_mode,
-                              dpre=dout, dres=dres, dres_acc=dres_acc, dres2=dres2, dres2_acc=dres2_acc,
+                              dpre=dout if dpre is None else dpre, dres=dres, dres_acc=dres_acc, dres2=dres2, dres2_acc=dres2_acc,
                               dbias=None if (conv.b is None or fz) else grad_acc(conv.b),
                               dprelu=None if (conv.prelu is None or fz) else grad_acc(conv.prelu), creal=conv.cout)
-        return dout
+        return dout if dpre is None else dpre
 
     def _wg(self, conv, dpre, x):
         if not conv.frozen:
@@ -302,11 +302,15 @@ class KBPN:
             # ---- KBlock backward
             hs = concat_h.slice(128 * (s - 1), 128 * s)
             dhs = dch.slice(128 * (s - 1), 128 * s)
-            dh = e.new(B, H, W, 128)
-            self._act_bwd(st.kb_up, dhs, hs, res=q["h"], res_mode=L.RES_ADD, dres=dh)
-            self._wg(st.kb_up, dhs, q["err16"])
+            # out = act(pre) + h: the gradient wrt h IS dOut, so dPre goes to a fresh buffer and dOut's own storage (this stage's slice of
+            # dch, dead after this block) carries on as dh -- one HR write stream less than copying it out (same below for up3 / h0)
+            dpk = e.new(B, H, W, 128)
+            self._act_bwd(st.kb_up, dhs, hs, res=q["h"], res_mode=L.RES_ADD, dpre=dpk)
+            dh = dhs
+            self._wg(st.kb_up, dpk, q["err16"])
             derr = e.f32(B, 3, h, w, zero=False)
-            st.kb_up.bwd_input(dhs, out32=derr, in_hw=(h, w))
+            st.kb_up.bwd_input(dpk, out32=derr, in_hw=(h, w))
+            del dpk
             dsr_t = e.f32(B, 3, H, W, zero=False)
             vec = q["vec"].contiguous()
             L.call("csbsr_blur_bwd_input", _ptr(derr), _ptr(vec), _ptr(dsr_t), 0, B, 3, H, W, self.K, self.scale, e.stream)
@@ -331,11 +335,12 @@ class KBPN:
                 st.sr_reconst.bwd_input(dpre, seg=0, out=dh, accumulate=True)
             del dpre, dsr_t, derr
             # ---- UpBlock backward
-            dh0 = e.new(B, H, W, 128)
-            self._act_bwd(st.up3, dh, q["h"], res=q["h0"], res_mode=L.RES_ADD, dres=dh0)
-            self._wg(st.up3, dh, q["d"])
-            dd_ = st.up3.bwd_input(dh, in_hw=(h, w))
-            del dh
+            dpu = e.new(B, H, W, 128)
+            self._act_bwd(st.up3, dh, q["h"], res=q["h0"], res_mode=L.RES_ADD, dpre=dpu)
+            dh0 = dh
+            self._wg(st.up3, dpu, q["d"])
+            dd_ = st.up3.bwd_input(dpu, in_hw=(h, w))
+            del dh, dpu
             dxu = e.new(B, h, w, 128)
             self._act_bwd(st.up2, dd_, q["d"], res=q["xu"], res_mode=L.RES_SUB, dres=dxu)
             self._wg(st.up2, dd_, q["h0"])
