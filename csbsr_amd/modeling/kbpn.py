@@ -250,12 +250,12 @@ class KBPN:
         B, h, w = sv["B"], sv["h"], sv["w"]
         H, W = h * self.scale, w * self.scale
         concat_h, concat_l = sv["concat_h"], sv["concat_l"]
-        dch = e.new(B, H, W, 128 * self.S, zero=True)
+        dch = e.new(B, H, W, 128 * self.S, zero=False)      # first written (every channel, every pixel) by output_conv's dgrad below
         dcl = e.new(B, h, w, 128 * (self.S - 1), zero=True) if self.S > 1 else None
         # output conv
         dpre = e.nchw32_to_fm(dsr32)
         self._wg(self.output_conv, dpre, concat_h)
-        self.output_conv.bwd_input(dpre, out=dch, accumulate=True)
+        self.output_conv.bwd_input(dpre, out=dch, accumulate=False)     # no 13 GB zero fill + read-back at micro-batch 4
         del dpre
         dvec_next = dkvec_final.clone()     # gradient wrt the normalised kernel vector leaving stage s
         dlowp = None
