@@ -174,7 +174,7 @@ def main():
         # every launch with the kernel it dispatched to).  achieved = algorithmic FLOPs of those launches / their HIP-event time.
         names = {0: "conv_igemm_kernel<32,4,1>", 1: "conv_igemm_kernel<64,2,2>", 2: "conv_igemm_kernel<128,2,2>",
                  3: "conv_igemm_glds_kernel<128,2,2>", 4: "conv_igemm_glds_kernel<256,4,3>", 5: "conv_thin_cout_kernel",
-                 6: "conv_thin_cin_kernel"}
+                 6: "conv_thin_cin_kernel", 7: "conv_igemm_glds_kernel<256,4,2,2>"}
         per = {}
         for t in eng.timing:
             key = names.get(t[7], "conv?") if t[0] == "conv" else "conv_wgrad_kernel (all variants)"

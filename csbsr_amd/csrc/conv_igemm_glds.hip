@@ -505,7 +505,7 @@ int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   // 256 px x 256 couts (128 flop per staged byte instead of 85) where the couts fill 256-wide tiles about as well as 128-wide ones
   const int pad128 = (k.coutp + 127) / 128 * 128, pad256 = (k.coutp + 255) / 256 * 256;
   const bool wide = big && g_glds_wide && k.coutp >= 256 && pad256 * 8 <= pad128 * 9 + 64;
-  g_last_conv_kernel = big ? CONVK_GLDS256 : CONVK_GLDS128;
+  g_last_conv_kernel = big ? (wide ? CONVK_GLDS256W : CONVK_GLDS256) : CONVK_GLDS128;
   if (!big) return launch_glds<128, 2, 2>(k, nphase, maxM, st);
   if (wide) return launch_glds<256, 4, 2, 2>(k, nphase, maxM, st);
   return launch_glds<256, 4, 3>(k, nphase, maxM, st);

@@ -23,6 +23,10 @@ TAG = sys.argv[2] if len(sys.argv) > 2 else "r01"
 
 def canon(name):
     """kernel name as bench.py prints it"""
+    m = re.search(r"conv_igemm_glds_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name) or re.search(r"conv_igemm_glds_kernel<(\d+), (\d+), (\d+), (\d+)>", name)
+    if m:      # <BM, wave rows, stages, cout tiles>: the single-cout-tile variants keep their three-parameter name
+        g = m.groups()
+        return "conv_igemm_glds_kernel<%s,%s,%s>" % g[:3] if g[3] == "1" else "conv_igemm_glds_kernel<%s,%s,%s,%s>" % g
     m = re.search(r"conv_igemm_glds_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name) or re.search(r"conv_igemm_glds_kernel<(\d+), (\d+), (\d+)>", name)
     if m:
         return "conv_igemm_glds_kernel<%s,%s,%s>" % m.groups()
