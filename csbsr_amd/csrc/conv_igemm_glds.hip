@@ -349,7 +349,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   for (int e = 0; e < 8; ++e) { bias[e] = sBias[lcol + e]; ssum[e] = ssq[e] = 0.f; }
   int cur_n = -1;
   if (fe.ok) {
-    constexpr int RPT = BM / RSTEP, EG = CT == 2 ? 2 : 4;
+    constexpr int RPT = BM / RSTEP, EG = CT == 2 ? 2 : 8;
     static_assert(RPT % EG == 0, "rows per thread must split into groups");
     auto rows = [&](auto EXTRA, auto BNSTAT) {       // EXTRA: a residual and / or the old output is combined in
 #pragma unroll 1
