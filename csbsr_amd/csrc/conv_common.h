@@ -27,7 +27,6 @@ struct ConvK {
   int tap_group;             // 1: strided layer, taps issued residue class by residue class (glds kernel, see issue())
   int tile2d;                // 1: 16-wide 2-D pixel tiles (glds kernel, see there)
   int nphase_flat;           // > 1: 1-D grid with the transposed conv's output phase as the fastest index (glds kernel)
-  int direct_epi;            // 1: register-direct epilogue when no statistics are requested
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0): between the epilogue passes that
@@ -234,7 +233,6 @@ __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const 
   }
 }
 
-extern int g_conv_direct_epi;
 // which kernel the last csbsr_conv_forward call of this thread dispatched to (csbsr_debug_last_conv_kernel): lets the host-side
 // timing attribute each launch to a kernel name, so bench.py's roofline block is about ONE kernel, the one rocprof lists
 enum { CONVK_IGEMM32 = 0, CONVK_IGEMM64, CONVK_IGEMM128, CONVK_GLDS128, CONVK_GLDS256, CONVK_THIN_COUT, CONVK_THIN_CIN, CONVK_GLDS256W };

@@ -264,16 +264,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
 
   // ---- epilogue: fp32 tile -> LDS [pixel][cout] in halves of HB couts (keeps LDS <= the main-loop footprint so three
   // workgroups fit per CU), then channel-contiguous 8-wide processing
-  if (p.stat_mode == CSBSR_STAT_NONE && p.direct_epi) {       // register-direct epilogue (conv_common.h)
-#pragma unroll
-    for (int b = 0; b < TP; ++b) {
-      const int row = wp * PW + b * 32 + (lane & 31);
-      const int n = sRow[row * 3], oy = py + sRow[row * 3 + 1] * o_step, ox = px + sRow[row * 3 + 2] * o_step;
-#pragma unroll
-      for (int a = 0; a < TC; ++a) conv_epilogue_direct_tile(p, acc[a][b], cout0 + wc * CW + a * 32, slope, n, oy, ox);
-    }
-    return;
-  }
   float* sO = reinterpret_cast<float*>(smem);
   const int n_first = sRow[0];
   int n_last = n_first;
@@ -457,7 +447,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   CSBSR_CHECK(d->res_mode != CSBSR_RES_FMA || d->res2, "conv: FMA needs res2");
   k.accumulate = d->accumulate; k.stat_mode = d->stat_mode; k.stat = d->stat;
   k.out_scale = d->out_scale;
-  k.direct_epi = g_conv_direct_epi; k.tile2d = 0; k.nphase_flat = 0; k.tap_group = 0;
+  k.tile2d = 0; k.nphase_flat = 0; k.tap_group = 0;
   CSBSR_CHECK(d->stat_mode == CSBSR_STAT_NONE || d->stat, "conv: stat_mode set without stat buffer");
   int nphase = 1;
   long maxM;

@@ -292,16 +292,6 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   TS(4);
   __syncthreads();
 
-  if (p.stat_mode == CSBSR_STAT_NONE && p.direct_epi) {       // register-direct epilogue
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int row = wm * 64 + b * 32 + (lane & 31);
-      const int n = sRow[row * 3], oy = py + sRow[row * 3 + 1] * o_step, ox = px + sRow[row * 3 + 2] * o_step;
-#pragma unroll
-      for (int a = 0; a < TA; ++a) conv_epilogue_direct_tile(p, acc[a][b], cout0 + wn * (32 * TA) + a * 32, slope, n, oy, ox);
-    }
-    return;
-  }
   // ---- epilogue staged through LDS in ONE pass: the whole BM x 128 fp32 tile goes into the (now dead) DMA ring -- unpadded rows
   // of 32 16-byte slots with slot' = slot ^ (row & 15) instead of padding, so it fits exactly (64 KB for BM = 128) -- all waves
   // stage at once, one LDS-only barrier, then every thread owns one 8-channel chunk of BM/RSTEP rows.  (Two 64-cout passes with
@@ -475,14 +465,12 @@ static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
 }
 
 static int g_glds_mode = 2;      // 0: off, 1: 128x128 x2 stages only, 2: + 256x128 x3 stages for long-K stride-1 layers
-int g_conv_direct_epi = 0;      // measured: 32-byte store segments lose to the LDS-staged 128-byte ones on the tile kernels
 extern "C" void csbsr_debug_set_conv_glds(int mode) {
   g_glds_mode = mode & 7;
   g_glds_phase_flat = (mode & 32) ? 0 : 1;
   g_glds_tap_group = (mode & 128) ? 0 : 1;       // bit 7: raster tap order on the strided layers (A/B timing)
   g_glds_tile2d = (mode & 64) ? 0 : 1;           // bit 6: linear pixel tiles everywhere (A/B timing)     // bit 5: phases back on grid.z (A/B timing)
   g_glds_wide = (mode & 256) ? 0 : 1;            // bit 8: no 256-cout tile (A/B timing)
-  g_conv_direct_epi = (mode & 8) ? 1 : 0;
   conv_thin_enable((mode & 16) ? 0 : 1);      // bit 4: route the 3-channel heads through the generic kernel (A/B timing)
 }
 

@@ -110,7 +110,7 @@ int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s);
  *   wgrad: bit0 hardware transpose reads (0 = scalar LDS transposition), 2 no thin kernel, 4 no XCD tap order, 8 no flat grid,
  *          16 flat grid everywhere, 32 no row shift, 64 no 128x256 tile, bits 8.. extra dynamic LDS in KiB (occupancy experiments)
  *   conv:  low 3 bits 0 = register-staged kernel only, 1 = 128x128 LDS-DMA tile only, 2 = default, 3 = 256x128 wherever it fits;
- *          8 register-direct epilogue, 16 no thin kernels, 32 phases on grid.z, 64 linear pixel tiles, 128 raster tap order */
+ *          16 no thin kernels, 32 phases on grid.z, 64 linear pixel tiles, 128 raster tap order */
 void csbsr_debug_set_wgrad_tr(int flags);
 void csbsr_debug_set_conv_glds(int mode);
 
