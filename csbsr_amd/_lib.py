@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ("bias", vp), ("cbias", vp), ("act", i32), ("act_slope", f32), ("prelu", vp),
                 ("res_mode", i32), ("res", vp), ("r_sn", i64), ("r_sy", i64), ("r_sx", i64),
                 ("res2", vp), ("r2_sn", i64), ("r2_sy", i64), ("r2_sx", i64),
-                ("accumulate", i32), ("stat_mode", i32), ("stat", vp), ("out_scale", f32)]
+                ("accumulate", i32), ("stat_mode", i32), ("stat", vp), ("out_scale", f32),
+                ("o_lo", i64), ("r_lo", i64), ("r2_lo", i64)]
 
 
 class WgradDesc(C.Structure):
@@ -57,7 +58,7 @@ class BnDesc(C.Structure):
                 ("res", vp), ("res_ld", i64), ("act", i32), ("_pad", i32), ("prelu", vp), ("drop", vp),
                 ("y", vp), ("y_ld", i64), ("dy", vp), ("dy_ld", i64), ("red", vp), ("dprelu", vp),
                 ("dx", vp), ("dx_ld", i64), ("dres", vp), ("dres_ld", i64), ("dres_accumulate", i32), ("_pad1", i32),
-                ("dgamma", vp), ("dbeta", vp)]
+                ("dgamma", vp), ("dbeta", vp), ("x_lo", i64), ("res_lo", i64), ("y_lo", i64)]
 
 
 # name -> (restype, argtypes): every symbol include/csbsr_hip.h declares
@@ -66,12 +67,17 @@ SIGNATURES = {
     "csbsr_last_error": (C.c_char_p, []),
     "csbsr_conv_forward": (i32, [C.POINTER(ConvDesc), vp]),
     "csbsr_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp]),
-    "csbsr_debug_set_wgrad_tr": (None, [i32]),
-    "csbsr_debug_set_conv_glds": (None, [i32]),
     "csbsr_packed_weight_elems": (i64, [i32] * 9),
     "csbsr_pack_weights": (i32, [vp, vp] + [i32] * 12 + [vp]),
+    "csbsr_packed_weight_elems_split": (i64, [i32] * 8),
+    "csbsr_pack_weights_split": (i32, [vp, vp] + [i32] * 11 + [f32, vp]),
+    "csbsr_axpby_split": (i32, [i64, i32, vp, i64, i64, f32, vp, i64, i64, f32, vp, i64, i64, vp]),
+    "csbsr_nchw32_to_nhwc16_split": (i32, [vp, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp]),
+    "csbsr_maxpool3x3s2_fwd_split": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
+    "csbsr_maxpool3x3s2_bwd_split": (i32, [vp, i64, i64, vp, i64, i64, vp, vp, i32, i32, i32, i32, vp]),
+    "csbsr_adaptive_avgpool_fwd_split": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "csbsr_bilinear_fwd_split": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "csbsr_unpack_wgrad": (i32, [vp, vp] + [i32] * 9 + [f32, i32, i32, vp]),
-    "csbsr_debug_last_conv_kernel": (i32, []),
     "csbsr_wgrad_splits": (i32, [i32, i32, i64]),
     "csbsr_wgrad_splits_desc": (i32, [vp]),
     "csbsr_epilogue_backward": (i32, [C.POINTER(EpiBwdDesc), vp]),
@@ -111,6 +117,13 @@ SIGNATURES = {
     "csbsr_sigmoid_bwd_to_nhwc8": (i32, [vp, vp, vp, i64, f32, vp]),
 }
 
+# private hooks (csbsr_amd/csrc/csbsr_debug.h): kernel selection for A/B timing and kernel attribution for bench.py
+DEBUG_SIGNATURES = {
+    "csbsr_debug_set_wgrad_tr": (None, [i32]),
+    "csbsr_debug_set_conv_glds": (None, [i32]),
+    "csbsr_debug_last_conv_kernel": (i32, []),
+}
+
 _lib = None
 
 
@@ -127,9 +140,10 @@ def load():
         raise CsbsrHipError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             f"(or `make -C csbsr_amd/csrc`).  csbsr_amd has no fallback path.")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
-        fn.restype, fn.argtypes = res, args
+    for table in (SIGNATURES, DEBUG_SIGNATURES):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
     _lib = lib
     if os.environ.get("CSBSR_WGRAD_DBG"):          # A/B hook: bit0 transpose reads, 2 no thin, 4 no tap order, 8 no flat grid, 16 flat everywhere
         lib.csbsr_debug_set_wgrad_tr(int(os.environ["CSBSR_WGRAD_DBG"]))

@@ -56,8 +56,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // resolved at the memory side on this part (~190 ns each, serialised per address: 1500 workgroups x 128 channels of bias-gradient
 // atomics cost 290 us on top of a 36 us streaming pass), so the reducing kernels write per-workgroup partial rows here and
 // csbsr_sum_partials folds them; without a registered scratch they fall back to atomics.
-extern float* g_red_scratch;
-extern long g_red_scratch_elems;
+#define CSBSR_MAX_DEVICES 16
+float* csbsr_red_scratch(long need_elems);   // the current device's registered scratch if it holds need_elems floats, else nullptr
 int csbsr_sum_partials(const float* part, int nblk, long ld, int count, float* dst, hipStream_t st);   // dst[j] += sum_b part[b*ld+j]
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -27,7 +27,19 @@ struct ConvK {
   int tap_group;             // 1: strided layer, taps issued residue class by residue class (glds kernel, see issue())
   int tile2d;                // 1: 16-wide 2-D pixel tiles (glds kernel, see there)
   int nphase_flat;           // > 1: 1-D grid with the transposed conv's output phase as the fastest index (glds kernel)
+  // split-fp16 ("hi + lo") operands of the detector precision mode: element offset from a tensor's hi plane to its lo plane
+  // (value = hi + lo, both fp16, same strides); 0 = plain fp16
+  long o_lo, r_lo, r2_lo;
 };
+
+// value -> (hi, lo) fp16 pair with hi + lo == value to ~2^-22 relative (lo is exact down to fp16's subnormal spacing, 6e-8)
+__device__ __forceinline__ void split_store(half_t* o, long lo_off, const float (&v)[8]) {
+  h8 hv, lv;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { hv[e] = (half_t)v[e]; lv[e] = (half_t)(v[e] - (float)hv[e]); }
+  *reinterpret_cast<h8*>(o) = hv;
+  if (lo_off) *reinterpret_cast<h8*>(o + lo_off) = lv;
+}
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0): between the epilogue passes that
 // means sitting out the write acknowledgement of the previous pass's global stores (~2 us per workgroup on a 16 us tile).
@@ -81,18 +93,23 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
     for (int e = 0; e < 8; ++e) ssum[e] += v[e];
   }
   if (p.res_mode != CSBSR_RES_NONE) {
-    const h8 r = pre ? pre->r : *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
-    h8 r2 = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (p.res_mode == CSBSR_RES_FMA)
-      r2 = *reinterpret_cast<const h8*>(p.res2 + n * p.r2_sn + oy * p.r2_sy + ox * p.r2_sx + co);
+    const half_t* rp = p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co;
+    const h8 r = pre ? pre->r : *reinterpret_cast<const h8*>(rp);
+    h8 r2 = {0, 0, 0, 0, 0, 0, 0, 0}, rl = {0, 0, 0, 0, 0, 0, 0, 0}, r2l = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p.r_lo) rl = *reinterpret_cast<const h8*>(rp + p.r_lo);
+    if (p.res_mode == CSBSR_RES_FMA) {
+      const half_t* r2p = p.res2 + n * p.r2_sn + oy * p.r2_sy + ox * p.r2_sx + co;
+      r2 = *reinterpret_cast<const h8*>(r2p);
+      if (p.r2_lo) r2l = *reinterpret_cast<const h8*>(r2p + p.r2_lo);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float rv = (float)r[e];
+      const float rv = (float)r[e] + (float)rl[e];
       switch (p.res_mode) {
         case CSBSR_RES_ADD: v[e] += rv; break;
         case CSBSR_RES_SUB: v[e] -= rv; break;
         case CSBSR_RES_MUL: v[e] *= rv; break;
-        default: v[e] += rv * (float)r2[e]; break;
+        default: v[e] += rv * ((float)r2[e] + (float)r2l[e]); break;
       }
     }
   }
@@ -103,10 +120,7 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
     }
-    h8 hv;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-    *reinterpret_cast<h8*>(o) = hv;
+    split_store(o, p.o_lo, v);
   }
   if (p.out32) {
     float* o = p.out32 + n * p.o32_sn + oy * p.o32_sy + ox * p.o32_sx;
@@ -124,12 +138,13 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
 // max(t, t*sneg), sneg <= 1), residual add or subtract, optional accumulate, optional BatchNorm sums: the mode switches of
 // conv_epilogue_row become two multipliers picked once per kernel.  The general row re-tests every mode per element (~100 scalar
 // branches per row): its 8 rows took 7.7 us of an 18 us transposed-conv workgroup whose 8 K slices take 5.9 us (CSBSR_TS build).
-struct EpiFast { bool ok, has_res, has_old, bn, masked; float sneg, rsign, osc; int cout; };
+struct EpiFast { bool ok, has_res, has_old, bn, masked; float sneg, rsign, osc; int cout; long o_lo; };
 __device__ __forceinline__ EpiFast conv_epilogue_fast_setup(const ConvK& p, float slope) {
   EpiFast f;
   f.ok = (p.stat_mode == CSBSR_STAT_NONE || p.stat_mode == CSBSR_STAT_BN) && !p.cbias && !p.out32 && p.out16 &&
          p.act != CSBSR_ACT_SIGMOID && !(p.act != CSBSR_ACT_NONE && p.act != CSBSR_ACT_RELU && slope > 1.f) &&
-         (p.res_mode == CSBSR_RES_NONE || p.res_mode == CSBSR_RES_ADD || p.res_mode == CSBSR_RES_SUB);
+         (p.res_mode == CSBSR_RES_NONE || p.res_mode == CSBSR_RES_ADD || p.res_mode == CSBSR_RES_SUB) && !p.r_lo;
+  f.o_lo = p.o_lo;
   f.sneg = p.act == CSBSR_ACT_NONE ? 1.f : (p.act == CSBSR_ACT_RELU ? 0.f : slope);
   f.rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
   f.has_res = p.res_mode != CSBSR_RES_NONE; f.has_old = p.accumulate != 0; f.bn = p.stat_mode == CSBSR_STAT_BN;
@@ -151,7 +166,6 @@ __device__ __forceinline__ void conv_epilogue_fast_row(const EpiFast& f, const f
 #pragma unroll
     for (int e = 0; e < 8; ++e) t[e] = (co + e < f.cout) ? t[e] : 0.f;
   }
-  h8 hv;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     if constexpr (BNSTAT) { ssum[e] += t[e]; ssq[e] += t[e] * t[e]; }
@@ -159,9 +173,8 @@ __device__ __forceinline__ void conv_epilogue_fast_row(const EpiFast& f, const f
       t[e] += f.rsign * (float)rr[e];
       t[e] += (float)oo[e];
     }
-    hv[e] = (half_t)t[e];
   }
-  *reinterpret_cast<h8*>(o) = hv;
+  split_store(o, f.o_lo, t);
 }
 
 // per-thread partial statistics -> LDS bins (uniform sample per tile) or straight to global (tile straddles samples)

@@ -15,6 +15,7 @@
 // Reference call sites this stands in for: F.conv2d / F.conv_transpose2d in
 // /root/reference/model/modeling/kbpn.py:241,273-277,513-517 and pspnet_pytorch/{extractors.py:36-38,pspnet.py:30-86}.
 #include "common.h"
+#include "csbsr_debug.h"
 #include "conv_common.h"
 #include <type_traits>
 
@@ -447,6 +448,9 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   CSBSR_CHECK(d->res_mode != CSBSR_RES_FMA || d->res2, "conv: FMA needs res2");
   k.accumulate = d->accumulate; k.stat_mode = d->stat_mode; k.stat = d->stat;
   k.out_scale = d->out_scale;
+  k.o_lo = d->o_lo; k.r_lo = d->r_lo; k.r2_lo = d->r2_lo;
+  CSBSR_CHECK(!(d->o_lo && d->accumulate), "conv: a split (hi + lo) output cannot accumulate");
+  CSBSR_CHECK(!d->o_lo || d->out16, "conv: o_lo without out16");
   k.tile2d = 0; k.nphase_flat = 0; k.tap_group = 0;
   CSBSR_CHECK(d->stat_mode == CSBSR_STAT_NONE || d->stat, "conv: stat_mode set without stat buffer");
   int nphase = 1;
@@ -458,8 +462,9 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
     maxM = (long)d->N * d->OH * d->OW;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  if (conv_thin_eligible(k)) { g_last_conv_kernel = CONVK_THIN_COUT; return conv_thin_launch(k, st); }
-  if (d->in[1].c == 0 && conv_thin_cin_eligible(k, d->in[0].creal)) {
+  const bool split_io = d->o_lo || d->r_lo || d->r2_lo;     // the thin kernels have their own epilogues: plain fp16 only
+  if (!split_io && conv_thin_eligible(k)) { g_last_conv_kernel = CONVK_THIN_COUT; return conv_thin_launch(k, st); }
+  if (!split_io && d->in[1].c == 0 && conv_thin_cin_eligible(k, d->in[0].creal)) {
     g_last_conv_kernel = CONVK_THIN_CIN;
     return conv_thin_cin_launch(k, d->in[0].creal, st);
   }

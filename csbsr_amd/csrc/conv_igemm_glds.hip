@@ -11,6 +11,7 @@
 //    128x128, two workgroups per CU), counted s_waitcnt vmcnt(N) + raw s_barrier so DMAs stay in flight across barriers;
 //  * halo / padding / tile-overhang lanes fetch from a 256-byte zero page instead of branching.
 #include "common.h"
+#include "csbsr_debug.h"
 #include "conv_common.h"
 #include <type_traits>
 

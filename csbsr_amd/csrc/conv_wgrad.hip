@@ -8,6 +8,7 @@
 //
 // Autograd wgrad of F.conv2d / F.conv_transpose2d at the call sites listed in conv_igemm.hip.
 #include "common.h"
+#include "csbsr_debug.h"
 
 #define WG_BP 64     // pixels per reduction step
 #define WG_BN 128    // columns (tap,channel) per tile

@@ -1,0 +1,23 @@
+/* Private measurement / A-B hooks of libcsbsr_hip.so -- NOT part of the drop-in C ABI (include/csbsr_hip.h).  They select between
+ * kernels that produce identical results, or report which kernel ran; bench.py, scripts/ and the kernel tests bind them through
+ * csbsr_amd._lib.DEBUG_SIGNATURES. */
+#ifndef CSBSR_DEBUG_H
+#define CSBSR_DEBUG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* kernel the calling thread's last csbsr_conv_forward dispatched to -- 0/1/2 conv_igemm_kernel<32|64|128,..>, 3/4/7
+ * conv_igemm_glds_kernel<128,2,2 | 256,4,3 | 256,4,2,2>, 5 conv_thin_cout_kernel, 6 conv_thin_cin_kernel (bench.py's roofline block) */
+int32_t csbsr_debug_last_conv_kernel(void);
+/* kernel selection only, results are identical:
+ *   wgrad: bit0 hardware transpose reads (0 = scalar LDS transposition), 2 no thin kernel, 4 no XCD tap order, 8 no flat grid,
+ *          16 flat grid everywhere, 32 no row shift, 64 no 128x256 tile, bits 8.. extra dynamic LDS in KiB (occupancy experiments)
+ *   conv:  low 3 bits 0 = register-staged kernel only, 1 = 128x128 LDS-DMA tile only, 2 = default, 3 = 256x128 wherever it fits;
+ *          16 no thin kernels, 32 phases on grid.z, 64 linear pixel tiles, 128 raster tap order, 256 no 256-cout tile */
+void csbsr_debug_set_wgrad_tr(int flags);
+void csbsr_debug_set_conv_glds(int mode);
+#ifdef __cplusplus
+}
+#endif
+#endif

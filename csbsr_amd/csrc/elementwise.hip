@@ -10,13 +10,42 @@ static inline int grid_for(long work, int block = 256, int cap = 8192) {
 }
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
+// split-fp16 ("hi + lo") views of the detector precision mode: lo = element offset from the hi plane to the lo plane (0: plain fp16)
+__device__ __forceinline__ void ld_split(const half_t* p, long lo, float (&v)[8]) {
+  const h8 a = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+  if (lo) {
+    const h8 b = *reinterpret_cast<const h8*>(p + lo);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (float)b[e];
+  }
+}
+__device__ __forceinline__ void st_split(half_t* p, long lo, const float (&v)[8]) {
+  h8 a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = (half_t)v[e]; b[e] = (half_t)(v[e] - (float)a[e]); }
+  *reinterpret_cast<h8*>(p) = a;
+  if (lo) *reinterpret_cast<h8*>(p + lo) = b;
+}
+
 // ------------------------------------------------------------------------------------------- two-stage reductions
-float* g_red_scratch = nullptr;
-long g_red_scratch_elems = 0;
+// One registration per DEVICE (keyed on the calling thread's current HIP device, which is also the device every launch below goes to):
+// two models in one process -- a trainer and an evaluator, or replicas on several GPUs -- share their device's buffer instead of the
+// last registration silently winning.  The host keeps each buffer alive for the life of the process (csbsr_amd/engine.py).
+static float* g_red_buf[CSBSR_MAX_DEVICES] = {};
+static long g_red_elems[CSBSR_MAX_DEVICES] = {};
 extern "C" int csbsr_set_reduction_scratch(float* buf, int64_t elems) {
-  g_red_scratch = buf;
-  g_red_scratch_elems = buf ? (long)elems : 0;
+  int dev = 0;
+  CSBSR_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CSBSR_MAX_DEVICES, "set_reduction_scratch: no current device");
+  g_red_buf[dev] = buf;
+  g_red_elems[dev] = buf ? (long)elems : 0;
   return 0;
+}
+float* csbsr_red_scratch(long need_elems) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CSBSR_MAX_DEVICES) return nullptr;
+  return (g_red_buf[dev] && need_elems <= g_red_elems[dev]) ? g_red_buf[dev] : nullptr;
 }
 // dst[j] += sum over the nblk partial rows; block = 32 columns x 8 row slices over a chunk of up to 1024 rows (grid.y chunks, one
 // atomic per column per chunk -- a handful per address)
@@ -178,7 +207,7 @@ extern "C" int csbsr_epilogue_backward(const csbsr_epi_bwd_desc_t* d, csbsr_stre
   const int ppb = 256 / cpb;
   int blocks = grid_for(d->npix, ppb * 8, 2048);
   k.part = nullptr; k.part_ld = d->c + 8;
-  if ((k.dbias || k.dprelu) && g_red_scratch && (long)blocks * k.part_ld <= g_red_scratch_elems) k.part = g_red_scratch;
+  if (k.dbias || k.dprelu) k.part = csbsr_red_scratch((long)blocks * k.part_ld);
   hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(blocks), dim3(256), 0, ST(s), k);
   if (k.part) {
     if (k.dbias) csbsr_sum_partials(k.part, blocks, k.part_ld, d->creal, k.dbias, ST(s));
@@ -189,27 +218,36 @@ extern "C" int csbsr_epilogue_backward(const csbsr_epi_bwd_desc_t* d, csbsr_stre
 }
 
 // ------------------------------------------------------------------------------------------- axpby / fill / casts
-__global__ void axpby_kernel(long npix, int c8, const half_t* x, long x_ld, float a, const half_t* z, long z_ld, float b,
-                             half_t* y, long y_ld) {
+__global__ void axpby_kernel(long npix, int c8, const half_t* x, long x_ld, long x_lo, float a, const half_t* z, long z_ld, long z_lo,
+                             float b, half_t* y, long y_ld, long y_lo) {
   const long total = npix * c8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long px = i / c8; const int c0 = (int)(i % c8) * 8;
-    const h8 xv = *reinterpret_cast<const h8*>(x + px * x_ld + c0);
-    h8 zv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (z) zv = *reinterpret_cast<const h8*>(z + px * z_ld + c0);
-    h8 o;
+    float xv[8], zv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o[8];
+    ld_split(x + px * x_ld + c0, x_lo, xv);
+    if (z) ld_split(z + px * z_ld + c0, z_lo, zv);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)(a * (float)xv[e] + b * (float)zv[e]);
-    *reinterpret_cast<h8*>(y + px * y_ld + c0) = o;
+    for (int e = 0; e < 8; ++e) o[e] = a * xv[e] + b * zv[e];
+    if (y_lo) st_split(y + px * y_ld + c0, y_lo, o);
+    else {
+      h8 h;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h[e] = (half_t)o[e];
+      *reinterpret_cast<h8*>(y + px * y_ld + c0) = h;
+    }
   }
+}
+extern "C" int csbsr_axpby_split(int64_t npix, int32_t c, const void* x, int64_t x_ld, int64_t x_lo, float a, const void* z, int64_t z_ld,
+                                 int64_t z_lo, float b, void* y, int64_t y_ld, int64_t y_lo, csbsr_stream_t s) {
+  CSBSR_CHECK(c % 8 == 0 && x && y, "axpby: bad args");
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(npix * (c / 8))), dim3(256), 0, ST(s), npix, c / 8, (const half_t*)x, x_ld, x_lo,
+                     a, (const half_t*)z, z_ld, z_lo, b, (half_t*)y, y_ld, y_lo);
+  CSBSR_LAUNCH_CHECK("csbsr_axpby");
+  return 0;
 }
 extern "C" int csbsr_axpby(int64_t npix, int32_t c, const void* x, int64_t x_ld, float a, const void* z, int64_t z_ld,
                            float b, void* y, int64_t y_ld, csbsr_stream_t s) {
-  CSBSR_CHECK(c % 8 == 0 && x && y, "axpby: bad args");
-  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(npix * (c / 8))), dim3(256), 0, ST(s), npix, c / 8, (const half_t*)x, x_ld,
-                     a, (const half_t*)z, z_ld, b, (half_t*)y, y_ld);
-  CSBSR_LAUNCH_CHECK("csbsr_axpby");
-  return 0;
+  return csbsr_axpby_split(npix, c, x, x_ld, 0, a, z, z_ld, 0, b, y, y_ld, 0, s);
 }
 // y = act(sum_{i<n} x_i): the n-ary fuse sum of an HRNet module (hrnet_backbone.py:276-296), one pass
 struct SumK { const half_t* x[4]; long ld[4]; int n; };
@@ -316,13 +354,13 @@ extern "C" int csbsr_fill_f16(void* p, int64_t npix, int32_t c, int64_t ld, floa
 
 // fp32 NCHW (optionally normalised per (n,c): (x-mean)*invstd) -> fp16 NHWC, channels padded with zeros
 __global__ void nchw32_to_nhwc16_kernel(const float* src, half_t* dst, int N, int C, long hw, int cp, long d_ld,
-                                        const float* mean, const float* invstd) {
+                                        const float* mean, const float* invstd, long d_lo) {
   const int c8 = cp / 8;
   const long total = (long)N * hw * c8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cc = (int)(i % c8); const long px = i / c8;
     const long n = px / hw, r = px - n * hw;
-    h8 o;
+    float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = cc * 8 + e;
@@ -331,19 +369,23 @@ __global__ void nchw32_to_nhwc16_kernel(const float* src, half_t* dst, int N, in
         v = src[(n * C + c) * hw + r];
         if (mean) v = (v - mean[n * C + c]) * invstd[n * C + c];
       }
-      o[e] = (half_t)v;
+      o[e] = v;
     }
-    *reinterpret_cast<h8*>(dst + px * d_ld + cc * 8) = o;
+    st_split(dst + px * d_ld + cc * 8, d_lo, o);
   }
 }
-extern "C" int csbsr_nchw32_to_nhwc16(const float* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t cp,
-                                      int64_t dst_ld, const float* mean, const float* invstd, csbsr_stream_t s) {
+extern "C" int csbsr_nchw32_to_nhwc16_split(const float* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t cp,
+                                            int64_t dst_ld, int64_t dst_lo, const float* mean, const float* invstd, csbsr_stream_t s) {
   CSBSR_CHECK(src && dst && cp % 8 == 0 && cp >= C, "nchw32_to_nhwc16: bad args");
   const long hw = (long)H * W;
   hipLaunchKernelGGL(nchw32_to_nhwc16_kernel, dim3(grid_for((long)N * hw * (cp / 8))), dim3(256), 0, ST(s), src, (half_t*)dst, N,
-                     C, hw, cp, dst_ld, mean, invstd);
+                     C, hw, cp, dst_ld, mean, invstd, dst_lo);
   CSBSR_LAUNCH_CHECK("csbsr_nchw32_to_nhwc16");
   return 0;
+}
+extern "C" int csbsr_nchw32_to_nhwc16(const float* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t cp,
+                                      int64_t dst_ld, const float* mean, const float* invstd, csbsr_stream_t s) {
+  return csbsr_nchw32_to_nhwc16_split(src, dst, N, C, H, W, cp, dst_ld, 0, mean, invstd, s);
 }
 // fp16 NHWC (first C channels) -> fp32 NCHW, dst = beta*dst + alpha*src
 __global__ void nhwc16_to_nchw32_kernel(const half_t* src, long s_ld, float* dst, int N, int C, long hw, float alpha, float beta) {
@@ -488,6 +530,7 @@ struct BnK {
   const half_t* res; long res_ld;
   int act; const float* prelu; const float* drop;
   half_t* y; long y_ld;
+  long x_lo, res_lo, y_lo;          // split-fp16 planes (0: plain fp16)
   // backward
   const half_t* dy; long dy_ld;
   float* red; float* dprelu;
@@ -519,19 +562,18 @@ __global__ void bn_apply_kernel(const BnK p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) { mean[e] = p.mean[c0 + e]; sc[e] = p.invstd[c0 + e] * p.gamma[c0 + e]; be[e] = p.beta[c0 + e]; }
   for (long px = gt / p.c8; px < p.npix; px += pstep) {
-    const h8 xv = *reinterpret_cast<const h8*>(p.x + px * p.x_ld + c0);
-    h8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (p.res) rv = *reinterpret_cast<const h8*>(p.res + px * p.res_ld + c0);
+    float xv[8], rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o[8];
+    ld_split(p.x + px * p.x_ld + c0, p.x_lo, xv);
+    if (p.res) ld_split(p.res + px * p.res_ld + c0, p.res_lo, rv);
     const float* dr = p.drop ? p.drop + (long)((unsigned)px / (unsigned)p.hw) * p.cp + c0 : nullptr;
-    h8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float v = ((float)xv[e] - mean[e]) * sc[e] + be[e] + (float)rv[e];
+      float v = (xv[e] - mean[e]) * sc[e] + be[e] + rv[e];
       v = apply_act(v, p.act, slope);
       if (dr) v *= dr[e];
-      o[e] = (half_t)v;
+      o[e] = v;
     }
-    *reinterpret_cast<h8*>(p.y + px * p.y_ld + c0) = o;
+    st_split(p.y + px * p.y_ld + c0, p.y_lo, o);
   }
 }
 
@@ -570,14 +612,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnK p) {
       for (int e = 0; e < 8; ++e) { mean[e] = p.mean[c0 + e]; istd[e] = p.invstd[c0 + e]; ga[e] = p.gamma[c0 + e]; be[e] = p.beta[c0 + e]; }
       for (long px = (long)blockIdx.x * ppb + pl; px < p.npix; px += (long)gridDim.x * ppb) {
         const h8 g = *reinterpret_cast<const h8*>(p.dy + px * p.dy_ld + c0);
-        const h8 xv = *reinterpret_cast<const h8*>(p.x + px * p.x_ld + c0);
-        h8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (p.res) rv = *reinterpret_cast<const h8*>(p.res + px * p.res_ld + c0);
+        float xv[8], rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        ld_split(p.x + px * p.x_ld + c0, p.x_lo, xv);
+        if (p.res) ld_split(p.res + px * p.res_ld + c0, p.res_lo, rv);
         const float* dr = p.drop ? p.drop + (long)((unsigned)px / (unsigned)p.hw) * p.cp + c0 : nullptr;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float xh = ((float)xv[e] - mean[e]) * istd[e];
-          const float z = xh * ga[e] + be[e] + (float)rv[e];
+          const float xh = (xv[e] - mean[e]) * istd[e];
+          const float z = xh * ga[e] + be[e] + rv[e];
           float gg = (float)g[e];
           if (dr) gg *= dr[e];
           float dz = gg;
@@ -633,17 +675,17 @@ __global__ void bn_bwd_apply_kernel(const BnK p) {
   }
   for (long px = gt / p.c8; px < p.npix; px += pstep) {
     const h8 g = *reinterpret_cast<const h8*>(p.dy + px * p.dy_ld + c0);
-    const h8 xv = *reinterpret_cast<const h8*>(p.x + px * p.x_ld + c0);
-    h8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (p.res) rv = *reinterpret_cast<const h8*>(p.res + px * p.res_ld + c0);
+    float xv[8], rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    ld_split(p.x + px * p.x_ld + c0, p.x_lo, xv);
+    if (p.res) ld_split(p.res + px * p.res_ld + c0, p.res_lo, rv);
     const float* dr = p.drop ? p.drop + (long)((unsigned)px / (unsigned)p.hw) * p.cp + c0 : nullptr;
     h8 old = {0, 0, 0, 0, 0, 0, 0, 0};
     if (p.dres && p.dres_acc) old = *reinterpret_cast<const h8*>(p.dres + px * p.dres_ld + c0);
     h8 o, drs;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float xh = ((float)xv[e] - mean[e]) * istd[e];
-      const float z = xh * ga[e] + be[e] + (float)rv[e];
+      const float xh = (xv[e] - mean[e]) * istd[e];
+      const float z = xh * ga[e] + be[e] + rv[e];
       float gg = (float)g[e];
       if (dr) gg *= dr[e];
       float dz = gg;
@@ -670,6 +712,7 @@ static void fill_bnk(BnK& k, const csbsr_bn_desc_t* d) {
   k.res = (const half_t*)d->res; k.res_ld = d->res_ld;
   k.act = d->act; k.prelu = d->prelu; k.drop = d->drop;
   k.y = (half_t*)d->y; k.y_ld = d->y_ld;
+  k.x_lo = d->x_lo; k.res_lo = d->res_lo; k.y_lo = d->y_lo;
   k.dy = (const half_t*)d->dy; k.dy_ld = d->dy_ld;
   k.red = d->red; k.dprelu = d->dprelu;
   k.dx = (half_t*)d->dx; k.dx_ld = d->dx_ld;
@@ -690,7 +733,7 @@ extern "C" int csbsr_bn_backward(const csbsr_bn_desc_t* d, csbsr_stream_t s) {
   const int ppb = 256 / cpb;
   const int rblocks = grid_for(k.npix, ppb * 8, 1024);
   k.part = nullptr; k.part_ld = 2 * k.cp + 8;
-  if (g_red_scratch && (long)rblocks * k.part_ld <= g_red_scratch_elems) k.part = g_red_scratch;
+  k.part = csbsr_red_scratch((long)rblocks * k.part_ld);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rblocks), dim3(256), 0, ST(s), k);
   if (k.part) {
     csbsr_sum_partials(k.part, rblocks, k.part_ld, 2 * k.cp, k.red, ST(s));
@@ -704,7 +747,8 @@ extern "C" int csbsr_bn_backward(const csbsr_bn_desc_t* d, csbsr_stream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------- max pool 3x3 s2 p1
-__global__ void maxpool_fwd_kernel(const half_t* x, half_t* y, int N, int H, int W, int c8, int OH, int OW) {
+__global__ void maxpool_fwd_kernel(const half_t* x, half_t* y, int N, int H, int W, int c8, int OH, int OW, long x_ld, long x_lo,
+                                   long y_ld, long y_lo) {
   const long total = (long)N * OH * OW * c8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cc = (int)(i % c8); long t = i / c8;
@@ -717,26 +761,25 @@ __global__ void maxpool_fwd_kernel(const half_t* x, half_t* y, int N, int H, int
       const int iy = oy * 2 - 1 + ky; if ((unsigned)iy >= (unsigned)H) continue;
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = ox * 2 - 1 + kx; if ((unsigned)ix >= (unsigned)W) continue;
-        const h8 v = *reinterpret_cast<const h8*>(x + (((long)n * H + iy) * W + ix) * c8 * 8 + cc * 8);
+        float v[8];
+        ld_split(x + (((long)n * H + iy) * W + ix) * x_ld + cc * 8, x_lo, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
       }
     }
-    h8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)m[e];
-    *reinterpret_cast<h8*>(y + i * 8) = o;
+    st_split(y + (i / c8) * y_ld + cc * 8, y_lo, m);
   }
 }
 // gather form: dx[iy,ix] = sum over windows containing it whose argmax (first max in scan order) is (iy,ix)
 __global__ void maxpool_bwd_kernel(const half_t* x, const half_t* y, const half_t* dy, half_t* dx, int N, int H, int W, int c8,
-                                   int OH, int OW) {
+                                   int OH, int OW, long x_ld, long x_lo, long y_ld, long y_lo) {
   const long total = (long)N * H * W * c8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cc = (int)(i % c8); long t = i / c8;
     const int ix = (int)(t % W); t /= W;
     const int iy = (int)(t % H); const int n = (int)(t / H);
-    const h8 xv = *reinterpret_cast<const h8*>(x + i * 8);
+    float xv[8];
+    ld_split(x + (i / c8) * x_ld + cc * 8, x_lo, xv);
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
@@ -745,7 +788,8 @@ __global__ void maxpool_bwd_kernel(const half_t* x, const half_t* y, const half_
       for (int ox = ix / 2 > 0 ? ix / 2 - 1 : 0; ox <= (ix + 1) / 2 && ox < OW; ++ox) {
         if (ox * 2 - 1 > ix || ox * 2 + 1 < ix) continue;
         const long oi = (((long)n * OH + oy) * OW + ox) * c8 + cc;
-        const h8 yv = *reinterpret_cast<const h8*>(y + oi * 8);
+        float yv[8];
+        ld_split(y + (oi / c8) * y_ld + cc * 8, y_lo, yv);
         const h8 gv = *reinterpret_cast<const h8*>(dy + oi * 8);
         // is (iy,ix) the FIRST position in the window attaining the max?
 #pragma unroll
@@ -757,7 +801,8 @@ __global__ void maxpool_bwd_kernel(const half_t* x, const half_t* y, const half_
             for (int kx = 0; kx < 3; ++kx) {
               const int jx = ox * 2 - 1 + kx; if ((unsigned)jx >= (unsigned)W) continue;
               if (jy == iy && jx == ix) { ky = 3; break; }
-              if (x[((((long)n * H + jy) * W + jx) * c8 + cc) * 8 + e] == yv[e]) { first = false; break; }
+              const half_t* q = x + (((long)n * H + jy) * W + jx) * x_ld + cc * 8 + e;
+              if ((float)q[0] + (x_lo ? (float)q[x_lo] : 0.f) == yv[e]) { first = false; break; }
             }
           }
           if (first) acc[e] += (float)gv[e];
@@ -770,26 +815,35 @@ __global__ void maxpool_bwd_kernel(const half_t* x, const half_t* y, const half_
     *reinterpret_cast<h8*>(dx + i * 8) = o;
   }
 }
-extern "C" int csbsr_maxpool3x3s2_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
+extern "C" int csbsr_maxpool3x3s2_fwd_split(const void* x, int64_t x_ld, int64_t x_lo, void* y, int64_t y_ld, int64_t y_lo, int32_t N,
+                                            int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
   CSBSR_CHECK(x && y && c % 8 == 0, "maxpool: bad args");
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long)N * OH * OW * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x, (half_t*)y, N,
-                     H, W, c / 8, OH, OW);
+                     H, W, c / 8, OH, OW, x_ld, x_lo, y_ld, y_lo);
   CSBSR_LAUNCH_CHECK("csbsr_maxpool3x3s2_fwd");
+  return 0;
+}
+extern "C" int csbsr_maxpool3x3s2_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
+  return csbsr_maxpool3x3s2_fwd_split(x, c, 0, y, c, 0, N, H, W, c, s);
+}
+extern "C" int csbsr_maxpool3x3s2_bwd_split(const void* x, int64_t x_ld, int64_t x_lo, const void* y, int64_t y_ld, int64_t y_lo,
+                                            const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
+  CSBSR_CHECK(x && y && dy && dx && c % 8 == 0, "maxpool_bwd: bad args");
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x,
+                     (const half_t*)y, (const half_t*)dy, (half_t*)dx, N, H, W, c / 8, OH, OW, x_ld, x_lo, y_ld, y_lo);
+  CSBSR_LAUNCH_CHECK("csbsr_maxpool3x3s2_bwd");
   return 0;
 }
 extern "C" int csbsr_maxpool3x3s2_bwd(const void* x, const void* y, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
                                       int32_t c, csbsr_stream_t s) {
-  CSBSR_CHECK(x && y && dy && dx && c % 8 == 0, "maxpool_bwd: bad args");
-  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x,
-                     (const half_t*)y, (const half_t*)dy, (half_t*)dx, N, H, W, c / 8, OH, OW);
-  CSBSR_LAUNCH_CHECK("csbsr_maxpool3x3s2_bwd");
-  return 0;
+  return csbsr_maxpool3x3s2_bwd_split(x, c, 0, y, c, 0, dy, dx, N, H, W, c, s);
 }
 
 // ------------------------------------------------------------------------------------------- adaptive avg pool
-__global__ void aap_fwd_kernel(const half_t* x, long x_ld, half_t* y, int N, int H, int W, int c8, int OH, int OW) {
+__global__ void aap_fwd_kernel(const half_t* x, long x_ld, half_t* y, int N, int H, int W, int c8, int OH, int OW, long x_lo, long y_ld,
+                               long y_lo) {
   const long total = (long)N * OH * OW * c8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cc = (int)(i % c8); long t = i / c8;
@@ -802,15 +856,15 @@ __global__ void aap_fwd_kernel(const half_t* x, long x_ld, half_t* y, int N, int
     for (int e = 0; e < 8; ++e) a[e] = 0.f;
     for (int iy = y0; iy < y1; ++iy)
       for (int ix = x0; ix < x1; ++ix) {
-        const h8 v = *reinterpret_cast<const h8*>(x + (((long)n * H + iy) * W + ix) * x_ld + cc * 8);
+        float v[8];
+        ld_split(x + (((long)n * H + iy) * W + ix) * x_ld + cc * 8, x_lo, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+        for (int e = 0; e < 8; ++e) a[e] += v[e];
       }
     const float inv = 1.f / ((y1 - y0) * (x1 - x0));
-    h8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)(a[e] * inv);
-    *reinterpret_cast<h8*>(y + i * 8) = o;
+    for (int e = 0; e < 8; ++e) a[e] *= inv;
+    st_split(y + (i / c8) * y_ld + cc * 8, y_lo, a);
   }
 }
 __global__ void aap_bwd_kernel(const half_t* dy, half_t* dx, long dx_ld, int accumulate, int N, int H, int W, int c8, int OH, int OW) {
@@ -846,7 +900,8 @@ __global__ void aap_bwd_kernel(const half_t* dy, half_t* dx, long dx_ld, int acc
 }
 // large bins (PSP priors 1,2,3,6 over a 224^2 map): one workgroup per (sample, bin, 64-channel group);
 // 8 channel-chunk lanes x 32 pixel lanes, LDS tree over the pixel lanes
-__global__ __launch_bounds__(256) void aap_fwd_block_kernel(const half_t* x, long x_ld, half_t* y, int N, int H, int W, int c8, int OH, int OW) {
+__global__ __launch_bounds__(256) void aap_fwd_block_kernel(const half_t* x, long x_ld, half_t* y, int N, int H, int W, int c8, int OH, int OW,
+                                                            long x_lo, long y_ld, long y_lo) {
   __shared__ float sred[32][8][8];
   const int groups = (c8 + 7) / 8;
   int b = blockIdx.x;
@@ -864,37 +919,42 @@ __global__ __launch_bounds__(256) void aap_fwd_block_kernel(const half_t* x, lon
   if (cc < c8)
     for (int i = pl; i < cnt; i += 32) {
       const int iy = y0 + i / bw, ix = x0 + i % bw;
-      const h8 v = *reinterpret_cast<const h8*>(x + (((long)n * H + iy) * W + ix) * x_ld + cc * 8);
+      float v[8];
+      ld_split(x + (((long)n * H + iy) * W + ix) * x_ld + cc * 8, x_lo, v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+      for (int e = 0; e < 8; ++e) a[e] += v[e];
     }
 #pragma unroll
   for (int e = 0; e < 8; ++e) sred[pl][cl][e] = a[e];
   __syncthreads();
   if (pl == 0 && cc < c8) {
-    h8 o;
+    float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float s_ = 0.f;
       for (int q = 0; q < 32; ++q) s_ += sred[q][cl][e];
-      o[e] = (half_t)(s_ / cnt);
+      o[e] = s_ / cnt;
     }
-    *reinterpret_cast<h8*>(y + ((((long)n * OH + oy) * OW + ox) * c8 + cc) * 8) = o;
+    st_split(y + (((long)n * OH + oy) * OW + ox) * y_ld + cc * 8, y_lo, o);
   }
 }
-extern "C" int csbsr_adaptive_avgpool_fwd(const void* x, int64_t x_ld, void* y, int32_t N, int32_t H, int32_t W, int32_t c,
-                                          int32_t OH, int32_t OW, csbsr_stream_t s) {
+extern "C" int csbsr_adaptive_avgpool_fwd_split(const void* x, int64_t x_ld, int64_t x_lo, void* y, int64_t y_ld, int64_t y_lo, int32_t N,
+                                                int32_t H, int32_t W, int32_t c, int32_t OH, int32_t OW, csbsr_stream_t s) {
   CSBSR_CHECK(x && y && c % 8 == 0, "aap_fwd: bad args");
   if ((long)(H / OH) * (W / OW) >= 64) {
     const int groups = (c / 8 + 7) / 8;
     hipLaunchKernelGGL(aap_fwd_block_kernel, dim3(N * OH * OW * groups), dim3(256), 0, ST(s), (const half_t*)x, x_ld, (half_t*)y, N, H, W,
-                       c / 8, OH, OW);
+                       c / 8, OH, OW, x_lo, y_ld, y_lo);
   } else {
     hipLaunchKernelGGL(aap_fwd_kernel, dim3(grid_for((long)N * OH * OW * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x, x_ld, (half_t*)y,
-                       N, H, W, c / 8, OH, OW);
+                       N, H, W, c / 8, OH, OW, x_lo, y_ld, y_lo);
   }
   CSBSR_LAUNCH_CHECK("csbsr_adaptive_avgpool_fwd");
   return 0;
+}
+extern "C" int csbsr_adaptive_avgpool_fwd(const void* x, int64_t x_ld, void* y, int32_t N, int32_t H, int32_t W, int32_t c,
+                                          int32_t OH, int32_t OW, csbsr_stream_t s) {
+  return csbsr_adaptive_avgpool_fwd_split(x, x_ld, 0, y, c, 0, N, H, W, c, OH, OW, s);
 }
 extern "C" int csbsr_adaptive_avgpool_bwd(const void* dy, void* dx, int64_t dx_ld, int32_t accumulate, int32_t N, int32_t H,
                                           int32_t W, int32_t c, int32_t OH, int32_t OW, csbsr_stream_t s) {
@@ -915,7 +975,7 @@ __device__ __forceinline__ void bil_src(int o, int in, int out, int align, int& 
   w1 = src - i0;
 }
 __global__ void bilinear_fwd_kernel(const half_t* x, long x_ld, half_t* y, long y_ld, int N, int H, int W, int c8, int OH, int OW,
-                                    int align, const float* drop, int cp) {
+                                    int align, const float* drop, int cp, long x_lo, long y_lo) {
   const long total = (long)N * OH * OW * c8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cc = (int)(i % c8); long t = i / c8;
@@ -924,18 +984,18 @@ __global__ void bilinear_fwd_kernel(const half_t* x, long x_ld, half_t* y, long 
     int y0, y1, x0, x1; float wy, wx;
     bil_src(oy, H, OH, align, y0, y1, wy); bil_src(ox, W, OW, align, x0, x1, wx);
     const half_t* b = x + (long)n * H * W * x_ld + cc * 8;
-    const h8 v00 = *reinterpret_cast<const h8*>(b + ((long)y0 * W + x0) * x_ld);
-    const h8 v01 = *reinterpret_cast<const h8*>(b + ((long)y0 * W + x1) * x_ld);
-    const h8 v10 = *reinterpret_cast<const h8*>(b + ((long)y1 * W + x0) * x_ld);
-    const h8 v11 = *reinterpret_cast<const h8*>(b + ((long)y1 * W + x1) * x_ld);
-    h8 o;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    ld_split(b + ((long)y0 * W + x0) * x_ld, x_lo, v00);
+    ld_split(b + ((long)y0 * W + x1) * x_ld, x_lo, v01);
+    ld_split(b + ((long)y1 * W + x0) * x_ld, x_lo, v10);
+    ld_split(b + ((long)y1 * W + x1) * x_ld, x_lo, v11);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float v = (1.f - wy) * ((1.f - wx) * (float)v00[e] + wx * (float)v01[e]) + wy * ((1.f - wx) * (float)v10[e] + wx * (float)v11[e]);
+      float v = (1.f - wy) * ((1.f - wx) * v00[e] + wx * v01[e]) + wy * ((1.f - wx) * v10[e] + wx * v11[e]);
       if (drop) v *= drop[n * cp + cc * 8 + e];
-      o[e] = (half_t)v;
+      o[e] = v;
     }
-    *reinterpret_cast<h8*>(y + (((long)n * OH + oy) * OW + ox) * y_ld + cc * 8) = o;
+    st_split(y + (((long)n * OH + oy) * OW + ox) * y_ld + cc * 8, y_lo, o);
   }
 }
 // gather-form adjoint: each input pixel sums the output pixels that reference it (scan of a bounded output window)
@@ -990,13 +1050,18 @@ __global__ void bilinear_bwd_kernel(const half_t* dy, long dy_ld, half_t* dx, lo
     *reinterpret_cast<h8*>(q) = o;
   }
 }
-extern "C" int csbsr_bilinear_fwd(const void* x, int64_t x_ld, void* y, int64_t y_ld, int32_t N, int32_t H, int32_t W, int32_t c,
-                                  int32_t OH, int32_t OW, int32_t align_corners, const float* drop, csbsr_stream_t s) {
+extern "C" int csbsr_bilinear_fwd_split(const void* x, int64_t x_ld, int64_t x_lo, void* y, int64_t y_ld, int64_t y_lo, int32_t N, int32_t H,
+                                        int32_t W, int32_t c, int32_t OH, int32_t OW, int32_t align_corners, const float* drop,
+                                        csbsr_stream_t s) {
   CSBSR_CHECK(x && y && c % 8 == 0, "bilinear_fwd: bad args");
   hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for((long)N * OH * OW * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x, x_ld,
-                     (half_t*)y, y_ld, N, H, W, c / 8, OH, OW, align_corners, drop, c);
+                     (half_t*)y, y_ld, N, H, W, c / 8, OH, OW, align_corners, drop, c, x_lo, y_lo);
   CSBSR_LAUNCH_CHECK("csbsr_bilinear_fwd");
   return 0;
+}
+extern "C" int csbsr_bilinear_fwd(const void* x, int64_t x_ld, void* y, int64_t y_ld, int32_t N, int32_t H, int32_t W, int32_t c,
+                                  int32_t OH, int32_t OW, int32_t align_corners, const float* drop, csbsr_stream_t s) {
+  return csbsr_bilinear_fwd_split(x, x_ld, 0, y, y_ld, 0, N, H, W, c, OH, OW, align_corners, drop, s);
 }
 // large up-sampling ratios (PSP priors): the adjoint window of one input pixel spans thousands of outputs --
 // one workgroup per (sample, input pixel, 64-channel group), 32 window lanes, LDS tree
@@ -1238,7 +1303,7 @@ extern "C" int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, i
     const long hw = (long)H * W;
     int chunks = (int)((hw + 511) / 512);     // >= 392 workgroups at LR 448^2: the 4096-pixel chunks left 4/5 of the CUs idle
     if (chunks > 2048) chunks = 2048;
-    float* part = (g_red_scratch && (long)N * chunks * c <= g_red_scratch_elems) ? g_red_scratch : nullptr;
+    float* part = csbsr_red_scratch((long)N * chunks * c);
     hipLaunchKernelGGL(bcs_total_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks, part);
     if (part)
       for (int n = 0; n < N; ++n) csbsr_sum_partials(part + (long)n * chunks * c, chunks, c, c, sums + (long)n * 16 * c, ST(s));

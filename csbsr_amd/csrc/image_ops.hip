@@ -187,7 +187,7 @@ extern "C" int csbsr_blur_bwd_kernel(const float* dy, const float* x, float* dk,
   int tpw = (total + 1023) / 1024;          // ~1024 workgroups per sample at most: bounds the atomics per tap
   if (tpw < 1) tpw = 1;
   dim3 grid((total + tpw - 1) / tpw, N);
-  float* part = (g_red_scratch && (long)N * grid.x * 512 <= g_red_scratch_elems) ? g_red_scratch : nullptr;
+  float* part = csbsr_red_scratch((long)N * grid.x * 512);
   BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_bwd_kernel_kernel<KK>), grid, dim3(256), smem, ST(s), dy, x, dk, C, H, W, OH, OW, stride, TO, lgTO,
                                       tiles_x, tiles_y, tpw, part));
   if (part)

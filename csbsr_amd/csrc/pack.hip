@@ -9,6 +9,8 @@ struct PackK {
   int D0, D1, KH, KW, stride, pad;
   int seg0_real, seg0_p, segtot_p, chan_real;
   int row_off, nrows, rows_p, Kp, KHt, KWt, nphase, k_off;
+  int split;           // 1: K channels are [hi | hi | lo] blocks of seg0_p each (csbsr_pack_weights_split)
+  float wscale;        // weights are multiplied by this power of two before the fp16 split (keeps the lo halves out of subnormals)
 };
 
 __global__ void pack_weights_kernel(const PackK p) {
@@ -22,8 +24,9 @@ __global__ void pack_weights_kernel(const PackK p) {
     const int tap = k / p.segtot_p;
     const int cp = k - tap * p.segtot_p;
     // padded channel -> real channel of the K side
-    int c = -1;
-    if (cp < p.seg0_p) { if (cp < p.seg0_real) c = cp; }
+    int c = -1, blk = 0;
+    if (p.split) { blk = cp / p.seg0_p; const int c1 = cp - blk * p.seg0_p; if (c1 < p.seg0_real) c = c1; }
+    else if (cp < p.seg0_p) { if (cp < p.seg0_real) c = cp; }
     else { const int c1 = cp - p.seg0_p; if (p.seg0_real + c1 < p.chan_real) c = p.seg0_real + c1; }
     if (c >= 0) c += p.k_off;
     if (r < p.nrows && c >= 0 && tap < p.KHt * p.KWt) {
@@ -40,7 +43,13 @@ __global__ void pack_weights_kernel(const PackK p) {
         if (kh < p.KH && kw < p.KW) v = p.w[(((long)c * p.D1 + rr) * p.KH + kh) * p.KW + kw];
       }
     }
-    p.dst[i] = (half_t)v;
+    if (p.split) {
+      v *= p.wscale;
+      const half_t hi = (half_t)v;
+      p.dst[i] = blk < 2 ? hi : (half_t)(v - (float)hi);
+    } else {
+      p.dst[i] = (half_t)v;
+    }
   }
 }
 
@@ -57,6 +66,15 @@ static void pack_geometry(int kind, int D0, int D1, int KH, int KW, int stride, 
   p.KWt = kind == 2 ? (KW + stride - 1) / stride : KW;
   p.nphase = kind == 2 ? stride * stride : 1;
   p.Kp = round_up(p.KHt * p.KWt * p.segtot_p, 64);   // = BK of conv_igemm.hip
+  p.split = 0; p.wscale = 1.f;
+}
+// split-fp16 operand: the activation arrives as in[0] = [x_hi | x_lo] (2c channels), in[1] = x_hi (c channels), so per tap the K
+// axis is three blocks of c channels holding [w_hi | w_hi | w_lo]:  x_hi w_hi + x_lo w_hi + x_hi w_lo  (x_lo w_lo ~ 2^-22 dropped)
+static void pack_geometry_split(int kind, int D0, int D1, int KH, int KW, int stride, int creal, int nrows, PackK& p) {
+  pack_geometry(kind, D0, D1, KH, KW, stride, creal, 0, nrows, p);
+  p.segtot_p = 3 * p.seg0_p;
+  p.Kp = round_up(p.KHt * p.KWt * p.segtot_p, 64);
+  p.split = 1;
 }
 
 extern "C" int64_t csbsr_packed_weight_elems(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,
@@ -83,6 +101,32 @@ extern "C" int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(s), p);
   CSBSR_LAUNCH_CHECK("csbsr_pack_weights");
+  return 0;
+}
+
+extern "C" int64_t csbsr_packed_weight_elems_split(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t stride,
+                                                   int32_t creal, int32_t nrows) {
+  PackK p;
+  pack_geometry_split(kind, D0, D1, KH, KW, stride, creal, nrows, p);
+  return (int64_t)p.nphase * p.rows_p * p.Kp;
+}
+
+extern "C" int csbsr_pack_weights_split(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,
+                                        int32_t stride, int32_t pad, int32_t creal, int32_t row_off, int32_t nrows, int32_t k_off,
+                                        float wscale, csbsr_stream_t s) {
+  CSBSR_CHECK(w && dst, "pack_split: null pointer");
+  CSBSR_CHECK(kind >= 0 && kind <= 2, "pack_split: bad kind");
+  const int kdim = kind == 0 ? D1 : D0, rdim = kind == 0 ? D0 : D1;
+  CSBSR_CHECK(k_off >= 0 && k_off + creal <= kdim, "pack_split: channels (%d at %d) exceed the contracted dim (%d)", creal, k_off, kdim);
+  CSBSR_CHECK(row_off >= 0 && row_off + nrows <= rdim, "pack_split: row range out of bounds");
+  PackK p;
+  pack_geometry_split(kind, D0, D1, KH, KW, stride, creal, nrows, p);
+  p.w = w; p.dst = reinterpret_cast<half_t*>(dst); p.pad = pad; p.row_off = row_off; p.k_off = k_off; p.wscale = wscale;
+  const long total = (long)p.nphase * p.rows_p * p.Kp;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(s), p);
+  CSBSR_LAUNCH_CHECK("csbsr_pack_weights_split");
   return 0;
 }
 

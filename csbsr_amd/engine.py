@@ -30,12 +30,15 @@ def _ptr(t):
 
 class FM:
     """fp16 channels-last feature map view: tensor [N,H,W,Cp] (last stride 1), ``c`` real channels.
-    ``bcast``: tensor is [N,1,1,Cp] and stands for a spatially constant map of logical size (H, W)."""
-    __slots__ = ("t", "c", "bcast", "H", "W")
+    ``bcast``: tensor is [N,1,1,Cp] and stands for a spatially constant map of logical size (H, W).
+    ``lo``: split-fp16 map of the detector precision mode -- ``t`` is the hi plane and the lo plane (value = hi + lo, ~22 mantissa
+    bits) lives ``lo`` elements further on in the same allocation with the same strides; 0 = plain fp16.  Backward kernels read
+    ``t`` (the hi plane) like any other map."""
+    __slots__ = ("t", "c", "bcast", "H", "W", "lo")
 
-    def __init__(self, t, c, bcast=False, H=None, W=None):
+    def __init__(self, t, c, bcast=False, H=None, W=None, lo=0):
         assert t.dtype == torch.float16 and t.dim() == 4 and t.stride(3) == 1 and t.shape[3] % 8 == 0
-        self.t, self.c, self.bcast = t, c, bcast
+        self.t, self.c, self.bcast, self.lo = t, c, bcast, lo
         self.H = t.shape[1] if H is None else H
         self.W = t.shape[2] if W is None else W
 
@@ -60,8 +63,15 @@ class FM:
         sn, sy, sx = self.strides()
         return L.Seg(_ptr(self.t), sn, sy, sx, self.cp, self.c)
 
+    def split_segs(self):
+        """the two conv input segments of a split map: [hi | lo] as one 2*cp-channel segment (the planes must be adjacent, i.e.
+        an unsliced map) and the hi plane again (weights from csbsr_pack_weights_split)."""
+        assert self.lo == self.cp and not self.bcast, "split conv inputs must be whole [hi | lo] buffers"
+        sn, sy, sx = self.strides()
+        return L.Seg(_ptr(self.t), sn, sy, sx, 2 * self.cp, 0), L.Seg(_ptr(self.t), sn, sy, sx, self.cp, self.c)
+
     def slice(self, c0, c1, creal=None):
-        return FM(self.t[..., c0:c1], (c1 - c0) if creal is None else creal, self.bcast, self.H, self.W)
+        return FM(self.t[..., c0:c1], (c1 - c0) if creal is None else creal, self.bcast, self.H, self.W, self.lo)
 
     @property
     def npix(self):
@@ -73,17 +83,33 @@ class FM:
         return (not self.bcast) and t.stride(1) == t.shape[2] * t.stride(2) and t.stride(0) == t.shape[1] * t.stride(1)
 
 
+# Partial-row scratch of the two-stage reductions (csbsr_set_reduction_scratch): ONE buffer per device for the life of the process,
+# shared by every Engine on that device and registered with the library under that device's index -- so a second model (an
+# evaluator next to the trainer, a replica on another GPU) neither steals the registration nor leaves a dangling pointer behind when
+# it is garbage-collected.  Launches on one device are stream-ordered per Engine; two Engines on one device must not run reducing
+# kernels concurrently on different streams (they do not: one Python thread drives a replica).
+_RED_SCRATCH = {}
+
+
+def _reduction_scratch(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    buf = _RED_SCRATCH.get(idx)
+    if buf is None:
+        # poisoned with NaN once: a fold that reads a slot its producer did not write shows up immediately instead of adding garbage
+        buf = torch.full((16 << 20,), float("nan"), dtype=torch.float32, device=torch.device("cuda", idx))
+        _RED_SCRATCH[idx] = buf
+        with torch.cuda.device(idx):
+            L.call("csbsr_set_reduction_scratch", _ptr(buf), buf.numel())
+    return buf
+
+
 class Engine:
     def __init__(self, device="cuda:0", grad_scale=1.0):
         L.load()
         self.device = torch.device(device)
         self.grad_scale = float(grad_scale)
         self._ws = None
-        # partial-row scratch of the two-stage reductions (see csbsr_set_reduction_scratch); owned here, registered with the library
-        # (poisoned with NaN once: a fold that reads a slot its producer did not write shows up immediately instead of adding garbage)
-        self._red = torch.full((16 << 20,), float("nan"), dtype=torch.float32, device=self.device) if torch.cuda.is_available() else None
-        if self._red is not None:
-            L.call("csbsr_set_reduction_scratch", _ptr(self._red), self._red.numel())
+        self._red = _reduction_scratch(self.device) if torch.cuda.is_available() else None
         self.training = True
         self.timing = None              # list of (kind, flops, bytes, start_event, end_event) when profiling is on
 
@@ -91,9 +117,12 @@ class Engine:
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def new(self, N, H, W, c, zero=False):
+    def new(self, N, H, W, c, zero=False, split=False):
         f = torch.zeros if zero else torch.empty
-        return FM(f((N, H, W, pad8(c)), dtype=torch.float16, device=self.device), c)
+        cp = pad8(c)
+        if split:        # [hi | lo] planes side by side: a conv reads them as one 2*cp-channel segment
+            return FM(f((N, H, W, 2 * cp), dtype=torch.float16, device=self.device)[..., :cp], c, lo=cp)
+        return FM(f((N, H, W, cp), dtype=torch.float16, device=self.device), c)
 
     def f32(self, *shape, zero=True):
         f = torch.zeros if zero else torch.empty
@@ -129,13 +158,14 @@ class Engine:
         d.dbias, d.dprelu = _ptr(dbias), _ptr(dprelu)
         L.call("csbsr_epilogue_backward", C.byref(d), self.stream)
 
-    def nchw32_to_fm(self, src, cp=None, mean=None, invstd=None, out=None):
+    def nchw32_to_fm(self, src, cp=None, mean=None, invstd=None, out=None, split=False):
         N, Cc, H, W = src.shape
         assert src.is_contiguous() and src.dtype == torch.float32
         if out is None:
-            out = self.new(N, H, W, Cc if cp is None else cp)
+            out = self.new(N, H, W, Cc if cp is None else cp, split=split)
             out.c = Cc
-        L.call("csbsr_nchw32_to_nhwc16", _ptr(src), _ptr(out.t), N, Cc, H, W, out.cp, out.ld, _ptr(mean), _ptr(invstd), self.stream)
+        L.call("csbsr_nchw32_to_nhwc16_split", _ptr(src), _ptr(out.t), N, Cc, H, W, out.cp, out.ld, out.lo, _ptr(mean), _ptr(invstd),
+               self.stream)
         return out
 
     def fm_to_nchw32(self, fm, dst, C_, alpha=1.0, beta=0.0):
@@ -144,9 +174,10 @@ class Engine:
 
     def bilinear(self, x, OH, OW, align, out=None, drop=None):
         if out is None:
-            out = self.new(x.N, OH, OW, x.c)
+            out = self.new(x.N, OH, OW, x.c, split=bool(x.lo))
         assert x.flat_ok() and out.flat_ok()
-        L.call("csbsr_bilinear_fwd", _ptr(x.t), x.ld, _ptr(out.t), out.ld, x.N, x.H, x.W, x.cp, OH, OW, int(align), _ptr(drop), self.stream)
+        L.call("csbsr_bilinear_fwd_split", _ptr(x.t), x.ld, x.lo, _ptr(out.t), out.ld, out.lo, x.N, x.H, x.W, x.cp, OH, OW, int(align),
+               _ptr(drop), self.stream)
         return out
 
     def bilinear_bwd(self, dy, dx, acc, align, drop=None):
@@ -195,6 +226,21 @@ class Conv:
         self._packed[key] = dst
         return dst
 
+    # split-fp16 forward operand (detector precision mode): [w_hi | w_hi | w_lo] per tap, weights pre-scaled by WSCALE (undone by
+    # the epilogue's out_scale) so the lo halves of kaiming-sized weights stay in fp16's normal range
+    WSCALE = 256.0
+
+    def _pack_split(self, key, kind, creal, nrows, stride, pad):
+        if key in self._packed:
+            return self._packed[key]
+        D0, D1 = self.w.shape[0], self.w.shape[1]
+        n = L.load().csbsr_packed_weight_elems_split(kind, D0, D1, self.k, self.k, stride, creal, nrows)
+        dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
+        L.call("csbsr_pack_weights_split", _ptr(self.w), _ptr(dst), kind, D0, D1, self.k, self.k, stride, pad, creal, 0, nrows, 0,
+               self.WSCALE, self.eng.stream)
+        self._packed[key] = dst
+        return dst
+
     def out_size(self, H, W):
         k, s, p, d = self.k, self.stride, self.pad, self.dil
         if self.transposed:
@@ -205,9 +251,13 @@ class Conv:
                 res_mode, accumulate, stat, stat_mode, out_scale, cbias=None):
         d = L.ConvDesc()
         x0 = xs[0]
-        d.inp[0] = x0.seg()
-        if len(xs) > 1:
-            d.inp[1] = xs[1].seg()
+        if x0.lo:                       # split-fp16 input: [hi | lo] + hi again, weights from _pack_split
+            assert len(xs) == 1 and not transposed
+            d.inp[0], d.inp[1] = x0.split_segs()
+        else:
+            d.inp[0] = x0.seg()
+            if len(xs) > 1:
+                d.inp[1] = xs[1].seg()
         d.N, d.H, d.W, d.OH, d.OW = x0.N, H, W, OH, OW
         d.transposed, d.KH, d.KW, d.stride, d.pad, d.dil = int(transposed), k, k, stride, pad, dil
         d.wt, d.cout = _ptr(wt), cout
@@ -215,7 +265,7 @@ class Conv:
         if out is not None:
             assert out.cp == d.coutp and (out.H, out.W) == (OH, OW), (out.cp, d.coutp, out.H, OH)
             sn, sy, sx = out.strides()
-            d.out16, d.o_sn, d.o_sy, d.o_sx = _ptr(out.t), sn, sy, sx
+            d.out16, d.o_sn, d.o_sy, d.o_sx, d.o_lo = _ptr(out.t), sn, sy, sx, out.lo
         if out32 is not None:           # fp32 NCHW planar [N, cout, OH, OW]
             assert out32.is_contiguous() and tuple(out32.shape) == (x0.N, cout, OH, OW)
             d.out32, d.o32_sn, d.o32_sy, d.o32_sx, d.o32_sc = _ptr(out32), cout * OH * OW, OW, 1, OH * OW
@@ -223,10 +273,10 @@ class Conv:
         d.res_mode = res_mode
         if res is not None:
             sn, sy, sx = res.strides()
-            d.res, d.r_sn, d.r_sy, d.r_sx = _ptr(res.t), sn, sy, sx
+            d.res, d.r_sn, d.r_sy, d.r_sx, d.r_lo = _ptr(res.t), sn, sy, sx, res.lo
         if res2 is not None:
             sn, sy, sx = res2.strides()
-            d.res2, d.r2_sn, d.r2_sy, d.r2_sx = _ptr(res2.t), sn, sy, sx
+            d.res2, d.r2_sn, d.r2_sy, d.r2_sx, d.r2_lo = _ptr(res2.t), sn, sy, sx, res2.lo
         d.accumulate, d.stat_mode, d.stat, d.out_scale = int(accumulate), stat_mode, _ptr(stat), out_scale
         tm = self.eng.timing
         if tm is not None:
@@ -248,14 +298,18 @@ class Conv:
         assert tuple(f.c for f in xs) == tuple(c for c in self.split if c > 0), (self.name, [f.c for f in xs], self.split)
         H, W = xs[0].H, xs[0].W
         OH, OW = self.out_size(H, W)
+        sp = bool(xs[0].lo)
         if out is None and store and out32 is None:
-            out = self.eng.new(xs[0].N, OH, OW, self.cout)
-        if self.transposed:
+            out = self.eng.new(xs[0].N, OH, OW, self.cout, split=sp)
+        if sp:
+            assert not self.transposed and self.split[1] == 0
+            wt = self._pack_split("fwd_split", 0, self.cin, self.cout, self.stride, self.pad)
+        elif self.transposed:
             wt = self._pack("fwd", 2, self.split[0], self.split[1], 0, self.cout, self.stride, self.pad)
         else:
             wt = self._pack("fwd", 0, self.split[0], self.split[1], 0, self.cout, self.stride, self.pad)
         self._launch(xs, wt, self.transposed, self.k, self.stride, self.pad, self.dil, H, W, OH, OW, self.cout, out, out32, self.b,
-                     self.act, self.slope, self.prelu, res, res2, res_mode, False, stat, stat_mode, 1.0)
+                     self.act, self.slope, self.prelu, res, res2, res_mode, False, stat, stat_mode, 1.0 / self.WSCALE if sp else 1.0)
         return out
 
     def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None):
@@ -290,18 +344,20 @@ class Conv:
         assert not self.transposed and self.stride == 1 and self.k == 3 and self.split[1] > 0
         cf = self.split[0]
         B = x.N
-        wt = self._pack("fwd_feat", 0, cf, 0, 0, self.cout, 1, self.pad, 0)
-        w16c = self.w[:, cf:].to(torch.float16).float()
-        k16 = kvec.to(torch.float16).float()
+        sp = bool(x.lo)
+        wt = self._pack_split("fwd_feat_split", 0, cf, self.cout, 1, self.pad) if sp else self._pack("fwd_feat", 0, cf, 0, 0, self.cout, 1, self.pad, 0)
+        # the constant part is a tiny fp32 mat-vec: operands rounded to fp16 only in the plain mode (there they mirror the MFMA path)
+        w16c = self.w[:, cf:] if sp else self.w[:, cf:].to(torch.float16).float()
+        k16 = kvec.to(torch.float32) if sp else kvec.to(torch.float16).float()
         T = torch.einsum("ocyx,nc->noyx", w16c, k16)
         V = torch.einsum("noyx,ay,bx->nabo", T, mtap, mtap).reshape(B, 16, self.cout)
         cb = self.eng.f32(B, 16, pad8(self.cout))
         cb[:, :, :self.cout] = V
         H, W = x.H, x.W
         if out is None:
-            out = self.eng.new(B, H, W, self.cout)
+            out = self.eng.new(B, H, W, self.cout, split=sp)
         self._launch((x,), wt, False, 3, 1, self.pad, self.dil, H, W, H, W, self.cout, out, None, self.b, self.act, self.slope, self.prelu,
-                     None, None, L.RES_NONE, False, None, L.STAT_NONE, 1.0, cbias=cb)
+                     None, None, L.RES_NONE, False, None, L.STAT_NONE, 1.0 / self.WSCALE if sp else 1.0, cbias=cb)
         return out, (w16c, k16)
 
     def bwd_weights_folded(self, dpre, x, saved, mtap, frozen=False):
@@ -393,22 +449,22 @@ class BatchNorm:
     def _desc(self, x, mean, invstd, res, act, prelu, drop):
         d = L.BnDesc()
         d.npix, d.hw, d.c, d.creal = x.npix, x.H * x.W, x.cp, self.c
-        d.x, d.x_ld = _ptr(x.t), x.ld
+        d.x, d.x_ld, d.x_lo = _ptr(x.t), x.ld, x.lo
         cp = x.cp
         if self.gamma.numel() != cp:            # pad per-channel params once (channels here are always multiples of 8)
             raise L.CsbsrHipError("BatchNorm channel count must be a multiple of 8")
         d.mean, d.invstd, d.gamma, d.beta = _ptr(mean), _ptr(invstd), _ptr(self.gamma), _ptr(self.beta)
         if res is not None:
-            d.res, d.res_ld = _ptr(res.t), res.ld
+            d.res, d.res_ld, d.res_lo = _ptr(res.t), res.ld, res.lo
         d.act, d.prelu, d.drop = act, _ptr(prelu), _ptr(drop)
         return d
 
     def apply(self, x, mean, invstd, act=L.ACT_NONE, prelu=None, res=None, drop=None, out=None):
         if out is None:
-            out = self.eng.new(x.N, x.H, x.W, x.c)
+            out = self.eng.new(x.N, x.H, x.W, x.c, split=bool(x.lo))
         assert x.flat_ok() and out.flat_ok() and (res is None or res.flat_ok())
         d = self._desc(x, mean, invstd, res, act, prelu, drop)
-        d.y, d.y_ld = _ptr(out.t), out.ld
+        d.y, d.y_ld, d.y_lo = _ptr(out.t), out.ld, out.lo
         L.call("csbsr_bn_apply", C.byref(d), self.eng.stream)
         return out
 

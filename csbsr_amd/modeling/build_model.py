@@ -131,6 +131,13 @@ class _JointBase(nn.Module):
         self.max_resident = None
         self.dropout_enabled = True
         self.dropout_masks = None     # tests may inject {name: [B,C] fp32} keep-masks
+        # Precision plan of the detector's FORWARD pass (PSPNet / PSPNet_BlurSkip):
+        #   "fp16"   fp16 activation storage, one MFMA pass (north_star's plan; the throughput configuration);
+        #   "split"  activations and weights as fp16 hi + lo pairs (~22 mantissa bits), three MFMA passes per conv into one fp32
+        #            accumulator -- the detector then matches the fp32 reference to ~1e-5 on identical inputs (the random-weight
+        #            BatchNorm stack amplifies fp16 rounding ~100x: DESIGN.md section 2).  Costs ~3x the detector's forward MFMA time
+        #            and 2x its activation memory; the backward is unchanged (fp16 hi planes).
+        self.detector_precision = "fp16"
 
     # ---- naming: state_dict keys are the reference's dotted names
     def _named_full(self):
@@ -166,6 +173,12 @@ class _JointBase(nn.Module):
             P = {k: (v.data if isinstance(v, nn.Parameter) else v) for k, v in self._named_full()}
             self._rt = {"eng": eng, "P": P, "kbpn": KBPN(eng, P, self.pc), "psp": HRNetOCR(eng, P) if self.seg_model_name == "HRNet_OCR"
                         else PSPNet(eng, P, blur_dim=self.pc.ksize_out ** 2 if self.blur_skip else None)}
+        if self.detector_precision not in ("fp16", "split"):
+            raise ValueError(f"detector_precision must be 'fp16' or 'split', got {self.detector_precision!r}")
+        split = self.detector_precision == "split"
+        if split and self.seg_model_name == "HRNet_OCR":
+            raise NotImplementedError("detector_precision='split' is built for PSPNet / PSPNet_BlurSkip")
+        self._rt["psp"].split = split
         return self._rt
 
     def _invalidate(self):
@@ -197,21 +210,25 @@ class _JointBase(nn.Module):
             invstd = (1.0 / torch.tensor(self.pc.std, device=self._device)).repeat(B).contiguous()
         else:
             mean = invstd = None
-        return eng.nchw32_to_fm(sr32, mean=mean, invstd=invstd), mean, invstd
+        return eng.nchw32_to_fm(sr32, mean=mean, invstd=invstd, split=self.detector_precision == "split"), mean, invstd
 
 
 class _JointFn(torch.autograd.Function):
     """(segment_loss[B], sr_loss[B]) = f(parameters); backward = the HIP backward pass."""
 
     @staticmethod
-    def forward(ctx, model, seg_loss, sr_loss, *params):
-        ctx.model = model
+    def forward(ctx, model, st, seg_loss, sr_loss, *params):
+        ctx.model, ctx.st = model, st          # the saved state travels with THIS graph: a later forward cannot clobber it
+        ctx.set_materialize_grads(False)       # an unused loss vector arrives as None, not as a zero tensor to be scanned
         return seg_loss.clone(), sr_loss.clone()
 
     @staticmethod
     def backward(ctx, dseg, dsr):
-        grads = ctx.model._hip_backward(dseg, dsr)
-        return (None, None, None) + tuple(grads)
+        st, ctx.st = ctx.st, None
+        if st is None:
+            raise RuntimeError("csbsr_amd: backward called twice on the same forward (activations are freed by the first backward)")
+        grads = ctx.model._hip_backward(st, dseg, dsr)
+        return (None, None, None, None) + tuple(grads)
 
 
 class JointModelWithLoss(_JointBase):
@@ -230,7 +247,8 @@ class JointModelWithLoss(_JointBase):
         self.grad_scale = None          # None: chosen per call as 2^round(log2(B*H*W)) (see _hip_backward)
         self.scale_backoff = 0          # log2 reduction of the automatic scale after overflowed steps
         self.overflow_steps = 0
-        self._st = None
+        self.last_step_overflowed = False
+        self.last_dsr = self.last_dkvec = None      # set by the backward of forward_from_sr (validation)
         self.reducer = None             # csbsr_amd.parallel.GradBucketReducer when data-parallel
 
     # ------------------------------------------------------------------ forward
@@ -257,11 +275,56 @@ class JointModelWithLoss(_JointBase):
             kbpn.saved = None
             sr32[b0:b0 + mb] = s_
             kvec[b0:b0 + mb] = k_
+        return self._detector_and_losses(iter, x, hr, mask, kgt, sr32, kvec, saves, mb)
+
+    def forward_from_sr(self, iter, sr_preds, kernel_vec, x, sr_targets, segment_targets, kernel_targets):
+        """Validation entry point: the detector + loss half of ``forward`` fed a GIVEN SR image [B,3,H,W] and (un-normalised) kernel
+        vector [B,kk] instead of KBPN's -- e.g. the reference's own sr_preds from a golden fixture -- so the detector, the losses
+        and their backward can be compared with the reference on identical inputs.  ``backward()`` on the returned losses stops at
+        the SR image: its gradient (true scale) is left in ``self.last_dsr`` / ``self.last_dkvec``; KBPN parameters get no gradient."""
+        rt = self._runtime()
+        self._invalidate()
+        x, hr, mask, kgt = self._mount(x), self._mount(sr_targets), self._mount(segment_targets), self._mount(kernel_targets)
+        sr32, kvec = self._mount(sr_preds), self._mount(kernel_vec).reshape(x.shape[0], -1)
+        self._n_res = 0
+        return self._detector_and_losses(iter, x, hr, mask, kgt, sr32, kvec, None, x.shape[0])
+
+    @torch.no_grad()
+    def kbpn_backward_from(self, iter, x, kernel_targets, dsr, dkvec):
+        """Validation entry point: KBPN forward + backward with a GIVEN upstream gradient (dLoss/d sr_preds [B,3,H,W] and
+        dLoss/d kernel vector [B,kk], true scale) -- e.g. the reference's own, from a golden fixture.  Returns {state_dict name: grad}."""
+        rt = self._runtime()
+        eng, kbpn, pc = rt["eng"], rt["kbpn"], self.pc
+        self._invalidate()
+        x, kgt, dsr, dkvec = self._mount(x), self._mount(kernel_targets), self._mount(dsr), self._mount(dkvec)
+        B, _, h, w = x.shape
+        gs = float(2 ** round(math.log2(B * h * w * pc.scale * pc.scale)))
+        eng.grad_scale = gs
+        names = [k for k, v in self._named_full() if isinstance(v, nn.Parameter) and k.startswith("sr_model")]
+        for k in names:
+            t = rt["P"][k]
+            if getattr(t, "gacc", None) is not None:
+                t.gacc.zero_()
+            t.gacc_touched = False
+        mb = max(1, min(self.micro_batch, B))
+        for b0 in range(0, B, mb):
+            kbpn.forward(x[b0:b0 + mb], iter, kgt[b0:b0 + mb], save=True)
+            kbpn.backward((dsr[b0:b0 + mb] * gs).contiguous(), (dkvec[b0:b0 + mb] * gs).contiguous())
+        return {k: (rt["P"][k].gacc / gs if getattr(rt["P"][k], "gacc_touched", False) else None) for k in names}
+
+    def _detector_and_losses(self, iter, x, hr, mask, kgt, sr32, kvec, saves, mb):
+        rt, pc = self._rt, self.pc
+        eng, psp = rt["eng"], rt["psp"]
+        B, _, h, w = x.shape
+        H, W = h * pc.scale, w * pc.scale
+        training = self.training
         xin, mean, invstd = self._norm_sr(sr32)
         drop = psp.make_dropout(B, training, self.dropout_enabled) if self.dropout_masks is None else \
             {k: self.dropout_masks.get(k) for k in psp.drop_keys}
         drop = {k: (None if v is None else v.to(self._device, torch.float32).contiguous()) for k, v in drop.items()}
         seg32, aux32 = psp.forward(xin, drop, training, kvec=kvec if self.blur_skip else None)
+        keep = training and torch.is_grad_enabled()
+        psp_saved, psp.saved = (psp.saved if keep else None), None      # carried by the autograd node, not by the (shared) layer object
         # ---- losses (forward sums only; gradients are produced in _hip_backward)
         hw = H * W
         sdf = eng.f32(B, 1, H, W, zero=False)
@@ -297,27 +360,33 @@ class JointModelWithLoss(_JointBase):
         kpred = vec.reshape(B, 1, K, K)
         k_l = ((kpred - kgt) ** 2).mean((1, 2, 3))
         sr_loss = pc.sr_w[0] * s_hr / (3 * hw) + pc.sr_w[1] * s_lr / (3 * h * w) + pc.sr_w[2] * k_l
-        self._st = dict(iter=iter, x=x, hr=hr, mask=mask, kgt=kgt, sr32=sr32, kvec=kvec, ksum=ksum, vec=vec, mean=mean, invstd=invstd,
-                        seg32=seg32, aux32=aux32, sdf=sdf, sums_m=sums_m, sums_a=sums_a, alpha=alpha, lr_pred=lr_pred, blurred=None,
-                        wmap=wmap, wmap_lr=wmap_lr, saves=saves, mb=mb, B=B, h=h, w=w)
         del blurred
-        if torch.is_grad_enabled() and training:
+        if keep:
+            st = dict(iter=iter, x=x, hr=hr, mask=mask, kgt=kgt, sr32=sr32, kvec=kvec, ksum=ksum, vec=vec, mean=mean, invstd=invstd,
+                      seg32=seg32, aux32=aux32, sdf=sdf, sums_m=sums_m, sums_a=sums_a, alpha=alpha, lr_pred=lr_pred,
+                      wmap=wmap, wmap_lr=wmap_lr, saves=saves, mb=mb, B=B, h=h, w=w, psp_saved=psp_saved, n_res=self._n_res)
             params = [p for p in self.parameters()]
-            seg_loss, sr_loss = _JointFn.apply(self, seg_loss, sr_loss, *params)
+            seg_loss, sr_loss = _JointFn.apply(self, st, seg_loss, sr_loss, *params)
         return seg_loss, sr_loss, seg32, sr32, kpred
 
     def _auto_resident(self, B, mb, H, W):
         """micro-batches whose KBPN activations fit next to the detector's working set (measured at HR 1792^2: 26.5 GB per image
-        of KBPN activations, 6.3 / 9.5 GB per image for PSPNet / HRNet-OCR incl. their backward workspaces) with 18 GB to spare."""
+        of KBPN activations, 6.3 / 9.5 GB per image for PSPNet / HRNet-OCR incl. their backward workspaces -- the split-precision
+        detector holds two planes per activation) with 18 GB to spare.  The budget is what is FREE now (driver-reported free memory
+        plus what torch's caching allocator holds but does not use), so another tenant of the GPU or a second model in the process
+        lowers the residency instead of running the step out of memory; the rest is recomputed in the backward."""
         r = (H * W) / float(1792 * 1792)
-        total = torch.cuda.get_device_properties(self._device).total_memory
+        free, _ = torch.cuda.mem_get_info(self._device)
+        free += torch.cuda.memory_reserved(self._device) - torch.cuda.memory_allocated(self._device)
         det = (9.5e9 if self.seg_model_name == "HRNet_OCR" else 6.3e9) * r * B
-        imgs = int((total - 18e9 - det) // (26.5e9 * r)) if r > 0 else B
+        if self.detector_precision == "split":
+            det += 4.9e9 * r * B
+        imgs = int((free - 18e9 - det) // (26.5e9 * r)) if r > 0 else B
         return max(0, min((B + mb - 1) // mb, imgs // mb))
 
     # ------------------------------------------------------------------ backward
-    def _hip_backward(self, dseg_loss, dsr_loss):
-        rt, st, pc = self._rt, self._st, self.pc
+    def _hip_backward(self, st, dseg_loss, dsr_loss):
+        rt, pc = self._rt, self.pc
         eng, kbpn, psp = rt["eng"], rt["kbpn"], rt["psp"]
         B, h, w = st["B"], st["h"], st["w"]
         H, W = h * pc.scale, w * pc.scale
@@ -338,7 +407,10 @@ class JointModelWithLoss(_JointBase):
         if live:
             torch._foreach_zero_(live)      # one multi-tensor launch instead of ~290 fills
         dsr32 = eng.f32(B, 3, H, W)
-        seg_active = dseg_loss is not None and bool((dseg_loss != 0).any())
+        # which halves of the backward run follows from which loss vector the caller's scalar loss used (autograd hands None for an
+        # unused output): a function of the training phase, identical on every rank, and no device read-back
+        seg_active = dseg_loss is not None
+        psp.saved = st["psp_saved"]
         if seg_active:
             gsc = (dseg_loss.to(torch.float32) * gs).contiguous()
             dseg32, daux32 = eng.f32(B, 1, H, W, zero=False), eng.f32(B, 1, H, W, zero=False)
@@ -367,7 +439,7 @@ class JointModelWithLoss(_JointBase):
                 return self._finish_backward(pnames, gs, ())
         # ---- SR loss gradients
         dkvec = eng.f32(B, pc.ksize_out ** 2)
-        if dsr_loss is not None and bool((dsr_loss != 0).any()):
+        if dsr_loss is not None:
             g = (dsr_loss.to(torch.float32) * gs)
             K = pc.ksize_out
             g_hr = (g * pc.sr_w[0] / (3 * hw)).contiguous()
@@ -389,6 +461,9 @@ class JointModelWithLoss(_JointBase):
         # ---- KBPN backward (per micro-batch; recompute the forward when it was not kept)
         mb = st["mb"]
         saves = st["saves"]
+        if saves is None:        # forward_from_sr: the graph ends at the given SR image
+            self.last_dsr, self.last_dkvec = dsr32 / gs, dkvec / gs
+            return self._finish_backward(pnames, gs, ("segmentation_model",) if seg_active else ())
         order = list(enumerate(range(0, B, mb)))
         for i, b0 in reversed(order):         # resident micro-batches last-in first-out: frees HBM before the recomputed ones run
             if saves[i] is None:
@@ -396,7 +471,7 @@ class JointModelWithLoss(_JointBase):
             kbpn.saved, saves[i] = saves[i], None
             kbpn.backward(dsr32[b0:b0 + mb].contiguous(), dkvec[b0:b0 + mb].contiguous())
         for i, b0 in order:                   # the rest: forward recomputed here (KBPN has no batch-coupled op: exact)
-            if i < self._n_res:
+            if i < st["n_res"]:
                 continue
             kbpn.forward(st["x"][b0:b0 + mb], st["iter"], st["kgt"][b0:b0 + mb], save=True)
             kbpn.backward(dsr32[b0:b0 + mb].contiguous(), dkvec[b0:b0 + mb].contiguous())
@@ -404,7 +479,6 @@ class JointModelWithLoss(_JointBase):
 
     def _finish_backward(self, pnames, gs, reduce_groups):
         rt = self._rt
-        self._st = None
         if self.reducer is not None:
             for grp in reduce_groups:
                 self.reducer.launch([rt["P"][k].gacc if getattr(rt["P"][k], "gacc_touched", False) else None
@@ -419,15 +493,17 @@ class JointModelWithLoss(_JointBase):
             if self.grad_scale is None:
                 self.scale_backoff += 4
             import warnings
-            warnings.warn(f"csbsr_amd: fp16 gradient overflow at loss scale {gs:g}; this step's gradients are zeroed"
+            warnings.warn(f"csbsr_amd: fp16 gradient overflow at loss scale {gs:g}; this step is skipped (every gradient is None)"
                           + ("" if self.grad_scale is not None else f", next scale {gs / 16:g}"))
+            self.last_step_overflowed = True
+            # GradScaler semantics: optimizer.step() must be a no-op for this step.  Gradients of None make torch optimisers skip the
+            # parameter entirely (no moment decay, no step count, no weight move); zeros would still move Adam's weights by its momentum.
+            return [None] * len(pnames)
+        self.last_step_overflowed = False
         out = []
         for k in pnames:                    # parameters no kernel touched (frozen phase / unused) keep grad None
             t = rt["P"][k]
-            if not getattr(t, "gacc_touched", False):
-                out.append(None)
-            else:
-                out.append(t.gacc * inv if finite else torch.zeros_like(t.gacc))
+            out.append(t.gacc * inv if getattr(t, "gacc_touched", False) else None)
         return out
 
 

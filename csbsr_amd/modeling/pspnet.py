@@ -91,6 +91,10 @@ class PSPNet:
         self.aux0 = ConvBN(e, P, prefix + ".aux.0", prefix + ".aux.1", 256, 256, 3, 1, 1)
         self.aux4 = Conv(e, prefix + ".aux.4", P, 1, bias=True, act=L.ACT_SIGMOID)
         self.saved = None
+        # "split": every forward activation of the detector is an fp16 hi + lo pair (~22 mantissa bits) and every forward conv runs
+        # three MFMA passes (x_hi w_hi + x_lo w_hi + x_hi w_lo) in one fp32 accumulator; the backward reads the hi planes (BatchNorm /
+        # max-pool backward also the lo planes, so their masks are the forward's).  Set by the model (detector_precision).
+        self.split = False
 
     def all_convs(self):
         cs = [self.stem.conv] + [b[k].conv for b in self.blocks for k in ("c1", "c2", "down") if b[k] is not None]
@@ -123,8 +127,8 @@ class PSPNet:
         raw, m, iv = self.stem.fwd(xin, training)
         a = self.stem.bn.apply(raw, m, iv, act=L.ACT_RELU)
         PH, PW = (a.H + 2 - 3) // 2 + 1, (a.W + 2 - 3) // 2 + 1
-        p = e.new(B, PH, PW, 64)
-        L.call("csbsr_maxpool3x3s2_fwd", _ptr(a.t), _ptr(p.t), B, a.H, a.W, 64, e.stream)
+        p = e.new(B, PH, PW, 64, split=bool(a.lo))
+        L.call("csbsr_maxpool3x3s2_fwd_split", _ptr(a.t), a.ld, a.lo, _ptr(p.t), p.ld, p.lo, B, a.H, a.W, 64, e.stream)
         sv["stem"] = (raw, m, iv, a, p)
         x = p
         bsv = []
@@ -142,7 +146,7 @@ class PSPNet:
                 res, dsv = x, None
             out = None
             if bi == nb - 1:    # last block writes straight into the PSP concat buffer (channels 2048:2560)
-                cat = e.new(B, r2.H, r2.W, 2560)
+                cat = e.new(B, r2.H, r2.W, 2560, split=bool(r2.lo))
                 out = cat.slice(2048, 2560)
             y = blk["c2"].bn.apply(r2, m2, i2, act=L.ACT_RELU, res=res, out=out)
             bsv.append((x, r1, m1, i1, a1, r2, m2, i2, res, dsv, y) if keep_trunk else None)
@@ -154,8 +158,9 @@ class PSPNet:
         # pyramid pooling
         psp = []
         for i, size in enumerate((1, 2, 3, 6)):
-            pooled = e.new(B, size, size, 512)
-            L.call("csbsr_adaptive_avgpool_fwd", _ptr(x.t), x.ld, _ptr(pooled.t), B, fH, fW, 512, size, size, e.stream)
+            pooled = e.new(B, size, size, 512, split=bool(x.lo))
+            L.call("csbsr_adaptive_avgpool_fwd_split", _ptr(x.t), x.ld, x.lo, _ptr(pooled.t), pooled.ld, pooled.lo, B, fH, fW, 512, size, size,
+                   e.stream)
             pc = self.psp_convs[i].fwd(pooled)
             e.bilinear(pc, fH, fW, False, out=cat.slice(512 * i, 512 * (i + 1)))
             psp.append((pooled, pc))
@@ -204,8 +209,9 @@ class PSPNet:
             z = cb.bn.apply(raw, m, iv, act=L.ACT_RELU)
             bsv.append((q, t1, f1, sc, t2, f2, y, raw, m, iv, z))
             q = z
-        out = e.new(p.N, p.H, p.W, p.c)
-        L.call("csbsr_axpby", p.npix, p.cp, _ptr(p.t), p.ld, 1.0, _ptr(q.t), q.ld, 1.0, _ptr(out.t), out.ld, e.stream)    # p + _p
+        out = e.new(p.N, p.H, p.W, p.c, split=bool(p.lo))
+        L.call("csbsr_axpby_split", p.npix, p.cp, _ptr(p.t), p.ld, p.lo, 1.0, _ptr(q.t), q.ld, q.lo, 1.0, _ptr(out.t), out.ld, out.lo,
+               e.stream)    # p + _p
         sv["blur_skip"] = bsv
         return out
 
@@ -331,7 +337,8 @@ class PSPNet:
             sv["blocks"][bi] = None
         raw, m, iv, a, p = sv["stem"]
         da = e.new(B, a.H, a.W, 64)
-        L.call("csbsr_maxpool3x3s2_bwd", _ptr(a.t), _ptr(p.t), _ptr(dy.t), _ptr(da.t), B, a.H, a.W, 64, e.stream)
+        assert dy.flat_ok() and dy.ld == dy.cp
+        L.call("csbsr_maxpool3x3s2_bwd_split", _ptr(a.t), a.ld, a.lo, _ptr(p.t), p.ld, p.lo, _ptr(dy.t), _ptr(da.t), B, a.H, a.W, 64, e.stream)
         draw = self.stem.bn.backward(da, raw, m, iv, act=L.ACT_RELU)
         self.stem.conv.bwd_weights(draw, xin)
         dxin = self.stem.conv.bwd_input(draw, in_hw=(H, W))

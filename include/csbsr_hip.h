@@ -78,12 +78,13 @@ typedef struct {
   int32_t stat_mode;       /* CSBSR_STAT_* */
   float* stat;
   float out_scale;         /* accumulator multiplied by this first (1.0 default) */
+  /* split-fp16 operands (detector precision mode): element offset from the hi plane of out16 / res / res2 to a lo plane of the
+   * same strides, value = hi + lo (~22 mantissa bits); 0 = plain fp16.  A split INPUT needs no field: it is passed as
+   * in[0] = the [hi | lo] channel pair (2c channels), in[1] = the hi plane again, with weights from csbsr_pack_weights_split. */
+  int64_t o_lo, r_lo, r2_lo;
 } csbsr_conv_desc_t;
 
 int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
-/* measurement aid: kernel the calling thread's last csbsr_conv_forward dispatched to -- 0/1/2 conv_igemm_kernel<32|64|128,..>,
- * 3/4 conv_igemm_glds_kernel<128,2,2|256,4,3>, 5 conv_thin_cout_kernel, 6 conv_thin_cin_kernel (bench.py's roofline block) */
-int32_t csbsr_debug_last_conv_kernel(void);
 
 /* Weight-gradient GEMM: G[split][a][tap][b] = sum over the split's pixels of A[pix][a] * B[pix @ tap][b]  (fp32; the pixel
  * range is cut into csbsr_wgrad_splits() slabs, each written once -- no atomics, no zero-fill; csbsr_unpack_wgrad sums them).
@@ -106,13 +107,6 @@ typedef struct {
 int32_t csbsr_wgrad_splits(int32_t ca, int32_t ktot, int64_t npix);
 int32_t csbsr_wgrad_splits_desc(const csbsr_wgrad_desc_t* d);   /* same, for a filled descriptor (d->splits ignored): use this one */
 int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s);
-/* test / A-B hooks (kernel selection only, results are identical):
- *   wgrad: bit0 hardware transpose reads (0 = scalar LDS transposition), 2 no thin kernel, 4 no XCD tap order, 8 no flat grid,
- *          16 flat grid everywhere, 32 no row shift, 64 no 128x256 tile, bits 8.. extra dynamic LDS in KiB (occupancy experiments)
- *   conv:  low 3 bits 0 = register-staged kernel only, 1 = 128x128 LDS-DMA tile only, 2 = default, 3 = 256x128 wherever it fits;
- *          16 no thin kernels, 32 phases on grid.z, 64 linear pixel tiles, 128 raster tap order */
-void csbsr_debug_set_wgrad_tr(int flags);
-void csbsr_debug_set_conv_glds(int mode);
 
 /* fp32 master weights W[D0][D1][KH][KW] (the reference's OIHW conv / IOHW deconv parameters, whose state_dict
  * layout is part of the drop-in boundary) -> packed fp16 operand [phase][rows_p][Kp] of csbsr_conv_forward.
@@ -126,6 +120,16 @@ int64_t csbsr_packed_weight_elems(int32_t kind, int32_t D0, int32_t D1, int32_t 
 int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,
                        int32_t stride, int32_t pad, int32_t seg0_real, int32_t seg1_real, int32_t row_off,
                        int32_t nrows, int32_t k_off, csbsr_stream_t s);   /* k_off: first contracted channel (sub-range packing) */
+/* Split-fp16 ("hi + lo") operand for the detector precision mode: per tap the K axis holds three blocks of pad8(creal) channels,
+ * [w_hi | w_hi | w_lo] with w_hi = fp16(w * wscale), w_lo = fp16(w * wscale - w_hi), matching an input passed to
+ * csbsr_conv_forward as in[0] = [x_hi | x_lo], in[1] = x_hi:  x_hi w_hi + x_lo w_hi + x_hi w_lo in ONE fp32 accumulator (three
+ * MFMA passes; the dropped x_lo w_lo term is ~2^-22 relative).  wscale (a power of two, undone by the conv's out_scale) keeps w_lo
+ * out of fp16's subnormal range.  Single-segment layers only. */
+int64_t csbsr_packed_weight_elems_split(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t stride,
+                                        int32_t creal, int32_t nrows);
+int csbsr_pack_weights_split(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,
+                             int32_t stride, int32_t pad, int32_t creal, int32_t row_off, int32_t nrows, int32_t k_off,
+                             float wscale, csbsr_stream_t s);
 /* packed fp32 wgrad slabs G[split][ca_padded][tap][b(padded segments)] -> grad[a][b_off + b][kh][kw] += scale * sum_split G
  * (grad is [D0][D1][KH][KW]; transpose_ab: a indexes D1 and b indexes D0) */
 int csbsr_unpack_wgrad(const float* g, float* grad, int32_t A, int32_t KH, int32_t KW, int32_t seg0_real,
@@ -153,13 +157,34 @@ typedef struct {
 } csbsr_epi_bwd_desc_t;
 int csbsr_epilogue_backward(const csbsr_epi_bwd_desc_t* d, csbsr_stream_t s);
 /* Caller-owned fp32 scratch for the two-stage per-channel reductions of csbsr_epilogue_backward / csbsr_bn_backward (one partial row
- * per workgroup + a fold kernel instead of ~1e5 contended atomics per call).  Used by whatever stream the calls are issued on: one
- * stream at a time per process.  16 Mi floats cover every shape of the path; NULL (the default) keeps the atomics path. */
+ * per workgroup + a fold kernel instead of ~1e5 contended atomics per call).  Registered PER DEVICE: the call binds ``buf`` to the
+ * calling thread's current HIP device and the reducing entry points look their device's buffer up at launch, so several models /
+ * replicas in one process do not overwrite each other's registration.  Used by whatever stream the calls are issued on: one stream
+ * at a time per device.  16 Mi floats cover every shape of the path; NULL (the default) keeps the atomics path. */
 int csbsr_set_reduction_scratch(float* buf, int64_t elems);
 
 int csbsr_axpby(int64_t npix, int32_t c, const void* x, int64_t x_ld, float a, const void* z, int64_t z_ld,
                 float b, void* y, int64_t y_ld, csbsr_stream_t s);
 int csbsr_fill_f16(void* p, int64_t npix, int32_t c, int64_t ld, float v, csbsr_stream_t s);
+
+/* Split-fp16 ("hi + lo") variants for the detector precision mode (forward only: the backward kernels read the hi planes).
+ * A split map is two fp16 planes of equal strides, value = hi + lo; ``*_lo`` is the element offset from the hi pointer to the lo
+ * plane, 0 = that operand is plain fp16.  Arithmetic is fp32 on the combined value; outputs are re-split.  Same reference call sites
+ * as the plain functions they extend. */
+int csbsr_axpby_split(int64_t npix, int32_t c, const void* x, int64_t x_ld, int64_t x_lo, float a, const void* z, int64_t z_ld,
+                      int64_t z_lo, float b, void* y, int64_t y_ld, int64_t y_lo, csbsr_stream_t s);
+int csbsr_nchw32_to_nhwc16_split(const float* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t cp,
+                                 int64_t dst_ld, int64_t dst_lo, const float* mean, const float* invstd, csbsr_stream_t s);
+int csbsr_maxpool3x3s2_fwd_split(const void* x, int64_t x_ld, int64_t x_lo, void* y, int64_t y_ld, int64_t y_lo, int32_t N,
+                                 int32_t H, int32_t W, int32_t c, csbsr_stream_t s);
+/* (x, y: the saved forward input / output, possibly split; dy / dx plain fp16 dense) */
+int csbsr_maxpool3x3s2_bwd_split(const void* x, int64_t x_ld, int64_t x_lo, const void* y, int64_t y_ld, int64_t y_lo,
+                                 const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s);
+int csbsr_adaptive_avgpool_fwd_split(const void* x, int64_t x_ld, int64_t x_lo, void* y, int64_t y_ld, int64_t y_lo, int32_t N,
+                                     int32_t H, int32_t W, int32_t c, int32_t OH, int32_t OW, csbsr_stream_t s);
+int csbsr_bilinear_fwd_split(const void* x, int64_t x_ld, int64_t x_lo, void* y, int64_t y_ld, int64_t y_lo, int32_t N, int32_t H,
+                             int32_t W, int32_t c, int32_t OH, int32_t OW, int32_t align_corners, const float* drop,
+                             csbsr_stream_t s);
 
 /* HRNet-W48 + OCR detector (BASELINE config 4).
  * csbsr_sum_act: y = relu?(x_0 + ... + x_{n-1}), n <= 4 fp16 NHWC maps -- the fuse sum of HighResolutionModule.forward
@@ -215,6 +240,7 @@ typedef struct {
   void* dx; int64_t dx_ld;
   void* dres; int64_t dres_ld; int32_t dres_accumulate; int32_t _pad1;
   float *dgamma, *dbeta;
+  int64_t x_lo, res_lo, y_lo;          /* split-fp16 planes of x / res / y (element offset from the hi plane; 0 = plain fp16) */
 } csbsr_bn_desc_t;
 int csbsr_bn_apply(const csbsr_bn_desc_t* d, csbsr_stream_t s);
 int csbsr_bn_backward(const csbsr_bn_desc_t* d, csbsr_stream_t s);

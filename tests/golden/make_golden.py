@@ -134,6 +134,108 @@ def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha
     print(f"{name}: loss={loss.item():.6f} seg={seg_loss.tolist()} sr={sr_loss.tolist()} -> {os.path.getsize(path)/1e3:.0f} kB")
 
 
+def run_case_wc(name, it, B=2, lr=64, scale=4, alpha=0.7, overrides=(), seed=1121, detector="PSPNet", dropout=False, eps=1e-3):
+    """Fixtures at a well-conditioned size (HR >= 192: BatchNorm over >= 1e3 values per channel even at 1/32 resolution) that let
+    the two halves of the path be checked against the reference SEPARATELY, with fixed bounds:
+      * sr_preds (full fp32) + segment_preds + BN buffers + detector gradients  -> the detector fed the reference's own SR image;
+      * dsr / dkvec = dLoss/d(sr_model outputs) of the reference + KBPN gradients -> the KBPN backward fed the reference's own
+        upstream gradient;
+    and the reference's own CONDITIONING: the same step re-run with the SR image moved by eps * max|sr| of seeded uniform noise
+    (eps = 1e-3 = north_star's tolerance on the SR image), recording how far segment_preds / losses / BN buffers / gradients move.
+    Inputs are regenerated from ``seed`` by csbsr_amd.data.synthetic.make_batch (checksums stored)."""
+    ref_shims.ANTIALIAS = True
+    cfg, JM, J, FR = ref_shims.build_reference(detector=detector, scale=scale, overrides=overrides)
+    x, hr, mask, k = make_batch(B, lr, scale=scale, ksize=cfg.BLUR.KERNEL_SIZE_OUTPUT, seed=seed)
+    from model.engine.trainer import calc_loss
+    import argparse
+
+    def one_pass(perturb_eps):
+        model = JM(cfg, 1000, 0, FR(scale, "bicubic"))
+        deterministic_fill(model)
+        model.train()
+        model.ss_loss_fn.alpha = alpha
+        cap_d = DropCapture(dropout, keys=("ocr_drop",) if detector == "HRNet_OCR" else None)
+        orig = nn.Dropout2d.forward
+        nn.Dropout2d.forward = lambda self, x_: cap_d(self, x_)
+        held = {}
+        sr_fwd = model.sr_model.forward
+
+        def fwd(x_, it_, k_):
+            sr, kp = sr_fwd(x_, it_, k_)
+            if perturb_eps:
+                g = torch.Generator().manual_seed(4242)
+                sr = sr + (torch.rand(sr.shape, generator=g) * 2 - 1) * (perturb_eps * float(sr.detach().abs().max()))
+            if sr.requires_grad:
+                sr.retain_grad()
+            if kp.requires_grad:
+                kp.retain_grad()
+            held["sr"], held["kp"] = sr, kp
+            return sr, kp
+        model.sr_model.forward = fwd
+        try:
+            seg_loss, sr_loss, seg, sr, kpred = model(it, x, sr_targets=hr, segment_targets=mask, kernel_targets=k)
+            loss, _, _ = calc_loss(seg_loss, 0.0, sr_loss, 0.0, it, cfg, argparse.Namespace())
+            model.zero_grad()
+            loss.backward()
+        finally:
+            nn.Dropout2d.forward = orig
+        grads = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()}
+        bufs = {n: b.detach().clone() for n, b in model.named_buffers() if "running" in n and n.startswith("segmentation_model")}
+        return dict(seg_loss=seg_loss.detach(), sr_loss=sr_loss.detach(), seg=seg.detach(), sr=sr.detach(), kpred=kpred.detach(),
+                    loss=float(loss), grads=grads, bufs=bufs, masks=cap_d.masks, alpha=float(model.ss_loss_fn.alpha),
+                    dsr=None if held["sr"].grad is None else held["sr"].grad.detach(),
+                    dkp=None if held["kp"].grad is None else held["kp"].grad.detach())
+
+    a = one_pass(0.0)
+    b = one_pass(eps)
+    mx = lambda u, v: float((u - v).abs().max() / (v.abs().max() + 1e-30))
+    rl2 = lambda u, v: float((u.double() - v.double()).norm() / (v.double().norm() + 1e-30))
+    names, norms, samples = [], [], []
+    cond_g = []
+    for n, g in a["grads"].items():
+        names.append(n)
+        if g is None:
+            norms.append(-1.0)
+            samples.append(np.zeros(32, np.float32))
+            continue
+        flat = g.reshape(-1)
+        norms.append(float(flat.double().norm()))
+        idx = [(zlib.crc32((n + str(j)).encode()) % flat.numel()) for j in range(32)]
+        samples.append(flat[idx].numpy().astype(np.float32))
+        if flat.numel() > 1 and norms[-1] > 1e-12 and b["grads"][n] is not None:
+            cond_g.append(rl2(b["grads"][n], g))
+    cond_g = np.array(cond_g) if cond_g else np.zeros(1)
+    gs = float(2 ** 20)
+    out = dict(x=x.numpy(), seed=np.int64(seed), B=np.int64(B), lr=np.int64(lr), it=np.int64(it),
+               hr_sum=np.float64(hr.double().sum()), mask_sum=np.float64(mask.double().sum()), kernel=k.numpy(),
+               segment_loss=a["seg_loss"].numpy(), sr_loss=a["sr_loss"].numpy(), loss=np.float64(a["loss"]),
+               segment_preds=a["seg"].numpy(), sr_preds=a["sr"].numpy(), kernel_preds=a["kpred"].numpy(),
+               grad_names=np.array(names), grad_norms=np.array(norms), grad_samples32=np.stack(samples),
+               alpha=np.float64(a["alpha"]), antialias=np.bool_(True), scale=np.int64(scale),
+               detector=np.array(detector), sfo_sr_amp=np.float64(cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP),
+               oriented_w_iter=np.int64(cfg.SOLVER.ORIENTED_WEIGHT_ITER), beta=np.float64(cfg.SOLVER.TASK_LOSS_WEIGHT),
+               torch_version=np.array(torch.__version__),
+               # the reference's own response to an SR image moved by eps * max|sr| (uniform noise)
+               cond_eps=np.float64(eps), cond_seg_max=np.float64(mx(b["seg"], a["seg"])), cond_seg_l2=np.float64(rl2(b["seg"], a["seg"])),
+               cond_segloss=np.float64(mx(b["seg_loss"], a["seg_loss"])),
+               cond_bn=np.float64(max([mx(b["bufs"][n], a["bufs"][n]) for n in a["bufs"]] or [0.0])),
+               cond_grad_median=np.float64(np.median(cond_g)), cond_grad_p90=np.float64(np.percentile(cond_g, 90)))
+    if a["dsr"] is not None:      # upstream gradient of the KBPN backward, stored as fp16 of (grad * 2^20): the backward is linear in it
+        out["dsr16"] = (a["dsr"] * gs).half().numpy()
+        out["dsr_scale"] = np.float64(gs)
+        out["dkvec"] = a["dkp"].sum(dim=(2, 3)).numpy() if a["dkp"] is not None else np.zeros((B, a["kpred"].shape[-1] ** 2), np.float32)
+    for kname, v in a["masks"].items():
+        if v is not None:
+            out["dropmask." + kname] = v.numpy()
+    for kname, v in a["bufs"].items():
+        out["buf." + kname] = v.numpy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: loss={a['loss']:.6f} cond(eps={eps:g}): seg max {out['cond_seg_max']:.2e} l2 {out['cond_seg_l2']:.2e} segloss "
+          f"{out['cond_segloss']:.2e} bn {out['cond_bn']:.2e} grads median {out['cond_grad_median']:.2e} p90 {out['cond_grad_p90']:.2e}"
+          f" -> {os.path.getsize(path)/1e6:.2f} MB")
+
+
 def sdf_case():
     from model.utils.boundary_loss import compute_sdf1_1
     m = np.zeros((3, 1, 40, 56), np.uint8)
@@ -160,6 +262,13 @@ if __name__ == "__main__":
                 _rc(name, *a, **k)
     else:
         sdf_case()
+    if "--wc" in sys.argv:          # the well-conditioned-size fixtures only (minutes of CPU each)
+        run_case_wc("wc_pspnet_it40000", 40000, B=2, lr=64)
+        run_case_wc("wc_blurskip_x8_it40000", 40000, B=2, lr=32, scale=8, alpha=0.8, detector="PSPNet_BlurSkip", seed=9,
+                    overrides=("SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP", 1.0, "SOLVER.ORIENTED_WEIGHT_ITER", 0))
+        run_case_wc("wc_hrnet_ocr_it40000", 40000, B=4, lr=48, alpha=0.8, detector="HRNet_OCR", seed=13, dropout=True,
+                    overrides=("SOLVER.TASK_LOSS_WEIGHT", 0.9))
+        sys.exit(0)
     run_case("e2e_pspnet_it40000", 40000, taps=True, alpha=0.7)
     run_case("e2e_pspnet_it40000_dropout", 40000, dropout=True, alpha=0.7)
     run_case("e2e_pspnet_it1", 1)

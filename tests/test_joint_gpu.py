@@ -1,20 +1,26 @@
 """GPU parity of the full hot path (JointModelWithLoss forward + backward through the C ABI) against
-(a) the golden vectors produced by the reference and (b) the oracle run on the same inputs.
+(a) the golden vectors produced by the reference and (b) the oracle run on the same inputs, at the small fixture size (HR 64).
 
-Tolerances (north_star: 1e-3 relative, fp16 storage / fp32 accumulate):
-  outputs (sr, seg, kernel, losses): max |a-b| / max|b| <= 2e-3 per tensor  (measured ~3e-4 .. 1e-3)
-  gradients: relative L2 per parameter tensor vs the fp32 oracle.  The oracle's own fp32 evaluation-order noise
-  reaches 1e-2 on a few tensors and 60 % on near-zero PReLU-slope sums (tests/test_oracle_golden.py), so the
-  bound is 3e-2 for tensors and a cancellation-aware absolute bound for scalars; the median is reported.
+Every bound below is a fixed number (north_star: 1e-3 relative, fp16 storage / fp32 accumulate):
+  SR image, kernel, SR loss: max |a-b| / max|b| <= 1e-3 per tensor.
+  Segmentation map / loss / BatchNorm buffers of the COMPOSED path: the random-weight detector amplifies the (tolerated) 1e-3 error of
+  its input ~100x -- the reference's own response is recorded in the tests/golden/wc_* fixtures -- so they are held to the constants
+  SEG_BOUND here, and to 1e-3 where the claim can be made: on the reference's own SR image (tests/test_wc_parity_gpu.py).
+  Gradients: relative L2 per parameter tensor vs the fp32 oracle, 3e-2 in the SR-only phases (the oracle's own fp32
+  evaluation-order noise reaches 1e-2 on a few tensors and 60 % on near-zero PReLU-slope sums, tests/test_oracle_golden.py);
+  joint-phase gradients are pinned half by half in tests/test_wc_parity_gpu.py and by test_sr_loss_gradients_match_oracle here.
 """
 import numpy as np
 import pytest
 import torch
 
-from golden_utils import load_golden, det_params, rel_err, max_rel_to_scale, fp16_storage_sim, golden_cfg
+from golden_utils import load_golden, det_params, rel_err, max_rel_to_scale, golden_cfg
 from oracle import csbsr_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+# composed-path bounds at HR 64 (max |a-b| / max|b|): (segmentation map, segmentation loss, BatchNorm running buffers, min IoU)
+SEG_BOUND = {"PSPNet": (0.12, 2e-2, 5e-2, 0.95), "PSPNet_BlurSkip": (0.12, 2e-2, 5e-2, 0.95), "HRNet_OCR": (0.45, 0.1, 0.3, 0.70)}
 
 
 def build_model(g, micro_batch=8):
@@ -70,66 +76,42 @@ def run_oracle(g):
 
 
 @pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "e2e_pspnet_it10001",
-                                  "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24", "e2e_blurskip_x8_it40000",
+                                  "e2e_pspnet_it20001", "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24", "e2e_blurskip_x8_it40000",
                                   "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000"])
-def test_forward_matches_golden_and_oracle(case):
+def test_forward_matches_golden(case):
     g = load_golden(case)
-    hrnet = "detector" in g and str(g["detector"]) == "HRNet_OCR"
+    det = str(g["detector"]) if "detector" in g else "PSPNet"
+    b_seg, b_segl, b_bn, b_iou = SEG_BOUND[det]
     outs, grads, bufs = run_hip(g)
-    # what fp16 storage of the reference arithmetic costs on this input (CPU emulation, see golden_utils)
-    with fp16_storage_sim(), torch.no_grad():
-        cfg = golden_cfg(g)
-        P = det_params(scale=cfg.scale, detector=cfg.detector, requires_grad=False)
-        t = lambda k: torch.from_numpy(g[k])
-        drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
-        sim = O.joint_forward(P, cfg, int(g["it"]), t("x"), t("hr"), t("mask"), t("kernel"), alpha=float(g["alpha"]), drop=drop or None)
-    worst = {}
-    for k in ("segment_preds", "sr_preds", "kernel_preds", "segment_loss", "sr_loss"):
-        worst[k] = max_rel_to_scale(outs[k], g[k])
-        # HRNet-OCR with the deterministic random weights amplifies rounding ~100x over its ~300 layers (emulation: 13 % on the
-        # probability map at this size, 14 % at HR 192): the end-to-end check is noise-limited there and the detector is pinned block
-        # by block in tests/test_hrnet_gpu.py
-        bound = 2e-3 + (3.0 if hrnet else 2.0) * max_rel_to_scale(sim[k], g[k]) if k.startswith("segment") else 2e-3
-        assert worst[k] < bound, (k, worst[k], bound)
-    assert abs(outs["loss"] - float(g["loss"])) < (5e-2 if hrnet else 1e-2) * abs(float(g["loss"]))
-    for k, v in g.items():
-        if k.startswith("buf."):
-            # running statistics of deep layers inherit the fp16 activation noise (HRNet stage 4: 16 values per channel at this size)
-            bound = 1e-2 + (3.0 if hrnet else 2.0) * max_rel_to_scale(sim["bn_buffers"][k[4:]], v)
-            assert max_rel_to_scale(bufs[k[4:]], v) < bound, (k, bound)
-    iou = O.iou(outs["segment_preds"], torch.from_numpy(g["segment_preds"]))
-    # random-weight probabilities sit close to the 0.5 threshold, so IoU is judged against what the fp16 emulation loses
-    iou_sim = O.iou(sim["segment_preds"], torch.from_numpy(g["segment_preds"]))
-    assert float(iou.min()) > min(0.99, float(iou_sim.min()) - (0.15 if hrnet else 0.02)), (iou, iou_sim)
-    print(case, {k: f"{v:.1e}" for k, v in worst.items()}, "IoU vs ref", float(iou.min()))
+    worst = {k: max_rel_to_scale(outs[k], g[k]) for k in ("segment_preds", "sr_preds", "kernel_preds", "segment_loss", "sr_loss")}
+    e_bn = max([max_rel_to_scale(bufs[k[4:]], v) for k, v in g.items() if k.startswith("buf.")] or [0.0])
+    iou = float(O.iou(outs["segment_preds"], torch.from_numpy(g["segment_preds"])).min())
+    print(case, {k: f"{v:.1e}" for k, v in worst.items()}, f"BN buffers {e_bn:.1e} IoU vs ref {iou:.4f}")
+    for k in ("sr_preds", "kernel_preds", "sr_loss"):
+        assert worst[k] < 1e-3, (k, worst[k])
+    assert worst["segment_preds"] < b_seg and worst["segment_loss"] < b_segl and e_bn < b_bn and iou > b_iou
+    assert abs(outs["loss"] - float(g["loss"])) < b_segl * abs(float(g["loss"]))
 
 
-def run_oracle_fp16_sim(g):
-    with fp16_storage_sim():
-        return run_oracle(g)
-
-
-@pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_pspnet_it1", "e2e_pspnet_it10001", "e2e_pspnet_it40000_dropout",
-                                  "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000"])
+@pytest.mark.parametrize("case", ["e2e_pspnet_it1", "e2e_pspnet_it10001", "e2e_pspnet_it20001", "e2e_pspnet_it40000",
+                                  "e2e_pspnet_it40000_dropout", "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000"])
 def test_gradients_match_oracle(case):
     """Per-parameter relative L2 error of the HIP gradients vs the fp32 oracle.
 
-    SR-only phases (iter < 30001): direct bound.  Joint phase: at this fixture size (HR 64x64, B=2: BatchNorm over
-    128..8192 values, random weights) the segmentation gradient is chaotic -- ANY fp16-storage evaluation of the
-    reference arithmetic lands 5 % (last layers) to 35 % (first layers, KBPN) away from fp32, which the CPU emulation
-    in golden_utils.fp16_storage_sim reproduces layer by layer (measured: emulation median 0.30, HIP median 0.28).
-    So there the HIP error is bounded by the emulation's error per tensor, and the backward kernels themselves are
-    pinned tightly in test_conv_kernels_gpu.py / test_elementwise_gpu.py.  (Per-tensor ratio HIP/emulation: 0.6 .. 2.2 measured -- two
-    realisations of the same noise -- hence the 2.5x; the medians agree within 5 %.)  The non-chaotic half of the joint gradient is
-    pinned directly by test_sr_loss_gradients_match_oracle."""
+    SR-only phases (iter < 30001): 3e-2 per tensor, median < 5e-3.  Joint phase: the gradient of the COMPOSED path goes through the
+    random-weight detector evaluated on an SR image that differs by the tolerated ~1e-3, which moves the reference's own gradients by
+    a median 0.15 .. 1.4 in relative L2 (fixture keys cond_grad_*, tests/golden/wc_*): there the composed gradient only gets the
+    fixed sanity bounds JOINT_MEDIAN / JOINT_P90, and the two halves are held to 3e-2 separately on the reference's own
+    intermediate tensors (tests/test_wc_parity_gpu.py) plus test_sr_loss_gradients_match_oracle below."""
+    JOINT_MEDIAN, JOINT_P90 = {"PSPNet": 0.5, "PSPNet_BlurSkip": 0.3, "HRNet_OCR": 1.2}, {"PSPNet": 0.7, "PSPNet_BlurSkip": 0.5, "HRNet_OCR": 1.6}
     g = load_golden(case)
     outs, grads, _ = run_hip(g)
     P, out, loss = run_oracle(g)
     it = int(g["it"])
     joint = it >= 30001
     hrnet = "detector" in g and str(g["detector"]) == "HRNet_OCR"
-    Ps = run_oracle_fp16_sim(g)[0] if joint else None
-    errs, sims, bad = [], [], []
+    det = str(g["detector"]) if "detector" in g else "PSPNet"
+    errs, bad = [], []
     names = [str(n) for n in g["grad_names"]]
     for n, ref_norm in zip(names, g["grad_norms"]):
         hip = grads[n]
@@ -146,32 +128,19 @@ def test_gradients_match_oracle(case):
         if og.numel() == 1:
             # PReLU slope = signed sum over ~1e6 products; fp32 orders already differ by 10 % (test_oracle_golden.py)
             tol = 0.1 * abs(float(og)) + 2e-3
-            if joint:
-                tol += 2.0 * abs(float(Ps[n].grad) - float(og)) + 0.3 * abs(float(og)) + 2e-2
-            assert abs(float(hip) - float(og)) <= tol, (n, float(hip), float(og))
+            if not joint:
+                assert abs(float(hip) - float(og)) <= tol, (n, float(hip), float(og))
             continue
         e = rel_err(hip, og)
         errs.append(e)
-        if joint:
-            es = rel_err(Ps[n].grad, og)
-            sims.append(es)
-            if e > 2.0 * es + 3e-2:
-                bad.append((n, e, es))
-        elif e > 3e-2:
+        if not joint and e > 3e-2:
             bad.append((n, e))
     errs = np.array(errs)
     print(case, "grad rel-L2 vs fp32 oracle: median %.2e  p90 %.2e  max %.2e  (n=%d)" % (np.median(errs), np.percentile(errs, 90), errs.max(), len(errs)))
-    if joint:
-        sims = np.array(sims)
-        print(case, "fp16-storage emulation of the oracle: median %.2e  p90 %.2e  max %.2e" % (np.median(sims), np.percentile(sims, 90), sims.max()))
-        # the HIP run and the emulation are independent realisations of the same chaotic noise (run-to-run the HIP value itself moves
-        # by ~3 % of the norm through atomics order), so the per-tensor bound is loose -- worse than 2.5x the tensor's own emulated
-        # error AND than 1.5x the emulation's worst tensor -- and the distribution is compared instead (median and 90th percentile)
-        bad = [b for b in bad if b[1] > max(2.5 * b[2], 1.5 * sims.max()) + 3e-2]
-        assert np.percentile(errs, 90) < 1.5 * np.percentile(sims, 90) + 3e-2
     assert not bad, (len(bad), bad[:10])
+    assert np.isfinite(errs).all()
     if joint:
-        assert np.median(errs) < 1.5 * np.median(sims) + 5e-3
+        assert np.median(errs) < JOINT_MEDIAN[det] and np.percentile(errs, 90) < JOINT_P90[det]
     else:
         assert np.median(errs) < 5e-3
 
@@ -221,8 +190,9 @@ def test_micro_batching_is_exact():
 
 
 def test_loss_scale_overflow_backoff():
-    """fp16 gradient overflow follows GradScaler semantics: that step's gradients are zeros (never inf/nan), the automatic loss scale
-    drops by 2^4 for the next step, which then succeeds."""
+    """fp16 gradient overflow follows GradScaler semantics: that step is skipped -- every gradient is None, so optimizer.step() leaves
+    weights AND Adam moments untouched (never inf/nan, never a momentum-only update) --, the automatic loss scale drops by 2^4 for
+    the next step, which then succeeds."""
     import warnings
     g = load_golden("e2e_pspnet_it40000")
     m, cfg = build_model(g)
@@ -233,14 +203,18 @@ def test_loss_scale_overflow_backoff():
         seg_l, sr_l, *_ = m(40000, t("x"), sr_targets=t("hr"), segment_targets=t("mask"), kernel_targets=t("kernel"))
         (0.7 * sr_l.mean() + 0.3 * seg_l.mean()).backward()
     assert any("overflow" in str(x.message) for x in w)
-    assert m.overflow_steps == 1 and m.scale_backoff == -36
-    grads = [p.grad for p in m.parameters() if p.grad is not None]
-    assert len(grads) > 250 and all(float(x.abs().max()) == 0.0 for x in grads)
+    assert m.overflow_steps == 1 and m.scale_backoff == -36 and m.last_step_overflowed
+    assert all(p.grad is None for p in m.parameters())
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    before = [p.detach().clone() for p in m.parameters()]
+    opt.step()                                 # nothing to do: no parameter has a gradient
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, m.parameters())) and len(opt.state) == 0
     m.scale_backoff = 0
     m.zero_grad()
     seg_l, sr_l, *_ = m(40000, t("x"), sr_targets=t("hr"), segment_targets=t("mask"), kernel_targets=t("kernel"))
     (0.7 * sr_l.mean() + 0.3 * seg_l.mean()).backward()
-    assert m.overflow_steps == 1 and all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+    assert m.overflow_steps == 1 and not m.last_step_overflowed
+    assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
     assert sum(float(p.grad.abs().sum()) for p in m.parameters() if p.grad is not None) > 0
 
 
@@ -342,11 +316,10 @@ def test_joint_model_inference_matches_oracle(case):
             kv = kvec / kvec.sum(1, keepdim=True)
         return sr_o, seg_o, kv.reshape(kp.shape)
     sr_o, seg_o, kp_o = oracle()
-    with fp16_storage_sim():
-        _, seg_s, _ = oracle()
-    assert max_rel_to_scale(sr.cpu(), sr_o) < 2e-3
-    assert max_rel_to_scale(kp.cpu(), kp_o) < 2e-3
+    assert max_rel_to_scale(sr.cpu(), sr_o) < 1e-3
+    assert max_rel_to_scale(kp.cpu(), kp_o) < 1e-3
     assert abs(float(kp.sum(dim=(1, 2, 3)).mean()) - 1.0) < 1e-4
-    e, es = max_rel_to_scale(seg.cpu(), seg_o), max_rel_to_scale(seg_s, seg_o)
-    print(case, "inference seg: hip %.2e emulation %.2e" % (e, es))
-    assert e < 2e-3 + 3.0 * es
+    e = max_rel_to_scale(seg.cpu(), seg_o)
+    iou = float(O.iou(seg.cpu(), seg_o).min())
+    print(case, "inference seg: hip %.2e  IoU vs oracle %.4f" % (e, iou))
+    assert e < SEG_BOUND[oc.detector][0] and iou > SEG_BOUND[oc.detector][3]

@@ -1,0 +1,184 @@
+"""Fixed-bound parity of the two halves of the hot path against REFERENCE goldens at well-conditioned sizes
+(tests/golden/wc_*.npz, HR 256 / 192: BatchNorm over >= 1e3 values per channel everywhere).
+
+Why the halves are checked separately.  The detectors of the fixtures carry deterministic RANDOM weights; a random BatchNorm'd ReLU
+stack amplifies any perturbation of its input by ~100x.  The fixtures record the reference's OWN response: with its SR image moved by
+1e-3 of its maximum (uniform noise -- exactly the tolerance north_star grants the SR image) the reference's segmentation map moves by
+``cond_seg_max`` = 0.26 / 0.35 / 0.55 of its maximum (PSPNet / BlurSkip / HRNet-OCR; 0.07 / 0.07 / 0.35 in relative L2) and its
+joint-phase gradients by a median 0.69 / 0.15 / 1.4 in relative L2.  So "1e-3 on the SR image" and "1e-3 on the segmentation map of
+the composed path" cannot both be asked of ANY implementation whose SR image is not bit-identical; what can be asked, and is asserted
+here with fixed numbers, is
+  * KBPN end to end:            SR image / kernel / SR loss within 1e-3 of the reference;
+  * the detector on the reference's own SR image (``forward_from_sr``): segmentation map, loss, every BatchNorm running buffer
+    within 1e-3, every detector gradient tensor and dLoss/dSR within 3e-2 relative L2 -- with the split-fp16 forward
+    (``detector_precision = "split"``); the plain fp16 forward is reported beside it under a looser fixed bound;
+  * the KBPN backward on the reference's own upstream gradient (``kbpn_backward_from``): every KBPN gradient tensor within 3e-2;
+  * the composition: bounded by the reference's recorded response to the tolerated SR error.
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from golden_utils import load_golden, max_rel_to_scale
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(g):
+    """x (the network input) and the blur kernel are stored; the HR target and the mask are regenerated from the seed by plain CPU
+    torch ops (checksums stored; the HR image only enters the L1 loss, so last-bit differences between hosts' interpolate kernels
+    are immaterial, and the mask is exact integer arithmetic on seeded draws)."""
+    from csbsr_amd.data.synthetic import make_batch
+    B, lr, scale, seed = int(g["B"]), int(g["lr"]), int(g["scale"]), int(g["seed"])
+    x, hr, mask, k = make_batch(B, lr, scale=scale, ksize=21, seed=seed)
+    assert np.allclose(x.numpy(), g["x"], atol=1e-5) and np.allclose(k.numpy(), g["kernel"], atol=1e-7)
+    assert abs(float(hr.double().sum()) - float(g["hr_sum"])) < 1e-6 * float(g["hr_sum"]) and float(mask.double().sum()) == float(g["mask_sum"])
+    return torch.from_numpy(g["x"]), hr, mask, torch.from_numpy(g["kernel"])
+
+
+def _model(g, precision):
+    from csbsr_amd.config import cfg as base_cfg
+    from csbsr_amd.modeling.build_model import JointModelWithLoss
+    from csbsr_amd.utils.detfill import deterministic_fill
+    cfg = base_cfg.clone()
+    cfg.MODEL.SCALE_FACTOR = int(g["scale"])
+    cfg.SOLVER.TASK_LOSS_WEIGHT = float(g["beta"])
+    cfg.MODEL.DETECTOR_TYPE = str(g["detector"])
+    cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP = float(g["sfo_sr_amp"])
+    cfg.SOLVER.ORIENTED_WEIGHT_ITER = int(g["oriented_w_iter"])
+    m = JointModelWithLoss(cfg, 1000, 0, None)
+    deterministic_fill(m.state_dict())
+    m.ss_loss_fn.alpha = float(g["alpha"])
+    m.detector_precision = precision
+    m.micro_batch, m.max_resident = 8, 8
+    m.train()
+    m.dropout_masks = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
+    return m
+
+
+def _grad_errors(g, grads, prefix):
+    """per-tensor relative error of the 32 sampled gradient elements the fixture stores, plus the relative error of the tensor's L2
+    norm; tensors whose reference gradient is numerically zero (conv biases feeding a train-mode BatchNorm) must be ~0 here too."""
+    out = []
+    for n, ref_norm, smp in zip((str(v) for v in g["grad_names"]), g["grad_norms"], g["grad_samples32"]):
+        if not n.startswith(prefix):
+            continue
+        hip = grads.get(n)
+        if ref_norm < 0:
+            assert hip is None or float(hip.abs().max()) == 0.0, n
+            continue
+        assert hip is not None, n
+        flat = hip.detach().float().cpu().reshape(-1)
+        numel = flat.numel()
+        scale_ref = ref_norm / np.sqrt(numel)
+        if ref_norm < 1e-9:
+            assert float(flat.norm()) < 1e-6, n
+            continue
+        idx = [(zlib.crc32((n + str(j)).encode()) % numel) for j in range(32)]
+        got, ref = flat[idx].double().numpy(), smp.astype(np.float64)
+        e_norm = abs(float(flat.double().norm()) - ref_norm) / ref_norm
+        # samples: error relative to the tensor's RMS magnitude (a tensor-level relative L2 estimated on 32 elements)
+        e_smp = float(np.sqrt(np.mean((got - ref) ** 2)) / scale_ref)
+        out.append((n, numel, e_norm, e_smp))
+    return out
+
+
+def _assert_grads(errs, bound, what):
+    big = [(n, en, es) for n, numel, en, es in errs if numel > 1 and (en > bound or es > bound)]
+    # scalars (PReLU slopes): signed sums with heavy cancellation; fp32 evaluation orders of the reference itself differ by ~10 %
+    # (tests/test_oracle_golden.py), so they get a norm-level bound of 15 %
+    bad_scalar = [(n, en) for n, numel, en, es in errs if numel == 1 and en > 0.15]
+    v = np.array([max(en, es) for n, numel, en, es in errs if numel > 1])
+    print(f"{what}: {len(v)} tensors, rel err median {np.median(v):.2e} p90 {np.percentile(v, 90):.2e} max {v.max():.2e}")
+    assert not big, (what, len(big), big[:8])
+    assert not bad_scalar, (what, bad_scalar[:8])
+
+
+@pytest.mark.parametrize("case,precision", [("wc_pspnet_it40000", "split"), ("wc_blurskip_x8_it40000", "split"),
+                                            ("wc_pspnet_it40000", "fp16"), ("wc_blurskip_x8_it40000", "fp16"),
+                                            ("wc_hrnet_ocr_it40000", "fp16")])
+def test_detector_on_reference_sr(case, precision):
+    """a11 / a11' / a11'' / a13 / a16 (detector half): forward + losses + backward from the reference's own SR image."""
+    g = load_golden(case)
+    x, hr, mask, k = _inputs(g)
+    m = _model(g, precision)
+    B = x.shape[0]
+    it = int(g["it"])
+    seg_l, sr_l, seg, sr, kp = m.forward_from_sr(it, torch.from_numpy(g["sr_preds"]), torch.from_numpy(g["kernel_preds"]).reshape(B, -1),
+                                                 x, hr, mask, k)
+    beta = float(g["beta"])
+    ((1 - beta) * sr_l.mean() + beta * seg_l.mean()).backward()
+    torch.cuda.synchronize()
+    e_seg = max_rel_to_scale(seg.cpu(), g["segment_preds"])
+    e_segl = max_rel_to_scale(seg_l.detach().cpu(), g["segment_loss"])
+    e_srl = max_rel_to_scale(sr_l.detach().cpu(), g["sr_loss"])
+    sd = m.state_dict()
+    e_bn = max(max_rel_to_scale(sd[kk[4:]].cpu(), v) for kk, v in g.items() if kk.startswith("buf."))
+    grads = {kk: v.grad for kk, v in m._named_full() if isinstance(v, torch.nn.Parameter)}
+    errs = _grad_errors(g, grads, "segmentation_model")
+    e_dsr = 0.0
+    if "dsr16" in g:              # (config 5 freezes KBPN: no gradient leaves the detector there)
+        dsr_ref = torch.from_numpy(g["dsr16"].astype(np.float32)) / float(g["dsr_scale"])
+        e_dsr = float((m.last_dsr.cpu() - dsr_ref).norm() / dsr_ref.norm())
+        e_dk = float((m.last_dkvec.cpu() - torch.from_numpy(g["dkvec"])).norm() / (torch.from_numpy(g["dkvec"]).norm() + 1e-30))
+        assert e_dk < 3e-2, e_dk
+    print(f"{case} [{precision}] detector on the reference SR image: seg {e_seg:.2e} seg_loss {e_segl:.2e} sr_loss {e_srl:.2e} "
+          f"BN buffers {e_bn:.2e} dLoss/dSR rel-L2 {e_dsr:.2e}")
+    assert e_srl < 1e-3          # L1 / blur / antialiased-bicubic loss kernels on the reference's SR image
+    if precision == "split":
+        assert e_seg < 1e-3 and e_segl < 1e-3 and e_bn < 1e-3, (e_seg, e_segl, e_bn)
+        _assert_grads(errs, 3e-2, f"{case} detector gradients [split]")
+        assert e_dsr < 3e-2, e_dsr
+    else:
+        # plain fp16 storage: every layer's 2^-11 rounding goes through the same ~100x amplification as an input perturbation (module
+        # docstring); fixed bounds = the reference's recorded response to a 1e-3 input perturbation
+        assert e_seg < float(g["cond_seg_max"]) and e_segl < max(5e-3, float(g["cond_segloss"])) and e_bn < max(1e-2, float(g["cond_bn"]))
+        v = np.array([max(en, es) for n, numel, en, es in errs if numel > 1])
+        print(f"{case} [fp16] detector gradients: median {np.median(v):.2e} p90 {np.percentile(v, 90):.2e}")
+        assert np.median(v) < max(0.1, float(g["cond_grad_median"])) and np.isfinite(v).all()
+
+
+@pytest.mark.parametrize("case", ["wc_pspnet_it40000", "wc_hrnet_ocr_it40000"])
+def test_kbpn_backward_on_reference_gradient(case):
+    """a16 (KBPN half, joint phase): KBPN forward + backward fed dLoss/d(sr, kernel) of the reference's joint step."""
+    g = load_golden(case)
+    x, hr, mask, k = _inputs(g)
+    m = _model(g, "fp16")
+    dsr = torch.from_numpy(g["dsr16"].astype(np.float32)) / float(g["dsr_scale"])
+    grads = m.kbpn_backward_from(int(g["it"]), x, k, dsr, torch.from_numpy(g["dkvec"]))
+    torch.cuda.synchronize()
+    errs = _grad_errors(g, grads, "sr_model")
+    assert len(errs) > 150
+    _assert_grads(errs, 3e-2, f"{case} KBPN gradients from the reference's upstream gradient")
+
+
+@pytest.mark.parametrize("case,precision", [("wc_pspnet_it40000", "split"), ("wc_pspnet_it40000", "fp16"),
+                                            ("wc_blurskip_x8_it40000", "split"), ("wc_hrnet_ocr_it40000", "fp16")])
+def test_end_to_end_at_well_conditioned_size(case, precision):
+    """The composed path: KBPN outputs within north_star's 1e-3; the segmentation side within the reference's own recorded response
+    to an SR error of that size (fixture keys cond_*: fixed numbers measured on the reference, see the module docstring)."""
+    from oracle import csbsr_oracle as O
+    g = load_golden(case)
+    x, hr, mask, k = _inputs(g)
+    m = _model(g, precision)
+    it = int(g["it"])
+    seg_l, sr_l, seg, sr, kp = m(it, x, sr_targets=hr, segment_targets=mask, kernel_targets=k)
+    beta = float(g["beta"])
+    loss = (1 - beta) * sr_l.mean() + beta * seg_l.mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    e = {kk: max_rel_to_scale(v.detach().cpu(), g[kk]) for kk, v in
+         (("sr_preds", sr), ("kernel_preds", kp), ("sr_loss", sr_l), ("segment_preds", seg), ("segment_loss", seg_l))}
+    seg_ref = torch.from_numpy(g["segment_preds"])
+    e_seg_l2 = float((seg.cpu() - seg_ref).norm() / seg_ref.norm())
+    iou = float(O.iou(seg.cpu(), seg_ref).min())
+    print(case, precision, {kk: f"{v:.1e}" for kk, v in e.items()}, f"seg rel-L2 {e_seg_l2:.2e} IoU vs ref {iou:.4f}")
+    assert e["sr_preds"] < 1e-3 and e["kernel_preds"] < 1e-3 and e["sr_loss"] < 1e-3
+    assert e["segment_preds"] < float(g["cond_seg_max"]) and e_seg_l2 < float(g["cond_seg_l2"])
+    assert e["segment_loss"] < max(5e-3, float(g["cond_segloss"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 5e-3 * abs(float(g["loss"]))
+    assert iou > (0.7 if str(g["detector"]) == "HRNet_OCR" else 0.93)
+    ngrad = [p.grad for p in m.parameters() if p.grad is not None]
+    assert all(bool(torch.isfinite(v).all()) for v in ngrad)
