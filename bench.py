@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--workload", default="pspnet_x4", choices=("pspnet_x4", "blurskip_x8", "hrnet_x4"),
                     help="pspnet_x4 = BASELINE config 2 (the bench line); blurskip_x8 = config 5 (x8, PSPNet_BlurSkip, w^F; use --lr-size 224 "
                          "--batch 4); hrnet_x4 = config 4 (HRNet-W48 + OCR, beta 0.9; use --batch 4) -- coverage timings, not the headline")
+    ap.add_argument("--detector-precision", default="fp16", choices=("fp16", "split"),
+                    help="fp16 = north_star's plan (the bench line); split = hi+lo fp16 detector forward (parity mode, cost reported in DESIGN.md)")
+    ap.add_argument("--no-h2d-leg", action="store_true", help="skip the extra (untimed-for-value) leg that re-times the step with the PCIe copy of the batch inside")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dump-layers", default=None, help="write the per-launch conv / wgrad log of the timed region (layer, shape, kernel, ms) as JSON")
@@ -115,6 +118,7 @@ def main():
     scale = cfg.MODEL.SCALE_FACTOR
     model = JointModelWithLoss(cfg, 9000, 40000, None, device=str(dev))
     model.micro_batch = args.micro_batch
+    model.detector_precision = args.detector_precision
     model.max_resident = None if args.max_resident < 0 else args.max_resident     # None: as many as the free HBM allows
     model.train()
     rt = model._runtime()
@@ -134,9 +138,15 @@ def main():
     it = 40000
     beta = cfg.SOLVER.TASK_LOSS_WEIGHT
 
+    host = None
+
     def step():
         opt.zero_grad(set_to_none=True)
-        seg_l, sr_l, seg, sr, kp = model(it, x, sr_targets=hr, segment_targets=mask, kernel_targets=k)
+        if host is not None:        # H2D leg only: the batch crosses PCIe inside the step, as the reference's loader hands it over
+            xx, hh, mm, kk = (t.to(dev, non_blocking=True) for t in host)
+        else:
+            xx, hh, mm, kk = x, hr, mask, k
+        seg_l, sr_l, seg, sr, kp = model(it, xx, sr_targets=hh, segment_targets=mm, kernel_targets=kk)
         loss = (1 - beta) * sr_l.mean() + beta * seg_l.mean()          # trainer.py:406-438, iter >= 30001
         loss.backward()
         opt.step()
@@ -164,28 +174,48 @@ def main():
         dt = float(tt)
     ms = dt / args.steps * 1e3
     imgs = B * world * args.steps / dt
+    timing_log, eng.timing = eng.timing, None
+    # ---- extra leg (never `value`): the same step with the host -> device copy of the batch inside it (SURVEY 8d counts it; the
+    # bench contract wants inputs resident).  Pinned host buffers, a few steps.
+    h2d = None
+    if not args.no_h2d_leg and world == 1:
+        host = tuple(t.cpu().pin_memory() for t in (x, hr, mask, k))
+        n2 = max(2, min(5, args.steps))
+        step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n2):
+            step()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        h2d = {"imgs_per_s": round(B * n2 / dt2, 4), "ms_per_step": round(dt2 / n2 * 1e3, 1), "steps": n2,
+               "batch_bytes": int(sum(t.numel() * t.element_size() for t in host))}
+        host = None
 
     roof = None
-    if eng.timing and args.dump_layers and rank == 0:
+    if timing_log and args.dump_layers and rank == 0:
         json.dump([{"kind": t[0], "flops": t[1], "bytes": t[2], "ms": t[3].elapsed_time(t[4]), "layer": t[5], "shape": list(t[6]),
-                    "kernel": (t[7] if len(t) > 7 else -1)} for t in eng.timing], open(args.dump_layers, "w"))
-    if eng.timing:
+                    "kernel": (t[7] if len(t) > 7 else -1)} for t in timing_log], open(args.dump_layers, "w"))
+    if timing_log:
         # one roofline block = ONE kernel: the conv kernel with the largest share of the timed region (csbsr_debug_last_conv_kernel tags
         # every launch with the kernel it dispatched to).  achieved = algorithmic FLOPs of those launches / their HIP-event time.
         names = {0: "conv_igemm_kernel<32,4,1>", 1: "conv_igemm_kernel<64,2,2>", 2: "conv_igemm_kernel<128,2,2>",
                  3: "conv_igemm_glds_kernel<128,2,2>", 4: "conv_igemm_glds_kernel<256,4,3>", 5: "conv_thin_cout_kernel",
                  6: "conv_thin_cin_kernel", 7: "conv_igemm_glds_kernel<256,4,2,2>"}
+        wnames = {0: "conv_wgrad_kernel<128,128,2,2>", 1: "conv_wgrad_kernel<128,256,2,4>", 2: "conv_wgrad_kernel<64,128,2,2>",
+                  3: "conv_wgrad_kernel<32,128,1,4>", 4: "conv_wgrad_thin_kernel", 5: "conv_wgrad_glds_kernel<128,128>",
+                  6: "conv_wgrad_glds_kernel<128,256>", 7: "conv_wgrad_glds_kernel<256,256>"}
         per = {}
-        for t in eng.timing:
-            key = names.get(t[7], "conv?") if t[0] == "conv" else "conv_wgrad_kernel (all variants)"
+        for t in timing_log:
+            key = names.get(t[7], "conv?") if t[0] == "conv" else wnames.get(t[7] if len(t) > 7 else -1, "conv_wgrad?")
             a = per.setdefault(key, [0.0, 0.0, 0.0, 0])
             a[0] += t[1]; a[1] += t[2]; a[2] += t[3].elapsed_time(t[4]) * 1e-3; a[3] += 1
-        conv_only = {k: v for k, v in per.items() if not k.startswith("conv_wgrad")}
-        dom = max(conv_only, key=lambda k: conv_only[k][2])
+        # the dominant kernel is chosen over EVERY MFMA kernel of the step, each wgrad variant on its own
+        dom = max(per, key=lambda k: per[k][2])
         fl, by, tt, nl = per[dom]
         ach = fl / tt / 1e12
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(tpath) and args.workload == "pspnet_x4":
             try:
                 tj = json.load(open(tpath))
@@ -194,7 +224,7 @@ def main():
                 traffic = None
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r01_pmc_traffic.json; "
+                "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r02_pmc_traffic.json; "
                                 "FETCH_SIZE doubled per MI355X_MICROARCH.md), same command at --batch 4 (one KBPN micro-batch of 4, as in the default run)" if traffic else None,
                 "launches": nl, "avg_launch_ms": round(tt * 1e3 / max(nl, 1), 4),
                 "alg_flop_per_launch": round(fl / max(nl, 1) / 1e9, 2), "alg_flop_unit": "GFLOP",
@@ -207,7 +237,8 @@ def main():
         per_img_s = dt / (B * args.steps)
         out = {"metric": "training imgs/s (448->1792 x4, PSPNet)" if not other else f"training imgs/s ({args.workload})", "value": round(imgs, 4), "unit": "imgs/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 1), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "fp16 storage / fp32 accumulate", "data": "synthetic",
+               "vs_baseline": None, "dtype": "fp16 storage / fp32 accumulate" + (" (detector forward: split fp16 hi+lo)" if args.detector_precision == "split" else ""),
+               "data": "synthetic",
                "config": {"workload": f"CSBSR KBPN x{scale} + {cfg.MODEL.DETECTOR_TYPE}, beta={beta}, joint phase (iter 40000), per-GPU batch {B}, "
                                       f"LR {lr}x{lr} -> HR {lr * scale}x{lr * scale}, fwd+loss+bwd+Adam", "global_batch": B * world,
                           "micro_batch": args.micro_batch, "parallelism": f"dp{world}"},
@@ -216,7 +247,8 @@ def main():
                                  "mfma_frac": round(ALG_TFLOP_PER_IMG_448 * pix / per_img_s / MFMA_PEAK_TFLOPS, 4),
                                  "note": "algorithmic work per image at LR 448 after exact constant-operand folding (fe_kernel.0 + SFT code channels): 73.3 TFLOP / 213.7 GB (SURVEY.md 8(d) as-executed: 108.3 TFLOP / 249 GB)"},
                "roofline": roof,
-               "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
+               "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+               "with_h2d_inside_step": h2d}
         if other:
             out["step_roofline"] = None          # the folded-work figures above are config 2's
         if not args.no_cpu_baseline and world == 1 and not other:

@@ -122,6 +122,7 @@ DEBUG_SIGNATURES = {
     "csbsr_debug_set_wgrad_tr": (None, [i32]),
     "csbsr_debug_set_conv_glds": (None, [i32]),
     "csbsr_debug_last_conv_kernel": (i32, []),
+    "csbsr_debug_last_wgrad_kernel": (i32, []),
 }
 
 _lib = None

@@ -10,25 +10,7 @@
 #include "common.h"
 #include "csbsr_debug.h"
 
-#define WG_BP 64     // pixels per reduction step
-#define WG_BN 128    // columns (tap,channel) per tile
-typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
-
-struct WgradK {
-  const half_t* a; long a_sn, a_sy, a_sx; int ca;
-  csbsr_seg_t b[2]; int cb0, cbtot;
-  int N, AH, AW, BH, BW;
-  int KH, KW, stride, pad, dil;
-  float* g; int ktot;        // row length of G
-  long M;                    // N*AH*AW
-  long per_split;            // pixels per split (multiple of 32)
-  unsigned tiles_a, tiles_b;
-  int ca_real;               // real channels of A (thin kernel: rows = (tap, channel))
-  int tap_perm;              // 1: XCD-aware tap order of the 8x8 stride-4 layers (see the kernel)
-  int flat;                  // 1: 1-D grid over (split, tile): all tiles of one pixel split run on ONE XCD (see the kernel)
-  int splits;
-  int row_shift;             // 1: per-tile pixel-range shift that aligns the gathered rows of taps a stride apart (see the kernel)
-};
+#include "conv_wgrad.h"
 
 template <bool USE_TR>
 __device__ __forceinline__ h8 frag_T(const half_t* tile, int ld, int pix0, int ch) {
@@ -256,6 +238,9 @@ __global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgradK p
   WTS_FLUSH;
 }
 
+// which kernel the calling thread's last csbsr_conv_wgrad dispatched to (csbsr_debug.h): 0 <128,128>, 1 <128,256>, 2 <64,128>, 3 <32,128>, 4 thin
+static thread_local int g_last_wgrad_kernel = -1;
+extern "C" int32_t csbsr_debug_last_wgrad_kernel(void) { return g_last_wgrad_kernel; }
 static int g_wgrad_use_tr = 1;
 static int g_wgrad_thin = 1;
 static int g_wgrad_tap_perm = 1;
@@ -263,7 +248,14 @@ static int g_wgrad_row_shift = 1;
 static int g_wgrad_wide = 1;
 static int g_wgrad_extra_lds = 0;   // A/B: dynamic LDS bytes added to the launch to lower the occupancy
 static int g_wgrad_flat = 1;     // 0 off, 1 every layer without the tap permutation, 2 every layer
-extern "C" void csbsr_debug_set_wgrad_tr(int v) { g_wgrad_use_tr = v & 1; g_wgrad_thin = !(v & 2); g_wgrad_tap_perm = !(v & 4); g_wgrad_flat = (v & 8) ? 0 : ((v & 16) ? 2 : 1); g_wgrad_row_shift = !(v & 32); g_wgrad_wide = !(v & 64); g_wgrad_extra_lds = (v >> 8) * 1024; }
+extern "C" void csbsr_debug_set_wgrad_tr(int v) {
+  g_wgrad_use_tr = v & 1; g_wgrad_thin = !(v & 2); g_wgrad_tap_perm = !(v & 4); g_wgrad_flat = (v & 8) ? 0 : ((v & 16) ? 2 : 1);
+  g_wgrad_row_shift = !(v & 32); g_wgrad_wide = !(v & 64);
+  // bit 7: register-staged kernel everywhere; bit 0 clear (scalar LDS transposition) implies it -- the LDS-DMA kernel only has the
+  // hardware-transpose read; bits 8..9: LDS-DMA tile menu (256: no 256 x 256 tile, 512: no 128 x 256 tile)
+  g_wgrad_glds = ((v & 128) || !(v & 1)) ? 0 : (1 | ((v & 256) ? 0 : 2) | ((v & 512) ? 4 : 0));
+  g_wgrad_extra_lds = ((v >> 12) & 0xff) * 1024;
+}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Thin-A variant: stride-1 "same" conv whose output has so few channels that KH*KW*ca_real <= 32 (the 3-channel image heads:
@@ -386,15 +378,24 @@ static bool wgrad_is_thin(const csbsr_wgrad_desc_t* d) {
 }
 
 static int wgrad_tile_a(int ca) { return ca > 64 ? 128 : (ca > 32 ? 64 : 32); }
+static int wgrad_tile_n(int ca, int ktot, bool perm8);
+// tile shape the dispatch below will use for a problem (the pixel splits, the flat grid and the tap permutation depend on it)
+static void wgrad_tiles(int ca, int ktot, bool perm8, int& BA, int& BN) {
+  WgradK t{};
+  t.ca = ca; t.ktot = ktot; t.tap_perm = perm8 ? 1 : 0;
+  if (wgrad_glds_eligible(t)) { BA = wgrad_glds_tile_a(t); BN = wgrad_glds_tile_n(t); }
+  else { BA = wgrad_tile_a(ca); BN = wgrad_tile_n(ca, ktot, perm8); }
+}
 // 128 x 256 tiles on 8 waves (each wave still owns 64 x 64) for the layers with thousands of columns: the kernel is bound by what a CU
 // can load (~16 B/clk, scripts/ts_wgrad.py) and the wide tile moves 48 KB per 64-pixel step for twice the MFMAs of the 32 KB square
 // one.  One such workgroup fits per CU (158 VGPRs x 8 waves), so it only pays where the pixel loops are long: +10..16 % on the SFT and
 // decoder 3x3 layers, -20 % on a 9-tile 128-channel 3x3, -2 % on the tap-permuted 8x8 stride-4 layers (which keep the square tile).
-static int wgrad_tile_n(int ca, int ktot, bool perm8 = false) { return (g_wgrad_wide && ca > 64 && ktot >= 6144 && !perm8) ? 256 : 128; }
+static int wgrad_tile_n(int ca, int ktot, bool perm8) { return (g_wgrad_wide && ca > 64 && ktot >= 6144 && !perm8) ? 256 : 128; }
 
 // number of pixel-range splits (= fp32 slabs the caller must provide) for a problem
 static int32_t wgrad_splits_impl(int32_t ca, int32_t ktot, int64_t M, bool perm8) {
-  const int BA = wgrad_tile_a(ca), BN = wgrad_tile_n(ca, ktot, perm8);
+  int BA, BN;
+  wgrad_tiles(ca, ktot, perm8, BA, BN);
   const long ntile = (long)((ca + BA - 1) / BA) * ((ktot + BN - 1) / BN);
   long want = (1536 + ntile - 1) / ntile;
   long maxs = (M + WG_BP * 8 - 1) / (WG_BP * 8);
@@ -432,6 +433,16 @@ extern "C" int32_t csbsr_wgrad_splits_desc(const csbsr_wgrad_desc_t* d) {
   return wgrad_splits_impl(d->ca, ktot, (long)d->N * d->AH * d->AW, perm8);
 }
 
+// locality switches shared by both kernels: per-tile row shift of the strided layers, flat (split, tile) grid
+static void wgrad_locality(WgradK& p, int BA, int BN, int splits) {
+  const unsigned ntile = (unsigned)((p.ca + BA - 1) / BA) * (unsigned)((p.ktot + BN - 1) / BN);
+  const long per_split = ((p.M + splits - 1) / splits + WG_BP - 1) / WG_BP * WG_BP;
+  // the shift must leave the first split non-empty (slabs are written, not accumulated)
+  p.row_shift = (g_wgrad_row_shift && p.stride > 1 && (long)((p.KH - 1) * p.dil / p.stride) * p.AW < per_split) ? 1 : 0;
+  if (g_wgrad_flat == 2) { p.flat = 1; p.tap_perm = 0; }
+  else p.flat = (g_wgrad_flat == 1 && !p.tap_perm && ntile <= 48) ? 1 : 0;   // measured: +5..25 % up to ~40 tiles, -1..2 % for the 100+ tile layers
+}
+
 template <int BA, int BN, int WA, int WB>
 static int launch_wgrad(const WgradK& k, int splits, hipStream_t st) {
   WgradK p = k;
@@ -444,10 +455,7 @@ static int launch_wgrad(const WgradK& k, int splits, hipStream_t st) {
     return 1;
   }
   p.splits = splits;
-  // the shift must leave the first split non-empty (slabs are written, not accumulated)
-  p.row_shift = (g_wgrad_row_shift && k.stride > 1 && (long)((k.KH - 1) * k.dil / k.stride) * k.AW < p.per_split) ? 1 : 0;
-  if (g_wgrad_flat == 2) { p.flat = 1; p.tap_perm = 0; }
-  else p.flat = (g_wgrad_flat == 1 && !p.tap_perm && ntile <= 48) ? 1 : 0;   // measured: +5..25 % up to ~40 tiles, -1..2 % for the 100+ tile layers
+  wgrad_locality(p, BA, BN, splits);
   dim3 grid(p.flat ? ntile * splits : ntile, 1, p.flat ? 1 : splits);
   if (g_wgrad_use_tr)
     hipLaunchKernelGGL((conv_wgrad_kernel<BA, BN, WA, WB, true>), grid, dim3(64 * WA * WB), g_wgrad_extra_lds, st, p);
@@ -481,15 +489,25 @@ extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
       return 1;
     }
     dim3 grid((k.cbtot + WG_BN - 1) / WG_BN, 1, d->splits);
+    g_last_wgrad_kernel = 4;
     if (g_wgrad_use_tr) hipLaunchKernelGGL((conv_wgrad_thin_kernel<true>), grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL((conv_wgrad_thin_kernel<false>), grid, dim3(256), 0, st, k);
     CSBSR_LAUNCH_CHECK("csbsr_conv_wgrad(thin)");
     return 0;
   }
+  if (wgrad_glds_eligible(k)) {
+    const int ta = wgrad_glds_tile_a(k), tn = wgrad_glds_tile_n(k);
+    g_last_wgrad_kernel = ta == 256 ? 7 : (tn == 256 ? 6 : 5);
+    k.ca_real = 0;
+    wgrad_locality(k, ta, tn, d->splits);
+    return wgrad_glds_launch(k, d->splits, st);
+  }
   if (d->ca > 64) {
-    if (wgrad_tile_n(d->ca, k.ktot, k.tap_perm != 0) == 256) return launch_wgrad<128, 256, 2, 4>(k, d->splits, st);
+    if (wgrad_tile_n(d->ca, k.ktot, k.tap_perm != 0) == 256) { g_last_wgrad_kernel = 1; return launch_wgrad<128, 256, 2, 4>(k, d->splits, st); }
+    g_last_wgrad_kernel = 0;
     return launch_wgrad<128, 128, 2, 2>(k, d->splits, st);
   }
-  if (d->ca > 32) return launch_wgrad<64, 128, 2, 2>(k, d->splits, st);
+  if (d->ca > 32) { g_last_wgrad_kernel = 2; return launch_wgrad<64, 128, 2, 2>(k, d->splits, st); }
+  g_last_wgrad_kernel = 3;
   return launch_wgrad<32, 128, 1, 4>(k, d->splits, st);
 }

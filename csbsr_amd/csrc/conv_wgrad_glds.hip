@@ -1,0 +1,275 @@
+// Weight-gradient GEMM, LDS-DMA variant:   G[a][tap][b] = sum over pixels  A[pix][a] * B[pix @ tap][b]
+//
+// Same math, grid and slab contract as conv_wgrad.hip; different data movement.  The register-staged kernel spends 55 % of a
+// workgroup's life issuing the next step's loads (address arithmetic, predicated 16-byte loads into staging VGPRs, a ds_write
+// pass): here both operand tiles go HBM -> LDS with global_load_lds_dwordx4 into an NSTAGE-deep ring (counted s_waitcnt vmcnt(N) +
+// raw s_barrier, DMAs stay in flight across barriers), exactly as conv_igemm_glds.hip stages the forward operands.
+//
+//  * a stage = 64 reduction pixels of the A tile ([pixel][BA channels]) followed by 64 pixels of the B tile ([pixel][BN columns]);
+//    one wave instruction moves 1 KiB = 4 pixel rows of a 128-channel tile / 2 rows of a 256-channel tile;
+//  * the MFMA fragments want 8 consecutive PIXELS per lane, so they are read with ds_read_b64_tr_b16 (hardware transpose), whose
+//    16-lane groups fetch a 4-pixel x 16-channel block (four 32-byte row pieces).  The LDS image is lane-linear (DMA), rows of
+//    256 / 512 bytes = a whole number of bank sweeps, so the four rows of a block would sit on the same banks: the 32-byte unit a
+//    lane FETCHES is permuted instead -- position (row, unit') holds channel unit  unit' ^ ((row & 3) << 1)  -- and the fragment
+//    reads apply the same XOR (cdna guide rule 21): the 8 row pieces a 32-lane group touches land on 8 distinct 32-byte bank groups;
+//  * out-of-image taps, pixels past the split's end and channel / column overhang fetch a 256-byte zero page;
+//  * tile order, tap permutation, row shift and the flat (split, tile) grid are those of conv_wgrad.hip.
+//
+// Autograd wgrad of F.conv2d / F.conv_transpose2d at the call sites listed in conv_igemm.hip.
+#include "common.h"
+#include "csbsr_debug.h"
+#include "conv_wgrad.h"
+
+int g_wgrad_glds = 1;
+
+template <int BA, int BN, int NWA, int NWB, int NSTAGE>
+__global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const WgradK p, const half_t* __restrict__ zero_page) {
+  constexpr int NW = NWA * NWB;
+  constexpr int AWv = BA / NWA, BWv = BN / NWB;      // rows / columns per wave
+  constexpr int TA = AWv / 32, TB = BWv / 32;
+  constexpr int BP = WG_BP;                          // 64 pixels per stage
+  constexpr int A_BYTES = BP * BA * 2, B_BYTES = BP * BN * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int AI = A_BYTES / 1024, BI = B_BYTES / 1024;      // wave instructions per stage
+  constexpr int NIA = AI / NW, NIB = BI / NW, NI = NIA + NIB;  // per wave
+  constexpr int CPRA = BA / 8, CPRB = BN / 8;                  // 16-byte chunks per tile row
+  constexpr int RPIA = 64 / CPRA, RPIB = 64 / CPRB;            // tile rows per wave instruction
+  constexpr int DA = NW * RPIA, DB = NW * RPIB;                // pixel distance between a lane's consecutive instructions
+  static_assert(AI % NW == 0 && BI % NW == 0, "stage instructions must split evenly over the waves");
+  static_assert(NIA * DA == BP && NIB * DB == BP, "a lane's instructions must cover the stage");
+  static_assert(NW % 2 == 0, "swizzle term must be lane-constant");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wid / NWB, wb = wid % NWB;
+  const unsigned ntile = p.tiles_a * p.tiles_b;
+  unsigned lt, zsplit;
+  if (p.flat) {
+    const unsigned w = xcd_remap(blockIdx.x, ntile * (unsigned)p.splits);
+    zsplit = w / ntile; lt = w - zsplit * ntile;
+  } else {
+    lt = xcd_remap(blockIdx.x, ntile); zsplit = blockIdx.z;
+  }
+  const int a0 = (lt % p.tiles_a) * BA;
+  int col0 = (lt / p.tiles_a) * BN;
+  if (p.tap_perm) {      // see conv_wgrad.hip: XCD j takes the taps with ky = j%4 (+4), kx in {2(j/4), 2(j/4)+1} (+4)
+    if constexpr (BN == 128) {
+      const int j = lt >> 3, r = lt & 7;
+      const int ky = (j & 3) + 4 * (r >> 2), kx = 2 * (j >> 2) + (r & 1) + 4 * ((r >> 1) & 1);
+      col0 = (ky * 8 + kx) * 128;
+    } else {
+      const int j = lt >> 2, r = lt & 3;
+      const int ky = (j & 3) + 4 * (r >> 1), kx0 = 2 * (j >> 2) + 4 * (r & 1);
+      col0 = (ky * 8 + kx0) * 128;
+    }
+  }
+  long shift = 0;
+  if (p.row_shift) shift = (long)((((col0 / p.cbtot) / p.KW) * p.dil) / p.stride) * p.AW;
+  long mbeg = (long)zsplit * p.per_split - shift;
+  long mend = mbeg + p.per_split;
+  if (mbeg < 0) mbeg = 0;
+  if (mend > p.M || (int)zsplit == p.splits - 1) mend = p.M;
+  if (mbeg >= mend) return;
+
+  // ---- per-lane DMA roles.  A: instruction j = wid + NW*i covers tile rows RPIA*j ..; lane -> row RPIA*j + lane/CPRA, LDS chunk
+  // position c' = lane % CPRA, fetched channel chunk c = ((c'>>1) ^ ((row & 3) << 1)) << 1 | (c' & 1)  (lane-constant: NW is even)
+  const int rowA0 = wid * RPIA + lane / CPRA, rowB0 = wid * RPIB + lane / CPRB;
+  const int cpa = lane % CPRA, cpb = lane % CPRB;
+  const int chA = ((((cpa >> 1) ^ ((rowA0 & 3) << 1)) << 1) | (cpa & 1)) * 8;
+  const int chB = ((((cpb >> 1) ^ ((rowB0 & 3) << 1)) << 1) | (cpb & 1)) * 8;
+  const bool a_ok = a0 + chA < p.ca;
+  // B column chunk -> (tap, channel, segment): constant per lane
+  int b_ky, b_kx;
+  const half_t* b_ptr;
+  long b_sn, b_sy, b_sx;
+  bool b_ok;
+  {
+    const int col = col0 + chB;
+    b_ok = col < p.ktot;
+    const int tap = b_ok ? col / p.cbtot : 0;
+    const int c = b_ok ? col - tap * p.cbtot : 0;
+    b_ky = (tap / p.KW) * p.dil - p.pad;
+    b_kx = (tap % p.KW) * p.dil - p.pad;
+    const csbsr_seg_t& sg = c < p.cb0 ? p.b[0] : p.b[1];
+    b_ptr = reinterpret_cast<const half_t*>(sg.ptr) + (c < p.cb0 ? c : c - p.cb0);
+    b_sn = sg.sn; b_sy = sg.sy; b_sx = sg.sx;
+  }
+  struct Pix { int n, y, x; long off; };
+  auto init_pix = [&](long m, long sn, long sy, long sx) {
+    Pix c;
+    c.n = (int)(m / ((long)p.AH * p.AW));
+    const int rem = (int)(m - (long)c.n * p.AH * p.AW);
+    c.y = rem / p.AW; c.x = rem - c.y * p.AW;
+    c.off = c.n * sn + c.y * sy + c.x * sx;
+    return c;
+  };
+  const long bsx = (long)p.stride * b_sx, bsy = (long)p.stride * b_sy;
+  const long b_tap = (long)b_ky * b_sy + (long)b_kx * b_sx;
+  const long b_dx = DB * bsx, b_rowfix = bsy - (long)p.AW * bsx, b_imgfix = b_sn - (long)p.AH * bsy;
+  const long a_dx = (long)DA * p.a_sx, a_rowfix = p.a_sy - (long)p.AW * p.a_sx, a_imgfix = p.a_sn - (long)p.AH * p.a_sy;
+  auto advance = [&](Pix& c, int d, long dxs, long rowfix, long imgfix) {
+    c.x += d; c.off += dxs;
+    while (c.x >= p.AW) { c.x -= p.AW; c.off += rowfix; if (++c.y == p.AH) { c.y = 0; ++c.n; c.off += imgfix; } }
+  };
+  Pix cb = init_pix(mbeg + rowB0, b_sn, bsy, bsx);
+  Pix ca_ = init_pix(mbeg + rowA0, p.a_sn, p.a_sy, p.a_sx);
+  const half_t* a_base = p.a + a0 + chA;
+  const half_t* b_base = b_ptr + b_tap;
+  const half_t* zp = zero_page + (lane & 7) * 8;
+  long m_issue = mbeg;                       // first pixel of the stage being ISSUED
+
+  auto issue = [&](int kt) {
+    char* sbase = smem + (kt % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const bool ok = a_ok && m_issue + rowA0 + DA * i < mend;
+      const half_t* src = ok ? a_base + ca_.off : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sbase + (wid + NW * i) * 1024), 16, 0, 0);
+      advance(ca_, DA, a_dx, a_rowfix, a_imgfix);
+    }
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int by = cb.y * p.stride + b_ky, bx = cb.x * p.stride + b_kx;
+      const bool ok = b_ok && m_issue + rowB0 + DB * i < mend && (unsigned)by < (unsigned)p.BH && (unsigned)bx < (unsigned)p.BW;
+      const half_t* src = ok ? b_base + cb.off : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wid + NW * i) * 1024), 16, 0, 0);
+      advance(cb, DB, b_dx, b_rowfix, b_imgfix);
+    }
+    m_issue += BP;
+  };
+
+  f16v acc[TA][TB];
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nkt = (int)((mend - mbeg + BP - 1) / BP);
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nkt) issue(s);
+
+  // ---- fragment addressing.  16-lane group g = lane/16: block of 4 pixel rows x 16 channels; lane i = lane%16 supplies the address
+  // of row (i>>2), column quad (i&3) of the block; after the transpose the lane holds channel (block + i) of the 4 rows.
+  // byte = row * ROWBYTES + ((unit ^ ((row & 3) << 1)) << 5) + (i & 3) * 8 ; row & 3 == i >> 2 for both reads (pix0 % 8 == 0, +4)
+  const int li = lane & 15;
+  const int sw = (li >> 2) << 1;
+  const int rsub = (lane >> 5) * 8 + (li >> 2);               // row within a 16-pixel sub-step (second read: + 4)
+  int offA[TA], offB[TB];
+#pragma unroll
+  for (int a = 0; a < TA; ++a) {
+    const int unit = (wa * AWv + a * 32) / 16 + ((lane >> 4) & 1);
+    offA[a] = rsub * (BA * 2) + ((unit ^ sw) << 5) + (li & 3) * 8;
+  }
+#pragma unroll
+  for (int b = 0; b < TB; ++b) {
+    const int unit = (wb * BWv + b * 32) / 16 + ((lane >> 4) & 1);
+    offB[b] = A_BYTES + rsub * (BN * 2) + ((unit ^ sw) << 5) + (li & 3) * 8;
+  }
+  auto tr8 = [&](const char* q, int rowbytes) {
+    const fp16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(q));
+    const fp16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(q + 4 * rowbytes));
+    h8 v;
+    v[0] = r0[0]; v[1] = r0[1]; v[2] = r0[2]; v[3] = r0[3]; v[4] = r1[0]; v[5] = r1[1]; v[6] = r1[2]; v[7] = r1[3];
+    return v;
+  };
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int ahead = (nkt - 1 - kt) < (NSTAGE - 2) ? (nkt - 1 - kt) : (NSTAGE - 2);   // stages still allowed in flight
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1);      // refills the buffer read in iteration kt-1
+    const char* st = smem + (kt % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BP / 16; ++ks) {
+      h8 af[TA], bf[TB];
+#pragma unroll
+      for (int a = 0; a < TA; ++a) af[a] = tr8(st + ks * 16 * (BA * 2) + offA[a], BA * 2);
+#pragma unroll
+      for (int b = 0; b < TB; ++b) bf[b] = tr8(st + ks * 16 * (BN * 2) + offB[b], BN * 2);
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: D[a][col], lane: col = lane%32, rows (r&3)+8*(r>>2)+4*(lane>>5); every (row < ca, col < ktot) element of this
+  // split's slab is written exactly once (csbsr_unpack_wgrad sums the slabs)
+  float* slab = p.g + (size_t)zsplit * p.ca * p.ktot;
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      const int col = col0 + wb * BWv + b * 32 + (lane & 31);
+      if (col >= p.ktot) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = a0 + wa * AWv + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= p.ca) continue;
+        slab[(size_t)row * p.ktot + col] = acc[a][b][r];
+      }
+    }
+}
+
+static half_t* g_wg_zero_page[CSBSR_MAX_DEVICES] = {};
+
+template <int BA, int BN, int NWA, int NWB, int NSTAGE>
+static int launch_wgrad_glds(const WgradK& k, int splits, hipStream_t st) {
+  WgradK p = k;
+  p.tiles_a = (unsigned)((k.ca + BA - 1) / BA);
+  p.tiles_b = (unsigned)((k.ktot + BN - 1) / BN);
+  const unsigned ntile = p.tiles_a * p.tiles_b;
+  p.per_split = ((k.M + splits - 1) / splits + WG_BP - 1) / WG_BP * WG_BP;
+  if ((int)((k.M + p.per_split - 1) / p.per_split) != splits) {
+    csbsr_set_error("wgrad(glds): splits=%d leaves an empty slab; use csbsr_wgrad_splits_desc()", splits);
+    return 1;
+  }
+  p.splits = splits;
+  constexpr int SM_BYTES = NSTAGE * WG_BP * (BA + BN) * 2;
+  static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_glds_kernel<BA, BN, NWA, NWB, NSTAGE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES) != hipSuccess) {
+      csbsr_set_error("wgrad(glds): cannot reserve %d bytes of LDS", SM_BYTES);
+      return 2;
+    }
+    attr_set = true;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CSBSR_MAX_DEVICES) { csbsr_set_error("wgrad(glds): no current device"); return 2; }
+  if (!g_wg_zero_page[dev]) {
+    if (hipMalloc(reinterpret_cast<void**>(&g_wg_zero_page[dev]), 256) != hipSuccess) { csbsr_set_error("wgrad(glds): zero page alloc failed"); return 2; }
+    (void)hipMemset(g_wg_zero_page[dev], 0, 256);
+  }
+  dim3 grid(p.flat ? ntile * splits : ntile, 1, p.flat ? 1 : splits);
+  hipLaunchKernelGGL((conv_wgrad_glds_kernel<BA, BN, NWA, NWB, NSTAGE>), grid, dim3(64 * NWA * NWB), SM_BYTES, st, p, g_wg_zero_page[dev]);
+  CSBSR_LAUNCH_CHECK("csbsr_conv_wgrad(glds)");
+  return 0;
+}
+
+bool wgrad_glds_eligible(const WgradK& k) { return g_wgrad_glds != 0 && k.ca > 64; }
+// 256 x 256 where both dimensions fill 256-wide tiles about as well as 128-wide ones and the reduction is long enough to amortise
+// the 128 KB ring of a one-workgroup-per-CU kernel; 128 x 256 on eight waves for the layers with thousands of columns (as the
+// register-staged kernel chose); 128 x 128 otherwise (tap-permuted 8x8 stride-4 layers included)
+static bool pad_ok(int c, int t) { const int p128 = (c + 127) / 128 * 128, pt = (c + t - 1) / t * t; return pt * 8 <= p128 * 9; }
+int wgrad_glds_tile_a(const WgradK& k) {
+  return (g_wgrad_glds & 2) && k.ca >= 256 && k.ktot >= 1024 && pad_ok(k.ca, 256) && pad_ok(k.ktot, 256) && !k.tap_perm ? 256 : 128;
+}
+int wgrad_glds_tile_n(const WgradK& k) {
+  if (wgrad_glds_tile_a(k) == 256) return 256;
+  return (k.ktot >= 6144 && !k.tap_perm && !(g_wgrad_glds & 4)) ? 256 : 128;
+}
+int wgrad_glds_launch(const WgradK& k, int splits, hipStream_t st) {
+  const int ta = wgrad_glds_tile_a(k), tn = wgrad_glds_tile_n(k);
+  if (ta == 256) return launch_wgrad_glds<256, 256, 2, 4, 2>(k, splits, st);
+  if (tn == 256) return launch_wgrad_glds<128, 256, 2, 4, 3>(k, splits, st);
+  return launch_wgrad_glds<128, 128, 2, 2, 2>(k, splits, st);
+}

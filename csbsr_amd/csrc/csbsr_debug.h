@@ -10,9 +10,13 @@ extern "C" {
 /* kernel the calling thread's last csbsr_conv_forward dispatched to -- 0/1/2 conv_igemm_kernel<32|64|128,..>, 3/4/7
  * conv_igemm_glds_kernel<128,2,2 | 256,4,3 | 256,4,2,2>, 5 conv_thin_cout_kernel, 6 conv_thin_cin_kernel (bench.py's roofline block) */
 int32_t csbsr_debug_last_conv_kernel(void);
+/* same for csbsr_conv_wgrad: 0 conv_wgrad_kernel<128,128,2,2>, 1 <128,256,2,4>, 2 <64,128,2,2>, 3 <32,128,1,4>, 4 conv_wgrad_thin_kernel,
+ * 5 / 6 / 7 conv_wgrad_glds_kernel<128,128,..> / <128,256,..> / <256,256,..> */
+int32_t csbsr_debug_last_wgrad_kernel(void);
 /* kernel selection only, results are identical:
  *   wgrad: bit0 hardware transpose reads (0 = scalar LDS transposition), 2 no thin kernel, 4 no XCD tap order, 8 no flat grid,
- *          16 flat grid everywhere, 32 no row shift, 64 no 128x256 tile, bits 8.. extra dynamic LDS in KiB (occupancy experiments)
+ *          16 flat grid everywhere, 32 no row shift, 64 no 128x256 tile (register-staged kernel), 128 register-staged kernel everywhere
+ *          (implied by bit0 = 0), 256 no 256x256 LDS-DMA tile, 512 no 128x256 LDS-DMA tile, bits 12..19 extra dynamic LDS in KiB
  *   conv:  low 3 bits 0 = register-staged kernel only, 1 = 128x128 LDS-DMA tile only, 2 = default, 3 = 256x128 wherever it fits;
  *          16 no thin kernels, 32 phases on grid.z, 64 linear pixel tiles, 128 raster tap order, 256 no 256-cout tile */
 void csbsr_debug_set_wgrad_tr(int flags);

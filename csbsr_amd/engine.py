@@ -406,7 +406,8 @@ class Conv:
             ev1.record()
             flops = 2.0 * a.N * a.H * a.W * a.c * sum(f.c for f in bs) * self.k * self.k
             nbytes = 2.0 * (a.N * a.H * a.W * a.c + sum(0 if f.bcast else f.N * f.H * f.W * f.c for f in bs))
-            tm.append(("wgrad", flops, nbytes, ev0, ev1, self.name, (a.N, a.H, a.W, a.c, sum(f.c for f in bs), self.k, self.stride, int(self.transposed))))
+            tm.append(("wgrad", flops, nbytes, ev0, ev1, self.name, (a.N, a.H, a.W, a.c, sum(f.c for f in bs), self.k, self.stride, int(self.transposed)),
+                       int(L.load().csbsr_debug_last_wgrad_kernel())))
         gacc = grad_acc(self.w)
         A_real = self.w.shape[0]
         L.call("csbsr_unpack_wgrad", _ptr(g), _ptr(gacc), A_real, self.k, self.k, seg0, seg1, self.w.shape[0], self.w.shape[1], 0, 0,

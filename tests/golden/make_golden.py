@@ -205,7 +205,11 @@ def run_case_wc(name, it, B=2, lr=64, scale=4, alpha=0.7, overrides=(), seed=112
         if flat.numel() > 1 and norms[-1] > 1e-12 and b["grads"][n] is not None:
             cond_g.append(rl2(b["grads"][n], g))
     cond_g = np.array(cond_g) if cond_g else np.zeros(1)
-    gs = float(2 ** 20)
+    # fp16 storage scale of dsr: the largest power of two that keeps max|dsr| * gs below 2^14 (HRNet-OCR's gradient at the SR image is
+    # ~1e4x PSPNet's)
+    gs = 1.0
+    if a["dsr"] is not None:
+        gs = float(2 ** int(np.floor(np.log2(16384.0 / max(float(a["dsr"].abs().max()), 1e-30)))))
     out = dict(x=x.numpy(), seed=np.int64(seed), B=np.int64(B), lr=np.int64(lr), it=np.int64(it),
                hr_sum=np.float64(hr.double().sum()), mask_sum=np.float64(mask.double().sum()), kernel=k.numpy(),
                segment_loss=a["seg_loss"].numpy(), sr_loss=a["sr_loss"].numpy(), loss=np.float64(a["loss"]),

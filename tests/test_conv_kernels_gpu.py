@@ -72,7 +72,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("use_tr", [1, 0])
+@pytest.mark.parametrize("use_tr", [1, 0, 129])      # wgrad: LDS-DMA kernel where eligible | register-staged, scalar LDS transposition | register-staged, hardware transpose
 def test_conv_fwd_dgrad_wgrad(case, use_tr):
     from csbsr_amd import _lib as L
     from csbsr_amd.engine import Conv
