@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ("res_mode", i32), ("res", vp), ("r_sn", i64), ("r_sy", i64), ("r_sx", i64),
                 ("res2", vp), ("r2_sn", i64), ("r2_sy", i64), ("r2_sx", i64),
                 ("accumulate", i32), ("stat_mode", i32), ("stat", vp), ("out_scale", f32),
-                ("o_lo", i64), ("r_lo", i64), ("r2_lo", i64)]
+                ("o_lo", i64), ("r_lo", i64), ("r2_lo", i64),
+                ("mask", vp), ("m_sn", i64), ("m_sy", i64), ("m_sx", i64), ("mask_slope", f32), ("_pad_mask", i32)]
 
 
 class WgradDesc(C.Structure):

@@ -30,6 +30,10 @@ struct ConvK {
   // split-fp16 ("hi + lo") operands of the detector precision mode: element offset from a tensor's hi plane to its lo plane
   // (value = hi + lo, both fp16, same strides); 0 = plain fp16
   long o_lo, r_lo, r2_lo;
+  // activation-derivative mask fused into a dgrad epilogue: the result (after residual / accumulate) is multiplied by
+  // (mask > 0 ? 1 : mask_slope), mask = the saved forward output of the layer whose input gradient this launch produces --
+  // i.e. dPre of that layer leaves this kernel directly and the stand-alone epilogue-backward pass is skipped
+  const half_t* mask; long m_sn, m_sy, m_sx; float mask_slope;
 };
 
 // value -> (hi, lo) fp16 pair with hi + lo == value to ~2^-22 relative (lo is exact down to fp16's subnormal spacing, 6e-8)
@@ -120,6 +124,11 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
     }
+    if (p.mask) {
+      const h8 mk = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oy * p.m_sy + ox * p.m_sx + co);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= ((float)mk[e] > 0.f ? 1.f : p.mask_slope);
+    }
     split_store(o, p.o_lo, v);
   }
   if (p.out32) {
@@ -138,7 +147,7 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
 // max(t, t*sneg), sneg <= 1), residual add or subtract, optional accumulate, optional BatchNorm sums: the mode switches of
 // conv_epilogue_row become two multipliers picked once per kernel.  The general row re-tests every mode per element (~100 scalar
 // branches per row): its 8 rows took 7.7 us of an 18 us transposed-conv workgroup whose 8 K slices take 5.9 us (CSBSR_TS build).
-struct EpiFast { bool ok, has_res, has_old, bn, masked; float sneg, rsign, osc; int cout; long o_lo; };
+struct EpiFast { bool ok, has_res, has_old, has_mask, bn, masked; float sneg, rsign, osc, mslope; int cout; long o_lo; };
 __device__ __forceinline__ EpiFast conv_epilogue_fast_setup(const ConvK& p, float slope) {
   EpiFast f;
   f.ok = (p.stat_mode == CSBSR_STAT_NONE || p.stat_mode == CSBSR_STAT_BN) && !p.cbias && !p.out32 && p.out16 &&
@@ -148,14 +157,17 @@ __device__ __forceinline__ EpiFast conv_epilogue_fast_setup(const ConvK& p, floa
   f.sneg = p.act == CSBSR_ACT_NONE ? 1.f : (p.act == CSBSR_ACT_RELU ? 0.f : slope);
   f.rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
   f.has_res = p.res_mode != CSBSR_RES_NONE; f.has_old = p.accumulate != 0; f.bn = p.stat_mode == CSBSR_STAT_BN;
+  f.has_mask = p.mask != nullptr; f.mslope = p.mask_slope;
   f.masked = (p.cout & 7) != 0;      // the last channel octet is partly padding: those lanes are forced to zero (one branch per row)
   f.osc = p.out_scale; f.cout = p.cout;
   return f;
 }
-// one pixel x 8 channels co..co+7; o = &out16[pixel][co]; rr / oo = residual / old output (zeros when absent; only read when EXTRA)
+// one pixel x 8 channels co..co+7; o = &out16[pixel][co]; rr / oo / mm = residual / old output / activation mask (zeros when absent;
+// only read when EXTRA)
 template <bool EXTRA, bool BNSTAT>
 __device__ __forceinline__ void conv_epilogue_fast_row(const EpiFast& f, const float (&v)[8], const float (&bias)[8], int co, half_t* o,
-                                                       const h8& rr, const h8& oo, float (&ssum)[8], float (&ssq)[8]) {
+                                                       const h8& rr, const h8& oo, float (&ssum)[8], float (&ssq)[8],
+                                                       const h8& mm = h8{1, 1, 1, 1, 1, 1, 1, 1}) {
   float t[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -172,6 +184,7 @@ __device__ __forceinline__ void conv_epilogue_fast_row(const EpiFast& f, const f
     if constexpr (EXTRA) {
       t[e] += f.rsign * (float)rr[e];
       t[e] += (float)oo[e];
+      if (f.has_mask) t[e] *= ((float)mm[e] > 0.f ? 1.f : f.mslope);
     }
   }
   split_store(o, f.o_lo, t);

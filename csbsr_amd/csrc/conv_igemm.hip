@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
       auto rows = [&](auto EXTRA, auto BNSTAT) {
 #pragma unroll 1
         for (int g = 0; g < RPT / EG; ++g) {
-          h8 rr[EG], oo[EG];
+          h8 rr[EG], oo[EG], mm[EG];
           long ooff[EG];
           bool live[EG];
 #pragma unroll
@@ -323,12 +323,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
             const int n = sRow[grow * 3];
             live[i] = n >= 0 && co < p.coutp;
             ooff[i] = sOOff[grow] + co;
-            rr[i] = h8{0, 0, 0, 0, 0, 0, 0, 0}; oo[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            rr[i] = h8{0, 0, 0, 0, 0, 0, 0, 0}; oo[i] = h8{0, 0, 0, 0, 0, 0, 0, 0}; mm[i] = h8{1, 1, 1, 1, 1, 1, 1, 1};
             if constexpr (decltype(EXTRA)::value) {
               if (live[i]) {
-                if (fe.has_res) {
+                if (fe.has_res || fe.has_mask) {
                   const int oyo = py + sRow[grow * 3 + 1] * o_step, oxo = px + sRow[grow * 3 + 2] * o_step;
-                  rr[i] = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oyo * p.r_sy + oxo * p.r_sx + co);
+                  if (fe.has_res) rr[i] = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oyo * p.r_sy + oxo * p.r_sx + co);
+                  if (fe.has_mask) mm[i] = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oyo * p.m_sy + oxo * p.m_sx + co);
                 }
                 if (fe.has_old) oo[i] = *reinterpret_cast<const h8*>(p.out16 + ooff[i]);
               }
@@ -341,11 +342,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
             const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
             const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, bias, co, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq);
+            conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, bias, co, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq, mm[i]);
           }
         }
       };
-      const bool extra = fe.has_res || fe.has_old;
+      const bool extra = fe.has_res || fe.has_old || fe.has_mask;
       if (fe.bn) { if (extra) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{}); }
       else { if (extra) rows(std::true_type{}, std::false_type{}); else rows(std::false_type{}, std::false_type{}); }
       if (fe.bn) conv_epilogue_flush_stats<CPR>(p, sStat, BN, hh * HB + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
@@ -449,6 +450,8 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   k.accumulate = d->accumulate; k.stat_mode = d->stat_mode; k.stat = d->stat;
   k.out_scale = d->out_scale;
   k.o_lo = d->o_lo; k.r_lo = d->r_lo; k.r2_lo = d->r2_lo;
+  k.mask = reinterpret_cast<const half_t*>(d->mask); k.m_sn = d->m_sn; k.m_sy = d->m_sy; k.m_sx = d->m_sx; k.mask_slope = d->mask_slope;
+  CSBSR_CHECK(!d->mask || (d->out16 && !d->o_lo), "conv: the activation mask applies to a plain fp16 output");
   CSBSR_CHECK(!(d->o_lo && d->accumulate), "conv: a split (hi + lo) output cannot accumulate");
   CSBSR_CHECK(!d->o_lo || d->out16, "conv: o_lo without out16");
   k.tile2d = 0; k.nphase_flat = 0; k.tap_group = 0;
@@ -462,7 +465,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
     maxM = (long)d->N * d->OH * d->OW;
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  const bool split_io = d->o_lo || d->r_lo || d->r2_lo;     // the thin kernels have their own epilogues: plain fp16 only
+  const bool split_io = d->o_lo || d->r_lo || d->r2_lo || d->mask;     // the thin kernels have their own epilogues: plain fp16, no mask
   if (!split_io && conv_thin_eligible(k)) { g_last_conv_kernel = CONVK_THIN_COUT; return conv_thin_launch(k, st); }
   if (!split_io && d->in[1].c == 0 && conv_thin_cin_eligible(k, d->in[0].creal)) {
     g_last_conv_kernel = CONVK_THIN_CIN;

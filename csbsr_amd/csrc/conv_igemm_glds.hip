@@ -345,7 +345,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     auto rows = [&](auto EXTRA, auto BNSTAT) {       // EXTRA: a residual and / or the old output is combined in
 #pragma unroll 1
       for (int g = 0; g < RPT / EG; ++g) {
-        h8 rr[EG], oo[EG];
+        h8 rr[EG], oo[EG], mm[EG];
         long ooff[EG];
         bool live[EG];
 #pragma unroll
@@ -354,12 +354,13 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
           const int n = sRow[grow * 3];
           live[i] = n >= 0 && co < p.coutp;
           ooff[i] = sOOff[grow] + co;
-          rr[i] = h8{0, 0, 0, 0, 0, 0, 0, 0}; oo[i] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+          rr[i] = h8{0, 0, 0, 0, 0, 0, 0, 0}; oo[i] = h8{0, 0, 0, 0, 0, 0, 0, 0}; mm[i] = h8{1, 1, 1, 1, 1, 1, 1, 1};
           if constexpr (decltype(EXTRA)::value) {
             if (live[i]) {
-              if (fe.has_res) {
+              if (fe.has_res || fe.has_mask) {
                 const int oyo = py + sRow[grow * 3 + 1] * o_step, oxo = px + sRow[grow * 3 + 2] * o_step;
-                rr[i] = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oyo * p.r_sy + oxo * p.r_sx + co);
+                if (fe.has_res) rr[i] = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oyo * p.r_sy + oxo * p.r_sx + co);
+                if (fe.has_mask) mm[i] = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oyo * p.m_sy + oxo * p.m_sx + co);
               }
               if (fe.has_old) oo[i] = *reinterpret_cast<const h8*>(p.out16 + ooff[i]);
             }
@@ -372,11 +373,11 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
           const f4 v0 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8) ^ (row & 15)) << 2));
           const f4 v1 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8 + 1) ^ (row & 15)) << 2));
           const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, bias, co, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq);
+          conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, bias, co, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq, mm[i]);
         }
       }
     };
-    const bool extra = fe.has_res || fe.has_old;
+    const bool extra = fe.has_res || fe.has_old || fe.has_mask;
     if (fe.bn) { if (extra) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{}); }
     else { if (extra) rows(std::true_type{}, std::false_type{}); else rows(std::false_type{}, std::false_type{}); }
     if (fe.bn) conv_epilogue_flush_stats<CPR>(p, sStat, BN, lcol, co, uniform_n, cur_n, ssum, ssq);

@@ -21,12 +21,16 @@ struct WgradK {
   int flat;                  // 1: 1-D grid over (split, tile): all tiles of one pixel split run on ONE XCD (see the kernel)
   int splits;
   int row_shift;             // 1: per-tile pixel-range shift that aligns the gathered rows of taps a stride apart (see the kernel)
+  // a launch may cover only rows [row0, row0 + ca) of the problem's G (the 256-row LDS-DMA tiles take the multiple-of-256 part of
+  // the A channels, a second launch the rest): ``a`` already points at channel row0, slabs are slab_stride elements apart
+  long slab_stride;          // elements per pixel-split slab = (all A channels) * ktot
+  int row0;
 };
 
 
 // conv_wgrad_glds.hip
 bool wgrad_glds_eligible(const WgradK& k);
 int wgrad_glds_tile_n(const WgradK& k);                  // 128 or 256 columns per tile (the caller sizes the pixel splits with it)
-int wgrad_glds_tile_a(const WgradK& k);                  // 128 or 256 rows
-int wgrad_glds_launch(const WgradK& k, int splits, hipStream_t st);
+int wgrad_glds_tile_a(const WgradK& k);                  // 256: rows [0, ca / 256 * 256) run on 256 x 256 tiles, the rest on 128-row tiles
+int wgrad_glds_launch(const WgradK& k, int ta, int tn, int splits, hipStream_t st);
 extern int g_wgrad_glds;                                 // 0: off (A/B timing, csbsr_debug_set_wgrad_tr bit 7)

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgradK p
   // ---- epilogue: D[a][col], lane: col = lane%32, rows (r&3)+8*(r>>2)+4*(lane>>5)
   // every (row < ca, col < ktot) element of this split's slab is written exactly once: no atomics, no zero-fill;
   // csbsr_unpack_wgrad sums the slabs
-  float* slab = p.g + (size_t)zsplit * p.ca * p.ktot;
+  float* slab = p.g + (size_t)zsplit * p.slab_stride;
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradK p) {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
     }
   }
-  float* slab = p.g + (size_t)blockIdx.z * p.ca * p.ktot;
+  float* slab = p.g + (size_t)blockIdx.z * p.slab_stride;
   const int ci = col0 + wid * 32 + (lane & 31);
   if (ci >= p.cbtot) return;
 #pragma unroll
@@ -383,7 +383,7 @@ static int wgrad_tile_n(int ca, int ktot, bool perm8);
 static void wgrad_tiles(int ca, int ktot, bool perm8, int& BA, int& BN) {
   WgradK t{};
   t.ca = ca; t.ktot = ktot; t.tap_perm = perm8 ? 1 : 0;
-  if (wgrad_glds_eligible(t)) { BA = wgrad_glds_tile_a(t); BN = wgrad_glds_tile_n(t); }
+  if (wgrad_glds_eligible(t)) { BA = wgrad_glds_tile_a(t); BN = BA == 256 ? 256 : wgrad_glds_tile_n(t); }
   else { BA = wgrad_tile_a(ca); BN = wgrad_tile_n(ca, ktot, perm8); }
 }
 // 128 x 256 tiles on 8 waves (each wave still owns 64 x 64) for the layers with thousands of columns: the kernel is bound by what a CU
@@ -478,6 +478,7 @@ extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
   k.g = d->g; k.ktot = d->KH * d->KW * k.cbtot;
   k.tap_perm = (g_wgrad_tap_perm && d->KH == 8 && d->KW == 8 && d->stride == 4 && k.cbtot == WG_BN && d->ca <= 128) ? 1 : 0;
   k.M = (long)d->N * d->AH * d->AW;
+  k.slab_stride = (long)d->ca * k.ktot; k.row0 = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   CSBSR_CHECK(d->splits >= 1, "wgrad: splits must come from csbsr_wgrad_splits()");
   if (wgrad_is_thin(d)) {
@@ -499,8 +500,21 @@ extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
     const int ta = wgrad_glds_tile_a(k), tn = wgrad_glds_tile_n(k);
     g_last_wgrad_kernel = ta == 256 ? 7 : (tn == 256 ? 6 : 5);
     k.ca_real = 0;
-    wgrad_locality(k, ta, tn, d->splits);
-    return wgrad_glds_launch(k, d->splits, st);
+    if (ta != 256) {
+      wgrad_locality(k, ta, tn, d->splits);
+      return wgrad_glds_launch(k, ta, tn, d->splits, st);
+    }
+    // rows [0, n256) on 256 x 256 tiles, the remaining (< 256) rows on 128-row tiles: same pixel splits, same slabs
+    const int n256 = d->ca / 256 * 256;
+    WgradK k1 = k;
+    k1.ca = n256;
+    wgrad_locality(k1, 256, 256, d->splits);
+    int rc = wgrad_glds_launch(k1, 256, 256, d->splits, st);
+    if (rc || n256 == d->ca) return rc;
+    WgradK k2 = k;
+    k2.a = k.a + n256; k2.ca = d->ca - n256; k2.row0 = n256;
+    wgrad_locality(k2, 128, tn, d->splits);
+    return wgrad_glds_launch(k2, 128, tn, d->splits, st);
   }
   if (d->ca > 64) {
     if (wgrad_tile_n(d->ca, k.ktot, k.tap_perm != 0) == 256) { g_last_wgrad_kernel = 1; return launch_wgrad<128, 256, 2, 4>(k, d->splits, st); }

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const W
 
   // ---- epilogue: D[a][col], lane: col = lane%32, rows (r&3)+8*(r>>2)+4*(lane>>5); every (row < ca, col < ktot) element of this
   // split's slab is written exactly once (csbsr_unpack_wgrad sums the slabs)
-  float* slab = p.g + (size_t)zsplit * p.ca * p.ktot;
+  float* slab = p.g + (size_t)zsplit * p.slab_stride + (size_t)p.row0 * p.ktot;
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -256,19 +256,20 @@ static int launch_wgrad_glds(const WgradK& k, int splits, hipStream_t st) {
 }
 
 bool wgrad_glds_eligible(const WgradK& k) { return g_wgrad_glds != 0 && k.ca > 64; }
-// 256 x 256 where both dimensions fill 256-wide tiles about as well as 128-wide ones and the reduction is long enough to amortise
-// the 128 KB ring of a one-workgroup-per-CU kernel; 128 x 256 on eight waves for the layers with thousands of columns (as the
-// register-staged kernel chose); 128 x 128 otherwise (tap-permuted 8x8 stride-4 layers included)
+// Measured at N = 4 (scripts/bench_wgrad_ab.sh): at equal tile size the LDS-DMA kernel only matches the register-staged one (the CU's
+// load path, ~16 B/clk, bounds both: 64 flop per staged byte at 128 x 128, 85 at 128 x 256) -- what it buys is the 256 x 256 tile
+// (128 flop/B; 8 waves, two 64 KB stages) that the register-staged kernel cannot hold: ResNet 512 3x3 560 -> 730 TF/s, up_1 1024 -> 256
+// 651 -> 808, ResNet 256 524 -> 637.  So: 256-row tiles for the multiple-of-256 part of the A channels wherever the columns fill
+// 256-wide tiles about as well as 128-wide ones (the caller runs the remaining rows as a second, 128-row launch); 128 x 256 for the
+// layers with thousands of columns; 128 x 128 otherwise (tap-permuted 8x8 stride-4 layers included).
 static bool pad_ok(int c, int t) { const int p128 = (c + 127) / 128 * 128, pt = (c + t - 1) / t * t; return pt * 8 <= p128 * 9; }
 int wgrad_glds_tile_a(const WgradK& k) {
-  return (g_wgrad_glds & 2) && k.ca >= 256 && k.ktot >= 1024 && pad_ok(k.ca, 256) && pad_ok(k.ktot, 256) && !k.tap_perm ? 256 : 128;
+  return (g_wgrad_glds & 2) && k.ca >= 256 && k.ktot >= 1024 && pad_ok(k.ktot, 256) && !k.tap_perm ? 256 : 128;
 }
 int wgrad_glds_tile_n(const WgradK& k) {
-  if (wgrad_glds_tile_a(k) == 256) return 256;
   return (k.ktot >= 6144 && !k.tap_perm && !(g_wgrad_glds & 4)) ? 256 : 128;
 }
-int wgrad_glds_launch(const WgradK& k, int splits, hipStream_t st) {
-  const int ta = wgrad_glds_tile_a(k), tn = wgrad_glds_tile_n(k);
+int wgrad_glds_launch(const WgradK& k, int ta, int tn, int splits, hipStream_t st) {
   if (ta == 256) return launch_wgrad_glds<256, 256, 2, 4, 2>(k, splits, st);
   if (tn == 256) return launch_wgrad_glds<128, 256, 2, 4, 3>(k, splits, st);
   return launch_wgrad_glds<128, 128, 2, 2, 2>(k, splits, st);

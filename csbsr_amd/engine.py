@@ -248,7 +248,7 @@ class Conv:
         return (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
 
     def _launch(self, xs, wt, transposed, k, stride, pad, dil, H, W, OH, OW, cout, out, out32, bias, act, slope, prelu, res, res2,
-                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None):
+                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None):
         d = L.ConvDesc()
         x0 = xs[0]
         if x0.lo:                       # split-fp16 input: [hi | lo] + hi again, weights from _pack_split
@@ -278,6 +278,11 @@ class Conv:
             sn, sy, sx = res2.strides()
             d.res2, d.r2_sn, d.r2_sy, d.r2_sx, d.r2_lo = _ptr(res2.t), sn, sy, sx, res2.lo
         d.accumulate, d.stat_mode, d.stat, d.out_scale = int(accumulate), stat_mode, _ptr(stat), out_scale
+        if mask is not None:            # (saved forward output of the consumer layer, its negative slope): see csbsr_conv_desc_t.mask
+            mfm, mslope = mask
+            assert out is not None and mfm.cp == d.coutp and (mfm.H, mfm.W) == (OH, OW) and not mfm.bcast
+            sn, sy, sx = mfm.strides()
+            d.mask, d.m_sn, d.m_sy, d.m_sx, d.mask_slope = _ptr(mfm.t), sn, sy, sx, float(mslope)
         tm = self.eng.timing
         if tm is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -312,8 +317,10 @@ class Conv:
                      self.act, self.slope, self.prelu, res, res2, res_mode, False, stat, stat_mode, 1.0 / self.WSCALE if sp else 1.0)
         return out
 
-    def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None):
-        """dgrad wrt input segment ``seg``; dpre: gradient wrt the pre-activation output (FM, may be bcast)."""
+    def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None, mask=None):
+        """dgrad wrt input segment ``seg``; dpre: gradient wrt the pre-activation output (FM, may be bcast).
+        ``mask`` = (saved output FM of the layer that produced this input, its negative slope): the activation derivative of that layer
+        is applied in the epilogue, so what leaves is its dPre (only on the launch that completes the gradient)."""
         c_seg = self.split[seg]
         row_off = 0 if seg == 0 else self.split[0]
         k, s, p, d = self.k, self.stride, self.pad, self.dil
@@ -334,7 +341,7 @@ class Conv:
         if out is None and out32 is None and stat is None:
             out = self.eng.new(dpre.N, OH, OW, c_seg)
         self._launch((dpre,), wt, tr, k, ps, pp, dd, H, W, OH, OW, c_seg, out, out32, None, L.ACT_NONE, 0.0, None, None, None,
-                     L.RES_NONE, accumulate, stat, L.STAT_SAMPLE_SUM if stat is not None else L.STAT_NONE, 1.0)
+                     L.RES_NONE, accumulate, stat, L.STAT_SAMPLE_SUM if stat is not None else L.STAT_NONE, 1.0, mask=mask)
         return out
 
     # -- exact folding of a spatially constant second input segment (SFT conv0: cat(features, kernel code), kbpn.py:513)

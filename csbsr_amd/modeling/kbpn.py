@@ -399,32 +399,31 @@ class KBPN:
         d49 = (dk2 @ self.U) / float(H * W)
         g = self._bcast_grad(d49, H, W)
         cat2, cat1, cat0 = st.fe_cat[2], st.fe_cat[1], st.fe_cat[0]
+        # Every layer of this branch is a bias-free conv + ReLU / LeakyReLU with a single consumer, so each dgrad applies the activation
+        # derivative of the layer below in its own epilogue (mask = that layer's saved output): what a dgrad writes IS the next
+        # dPre, and the ten stand-alone HR epilogue-backward passes per stage (read dOut, read out, write dPre) are gone.
+        msk = lambda conv, out: (out, 0.0 if conv.act == A_RELU else conv.slope)
         self._wg(cat2, g, c2)
-        dc2 = cat2.bwd_input(g)
-        self._act_bwd(cat1, dc2, c2)
+        dc2 = cat2.bwd_input(g, mask=msk(cat1, c2))
         self._wg(cat1, dc2, c1)
-        dc1 = cat1.bwd_input(dc2)
+        dc1 = cat1.bwd_input(dc2, mask=msk(cat0, c1))
         del dc2
-        self._act_bwd(cat0, dc1, c1)
         self._wg(cat0, dc1, (a[-1], b2))
-        da = cat0.bwd_input(dc1, seg=0)
-        db2 = cat0.bwd_input(dc1, seg=1)
+        da = cat0.bwd_input(dc1, seg=0, mask=msk(st.fe_sr[4], a[5]))
+        db2 = cat0.bwd_input(dc1, seg=1, mask=msk(st.fe_k[1], b2))
         del dc1
         # fe_kernel chain
-        self._act_bwd(st.fe_k[1], db2, b2)
         self._wg(st.fe_k[1], db2, b1)
-        db1 = st.fe_k[1].bwd_input(db2)
+        db1 = st.fe_k[1].bwd_input(db2, mask=msk(st.fe_k[0], b1))
         del db2
-        self._act_bwd(st.fe_k[0], db1, b1)
         dkin = self._fold_const_conv_bwd(st.fe_k[0], db1, kfm, H, W)
         del db1
         # fe_SR chain
         for i in (4, 3, 2, 1, 0):
             c = st.fe_sr[i]
-            self._act_bwd(c, da, a[i + 1])
             self._wg(c, da, a[i])
             if i > 0:
-                da = c.bwd_input(da)
+                da = c.bwd_input(da, mask=msk(st.fe_sr[i - 1], a[i]))
             else:
                 c.bwd_input(da, out32=dsr_t, accumulate=True)
         return dk2 + dkin

@@ -82,6 +82,11 @@ typedef struct {
    * same strides, value = hi + lo (~22 mantissa bits); 0 = plain fp16.  A split INPUT needs no field: it is passed as
    * in[0] = the [hi | lo] channel pair (2c channels), in[1] = the hi plane again, with weights from csbsr_pack_weights_split. */
   int64_t o_lo, r_lo, r2_lo;
+  /* dgrad launches: activation-derivative mask fused into the epilogue.  The result (after residual / accumulate) is multiplied by
+   * (mask > 0 ? 1 : mask_slope) where mask = the saved forward OUTPUT of the layer whose input gradient this launch produces
+   * (ReLU: slope 0; LeakyReLU / PReLU: the slope): autograd of F.relu / F.leaky_relu (kbpn.py:236-247) without a pass of its own.
+   * Only valid on the launch that completes the gradient (the last accumulating contribution).  NULL = off. */
+  const void* mask; int64_t m_sn, m_sy, m_sx; float mask_slope; int32_t _pad_mask;
 } csbsr_conv_desc_t;
 
 int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);

@@ -152,3 +152,27 @@ def test_two_segment_broadcast_and_epilogue():
     assert relmax(dk[:, :c1].cpu(), catr.grad[:, c0:].sum((2, 3))) < 2e-3
     assert relmax(from_fm(d0), catr.grad[:, :c0]) < 2e-3
     assert relmax(params["l.weight"].gacc.cpu(), wr.grad) < 3e-3
+
+
+@pytest.mark.parametrize("cin,cout,H,W,acc", [(32, 49, 40, 36, False), (128, 128, 24, 24, True), (256, 128, 192, 192, False), (49, 32, 33, 70, True)])
+def test_dgrad_with_fused_activation_mask(cin, cout, H, W, acc):
+    """dgrad whose epilogue applies the activation derivative of the layer below (mask = that layer's saved output): equals the
+    plain dgrad (+ old contents when accumulating) times (out > 0 ? 1 : slope) -- the stand-alone epilogue-backward pass, fused."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    torch.manual_seed(cin * 7 + cout)
+    eng = _eng()
+    N, slope = 2, 0.01
+    w = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).half().float()
+    params = {"l.weight": w.cuda()}
+    conv = Conv(eng, "l", params, 3, 1, 1, 1, bias=False, act=L.ACT_NONE)
+    dpre = torch.randn(N, cout, H, W).half().float()
+    below = torch.randn(N, cin, H, W).half().float()          # saved output of the layer below (sign decides the mask)
+    old = torch.randn(N, cin, H, W).half().float()
+    xr = torch.zeros(N, cin, H, W, requires_grad=True)
+    F.conv2d(xr, w, None, 1, 1).backward(dpre)
+    ref = (xr.grad + (old if acc else 0.0)) * torch.where(below > 0, torch.ones(()), torch.full((), slope))
+    out = to_fm(eng, old)
+    conv.bwd_input(to_fm(eng, dpre), out=out, accumulate=acc, mask=(to_fm(eng, below), slope))
+    torch.cuda.synchronize()
+    assert relmax(from_fm(out), ref) < 2e-3
