@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64 * WA * WB) void conv_wgrad_kernel(const WgradK p
   // ---- epilogue: D[a][col], lane: col = lane%32, rows (r&3)+8*(r>>2)+4*(lane>>5)
   // every (row < ca, col < ktot) element of this split's slab is written exactly once: no atomics, no zero-fill;
   // csbsr_unpack_wgrad sums the slabs
-  float* slab = p.g + (size_t)zsplit * p.slab_stride;
+  float* slab = p.g + (size_t)zsplit * p.slab_stride + (size_t)p.row0 * p.ktot;
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -253,7 +253,7 @@ extern "C" void csbsr_debug_set_wgrad_tr(int v) {
   g_wgrad_row_shift = !(v & 32); g_wgrad_wide = !(v & 64);
   // bit 7: register-staged kernel everywhere; bit 0 clear (scalar LDS transposition) implies it -- the LDS-DMA kernel only has the
   // hardware-transpose read; bits 8..9: LDS-DMA tile menu (256: no 256 x 256 tile, 512: no 128 x 256 tile)
-  g_wgrad_glds = ((v & 128) || !(v & 1)) ? 0 : (1 | ((v & 256) ? 0 : 2) | ((v & 512) ? 4 : 0));
+  g_wgrad_glds = ((v & 128) || !(v & 1)) ? 0 : (1 | ((v & 256) ? 0 : 2) | ((v & 512) ? 4 : 0) | ((v & 1024) ? 8 : 0));
   g_wgrad_extra_lds = ((v >> 12) & 0xff) * 1024;
 }
 
@@ -383,7 +383,7 @@ static int wgrad_tile_n(int ca, int ktot, bool perm8);
 static void wgrad_tiles(int ca, int ktot, bool perm8, int& BA, int& BN) {
   WgradK t{};
   t.ca = ca; t.ktot = ktot; t.tap_perm = perm8 ? 1 : 0;
-  if (wgrad_glds_eligible(t)) { BA = wgrad_glds_tile_a(t); BN = BA == 256 ? 256 : wgrad_glds_tile_n(t); }
+  if (wgrad_glds_eligible(t) && wgrad_glds_tile_a(t) == 256) { BA = BN = 256; }
   else { BA = wgrad_tile_a(ca); BN = wgrad_tile_n(ca, ktot, perm8); }
 }
 // 128 x 256 tiles on 8 waves (each wave still owns 64 x 64) for the layers with thousands of columns: the kernel is bound by what a CU
@@ -496,7 +496,11 @@ extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
     CSBSR_LAUNCH_CHECK("csbsr_conv_wgrad(thin)");
     return 0;
   }
-  if (wgrad_glds_eligible(k)) {
+  // LDS-DMA kernel: measured (scripts/bench_wgrad_ab.sh, N = 4) it only matches the register-staged kernel at equal tile size (and
+  // trails it by 6 % on the 128 x 128 tap-permuted 8x8 stride-4 layers), so it is used for what only it can hold, the 256 x 256
+  // tile.  CSBSR_WGRAD_DBG bit 10 forces it for the other tiles too (A/B timing, tests).
+  const bool glds_all = wgrad_glds_eligible(k) && (g_wgrad_glds & 8);
+  if (wgrad_glds_eligible(k) && (glds_all || wgrad_glds_tile_a(k) == 256)) {
     const int ta = wgrad_glds_tile_a(k), tn = wgrad_glds_tile_n(k);
     g_last_wgrad_kernel = ta == 256 ? 7 : (tn == 256 ? 6 : 5);
     k.ca_real = 0;
@@ -513,8 +517,16 @@ extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
     if (rc || n256 == d->ca) return rc;
     WgradK k2 = k;
     k2.a = k.a + n256; k2.ca = d->ca - n256; k2.row0 = n256;
-    wgrad_locality(k2, 128, tn, d->splits);
-    return wgrad_glds_launch(k2, 128, tn, d->splits, st);
+    if (glds_all) {
+      wgrad_locality(k2, 128, tn, d->splits);
+      return wgrad_glds_launch(k2, 128, tn, d->splits, st);
+    }
+    if (k2.ca > 64) {
+      if (wgrad_tile_n(k2.ca, k.ktot, false) == 256) return launch_wgrad<128, 256, 2, 4>(k2, d->splits, st);
+      return launch_wgrad<128, 128, 2, 2>(k2, d->splits, st);
+    }
+    if (k2.ca > 32) return launch_wgrad<64, 128, 2, 2>(k2, d->splits, st);
+    return launch_wgrad<32, 128, 1, 4>(k2, d->splits, st);
   }
   if (d->ca > 64) {
     if (wgrad_tile_n(d->ca, k.ktot, k.tap_perm != 0) == 256) { g_last_wgrad_kernel = 1; return launch_wgrad<128, 256, 2, 4>(k, d->splits, st); }

@@ -72,7 +72,9 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("use_tr", [1, 0, 129])      # wgrad: LDS-DMA kernel where eligible | register-staged, scalar LDS transposition | register-staged, hardware transpose
+# wgrad: default (LDS-DMA 256x256 tiles where eligible, register-staged elsewhere) | register-staged, scalar LDS transposition |
+# register-staged, hardware transpose | LDS-DMA kernel for every eligible problem (128x128 / 128x256 / 256x256 tiles)
+@pytest.mark.parametrize("use_tr", [1, 0, 129, 1025])
 def test_conv_fwd_dgrad_wgrad(case, use_tr):
     from csbsr_amd import _lib as L
     from csbsr_amd.engine import Conv
