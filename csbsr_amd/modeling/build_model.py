@@ -173,6 +173,7 @@ class _JointBase(nn.Module):
             P = {k: (v.data if isinstance(v, nn.Parameter) else v) for k, v in self._named_full()}
             self._rt = {"eng": eng, "P": P, "kbpn": KBPN(eng, P, self.pc), "psp": HRNetOCR(eng, P) if self.seg_model_name == "HRNet_OCR"
                         else PSPNet(eng, P, blur_dim=self.pc.ksize_out ** 2 if self.blur_skip else None)}
+            self._make_grad_buckets()
         if self.detector_precision not in ("fp16", "split"):
             raise ValueError(f"detector_precision must be 'fp16' or 'split', got {self.detector_precision!r}")
         split = self.detector_precision == "split"
@@ -180,6 +181,36 @@ class _JointBase(nn.Module):
             raise NotImplementedError("detector_precision='split' is built for PSPNet / PSPNet_BlurSkip")
         self._rt["psp"].split = split
         return self._rt
+
+    def _bucket_of(self, name):
+        """gradient bucket of a parameter: the order buckets complete in the explicit backward (segmentation net, then KBPN stages
+        S .. 1 -- output_conv goes with stage S --, then the predictor + VGG head)."""
+        if name.startswith("segmentation_model"):
+            return "seg"
+        S = self.pc.num_stages
+        if name.startswith("sr_model.back_projection_stages."):
+            return f"kbpn.{int(name.split('.')[2]) + 1}"
+        if name.startswith("sr_model.output_conv"):
+            return f"kbpn.{S}"
+        return "kbpn.0"
+
+    def _make_grad_buckets(self):
+        """One flat fp32 buffer per bucket; every trainable parameter's accumulator (``gacc``, written by the kernels) is a view of
+        it, so a bucket is zeroed / all-reduced / scaled as ONE tensor."""
+        rt = self._rt
+        sizes = {}
+        for k, v in self._named_full():
+            if isinstance(v, nn.Parameter) and v.requires_grad:
+                sizes[self._bucket_of(k)] = sizes.get(self._bucket_of(k), 0) + v.numel()
+        flats = {b: torch.zeros(n, dtype=torch.float32, device=self._device) for b, n in sizes.items()}
+        off = {b: 0 for b in sizes}
+        for k, v in self._named_full():
+            if isinstance(v, nn.Parameter) and v.requires_grad:
+                b, t = self._bucket_of(k), rt["P"][k]
+                t.gacc = flats[b][off[b]:off[b] + v.numel()].view(t.shape)
+                t.gacc_touched = False
+                off[b] += v.numel()
+        rt["flat"] = flats
 
     def _invalidate(self):
         rt = self._rt
@@ -398,14 +429,9 @@ class JointModelWithLoss(_JointBase):
         gs = self.grad_scale or float(2 ** (round(math.log2(B * hw)) - (8 if self.seg_model_name == "HRNet_OCR" else 0) - self.scale_backoff))
         eng.grad_scale = gs
         pnames = [k for k, v in self._named_full() if isinstance(v, nn.Parameter)]     # == self.parameters() order
-        live = []
         for k in pnames:                    # fresh fp32 accumulators for this backward
-            t = rt["P"][k]
-            if getattr(t, "gacc", None) is not None:
-                live.append(t.gacc)
-            t.gacc_touched = False
-        if live:
-            torch._foreach_zero_(live)      # one multi-tensor launch instead of ~290 fills
+            rt["P"][k].gacc_touched = False
+        torch._foreach_zero_(list(rt["flat"].values()))      # the accumulators are views of a handful of flat buckets
         dsr32 = eng.f32(B, 3, H, W)
         # which halves of the backward run follows from which loss vector the caller's scalar loss used (autograd hands None for an
         # unused output): a function of the training phase, identical on every rank, and no device read-back
@@ -420,10 +446,10 @@ class JointModelWithLoss(_JointBase):
                        lw[0], lw[1], wgt, _ptr(gsc), None, _ptr(dp), 0, eng.stream)
             dxin = psp.backward(dseg32, daux32)
             if self.blur_skip:                  # only blur_skip.* trains: no gradient leaves the segmentation net
-                return self._finish_backward(pnames, gs, ("segmentation_model",))
+                return self._finish_backward(pnames, gs, ("segmentation_model",), st)
             if self.reducer is not None:        # segmentation gradients are final: exchange them under the KBPN backward
-                self.reducer.launch([rt["P"][k].gacc if getattr(rt["P"][k], "gacc_touched", False) else None
-                                     for k in pnames if k.startswith("segmentation_model")])
+                self.reducer.launch_flat(rt["flat"].get("seg"))
+                st["seg_launched"] = True
             if st["mean"] is not None and self.norm_method == "instance":
                 red = eng.f32(B * 3, 2)
                 L.call("csbsr_instnorm_bwd", _ptr(dxin.t), dxin.ld, _ptr(st["sr32"]), _ptr(st["mean"]), _ptr(st["invstd"]), _ptr(dsr32), 0,
@@ -436,7 +462,7 @@ class JointModelWithLoss(_JointBase):
         else:
             psp.saved = None
             if self.blur_skip:
-                return self._finish_backward(pnames, gs, ())
+                return self._finish_backward(pnames, gs, (), st)
         # ---- SR loss gradients
         dkvec = eng.f32(B, pc.ksize_out ** 2)
         if dsr_loss is not None:
@@ -463,31 +489,40 @@ class JointModelWithLoss(_JointBase):
         saves = st["saves"]
         if saves is None:        # forward_from_sr: the graph ends at the given SR image
             self.last_dsr, self.last_dkvec = dsr32 / gs, dkvec / gs
-            return self._finish_backward(pnames, gs, ("segmentation_model",) if seg_active else ())
+            return self._finish_backward(pnames, gs, ("segmentation_model",) if seg_active else (), st)
         order = list(enumerate(range(0, B, mb)))
-        for i, b0 in reversed(order):         # resident micro-batches last-in first-out: frees HBM before the recomputed ones run
-            if saves[i] is None:
-                continue
-            kbpn.saved, saves[i] = saves[i], None
-            kbpn.backward(dsr32[b0:b0 + mb].contiguous(), dkvec[b0:b0 + mb].contiguous())
-        for i, b0 in order:                   # the rest: forward recomputed here (KBPN has no batch-coupled op: exact)
-            if i < st["n_res"]:
-                continue
-            kbpn.forward(st["x"][b0:b0 + mb], st["iter"], st["kgt"][b0:b0 + mb], save=True)
-            kbpn.backward(dsr32[b0:b0 + mb].contiguous(), dkvec[b0:b0 + mb].contiguous())
-        return self._finish_backward(pnames, gs, ("sr_model",))
+        # resident micro-batches last-in first-out (frees HBM before the recomputed ones run), then the rest with their forward
+        # recomputed here (KBPN has no batch-coupled op: exact)
+        sched = [(i, b0, False) for i, b0 in reversed(order) if saves[i] is not None] + [(i, b0, True) for i, b0 in order if i >= st["n_res"]]
+        launched = set()
 
-    def _finish_backward(self, pnames, gs, reduce_groups):
+        def stage_done(s):      # last micro-batch only: stage s's parameter gradients are final -> exchange them under the rest
+            if self.reducer is not None:
+                self.reducer.launch_flat(rt["flat"].get(f"kbpn.{s}"))
+                launched.add(f"kbpn.{s}")
+        for j, (i, b0, recompute) in enumerate(sched):
+            if recompute:
+                kbpn.forward(st["x"][b0:b0 + mb], st["iter"], st["kgt"][b0:b0 + mb], save=True)
+            else:
+                kbpn.saved, saves[i] = saves[i], None
+            kbpn.backward(dsr32[b0:b0 + mb].contiguous(), dkvec[b0:b0 + mb].contiguous(),
+                          stage_done=stage_done if j == len(sched) - 1 else None)
+        st["kbpn_launched"] = launched
+        return self._finish_backward(pnames, gs, ("sr_model",), st)
+
+    def _finish_backward(self, pnames, gs, reduce_groups, st):
         rt = self._rt
         if self.reducer is not None:
-            for grp in reduce_groups:
-                self.reducer.launch([rt["P"][k].gacc if getattr(rt["P"][k], "gacc_touched", False) else None
-                                     for k in pnames if k.startswith(grp)])
+            # whatever this phase's backward wrote and has not been launched yet (every rank takes the same branch: the set of
+            # buckets depends on the training phase only)
+            for b, flat in rt["flat"].items():
+                grp = "segmentation_model" if b == "seg" else "sr_model"
+                if grp in reduce_groups and not (b == "seg" and st.get("seg_launched")) and b not in st.get("kbpn_launched", ()):
+                    self.reducer.launch_flat(flat)
             self.reducer.finish()
         inv = 1.0 / gs
-        touched = [rt["P"][k] for k in pnames if getattr(rt["P"][k], "gacc_touched", False)]
         # overflow check on the (already all-reduced, so rank-consistent) accumulators: one scalar read back per step
-        finite = bool(torch.isfinite(torch.stack(torch._foreach_norm([t.gacc for t in touched])).sum())) if touched else True
+        finite = bool(torch.isfinite(torch.stack(torch._foreach_norm(list(rt["flat"].values()))).sum()))
         if not finite:
             self.overflow_steps += 1
             if self.grad_scale is None:

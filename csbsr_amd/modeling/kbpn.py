@@ -243,9 +243,12 @@ class KBPN:
         if not conv.frozen:
             conv.bwd_weights(dpre, x)
 
-    def backward(self, dsr32, dkvec_final):
+    def backward(self, dsr32, dkvec_final, stage_done=None):
         """dsr32: fp32 [B,3,H,W] gradient wrt sr (scaled by eng.grad_scale); dkvec_final: [B,kk] fp32 gradient wrt
-        the returned normalised kernel vector (scaled).  Accumulates parameter gradients (scaled)."""
+        the returned normalised kernel vector (scaled).  Accumulates parameter gradients (scaled).
+        ``stage_done(s)``: called when no later kernel of this backward writes the parameter gradients of back-projection stage s
+        any more (s = S .. 1; output_conv counts with stage S) and with s = 0 after the predictor / VGG head: the data-parallel
+        reducer launches that stage's bucket there."""
         e, sv = self.eng, self.saved
         B, h, w = sv["B"], sv["h"], sv["w"]
         H, W = h * self.scale, w * self.scale
@@ -355,6 +358,8 @@ class KBPN:
             dlowp = st.up_conv.bwd_input(dxu)        # gradient wrt this stage's `low` input
             del dxu
             sv["stages"][s - 1] = None
+            if stage_done is not None:
+                stage_done(s)
         # ---- initial kernel predictor + VGG head
         dinit = dlowp
         feats = sv["feats"]
@@ -390,6 +395,8 @@ class KBPN:
             if i > 0:
                 d = c.bwd_input(d)
         self.saved = None
+        if stage_done is not None:
+            stage_done(0)
 
     def _kernel_predictor_bwd(self, st, q, dk2, dsr_t, H, W):
         """backward of kvec2 = kvec_in + U @ GAP(fe_cat(...)); adds the fe_SR path into dsr_t (fp32 planar)."""

@@ -5,7 +5,10 @@ in the CPU tests), averaged by 1/world.
 Replaces the reference's single-process nn.DataParallel (train.py:108-112: per-step parameter broadcast +
 ReduceAddCoalesced of 357 MB of gradients to GPU 0).  Buckets follow the order in which the
 explicit backward finishes parameter groups -- the segmentation network's bucket is final before the SR
-network's backward starts, so its all-reduce runs on a side stream underneath the KBPN backward.
+network's backward starts, and each KBPN stage's bucket (reverse stage order) is final when the LAST micro-batch's
+backward has passed that stage -- so every all-reduce but the last runs on a side stream underneath the remaining
+backward.  Buckets are preallocated flat fp32 buffers that the per-parameter gradient accumulators are views of
+(``launch_flat``): no flatten / scatter copies.
 """
 import torch
 import torch.distributed as dist
@@ -37,6 +40,21 @@ class GradBucketReducer:
         self._pending.append(h)
         return h
 
+    def launch_flat(self, flat):
+        """Start the in-place all-reduce of one preallocated flat fp32 bucket (the gradient accumulators of a parameter group are
+        views into it: no flatten copy before, no scatter copy after).  The caller must not touch the bucket until finish()."""
+        if self.world == 1 or flat is None or flat.numel() == 0:
+            return None
+        if self.side_stream is not None and flat.is_cuda:
+            self.side_stream.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(self.side_stream):
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        else:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        h = (None, None, flat, work)
+        self._pending.append(h)
+        return h
+
     def finish(self):
         """Wait for every launched bucket and write the averaged values back in place."""
         for grads, live, flat, work in self._pending:
@@ -46,6 +64,8 @@ class GradBucketReducer:
             if self.side_stream is not None and flat.is_cuda:
                 torch.cuda.current_stream(flat.device).wait_stream(self.side_stream)
             flat.mul_(1.0 / self.world)
+            if live is None:            # launch_flat: the accumulators are views of the bucket
+                continue
             off = 0
             for g in live:
                 n = g.numel()
