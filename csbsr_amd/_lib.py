@@ -116,6 +116,9 @@ SIGNATURES = {
     "csbsr_segloss_finish": (i32, [vp, vp, vp, i32, i64, vp, f32, f32, f32, f32, f32, f32, vp, vp, vp, i32, vp]),
     "csbsr_l1_fwd_bwd": (i32, [vp, vp, vp, i32, i32, i64, vp, f32, vp, vp, i32, vp]),
     "csbsr_sigmoid_bwd_to_nhwc8": (i32, [vp, vp, vp, i64, f32, vp]),
+    "csbsr_gaussian_kernels": (i32, [vp, vp, i32, i32, vp]),
+    "csbsr_iou_sweep": (i32, [vp, vp, vp, i32, i64, i32, f32, vp, vp, vp, vp, vp]),
+    "csbsr_psnr_ssim": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
 }
 
 # private hooks (csbsr_amd/csrc/csbsr_debug.h): kernel selection for A/B timing and kernel attribution for bench.py

@@ -283,7 +283,9 @@ class JointModelWithLoss(_JointBase):
         self.reducer = None             # csbsr_amd.parallel.GradBucketReducer when data-parallel
 
     # ------------------------------------------------------------------ forward
-    def forward(self, iter, x, sr_targets=None, segment_targets=None, kernel_targets=None):
+    def forward(self, iter, x, sr_targets=None, segment_targets=None, kernel_targets=None, segment_sdf=None):
+        """``segment_sdf`` (optional, not in the reference's signature): the signed distance map of ``segment_targets`` already on the
+        device -- csbsr_amd.data.degrade.DeviceDegradation computes it with the batch -- so the loss does not recompute it."""
         rt = self._runtime()
         eng, kbpn, psp, pc = rt["eng"], rt["kbpn"], rt["psp"], self.pc
         self._invalidate()              # master weights may have been stepped by the optimiser
@@ -306,7 +308,7 @@ class JointModelWithLoss(_JointBase):
             kbpn.saved = None
             sr32[b0:b0 + mb] = s_
             kvec[b0:b0 + mb] = k_
-        return self._detector_and_losses(iter, x, hr, mask, kgt, sr32, kvec, saves, mb)
+        return self._detector_and_losses(iter, x, hr, mask, kgt, sr32, kvec, saves, mb, sdf=self._mount(segment_sdf))
 
     def forward_from_sr(self, iter, sr_preds, kernel_vec, x, sr_targets, segment_targets, kernel_targets):
         """Validation entry point: the detector + loss half of ``forward`` fed a GIVEN SR image [B,3,H,W] and (un-normalised) kernel
@@ -343,7 +345,7 @@ class JointModelWithLoss(_JointBase):
             kbpn.backward((dsr[b0:b0 + mb] * gs).contiguous(), (dkvec[b0:b0 + mb] * gs).contiguous())
         return {k: (rt["P"][k].gacc / gs if getattr(rt["P"][k], "gacc_touched", False) else None) for k in names}
 
-    def _detector_and_losses(self, iter, x, hr, mask, kgt, sr32, kvec, saves, mb):
+    def _detector_and_losses(self, iter, x, hr, mask, kgt, sr32, kvec, saves, mb, sdf=None):
         rt, pc = self._rt, self.pc
         eng, psp = rt["eng"], rt["psp"]
         B, _, h, w = x.shape
@@ -358,10 +360,11 @@ class JointModelWithLoss(_JointBase):
         psp_saved, psp.saved = (psp.saved if keep else None), None      # carried by the autograd node, not by the (shared) layer object
         # ---- losses (forward sums only; gradients are produced in _hip_backward)
         hw = H * W
-        sdf = eng.f32(B, 1, H, W, zero=False)
-        scratch = eng.f32(3 * B * hw + 2 * B, zero=False)
-        L.call("csbsr_sdf", _ptr(mask), _ptr(sdf), _ptr(scratch), B, H, W, eng.stream)
-        del scratch
+        if sdf is None:
+            sdf = eng.f32(B, 1, H, W, zero=False)
+            scratch = eng.f32(3 * B * hw + 2 * B, zero=False)
+            L.call("csbsr_sdf", _ptr(mask), _ptr(sdf), _ptr(scratch), B, H, W, eng.stream)
+            del scratch
         alpha = float(self.ss_loss_fn.alpha)
         seg_loss = eng.f32(B)
         sums_m, sums_a = eng.f32(B, 8), eng.f32(B, 8)

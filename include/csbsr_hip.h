@@ -308,6 +308,21 @@ int csbsr_l1_fwd_bwd(const float* a, const float* b, const float* wmap, int32_t 
 int csbsr_sigmoid_bwd_to_nhwc8(const float* dp, const float* p, void* out, int64_t npix, float scale,
                                csbsr_stream_t s);
 
+/* ------------------------------------------------------------------------------------------- data path either side of the hot path */
+/* Anisotropic Gaussian blur kernels, out[n] = exp(-(a x^2 + 2 b x y + c y^2)) / sum on linspace(-K/2, K/2, K)^2 with (a, b, c) from
+ * params[n] = (sigma_x, sigma_y, theta in radians): GaussianBlur.make(), model/data/blur/blur.py:121-167 (the degradation batch
+ * generator, crack_dataset.py:40-64; blur + antialiased bicubic down-scaling reuse csbsr_blur_fwd / csbsr_aa_bicubic_down_fwd). */
+int csbsr_gaussian_kernels(const float* params, float* out, int32_t N, int32_t K, csbsr_stream_t s);
+/* IoU of (pred - t_i > 0) against (mask > 0.5) for T ascending thresholds in one pass: inference.py:50-53,111-119 with
+ * estimate_metrics.IoU (:64-84).  hist = caller-zeroed uint32 [N][2][T+1] workspace; iou / inter / uni are fp32 [N][T] (inter, uni
+ * optional). */
+int csbsr_iou_sweep(const float* pred, const float* mask, const float* thresholds, int32_t N, int64_t hw, int32_t T, float smooth,
+                    uint32_t* hist, float* iou, float* inter, float* uni, csbsr_stream_t s);
+/* PSNR = 10 log10(1 / mse) and SSIM (11x11 Gaussian window, sigma 1.5, zero padding) per sample of fp32 NCHW batches in [0,1]:
+ * estimate_metrics.py:89-101 (PSNR), :135-191 (SSIM).  sums = caller-zeroed fp32 [N][2] workspace. */
+int csbsr_psnr_ssim(const float* a, const float* b, int32_t N, int32_t C, int32_t H, int32_t W, float* sums, float* psnr, float* ssim,
+                    csbsr_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -240,6 +240,68 @@ def run_case_wc(name, it, B=2, lr=64, scale=4, alpha=0.7, overrides=(), seed=112
           f" -> {os.path.getsize(path)/1e6:.2f} MB")
 
 
+
+def aux_cases():
+    """Fixtures of the rows either side of the hot path, every value produced by the reference's own classes:
+    degradation (GaussianBlur.make + conv_kernel2d + FactorResize), SplitPatch / JointPatch, PSNR / SSIM / the 99-threshold IoU
+    sweep, and the key / shape / checksum digest of a checkpoint saved from the DataParallel-wrapped reference model."""
+    import model.data.blur.blur as RB
+    from model.data.transforms.transforms import FactorResize
+    from model.data.samplers.patch_sampler import SplitPatch, JointPatch
+    from model.utils.estimate_metrics import PSNR, SSIM, IoU
+    out = {}
+    # ---- f1: degradation with scripted draws (theta from torch.rand, sigmas from np.random.rand: blur.py:128,160-167)
+    ref_shims.ANTIALIAS = True
+    g = torch.Generator().manual_seed(31)
+    hr = torch.rand(2, 3, 48, 64, generator=g)
+    draws = [(0.37, 0.81, 0.12), (0.05, 0.93, 0.66)]          # (theta_u, sigma_x_u, sigma_y_u) in [0,1)
+    kernels, lrs, params = [], [], []
+    t_rand, n_rand = torch.rand, np.random.rand
+    try:
+        for b, (tu, su, sv) in enumerate(draws):
+            seq = iter([su, sv])
+            torch.rand = lambda *a, **k: torch.tensor([tu])
+            np.random.rand = lambda *a: next(seq)
+            gb = RB.GaussianBlur(size=21, isotropic=False, device="cpu", range_deterioration_ratio=(0.2, 4))
+            kern = gb.make()
+            torch.rand, np.random.rand = t_rand, n_rand
+            img = RB.conv_kernel2d(hr[b], kern, device="cpu")
+            lrs.append(FactorResize(4, "bicubic")(img).numpy())
+            kernels.append(kern.numpy())
+            params.append([0.2 + 3.8 * su, 0.2 + 3.8 * sv, (180.0 * tu) * np.pi / 180])
+    finally:
+        torch.rand, np.random.rand = t_rand, n_rand
+    out.update(deg_hr=hr.numpy(), deg_params=np.array(params, np.float32), deg_kernels=np.stack(kernels), deg_lr=np.stack(lrs))
+    # ---- f2: patch sampler (index permutation) and the threshold sweep
+    x = torch.arange(3 * 12 * 20, dtype=torch.float32).reshape(3, 12, 20)
+    patches, shape = SplitPatch(1, 3, 6, 5)(x)
+    out.update(patch_in=x.numpy(), patch_out=patches.numpy(), patch_shape=np.array(shape))
+    two = torch.stack([x, x + 1000.0])                       # JointPatch on a batch of two images' patches
+    pp = torch.cat([SplitPatch(1, 3, 6, 5)(two[i])[0] for i in range(2)])
+    out.update(joint_out=JointPatch()(pp, shape).numpy())
+    pred = torch.rand(2, 1, 40, 52, generator=g)
+    mask = (torch.rand(2, 1, 40, 52, generator=g) > 0.7).float()
+    thresholds = [i * 0.01 for i in range(1, 100)]
+    tmap = torch.Tensor(thresholds).view(len(thresholds), 1, 1)
+    bi = (pred - tmap > torch.Tensor([0])).float()
+    out.update(iou_pred=pred.numpy(), iou_mask=mask.numpy(), iou_sweep=np.reshape(IoU()(bi, mask), (2, -1)))
+    # ---- f4: PSNR / SSIM
+    a = torch.rand(2, 3, 40, 52, generator=g)
+    b_ = (a + 0.05 * torch.randn(2, 3, 40, 52, generator=g)).clamp(0, 1)
+    out.update(met_a=a.numpy(), met_b=b_.numpy(), met_psnr=PSNR()(a, b_), met_ssim=SSIM()(a, b_))
+    # ---- f3: checkpoint digest, as trainer.py:117-131 saves it from the DataParallel-wrapped model
+    cfg, JM, J, FR = ref_shims.build_reference(detector="PSPNet", scale=4)
+    model = JM(cfg, 1000, 0, FR(4, "bicubic"))
+    deterministic_fill(model)
+    sd = nn.DataParallel(model).state_dict()
+    keys = list(sd.keys())
+    out.update(ckpt_keys=np.array(keys), ckpt_shapes=np.array([",".join(str(d) for d in v.shape) for v in sd.values()]),
+               ckpt_sum=np.array([float(v.double().sum()) for v in sd.values()]),
+               ckpt_abs=np.array([float(v.double().abs().sum()) for v in sd.values()]))
+    np.savez_compressed(os.path.join(HERE, "aux_reference.npz"), **out)
+    print("aux_reference written:", {k: getattr(v, "shape", None) for k, v in out.items() if not k.startswith("ckpt")}, len(keys), "checkpoint keys")
+
+
 def sdf_case():
     from model.utils.boundary_loss import compute_sdf1_1
     m = np.zeros((3, 1, 40, 56), np.uint8)
@@ -266,6 +328,9 @@ if __name__ == "__main__":
                 _rc(name, *a, **k)
     else:
         sdf_case()
+    if "--aux" in sys.argv:
+        aux_cases()
+        sys.exit(0)
     if "--wc" in sys.argv:          # the well-conditioned-size fixtures only (minutes of CPU each)
         run_case_wc("wc_pspnet_it40000", 40000, B=2, lr=64)
         run_case_wc("wc_blurskip_x8_it40000", 40000, B=2, lr=32, scale=8, alpha=0.8, detector="PSPNet_BlurSkip", seed=9,
