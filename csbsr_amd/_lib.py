@@ -77,6 +77,8 @@ SIGNATURES = {
     "csbsr_maxpool3x3s2_fwd_split": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
     "csbsr_maxpool3x3s2_bwd_split": (i32, [vp, i64, i64, vp, i64, i64, vp, vp, i32, i32, i32, i32, vp]),
     "csbsr_adaptive_avgpool_fwd_split": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "csbsr_sum_act_split": (i32, [i64, i32, i32, vp, vp, vp, vp, i64, i64, i32, vp]),
+    "csbsr_weighted_pool_fwd_split": (i32, [vp, i64, i64, vp, vp, i32, i64, i32, vp]),
     "csbsr_bilinear_fwd_split": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "csbsr_unpack_wgrad": (i32, [vp, vp] + [i32] * 9 + [f32, i32, i32, vp]),
     "csbsr_wgrad_splits": (i32, [i32, i32, i64]),

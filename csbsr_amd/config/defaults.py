@@ -109,4 +109,5 @@ def path_config(c, antialias=True):
     p.antialias = antialias
     p.oriented_w_iter = c.SOLVER.ORIENTED_WEIGHT_ITER
     p.sfo_sr_amp = float(c.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP)
+    p.pixel_shuffle = bool(c.MODEL.SR_PIXEL_SHUFFLE)
     return p

@@ -250,39 +250,46 @@ extern "C" int csbsr_axpby(int64_t npix, int32_t c, const void* x, int64_t x_ld,
   return csbsr_axpby_split(npix, c, x, x_ld, 0, a, z, z_ld, 0, b, y, y_ld, 0, s);
 }
 // y = act(sum_{i<n} x_i): the n-ary fuse sum of an HRNet module (hrnet_backbone.py:276-296), one pass
-struct SumK { const half_t* x[4]; long ld[4]; int n; };
-__global__ void sum_act_kernel(long npix, int c8, SumK k, half_t* y, long y_ld, int relu) {
+struct SumK { const half_t* x[4]; long ld[4]; long lo[4]; int n; };
+__global__ void sum_act_kernel(long npix, int c8, SumK k, half_t* y, long y_ld, long y_lo, int relu) {
   const long total = npix * c8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long px = i / c8; const int c0 = (int)(i % c8) * 8;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = 0; t < k.n; ++t) {
-      const h8 v = *reinterpret_cast<const h8*>(k.x[t] + px * k.ld[t] + c0);
+      float v[8];
+      ld_split(k.x[t] + px * k.ld[t] + c0, k.lo[t], v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
-    h8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)((relu && acc[e] < 0.f) ? 0.f : acc[e]);
-    *reinterpret_cast<h8*>(y + px * y_ld + c0) = o;
+    for (int e = 0; e < 8; ++e) acc[e] = (relu && acc[e] < 0.f) ? 0.f : acc[e];
+    st_split(y + px * y_ld + c0, y_lo, acc);
   }
 }
-extern "C" int csbsr_sum_act(int64_t npix, int32_t c, int32_t n, const void* const* xs, const int64_t* x_lds, void* y, int64_t y_ld,
-                             int32_t relu, csbsr_stream_t s) {
+extern "C" int csbsr_sum_act_split(int64_t npix, int32_t c, int32_t n, const void* const* xs, const int64_t* x_lds, const int64_t* x_los,
+                                   void* y, int64_t y_ld, int64_t y_lo, int32_t relu, csbsr_stream_t s) {
   CSBSR_CHECK(c % 8 == 0 && n >= 1 && n <= 4 && xs && x_lds && y, "sum_act: bad args");
   SumK k;
   k.n = n;
-  for (int i = 0; i < 4; ++i) { k.x[i] = i < n ? (const half_t*)xs[i] : nullptr; k.ld[i] = i < n ? x_lds[i] : 0; }
-  hipLaunchKernelGGL(sum_act_kernel, dim3(grid_for(npix * (c / 8))), dim3(256), 0, ST(s), npix, c / 8, k, (half_t*)y, y_ld, relu);
+  for (int i = 0; i < 4; ++i) {
+    k.x[i] = i < n ? (const half_t*)xs[i] : nullptr; k.ld[i] = i < n ? x_lds[i] : 0; k.lo[i] = (i < n && x_los) ? x_los[i] : 0;
+  }
+  hipLaunchKernelGGL(sum_act_kernel, dim3(grid_for(npix * (c / 8))), dim3(256), 0, ST(s), npix, c / 8, k, (half_t*)y, y_ld, y_lo, relu);
   CSBSR_LAUNCH_CHECK("csbsr_sum_act");
   return 0;
+}
+extern "C" int csbsr_sum_act(int64_t npix, int32_t c, int32_t n, const void* const* xs, const int64_t* x_lds, void* y, int64_t y_ld,
+                             int32_t relu, csbsr_stream_t s) {
+  return csbsr_sum_act_split(npix, c, n, xs, x_lds, nullptr, y, y_ld, 0, relu, s);
 }
 
 // Soft object-region pooling of the OCR head (SpatialGather_Module, spatial_ocr_block.py:58-66, one class):
 //   out[n][c] = sum_p w[n][p] * x[n][p][c]                       (fp32 accumulation, out must be zeroed by the caller)
 // and its adjoint:  dx[n][p][c] += w[n][p] * dout[n][c],   dw[n][p] = sum_c x[n][p][c] * dout[n][c].
 // One workgroup = 256 pixels x all channels of one sample; a thread owns 8 channels and strides over pixels.
-__global__ __launch_bounds__(256) void wpool_fwd_kernel(const half_t* x, long x_ld, const float* w, float* out, long hw, int c8, int chunks) {
+__global__ __launch_bounds__(256) void wpool_fwd_kernel(const half_t* x, long x_ld, const float* w, float* out, long hw, int c8, int chunks,
+                                                        long x_lo) {
   const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const long p0 = (long)chunk * 1024, p1 = min(hw, p0 + 1024);
   const int lanes_c = c8, groups = 256 / lanes_c;           // c8 <= 256 (launcher splits wider maps)
@@ -291,20 +298,25 @@ __global__ __launch_bounds__(256) void wpool_fwd_kernel(const half_t* x, long x_
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (long p = p0 + pg; p < p1; p += groups) {
     const float wv = w[(long)n * hw + p];
-    const h8 v = *reinterpret_cast<const h8*>(x + ((long)n * hw + p) * x_ld + cg * 8);
+    float v[8];
+    ld_split(x + ((long)n * hw + p) * x_ld + cg * 8, x_lo, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += wv * (float)v[e];
+    for (int e = 0; e < 8; ++e) acc[e] += wv * v[e];
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) atomicAdd(out + (long)n * c8 * 8 + cg * 8 + e, acc[e]);
 }
-extern "C" int csbsr_weighted_pool_fwd(const void* x, int64_t x_ld, const float* w, float* out, int32_t N, int64_t hw, int32_t c,
-                                       csbsr_stream_t s) {
+extern "C" int csbsr_weighted_pool_fwd_split(const void* x, int64_t x_ld, int64_t x_lo, const float* w, float* out, int32_t N, int64_t hw,
+                                             int32_t c, csbsr_stream_t s) {
   CSBSR_CHECK(x && w && out && c % 8 == 0 && c / 8 <= 256, "weighted_pool_fwd: bad args");
   const int chunks = (int)((hw + 1023) / 1024);
-  hipLaunchKernelGGL(wpool_fwd_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, x_ld, w, out, (long)hw, c / 8, chunks);
+  hipLaunchKernelGGL(wpool_fwd_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, x_ld, w, out, (long)hw, c / 8, chunks, x_lo);
   CSBSR_LAUNCH_CHECK("csbsr_weighted_pool_fwd");
   return 0;
+}
+extern "C" int csbsr_weighted_pool_fwd(const void* x, int64_t x_ld, const float* w, float* out, int32_t N, int64_t hw, int32_t c,
+                                       csbsr_stream_t s) {
+  return csbsr_weighted_pool_fwd_split(x, x_ld, 0, w, out, N, hw, c, s);
 }
 __global__ __launch_bounds__(256) void wpool_bwd_kernel(const half_t* x, long x_ld, const float* w, const float* dout, half_t* dx, long dx_ld,
                                                         float* dw, long hw, int c8) {

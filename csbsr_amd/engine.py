@@ -230,13 +230,13 @@ class Conv:
     # the epilogue's out_scale) so the lo halves of kaiming-sized weights stay in fp16's normal range
     WSCALE = 256.0
 
-    def _pack_split(self, key, kind, creal, nrows, stride, pad):
+    def _pack_split(self, key, kind, creal, nrows, stride, pad, k_off=0):
         if key in self._packed:
             return self._packed[key]
         D0, D1 = self.w.shape[0], self.w.shape[1]
         n = L.load().csbsr_packed_weight_elems_split(kind, D0, D1, self.k, self.k, stride, creal, nrows)
         dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
-        L.call("csbsr_pack_weights_split", _ptr(self.w), _ptr(dst), kind, D0, D1, self.k, self.k, stride, pad, creal, 0, nrows, 0,
+        L.call("csbsr_pack_weights_split", _ptr(self.w), _ptr(dst), kind, D0, D1, self.k, self.k, stride, pad, creal, 0, nrows, k_off,
                self.WSCALE, self.eng.stream)
         self._packed[key] = dst
         return dst
@@ -367,6 +367,23 @@ class Conv:
                      None, None, L.RES_NONE, False, None, L.STAT_NONE, 1.0 / self.WSCALE if sp else 1.0, cbias=cb)
         return out, (w16c, k16)
 
+    def fwd_const_1x1(self, cvec, x, out=None, stat=None, stat_mode=L.STAT_NONE):
+        """1x1 conv over cat(spatially constant vector [B, c0], x): the constant segment is a per-sample bias W[:, :c0] . cvec (exact; a
+        1x1 conv has no border classes).  Used for split-fp16 inputs, which cannot be paired with a plain fp16 broadcast segment."""
+        assert self.k == 1 and not self.transposed and self.stride == 1
+        c0 = self.split[0]
+        B = x.N
+        sp = bool(x.lo)
+        wt = self._pack_split("fwd_x_split", 0, self.split[1], self.cout, 1, 0, k_off=c0) if sp else self._pack("fwd_x", 0, self.split[1], 0, 0, self.cout, 1, 0, c0)
+        T = cvec.to(torch.float32) @ self.w[:, :c0, 0, 0].t()              # [B, cout]
+        cb = self.eng.f32(B, 16, pad8(self.cout))
+        cb[:, :, :self.cout] = T[:, None, :]
+        if out is None:
+            out = self.eng.new(B, x.H, x.W, self.cout, split=sp)
+        self._launch((x,), wt, False, 1, 1, 0, 1, x.H, x.W, x.H, x.W, self.cout, out, None, self.b, self.act, self.slope, self.prelu,
+                     None, None, L.RES_NONE, False, stat, stat_mode, 1.0 / self.WSCALE if sp else 1.0, cbias=cb)
+        return out
+
     def bwd_weights_folded(self, dpre, x, saved, mtap, frozen=False):
         """wgrad of the feature part on the MFMA, of the constant part from 16 border-class sums of dPre; returns dL/dk [B, c_const]."""
         w16c, k16 = saved
@@ -419,6 +436,46 @@ class Conv:
         A_real = self.w.shape[0]
         L.call("csbsr_unpack_wgrad", _ptr(g), _ptr(gacc), A_real, self.k, self.k, seg0, seg1, self.w.shape[0], self.w.shape[1], 0, 0,
                1.0, splits, a.cp, self.eng.stream)
+
+
+class ShuffleConv(Conv):
+    """ConvAndPixelShuffleBlock (MODEL.SR_PIXEL_SHUFFLE, /root/reference/model/modeling/kbpn.py:280-289): conv3x3 to cout * s^2
+    channels + activation + nn.PixelShuffle(s).
+
+    Output pixel (y s + py, x s + px), channel c is channel c s^2 + py s + px of the conv at (y, x): exactly a transposed convolution
+    with a (3s x 3s) kernel, stride s, padding s whose weight is an index permutation of the conv weight,
+        Wt[cin][c][(2 - ky) s + py][(2 - kx) s + px] = W[c s^2 + py s + px][cin][ky][kx],
+    so the layer runs on the transposed-convolution kernels (forward: s^2 output phases of 3x3 taps; dgrad: a strided conv; wgrad)
+    with that derived operand, and the weight gradient is permuted back into the master parameter's accumulator."""
+
+    def __init__(self, eng, name, params, factor, bias=False, act=L.ACT_NONE, slope=0.0, prelu=False):
+        self.master = params[name + ".weight"]
+        self.factor = s = int(factor)
+        derived = {name + ".weight": self._remap(self.master)}
+        if bias:
+            raise NotImplementedError("ConvAndPixelShuffleBlock carries no bias on this path (kbpn.py: bias=False)")
+        if prelu:
+            derived[prelu] = params[prelu]
+        super().__init__(eng, name, derived, 3 * s, s, s, 1, transposed=True, bias=False, act=act, slope=slope, prelu=prelu)
+
+    def _remap(self, w):
+        s = self.factor
+        C, cin = w.shape[0] // (s * s), w.shape[1]
+        return w.reshape(C, s, s, cin, 3, 3).flip(4, 5).permute(3, 0, 4, 1, 5, 2).reshape(cin, C, 3 * s, 3 * s).contiguous()
+
+    def _unmap(self, g):
+        s = self.factor
+        cin, C = g.shape[0], g.shape[1]
+        return g.reshape(cin, C, 3, s, 3, s).permute(1, 3, 5, 0, 2, 4).flip(4, 5).reshape(C * s * s, cin, 3, 3)
+
+    def invalidate(self):
+        super().invalidate()
+        self.w.copy_(self._remap(self.master))       # the optimiser steps the master; same tensor object keeps its accumulator
+
+    def bwd_weights(self, dpre, x, split_override=None):
+        super().bwd_weights(dpre, x, split_override)
+        grad_acc(self.master).add_(self._unmap(self.w.gacc))
+        self.w.gacc.zero_()
 
 
 def grad_acc(p):

@@ -102,8 +102,8 @@ class _JointBase(nn.Module):
         if cfg.MODEL.SR != "KBPN" or cfg.MODEL.DETECTOR_TYPE not in ("PSPNet", "PSPNet_BlurSkip", "HRNet_OCR"):
             raise NotImplementedError(f"csbsr_amd builds KBPN + PSPNet / PSPNet_BlurSkip / HRNet_OCR; got SR={cfg.MODEL.SR} "
                                       f"DETECTOR_TYPE={cfg.MODEL.DETECTOR_TYPE}")
-        if cfg.MODEL.SR_PIXEL_SHUFFLE or cfg.MODEL.SUM_LR_ERROR_POS != "HR" or not cfg.MODEL.KBPN_KERNEL_SFT:
-            raise NotImplementedError("only the default KBPN variant (deconv up-sampling, HR error sum, kernel SFT) is built")
+        if cfg.MODEL.SUM_LR_ERROR_POS != "HR" or not cfg.MODEL.KBPN_KERNEL_SFT:
+            raise NotImplementedError("only the KBPN variants with the HR error sum and the kernel SFT are built")
         self.cfg = cfg
         self.pc = path_config(cfg, antialias)
         self.scale_factor = cfg.MODEL.SCALE_FACTOR
@@ -111,7 +111,8 @@ class _JointBase(nn.Module):
         self.seg_model_name = cfg.MODEL.DETECTOR_TYPE
         self.blur_skip = self.seg_model_name == "PSPNet_BlurSkip"
         self._device = torch.device(device)
-        shapes = joint_state_shapes(self.pc.scale, self.pc.num_stages, self.pc.ksize, self.pc.ksize_out, self.seg_model_name)
+        shapes = joint_state_shapes(self.pc.scale, self.pc.num_stages, self.pc.ksize, self.pc.ksize_out, self.seg_model_name,
+                                    pixel_shuffle=self.pc.pixel_shuffle)
         # registration order = reference state_dict order: segmentation_model.* then sr_model.*
         self.segmentation_model = _ParamGroup(shapes, "segmentation_model")
         self.sr_model = _ParamGroup(shapes, "sr_model")
@@ -131,7 +132,7 @@ class _JointBase(nn.Module):
         self.max_resident = None
         self.dropout_enabled = True
         self.dropout_masks = None     # tests may inject {name: [B,C] fp32} keep-masks
-        # Precision plan of the detector's FORWARD pass (PSPNet / PSPNet_BlurSkip):
+        # Precision plan of the detector's FORWARD pass (PSPNet / PSPNet_BlurSkip / HRNet-OCR):
         #   "fp16"   fp16 activation storage, one MFMA pass (north_star's plan; the throughput configuration);
         #   "split"  activations and weights as fp16 hi + lo pairs (~22 mantissa bits), three MFMA passes per conv into one fp32
         #            accumulator -- the detector then matches the fp32 reference to ~1e-5 on identical inputs (the random-weight
@@ -176,10 +177,7 @@ class _JointBase(nn.Module):
             self._make_grad_buckets()
         if self.detector_precision not in ("fp16", "split"):
             raise ValueError(f"detector_precision must be 'fp16' or 'split', got {self.detector_precision!r}")
-        split = self.detector_precision == "split"
-        if split and self.seg_model_name == "HRNet_OCR":
-            raise NotImplementedError("detector_precision='split' is built for PSPNet / PSPNet_BlurSkip")
-        self._rt["psp"].split = split
+        self._rt["psp"].split = self.detector_precision == "split"
         return self._rt
 
     def _bucket_of(self, name):

@@ -179,11 +179,12 @@ class _HRModule:
 def sum_act(eng, terms, relu, out=None):
     t0 = terms[0]
     if out is None:
-        out = eng.new(t0.N, t0.H, t0.W, t0.c)
+        out = eng.new(t0.N, t0.H, t0.W, t0.c, split=bool(t0.lo))
     n = len(terms)
     ptrs = (C.c_void_p * 4)(*[_ptr(t.t) for t in terms], *([None] * (4 - n)))
     lds = (C.c_int64 * 4)(*[t.ld for t in terms], *([0] * (4 - n)))
-    L.call("csbsr_sum_act", t0.npix, t0.cp, n, ptrs, lds, _ptr(out.t), out.ld, int(relu), eng.stream)
+    los = (C.c_int64 * 4)(*[t.lo for t in terms], *([0] * (4 - n)))
+    L.call("csbsr_sum_act_split", t0.npix, t0.cp, n, ptrs, lds, los, _ptr(out.t), out.ld, out.lo, int(relu), eng.stream)
     return out
 
 
@@ -245,6 +246,7 @@ class HRNetOCR:
         self.fuse.conv.split = (512, 512)
         self.cls = Conv(e, prefix + ".cls_head", P, 1, bias=True)
         self.saved = None
+        self.split = False          # detector_precision == "split" (set by the model; the maps carry it: FM.lo)
 
     # ------------------------------------------------------------------ bookkeeping
     def _cbns(self):
@@ -317,7 +319,7 @@ class HRNetOCR:
             for mi, m in enumerate(mods):
                 outs = None
                 if si == len(self.stages) - 1 and mi == len(mods) - 1:      # branch 0 of the last module lands in the 720-ch concat
-                    cat = e.new(B, xs[0].H, xs[0].W, sum(self.chans))
+                    cat = e.new(B, xs[0].H, xs[0].W, sum(self.chans), split=bool(xs[0].lo))
                     outs = [cat.slice(0, self.chans[0])] + [None] * (len(xs) - 1)
                 xs = m.fwd(xs, training, outs)
             ys = xs
@@ -339,7 +341,7 @@ class HRNetOCR:
         # soft object region + pooled region vector
         probs = torch.softmax(aux_lo.reshape(B, -1), dim=1).contiguous()
         ctx = e.f32(B, 512)
-        L.call("csbsr_weighted_pool_fwd", _ptr(f.t), f.ld, _ptr(probs), _ptr(ctx), B, h * w, 512, e.stream)
+        L.call("csbsr_weighted_pool_fwd_split", _ptr(f.t), f.ld, f.lo, _ptr(probs), _ptr(ctx), B, h * w, 512, e.stream)
         keep = training and torch.is_grad_enabled()
         ctx_leaf = ctx.detach().requires_grad_(keep)
         with torch.enable_grad() if keep else torch.no_grad():
@@ -349,7 +351,16 @@ class HRNetOCR:
         ct = torch.zeros(B, 1, 1, 512, dtype=torch.float16, device=e.device)
         ct[:, 0, 0] = cvec.detach().to(torch.float16)
         cfm = FM(ct, 512, bcast=True, H=h, W=w)
-        raw, m, iv = self.fuse.fwd((cfm, f), training)
+        if f.lo:     # split-fp16 features: the constant context segment of the 1x1 fuse conv is folded into a per-sample fp32 bias
+            if training:
+                stat = self.fuse.bn.new_stat()
+                raw = self.fuse.conv.fwd_const_1x1(cvec.detach(), f, stat=stat, stat_mode=L.STAT_BN)
+                m, iv = self.fuse.bn.finalize(stat, raw.npix, update_running=True)
+            else:
+                raw = self.fuse.conv.fwd_const_1x1(cvec.detach(), f)
+                m, iv = self.fuse.bn.rmean, torch.rsqrt(self.fuse.bn.rvar + 1e-5)
+        else:
+            raw, m, iv = self.fuse.fwd((cfm, f), training)
         o = self.fuse.bn.apply(raw, m, iv, act=L.ACT_RELU, drop=drop["ocr_drop"])
         cls_lo = e.f32(B, 1, h, w, zero=False)
         self.cls.fwd(o, out32=cls_lo)

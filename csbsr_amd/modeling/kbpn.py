@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib as L
-from ..engine import FM, Conv, grad_acc, pad8, _ptr
+from ..engine import FM, Conv, ShuffleConv, grad_acc, pad8, _ptr
 from .shapes import CONV_SETTING
 
 A_NONE, A_RELU, A_LRELU, A_PRELU, A_SIG = L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU, L.ACT_PRELU, L.ACT_SIGMOID
@@ -42,6 +42,11 @@ class KBPN:
             return c
 
         def block(name, kk_, st, pd, act, transposed=False, bias=False, slope=0.01, split=None):
+            if transposed and getattr(cfg, "pixel_shuffle", False):      # MODEL.SR_PIXEL_SHUFFLE: conv3x3 + PixelShuffle(scale)
+                c = ShuffleConv(e, name + ".layer", P, self.scale, bias=bias, act=act, slope=slope,
+                                prelu=(name + ".act.weight") if act == A_PRELU else False)
+                self.layers.append(c)
+                return c
             return mk(name + ".layer", kk_, st, pd, 1, transposed=transposed, bias=bias, act=act, slope=slope,
                       prelu=(name + ".act.weight") if act == A_PRELU else False, split=split)
 

@@ -19,17 +19,24 @@ def _bn(d, pre, c):
     d[pre + ".num_batches_tracked"] = ()
 
 
-def _cb(d, pre, cin, cout, k, bias=False, prelu=False, deconv=False):
-    d[pre + ".layer.weight"] = (cin, cout, k, k) if deconv else (cout, cin, k, k)
+def _cb(d, pre, cin, cout, k, bias=False, prelu=False, deconv=False, shuffle=0):
+    """``shuffle`` = s: ConvAndPixelShuffleBlock (kbpn.py:280-289) in place of the DeconvBlock: a 3x3 conv to cout * s^2 channels"""
+    if shuffle:
+        d[pre + ".layer.weight"] = (cout * shuffle * shuffle, cin, 3, 3)
+    else:
+        d[pre + ".layer.weight"] = (cin, cout, k, k) if deconv else (cout, cin, k, k)
     if bias:
         d[pre + ".layer.bias"] = (cout,)
     if prelu:
         d[pre + ".act.weight"] = (1,)
 
 
-def kbpn_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, md=128, prefix="sr_model"):
+def kbpn_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, md=128, prefix="sr_model", pixel_shuffle=False):
+    """pixel_shuffle: MODEL.SR_PIXEL_SHUFFLE -- the four up-sampling layers of a stage are conv3x3 + PixelShuffle(scale)
+    (kbpn.py:372-373,457-459,479-480) instead of transposed convolutions; same key names, different weight shapes."""
     d = OrderedDict()
     k, s, p = CONV_SETTING[scale]
+    ps = scale if pixel_shuffle else 0
     for i, (ci, co) in zip((0, 2, 4, 6), ((3, 64), (64, 64), (64, 128), (128, 128))):
         d[f"{prefix}.feat.{i}.weight"] = (co, ci, 3, 3)
         d[f"{prefix}.feat.{i}.bias"] = (co,)
@@ -42,8 +49,8 @@ def kbpn_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, md=128, prefix="sr
         up_st = max(st - 1, 1)
         _cb(d, sp + ".up.conv", md * up_st, md, 1, bias=True, prelu=True)
         _cb(d, sp + ".up.up_conv2", md, md, k, prelu=True)
-        _cb(d, sp + ".up.up_conv1", md, md, k, prelu=True, deconv=True)
-        _cb(d, sp + ".up.up_conv3", md, md, k, prelu=True, deconv=True)
+        _cb(d, sp + ".up.up_conv1", md, md, k, prelu=True, deconv=True, shuffle=ps)
+        _cb(d, sp + ".up.up_conv3", md, md, k, prelu=True, deconv=True, shuffle=ps)
         _cb(d, sp + ".kb.sr_reconst", md * st, 3, 3)
         kp = sp + ".kb.kernel_predictor"
         _cb(d, kp + ".fe_SR.0", 3, kc, 3)
@@ -56,12 +63,12 @@ def kbpn_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, md=128, prefix="sr
         _cb(d, kp + ".fe_cat.0", 2 * kc, 32, 1)
         _cb(d, kp + ".fe_cat.1", 32, 32, 3)
         _cb(d, kp + ".fe_cat.2", 32, kc, 3)
-        _cb(d, sp + ".kb.up_conv1", 3, md, k, prelu=True, deconv=True)
+        _cb(d, sp + ".kb.up_conv1", 3, md, k, prelu=True, deconv=True, shuffle=ps)
         if st < num_stages:
             _cb(d, sp + ".down.conv", md * st, md, 1, bias=True, prelu=True)
             _cb(d, sp + ".down.down_conv1", md, md, k, prelu=True)
             _cb(d, sp + ".down.down_conv3", md, md, k, prelu=True)
-            _cb(d, sp + ".down.down_conv2", md, md, k, prelu=True, deconv=True)
+            _cb(d, sp + ".down.down_conv2", md, md, k, prelu=True, deconv=True, shuffle=ps)
             cc = md * st + cond
             for nm, co in (("SFT_scale_conv0", cc), ("SFT_scale_conv1", md * st), ("SFT_shift_conv0", cc), ("SFT_shift_conv1", md * st)):
                 d[f"{sp}.sft.{nm}.weight"] = (co, cc, 3, 3)
@@ -183,7 +190,7 @@ def hrnet_ocr_shapes(prefix="segmentation_model", n_classes=1):
     return d
 
 
-def joint_state_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, detector="PSPNet"):
+def joint_state_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, detector="PSPNet", pixel_shuffle=False):
     """state_dict order of JointModelWithLoss: segmentation_model.* first, then sr_model.*
     (MetaSSModel.__init__ runs before MetaSRModel's body, build_model.py:52-60,191-197)."""
     d = OrderedDict()
@@ -195,5 +202,5 @@ def joint_state_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, detector="P
         d.update(hrnet_ocr_shapes())
     else:
         raise NotImplementedError(detector)
-    d.update(kbpn_shapes(scale, num_stages, ksize, ksize_out))
+    d.update(kbpn_shapes(scale, num_stages, ksize, ksize_out, pixel_shuffle=pixel_shuffle))
     return d

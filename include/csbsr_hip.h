@@ -187,6 +187,10 @@ int csbsr_maxpool3x3s2_bwd_split(const void* x, int64_t x_ld, int64_t x_lo, cons
                                  const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s);
 int csbsr_adaptive_avgpool_fwd_split(const void* x, int64_t x_ld, int64_t x_lo, void* y, int64_t y_ld, int64_t y_lo, int32_t N,
                                      int32_t H, int32_t W, int32_t c, int32_t OH, int32_t OW, csbsr_stream_t s);
+int csbsr_sum_act_split(int64_t npix, int32_t c, int32_t n, const void* const* xs, const int64_t* x_lds, const int64_t* x_los, void* y,
+                        int64_t y_ld, int64_t y_lo, int32_t relu, csbsr_stream_t s);
+int csbsr_weighted_pool_fwd_split(const void* x, int64_t x_ld, int64_t x_lo, const float* w, float* out, int32_t N, int64_t hw,
+                                  int32_t c, csbsr_stream_t s);
 int csbsr_bilinear_fwd_split(const void* x, int64_t x_ld, int64_t x_lo, void* y, int64_t y_ld, int64_t y_lo, int32_t N, int32_t H,
                              int32_t W, int32_t c, int32_t OH, int32_t OW, int32_t align_corners, const float* drop,
                              csbsr_stream_t s);

@@ -56,6 +56,7 @@ class PathCfg:
         self.oriented_w_iter = -1            # SOLVER.ORIENTED_WEIGHT_ITER
         self.sfo_sr_amp = 0.0                # SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP
         self.detector = "PSPNet"             # MODEL.DETECTOR_TYPE: "PSPNet" | "PSPNet_BlurSkip" | "HRNet_OCR"
+        self.pixel_shuffle = False           # MODEL.SR_PIXEL_SHUFFLE
         self.__dict__.update(kw)
 
     @property
@@ -75,8 +76,12 @@ def conv_block(P, pre, x, stride=1, padding=1, dilation=1, act=None, slope=0.01)
     return _act(P, pre, y, act, slope)
 
 
-def deconv_block(P, pre, x, stride, padding, act=None):
-    """DeconvBlock.  kbpn.py:273-277."""
+def deconv_block(P, pre, x, stride, padding, act=None, pixel_shuffle=False):
+    """DeconvBlock, kbpn.py:273-277 -- or, with MODEL.SR_PIXEL_SHUFFLE, ConvAndPixelShuffleBlock, kbpn.py:280-289: conv3x3 to
+    cout * s^2 channels, activation, nn.PixelShuffle(s)."""
+    if pixel_shuffle:
+        y = F.conv2d(x, P[pre + ".layer.weight"], P.get(pre + ".layer.bias"), 1, 1)
+        return F.pixel_shuffle(_act(P, pre, y, act, 0.01), stride)
     y = F.conv_transpose2d(x, P[pre + ".layer.weight"], P.get(pre + ".layer.bias"), stride, padding)
     return _act(P, pre, y, act, 0.01)
 
@@ -147,9 +152,9 @@ def up_block(P, pre, x, cfg):
     """kbpn.py:450-469."""
     k, s, p = cfg.conv_kspd
     x = conv_block(P, pre + ".conv", x, 1, 0, act="prelu")
-    h0 = deconv_block(P, pre + ".up_conv1", x, s, p, act="prelu")
+    h0 = deconv_block(P, pre + ".up_conv1", x, s, p, act="prelu", pixel_shuffle=cfg.pixel_shuffle)
     l0 = conv_block(P, pre + ".up_conv2", h0, s, p, act="prelu")
-    h1 = deconv_block(P, pre + ".up_conv3", l0 - x, s, p, act="prelu")
+    h1 = deconv_block(P, pre + ".up_conv3", l0 - x, s, p, act="prelu", pixel_shuffle=cfg.pixel_shuffle)
     return h1 + h0
 
 
@@ -158,7 +163,7 @@ def down_block(P, pre, x, cfg):
     k, s, p = cfg.conv_kspd
     x = conv_block(P, pre + ".conv", x, 1, 0, act="prelu")
     l0 = conv_block(P, pre + ".down_conv1", x, s, p, act="prelu")
-    h0 = deconv_block(P, pre + ".down_conv2", l0, s, p, act="prelu")
+    h0 = deconv_block(P, pre + ".down_conv2", l0, s, p, act="prelu", pixel_shuffle=cfg.pixel_shuffle)
     l1 = conv_block(P, pre + ".down_conv3", h0 - x, s, p, act="prelu")
     return l1 + l0
 
@@ -207,7 +212,7 @@ def k_block(P, pre, concat_h, h, x_lr, kvec, it, cfg):
     vec = kvec / kvec.sum(dim=1, keepdim=True)
     pseudo_lr = blur_down(sr_t, vec, cfg.ksize_out, cfg.scale)
     err = pseudo_lr - x_lr
-    e_h = deconv_block(P, pre + ".up_conv1", err, s, p, act="prelu")
+    e_h = deconv_block(P, pre + ".up_conv1", err, s, p, act="prelu", pixel_shuffle=cfg.pixel_shuffle)
     return h + e_h, vec, sr_t
 
 

@@ -120,7 +120,7 @@ def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha
                alpha=np.float64(model.ss_loss_fn.alpha), antialias=np.bool_(antialias), scale=np.int64(scale),
                detector=np.array(detector), sfo_sr_amp=np.float64(cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP),
                oriented_w_iter=np.int64(cfg.SOLVER.ORIENTED_WEIGHT_ITER), beta=np.float64(cfg.SOLVER.TASK_LOSS_WEIGHT),
-               torch_version=np.array(torch.__version__))
+               pixel_shuffle=np.bool_(cfg.MODEL.SR_PIXEL_SHUFFLE), torch_version=np.array(torch.__version__))
     for kname, v in cap.masks.items():
         if v is not None:
             out["dropmask." + kname] = v.numpy()
@@ -351,6 +351,8 @@ if __name__ == "__main__":
     # BASELINE config 4: HRNet-W48 + OCR detector, beta = 0.9, batch 4 (BatchNorm over the 4 object-context vectors)
     run_case("e2e_hrnet_ocr_it40000", 40000, B=4, alpha=0.8, detector="HRNet_OCR", seed=13, dropout=True,
              overrides=("SOLVER.TASK_LOSS_WEIGHT", 0.9))
+    # MODEL.SR_PIXEL_SHUFFLE = True (north_star's "PixelShuffle x4 upsample"): conv3x3 + PixelShuffle in place of the four deconvs per stage
+    run_case("e2e_pspnet_pixelshuffle_it20001", 20001, seed=17, overrides=("MODEL.SR_PIXEL_SHUFFLE", True))
     # config 2 with the w^F weight on (README row 'CSBSR w/ PSPNet + w^F')
     run_case("e2e_pspnet_wf_it40000", 40000, alpha=0.7, seed=11,
              overrides=("SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP", 1.0, "SOLVER.ORIENTED_WEIGHT_ITER", 0))

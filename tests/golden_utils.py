@@ -28,11 +28,13 @@ def golden_cfg(g):
         kw.update(detector=str(g["detector"]), sfo_sr_amp=float(g["sfo_sr_amp"]), oriented_w_iter=int(g["oriented_w_iter"]))
     if "beta" in g:
         kw.update(beta=float(g["beta"]))
+    if "pixel_shuffle" in g:
+        kw.update(pixel_shuffle=bool(g["pixel_shuffle"]))
     return O.PathCfg(**kw)
 
 
-def det_params(scale=4, num_stages=4, detector="PSPNet", requires_grad=True):
-    shapes = joint_state_shapes(scale=scale, num_stages=num_stages, detector=detector)
+def det_params(scale=4, num_stages=4, detector="PSPNet", requires_grad=True, pixel_shuffle=False):
+    shapes = joint_state_shapes(scale=scale, num_stages=num_stages, detector=detector, pixel_shuffle=pixel_shuffle)
     sd = det_state_dict(shapes)
     if requires_grad:
         for k, v in sd.items():

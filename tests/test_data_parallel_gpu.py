@@ -2,8 +2,12 @@
 reducer, the bucket layout, the side-stream launches and their ordering are the same code as with nccl).
 
   * iter 1 (SR pretrain: no BatchNorm in the gradient): 2 ranks x B=2 after the all-reduce == 1 rank x B=4, every KBPN gradient;
-  * iter 40000 (joint phase, BatchNorm per replica as in the reference's multi-GPU behaviour): every rank's result == the average of
-    the two shards' single-process gradients -- segmentation bucket and the per-stage KBPN buckets launched under the backward.
+  * iter 40000 (joint phase, BatchNorm per replica as in the reference's multi-GPU behaviour): every bucket -- the segmentation
+    bucket launched under the KBPN backward, the per-stage KBPN buckets launched under the last micro-batch's backward -- ends up
+    holding exactly the mean over ranks of what it held when it was launched (nothing launched early, twice or not at all), in the
+    order the backward completes them.  (Comparing with separately computed single-process gradients is not a test there: two runs
+    of the SAME shard differ by ~20 % in relative L2 at this size -- fp32-atomics order in the kernel predictor's pooling sums
+    flips fp16 roundings of the SR image and the random-weight detector amplifies that, see tests/test_wc_parity_gpu.py.)
 """
 import os
 import socket
@@ -47,6 +51,25 @@ def _grads(m, it, batch):
     return {n: (None if p.grad is None else p.grad.detach().cpu().clone()) for n, p in m._named_full() if isinstance(p, torch.nn.Parameter)}
 
 
+class _RecordingReducer:
+    """GradBucketReducer that keeps a copy of every bucket as it stood at launch time"""
+
+    def __init__(self, inner):
+        self.inner, self.snaps, self.order = inner, {}, []
+
+    def launch_flat(self, flat):
+        if flat is not None:
+            self.snaps[flat.data_ptr()] = flat.clone()
+            self.order.append(flat.data_ptr())
+        return self.inner.launch_flat(flat)
+
+    def launch(self, grads):
+        return self.inner.launch(grads)
+
+    def finish(self):
+        return self.inner.finish()
+
+
 def _worker(rank, world, port, it, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -59,10 +82,20 @@ def _worker(rank, world, port, it, out):
     m = _build(micro_batch=1)            # two micro-batches per rank: the bucket launches ride on the LAST one's backward
     m._runtime()
     broadcast_parameters(m)
-    m.reducer = GradBucketReducer(side_stream=torch.cuda.Stream(torch.device("cuda:0")))
+    m.reducer = _RecordingReducer(GradBucketReducer(side_stream=torch.cuda.Stream(torch.device("cuda:0"))))
     full = make_batch(4, 16, seed=21)
     shard = tuple(t[rank * 2:(rank + 1) * 2] for t in full)
-    out[rank] = _grads(m, it, shard)
+    grads = _grads(m, it, shard)
+    # every bucket == mean over ranks of its launch-time contents (a plain blocking all-reduce of the snapshots is the reference)
+    names = {f.data_ptr(): b for b, f in m._rt["flat"].items()}
+    audit = {}
+    for ptr in m.reducer.order:
+        exp = m.reducer.snaps[ptr]
+        dist.all_reduce(exp)
+        exp /= world
+        flat = m._rt["flat"][names[ptr]]
+        audit[names[ptr]] = (float((flat - exp).abs().max()), float(exp.abs().max()))
+    out[rank] = (grads, [names[p] for p in m.reducer.order], audit)
     dist.destroy_process_group()
 
 
@@ -73,24 +106,31 @@ def test_two_ranks_equal_the_global_batch(it):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), it, out), nprocs=world, join=True)
-    g0, g1 = out[0], out[1]
+    (g0, order0, audit0), (g1, order1, audit1) = out[0], out[1]
+    assert order0 == order1
+    for n in g0:
+        assert (g0[n] is None) == (g1[n] is None), n
+        if g0[n] is not None:
+            assert torch.equal(g0[n], g1[n]), n                    # every replica holds the same reduced gradient
+    for audit in (audit0, audit1):
+        for b, (dev, scale) in audit.items():
+            assert dev <= 1e-7 * max(scale, 1e-30), (b, dev, scale)
+    if it != 1:
+        # segmentation bucket first (under the whole KBPN backward), then the KBPN stages in reverse, the predictor / VGG head last
+        assert order0 == ["seg", "kbpn.4", "kbpn.3", "kbpn.2", "kbpn.1", "kbpn.0"], order0
+        assert sum(1 for v in g0.values() if v is not None) == 290
+        print("iter 40000: buckets", order0, "max deviation from the mean of the launch-time contents",
+              max(d for d, _ in audit0.values()))
+        return
+    assert order0 == ["kbpn.4", "kbpn.3", "kbpn.2", "kbpn.1", "kbpn.0"], order0
     full = make_batch(4, 16, seed=21)
     m = _build(micro_batch=2)
-    if it == 1:          # no batch-coupled op in the gradient: the all-reduced result IS the global-batch gradient
-        ref = _grads(m, it, full)
-    else:                # per-replica BatchNorm: the all-reduced result is the average of the shards' own gradients
-        ga = _grads(m, it, tuple(t[0:2] for t in full))
-        sd = m.state_dict()
-        from csbsr_amd.utils.detfill import deterministic_fill
-        deterministic_fill(sd)          # (running statistics moved in the first pass; gradients do not depend on them in train mode)
-        gb = _grads(m, it, tuple(t[2:4] for t in full))
-        ref = {n: (None if ga[n] is None else 0.5 * (ga[n] + gb[n])) for n in ga}
+    ref = _grads(m, it, full)          # no batch-coupled op in the gradient: the all-reduced result IS the global-batch gradient
     worst, n_checked, devs = 0.0, 0, []
     for n, r in ref.items():
-        assert (r is None) == (g0[n] is None) == (g1[n] is None), n
+        assert (r is None) == (g0[n] is None), n
         if r is None:
             continue
-        assert torch.equal(g0[n], g1[n]), n                        # every replica holds the same reduced gradient
         den = float(r.norm())
         if den < 1e-12:
             continue
@@ -99,16 +139,9 @@ def test_two_ranks_equal_the_global_batch(it):
         n_checked += 1
         if r.numel() > 1:
             devs.append(e)
-        if it == 1:
-            # fp32 accumulation order differs (pixel splits of the wgrad slabs) and the loss scale differs by 2x between B=2 and B=4
-            # (a power of two: fp16 roundings identical short of underflow): fp32-noise level
-            assert e < (2e-3 if r.numel() > 1 else 5e-2), (n, e)
+        # fp32 accumulation order differs (pixel splits of the wgrad slabs) and the loss scale differs by 2x between B=2 and B=4
+        # (a power of two: fp16 roundings identical short of underflow): fp32-noise level
+        assert e < (2e-3 if r.numel() > 1 else 5e-2), (n, e)
     devs = torch.tensor(devs)
     print(f"iter {it}: {n_checked} gradient tensors, relative L2 deviation median {float(devs.median()):.2e} worst {worst:.2e}")
-    assert n_checked > (100 if it == 1 else 250)
-    if it != 1:
-        # joint phase: two runs of the SAME shard already differ at this level -- the order of the fp32 atomics behind the kernel
-        # predictor's global-average-pool sums flips fp16 roundings of the SR image, and the random-weight detector amplifies that
-        # ~100x (tests/test_wc_parity_gpu.py) -- so the check is that the exchange happened for every bucket (bit-equal replicas,
-        # above) and that the result is the shards' average up to that run-to-run noise
-        assert float(devs.median()) < 5e-2 and worst < 0.6
+    assert n_checked > 100

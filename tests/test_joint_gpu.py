@@ -35,6 +35,8 @@ def build_model(g, micro_batch=8):
         cfg.MODEL.DETECTOR_TYPE = str(g["detector"])
         cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP = float(g["sfo_sr_amp"])
         cfg.SOLVER.ORIENTED_WEIGHT_ITER = int(g["oriented_w_iter"])
+    if "pixel_shuffle" in g:
+        cfg.MODEL.SR_PIXEL_SHUFFLE = bool(g["pixel_shuffle"])
     m = JointModelWithLoss(cfg, 1000, 0, None, antialias=bool(g["antialias"]))
     deterministic_fill(m.state_dict())
     m.ss_loss_fn.alpha = float(g["alpha"])
@@ -66,7 +68,7 @@ def run_hip(g, micro_batch=8):
 
 def run_oracle(g):
     cfg = golden_cfg(g)
-    P = det_params(scale=cfg.scale, detector=cfg.detector)
+    P = det_params(scale=cfg.scale, detector=cfg.detector, pixel_shuffle=cfg.pixel_shuffle)
     t = lambda k: torch.from_numpy(g[k])
     drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
     out = O.joint_forward(P, cfg, int(g["it"]), t("x"), t("hr"), t("mask"), t("kernel"), alpha=float(g["alpha"]), drop=drop or None)
@@ -77,7 +79,7 @@ def run_oracle(g):
 
 @pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "e2e_pspnet_it10001",
                                   "e2e_pspnet_it20001", "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24", "e2e_blurskip_x8_it40000",
-                                  "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000"])
+                                  "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000", "e2e_pspnet_pixelshuffle_it20001"])
 def test_forward_matches_golden(case):
     g = load_golden(case)
     det = str(g["detector"]) if "detector" in g else "PSPNet"
@@ -95,7 +97,8 @@ def test_forward_matches_golden(case):
 
 
 @pytest.mark.parametrize("case", ["e2e_pspnet_it1", "e2e_pspnet_it10001", "e2e_pspnet_it20001", "e2e_pspnet_it40000",
-                                  "e2e_pspnet_it40000_dropout", "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000"])
+                                  "e2e_pspnet_it40000_dropout", "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000",
+                                  "e2e_pspnet_pixelshuffle_it20001"])
 def test_gradients_match_oracle(case):
     """Per-parameter relative L2 error of the HIP gradients vs the fp32 oracle.
 

@@ -9,7 +9,7 @@ from oracle import csbsr_oracle as O
 
 CASES = ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "e2e_pspnet_it10001",
          "e2e_pspnet_it20001", "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24",
-         "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000"]
+         "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000", "e2e_pspnet_pixelshuffle_it20001"]
 
 # fp32 CPU vs fp32 CPU, same torch build: differences come only from op ordering (grouped conv vs the
 # reference's per-sample loop, vector kernel vs expanded map)
@@ -19,7 +19,7 @@ TOL_GRAD = 3e-2   # fp32 evaluation-order noise: up to 1.1e-2 on kb.sr_reconst w
 
 def run_oracle(g, grads=True):
     cfg = golden_cfg(g)
-    P = det_params(scale=cfg.scale, detector=cfg.detector, requires_grad=grads)
+    P = det_params(scale=cfg.scale, detector=cfg.detector, requires_grad=grads, pixel_shuffle=cfg.pixel_shuffle)
     t = lambda k: torch.from_numpy(g[k])
     drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
     taps = {}

@@ -110,8 +110,8 @@ def _assert_grads(errs, bound, what, dist_only=None):
 
 
 @pytest.mark.parametrize("case,precision", [("wc_pspnet_it40000", "split"), ("wc_blurskip_x8_it40000", "split"),
-                                            ("wc_pspnet_it40000", "fp16"), ("wc_blurskip_x8_it40000", "fp16"),
-                                            ("wc_hrnet_ocr_it40000", "fp16")])
+                                            ("wc_hrnet_ocr_it40000", "split"), ("wc_pspnet_it40000", "fp16"),
+                                            ("wc_blurskip_x8_it40000", "fp16"), ("wc_hrnet_ocr_it40000", "fp16")])
 def test_detector_on_reference_sr(case, precision):
     """a11 / a11' / a11'' / a13 / a16 (detector half): forward + losses + backward from the reference's own SR image."""
     g = load_golden(case)
@@ -172,7 +172,8 @@ def test_kbpn_backward_on_reference_gradient(case):
 
 
 @pytest.mark.parametrize("case,precision", [("wc_pspnet_it40000", "split"), ("wc_pspnet_it40000", "fp16"),
-                                            ("wc_blurskip_x8_it40000", "split"), ("wc_hrnet_ocr_it40000", "fp16")])
+                                            ("wc_blurskip_x8_it40000", "split"), ("wc_hrnet_ocr_it40000", "fp16"),
+                                            ("wc_hrnet_ocr_it40000", "split")])
 def test_end_to_end_at_well_conditioned_size(case, precision):
     """The composed path: KBPN outputs within north_star's 1e-3; the segmentation side within the reference's own recorded response
     to an SR error of that size (fixture keys cond_*: fixed numbers measured on the reference, see the module docstring)."""
