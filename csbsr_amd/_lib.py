@@ -70,8 +70,8 @@ SIGNATURES = {
     "csbsr_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp]),
     "csbsr_packed_weight_elems": (i64, [i32] * 9),
     "csbsr_pack_weights": (i32, [vp, vp] + [i32] * 12 + [vp]),
-    "csbsr_packed_weight_elems_split": (i64, [i32] * 8),
-    "csbsr_pack_weights_split": (i32, [vp, vp] + [i32] * 11 + [f32, vp]),
+    "csbsr_packed_weight_elems_split": (i64, [i32] * 9),
+    "csbsr_pack_weights_split": (i32, [vp, vp] + [i32] * 11 + [f32, i32, vp]),
     "csbsr_axpby_split": (i32, [i64, i32, vp, i64, i64, f32, vp, i64, i64, f32, vp, i64, i64, vp]),
     "csbsr_nchw32_to_nhwc16_split": (i32, [vp, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp]),
     "csbsr_maxpool3x3s2_fwd_split": (i32, [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),

@@ -9,7 +9,7 @@ struct PackK {
   int D0, D1, KH, KW, stride, pad;
   int seg0_real, seg0_p, segtot_p, chan_real;
   int row_off, nrows, rows_p, Kp, KHt, KWt, nphase, k_off;
-  int split;           // 1: K channels are [hi | hi | lo] blocks of seg0_p each (csbsr_pack_weights_split)
+  int split;           // 1: K channels are [hi | hi | lo] blocks of seg0_p each, 2: [hi | lo] (csbsr_pack_weights_split)
   float wscale;        // weights are multiplied by this power of two before the fp16 split (keeps the lo halves out of subnormals)
 };
 
@@ -46,7 +46,7 @@ __global__ void pack_weights_kernel(const PackK p) {
     if (p.split) {
       v *= p.wscale;
       const half_t hi = (half_t)v;
-      p.dst[i] = blk < 2 ? hi : (half_t)(v - (float)hi);
+      p.dst[i] = blk < (p.split == 1 ? 2 : 1) ? hi : (half_t)(v - (float)hi);
     } else {
       p.dst[i] = (half_t)v;
     }
@@ -70,11 +70,14 @@ static void pack_geometry(int kind, int D0, int D1, int KH, int KW, int stride, 
 }
 // split-fp16 operand: the activation arrives as in[0] = [x_hi | x_lo] (2c channels), in[1] = x_hi (c channels), so per tap the K
 // axis is three blocks of c channels holding [w_hi | w_hi | w_lo]:  x_hi w_hi + x_lo w_hi + x_hi w_lo  (x_lo w_lo ~ 2^-22 dropped)
-static void pack_geometry_split(int kind, int D0, int D1, int KH, int KW, int stride, int creal, int nrows, PackK& p) {
+// layout 1 (dgrad of the split-precision detector): the activation gradient is plain fp16, passed as in[0] = in[1] = dY, against
+// [w_hi | w_lo]:  dY w_hi + dY w_lo -- the weight's fp16 rounding error is the same for every pixel, so unlike the (incoherent)
+// rounding of the gradients it does not average out in the BatchNorm backward sums
+static void pack_geometry_split(int kind, int D0, int D1, int KH, int KW, int stride, int creal, int nrows, int layout, PackK& p) {
   pack_geometry(kind, D0, D1, KH, KW, stride, creal, 0, nrows, p);
-  p.segtot_p = 3 * p.seg0_p;
+  p.segtot_p = (layout == 1 ? 2 : 3) * p.seg0_p;
   p.Kp = round_up(p.KHt * p.KWt * p.segtot_p, 64);
-  p.split = 1;
+  p.split = layout == 1 ? 2 : 1;
 }
 
 extern "C" int64_t csbsr_packed_weight_elems(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,
@@ -105,22 +108,22 @@ extern "C" int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32
 }
 
 extern "C" int64_t csbsr_packed_weight_elems_split(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t stride,
-                                                   int32_t creal, int32_t nrows) {
+                                                   int32_t creal, int32_t nrows, int32_t layout) {
   PackK p;
-  pack_geometry_split(kind, D0, D1, KH, KW, stride, creal, nrows, p);
+  pack_geometry_split(kind, D0, D1, KH, KW, stride, creal, nrows, layout, p);
   return (int64_t)p.nphase * p.rows_p * p.Kp;
 }
 
 extern "C" int csbsr_pack_weights_split(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,
                                         int32_t stride, int32_t pad, int32_t creal, int32_t row_off, int32_t nrows, int32_t k_off,
-                                        float wscale, csbsr_stream_t s) {
+                                        float wscale, int32_t layout, csbsr_stream_t s) {
   CSBSR_CHECK(w && dst, "pack_split: null pointer");
   CSBSR_CHECK(kind >= 0 && kind <= 2, "pack_split: bad kind");
   const int kdim = kind == 0 ? D1 : D0, rdim = kind == 0 ? D0 : D1;
   CSBSR_CHECK(k_off >= 0 && k_off + creal <= kdim, "pack_split: channels (%d at %d) exceed the contracted dim (%d)", creal, k_off, kdim);
   CSBSR_CHECK(row_off >= 0 && row_off + nrows <= rdim, "pack_split: row range out of bounds");
   PackK p;
-  pack_geometry_split(kind, D0, D1, KH, KW, stride, creal, nrows, p);
+  pack_geometry_split(kind, D0, D1, KH, KW, stride, creal, nrows, layout, p);
   p.w = w; p.dst = reinterpret_cast<half_t*>(dst); p.pad = pad; p.row_off = row_off; p.k_off = k_off; p.wscale = wscale;
   const long total = (long)p.nphase * p.rows_p * p.Kp;
   int blocks = (int)((total + 255) / 256);

@@ -210,6 +210,7 @@ class Conv:
         self.act, self.slope = act, slope
         self.prelu = params[prelu] if prelu else None
         self._packed = {}
+        self.hp_dgrad = False        # detector precision mode: dgrad against [w_hi | w_lo] (two MFMA passes), see bwd_input
 
     # -- packed operand cache (invalidated by the model at every optimiser step)
     def invalidate(self):
@@ -230,14 +231,14 @@ class Conv:
     # the epilogue's out_scale) so the lo halves of kaiming-sized weights stay in fp16's normal range
     WSCALE = 256.0
 
-    def _pack_split(self, key, kind, creal, nrows, stride, pad, k_off=0):
+    def _pack_split(self, key, kind, creal, nrows, stride, pad, k_off=0, layout=0, row_off=0):
         if key in self._packed:
             return self._packed[key]
         D0, D1 = self.w.shape[0], self.w.shape[1]
-        n = L.load().csbsr_packed_weight_elems_split(kind, D0, D1, self.k, self.k, stride, creal, nrows)
+        n = L.load().csbsr_packed_weight_elems_split(kind, D0, D1, self.k, self.k, stride, creal, nrows, layout)
         dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
-        L.call("csbsr_pack_weights_split", _ptr(self.w), _ptr(dst), kind, D0, D1, self.k, self.k, stride, pad, creal, 0, nrows, k_off,
-               self.WSCALE, self.eng.stream)
+        L.call("csbsr_pack_weights_split", _ptr(self.w), _ptr(dst), kind, D0, D1, self.k, self.k, stride, pad, creal, row_off, nrows, k_off,
+               self.WSCALE, layout, self.eng.stream)
         self._packed[key] = dst
         return dst
 
@@ -325,7 +326,18 @@ class Conv:
         row_off = 0 if seg == 0 else self.split[0]
         k, s, p, d = self.k, self.stride, self.pad, self.dil
         H, W = dpre.H, dpre.W
-        if self.transposed:                      # dgrad of a transposed conv = strided conv on dOut
+        hp = self.hp_dgrad and not dpre.bcast and not self.transposed
+        if hp:       # weights as fp16 hi + lo pairs against the (plain fp16) gradient passed twice
+            kind = 1 if s == 1 else 2
+            wt = self._pack_split(("dg_hp", seg), kind, self.cout, c_seg, s if kind == 2 else 1, p, layout=1, row_off=row_off)
+            if s == 1:
+                OH, OW = in_hw if in_hw else (H + 2 * (d * (k - 1) - p) - d * (k - 1), W + 2 * (d * (k - 1) - p) - d * (k - 1))
+                tr, ps, pp, dd = False, 1, d * (k - 1) - p, d
+            else:
+                assert d == 1 and in_hw is not None
+                OH, OW = in_hw
+                tr, ps, pp, dd = True, s, p, 1
+        elif self.transposed:                      # dgrad of a transposed conv = strided conv on dOut
             wt = self._pack(("dg", seg), 0, self.cout, 0, row_off, c_seg, s, p)
             OH, OW = in_hw if in_hw else ((H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1)
             tr, ps, pp, dd = False, s, p, 1
@@ -340,8 +352,9 @@ class Conv:
             tr, ps, pp, dd = True, s, p, 1
         if out is None and out32 is None and stat is None:
             out = self.eng.new(dpre.N, OH, OW, c_seg)
-        self._launch((dpre,), wt, tr, k, ps, pp, dd, H, W, OH, OW, c_seg, out, out32, None, L.ACT_NONE, 0.0, None, None, None,
-                     L.RES_NONE, accumulate, stat, L.STAT_SAMPLE_SUM if stat is not None else L.STAT_NONE, 1.0, mask=mask)
+        self._launch((dpre, dpre) if hp else (dpre,), wt, tr, k, ps, pp, dd, H, W, OH, OW, c_seg, out, out32, None, L.ACT_NONE, 0.0, None,
+                     None, None, L.RES_NONE, accumulate, stat, L.STAT_SAMPLE_SUM if stat is not None else L.STAT_NONE,
+                     1.0 / self.WSCALE if hp else 1.0, mask=mask)
         return out
 
     # -- exact folding of a spatially constant second input segment (SFT conv0: cat(features, kernel code), kbpn.py:513)

@@ -177,7 +177,10 @@ class _JointBase(nn.Module):
             self._make_grad_buckets()
         if self.detector_precision not in ("fp16", "split"):
             raise ValueError(f"detector_precision must be 'fp16' or 'split', got {self.detector_precision!r}")
-        self._rt["psp"].split = self.detector_precision == "split"
+        split = self.detector_precision == "split"
+        self._rt["psp"].split = split
+        for c in self._rt["psp"].all_convs():      # the split mode's dgrads run against fp16 hi + lo weight pairs (Conv.bwd_input)
+            c.hp_dgrad = split
         return self._rt
 
     def _bucket_of(self, name):

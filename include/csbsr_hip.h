@@ -130,11 +130,13 @@ int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32_t D0, int3
  * csbsr_conv_forward as in[0] = [x_hi | x_lo], in[1] = x_hi:  x_hi w_hi + x_lo w_hi + x_hi w_lo in ONE fp32 accumulator (three
  * MFMA passes; the dropped x_lo w_lo term is ~2^-22 relative).  wscale (a power of two, undone by the conv's out_scale) keeps w_lo
  * out of fp16's subnormal range.  Single-segment layers only. */
+/* layout 0: the three-block forward operand above.  layout 1: two blocks [w_hi | w_lo] for the dgrads of that mode, whose input (a
+ * plain fp16 activation gradient) is passed twice, in[0] = in[1] = dY. */
 int64_t csbsr_packed_weight_elems_split(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t stride,
-                                        int32_t creal, int32_t nrows);
+                                        int32_t creal, int32_t nrows, int32_t layout);
 int csbsr_pack_weights_split(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,
                              int32_t stride, int32_t pad, int32_t creal, int32_t row_off, int32_t nrows, int32_t k_off,
-                             float wscale, csbsr_stream_t s);
+                             float wscale, int32_t layout, csbsr_stream_t s);
 /* packed fp32 wgrad slabs G[split][ca_padded][tap][b(padded segments)] -> grad[a][b_off + b][kh][kw] += scale * sum_split G
  * (grad is [D0][D1][KH][KW]; transpose_ab: a indexes D1 and b indexes D0) */
 int csbsr_unpack_wgrad(const float* g, float* grad, int32_t A, int32_t KH, int32_t KW, int32_t seg0_real,
