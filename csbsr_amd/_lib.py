@@ -68,6 +68,10 @@ SIGNATURES = {
     "csbsr_last_error": (C.c_char_p, []),
     "csbsr_conv_forward": (i32, [C.POINTER(ConvDesc), vp]),
     "csbsr_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp]),
+    "csbsr_conv_hr_eligible": (i32, [C.POINTER(ConvDesc)]),
+    "csbsr_conv_hr_forward": (i32, [C.POINTER(ConvDesc), vp]),
+    "csbsr_packed_weight_elems_hr": (i64, [i32, i32]),
+    "csbsr_pack_weights_hr": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "csbsr_packed_weight_elems": (i64, [i32] * 9),
     "csbsr_pack_weights": (i32, [vp, vp] + [i32] * 12 + [vp]),
     "csbsr_packed_weight_elems_split": (i64, [i32] * 9),

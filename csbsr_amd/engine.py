@@ -14,6 +14,7 @@ PyTorch is used for device memory and the current HIP stream only.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -111,6 +112,7 @@ class Engine:
         self._ws = None
         self._red = _reduction_scratch(self.device) if torch.cuda.is_available() else None
         self.training = True
+        self.use_hr = os.environ.get("CSBSR_CONV_HR", "1") != "0"       # A/B hook: 0 routes the HR small-channel layers through the implicit-GEMM kernels
         self.timing = None              # list of (kind, flops, bytes, start_event, end_event) when profiling is on
 
     @property
@@ -249,7 +251,7 @@ class Conv:
         return (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
 
     def _launch(self, xs, wt, transposed, k, stride, pad, dil, H, W, OH, OW, cout, out, out32, bias, act, slope, prelu, res, res2,
-                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None):
+                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None, hr=None):
         d = L.ConvDesc()
         x0 = xs[0]
         if x0.lo:                       # split-fp16 input: [hi | lo] + hi again, weights from _pack_split
@@ -288,7 +290,20 @@ class Conv:
         if tm is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        L.call("csbsr_conv_forward", C.byref(d), self.eng.stream)
+        # full-resolution 32 / 49-channel 3x3 layers: the direct kernel (csrc/conv_hr.hip) with its own fragment-ordered weights
+        if hr is not None and self.eng.use_hr and L.load().csbsr_conv_hr_eligible(C.byref(d)):
+            kind, c_real, rows_real, row_off = hr
+            key = ("hr", kind, row_off)
+            if key not in self._packed:
+                n = L.load().csbsr_packed_weight_elems_hr(c_real, rows_real)
+                dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
+                L.call("csbsr_pack_weights_hr", _ptr(self.w), _ptr(dst), kind, self.w.shape[0], self.w.shape[1], c_real, rows_real, row_off, 0,
+                       self.eng.stream)
+                self._packed[key] = dst
+            d.wt = _ptr(self._packed[key])
+            L.call("csbsr_conv_hr_forward", C.byref(d), self.eng.stream)
+        else:
+            L.call("csbsr_conv_forward", C.byref(d), self.eng.stream)
         if tm is not None:
             ev1.record()
             ctot = sum(f.c for f in xs)
@@ -314,8 +329,9 @@ class Conv:
             wt = self._pack("fwd", 2, self.split[0], self.split[1], 0, self.cout, self.stride, self.pad)
         else:
             wt = self._pack("fwd", 0, self.split[0], self.split[1], 0, self.cout, self.stride, self.pad)
+        hr = (0, self.cin, self.cout, 0) if (not sp and not self.transposed and self.k == 3 and len(xs) == 1 and self.prelu is None) else None
         self._launch(xs, wt, self.transposed, self.k, self.stride, self.pad, self.dil, H, W, OH, OW, self.cout, out, out32, self.b,
-                     self.act, self.slope, self.prelu, res, res2, res_mode, False, stat, stat_mode, 1.0 / self.WSCALE if sp else 1.0)
+                     self.act, self.slope, self.prelu, res, res2, res_mode, False, stat, stat_mode, 1.0 / self.WSCALE if sp else 1.0, hr=hr)
         return out
 
     def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None, mask=None):
@@ -352,9 +368,10 @@ class Conv:
             tr, ps, pp, dd = True, s, p, 1
         if out is None and out32 is None and stat is None:
             out = self.eng.new(dpre.N, OH, OW, c_seg)
+        hr = (1, self.cout, c_seg, row_off) if (not hp and not self.transposed and s == 1 and k == 3 and stat is None) else None
         self._launch((dpre, dpre) if hp else (dpre,), wt, tr, k, ps, pp, dd, H, W, OH, OW, c_seg, out, out32, None, L.ACT_NONE, 0.0, None,
                      None, None, L.RES_NONE, accumulate, stat, L.STAT_SAMPLE_SUM if stat is not None else L.STAT_NONE,
-                     1.0 / self.WSCALE if hp else 1.0, mask=mask)
+                     1.0 / self.WSCALE if hp else 1.0, mask=mask, hr=hr)
         return out
 
     # -- exact folding of a spatially constant second input segment (SFT conv0: cat(features, kernel code), kbpn.py:513)

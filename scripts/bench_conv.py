@@ -10,7 +10,7 @@ def run(name, N, H, W, cin, cout, k, s, p, d=1, tr=False, iters=10, what=("fwd",
     eng = Engine()
     wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
     params = {"l.weight": (torch.randn(wshape, device="cuda") / (cin * k * k) ** 0.5), "l.bias": torch.zeros(cout, device="cuda")}
-    conv = Conv(eng, "l", params, k, s, p, d, transposed=tr, bias=True, act=L.ACT_LRELU, slope=0.1)
+    conv = Conv(eng, "l", params, k, s, p, d, transposed=tr, bias=os.environ.get("BENCH_NOBIAS") is None, act=L.ACT_LRELU, slope=0.1)
     x = FM(torch.randn(N, H, W, pad8(cin), device="cuda", dtype=torch.float16), cin)
     OH, OW = conv.out_size(H, W)
     y = eng.new(N, OH, OW, cout)
@@ -46,6 +46,8 @@ if __name__ == "__main__":
         "hr32": (1, 1792, 1792, 32, 32, 3, 1, 1),
         "gemm1x1": (1, 1792, 1792, 128, 128, 1, 1, 0),
         "hr49": (1, 1792, 1792, 49, 49, 3, 1, 1),
+        "hr32_49": (1, 1792, 1792, 32, 49, 3, 1, 1),
+        "hr49_32": (1, 1792, 1792, 49, 32, 3, 1, 1),
         "thin3_128": (1, 1792, 1792, 3, 128, 3, 1, 1),
         "thin3_512": (1, 1792, 1792, 3, 512, 3, 1, 1),
         "conv8s4_small": (1, 448, 448, 128, 128, 8, 4, 2),

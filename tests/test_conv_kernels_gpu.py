@@ -178,3 +178,46 @@ def test_dgrad_with_fused_activation_mask(cin, cout, H, W, acc):
     conv.bwd_input(to_fm(eng, dpre), out=out, accumulate=acc, mask=(to_fm(eng, below), slope))
     torch.cuda.synchronize()
     assert relmax(from_fm(out), ref) < 2e-3
+
+
+@pytest.mark.parametrize("cin,cout,act", [(32, 32, "lrelu"), (32, 49, "none"), (49, 49, "lrelu"), (49, 32, "relu"), (3, 49, "relu")])
+def test_hr_direct_conv_kernel(cin, cout, act):
+    """The direct 3x3 kernel of the full-resolution 32 / 49-channel layers (csrc/conv_hr.hip: halo tile in LDS, weights in registers),
+    forward (+ per-sample channel sums without a stored output for the 32 -> 49 case, as fe_cat.2 runs) and dgrad with the fused
+    activation mask, against torch on the same fp16-rounded operands; ragged tiles on both axes; (3, 49) is NOT eligible and must
+    still come out right through the other kernels."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    torch.manual_seed(cin * 100 + cout)
+    eng = _eng()
+    N, H, W = 2, 363, 371
+    x = torch.randn(N, cin, H, W).half().float()
+    w = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).half().float()
+    params = {"l.weight": w.cuda()}
+    a = {"lrelu": L.ACT_LRELU, "relu": L.ACT_RELU, "none": L.ACT_NONE}[act]
+    conv = Conv(eng, "l", params, 3, 1, 1, 1, bias=False, act=a, slope=0.01)
+    ref_pre = F.conv2d(x, w, None, 1, 1)
+    ref = {"lrelu": F.leaky_relu(ref_pre, 0.01), "relu": F.relu(ref_pre), "none": ref_pre}[act]
+    xf = to_fm(eng, x)
+    y = conv.fwd(xf)
+    torch.cuda.synchronize()
+    used_hr = L.load().csbsr_debug_last_conv_kernel() == 8
+    assert used_hr == (cin in (32, 49))
+    assert relmax(from_fm(y), ref) < 2e-3
+    if act == "none":       # global-average-pool sums, output not stored (fe_cat.2)
+        from csbsr_amd.engine import pad8
+        stat = torch.zeros(N, pad8(cout), device="cuda")
+        conv.fwd(xf, stat=stat, stat_mode=L.STAT_SAMPLE_SUM, store=False)
+        torch.cuda.synchronize()
+        assert L.load().csbsr_debug_last_conv_kernel() == 8
+        assert relmax(stat[:, :cout].cpu(), ref.sum((2, 3))) < 2e-3
+    # dgrad with the activation mask of the layer below
+    dpre = torch.randn(N, cout, H, W).half().float()
+    below = torch.randn(N, cin, H, W).half().float()
+    xr = torch.zeros(N, cin, H, W, requires_grad=True)
+    F.conv2d(xr, w, None, 1, 1).backward(dpre)
+    refd = xr.grad * torch.where(below > 0, torch.ones(()), torch.full((), 0.01))
+    dx = conv.bwd_input(to_fm(eng, dpre), mask=(to_fm(eng, below), 0.01))
+    torch.cuda.synchronize()
+    assert (L.load().csbsr_debug_last_conv_kernel() == 8) == (cout in (32, 49) and cin > 3)
+    assert relmax(from_fm(dx), refd) < 2e-3
