@@ -10,9 +10,10 @@
 //    ds_read_b128 of the pixel operand per MFMA and nothing else;
 //  * K is flattened over (tap, 8-channel chunk): an MFMA K step = two chunks, one per half-wave, each half-wave addressing its own
 //    (tap, chunk) -- 56-channel maps need no padding to 64 (63 chunks -> 32 steps);
-//  * bank conflicts: a 64-byte pixel pitch (32 channels) puts pixels p and p + 4 on the same 16-byte slots: the chunk a lane FETCHES
-//    is chunk' ^ ((pixel >> 2) & 3) and reads apply the same XOR (cdna guide rule 21); the 112-byte pitch of 56 channels is odd in
-//    16-byte slots and conflict-free as it is;
+//  * bank conflicts: a 64-byte pixel pitch (32 channels) would put pixels p and p + 4 on the same 16-byte slots, so a 32-channel
+//    pixel is laid out on FIVE slots (80 bytes, the fifth fetched from the zero page): an odd pitch in 16-byte slots is conflict-free
+//    for the 16 consecutive-pixel lanes of a ds_read_b128 group, as the 112-byte pitch of 56 channels already is -- and with no XOR
+//    swizzle every fragment address is one per-lane base register plus a compile-time offset (no address arithmetic in the K loop);
 //  * epilogue in registers: v_permlane32_swap turns the MFMA layout into 8 consecutive couts per lane, activation, optional fused
 //    activation-derivative mask (dgrads), optional global-average-pool sums (fe_cat.2), 16-byte stores.
 //
@@ -37,12 +38,13 @@ struct ConvHrK {
   unsigned tiles_x, tiles_y;
 };
 
-template <int CH8>
-__global__ __launch_bounds__(256) void conv_hr_kernel(const ConvHrK p, const half_t* __restrict__ zero_page) {
+template <int CH8, bool STAT>
+__global__ __launch_bounds__(256, (CH8 == 4 ? (STAT ? 3 : 4) : 2)) void conv_hr_kernel(const ConvHrK p, const half_t* __restrict__ zero_page) {
   constexpr int NCHUNK = 9 * CH8;                       // K in 8-channel chunks
   constexpr int NKS = (NCHUNK + 1) / 2;                 // MFMA K steps (16 channels = two chunks)
-  constexpr int PIXB = CH8 * 16;                        // bytes per pixel in LDS
-  constexpr int NG = HR_NPIX * CH8;                     // 16-byte chunks of the halo tile
+  constexpr int SLOTS = (CH8 % 2) ? CH8 : CH8 + 1;      // 16-byte slots per pixel in LDS: odd, so consecutive pixels walk all banks
+  constexpr int PIXB = SLOTS * 16;                      // bytes per pixel in LDS
+  constexpr int NG = HR_NPIX * SLOTS;                   // 16-byte chunks of the halo tile (incl. the pad slots)
   constexpr int NINST = (NG + 63) / 64;                 // wave instructions to fill it
   constexpr int TILE_BYTES = NINST * 1024;              // (rounded up: overhang lanes fetch the zero page)
   constexpr int ZERO_OFF = TILE_BYTES;                  // one zero chunk for the padded half K step
@@ -64,11 +66,10 @@ __global__ __launch_bounds__(256) void conv_hr_kernel(const ConvHrK p, const hal
     const int inst = wid + 4 * i;
     if (inst < NINST) {
       const int g = inst * 64 + lane;
-      const int q = g / CH8, cpos = g - q * CH8;
+      const int q = g / SLOTS, c = g - q * SLOTS;
       const int ty = q / HR_HW, tx = q - ty * HR_HW;
       const int iy = y0 - 1 + ty, ix = x0 - 1 + tx;
-      const int c = CH8 == 4 ? (cpos ^ ((q >> 2) & 3)) : cpos;
-      const bool ok = g < NG && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const bool ok = g < NG && c < CH8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       const half_t* src = ok ? p.in + n * p.i_sn + iy * p.i_sy + ix * p.i_sx + c * 8 : zp;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(smem + inst * 1024), 16, 0, 0);
@@ -90,10 +91,11 @@ __global__ __launch_bounds__(256) void conv_hr_kernel(const ConvHrK p, const hal
       __syncthreads();
       first = false;
     }
-    float gsum[16];
+    float gsum[STAT ? 16 : 1];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) gsum[e] = 0.f;
-#pragma unroll
+    for (int e = 0; e < (STAT ? 16 : 1); ++e) gsum[e] = 0.f;
+    const char* lbase = smem + pix * PIXB;             // per-lane base: every fragment address below is lbase + a compile-time constant
+#pragma unroll 1      // (both rows unrolled: the scheduler hoists all 2 x NKS fragment reads and spills the weights)
     for (int rr = 0; rr < 2; ++rr) {
       const int row = 2 * wid + rr;                      // output row of the tile
       f16v acc;
@@ -104,18 +106,12 @@ __global__ __launch_bounds__(256) void conv_hr_kernel(const ConvHrK p, const hal
         // chunk kc = 2 ks + hi of the flattened (tap, chunk) axis: compile-time for each half-wave
         const int kc0 = 2 * ks, kc1 = 2 * ks + 1;
         const int t0 = kc0 / CH8, c0 = kc0 % CH8, t1 = kc1 / CH8, c1 = kc1 % CH8;
-        const int q0 = (row + t0 / 3) * HR_HW + (t0 % 3) + pix;
-        const int q1 = (row + t1 / 3) * HR_HW + (t1 % 3) + pix;
-        int a0, a1;
-        if constexpr (CH8 == 4) {
-          a0 = q0 * PIXB + ((c0 ^ ((q0 >> 2) & 3)) << 4);
-          a1 = q1 * PIXB + ((c1 ^ ((q1 >> 2) & 3)) << 4);
-        } else {
-          a0 = q0 * PIXB + (c0 << 4);
-          a1 = q1 * PIXB + (c1 << 4);
-        }
-        if (kc1 >= NCHUNK) a1 = ZERO_OFF;                  // odd chunk count: the last step's upper half reads zeros
-        const h8 bf = *reinterpret_cast<const h8*>(smem + (hi ? a1 : a0));
+        const int a0 = ((t0 / 3) * HR_HW + (t0 % 3)) * PIXB + (c0 << 4);
+        const int a1 = ((t1 / 3) * HR_HW + (t1 % 3)) * PIXB + (c1 << 4);
+        const char* rbase = lbase + row * HR_HW * PIXB;
+        // odd chunk count: the last step's upper half reads the zero chunk
+        const char* addr = (kc1 >= NCHUNK) ? (hi ? smem + ZERO_OFF : rbase + a0) : rbase + (hi ? a1 : a0);
+        const h8 bf = *reinterpret_cast<const h8*>(addr);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], bf, acc, 0, 0, 0);
       }
       // ---- epilogue: acc[4q + j] = cout 8q + 4 hi + j of pixel `pix`; swap pairs -> 8 consecutive couts per lane
@@ -140,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_hr_kernel(const ConvHrK p, const hal
           else if (p.act == CSBSR_ACT_LRELU) t = fmaxf(t, t * slope);
           v[e] = (co + e < p.cout) ? t : 0.f;
         }
-        if (p.stat) {
+        if constexpr (STAT) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) gsum[8 * pair + e] += v[e];
         }
@@ -157,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_hr_kernel(const ConvHrK p, const hal
         }
       }
     }
-    if (p.stat) {          // lanes with equal (hi, pair) hold the same couts for different pixels: fold the 32 pixels, then LDS bins
+    if constexpr (STAT) {  // lanes with equal (hi, pair) hold the same couts for different pixels: fold the 32 pixels, then LDS bins
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         float a = gsum[e];
@@ -173,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_hr_kernel(const ConvHrK p, const hal
       }
     }
   }
-  if (p.stat) {
+  if constexpr (STAT) {
     __syncthreads();
     if (tid < 64 && tid < p.coutp) atomicAdd(p.stat + (size_t)n * p.coutp + tid, sStat[tid]);
   }
@@ -253,10 +249,12 @@ static half_t* g_hr_zero_page[CSBSR_MAX_DEVICES] = {};
 
 template <int CH8>
 static int launch_hr(const ConvHrK& k, hipStream_t st, const half_t* zp) {
-  constexpr int NG = HR_NPIX * CH8, NINST = (NG + 63) / 64;
+  constexpr int SLOTS = (CH8 % 2) ? CH8 : CH8 + 1;
+  constexpr int NG = HR_NPIX * SLOTS, NINST = (NG + 63) / 64;
   constexpr int SM_BYTES = NINST * 1024 + 16 + 64 * 4;
   dim3 grid(k.tiles_x * k.tiles_y * k.N);
-  hipLaunchKernelGGL((conv_hr_kernel<CH8>), grid, dim3(256), SM_BYTES, st, k, zp);
+  if (k.stat) hipLaunchKernelGGL((conv_hr_kernel<CH8, true>), grid, dim3(256), SM_BYTES, st, k, zp);
+  else hipLaunchKernelGGL((conv_hr_kernel<CH8, false>), grid, dim3(256), SM_BYTES, st, k, zp);
   CSBSR_LAUNCH_CHECK("csbsr_conv_hr_forward");
   return 0;
 }

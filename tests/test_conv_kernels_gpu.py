@@ -219,5 +219,5 @@ def test_hr_direct_conv_kernel(cin, cout, act):
     refd = xr.grad * torch.where(below > 0, torch.ones(()), torch.full((), 0.01))
     dx = conv.bwd_input(to_fm(eng, dpre), mask=(to_fm(eng, below), 0.01))
     torch.cuda.synchronize()
-    assert (L.load().csbsr_debug_last_conv_kernel() == 8) == (cout in (32, 49) and cin > 3)
+    assert L.load().csbsr_debug_last_conv_kernel() == 8          # the dgrad's own input is the 32 / 49-channel dPre: always eligible here
     assert relmax(from_fm(dx), refd) < 2e-3
