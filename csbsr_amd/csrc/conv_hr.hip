@@ -39,7 +39,7 @@ struct ConvHrK {
 };
 
 template <int CH8, bool STAT>
-__global__ __launch_bounds__(256, (CH8 == 4 ? (STAT ? 3 : 4) : 2)) void conv_hr_kernel(const ConvHrK p, const half_t* __restrict__ zero_page) {
+__global__ __launch_bounds__(256, (CH8 == 4 ? 3 : 2)) void conv_hr_kernel(const ConvHrK p, const half_t* __restrict__ zero_page) {
   constexpr int NCHUNK = 9 * CH8;                       // K in 8-channel chunks
   constexpr int NKS = (NCHUNK + 1) / 2;                 // MFMA K steps (16 channels = two chunks)
   constexpr int SLOTS = (CH8 % 2) ? CH8 : CH8 + 1;      // 16-byte slots per pixel in LDS: odd, so consecutive pixels walk all banks
@@ -49,55 +49,60 @@ __global__ __launch_bounds__(256, (CH8 == 4 ? (STAT ? 3 : 4) : 2)) void conv_hr_
   constexpr int TILE_BYTES = NINST * 1024;              // (rounded up: overhang lanes fetch the zero page)
   constexpr int ZERO_OFF = TILE_BYTES;                  // one zero chunk for the padded half K step
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sStat = reinterpret_cast<float*>(smem + ZERO_OFF + 16);      // [64] per-cout sums of this workgroup
+  float* sStat = reinterpret_cast<float*>(smem + ZERO_OFF + 16);      // [32] per-cout sums of the current tile
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned per_img = p.tiles_x * p.tiles_y;
-  const unsigned lt = xcd_remap(blockIdx.x, per_img * (unsigned)p.N);
-  const int n = lt / per_img;
-  const unsigned r_ = lt - n * per_img;
-  const int y0 = (r_ / p.tiles_x) * HR_TH, x0 = (r_ % p.tiles_x) * HR_TW;
-
-  // ---- halo tile -> LDS
-  const half_t* zp = zero_page + (lane & 7) * 8;
-#pragma unroll
-  for (int i = 0; i < (NINST + 3) / 4; ++i) {
-    const int inst = wid + 4 * i;
-    if (inst < NINST) {
-      const int g = inst * 64 + lane;
-      const int q = g / SLOTS, c = g - q * SLOTS;
-      const int ty = q / HR_HW, tx = q - ty * HR_HW;
-      const int iy = y0 - 1 + ty, ix = x0 - 1 + tx;
-      const bool ok = g < NG && c < CH8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const half_t* src = ok ? p.in + n * p.i_sn + iy * p.i_sy + ix * p.i_sx + c * 8 : zp;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(smem + inst * 1024), 16, 0, 0);
-    }
-  }
-  if (tid < 4) reinterpret_cast<float*>(smem + ZERO_OFF)[tid] = 0.f;
-  if (tid < 64) sStat[tid] = 0.f;
-  const float slope = p.slope;
-
   const int pix = lane & 31, hi = lane >> 5;
-  bool first = true;
-  for (int ct = 0; ct < p.ntile_c; ++ct) {
-    // ---- this cout tile's weights: NKS fragments per lane, straight from the fragment-ordered pack (L2-resident, 1 KiB per step)
-    h8 wf[NKS];
+  const float slope = p.slope;
+  const half_t* zp = zero_page + (lane & 7) * 8;
+  // ---- persistent workgroup: ONE 32-cout tile's weights stay in registers (NKS fragments per lane, straight from the
+  // fragment-ordered pack) while the workgroup walks its share of the pixel tiles -- reloading them per tile cost as many bytes
+  // through the CU's load path as the tile itself.  Workgroups whose blockIdx / 8 agree modulo ntile_c share a cout tile; a
+  // workgroup's virtual block ids vb = j0, j0 + G', ... keep vb % 8 == blockIdx % 8, so xcd_remap still hands every XCD one
+  // contiguous run of the (row-major) tile order and neighbouring tiles' halos meet in its L2.
+  const int ct = (blockIdx.x >> 3) % p.ntile_c;
+  const unsigned gsub = gridDim.x / p.ntile_c;                          // workgroups per cout tile (launcher: a multiple of 8)
+  const unsigned j0 = ((blockIdx.x >> 3) / p.ntile_c) * 8 + (blockIdx.x & 7);
+  h8 wf[NKS];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) wf[ks] = *reinterpret_cast<const h8*>(p.wt + ((size_t)(ct * NKS + ks) * 64 + lane) * 8);
-    if (first) {          // the tile DMAs land while the first weight loads are in flight
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      first = false;
+  for (int ks = 0; ks < NKS; ++ks) wf[ks] = *reinterpret_cast<const h8*>(p.wt + ((size_t)(ct * NKS + ks) * 64 + lane) * 8);
+  if (tid < 4) reinterpret_cast<float*>(smem + ZERO_OFF)[tid] = 0.f;
+  const unsigned per_img = p.tiles_x * p.tiles_y, total = per_img * (unsigned)p.N;
+  const char* lbase = smem + pix * PIXB;               // per-lane base: every fragment address below is lbase + a compile-time constant
+
+  for (unsigned vb = j0; vb < total; vb += gsub) {
+    const unsigned lt = xcd_remap(vb, total);
+    const int n = lt / per_img;
+    const unsigned r_ = lt - n * per_img;
+    const int y0 = (r_ / p.tiles_x) * HR_TH, x0 = (r_ % p.tiles_x) * HR_TW;
+    if (vb != j0) __syncthreads();                     // every wave is done reading the previous tile (and its sums are flushed)
+    // ---- halo tile -> LDS
+#pragma unroll
+    for (int i = 0; i < (NINST + 3) / 4; ++i) {
+      const int inst = wid + 4 * i;
+      if (inst < NINST) {
+        const int g = inst * 64 + lane;
+        const int q = g / SLOTS, c = g - q * SLOTS;
+        const int ty = q / HR_HW, tx = q - ty * HR_HW;
+        const int iy = y0 - 1 + ty, ix = x0 - 1 + tx;
+        const bool ok = g < NG && c < CH8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const half_t* src = ok ? p.in + n * p.i_sn + iy * p.i_sy + ix * p.i_sx + c * 8 : zp;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + inst * 1024), 16, 0, 0);
+      }
     }
+    if (STAT && tid < 32) sStat[tid] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
     float gsum[STAT ? 16 : 1];
 #pragma unroll
     for (int e = 0; e < (STAT ? 16 : 1); ++e) gsum[e] = 0.f;
-    const char* lbase = smem + pix * PIXB;             // per-lane base: every fragment address below is lbase + a compile-time constant
 #pragma unroll 1      // (both rows unrolled: the scheduler hoists all 2 x NKS fragment reads and spills the weights)
     for (int rr = 0; rr < 2; ++rr) {
       const int row = 2 * wid + rr;                      // output row of the tile
+      const char* rbase = lbase + row * HR_HW * PIXB;
       f16v acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -108,7 +113,6 @@ __global__ __launch_bounds__(256, (CH8 == 4 ? (STAT ? 3 : 4) : 2)) void conv_hr_
         const int t0 = kc0 / CH8, c0 = kc0 % CH8, t1 = kc1 / CH8, c1 = kc1 % CH8;
         const int a0 = ((t0 / 3) * HR_HW + (t0 % 3)) * PIXB + (c0 << 4);
         const int a1 = ((t1 / 3) * HR_HW + (t1 % 3)) * PIXB + (c1 << 4);
-        const char* rbase = lbase + row * HR_HW * PIXB;
         // odd chunk count: the last step's upper half reads the zero chunk
         const char* addr = (kc1 >= NCHUNK) ? (hi ? smem + ZERO_OFF : rbase + a0) : rbase + (hi ? a1 : a0);
         const h8 bf = *reinterpret_cast<const h8*>(addr);
@@ -165,14 +169,12 @@ __global__ __launch_bounds__(256, (CH8 == 4 ? (STAT ? 3 : 4) : 2)) void conv_hr_
 #pragma unroll
         for (int pair = 0; pair < 2; ++pair)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) atomicAdd(&sStat[ct * 32 + 16 * pair + 8 * hi + e], gsum[8 * pair + e]);
+          for (int e = 0; e < 8; ++e) atomicAdd(&sStat[16 * pair + 8 * hi + e], gsum[8 * pair + e]);
       }
+      __syncthreads();
+      if (tid < 32 && ct * 32 + tid < p.coutp) atomicAdd(p.stat + (size_t)n * p.coutp + ct * 32 + tid, sStat[tid]);
     }
-  }
-  if constexpr (STAT) {
-    __syncthreads();
-    if (tid < 64 && tid < p.coutp) atomicAdd(p.stat + (size_t)n * p.coutp + tid, sStat[tid]);
-  }
+  }      // tiles
 }
 
 // ---- weights in fragment order:  dst[ct][ks][lane][e] = W(cout = 32 ct + lane%32, chunk kc = 2 ks + lane/32, channel 8 (kc % CH8) + e)
@@ -252,7 +254,13 @@ static int launch_hr(const ConvHrK& k, hipStream_t st, const half_t* zp) {
   constexpr int SLOTS = (CH8 % 2) ? CH8 : CH8 + 1;
   constexpr int NG = HR_NPIX * SLOTS, NINST = (NG + 63) / 64;
   constexpr int SM_BYTES = NINST * 1024 + 16 + 64 * 4;
-  dim3 grid(k.tiles_x * k.tiles_y * k.N);
+  // persistent: (workgroups per CU the registers admit) x 256 CUs, a multiple of 8 x ntile_c; never more than there is work
+  const unsigned total = k.tiles_x * k.tiles_y * k.N;
+  const unsigned unit = 8u * k.ntile_c;
+  unsigned g = 256u * (CH8 == 4 ? 3u : 2u);
+  if (g > total * k.ntile_c) g = total * k.ntile_c;
+  g = (g + unit - 1) / unit * unit;
+  dim3 grid(g);
   if (k.stat) hipLaunchKernelGGL((conv_hr_kernel<CH8, true>), grid, dim3(256), SM_BYTES, st, k, zp);
   else hipLaunchKernelGGL((conv_hr_kernel<CH8, false>), grid, dim3(256), SM_BYTES, st, k, zp);
   CSBSR_LAUNCH_CHECK("csbsr_conv_hr_forward");
