@@ -39,7 +39,7 @@ struct ConvHrK {
 };
 
 template <int CH8, bool STAT>
-__global__ __launch_bounds__(256, 2) void conv_hr_kernel(const ConvHrK p, const half_t* __restrict__ zero_page) {
+__global__ __launch_bounds__(256, (CH8 == 4 ? 3 : 2)) void conv_hr_kernel(const ConvHrK p, const half_t* __restrict__ zero_page) {
   constexpr int NCHUNK = 9 * CH8;                       // K in 8-channel chunks
   constexpr int NKS = (NCHUNK + 1) / 2;                 // MFMA K steps (16 channels = two chunks)
   constexpr int SLOTS = (CH8 % 2) ? CH8 : CH8 + 1;      // 16-byte slots per pixel in LDS: odd, so consecutive pixels walk all banks
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void conv_hr_kernel(const ConvHrK p, const 
   constexpr int NG = HR_NPIX * SLOTS;                   // 16-byte chunks of the halo tile (incl. the pad slots)
   constexpr int NINST = (NG + 63) / 64;                 // wave instructions to fill it
   constexpr int TILE_BYTES = NINST * 1024;              // (rounded up: overhang lanes fetch the zero page)
-  constexpr int ZERO_OFF = 2 * TILE_BYTES;              // (two tile buffers, then) one zero chunk for the padded half K step
+  constexpr int ZERO_OFF = TILE_BYTES;                  // one zero chunk for the padded half K step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sStat = reinterpret_cast<float*>(smem + ZERO_OFF + 16);      // [32] per-cout sums of the current tile
 
@@ -71,12 +71,13 @@ __global__ __launch_bounds__(256, 2) void conv_hr_kernel(const ConvHrK p, const 
   const unsigned per_img = p.tiles_x * p.tiles_y, total = per_img * (unsigned)p.N;
   const char* lbase = smem + pix * PIXB;               // per-lane base: every fragment address below is lbase + a compile-time constant
 
-  // ---- halo tile of virtual block vb -> LDS buffer `buf` (DMA; zero page for out-of-image pixels, pad slots and overhang lanes)
-  auto fill = [&](unsigned vb, int buf) {
+  for (unsigned vb = j0; vb < total; vb += gsub) {
     const unsigned lt = xcd_remap(vb, total);
     const int n = lt / per_img;
     const unsigned r_ = lt - n * per_img;
     const int y0 = (r_ / p.tiles_x) * HR_TH, x0 = (r_ % p.tiles_x) * HR_TW;
+    if (vb != j0) __syncthreads();                     // every wave is done reading the previous tile (and its sums are flushed)
+    // ---- halo tile -> LDS
 #pragma unroll
     for (int i = 0; i < (NINST + 3) / 4; ++i) {
       const int inst = wid + 4 * i;
@@ -88,23 +89,12 @@ __global__ __launch_bounds__(256, 2) void conv_hr_kernel(const ConvHrK p, const 
         const bool ok = g < NG && c < CH8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const half_t* src = ok ? p.in + n * p.i_sn + iy * p.i_sy + ix * p.i_sx + c * 8 : zp;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(smem + buf * TILE_BYTES + inst * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(smem + inst * 1024), 16, 0, 0);
       }
     }
-  };
-  if (j0 < total) fill(j0, 0);
-  int cur = 0;
-  for (unsigned vb = j0; vb < total; vb += gsub, cur ^= 1) {
-    const unsigned lt = xcd_remap(vb, total);
-    const int n = lt / per_img;
-    const unsigned r_ = lt - n * per_img;
-    const int y0 = (r_ / p.tiles_x) * HR_TH, x0 = (r_ % p.tiles_x) * HR_TW;
     if (STAT && tid < 32) sStat[tid] = 0.f;
-    // tile vb has landed (this wave's DMAs, then everyone's); every wave is also past its reads of the OTHER buffer (tile vb - gsub),
-    // so the next tile's DMA can start into it now and fly under this tile's MFMAs and stores
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (vb + gsub < total) fill(vb + gsub, cur ^ 1);
 
     float gsum[STAT ? 16 : 1];
 #pragma unroll
@@ -112,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv_hr_kernel(const ConvHrK p, const 
 #pragma unroll 1      // (both rows unrolled: the scheduler hoists all 2 x NKS fragment reads and spills the weights)
     for (int rr = 0; rr < 2; ++rr) {
       const int row = 2 * wid + rr;                      // output row of the tile
-      const char* rbase = lbase + cur * TILE_BYTES + row * HR_HW * PIXB;
+      const char* rbase = lbase + row * HR_HW * PIXB;
       f16v acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -263,17 +253,11 @@ template <int CH8>
 static int launch_hr(const ConvHrK& k, hipStream_t st, const half_t* zp) {
   constexpr int SLOTS = (CH8 % 2) ? CH8 : CH8 + 1;
   constexpr int NG = HR_NPIX * SLOTS, NINST = (NG + 63) / 64;
-  constexpr int SM_BYTES = 2 * NINST * 1024 + 16 + 64 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
-    attr_set = true;
-  }
-  // persistent: two double-buffered workgroups per CU x 256 CUs, a multiple of 8 x ntile_c; never more than there is work
+  constexpr int SM_BYTES = NINST * 1024 + 16 + 64 * 4;
+  // persistent: (workgroups per CU the registers admit) x 256 CUs, a multiple of 8 x ntile_c; never more than there is work
   const unsigned total = k.tiles_x * k.tiles_y * k.N;
   const unsigned unit = 8u * k.ntile_c;
-  unsigned g = 256u * 2u;
+  unsigned g = 256u * (CH8 == 4 ? 3u : 2u);
   if (g > total * k.ntile_c) g = total * k.ntile_c;
   g = (g + unit - 1) / unit * unit;
   dim3 grid(g);
