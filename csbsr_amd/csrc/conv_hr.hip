@@ -3,8 +3,8 @@
 // implicit-GEMM kernels ran ~4x off their byte roofline (each of the 9 taps re-gathers the pixel operand through the L1/LDS path and
 // every fragment pair is read from LDS: a 32-cout K slice is 4 MFMAs per wave against ~60 address instructions).
 //
-//  * one workgroup (4 waves) = one 8 x 32 output tile; its (8+2) x (32+2) input halo tile goes HBM -> LDS ONCE with
-//    global_load_lds_dwordx4 (16-byte channel chunks, zero page for out-of-image pixels) -- 1.33x the tile's own bytes instead of 9x;
+//  * one workgroup (4 waves) = 16 x 32 output tiles; a tile's (16+2) x (32+2) input halo goes HBM -> LDS ONCE with
+//    global_load_lds_dwordx4 (16-byte channel chunks, zero page for out-of-image pixels) -- 1.2x the tile's own bytes instead of 9x;
 //  * the WEIGHTS never touch LDS: they are packed in MFMA-fragment order (csbsr_pack_weights_hr) and each lane keeps its A fragments
 //    of all K steps of one 32-cout tile in registers (18 steps x 4 VGPRs for 32 channels, 32 x 4 for 49 -> 56), so the K loop is one
 //    ds_read_b128 of the pixel operand per MFMA and nothing else;
@@ -20,8 +20,9 @@
 // Replaces F.conv2d at kbpn.py:536-547 (via ConvBlock) and its autograd dgrad for the eligible layers.
 #include "common.h"
 #include "conv_common.h"
+#include <cstdlib>
 
-#define HR_TH 8
+#define HR_TH 16
 #define HR_TW 32
 #define HR_HW (HR_TW + 2)
 #define HR_NPIX ((HR_TH + 2) * HR_HW)          // 340 halo pixels
@@ -36,6 +37,7 @@ struct ConvHrK {
   const half_t* mask; long m_sn, m_sy, m_sx; float mask_slope;
   float* stat;                      // optional [N][coutp] per-sample channel sums of act(conv) (global average pool)
   unsigned tiles_x, tiles_y;
+  int dbg;                          // ablation bits (CSBSR_HR_DBG): 1 no stores, 2 no K loop, 4 no tile DMA
 };
 
 template <int CH8, bool STAT>
@@ -70,6 +72,20 @@ __global__ __launch_bounds__(256, (CH8 == 4 ? 3 : 2)) void conv_hr_kernel(const 
   if (tid < 4) reinterpret_cast<float*>(smem + ZERO_OFF)[tid] = 0.f;
   const unsigned per_img = p.tiles_x * p.tiles_y, total = per_img * (unsigned)p.N;
   const char* lbase = smem + pix * PIXB;               // per-lane base: every fragment address below is lbase + a compile-time constant
+  // DMA roles are the same for every tile: chunk g = (wid + 4 i) * 64 + lane of the halo tile = (halo row ty, halo column tx, slot
+  // c).  The first instruction's role is computed once; consecutive instructions of a lane are 256 chunks apart, i.e. a fixed
+  // (DQ pixels, DC slots) step with carries -- a handful of compares instead of two integer divisions per instruction.
+  constexpr int NFI = (NINST + 3) / 4;
+  constexpr int DQ = 256 / SLOTS, DC = 256 % SLOTS;
+  int f_ty0, f_tx0, f_c0;
+  {
+    const int g = wid * 64 + lane;
+    const int q = g / SLOTS;
+    f_c0 = g - q * SLOTS;
+    f_ty0 = q / HR_HW;
+    f_tx0 = q - f_ty0 * HR_HW;
+  }
+  const int isy = (int)p.i_sy, isx = (int)p.i_sx;        // (within one image: < 2^31 elements, launcher checks)
 
   for (unsigned vb = j0; vb < total; vb += gsub) {
     const unsigned lt = xcd_remap(vb, total);
@@ -78,19 +94,22 @@ __global__ __launch_bounds__(256, (CH8 == 4 ? 3 : 2)) void conv_hr_kernel(const 
     const int y0 = (r_ / p.tiles_x) * HR_TH, x0 = (r_ % p.tiles_x) * HR_TW;
     if (vb != j0) __syncthreads();                     // every wave is done reading the previous tile (and its sums are flushed)
     // ---- halo tile -> LDS
-#pragma unroll
-    for (int i = 0; i < (NINST + 3) / 4; ++i) {
+    const half_t* tbase = p.in + n * p.i_sn + (long)(y0 - 1) * p.i_sy + (long)(x0 - 1) * p.i_sx;      // wave-uniform
+    int ty = f_ty0, tx = f_tx0, c = f_c0;
+#pragma unroll 2      // (fully unrolled the scheduler computes every 64-bit source address up front: 2 x NFI registers)
+    for (int i = 0; i < NFI; ++i) {
       const int inst = wid + 4 * i;
       if (inst < NINST) {
-        const int g = inst * 64 + lane;
-        const int q = g / SLOTS, c = g - q * SLOTS;
-        const int ty = q / HR_HW, tx = q - ty * HR_HW;
         const int iy = y0 - 1 + ty, ix = x0 - 1 + tx;
-        const bool ok = g < NG && c < CH8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const half_t* src = ok ? p.in + n * p.i_sn + iy * p.i_sy + ix * p.i_sx + c * 8 : zp;
+        const bool ok = ty < HR_TH + 2 && c < CH8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && !(p.dbg & 4);
+        const half_t* src = ok ? tbase + (ty * isy + tx * isx + c * 8) : zp;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(smem + inst * 1024), 16, 0, 0);
       }
+      c += DC; tx += DQ;
+      if (c >= SLOTS) { c -= SLOTS; ++tx; }
+      if (tx >= HR_HW) { tx -= HR_HW; ++ty; }
+      if (tx >= HR_HW) { tx -= HR_HW; ++ty; }
     }
     if (STAT && tid < 32) sStat[tid] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -99,13 +118,14 @@ __global__ __launch_bounds__(256, (CH8 == 4 ? 3 : 2)) void conv_hr_kernel(const 
     float gsum[STAT ? 16 : 1];
 #pragma unroll
     for (int e = 0; e < (STAT ? 16 : 1); ++e) gsum[e] = 0.f;
-#pragma unroll 1      // (both rows unrolled: the scheduler hoists all 2 x NKS fragment reads and spills the weights)
-    for (int rr = 0; rr < 2; ++rr) {
-      const int row = 2 * wid + rr;                      // output row of the tile
+#pragma unroll 1      // (rows unrolled: the scheduler hoists every row's NKS fragment reads and spills the weights)
+    for (int rr = 0; rr < HR_TH / 4; ++rr) {
+      const int row = (HR_TH / 4) * wid + rr;            // output row of the tile
       const char* rbase = lbase + row * HR_HW * PIXB;
       f16v acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      if (!(p.dbg & 2))
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
         // chunk kc = 2 ks + hi of the flattened (tap, chunk) axis: compile-time for each half-wave
@@ -149,7 +169,7 @@ __global__ __launch_bounds__(256, (CH8 == 4 ? 3 : 2)) void conv_hr_kernel(const 
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= ((float)mk[e] > 0.f ? 1.f : p.mask_slope);
         }
-        if (p.out16) {
+        if (p.out16 && (!(p.dbg & 1) || v[0] == 12345.678f)) {
           h8 hv;
 #pragma unroll
           for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
@@ -254,6 +274,13 @@ static int launch_hr(const ConvHrK& k, hipStream_t st, const half_t* zp) {
   constexpr int SLOTS = (CH8 % 2) ? CH8 : CH8 + 1;
   constexpr int NG = HR_NPIX * SLOTS, NINST = (NG + 63) / 64;
   constexpr int SM_BYTES = NINST * 1024 + 16 + 64 * 4;
+  static_assert(SM_BYTES <= 80 * 1024, "two workgroups per CU must fit");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
+    attr_set = true;
+  }
   // persistent: (workgroups per CU the registers admit) x 256 CUs, a multiple of 8 x ntile_c; never more than there is work
   const unsigned total = k.tiles_x * k.tiles_y * k.N;
   const unsigned unit = 8u * k.ntile_c;
@@ -280,6 +307,7 @@ extern "C" int csbsr_conv_hr_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   k.mask = reinterpret_cast<const half_t*>(d->mask); k.m_sn = d->m_sn; k.m_sy = d->m_sy; k.m_sx = d->m_sx; k.mask_slope = d->mask_slope;
   k.stat = d->stat_mode == CSBSR_STAT_SAMPLE_SUM ? d->stat : nullptr;
   k.tiles_x = (unsigned)((d->W + HR_TW - 1) / HR_TW); k.tiles_y = (unsigned)((d->H + HR_TH - 1) / HR_TH);
+  { const char* e = getenv("CSBSR_HR_DBG"); k.dbg = e ? atoi(e) : 0; }
   int dev = 0;
   CSBSR_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CSBSR_MAX_DEVICES, "conv_hr: no current device");
   if (!g_hr_zero_page[dev]) {
