@@ -70,6 +70,10 @@ SIGNATURES = {
     "csbsr_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp]),
     "csbsr_conv_hr_eligible": (i32, [C.POINTER(ConvDesc)]),
     "csbsr_conv_hr_forward": (i32, [C.POINTER(ConvDesc), vp]),
+    "csbsr_conv_tp_eligible": (i32, [C.POINTER(ConvDesc)]),
+    "csbsr_conv_tp_forward": (i32, [C.POINTER(ConvDesc), vp]),
+    "csbsr_packed_weight_elems_tp": (i64, [i32, i32]),
+    "csbsr_pack_weights_tp": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "csbsr_packed_weight_elems_hr": (i64, [i32, i32]),
     "csbsr_pack_weights_hr": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "csbsr_packed_weight_elems": (i64, [i32] * 9),
@@ -131,6 +135,7 @@ SIGNATURES = {
 DEBUG_SIGNATURES = {
     "csbsr_debug_set_wgrad_tr": (None, [i32]),
     "csbsr_debug_set_conv_glds": (None, [i32]),
+    "csbsr_debug_set_conv_tp": (None, [i32]),
     "csbsr_debug_last_conv_kernel": (i32, []),
     "csbsr_debug_last_wgrad_kernel": (i32, []),
 }
@@ -158,6 +163,8 @@ def load():
     _lib = lib
     if os.environ.get("CSBSR_WGRAD_DBG"):          # A/B hook: bit0 transpose reads, 2 no thin, 4 no tap order, 8 no flat grid, 16 flat everywhere
         lib.csbsr_debug_set_wgrad_tr(int(os.environ["CSBSR_WGRAD_DBG"]))
+    if os.environ.get("CSBSR_CONV_TP"):            # A/B hook: 0 off, 1 default, 2 every eligible launch
+        lib.csbsr_debug_set_conv_tp(int(os.environ["CSBSR_CONV_TP"]))
     if os.environ.get("CSBSR_CONV_GLDS"):          # A/B hook for kernel selection experiments
         lib.csbsr_debug_set_conv_glds(int(os.environ["CSBSR_CONV_GLDS"]))
     return lib

@@ -20,7 +20,7 @@
 #include "csbsr_debug.h"
 #include "conv_wgrad.h"
 
-int g_wgrad_glds = 1;
+int g_wgrad_glds = 3;      // bit 0 kernel enabled, bit 1 256 x 256 tile, bit 2 no 128 x 256 tile, bit 3 every eligible problem (csbsr_debug_set_wgrad_tr)
 
 template <int BA, int BN, int NWA, int NWB, int NSTAGE>
 __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const WgradK p, const half_t* __restrict__ zero_page) {

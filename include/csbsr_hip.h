@@ -98,6 +98,21 @@ int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
  * pack: kind 0 = forward conv (W OIHW, rows = D0), kind 1 = dgrad of a stride-1 conv (rows = D1, taps flipped). */
 int32_t csbsr_conv_hr_eligible(const csbsr_conv_desc_t* d);
 int csbsr_conv_hr_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
+
+/* Phase-decomposed transposed convolution (ConvTranspose2d with stride < kernel <= 2 stride: the 8x8 stride-4 / 12x12 stride-8
+ * up-projections of /root/reference/model/modeling/kbpn.py:230-262 via DeconvBlock, and the dgrads of the matching strided Conv2d
+ * layers that autograd runs for kbpn.py:230-262): the low-resolution halo tile stays in LDS for all phases and taps, only the
+ * fragment-ordered weights (csbsr_pack_weights_tp) stream through a 4-stage LDS ring, register epilogue -- see csrc/conv_tp.hip.
+ * Same descriptor as csbsr_conv_forward except d->wt, which must come from csbsr_pack_weights_tp; csbsr_conv_tp_eligible says
+ * whether a launch qualifies (64 / 128 padded input channels in one plain fp16 segment, 128 padded output channels, output exactly
+ * stride x input, bias / ReLU / leaky / PReLU / residual add or subtract / accumulate / activation mask). */
+int32_t csbsr_conv_tp_eligible(const csbsr_conv_desc_t* d);
+int csbsr_conv_tp_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
+/* w indexed [contracted channel][row][kh][kw] (IOHW of ConvTranspose2d, or OIHW of a Conv2d seen from its dgrad); packs rows
+ * [row_off, row_off + rows_real) against contracted channels [k_off, k_off + c_real). */
+int64_t csbsr_packed_weight_elems_tp(int32_t stride, int32_t c_real);
+int csbsr_pack_weights_tp(const float* w, void* dst, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                          int32_t c_real, int32_t rows_real, int32_t row_off, int32_t k_off, csbsr_stream_t s);
 int64_t csbsr_packed_weight_elems_hr(int32_t c_real, int32_t rows_real);
 int csbsr_pack_weights_hr(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
                           int32_t row_off, int32_t k_off, csbsr_stream_t s);

@@ -27,13 +27,13 @@ torch.cuda.synchronize()
 import time
 t0 = time.time(); step(); torch.cuda.synchronize(); dt = time.time() - t0
 agg = collections.OrderedDict()
-for kind, fl, by, e0, e1, name, shp, *_ in rt["eng"].timing:
-    key = (kind, shp)
+for kind, fl, by, e0, e1, name, shp, *rest in rt["eng"].timing:
+    key = (kind + str(rest[0] if rest else ''), shp)
     a = agg.setdefault(key, [0, 0.0, 0.0, 0.0, name])
     a[0] += 1; a[1] += fl; a[2] += by; a[3] += e0.elapsed_time(e1)
 rows = sorted(agg.items(), key=lambda kv: -kv[1][3])
 tot = sum(v[3] for v in agg.values())
 print(f"step {dt*1e3:.0f} ms; conv+wgrad {tot:.0f} ms")
 print("kind   (N,H,W,Cin,Cout,k,s,T)                       n    ms     %    TF/s   GB/s  example")
-for (kind, shp), (n, fl, by, ms, name) in rows[:45]:
-    print(f"{kind:5s} {str(shp):44s} {n:3d} {ms:7.1f} {100*ms/tot:5.1f} {fl/ms/1e9:7.1f} {by/ms/1e6:6.0f}  {name[-50:]}")
+for (kind, shp), (n, fl, by, ms, name) in rows[:70]:
+    print(f"{kind:6s} {str(shp):44s} {n:3d} {ms:7.1f} {100*ms/tot:5.1f} {fl/ms/1e9:7.1f} {by/ms/1e6:6.0f}  {name[-50:]}")

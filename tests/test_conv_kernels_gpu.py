@@ -221,3 +221,86 @@ def test_hr_direct_conv_kernel(cin, cout, act):
     torch.cuda.synchronize()
     assert L.load().csbsr_debug_last_conv_kernel() == 8          # the dgrad's own input is the 32 / 49-channel dPre: always eligible here
     assert relmax(from_fm(dx), refd) < 2e-3
+
+
+@pytest.mark.parametrize("k,s,p,cin,cout,H,W,mode", [
+    (8, 4, 2, 128, 128, 24, 40, "prelu_add"),      # up_conv3: PReLU + residual add, ragged tiles on both axes
+    (8, 4, 2, 128, 128, 16, 64, "prelu"),          # up_conv1
+    (8, 4, 2, 128, 128, 17, 33, "prelu_sub"),      # down_conv2: PReLU - residual
+    (12, 8, 2, 128, 128, 9, 34, "prelu_add"),      # x8 variant: 64 phases, phases with a single valid tap per axis
+    (8, 4, 2, 64, 128, 16, 32, "relu"),            # one 64-channel K chunk per tap
+    (8, 4, 2, 128, 100, 10, 20, "none"),           # padded output channels
+])
+def test_phase_decomposed_transposed_conv(k, s, p, cin, cout, H, W, mode):
+    """csrc/conv_tp.hip (halo tile resident in LDS for all phases and taps, streamed fragment-ordered weights, register epilogue)
+    against conv_transpose2d on the same fp16-rounded operands, and the same launches through the general LDS-DMA kernel."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    torch.manual_seed(k * 1000 + cin + cout + H)
+    eng = _eng()
+    N = 2
+    lib = L.load()
+    x = torch.randn(N, cin, H, W).half().float()
+    w = (torch.randn(cin, cout, k, k) / (cin * 4) ** 0.5).half().float()
+    b = torch.randn(cout) * 0.1
+    a = torch.tensor([0.25])
+    params = {"l.weight": w.cuda(), "l.bias": b.cuda(), "a": a.cuda()}
+    act = {"prelu": L.ACT_PRELU, "relu": L.ACT_RELU, "none": L.ACT_NONE}[mode.split("_")[0]]
+    conv = Conv(eng, "l", params, k, s, p, 1, transposed=True, bias=True, act=act, prelu="a" if act == L.ACT_PRELU else False)
+    pre = F.conv_transpose2d(x, w, b, s, p)
+    ref = {L.ACT_PRELU: F.prelu(pre, a), L.ACT_RELU: F.relu(pre), L.ACT_NONE: pre}[act]
+    res = torch.randn_like(ref).half().float()
+    rm = L.RES_ADD if mode.endswith("_add") else (L.RES_SUB if mode.endswith("_sub") else L.RES_NONE)
+    if rm == L.RES_ADD: ref = ref + res
+    if rm == L.RES_SUB: ref = ref - res
+    outs = []
+    for tp_mode in (2, 0):
+        lib.csbsr_debug_set_conv_tp(tp_mode)
+        try:
+            y = conv.fwd(to_fm(eng, x), res=to_fm(eng, res) if rm != L.RES_NONE else None, res_mode=rm)
+            torch.cuda.synchronize()
+            assert (lib.csbsr_debug_last_conv_kernel() == 9) == (tp_mode == 2)
+        finally:
+            lib.csbsr_debug_set_conv_tp(1)
+        outs.append(from_fm(y))
+        assert relmax(outs[-1], ref) < 2e-3
+    assert relmax(outs[0], outs[1]) < 1e-3
+
+
+@pytest.mark.parametrize("cin,cout,H,W,acc,masked", [(128, 128, 16, 32, True, True), (128, 128, 9, 40, False, True), (128, 128, 24, 33, True, False),
+                                                     (128, 96, 8, 32, False, False), (128, 64, 12, 36, True, True), (100, 128, 8, 32, False, True)])
+def test_phase_decomposed_strided_dgrad(cin, cout, H, W, acc, masked):
+    """dgrad of the 8x8 stride-4 convolutions (a transposed conv over dOut) through csrc/conv_tp.hip, accumulating into the gradient
+    buffer and applying the fused activation-derivative mask of the layer below, as up_conv2 / down_conv1 / down_conv3 run it."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    torch.manual_seed(cin + cout + H * W)
+    eng = _eng()
+    lib = L.load()
+    N, slope, k, s, p = 2, 0.2, 8, 4, 2
+    w = (torch.randn(cout, cin, k, k) / (cin * 4) ** 0.5).half().float()
+    conv = Conv(eng, "l", {"l.weight": w.cuda()}, k, s, p, 1, bias=False, act=L.ACT_NONE)
+    dpre = torch.randn(N, cout, H, W).half().float()
+    IH, IW = s * H, s * W
+    below = torch.randn(N, cin, IH, IW).half().float()
+    old = torch.randn(N, cin, IH, IW).half().float()
+    xr = torch.zeros(N, cin, IH, IW, requires_grad=True)
+    F.conv2d(xr, w, None, s, p).backward(dpre)
+    ref = xr.grad + (old if acc else 0.0)
+    if masked:
+        ref = ref * torch.where(below > 0, torch.ones(()), torch.full((), slope))
+    outs = []
+    for tp_mode in (2, 0):
+        lib.csbsr_debug_set_conv_tp(tp_mode)
+        try:
+            out = to_fm(eng, old)
+            conv.invalidate()
+            conv.bwd_input(to_fm(eng, dpre), out=out, accumulate=acc, in_hw=(IH, IW), mask=(to_fm(eng, below), slope) if masked else None)
+            torch.cuda.synchronize()
+            from csbsr_amd.engine import pad8
+            assert (lib.csbsr_debug_last_conv_kernel() == 9) == (tp_mode == 2 and pad8(cout) in (64, 128) and pad8(cin) > 64)
+        finally:
+            lib.csbsr_debug_set_conv_tp(1)
+        outs.append(from_fm(out))
+        assert relmax(outs[-1], ref) < 2e-3
+    assert relmax(outs[0], outs[1]) < 1e-3
