@@ -1,24 +1,30 @@
 // Transposed convolution with a 2 x 2-tap phase decomposition (kernel <= 2 x stride: DBPN's 8x8 stride-4 / 12x12 stride-8 up-projections,
-// kbpn.py:230-262 UpBlock / DownBlock deconvs, and -- same geometry -- the dgrads of their strided convolutions), 64 or 128 input
-// channels -> 128 output channels.  Per output phase (oy % s, ox % s) the layer is a 2x2 convolution of the LOW-resolution input with
-// that phase's weights, K = 4 taps x cin: short-K GEMMs that the general LDS-DMA kernel ran at ~520 TF/s because every
-// (tile, phase, tap) re-fetched its pixel operand through L2 (80 % hit rate, 20 % at fabric latency behind a 2-3 stage ring) and paid a
-// 3.3 us prologue + 3.3 us LDS-staged epilogue around 6.7 us of K loop.  Here:
+// kbpn.py:230-262 UpBlock / DownBlock deconvs, and -- same geometry -- the dgrads of their strided convolutions), 128 input channels ->
+// 128 output channels.  Per output phase (oy % s, ox % s) the layer is a 2x2 convolution of the LOW-resolution input with that phase's
+// weights, K = 4 taps x cin = 512: short-K GEMMs that the general LDS-DMA kernel ran at ~520 TF/s in the training step because every
+// (tile, phase, tap) re-fetched its pixel operand through L2 (rocprof: 80 % hit rate, the 20 % at fabric latency behind a 2-3 stage ring)
+// and paid a 3.3 us prologue + 3.3 us LDS-staged epilogue around 6.7 us of K loop.  Here:
 //
-//  * one persistent workgroup (8 waves) per CU owns an 8 x 32 tile of input positions; its (8+2) x (32+2) halo goes HBM -> LDS ONCE
-//    (global_load_lds_dwordx4, zero page outside the image) and serves all taps of up to 8 phases: the pixel operand crosses the
-//    fabric ~1.3 times instead of 64;
-//  * the only operand streamed in the K loop is the phase's weights, 16 KB per 64-channel K step, L2-resident (<= 2 MB per layer),
-//    packed in MFMA-fragment order (csbsr_pack_weights_tp) so the 4-stage LDS ring is filled by straight 1 KB wave copies and read
-//    with conflict-free lane-linear ds_read_b128; the ring runs 3 steps ahead and straight through phase and tile boundaries;
-//  * pixel fragments are ds_read_b128 at (per-phase lane base + compile-time offset): odd 16-byte pixel pitch, no swizzle;
+//  * one persistent workgroup per CU (4 waves, one per SIMD, ~450 VGPR + AGPR each) owns an 8 x 32 tile of input positions; its
+//    (8+2) x (32+2) halo goes HBM -> LDS ONCE (global_load_lds_dwordx4, zero page outside the image) and serves all taps of up to 8
+//    phases: the pixel operand crosses the fabric ~1.3 times instead of 64;
+//  * a wave owns 32 output channels x all 256 pixels of the tile.  Its weight operand never touches LDS: the weights are packed in
+//    MFMA-fragment order (csbsr_pack_weights_tp), a K step's 32 couts x 64 channels are four 16-byte loads per lane from L2 (<= 2 MB
+//    per layer, resident), kept three steps ahead in registers.  So the K loop has NO barrier and no hand-counted vmcnt: the only
+//    workgroup synchronisation is the halo reload, once per 64 K steps;
+//  * pixel fragments are ds_read_b128 at (per-phase lane base + compile-time offset): odd 16-byte pixel pitch, no swizzle, 0 bank
+//    conflicts (SQ_LDS_BANK_CONFLICT); one read per MFMA, issued eight MFMAs ahead into the register the MFMA has just consumed;
 //  * D = W x X^T orientation: a lane ends up with 4+4 consecutive output channels of one pixel, v_permlane32_swap makes that 8 -- the
 //    epilogue (bias, PReLU, residual add / subtract, accumulate, activation-derivative mask) runs in registers with 16-byte loads and
-//    stores, no LDS staging.
+//    stores, no LDS staging;
+//  * the epilogue of phase i is software-pipelined under the K loop of phase i + 1 (second accumulator set): two 8-cout x 32-pixel
+//    pieces per K step, their residual / old-output / mask operands loaded one step ahead, their arithmetic cut into chunks that sit
+//    in the MFMA shadows (the wave is alone on its SIMD and issues in order; __builtin_amdgcn_sched_barrier pins the order).  Which
+//    operands the epilogue reads is a template parameter so that a K step is one basic block; dead lanes of ragged tiles are
+//    redirected (loads to offset 0, stores to a sink), never branched around.
 //
-// vmcnt discipline: loads complete in order, stores do not order against them, so every counted wait below only ever has stores that
-// are OLDER than the load it waits for (safe, at worst it also sits out their acknowledgement), and the stages the next phase starts
-// on are confirmed (vmcnt(0) + barrier) before the epilogue issues its stores.
+// Measured (N = 4, 448^2 -> 1792^2, 128 -> 128, 8x8 stride 4): 2.66 ms (633 TF/s) -> 2.00 ms (840 TF/s); in the training step the 21
+// launches per micro-batch went 68 -> 45 ms.  rocprof: MFMA pipe 56 % busy in cycles at a ~1.4 GHz effective clock under the counters.
 #include "common.h"
 #include "conv_common.h"
 #include "csbsr_debug.h"
@@ -29,15 +35,14 @@
 #define TP_HW (TP_TW + 2)
 #define TP_HH (TP_TH + 2)
 #define TP_NPIX (TP_HH * TP_HW)          // 340 halo pixels
-#define TP_NST 4                         // weight ring stages
-#define TP_STAGE 16384                   // bytes per stage: 128 couts x 64 channels
+#define TP_STAGE 16384                   // bytes of one K step's weights: 128 couts x 64 channels, [cout tile][k-slice][lane][8]
 #define TP_MAXPG 8                       // phases per work item
 
 struct ConvTpK {
   const half_t* in; long i_sn, i_sy, i_sx;
   int N, H, W;                      // input (low-resolution) size; output = stride x that
   int stride, pad;
-  const half_t* wt;                 // [phase][4 taps x NKC][16 KB fragment image]
+  const half_t* wt;                 // [phase][4 taps x NKC][16 KB: cout tile mt, k-slice kk, lane, 8 halves]
   int cout, coutp;
   half_t* out16; long o_sn, o_sy, o_sx;
   const float* bias; int act; float slope; const float* prelu; float out_scale;
@@ -45,7 +50,7 @@ struct ConvTpK {
   int accumulate;
   const half_t* mask; long m_sn, m_sy, m_sx; float mask_slope;
   unsigned tiles_x, tiles_y, pg, pgroups;     // phases per work item, items per tile
-  int dbg;                          // ablation bits (CSBSR_TP_DBG): 1 no stores, 2 no K-loop math, 4 no weight DMA, 8 / 16 no A / B fragment reads
+  int dbg;                          // ablation bit (CSBSR_TP_DBG): 1 stores go to the sink
 };
 
 __device__ __forceinline__ void tp_wait_barrier_all() {
@@ -53,26 +58,34 @@ __device__ __forceinline__ void tp_wait_barrier_all() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+// where one phase of one tile lands: image bases + byte offset of the tile's first pixel of that phase + what part of it is inside
+struct TpCtx {
+  const char *ob, *rb, *mb;
+  unsigned to, tr, tm;
+  int xlim, ylim;                   // lane live iff pix < xlim; the wave's row nt live iff nt < ylim
+};
 
-template <int NKC>
-__global__ __launch_bounds__(512) void conv_tp_kernel(const ConvTpK p, const half_t* __restrict__ zero_page) {
+template <int NKC, bool HAS_RES, bool HAS_ACC, bool HAS_MASK>
+__global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const half_t* __restrict__ zero_page, half_t* __restrict__ sink) {
   constexpr int SLOTS = NKC * 8 + 1;                    // 16-byte slots per pixel: odd -> consecutive pixels walk all banks
   constexpr int PITCH = SLOTS * 16;
   constexpr int NG = TP_NPIX * SLOTS;
   constexpr int NINST = (NG + 63) / 64;                 // wave instructions that fill the halo tile
   constexpr int XBYTES = NINST * 1024;
-  constexpr int WOFF = XBYTES;
-  constexpr int BOFF = WOFF + TP_NST * TP_STAGE;        // 128 biases
+  constexpr int BOFF = XBYTES;                          // 128 biases
+  constexpr int DOFF = BOFF + 512;                      // 1 KB landing area for the halo DMA's padding instructions
   constexpr int NKS = 4 * NKC;                          // K steps per phase (64 channels of one tap each)
-  constexpr int NFI = (NINST + 7) / 8;
-  constexpr int DQ = 512 / SLOTS, DC = 512 % SLOTS;
+  constexpr int PPS = 16 / NKS;                         // epilogue pieces (of the previous phase) drained per K step
+  constexpr int NFI = (NINST + 3) / 4;
+  constexpr int DQ = 256 / SLOTS, DC = 256 % SLOTS;
+  constexpr int WD = 3;                                 // weight stages in flight ahead of the MFMAs (WD + 1 register buffers)
+  static_assert(NKS % (WD + 1) == 0 && PPS == 2, "buffer indices must be compile-time across phases");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sBias = reinterpret_cast<float*>(smem + BOFF);
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // = the wave's 32-cout tile
   const int pix = lane & 31, hi = lane >> 5;
-  const int mh = wid & 1, pr = wid >> 1;                // cout half, row pair of the tile
   const half_t* zp = zero_page + (lane & 7) * 8;
   const int s = p.stride;
   const unsigned per_img = p.tiles_x * p.tiles_y, ntiles = per_img * (unsigned)p.N, items = ntiles * p.pgroups;
@@ -81,8 +94,16 @@ __global__ __launch_bounds__(512) void conv_tp_kernel(const ConvTpK p, const hal
   if (tid < 128) sBias[tid] = (p.bias && tid < p.cout) ? p.bias[tid] : 0.f;
   const float slope = p.act == CSBSR_ACT_PRELU ? *p.prelu : (p.act == CSBSR_ACT_RELU ? 0.f : (p.act == CSBSR_ACT_NONE ? 1.f : p.slope));
   const float rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
+  // (which operands the epilogue reads is compile-time: a K step is one basic block)
+  constexpr bool has_res = HAS_RES, has_acc = HAS_ACC, has_mask = HAS_MASK;
+  // a lane's share of every output / residual / mask address (bytes, within one image): its pixel column, cout tile, channel octet
+  const unsigned lane_o = 2u * (unsigned)((s * pix) * (int)p.o_sx + 32 * wid + 8 * hi);
+  const unsigned lane_r = 2u * (unsigned)((s * pix) * (int)p.r_sx + 32 * wid + 8 * hi);
+  const unsigned lane_m = 2u * (unsigned)((s * pix) * (int)p.m_sx + 32 * wid + 8 * hi);
+  const unsigned row_o = 2u * (unsigned)(s * (int)p.o_sy), row_r = 2u * (unsigned)(s * (int)p.r_sy), row_m = 2u * (unsigned)(s * (int)p.m_sy);
+  char* const sink_l = reinterpret_cast<char*>(sink) + lane * 16;
 
-  // halo-tile DMA roles (same for every tile): chunk g = (wid + 8 i) * 64 + lane = (halo pixel q, slot c)
+  // halo-tile DMA roles (same for every tile): chunk g = (wid + 4 i) * 64 + lane = (halo pixel q, slot c)
   int f_ty0, f_tx0, f_c0;
   {
     const int g = wid * 64 + lane;
@@ -93,164 +114,213 @@ __global__ __launch_bounds__(512) void conv_tp_kernel(const ConvTpK p, const hal
   }
   const int isy = (int)p.i_sy, isx = (int)p.i_sx;
   const long stage_elems = TP_STAGE / 2;
-  // one weight stage: 16 wave instructions, this wave's two
-  auto issue_w = [&](const half_t* src, int slot) {
-    if (p.dbg & 4) return;
+  // a wave's A operand never touches LDS: its 32 couts x 64 channels of a stage are 4 fragment-ordered KB, one 16-byte load per lane each
+  const unsigned wlane = (unsigned)((4 * wid) * 1024 + lane * 16);
+  auto load_w = [&](const half_t* src, h8 (&w)[4]) __attribute__((always_inline)) {
+    const char* b = reinterpret_cast<const char*>(src);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int blk = 2 * wid + j;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + blk * 512 + lane * 8),
-                                       (__attribute__((address_space(3))) void*)(smem + WOFF + slot * TP_STAGE + blk * 1024), 16, 0, 0);
-    }
+    for (int kk = 0; kk < 4; ++kk) w[kk] = *reinterpret_cast<const h8*>(b + (wlane + kk * 1024));
   };
-  const char* wl = smem + WOFF + mh * 8192 + lane * 16;   // A fragments: + slot * 16384 + mt * 4096 + kk * 1024
   const char* xl = smem + pix * PITCH + hi * 16;          // B fragments: + per-phase pixel base + compile-time (tap, row, channel) offset
 
-  {                                                       // ring prologue: the first phase's stages 0..2
-    const half_t* w0 = p.wt + (size_t)((it / ntiles) * p.pg) * NKS * stage_elems;
-    issue_w(w0, 0); issue_w(w0 + stage_elems, 1); issue_w(w0 + 2 * stage_elems, 2);
-  }
+  // ---- epilogue pieces: piece pi = (row nt = pi / 2, cout half pair = pi % 2) of a wave's 32 couts x 8 rows x 32 pixels; a lane owns
+  // couts 32 wid + 16 pair + 8 hi .. +7 of pixel (row nt, column pix).  Loads and stores are issued unconditionally (dead lanes read
+  // offset 0 of the image / write the sink): no divergent control flow inside a K step.
+  auto piece_loads = [&](const TpCtx& c, int pi, h8& r, h8& o, h8& m) __attribute__((always_inline)) {
+    const int nt = pi >> 1, pair = pi & 1;
+    const bool lv = pix < c.xlim && nt < c.ylim;
+    if (has_res) { const unsigned off = lane_r + c.tr + nt * row_r + 32 * pair; r = *reinterpret_cast<const h8*>(c.rb + (lv ? off : 0u)); }
+    if (has_acc) { const unsigned off = lane_o + c.to + nt * row_o + 32 * pair; o = *reinterpret_cast<const h8*>(c.ob + (lv ? off : 0u)); }
+    if (has_mask) { const unsigned off = lane_m + c.tm + nt * row_m + 32 * pair; m = *reinterpret_cast<const h8*>(c.mb + (lv ? off : 0u)); }
+  };
+  // The piece arithmetic comes in chunks small enough for one MFMA shadow each (a wave is alone on its SIMD and issues in order, so
+  // whatever follows an MFMA in program order runs while the matrix pipe works on it):
+  // act chunk c = 0..3: accumulator pair -> couts c and 4 + c of the lane's octet, scale + bias + activation
+  auto act_chunk = [&](const f16v (&pa)[8], int pi, int c, float (&v)[8], f4 (&bq)[2]) __attribute__((always_inline)) {
+    const int nt = pi >> 1, pair = pi & 1;
+    if (c == 0) {
+      const int co = 32 * wid + 16 * pair + 8 * hi;
+      bq[0] = *reinterpret_cast<const f4*>(sBias + co); bq[1] = *reinterpret_cast<const f4*>(sBias + co + 4);
+    }
+    const unsigned a = __float_as_uint(pa[nt][8 * pair + c]), b = __float_as_uint(pa[nt][8 * pair + 4 + c]);
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    // (output channels >= cout need no masking: their packed weights and LDS biases are zero, and so are the padding channels of
+    // the residual / old-output maps)
+    float t0 = __uint_as_float(r[0]) * p.out_scale + bq[0][c], t1 = __uint_as_float(r[1]) * p.out_scale + bq[1][c];
+    v[c] = t0 > 0.f ? t0 : t0 * slope;
+    v[4 + c] = t1 > 0.f ? t1 : t1 * slope;
+  };
+  // store chunk c = 0..3: residual / old output / activation mask on couts c and 4 + c
+  auto store_chunk = [&](int c, float (&v)[8], const h8& r, const h8& o, const h8& m) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = c; e < 8; e += 4) {
+      if (has_res) v[e] += rsign * (float)r[e];
+      if (has_acc) v[e] += (float)o[e];
+      if (has_mask) v[e] *= ((float)m[e] > 0.f ? 1.f : p.mask_slope);
+    }
+  };
+  auto store_fin = [&](const TpCtx& c, int pi, const float (&v)[8]) __attribute__((always_inline)) {
+    const int nt = pi >> 1, pair = pi & 1;
+    h8 hv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
+    const bool lv = pix < c.xlim && nt < c.ylim && 32 * wid + 16 * pair + 8 * hi < p.coutp && !(p.dbg & 1);
+    const unsigned off = lane_o + c.to + nt * row_o + 32 * pair;
+    char* dst = lv ? const_cast<char*>(c.ob) + off : sink_l;
+    *reinterpret_cast<h8*>(dst) = hv;
+  };
 
-  for (; it < items; it += gridDim.x) {
-    const unsigned pgi = it / ntiles, tile = it - pgi * ntiles;
-    const int n = tile / per_img;
-    const unsigned r_ = tile - n * per_img;
-    const int Y0 = (r_ / p.tiles_x) * TP_TH, X0 = (r_ % p.tiles_x) * TP_TW;
-    const unsigned itn = it + gridDim.x;
-    // ---- halo tile -> LDS (every wave is past the previous item's last K step: end-of-phase barrier)
-    {
+  TpCtx cur, pend;
+  cur.ob = pend.ob = reinterpret_cast<const char*>(p.out16);
+  cur.rb = pend.rb = reinterpret_cast<const char*>(has_res ? p.res : p.out16);
+  cur.mb = pend.mb = reinterpret_cast<const char*>(has_mask ? p.mask : p.out16);
+  cur.to = cur.tr = cur.tm = pend.to = pend.tr = pend.tm = 0u;
+  cur.xlim = cur.ylim = pend.xlim = pend.ylim = 0;        // nothing pending yet: its pieces load offset 0 and store to the sink
+  h8 lr[2][PPS], lo[2][PPS], lm[2][PPS];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < PPS; ++b) lr[a][b] = lo[a][b] = lm[a][b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+
+  h8 wreg[WD + 1][4];                                     // stage ks of a phase lives in wreg[ks % (WD + 1)]
+  {                                                       // the first phase's stages 0 .. WD - 1
+    const half_t* w0 = p.wt + (size_t)((it / ntiles) * p.pg) * NKS * stage_elems;
+#pragma unroll
+    for (int d = 0; d < WD; ++d) load_w(w0 + d * stage_elems, wreg[d]);
+  }
+  h8 bfr[8];                                              // B fragments of the k-slice in flight: pixel row nt, one read per MFMA
+
+  unsigned pgi = 0, itn = 0;
+  int n = 0, Y0 = 0, X0 = 0;
+  // ---- one phase: K loop into `acc` while the previous phase's accumulators `pd` drain, two pieces per K step.  No barrier in here:
+  // the pixel operand is the (static) LDS tile, the weight operand is private to the wave.
+  auto phase = [&](f16v (&acc)[8], const f16v (&pd)[8], unsigned j, bool first_of_item) __attribute__((always_inline)) {
+    const unsigned ph = pgi * p.pg + j;
+    const int py = ph / s, px = ph - py * s;
+    const int by = (py + p.pad) / s, bx = (px + p.pad) / s;
+    const bool last_of_item = j + 1 >= p.pg;
+    const unsigned phn = !last_of_item ? ph + 1 : (itn < items ? (itn / ntiles) * p.pg : ph);   // (last phase of all: harmless refetch)
+    const int pyn = phn / s, pxn = phn - pyn * s;
+    const half_t* wcur = p.wt + (size_t)ph * NKS * stage_elems;
+    const half_t* wnext = p.wt + (size_t)phn * NKS * stage_elems;
+    // rows 0..3 and 4..7 of the tile get their own base register (the 16-bit ds_read offset does not reach over all eight)
+    const char* xph = xl + (by * TP_HW + bx) * PITCH;
+    const char* xphn = xl + (((pyn + p.pad) / s) * TP_HW + (pxn + p.pad) / s) * PITCH;
+    cur.ob = reinterpret_cast<const char*>(p.out16 + n * p.o_sn);
+    cur.rb = reinterpret_cast<const char*>(has_res ? p.res + n * p.r_sn : p.out16);
+    cur.mb = reinterpret_cast<const char*>(has_mask ? p.mask + n * p.m_sn : p.out16);
+    cur.to = 2u * (unsigned)((s * Y0 + py) * (int)p.o_sy + (s * X0 + px) * (int)p.o_sx);
+    cur.tr = 2u * (unsigned)((s * Y0 + py) * (int)p.r_sy + (s * X0 + px) * (int)p.r_sx);
+    cur.tm = 2u * (unsigned)((s * Y0 + py) * (int)p.m_sy + (s * X0 + px) * (int)p.m_sx);
+    cur.xlim = p.W - X0; cur.ylim = p.H - Y0;
+    // B fragment (row nt) of k-slice (ks, kk) of the phase whose lane base is xb
+    auto rdb = [&](const char* xb, int ks, int kk, int nt) __attribute__((always_inline)) {
+      const int tap = ks / NKC, kc = ks % NKC;
+      const int jy = tap >> 1, jx = tap & 1;
+      const int xo = ((1 - jy) * TP_HW + (1 - jx)) * PITCH + kc * 128 + kk * 32;
+      return *reinterpret_cast<const h8*>((nt < 4 ? xb : xb + 4 * TP_HW * PITCH) + xo + (nt & 3) * TP_HW * PITCH);
+    };
+    if (first_of_item) {
+      // ---- halo tile -> LDS (every wave has to be past its last read of the old tile)
+      __syncthreads();
       const half_t* tbase = p.in + n * p.i_sn + (long)(Y0 - 1) * p.i_sy + (long)(X0 - 1) * p.i_sx;
       int ty = f_ty0, tx = f_tx0, c = f_c0;
 #pragma unroll 2
       for (int i = 0; i < NFI; ++i) {
-        const int inst = wid + 8 * i;
-        if (inst < NINST) {
-          const int iy = Y0 - 1 + ty, ix = X0 - 1 + tx;
-          const bool ok = ty < TP_HH && c < NKC * 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-          const half_t* src = ok ? tbase + (ty * isy + tx * isx + c * 8) : zp;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(smem + inst * 1024), 16, 0, 0);
-        }
+        const int inst = wid + 4 * i;
+        const int iy = Y0 - 1 + ty, ix = X0 - 1 + tx;
+        const bool ok = ty < TP_HH && c < NKC * 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const half_t* src = ok ? tbase + (ty * isy + tx * isx + c * 8) : zp;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + (inst < NINST ? inst * 1024 : DOFF)), 16, 0, 0);
         c += DC; tx += DQ;
         if (c >= SLOTS) { c -= SLOTS; ++tx; }
         if (tx >= TP_HW) { tx -= TP_HW; ++ty; }
         if (tx >= TP_HW) { tx -= TP_HW; ++ty; }
       }
-    }
-
-    for (unsigned j = 0; j < p.pg; ++j) {
-      const unsigned ph = pgi * p.pg + j;
-      const int py = ph / s, px = ph - py * s;
-      const int by = (py + p.pad) / s, bx = (px + p.pad) / s;
-      const unsigned phn = (j + 1 < p.pg) ? ph + 1 : (itn < items ? (itn / ntiles) * p.pg : ph);   // (last phase of all: harmless refetch)
-      const half_t* wcur = p.wt + (size_t)ph * NKS * stage_elems;
-      const half_t* wnext = p.wt + (size_t)phn * NKS * stage_elems;
-      const char* xph = xl + ((2 * pr + by) * TP_HW + bx) * PITCH;
-
-      f16v acc[2][2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        // stage ks landed everywhere + every wave is done with step ks-1 (whose slot is refilled below)
-        if (ks == 0) { if (j == 0) tp_wait_barrier_all(); }
-        else if (ks < 3) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-        else { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-        issue_w(ks + 3 < NKS ? wcur + (ks + 3) * stage_elems : wnext + (ks + 3 - NKS) * stage_elems, (ks + 3) % TP_NST);
-        const int tap = ks / NKC, kc = ks % NKC;
-        const int jy = tap >> 1, jx = tap & 1;
-        const int xo = ((1 - jy) * TP_HW + (1 - jx)) * PITCH + kc * 128;
-        const int wo = (ks % TP_NST) * TP_STAGE;
-        if (!(p.dbg & 2)) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          h8 a0, a1, b0, b1;
-          if (!(p.dbg & 8)) {
-            a0 = *reinterpret_cast<const h8*>(wl + wo + kk * 1024);
-            a1 = *reinterpret_cast<const h8*>(wl + wo + 4096 + kk * 1024);
-          } else { a0 = a1 = h8{1, 1, 1, 1, 1, 1, 1, 1} * (half_t)slope; }
-          if (!(p.dbg & 16)) {
-            b0 = *reinterpret_cast<const h8*>(xph + xo + kk * 32);
-            b1 = *reinterpret_cast<const h8*>(xph + xo + TP_HW * PITCH + kk * 32);
-          } else { b0 = b1 = h8{1, 1, 1, 1, 1, 1, 1, 1} * (half_t)rsign; }
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        }
-      }
-      // the next phase's first three stages are in flight: confirm them (and that every wave has left the K loop) before any store
       tp_wait_barrier_all();
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) bfr[nt] = rdb(xph, 0, 0, nt);
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-      // ---- epilogue: acc[mt][nt][4q + jj] = cout 64 mh + 32 mt + 8 q + 4 hi + jj of pixel (row 2 pr + nt, column pix)
-      const int qx = X0 + pix;
-      const long ox = (long)s * qx + px;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int qy = Y0 + 2 * pr + nt;
-        const bool live = qy < p.H && qx < p.W;
-        const long oy = (long)s * qy + py;
-        const long ooff = n * p.o_sn + oy * p.o_sy + ox * p.o_sx + 64 * mh + 8 * hi;
-        const long roff = n * p.r_sn + oy * p.r_sy + ox * p.r_sx + 64 * mh + 8 * hi;
-        const long moff = n * p.m_sn + oy * p.m_sy + ox * p.m_sx + 64 * mh + 8 * hi;
-        h8 rr[4], oo[4], mm[4];
+    for (int ks = 0; ks < NKS; ++ks) {
+      // the next step's pieces: operands on their way one step ahead
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {          // piece q = (mt, pair): couts 64 mh + 16 q + 8 hi ..
-          const bool lq = live && 64 * mh + 16 * q + 8 * hi < p.coutp;
-          if (rsign != 0.f && lq) rr[q] = *reinterpret_cast<const h8*>(p.res + roff + 16 * q);
-          if (p.accumulate && lq) oo[q] = *reinterpret_cast<const h8*>(p.out16 + ooff + 16 * q);
-          if (p.mask && lq) mm[q] = *reinterpret_cast<const h8*>(p.mask + moff + 16 * q);
-        }
+      for (int pp = 0; pp < PPS; ++pp) {
+        const int pn_ = (ks + 1) * PPS + pp;
+        if (pn_ < 16) piece_loads(pend, pn_, lr[(ks + 1) & 1][pp], lo[(ks + 1) & 1][pp], lm[(ks + 1) & 1][pp]);
+        else piece_loads(cur, pn_ - 16, lr[(ks + 1) & 1][pp], lo[(ks + 1) & 1][pp], lm[(ks + 1) & 1][pp]);
+      }
+      // the weight stage WD steps ahead
+      load_w(ks + WD < NKS ? wcur + (ks + WD) * stage_elems : wnext + (ks + WD - NKS) * stage_elems, wreg[(ks + WD) % (WD + 1)]);
+      __builtin_amdgcn_sched_barrier(0);
+      float v[PPS][8];
+      f4 bq[PPS][2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int mt = q >> 1, pair = q & 1;
-          float v[8];
+      for (int kk = 0; kk < 4; ++kk) {
+        const h8 af = wreg[ks % (WD + 1)][kk];
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const unsigned a = __float_as_uint(acc[mt][nt][8 * pair + jj]), b = __float_as_uint(acc[mt][nt][8 * pair + 4 + jj]);
-            auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-            v[jj] = __uint_as_float(r[0]);
-            v[4 + jj] = __uint_as_float(r[1]);
+        for (int i = 0; i < 8; ++i) {
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfr[i], acc[i], 0, 0, 0);
+          // the same row's fragment of the next k-slice (of the next step / next phase at the ends; across a tile change it reads
+          // the old tile and is replaced after the reload)
+          if (kk < 3) bfr[i] = rdb(xph, ks, kk + 1, i);
+          else if (ks + 1 < NKS) bfr[i] = rdb(xph, ks + 1, 0, i);
+          else bfr[i] = rdb(xphn, 0, 0, i);
+          // the pending pieces' arithmetic and stores, one chunk per MFMA shadow, spread over the four k-slices
+#pragma unroll
+          for (int pp = 0; pp < PPS; ++pp) {
+            const int k_act = 2 * pp, k_st = k_act + 1;
+            if (kk == k_act && i < 4) act_chunk(pd, ks * PPS + pp, i, v[pp], bq[pp]);
+            if (kk == k_st && i < 4) store_chunk(i, v[pp], lr[ks & 1][pp], lo[ks & 1][pp], lm[ks & 1][pp]);
+            if (kk == k_st && i == 4) store_fin(pend, ks * PPS + pp, v[pp]);
           }
-          const int co = 64 * mh + 16 * q + 8 * hi;
-          const f4 b0 = *reinterpret_cast<const f4*>(sBias + co), b1 = *reinterpret_cast<const f4*>(sBias + co + 4);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float t = v[e] * p.out_scale + (e < 4 ? b0[e & 3] : b1[e & 3]);
-            t = t > 0.f ? t : t * slope;                   // identity 1, ReLU 0, leaky / PReLU slope
-            v[e] = (co + e < p.cout) ? t : 0.f;
-          }
-          if (live && co < p.coutp) {
-            if (rsign != 0.f) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += rsign * (float)rr[q][e];
-            }
-            if (p.accumulate) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)oo[q][e];
-            }
-            if (p.mask) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= ((float)mm[q][e] > 0.f ? 1.f : p.mask_slope);
-            }
-            h8 hv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-            if (!(p.dbg & 1) || v[0] == 12345.678f) *reinterpret_cast<h8*>(p.out16 + ooff + 16 * q) = hv;
-          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-    }      // phases
-  }        // items
+    }
+    pend = cur;
+  };
+
+  f16v accA[8], accB[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accB[a][r] = 0.f;
+
+  for (; it < items; it += gridDim.x) {
+    pgi = it / ntiles;
+    const unsigned tile = it - pgi * ntiles;
+    n = tile / per_img;
+    const unsigned r_ = tile - n * per_img;
+    Y0 = (r_ / p.tiles_x) * TP_TH; X0 = (r_ % p.tiles_x) * TP_TW;
+    itn = it + gridDim.x;
+    for (unsigned j = 0; j < p.pg; j += 2) {             // (pg is even: the accumulator sets alternate)
+      phase(accA, accB, j, j == 0);
+      phase(accB, accA, j + 1, false);
+    }
+  }
+  // ---- the last phase's accumulators (in accB) drain on their own
+#pragma unroll
+  for (int pi = 0; pi < 16; ++pi) {
+    h8 r = h8{0, 0, 0, 0, 0, 0, 0, 0}, o = r, m = r;
+    float v[8];
+    f4 bq[2];
+    piece_loads(pend, pi, r, o, m);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) act_chunk(accB, pi, c, v, bq);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) store_chunk(c, v, r, o, m);
+    store_fin(pend, pi, v);
+  }
 }
 
-// ---- weights in ring-stage order: dst[phase][ks = tap * NKC + kc][mt][kk][lane][e] =
+// ---- weights in K-step order: dst[phase][ks = tap * NKC + kc][mt][kk][lane][e] =
 //        W(cout 32 mt + lane % 32, channel 64 kc + 16 kk + 8 (lane / 32) + e, kh = (py + pad) % s + s jy, kw likewise), tap = 2 jy + jx
 // W is indexed [contracted channel][row][kh][kw]: ConvTranspose2d's IOHW parameter, or a Conv2d's OIHW parameter seen from its dgrad
 // (contracted = the conv's output channels, rows = its input channels) -- csbsr_pack_weights kind 2 in this kernel's order.
@@ -275,7 +345,7 @@ __global__ void pack_weights_tp_kernel(const PackTpK p, long total) {
   }
 }
 
-static int tp_nkc(int cin_padded) { return cin_padded == 64 ? 1 : (cin_padded == 128 ? 2 : 0); }
+static int tp_nkc(int cin_padded) { return 2; }      // 128 padded input channels = two 64-channel K chunks per tap (the only instantiation)
 
 extern "C" int64_t csbsr_packed_weight_elems_tp(int32_t stride, int32_t c_real) {
   const int nkc = tp_nkc(round_up(c_real, 8) <= 64 ? 64 : 128);
@@ -286,7 +356,7 @@ extern "C" int csbsr_pack_weights_tp(const float* w, void* dst, int32_t D0, int3
                                      int32_t c_real, int32_t rows_real, int32_t row_off, int32_t k_off, csbsr_stream_t s) {
   CSBSR_CHECK(w && dst, "pack_tp: null pointer");
   CSBSR_CHECK(stride >= 2 && KH == KW && KH > stride && KH <= 2 * stride && pad >= 0 && pad < stride, "pack_tp: needs stride < kernel <= 2 stride");
-  CSBSR_CHECK(c_real >= 1 && c_real <= 128 && rows_real >= 1 && rows_real <= 128, "pack_tp: at most 128 channels either side");
+  CSBSR_CHECK(c_real > 64 && c_real <= 128 && rows_real >= 1 && rows_real <= 128, "pack_tp: at most 128 channels either side");
   CSBSR_CHECK(k_off >= 0 && k_off + c_real <= D0 && row_off >= 0 && row_off + rows_real <= D1, "pack_tp: range out of bounds");
   PackTpK p;
   p.w = w; p.dst = reinterpret_cast<half_t*>(dst); p.D1 = D1; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
@@ -303,39 +373,43 @@ static int g_conv_tp_mode = 1;      // 0 off, 1 problems that fill the chip, 2 e
 extern "C" void csbsr_debug_set_conv_tp(int mode) { g_conv_tp_mode = mode; }
 
 // Which launches take this kernel: transposed, stride < kernel <= 2 stride (2 x 2 taps per phase), output exactly stride x input,
-// one plain-fp16 input segment of 64 or 128 padded channels, 65..128 (padded: 72..128) output channels, bias / ReLU / leaky / PReLU /
+// one plain-fp16 input segment of 128 padded channels (65..128 real), 65..128 (padded: 72..128) output channels, bias / ReLU / leaky / PReLU /
 // residual add or subtract / accumulate / activation mask; no fp32 or split outputs, statistics or constant-segment bias.
 extern "C" int32_t csbsr_conv_tp_eligible(const csbsr_conv_desc_t* d) {
-  if (!d || !g_conv_tp_mode || !d->transposed || d->KH != d->KW || d->stride < 2 || d->KH <= d->stride || d->KH > 2 * d->stride) return 0;
+  if (!d || !g_conv_tp_mode || !d->transposed || d->KH != d->KW || d->stride < 2 || (d->stride & 1) || d->KH <= d->stride || d->KH > 2 * d->stride) return 0;
   if (d->pad < 0 || d->pad >= d->stride || d->dil != 1 || d->OH != d->H * d->stride || d->OW != d->W * d->stride) return 0;
-  if (d->in[1].c != 0 || d->in[0].sx == 0 || (d->in[0].c != 64 && d->in[0].c != 128)) return 0;
+  if (d->in[1].c != 0 || d->in[0].sx == 0 || d->in[0].c != 128) return 0;
   if (d->coutp <= 64 || d->coutp > 128 || !d->out16 || d->out32 || d->cbias || d->o_lo || d->r_lo || d->r2_lo) return 0;
   if (d->stat_mode != CSBSR_STAT_NONE) return 0;
+  if (d->res_mode != CSBSR_RES_NONE && (d->accumulate || d->mask)) return 0;
   if (d->res_mode != CSBSR_RES_NONE && d->res_mode != CSBSR_RES_ADD && d->res_mode != CSBSR_RES_SUB) return 0;
   if (d->act == CSBSR_ACT_SIGMOID) return 0;
-  if (d->in[0].sn >= (1ll << 31) || d->o_sn >= (1ll << 40)) return 0;
+  // in-image offsets are 32-bit byte offsets
+  const long lim = 1l << 31;
+  if (d->in[0].sn >= lim || (long)d->OH * d->o_sy >= lim || (d->res_mode != CSBSR_RES_NONE && (long)d->OH * d->r_sy >= lim) ||
+      (d->mask && (long)d->OH * d->m_sy >= lim)) return 0;
   if (g_conv_tp_mode == 1 && (long)d->N * d->H * d->W < 128L * TP_TH * TP_TW) return 0;
   return 1;
 }
 
-static half_t* g_tp_zero_page[CSBSR_MAX_DEVICES] = {};
+static half_t* g_tp_zero_page[CSBSR_MAX_DEVICES] = {};      // 256 B of zeros + a 1 KB sink for the dead lanes' stores
 
-template <int NKC>
-static int launch_tp(const ConvTpK& k, hipStream_t st, const half_t* zp) {
+template <int NKC, bool R, bool A, bool M>
+static int launch_tp(const ConvTpK& k, hipStream_t st, half_t* zp) {
   constexpr int SLOTS = NKC * 8 + 1;
   constexpr int NINST = (TP_NPIX * SLOTS + 63) / 64;
-  constexpr int SM_BYTES = NINST * 1024 + TP_NST * TP_STAGE + 128 * 4;
+  constexpr int SM_BYTES = NINST * 1024 + 128 * 4 + 1024;
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tp_kernel<NKC>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tp_kernel<NKC, R, A, M>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
     attr_set = true;
   }
   const unsigned items = k.tiles_x * k.tiles_y * k.N * k.pgroups;
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   const unsigned g = items < (unsigned)ncu ? items : (unsigned)ncu;
-  hipLaunchKernelGGL((conv_tp_kernel<NKC>), dim3(g), dim3(512), SM_BYTES, st, k, zp);
+  hipLaunchKernelGGL((conv_tp_kernel<NKC, R, A, M>), dim3(g), dim3(256), SM_BYTES, st, k, zp, zp + 128);
   CSBSR_LAUNCH_CHECK("csbsr_conv_tp_forward");
   return 0;
 }
@@ -357,17 +431,25 @@ extern "C" int csbsr_conv_tp_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   k.tiles_x = (unsigned)((d->W + TP_TW - 1) / TP_TW); k.tiles_y = (unsigned)((d->H + TP_TH - 1) / TP_TH);
   const unsigned nphase = (unsigned)(d->stride * d->stride);
   k.pg = nphase < TP_MAXPG ? nphase : TP_MAXPG;
-  while (nphase % k.pg) --k.pg;
+  while (nphase % k.pg) --k.pg;          // (stride is even: pg is too)
   k.pgroups = nphase / k.pg;
   { const char* e = getenv("CSBSR_TP_DBG"); k.dbg = e ? atoi(e) : 0; }
   int dev = 0;
   CSBSR_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CSBSR_MAX_DEVICES, "conv_tp: no current device");
   if (!g_tp_zero_page[dev]) {
-    CSBSR_CHECK(hipMalloc(reinterpret_cast<void**>(&g_tp_zero_page[dev]), 256) == hipSuccess, "conv_tp: zero page alloc failed");
-    (void)hipMemset(g_tp_zero_page[dev], 0, 256);
+    CSBSR_CHECK(hipMalloc(reinterpret_cast<void**>(&g_tp_zero_page[dev]), 256 + 1024) == hipSuccess, "conv_tp: zero page alloc failed");
+    (void)hipMemset(g_tp_zero_page[dev], 0, 256 + 1024);
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   g_last_conv_kernel = CONVK_TP;
-  if (d->in[0].c == 64) return launch_tp<1>(k, st, g_tp_zero_page[dev]);
-  return launch_tp<2>(k, st, g_tp_zero_page[dev]);
+  half_t* zp = g_tp_zero_page[dev];
+  const bool r = d->res_mode != CSBSR_RES_NONE, a = d->accumulate != 0, m = d->mask != nullptr;
+  // the instantiated epilogues: forward (plain / residual), dgrad (plain / accumulate / mask / accumulate + mask)
+  if (!r && !a && !m) return launch_tp<2, false, false, false>(k, st, zp);
+  if (r && !a && !m) return launch_tp<2, true, false, false>(k, st, zp);
+  if (!r && a && !m) return launch_tp<2, false, true, false>(k, st, zp);
+  if (!r && !a && m) return launch_tp<2, false, false, true>(k, st, zp);
+  if (!r && a && m) return launch_tp<2, false, true, true>(k, st, zp);
+  csbsr_set_error("conv_tp: residual together with accumulate / mask is not instantiated");
+  return 1;
 }

@@ -104,7 +104,7 @@ int csbsr_conv_hr_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
  * layers that autograd runs for kbpn.py:230-262): the low-resolution halo tile stays in LDS for all phases and taps, only the
  * fragment-ordered weights (csbsr_pack_weights_tp) stream through a 4-stage LDS ring, register epilogue -- see csrc/conv_tp.hip.
  * Same descriptor as csbsr_conv_forward except d->wt, which must come from csbsr_pack_weights_tp; csbsr_conv_tp_eligible says
- * whether a launch qualifies (64 / 128 padded input channels in one plain fp16 segment, 128 padded output channels, output exactly
+ * whether a launch qualifies (128 padded input channels in one plain fp16 segment, 72..128 padded output channels, output exactly
  * stride x input, bias / ReLU / leaky / PReLU / residual add or subtract / accumulate / activation mask). */
 int32_t csbsr_conv_tp_eligible(const csbsr_conv_desc_t* d);
 int csbsr_conv_tp_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);

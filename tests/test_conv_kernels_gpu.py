@@ -228,7 +228,8 @@ def test_hr_direct_conv_kernel(cin, cout, act):
     (8, 4, 2, 128, 128, 16, 64, "prelu"),          # up_conv1
     (8, 4, 2, 128, 128, 17, 33, "prelu_sub"),      # down_conv2: PReLU - residual
     (12, 8, 2, 128, 128, 9, 34, "prelu_add"),      # x8 variant: 64 phases, phases with a single valid tap per axis
-    (8, 4, 2, 64, 128, 16, 32, "relu"),            # one 64-channel K chunk per tap
+    (8, 4, 2, 64, 128, 16, 32, "relu"),            # 64 input channels: not eligible, general kernel
+    (8, 4, 2, 100, 128, 16, 32, "relu"),           # padded input channels
     (8, 4, 2, 128, 100, 10, 20, "none"),           # padded output channels
 ])
 def test_phase_decomposed_transposed_conv(k, s, p, cin, cout, H, W, mode):
@@ -259,7 +260,8 @@ def test_phase_decomposed_transposed_conv(k, s, p, cin, cout, H, W, mode):
         try:
             y = conv.fwd(to_fm(eng, x), res=to_fm(eng, res) if rm != L.RES_NONE else None, res_mode=rm)
             torch.cuda.synchronize()
-            assert (lib.csbsr_debug_last_conv_kernel() == 9) == (tp_mode == 2)
+            from csbsr_amd.engine import pad8
+            assert (lib.csbsr_debug_last_conv_kernel() == 9) == (tp_mode == 2 and pad8(cin) == 128 and pad8(cout) > 64)
         finally:
             lib.csbsr_debug_set_conv_tp(1)
         outs.append(from_fm(y))
@@ -298,7 +300,7 @@ def test_phase_decomposed_strided_dgrad(cin, cout, H, W, acc, masked):
             conv.bwd_input(to_fm(eng, dpre), out=out, accumulate=acc, in_hw=(IH, IW), mask=(to_fm(eng, below), slope) if masked else None)
             torch.cuda.synchronize()
             from csbsr_amd.engine import pad8
-            assert (lib.csbsr_debug_last_conv_kernel() == 9) == (tp_mode == 2 and pad8(cout) in (64, 128) and pad8(cin) > 64)
+            assert (lib.csbsr_debug_last_conv_kernel() == 9) == (tp_mode == 2 and pad8(cout) == 128 and pad8(cin) > 64)
         finally:
             lib.csbsr_debug_set_conv_tp(1)
         outs.append(from_fm(out))
