@@ -14,8 +14,8 @@
 //    workgroup synchronisation is the halo reload, once per 64 K steps;
 //  * pixel fragments are ds_read_b128 at (per-phase lane base + compile-time offset): odd 16-byte pixel pitch, no swizzle, 0 bank
 //    conflicts (SQ_LDS_BANK_CONFLICT); one read per MFMA, issued eight MFMAs ahead into the register the MFMA has just consumed;
-//  * D = W x X^T orientation: a lane ends up with 4+4 consecutive output channels of one pixel, v_permlane32_swap makes that 8 -- the
-//    epilogue (bias, PReLU, residual add / subtract, accumulate, activation-derivative mask) runs in registers with 16-byte loads and
+//  * D = W x X^T orientation with the couts of a 32-row tile permuted in the pack (cout 16 h + 4 q + j on MFMA row 8 q + 4 h + j): a
+//    lane's 16 accumulator registers are 16 consecutive output channels of one pixel, no cross-lane exchange -- the epilogue (bias, PReLU, residual add / subtract, accumulate, activation-derivative mask) runs in registers with 16-byte loads and
 //    stores, no LDS staging;
 //  * the epilogue of phase i is software-pipelined under the K loop of phase i + 1 (second accumulator set): two 8-cout x 32-pixel
 //    pieces per K step, their residual / old-output / mask operands loaded one step ahead, their arithmetic cut into chunks that sit
@@ -97,9 +97,9 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   // (which operands the epilogue reads is compile-time: a K step is one basic block)
   constexpr bool has_res = HAS_RES, has_acc = HAS_ACC, has_mask = HAS_MASK;
   // a lane's share of every output / residual / mask address (bytes, within one image): its pixel column, cout tile, channel octet
-  const unsigned lane_o = 2u * (unsigned)((s * pix) * (int)p.o_sx + 32 * wid + 8 * hi);
-  const unsigned lane_r = 2u * (unsigned)((s * pix) * (int)p.r_sx + 32 * wid + 8 * hi);
-  const unsigned lane_m = 2u * (unsigned)((s * pix) * (int)p.m_sx + 32 * wid + 8 * hi);
+  const unsigned lane_o = 2u * (unsigned)((s * pix) * (int)p.o_sx + 32 * wid + 16 * hi);
+  const unsigned lane_r = 2u * (unsigned)((s * pix) * (int)p.r_sx + 32 * wid + 16 * hi);
+  const unsigned lane_m = 2u * (unsigned)((s * pix) * (int)p.m_sx + 32 * wid + 16 * hi);
   const unsigned row_o = 2u * (unsigned)(s * (int)p.o_sy), row_r = 2u * (unsigned)(s * (int)p.r_sy), row_m = 2u * (unsigned)(s * (int)p.m_sy);
   char* const sink_l = reinterpret_cast<char*>(sink) + lane * 16;
 
@@ -123,30 +123,29 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   };
   const char* xl = smem + pix * PITCH + hi * 16;          // B fragments: + per-phase pixel base + compile-time (tap, row, channel) offset
 
-  // ---- epilogue pieces: piece pi = (row nt = pi / 2, cout half pair = pi % 2) of a wave's 32 couts x 8 rows x 32 pixels; a lane owns
-  // couts 32 wid + 16 pair + 8 hi .. +7 of pixel (row nt, column pix).  Loads and stores are issued unconditionally (dead lanes read
+  // ---- epilogue pieces: piece pi = (row nt = pi / 2, octet pair = pi % 2) of a wave's 32 couts x 8 rows x 32 pixels.  The packed
+  // weights put cout 16 h + 4 q + j on MFMA row 8 q + 4 h + j, so the 16 accumulator registers of a lane ARE 16 consecutive couts,
+  // 32 wid + 16 hi + (0..15), of its pixel (row nt, column pix) -- no cross-lane exchange; a piece is one 16-byte octet of them.  Loads and stores are issued unconditionally (dead lanes read
   // offset 0 of the image / write the sink): no divergent control flow inside a K step.
   auto piece_loads = [&](const TpCtx& c, int pi, h8& r, h8& o, h8& m) __attribute__((always_inline)) {
     const int nt = pi >> 1, pair = pi & 1;
     const bool lv = pix < c.xlim && nt < c.ylim;
-    if (has_res) { const unsigned off = lane_r + c.tr + nt * row_r + 32 * pair; r = *reinterpret_cast<const h8*>(c.rb + (lv ? off : 0u)); }
-    if (has_acc) { const unsigned off = lane_o + c.to + nt * row_o + 32 * pair; o = *reinterpret_cast<const h8*>(c.ob + (lv ? off : 0u)); }
-    if (has_mask) { const unsigned off = lane_m + c.tm + nt * row_m + 32 * pair; m = *reinterpret_cast<const h8*>(c.mb + (lv ? off : 0u)); }
+    if (has_res) { const unsigned off = lane_r + c.tr + nt * row_r + 16 * pair; r = *reinterpret_cast<const h8*>(c.rb + (lv ? off : 0u)); }
+    if (has_acc) { const unsigned off = lane_o + c.to + nt * row_o + 16 * pair; o = *reinterpret_cast<const h8*>(c.ob + (lv ? off : 0u)); }
+    if (has_mask) { const unsigned off = lane_m + c.tm + nt * row_m + 16 * pair; m = *reinterpret_cast<const h8*>(c.mb + (lv ? off : 0u)); }
   };
   // The piece arithmetic comes in chunks small enough for one MFMA shadow each (a wave is alone on its SIMD and issues in order, so
   // whatever follows an MFMA in program order runs while the matrix pipe works on it):
-  // act chunk c = 0..3: accumulator pair -> couts c and 4 + c of the lane's octet, scale + bias + activation
+  // act chunk c = 0..3: couts c and 4 + c of the piece's octet: scale + bias + activation
   auto act_chunk = [&](const f16v (&pa)[8], int pi, int c, float (&v)[8], f4 (&bq)[2]) __attribute__((always_inline)) {
     const int nt = pi >> 1, pair = pi & 1;
     if (c == 0) {
-      const int co = 32 * wid + 16 * pair + 8 * hi;
+      const int co = 32 * wid + 16 * hi + 8 * pair;
       bq[0] = *reinterpret_cast<const f4*>(sBias + co); bq[1] = *reinterpret_cast<const f4*>(sBias + co + 4);
     }
-    const unsigned a = __float_as_uint(pa[nt][8 * pair + c]), b = __float_as_uint(pa[nt][8 * pair + 4 + c]);
-    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     // (output channels >= cout need no masking: their packed weights and LDS biases are zero, and so are the padding channels of
     // the residual / old-output maps)
-    float t0 = __uint_as_float(r[0]) * p.out_scale + bq[0][c], t1 = __uint_as_float(r[1]) * p.out_scale + bq[1][c];
+    float t0 = pa[nt][8 * pair + c] * p.out_scale + bq[0][c], t1 = pa[nt][8 * pair + 4 + c] * p.out_scale + bq[1][c];
     v[c] = t0 > 0.f ? t0 : t0 * slope;
     v[4 + c] = t1 > 0.f ? t1 : t1 * slope;
   };
@@ -164,8 +163,8 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     h8 hv;
 #pragma unroll
     for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-    const bool lv = pix < c.xlim && nt < c.ylim && 32 * wid + 16 * pair + 8 * hi < p.coutp && !(p.dbg & 1);
-    const unsigned off = lane_o + c.to + nt * row_o + 32 * pair;
+    const bool lv = pix < c.xlim && nt < c.ylim && 32 * wid + 16 * hi + 8 * pair < p.coutp && !(p.dbg & 1);
+    const unsigned off = lane_o + c.to + nt * row_o + 16 * pair;
     char* dst = lv ? const_cast<char*>(c.ob) + off : sink_l;
     *reinterpret_cast<h8*>(dst) = hv;
   };
@@ -321,7 +320,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
 }
 
 // ---- weights in K-step order: dst[phase][ks = tap * NKC + kc][mt][kk][lane][e] =
-//        W(cout 32 mt + lane % 32, channel 64 kc + 16 kk + 8 (lane / 32) + e, kh = (py + pad) % s + s jy, kw likewise), tap = 2 jy + jx
+//        W(cout 32 mt + perm(lane % 32), perm(8 q + 4 h + j) = 16 h + 4 q + j, channel 64 kc + 16 kk + 8 (lane / 32) + e, kh = (py + pad) % s + s jy, kw likewise), tap = 2 jy + jx
 // W is indexed [contracted channel][row][kh][kw]: ConvTranspose2d's IOHW parameter, or a Conv2d's OIHW parameter seen from its dgrad
 // (contracted = the conv's output channels, rows = its input channels) -- csbsr_pack_weights kind 2 in this kernel's order.
 struct PackTpK { const float* w; half_t* dst; int D1, KH, KW, stride, pad, nkc, c_real, rows_real, row_off, k_off; };
@@ -332,7 +331,8 @@ __global__ void pack_weights_tp_kernel(const PackTpK p, long total) {
     const long stage = i >> 13;
     const int ks = (int)(stage % nks), ph = (int)(stage / nks);
     const int mt = blk >> 2, kk = blk & 3;
-    const int row = 32 * mt + (lane & 31);
+    const int m = lane & 31;                                 // MFMA row of the A operand -> the cout it carries (see the epilogue)
+    const int row = 32 * mt + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
     const int tap = ks / p.nkc, kc = ks % p.nkc;
     const int c = 64 * kc + 16 * kk + 8 * (lane >> 5) + e;
     const int jy = tap >> 1, jx = tap & 1;

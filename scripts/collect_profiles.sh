@@ -1,15 +1,19 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): bench line, rocprofv3 kernel stats of the same command, and the two PMC passes for HBM traffic.
-# Outputs land in gpurun_out/r01/ ; scripts/summarise_profiles.py turns them into the committed files under profiles/.
+# Run on the GPU box (gpurun): bench line, rocprofv3 kernel stats of the same command, the two PMC passes for HBM traffic and the PMC
+# pass for MFMA utilisation.  Outputs land in gpurun_out/$TAG/ (TAG = first argument, default r02); scripts/summarise_profiles.py turns
+# them into the committed files under profiles/.  Counters are collected in their own runs (kernel trace only), one counter set per run.
 set -u
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r01
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch --output-format csv -- python3 $R/bench.py --batch 4 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write --output-format csv -- python3 $R/bench.py --batch 4 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
+PM="--batch 4 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-h2d-leg"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch --output-format csv -- python3 $R/bench.py $PM > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write --output-format csv -- python3 $R/bench.py $PM > $O/pmc_write.json 2> $O/pmc_write.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_MFMA -d $O/pmc_mfma -o mfma --output-format csv -- python3 $R/bench.py $PM > $O/pmc_mfma.json 2> $O/pmc_mfma.err
 rm -f $O/*/*kernel_trace.csv $O/*/*agent_info.csv 2>/dev/null     # large; the stats / counter files are what is summarised
 ls -la $O $O/* | head -40
 tail -c 600 $O/bench.json

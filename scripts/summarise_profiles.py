@@ -1,8 +1,10 @@
-"""Turn gpurun_out/r01/ (written by scripts/collect_profiles.sh on the GPU box) into the committed evidence under profiles/:
+"""Turn gpurun_out/<tag>/ (written by scripts/collect_profiles.sh on the GPU box) into the committed evidence under profiles/
+(usage: summarise_profiles.py [dir under gpurun_out] [tag], default r02 r02):
 
-  profiles/r01_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `python bench.py` (default flags)
-  profiles/r01_bench.json               the JSON line of the same command
-  profiles/r01_pmc_traffic.json         per-kernel HBM bytes per launch from the two --pmc passes (FETCH_SIZE, WRITE_SIZE), at --batch 4 (one micro-batch of 4, as in the bench)
+  profiles/<tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `python bench.py` (default flags)
+  profiles/<tag>_bench.json               the JSON line of the same command
+  profiles/<tag>_pmc_traffic.json         per-kernel HBM bytes per launch from the two --pmc passes (FETCH_SIZE, WRITE_SIZE), at --batch 4 (one micro-batch of 4, as in the bench)
+  profiles/<tag>_pmc_mfma.json            per-kernel MFMA-pipe utilisation from the SQ_VALU_MFMA_BUSY_CYCLES pass (same command)
 
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950
 FETCH_SIZE counts 128-byte requests as 64 bytes for wide coalesced reads, so it is doubled; WRITE_SIZE is taken as is (uncalibrated).
@@ -16,9 +18,9 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r01")
+SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r02")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[2] if len(sys.argv) > 2 else "r01"
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r02"
 
 
 def canon(name):
@@ -33,6 +35,18 @@ def canon(name):
     m = re.search(r"conv_igemm_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name) or re.search(r"conv_igemm_kernel<(\d+), (\d+), (\d+)>", name)
     if m:
         return "conv_igemm_kernel<%s,%s,%s>" % m.groups()
+    m = re.search(r"conv_wgrad_glds_kernelILi(\d+)ELi(\d+)E", name) or re.search(r"conv_wgrad_glds_kernel<(\d+), (\d+)", name)
+    if m:
+        return "conv_wgrad_glds_kernel<%s,%s>" % m.groups()
+    m = re.search(r"conv_wgrad_kernel<(\d+), (\d+), (\d+), (\d+)", name) or re.search(r"conv_wgrad_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+    if m:
+        return "conv_wgrad_kernel<%s,%s,%s,%s>" % m.groups()
+    m = re.search(r"conv_hr_kernelILi(\d+)ELb(\d)E", name) or re.search(r"conv_hr_kernel<(\d+), (\w+)>", name)
+    if m:
+        return "conv_hr_kernel<%s>" % m.group(1)
+    m = re.search(r"conv_tp_kernelILi\d+ELb(\d)ELb(\d)ELb(\d)E", name)
+    if m:
+        return "conv_tp_kernel<res=%s,acc=%s,mask=%s>" % m.groups()
     for k in ("conv_wgrad_thin_kernel", "conv_wgrad_kernel", "conv_thin_cout_kernel", "conv_thin_cin_kernel", "epilogue_bwd_kernel",
               "unpack_wgrad_kernel", "bn_bwd_apply_kernel", "bn_bwd_reduce_kernel", "bn_apply_kernel"):
         if k in name:
@@ -70,6 +84,36 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0]):
     out["kernels"][k] = {"launches": n, "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                          "hbm_bytes_per_launch": round(fb + wb)}
 json.dump(out, open(os.path.join(DST, f"{TAG}_pmc_traffic.json"), "w"), indent=1)
+# ---- MFMA utilisation: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs (= 32 x the 32x32x16 MFMA instructions, checked
+# against SQ_INSTS_MFMA); utilisation = busy / (1024 SIMDs x the kernel's cycles), the kernel's cycles taken from GRBM_GUI_ACTIVE
+# (GRBM_GUI_ACTIVE is reported summed over the 8 XCDs, so / 8; per launch the effective clock under the counters comes out at
+# 1.8-2.3 GHz, not the 2.4 GHz peak clock the roofline is priced at)
+mp = os.path.join(SRC, "pmc_mfma", "mfma_counter_collection.csv")
+if os.path.exists(mp):
+    busy, gui, wavec, ninst = (pmc(mp, c) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_INSTS_MFMA"))
+    dur = defaultdict(lambda: [0.0, 0])
+    with open(mp) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                a = dur[canon(r["Kernel_Name"])]
+                a[0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); a[1] += 1
+    mo = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_MFMA -- python3 "
+                     "bench.py --batch 4 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-h2d-leg",
+          "units": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); clock_ghz = GRBM_GUI_ACTIVE / 8 / launch duration; "
+                   "mfma_util_at_2p4ghz = busy cycles / (1024 x 2.4e9 x duration), i.e. against the peak-clock MFMA rate the roofline uses",
+          "kernels": {}}
+    for k in sorted(busy, key=lambda k: -busy[k][0]):
+        b, n = busy[k]
+        g = gui[k][0] / 8.0
+        d_ns = dur[k][0]
+        if n < 2 or g <= 0 or b <= 0:
+            continue
+        mo["kernels"][k] = {"launches": n, "avg_launch_us": round(d_ns / n / 1e3, 1), "mfma_util": round(b / (1024.0 * g), 4),
+                            "clock_ghz": round(g / d_ns, 3), "mfma_util_at_2p4ghz": round(b / (1024.0 * 2.4 * d_ns), 4),
+                            "mfma_insts_per_launch": round(ninst[k][0] / n)}
+    json.dump(mo, open(os.path.join(DST, f"{TAG}_pmc_mfma.json"), "w"), indent=1)
+    for k, v in list(mo["kernels"].items())[:12]:
+        print(f"{k:44s} n={v['launches']:5d} {v['avg_launch_us']:9.1f} us  MFMA busy {100*v['mfma_util']:5.1f} %  clock {v['clock_ghz']:.2f} GHz")
 tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out["kernels"].values())
 print("total HBM bytes over the profiled run: %.1f GB" % (tot / 1e9))
 for k, v in list(out["kernels"].items())[:12]:
