@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   const float rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
   // (which operands the epilogue reads is compile-time: a K step is one basic block)
   constexpr bool has_res = HAS_RES, has_acc = HAS_ACC, has_mask = HAS_MASK;
+  constexpr bool has_bias = !(HAS_ACC || HAS_MASK);       // the accumulate / mask variants are dgrad launches: no bias, no activation
   // a lane's share of every output / residual / mask address (bytes, within one image): its pixel column, cout tile, channel octet
   const unsigned lane_o = 2u * (unsigned)((s * pix) * (int)p.o_sx + 32 * wid + 16 * hi);
   const unsigned lane_r = 2u * (unsigned)((s * pix) * (int)p.r_sx + 32 * wid + 16 * hi);
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   // act chunk c = 0..3: couts c and 4 + c of the piece's octet: scale + bias + activation
   auto act_chunk = [&](const f16v (&pa)[8], int pi, int c, float (&v)[8], f4 (&bq)[2]) __attribute__((always_inline)) {
     const int nt = pi >> 1, pair = pi & 1;
+    if (!has_bias) { v[c] = pa[nt][8 * pair + c] * p.out_scale; v[4 + c] = pa[nt][8 * pair + 4 + c] * p.out_scale; return; }
     if (c == 0) {
       const int co = 32 * wid + 16 * hi + 8 * pair;
       bq[0] = *reinterpret_cast<const f4*>(sBias + co); bq[1] = *reinterpret_cast<const f4*>(sBias + co + 4);
@@ -382,6 +384,7 @@ extern "C" int32_t csbsr_conv_tp_eligible(const csbsr_conv_desc_t* d) {
   if (d->coutp <= 64 || d->coutp > 128 || !d->out16 || d->out32 || d->cbias || d->o_lo || d->r_lo || d->r2_lo) return 0;
   if (d->stat_mode != CSBSR_STAT_NONE) return 0;
   if (d->res_mode != CSBSR_RES_NONE && (d->accumulate || d->mask)) return 0;
+  if ((d->accumulate || d->mask) && (d->bias || d->act != CSBSR_ACT_NONE)) return 0;
   if (d->res_mode != CSBSR_RES_NONE && d->res_mode != CSBSR_RES_ADD && d->res_mode != CSBSR_RES_SUB) return 0;
   if (d->act == CSBSR_ACT_SIGMOID) return 0;
   // in-image offsets are 32-bit byte offsets
