@@ -74,8 +74,8 @@ SIGNATURES = {
     "csbsr_conv_tp_forward": (i32, [C.POINTER(ConvDesc), vp]),
     "csbsr_packed_weight_elems_tp": (i64, [i32, i32]),
     "csbsr_pack_weights_tp": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "csbsr_packed_weight_elems_hr": (i64, [i32, i32]),
-    "csbsr_pack_weights_hr": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "csbsr_packed_weight_elems_hr": (i64, [i32, i32, i32]),
+    "csbsr_pack_weights_hr": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "csbsr_packed_weight_elems": (i64, [i32] * 9),
     "csbsr_pack_weights": (i32, [vp, vp] + [i32] * 12 + [vp]),
     "csbsr_packed_weight_elems_split": (i64, [i32] * 9),

@@ -24,8 +24,6 @@
 
 #define HR_TH 16
 #define HR_TW 32
-#define HR_HW (HR_TW + 2)
-#define HR_NPIX ((HR_TH + 2) * HR_HW)          // 340 halo pixels
 
 struct ConvHrK {
   const half_t* in; long i_sn, i_sy, i_sx;
@@ -40,9 +38,13 @@ struct ConvHrK {
   int dbg;                          // ablation bits (CSBSR_HR_DBG): 1 no stores, 2 no K loop, 4 no tile DMA
 };
 
-template <int CH8, bool STAT>
+// TAPS = 9 (3x3, one-pixel halo) or 1 (the 1x1 layers of the same chains -- fe_SR.1, fe_cat.0 and their dgrads: no halo, two or four
+// MFMA K steps per 32 pixels, a pure HBM stream)
+template <int CH8, bool STAT, int TAPS>
 __global__ __launch_bounds__(256, (CH8 == 4 ? 3 : 2)) void conv_hr_kernel(const ConvHrK p, const half_t* __restrict__ zero_page) {
-  constexpr int NCHUNK = 9 * CH8;                       // K in 8-channel chunks
+  constexpr int HALO = TAPS == 9 ? 1 : 0;
+  constexpr int HR_HW = HR_TW + 2 * HALO, HR_NPIX = (HR_TH + 2 * HALO) * HR_HW;      // 18 x 34 = 612 halo pixels (3x3)
+  constexpr int NCHUNK = TAPS * CH8;                    // K in 8-channel chunks
   constexpr int NKS = (NCHUNK + 1) / 2;                 // MFMA K steps (16 channels = two chunks)
   constexpr int SLOTS = (CH8 % 2) ? CH8 : CH8 + 1;      // 16-byte slots per pixel in LDS: odd, so consecutive pixels walk all banks
   constexpr int PIXB = SLOTS * 16;                      // bytes per pixel in LDS
@@ -94,14 +96,14 @@ __global__ __launch_bounds__(256, (CH8 == 4 ? 3 : 2)) void conv_hr_kernel(const 
     const int y0 = (r_ / p.tiles_x) * HR_TH, x0 = (r_ % p.tiles_x) * HR_TW;
     if (vb != j0) __syncthreads();                     // every wave is done reading the previous tile (and its sums are flushed)
     // ---- halo tile -> LDS
-    const half_t* tbase = p.in + n * p.i_sn + (long)(y0 - 1) * p.i_sy + (long)(x0 - 1) * p.i_sx;      // wave-uniform
+    const half_t* tbase = p.in + n * p.i_sn + (long)(y0 - HALO) * p.i_sy + (long)(x0 - HALO) * p.i_sx;      // wave-uniform
     int ty = f_ty0, tx = f_tx0, c = f_c0;
 #pragma unroll 2      // (fully unrolled the scheduler computes every 64-bit source address up front: 2 x NFI registers)
     for (int i = 0; i < NFI; ++i) {
       const int inst = wid + 4 * i;
       if (inst < NINST) {
-        const int iy = y0 - 1 + ty, ix = x0 - 1 + tx;
-        const bool ok = ty < HR_TH + 2 && c < CH8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && !(p.dbg & 4);
+        const int iy = y0 - HALO + ty, ix = x0 - HALO + tx;
+        const bool ok = ty < HR_TH + 2 * HALO && c < CH8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && !(p.dbg & 4);
         const half_t* src = ok ? tbase + (ty * isy + tx * isx + c * 8) : zp;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(smem + inst * 1024), 16, 0, 0);
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256, (CH8 == 4 ? 3 : 2)) void conv_hr_kernel(const 
 // ---- weights in fragment order:  dst[ct][ks][lane][e] = W(cout = 32 ct + lane%32, chunk kc = 2 ks + lane/32, channel 8 (kc % CH8) + e)
 // with tap = kc / CH8 -> (ky, kx).  kind 0: forward conv, W is OIHW [cout][cin];  kind 1: dgrad of a stride-1 conv: rows are the conv's
 // INPUT channels, contracted channels its output channels, taps flipped (W[contracted][row][2-ky][2-kx]).
-struct PackHrK { const float* w; half_t* dst; int kind, D0, D1, ch8, nks, rows_real, c_real, ntile_c, row_off, k_off; };
+struct PackHrK { const float* w; half_t* dst; int kind, D0, D1, ch8, nks, rows_real, c_real, ntile_c, row_off, k_off, ks; };
 __global__ void pack_weights_hr_kernel(const PackHrK p) {
   const long total = (long)p.ntile_c * p.nks * 64 * 8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -212,37 +214,39 @@ __global__ void pack_weights_hr_kernel(const PackHrK p) {
     const int kc = 2 * ks + (lane >> 5);
     const int tap = kc / p.ch8, c = (kc % p.ch8) * 8 + e;
     float v = 0.f;
-    if (row < p.rows_real && tap < 9 && c < p.c_real) {
-      const int ky = tap / 3, kx = tap % 3;
+    if (row < p.rows_real && tap < p.ks * p.ks && c < p.c_real) {
+      const int ky = tap / p.ks, kx = tap % p.ks;
       const int rr = p.row_off + row, cc = p.k_off + c;
-      if (p.kind == 0) v = p.w[(((long)rr * p.D1 + cc) * 3 + ky) * 3 + kx];
-      else v = p.w[(((long)cc * p.D1 + rr) * 3 + (2 - ky)) * 3 + (2 - kx)];
+      if (p.kind == 0) v = p.w[(((long)rr * p.D1 + cc) * p.ks + ky) * p.ks + kx];
+      else v = p.w[(((long)cc * p.D1 + rr) * p.ks + (p.ks - 1 - ky)) * p.ks + (p.ks - 1 - kx)];
     }
     p.dst[i] = (half_t)v;
   }
 }
 
-static bool hr_geometry(int c_real, int rows_real, int& ch8, int& nks, int& ntile_c) {
+static bool hr_geometry(int ksize, int c_real, int rows_real, int& ch8, int& nks, int& ntile_c) {
+  if (ksize != 1 && ksize != 3) return false;
   const int cp = round_up(c_real, 8);
   if (cp == 32) ch8 = 4;
   else if (cp == 56) ch8 = 7;
   else return false;
-  nks = (9 * ch8 + 1) / 2;
+  nks = (ksize * ksize * ch8 + 1) / 2;
   ntile_c = (round_up(rows_real, 8) + 31) / 32;
   return rows_real >= 1 && ntile_c <= 2;
 }
 
-extern "C" int64_t csbsr_packed_weight_elems_hr(int32_t c_real, int32_t rows_real) {
+extern "C" int64_t csbsr_packed_weight_elems_hr(int32_t ksize, int32_t c_real, int32_t rows_real) {
   int ch8, nks, nt;
-  if (!hr_geometry(c_real, rows_real, ch8, nks, nt)) return 0;
+  if (!hr_geometry(ksize, c_real, rows_real, ch8, nks, nt)) return 0;
   return (int64_t)nt * nks * 64 * 8;
 }
 
-extern "C" int csbsr_pack_weights_hr(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
+extern "C" int csbsr_pack_weights_hr(const float* w, void* dst, int32_t kind, int32_t ksize, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
                                      int32_t row_off, int32_t k_off, csbsr_stream_t s) {
   CSBSR_CHECK(w && dst && (kind == 0 || kind == 1), "pack_hr: bad args");
   PackHrK p;
-  CSBSR_CHECK(hr_geometry(c_real, rows_real, p.ch8, p.nks, p.ntile_c), "pack_hr: channels must pad to 32 or 56, rows to <= 64");
+  CSBSR_CHECK(hr_geometry(ksize, c_real, rows_real, p.ch8, p.nks, p.ntile_c), "pack_hr: 1x1 or 3x3, channels must pad to 32 or 56, rows to <= 64");
+  p.ks = ksize;
   const int kdim = kind == 0 ? D1 : D0, rdim = kind == 0 ? D0 : D1;
   CSBSR_CHECK(k_off >= 0 && k_off + c_real <= kdim && row_off >= 0 && row_off + rows_real <= rdim, "pack_hr: range out of bounds");
   p.w = w; p.dst = reinterpret_cast<half_t*>(dst); p.kind = kind; p.D0 = D0; p.D1 = D1;
@@ -253,11 +257,12 @@ extern "C" int csbsr_pack_weights_hr(const float* w, void* dst, int32_t kind, in
   return 0;
 }
 
-// Which launches take this kernel: 3x3, stride 1, pad 1, dilation 1, one plain-fp16 input segment of 32 or 56 (padded) channels,
+// Which launches take this kernel: 3x3 / pad 1 or 1x1 / pad 0, stride 1, dilation 1, one plain-fp16 input segment of 32 or 56 (padded) channels,
 // <= 64 output channels, ReLU / LeakyReLU / no activation, no bias / residual / accumulate / fp32 side output / BatchNorm sums; large
 // maps only (the tile grid must fill the chip).
 extern "C" int32_t csbsr_conv_hr_eligible(const csbsr_conv_desc_t* d) {
-  if (!d || d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->dil != 1) return 0;
+  if (!d || d->transposed || d->KH != d->KW || d->stride != 1 || d->dil != 1) return 0;
+  if (!((d->KH == 3 && d->pad == 1) || (d->KH == 1 && d->pad == 0))) return 0;
   if (d->in[1].c != 0 || d->in[0].sx == 0 || (d->in[0].c != 32 && d->in[0].c != 56)) return 0;
   if (d->coutp > 64 || d->OH != d->H || d->OW != d->W) return 0;
   if (d->bias || d->cbias || d->res_mode != CSBSR_RES_NONE || d->accumulate || d->out32 || d->o_lo) return 0;
@@ -269,16 +274,17 @@ extern "C" int32_t csbsr_conv_hr_eligible(const csbsr_conv_desc_t* d) {
 
 static half_t* g_hr_zero_page[CSBSR_MAX_DEVICES] = {};
 
-template <int CH8>
+template <int CH8, int TAPS>
 static int launch_hr(const ConvHrK& k, hipStream_t st, const half_t* zp) {
   constexpr int SLOTS = (CH8 % 2) ? CH8 : CH8 + 1;
-  constexpr int NG = HR_NPIX * SLOTS, NINST = (NG + 63) / 64;
+  constexpr int HALO = TAPS == 9 ? 1 : 0;
+  constexpr int NG = (HR_TH + 2 * HALO) * (HR_TW + 2 * HALO) * SLOTS, NINST = (NG + 63) / 64;
   constexpr int SM_BYTES = NINST * 1024 + 16 + 64 * 4;
   static_assert(SM_BYTES <= 80 * 1024, "two workgroups per CU must fit");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, true, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, false, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
     attr_set = true;
   }
   // persistent: (workgroups per CU the registers admit) x 256 CUs, a multiple of 8 x ntile_c; never more than there is work
@@ -288,8 +294,8 @@ static int launch_hr(const ConvHrK& k, hipStream_t st, const half_t* zp) {
   if (g > total * k.ntile_c) g = total * k.ntile_c;
   g = (g + unit - 1) / unit * unit;
   dim3 grid(g);
-  if (k.stat) hipLaunchKernelGGL((conv_hr_kernel<CH8, true>), grid, dim3(256), SM_BYTES, st, k, zp);
-  else hipLaunchKernelGGL((conv_hr_kernel<CH8, false>), grid, dim3(256), SM_BYTES, st, k, zp);
+  if (k.stat) hipLaunchKernelGGL((conv_hr_kernel<CH8, true, TAPS>), grid, dim3(256), SM_BYTES, st, k, zp);
+  else hipLaunchKernelGGL((conv_hr_kernel<CH8, false, TAPS>), grid, dim3(256), SM_BYTES, st, k, zp);
   CSBSR_LAUNCH_CHECK("csbsr_conv_hr_forward");
   return 0;
 }
@@ -316,6 +322,10 @@ extern "C" int csbsr_conv_hr_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   g_last_conv_kernel = CONVK_HR;
-  if (d->in[0].c == 32) return launch_hr<4>(k, st, g_hr_zero_page[dev]);
-  return launch_hr<7>(k, st, g_hr_zero_page[dev]);
+  if (d->KH == 3) {
+    if (d->in[0].c == 32) return launch_hr<4, 9>(k, st, g_hr_zero_page[dev]);
+    return launch_hr<7, 9>(k, st, g_hr_zero_page[dev]);
+  }
+  if (d->in[0].c == 32) return launch_hr<4, 1>(k, st, g_hr_zero_page[dev]);
+  return launch_hr<7, 1>(k, st, g_hr_zero_page[dev]);
 }

@@ -296,9 +296,9 @@ class Conv:
             kind, c_real, rows_real, row_off = hr
             key = ("hr", kind, row_off)
             if key not in self._packed:
-                n = L.load().csbsr_packed_weight_elems_hr(c_real, rows_real)
+                n = L.load().csbsr_packed_weight_elems_hr(k, c_real, rows_real)
                 dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
-                L.call("csbsr_pack_weights_hr", _ptr(self.w), _ptr(dst), kind, self.w.shape[0], self.w.shape[1], c_real, rows_real, row_off, 0,
+                L.call("csbsr_pack_weights_hr", _ptr(self.w), _ptr(dst), kind, k, self.w.shape[0], self.w.shape[1], c_real, rows_real, row_off, 0,
                        self.eng.stream)
                 self._packed[key] = dst
             d.wt = _ptr(self._packed[key])
@@ -342,7 +342,7 @@ class Conv:
             wt = self._pack("fwd", 2, self.split[0], self.split[1], 0, self.cout, self.stride, self.pad)
         else:
             wt = self._pack("fwd", 0, self.split[0], self.split[1], 0, self.cout, self.stride, self.pad)
-        hr = (0, self.cin, self.cout, 0) if (not sp and not self.transposed and self.k == 3 and len(xs) == 1 and self.prelu is None) else None
+        hr = (0, self.cin, self.cout, 0) if (not sp and not self.transposed and self.k in (1, 3) and len(xs) == 1 and self.prelu is None) else None
         self._launch(xs, wt, self.transposed, self.k, self.stride, self.pad, self.dil, H, W, OH, OW, self.cout, out, out32, self.b,
                      self.act, self.slope, self.prelu, res, res2, res_mode, False, stat, stat_mode, 1.0 / self.WSCALE if sp else 1.0, hr=hr,
                      tp=(self.cin, self.cout, 0, 0) if (self.transposed and len(xs) == 1 and not sp) else None)
@@ -382,7 +382,7 @@ class Conv:
             tr, ps, pp, dd = True, s, p, 1
         if out is None and out32 is None and stat is None:
             out = self.eng.new(dpre.N, OH, OW, c_seg)
-        hr = (1, self.cout, c_seg, row_off) if (not hp and not self.transposed and s == 1 and k == 3 and stat is None) else None
+        hr = (1, self.cout, c_seg, row_off) if (not hp and not self.transposed and s == 1 and k in (1, 3) and stat is None) else None
         self._launch((dpre, dpre) if hp else (dpre,), wt, tr, k, ps, pp, dd, H, W, OH, OW, c_seg, out, out32, None, L.ACT_NONE, 0.0, None,
                      None, None, L.RES_NONE, accumulate, stat, L.STAT_SAMPLE_SUM if stat is not None else L.STAT_NONE,
                      1.0 / self.WSCALE if hp else 1.0, mask=mask, hr=hr,

@@ -93,11 +93,15 @@ int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
 
 /* Direct 3x3 convolution for the 32 / 49-channel full-resolution layers of the kernel predictor (kbpn.py:521-578) and their dgrads:
  * halo tile in LDS, weights in registers (packed in MFMA-fragment order by csbsr_pack_weights_hr), see csrc/conv_hr.hip.  Same
- * descriptor as csbsr_conv_forward; csbsr_conv_hr_eligible says whether a launch qualifies (3x3 / stride 1 / pad 1, one plain fp16
+ * descriptor as csbsr_conv_forward; csbsr_conv_hr_eligible says whether a launch qualifies (3x3 / pad 1 or 1x1 / pad 0, stride 1, one plain fp16
  * segment of 32 or 56 padded channels, <= 64 couts, ReLU / LeakyReLU / none, optional mask and per-sample sums, nothing else fused).
  * pack: kind 0 = forward conv (W OIHW, rows = D0), kind 1 = dgrad of a stride-1 conv (rows = D1, taps flipped). */
 int32_t csbsr_conv_hr_eligible(const csbsr_conv_desc_t* d);
 int csbsr_conv_hr_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
+/* ksize = 3 (pad 1) or 1 (pad 0); kind 0 forward (w = OIHW), 1 dgrad of a stride-1 conv (rows = the conv's input channels, taps flipped) */
+int64_t csbsr_packed_weight_elems_hr(int32_t ksize, int32_t c_real, int32_t rows_real);
+int csbsr_pack_weights_hr(const float* w, void* dst, int32_t kind, int32_t ksize, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
+                          int32_t row_off, int32_t k_off, csbsr_stream_t s);
 
 /* Phase-decomposed transposed convolution (ConvTranspose2d with stride < kernel <= 2 stride: the 8x8 stride-4 / 12x12 stride-8
  * up-projections of /root/reference/model/modeling/kbpn.py:230-262 via DeconvBlock, and the dgrads of the matching strided Conv2d
@@ -113,9 +117,6 @@ int csbsr_conv_tp_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
 int64_t csbsr_packed_weight_elems_tp(int32_t stride, int32_t c_real);
 int csbsr_pack_weights_tp(const float* w, void* dst, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                           int32_t c_real, int32_t rows_real, int32_t row_off, int32_t k_off, csbsr_stream_t s);
-int64_t csbsr_packed_weight_elems_hr(int32_t c_real, int32_t rows_real);
-int csbsr_pack_weights_hr(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
-                          int32_t row_off, int32_t k_off, csbsr_stream_t s);
 
 /* Weight-gradient GEMM: G[split][a][tap][b] = sum over the split's pixels of A[pix][a] * B[pix @ tap][b]  (fp32; the pixel
  * range is cut into csbsr_wgrad_splits() slabs, each written once -- no atomics, no zero-fill; csbsr_unpack_wgrad sums them).

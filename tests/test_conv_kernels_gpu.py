@@ -180,9 +180,10 @@ def test_dgrad_with_fused_activation_mask(cin, cout, H, W, acc):
     assert relmax(from_fm(out), ref) < 2e-3
 
 
-@pytest.mark.parametrize("cin,cout,act", [(32, 32, "lrelu"), (32, 49, "none"), (49, 49, "lrelu"), (49, 32, "relu"), (3, 49, "relu")])
-def test_hr_direct_conv_kernel(cin, cout, act):
-    """The direct 3x3 kernel of the full-resolution 32 / 49-channel layers (csrc/conv_hr.hip: halo tile in LDS, weights in registers),
+@pytest.mark.parametrize("cin,cout,act,ks", [(32, 32, "lrelu", 3), (32, 49, "none", 3), (49, 49, "lrelu", 3), (49, 32, "relu", 3), (3, 49, "relu", 3),
+                                             (49, 32, "lrelu", 1), (32, 49, "none", 1), (32, 32, "relu", 1)])
+def test_hr_direct_conv_kernel(cin, cout, act, ks):
+    """The direct 3x3 / 1x1 kernel of the full-resolution 32 / 49-channel layers (csrc/conv_hr.hip: halo tile in LDS, weights in registers),
     forward (+ per-sample channel sums without a stored output for the 32 -> 49 case, as fe_cat.2 runs) and dgrad with the fused
     activation mask, against torch on the same fp16-rounded operands; ragged tiles on both axes; (3, 49) is NOT eligible and must
     still come out right through the other kernels."""
@@ -192,11 +193,11 @@ def test_hr_direct_conv_kernel(cin, cout, act):
     eng = _eng()
     N, H, W = 2, 363, 371
     x = torch.randn(N, cin, H, W).half().float()
-    w = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).half().float()
+    w = (torch.randn(cout, cin, ks, ks) / (cin * ks * ks) ** 0.5).half().float()
     params = {"l.weight": w.cuda()}
     a = {"lrelu": L.ACT_LRELU, "relu": L.ACT_RELU, "none": L.ACT_NONE}[act]
-    conv = Conv(eng, "l", params, 3, 1, 1, 1, bias=False, act=a, slope=0.01)
-    ref_pre = F.conv2d(x, w, None, 1, 1)
+    conv = Conv(eng, "l", params, ks, 1, ks // 2, 1, bias=False, act=a, slope=0.01)
+    ref_pre = F.conv2d(x, w, None, 1, ks // 2)
     ref = {"lrelu": F.leaky_relu(ref_pre, 0.01), "relu": F.relu(ref_pre), "none": ref_pre}[act]
     xf = to_fm(eng, x)
     y = conv.fwd(xf)
@@ -215,7 +216,7 @@ def test_hr_direct_conv_kernel(cin, cout, act):
     dpre = torch.randn(N, cout, H, W).half().float()
     below = torch.randn(N, cin, H, W).half().float()
     xr = torch.zeros(N, cin, H, W, requires_grad=True)
-    F.conv2d(xr, w, None, 1, 1).backward(dpre)
+    F.conv2d(xr, w, None, 1, ks // 2).backward(dpre)
     refd = xr.grad * torch.where(below > 0, torch.ones(()), torch.full((), 0.01))
     dx = conv.bwd_input(to_fm(eng, dpre), mask=(to_fm(eng, below), 0.01))
     torch.cuda.synchronize()
