@@ -31,15 +31,17 @@ MFMA_PEAK_TFLOPS = 2500.0     # dense fp16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """The oracle (CPU restatement of the reference path, fp32 torch ops) timed on this host's cores on a bounded
-    sample: B=2, LR 32 -> HR 128, forward+backward, repeated until ~the budget; imgs/s scaled to LR 448 by pixels."""
+def cpu_baseline(lr=112, seconds_budget=10.0):
+    """The oracle (CPU restatement of the reference path, fp32 torch ops) timed on this host's cores on a bounded sample of the
+    bench workload: B=1, LR 112 -> HR 448 (BASELINE.md section 2's CPU-runnable size), forward + backward, repeated until ~the
+    budget; imgs/s scaled to LR 448 by the pixel ratio (x16; every term of the path is linear in pixels).  ``--cpu-baseline-lr 32``
+    gives round 1's smaller sample (B=2), which over-states CPU throughput ~5x: its maps are cache-resident."""
     from oracle import csbsr_oracle as O
     from csbsr_amd.utils.detfill import det_state_dict
     from csbsr_amd.modeling.shapes import joint_state_shapes
     from csbsr_amd.data.synthetic import make_batch
-    # intra-op threads: the oracle's convolutions at this sample size stop scaling past ~16 threads (a 256-thread pool on the GPU
-    # box's host took 315 s for one step against ~20 s with 16), so the pool is capped and the count actually used is reported
+    # intra-op threads: the oracle's convolutions stop scaling past ~16 threads (a 256-thread pool on the GPU box's host took 315 s
+    # for one LR-32 step against ~1.3 s with 16), so the pool is capped and the count actually used is reported
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     P = det_state_dict(joint_state_shapes())
@@ -47,8 +49,8 @@ def cpu_baseline(seconds_budget=15.0):
         if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
             v.requires_grad_(True)
     cfg = O.PathCfg()
-    lr = 32
-    x, hr, mask, k = make_batch(2, lr, seed=1)
+    B = 2 if lr <= 32 else 1
+    x, hr, mask, k = make_batch(B, lr, seed=1)
     n, t0 = 0, time.time()
     while True:
         out = O.joint_forward(P, cfg, 40000, x, hr, mask, k, alpha=0.9)
@@ -57,11 +59,11 @@ def cpu_baseline(seconds_budget=15.0):
         if time.time() - t0 > seconds_budget or n >= 40:
             break
     dt = time.time() - t0
-    ips = 2 * n / dt
+    ips = B * n / dt
     scale = (448.0 / lr) ** 2
     return {"value": ips / scale, "unit": "imgs/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fwd+bwd, B=2, LR {lr}->HR {lr * 4}, {n} steps in {dt:.1f}s = {ips:.4f} img/s at LR {lr}; "
-                      f"divided by (448/{lr})^2 = {scale:.0f} (conv work linear in pixels) to quote it at LR 448"}
+            "sample": f"oracle fwd+bwd, B={B}, LR {lr}->HR {lr * 4}, {n} steps in {dt:.1f}s = {ips:.4f} img/s at LR {lr}; "
+                      f"divided by (448/{lr})^2 = {scale:.2f} (conv work linear in pixels) to quote it at LR 448"}
 
 
 def main():
@@ -80,6 +82,7 @@ def main():
                     help="fp16 = north_star's plan (the bench line); split = hi+lo fp16 detector forward (parity mode, cost reported in DESIGN.md)")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the extra (untimed-for-value) leg that re-times the step with the PCIe copy of the batch inside")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-lr", type=int, default=112, help="LR size of the bounded CPU sample (112 = BASELINE.md section 2's size; 32 = round 1's)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dump-layers", default=None, help="write the per-launch conv / wgrad log of the timed region (layer, shape, kernel, ms) as JSON")
     args = ap.parse_args()
@@ -252,7 +255,7 @@ def main():
         if other:
             out["step_roofline"] = None          # the folded-work figures above are config 2's
         if not args.no_cpu_baseline and world == 1 and not other:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_lr)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
