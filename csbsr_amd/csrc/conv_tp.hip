@@ -14,8 +14,8 @@
 //    workgroup synchronisation is the halo reload, once per 64 K steps;
 //  * pixel fragments are ds_read_b128 at (per-phase lane base + compile-time offset): odd 16-byte pixel pitch, no swizzle, 0 bank
 //    conflicts (SQ_LDS_BANK_CONFLICT); one read per MFMA, issued eight MFMAs ahead into the register the MFMA has just consumed;
-//  * D = W x X^T orientation with the couts of a 32-row tile permuted in the pack (cout 16 h + 4 q + j on MFMA row 8 q + 4 h + j): a
-//    lane's 16 accumulator registers are 16 consecutive output channels of one pixel, no cross-lane exchange -- the epilogue (bias, PReLU, residual add / subtract, accumulate, activation-derivative mask) runs in registers with 16-byte loads and
+//  * D = W x X^T orientation with the couts of a 32-row tile permuted in the pack (cout 16 (q/2) + 8 h + 4 (q%2) + j on MFMA row 8 q + 4 h + j): a
+//    lane's accumulator registers are two octets of consecutive output channels of one pixel, no cross-lane exchange -- the epilogue (bias, PReLU, residual add / subtract, accumulate, activation-derivative mask) runs in registers with 16-byte loads and
 //    stores, no LDS staging;
 //  * the epilogue of phase i is software-pipelined under the K loop of phase i + 1 (second accumulator set): two 8-cout x 32-pixel
 //    pieces per K step, their residual / old-output / mask operands loaded one step ahead, their arithmetic cut into chunks that sit
@@ -98,9 +98,9 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   constexpr bool has_res = HAS_RES, has_acc = HAS_ACC, has_mask = HAS_MASK;
   constexpr bool has_bias = !(HAS_ACC || HAS_MASK);       // the accumulate / mask variants are dgrad launches: no bias, no activation
   // a lane's share of every output / residual / mask address (bytes, within one image): its pixel column, cout tile, channel octet
-  const unsigned lane_o = 2u * (unsigned)((s * pix) * (int)p.o_sx + 32 * wid + 16 * hi);
-  const unsigned lane_r = 2u * (unsigned)((s * pix) * (int)p.r_sx + 32 * wid + 16 * hi);
-  const unsigned lane_m = 2u * (unsigned)((s * pix) * (int)p.m_sx + 32 * wid + 16 * hi);
+  const unsigned lane_o = 2u * (unsigned)((s * pix) * (int)p.o_sx + 32 * wid + 8 * hi);
+  const unsigned lane_r = 2u * (unsigned)((s * pix) * (int)p.r_sx + 32 * wid + 8 * hi);
+  const unsigned lane_m = 2u * (unsigned)((s * pix) * (int)p.m_sx + 32 * wid + 8 * hi);
   const unsigned row_o = 2u * (unsigned)(s * (int)p.o_sy), row_r = 2u * (unsigned)(s * (int)p.r_sy), row_m = 2u * (unsigned)(s * (int)p.m_sy);
   char* const sink_l = reinterpret_cast<char*>(sink) + lane * 16;
 
@@ -125,15 +125,16 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   const char* xl = smem + pix * PITCH + hi * 16;          // B fragments: + per-phase pixel base + compile-time (tap, row, channel) offset
 
   // ---- epilogue pieces: piece pi = (row nt = pi / 2, octet pair = pi % 2) of a wave's 32 couts x 8 rows x 32 pixels.  The packed
-  // weights put cout 16 h + 4 q + j on MFMA row 8 q + 4 h + j, so the 16 accumulator registers of a lane ARE 16 consecutive couts,
-  // 32 wid + 16 hi + (0..15), of its pixel (row nt, column pix) -- no cross-lane exchange; a piece is one 16-byte octet of them.  Loads and stores are issued unconditionally (dead lanes read
+  // weights put cout 16 (q / 2) + 8 h + 4 (q % 2) + j on MFMA row 8 q + 4 h + j, so accumulator registers 8 pair .. 8 pair + 7 of a lane
+  // ARE the 8 consecutive couts 32 wid + 16 pair + 8 hi + (0..7) of its pixel (row nt, column pix) -- no cross-lane exchange, and the two
+  // half-waves of one store instruction write one contiguous 32-byte segment per pixel; a piece is one such 16-byte octet.  Loads and stores are issued unconditionally (dead lanes read
   // offset 0 of the image / write the sink): no divergent control flow inside a K step.
   auto piece_loads = [&](const TpCtx& c, int pi, h8& r, h8& o, h8& m) __attribute__((always_inline)) {
     const int nt = pi >> 1, pair = pi & 1;
     const bool lv = pix < c.xlim && nt < c.ylim;
-    if (has_res) { const unsigned off = lane_r + c.tr + nt * row_r + 16 * pair; r = *reinterpret_cast<const h8*>(c.rb + (lv ? off : 0u)); }
-    if (has_acc) { const unsigned off = lane_o + c.to + nt * row_o + 16 * pair; o = *reinterpret_cast<const h8*>(c.ob + (lv ? off : 0u)); }
-    if (has_mask) { const unsigned off = lane_m + c.tm + nt * row_m + 16 * pair; m = *reinterpret_cast<const h8*>(c.mb + (lv ? off : 0u)); }
+    if (has_res) { const unsigned off = lane_r + c.tr + nt * row_r + 32 * pair; r = *reinterpret_cast<const h8*>(c.rb + (lv ? off : 0u)); }
+    if (has_acc) { const unsigned off = lane_o + c.to + nt * row_o + 32 * pair; o = *reinterpret_cast<const h8*>(c.ob + (lv ? off : 0u)); }
+    if (has_mask) { const unsigned off = lane_m + c.tm + nt * row_m + 32 * pair; m = *reinterpret_cast<const h8*>(c.mb + (lv ? off : 0u)); }
   };
   // The piece arithmetic comes in chunks small enough for one MFMA shadow each (a wave is alone on its SIMD and issues in order, so
   // whatever follows an MFMA in program order runs while the matrix pipe works on it):
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     const int nt = pi >> 1, pair = pi & 1;
     if (!has_bias) { v[c] = pa[nt][8 * pair + c] * p.out_scale; v[4 + c] = pa[nt][8 * pair + 4 + c] * p.out_scale; return; }
     if (c == 0) {
-      const int co = 32 * wid + 16 * hi + 8 * pair;
+      const int co = 32 * wid + 16 * pair + 8 * hi;
       bq[0] = *reinterpret_cast<const f4*>(sBias + co); bq[1] = *reinterpret_cast<const f4*>(sBias + co + 4);
     }
     // (output channels >= cout need no masking: their packed weights and LDS biases are zero, and so are the padding channels of
@@ -165,8 +166,8 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     h8 hv;
 #pragma unroll
     for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-    const bool lv = pix < c.xlim && nt < c.ylim && 32 * wid + 16 * hi + 8 * pair < p.coutp && !(p.dbg & 1);
-    const unsigned off = lane_o + c.to + nt * row_o + 16 * pair;
+    const bool lv = pix < c.xlim && nt < c.ylim && 32 * wid + 16 * pair + 8 * hi < p.coutp && !(p.dbg & 1);
+    const unsigned off = lane_o + c.to + nt * row_o + 32 * pair;
     char* dst = lv ? const_cast<char*>(c.ob) + off : sink_l;
     *reinterpret_cast<h8*>(dst) = hv;
   };
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
 }
 
 // ---- weights in K-step order: dst[phase][ks = tap * NKC + kc][mt][kk][lane][e] =
-//        W(cout 32 mt + perm(lane % 32), perm(8 q + 4 h + j) = 16 h + 4 q + j, channel 64 kc + 16 kk + 8 (lane / 32) + e, kh = (py + pad) % s + s jy, kw likewise), tap = 2 jy + jx
+//        W(cout 32 mt + perm(lane % 32), perm(8 q + 4 h + j) = 16 (q / 2) + 8 h + 4 (q % 2) + j, channel 64 kc + 16 kk + 8 (lane / 32) + e, kh = (py + pad) % s + s jy, kw likewise), tap = 2 jy + jx
 // W is indexed [contracted channel][row][kh][kw]: ConvTranspose2d's IOHW parameter, or a Conv2d's OIHW parameter seen from its dgrad
 // (contracted = the conv's output channels, rows = its input channels) -- csbsr_pack_weights kind 2 in this kernel's order.
 struct PackTpK { const float* w; half_t* dst; int D1, KH, KW, stride, pad, nkc, c_real, rows_real, row_off, k_off; };
@@ -334,7 +335,8 @@ __global__ void pack_weights_tp_kernel(const PackTpK p, long total) {
     const int ks = (int)(stage % nks), ph = (int)(stage / nks);
     const int mt = blk >> 2, kk = blk & 3;
     const int m = lane & 31;                                 // MFMA row of the A operand -> the cout it carries (see the epilogue)
-    const int row = 32 * mt + 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
+    const int q_ = m >> 3, h_ = (m >> 2) & 1;
+    const int row = 32 * mt + 16 * (q_ >> 1) + 8 * h_ + 4 * (q_ & 1) + (m & 3);
     const int tap = ks / p.nkc, kc = ks % p.nkc;
     const int c = 64 * kc + 16 * kk + 8 * (lane >> 5) + e;
     const int jy = tap >> 1, jx = tap & 1;
