@@ -32,7 +32,8 @@ class ConvDesc(C.Structure):
                 ("res2", vp), ("r2_sn", i64), ("r2_sy", i64), ("r2_sx", i64),
                 ("accumulate", i32), ("stat_mode", i32), ("stat", vp), ("out_scale", f32),
                 ("o_lo", i64), ("r_lo", i64), ("r2_lo", i64),
-                ("mask", vp), ("m_sn", i64), ("m_sy", i64), ("m_sx", i64), ("mask_slope", f32), ("_pad_mask", i32)]
+                ("mask", vp), ("m_sn", i64), ("m_sy", i64), ("m_sx", i64), ("mask_slope", f32), ("_pad_mask", i32),
+                ("mask_prelu", vp), ("dact_bias", vp), ("dact_prelu", vp)]
 
 
 class WgradDesc(C.Structure):

@@ -48,7 +48,8 @@ struct ConvTpK {
   const float* bias; int act; float slope; const float* prelu; float out_scale;
   int res_mode; const half_t* res; long r_sn, r_sy, r_sx;
   int accumulate;
-  const half_t* mask; long m_sn, m_sy, m_sx; float mask_slope;
+  const half_t* mask; long m_sn, m_sy, m_sx; float mask_slope; const float* mask_prelu;
+  float* part; long part_ld;        // HAS_STAT: per-workgroup partial rows [gridDim.x][part_ld]: bias-gradient sums in [0, coutp), PReLU-slope sum at coutp
   unsigned tiles_x, tiles_y, pg, pgroups;     // phases per work item, items per tile
   int dbg;                          // ablation bit (CSBSR_TP_DBG): 1 stores go to the sink
 };
@@ -65,7 +66,10 @@ struct TpCtx {
   int xlim, ylim;                   // lane live iff pix < xlim; the wave's row nt live iff nt < ylim
 };
 
-template <int NKC, bool HAS_RES, bool HAS_ACC, bool HAS_MASK>
+// HAS_STAT (accumulate + mask launches): also the masking layer's bias / PReLU-slope gradient sums.  Their 17 per-lane accumulators do
+// not fit next to two accumulator sets (256 of the 512 registers are AGPRs, which only MFMA results can live in), so that variant is
+// NOT software-pipelined: one accumulator set, the epilogue of a phase runs right after its K loop.
+template <int NKC, bool HAS_RES, bool HAS_ACC, bool HAS_MASK, bool HAS_STAT>
 __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const half_t* __restrict__ zero_page, half_t* __restrict__ sink) {
   constexpr int SLOTS = NKC * 8 + 1;                    // 16-byte slots per pixel: odd -> consecutive pixels walk all banks
   constexpr int PITCH = SLOTS * 16;
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   constexpr int PPS = 16 / NKS;                         // epilogue pieces (of the previous phase) drained per K step
   constexpr int NFI = (NINST + 3) / 4;
   constexpr int DQ = 256 / SLOTS, DC = 256 % SLOTS;
-  constexpr int WD = 3;                                 // weight stages in flight ahead of the MFMAs (WD + 1 register buffers)
+  constexpr bool PIPE = !HAS_STAT;
+  constexpr int WD = PIPE ? 3 : 1;                      // weight stages in flight ahead of the MFMAs (WD + 1 register buffers)
   static_assert(NKS % (WD + 1) == 0 && PPS == 2, "buffer indices must be compile-time across phases");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sBias = reinterpret_cast<float*>(smem + BOFF);
@@ -93,6 +98,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   if (it >= items) return;
   if (tid < 128) sBias[tid] = (p.bias && tid < p.cout) ? p.bias[tid] : 0.f;
   const float slope = p.act == CSBSR_ACT_PRELU ? *p.prelu : (p.act == CSBSR_ACT_RELU ? 0.f : (p.act == CSBSR_ACT_NONE ? 1.f : p.slope));
+  const float mslope = (HAS_MASK && p.mask_prelu) ? *p.mask_prelu : p.mask_slope;
   const float rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
   // (which operands the epilogue reads is compile-time: a K step is one basic block)
   constexpr bool has_res = HAS_RES, has_acc = HAS_ACC, has_mask = HAS_MASK;
@@ -153,12 +159,22 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     v[4 + c] = t1 > 0.f ? t1 : t1 * slope;
   };
   // store chunk c = 0..3: residual / old output / activation mask on couts c and 4 + c
-  auto store_chunk = [&](int c, float (&v)[8], const h8& r, const h8& o, const h8& m) __attribute__((always_inline)) {
+  // (HAS_STAT: the masking layer's bias gradient = per-channel sum of the masked result, its PReLU-slope gradient = sum over the
+  // pixels with mask <= 0 of (unmasked result) x mask, divided by the slope at the end -- csbsr_epilogue_backward's sums, per lane)
+  float sb[HAS_STAT ? 16 : 1], sp = 0.f;
+#pragma unroll
+  for (int e = 0; e < (HAS_STAT ? 16 : 1); ++e) sb[e] = 0.f;
+  auto store_chunk = [&](int pair, int c, float (&v)[8], const h8& r, const h8& o, const h8& m) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = c; e < 8; e += 4) {
       if (has_res) v[e] += rsign * (float)r[e];
       if (has_acc) v[e] += (float)o[e];
-      if (has_mask) v[e] *= ((float)m[e] > 0.f ? 1.f : p.mask_slope);
+      if (has_mask) {
+        const float mk = (float)m[e];
+        if (HAS_STAT) sp += mk > 0.f ? 0.f : v[e] * mk;
+        v[e] *= (mk > 0.f ? 1.f : mslope);
+        if (HAS_STAT) sb[8 * pair + e] += v[e];
+      }
     }
   };
   auto store_fin = [&](const TpCtx& c, int pi, const float (&v)[8]) __attribute__((always_inline)) {
@@ -191,6 +207,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     for (int d = 0; d < WD; ++d) load_w(w0 + d * stage_elems, wreg[d]);
   }
   h8 bfr[8];                                              // B fragments of the k-slice in flight: pixel row nt, one read per MFMA
+  h8 ql[PIPE ? 1 : 8], qm[PIPE ? 1 : 8];                  // (!PIPE) old-output / mask operands of eight pieces
 
   unsigned pgi = 0, itn = 0;
   int n = 0, Y0 = 0, X0 = 0;
@@ -248,10 +265,16 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     for (int a = 0; a < 8; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    if (!PIPE) {
+      h8 r_;
+#pragma unroll
+      for (int pi = 0; pi < 8; ++pi) piece_loads(cur, pi, r_, ql[pi], qm[pi]);
+    }
 
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       // the next step's pieces: operands on their way one step ahead
+      if (PIPE)
 #pragma unroll
       for (int pp = 0; pp < PPS; ++pp) {
         const int pn_ = (ks + 1) * PPS + pp;
@@ -275,11 +298,12 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
           else if (ks + 1 < NKS) bfr[i] = rdb(xph, ks + 1, 0, i);
           else bfr[i] = rdb(xphn, 0, 0, i);
           // the pending pieces' arithmetic and stores, one chunk per MFMA shadow, spread over the four k-slices
+          if (PIPE)
 #pragma unroll
           for (int pp = 0; pp < PPS; ++pp) {
             const int k_act = 2 * pp, k_st = k_act + 1;
             if (kk == k_act && i < 4) act_chunk(pd, ks * PPS + pp, i, v[pp], bq[pp]);
-            if (kk == k_st && i < 4) store_chunk(i, v[pp], lr[ks & 1][pp], lo[ks & 1][pp], lm[ks & 1][pp]);
+            if (kk == k_st && i < 4) store_chunk((ks * PPS + pp) & 1, i, v[pp], lr[ks & 1][pp], lo[ks & 1][pp], lm[ks & 1][pp]);
             if (kk == k_st && i == 4) store_fin(pend, ks * PPS + pp, v[pp]);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -287,6 +311,22 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
       }
     }
     pend = cur;
+    if (!PIPE) {
+      // one accumulator set: this phase's 16 pieces now.  Pieces 0..7 had their operands requested before the K loop (ql / qm), the
+      // operands of piece i + 8 are requested as piece i retires
+#pragma unroll
+      for (int pi = 0; pi < 16; ++pi) {
+        float v[8];
+        f4 bq[2];
+        h8 r = h8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) act_chunk(acc, pi, c, v, bq);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) store_chunk(pi & 1, c, v, r, ql[pi & 7], qm[pi & 7]);
+        store_fin(cur, pi, v);
+        if (pi < 8) piece_loads(cur, pi + 8, r, ql[pi], qm[pi]);
+      }
+    }
   };
 
   f16v accA[8], accB[8];
@@ -302,12 +342,17 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     const unsigned r_ = tile - n * per_img;
     Y0 = (r_ / p.tiles_x) * TP_TH; X0 = (r_ % p.tiles_x) * TP_TW;
     itn = it + gridDim.x;
-    for (unsigned j = 0; j < p.pg; j += 2) {             // (pg is even: the accumulator sets alternate)
-      phase(accA, accB, j, j == 0);
-      phase(accB, accA, j + 1, false);
+    if (PIPE) {
+      for (unsigned j = 0; j < p.pg; j += 2) {           // (pg is even: the accumulator sets alternate)
+        phase(accA, accB, j, j == 0);
+        phase(accB, accA, j + 1, false);
+      }
+    } else {
+      for (unsigned j = 0; j < p.pg; ++j) phase(accA, accA, j, j == 0);
     }
   }
   // ---- the last phase's accumulators (in accB) drain on their own
+  if (PIPE)
 #pragma unroll
   for (int pi = 0; pi < 16; ++pi) {
     h8 r = h8{0, 0, 0, 0, 0, 0, 0, 0}, o = r, m = r;
@@ -317,8 +362,32 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
 #pragma unroll
     for (int c = 0; c < 4; ++c) act_chunk(accB, pi, c, v, bq);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) store_chunk(c, v, r, o, m);
+    for (int c = 0; c < 4; ++c) store_chunk(pi & 1, c, v, r, o, m);
     store_fin(pend, pi, v);
+  }
+  if (HAS_STAT) {
+    // lanes of one half-wave hold the same couts (32 wid + 16 pair + 8 hi + e at sb[8 pair + e]) for 32 different pixels
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) sb[e] += __shfl_xor(sb[e], o, 64);
+    }
+    sp = wave_sum(sp);
+    float* row = p.part + (size_t)blockIdx.x * p.part_ld;
+    float* sSp = reinterpret_cast<float*>(smem + DOFF);           // (the halo DMA's padding KB is idle by now)
+    __syncthreads();
+    if (tid == 0) sSp[0] = 0.f;
+    __syncthreads();
+    if (pix == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = 32 * wid + 16 * (e >> 3) + 8 * hi + (e & 7);
+        if (co < p.coutp) row[co] = sb[e];
+      }
+    }
+    if (lane == 0) atomicAdd(sSp, sp);
+    __syncthreads();
+    if (tid == 0) row[p.coutp] = sSp[0] / mslope;
   }
 }
 
@@ -387,6 +456,9 @@ extern "C" int32_t csbsr_conv_tp_eligible(const csbsr_conv_desc_t* d) {
   if (d->stat_mode != CSBSR_STAT_NONE) return 0;
   if (d->res_mode != CSBSR_RES_NONE && (d->accumulate || d->mask)) return 0;
   if ((d->accumulate || d->mask) && (d->bias || d->act != CSBSR_ACT_NONE)) return 0;
+  // the fused bias / PReLU-slope sums: accumulate + mask launches over whole tiles (a dead lane would add its garbage to the sums)
+  if ((d->dact_bias || d->dact_prelu) && !(d->accumulate && d->mask && d->H % TP_TH == 0 && d->W % TP_TW == 0)) return 0;
+  if (d->mask_prelu && !d->mask) return 0;
   if (d->res_mode != CSBSR_RES_NONE && d->res_mode != CSBSR_RES_ADD && d->res_mode != CSBSR_RES_SUB) return 0;
   if (d->act == CSBSR_ACT_SIGMOID) return 0;
   // in-image offsets are 32-bit byte offsets
@@ -399,22 +471,31 @@ extern "C" int32_t csbsr_conv_tp_eligible(const csbsr_conv_desc_t* d) {
 
 static half_t* g_tp_zero_page[CSBSR_MAX_DEVICES] = {};      // 256 B of zeros + a 1 KB sink for the dead lanes' stores
 
-template <int NKC, bool R, bool A, bool M>
-static int launch_tp(const ConvTpK& k, hipStream_t st, half_t* zp) {
+template <int NKC, bool R, bool A, bool M, bool S>
+static int launch_tp(ConvTpK& k, hipStream_t st, half_t* zp, float* dbias, float* dprelu) {
   constexpr int SLOTS = NKC * 8 + 1;
   constexpr int NINST = (TP_NPIX * SLOTS + 63) / 64;
   constexpr int SM_BYTES = NINST * 1024 + 128 * 4 + 1024;
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tp_kernel<NKC, R, A, M>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tp_kernel<NKC, R, A, M, S>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
     attr_set = true;
   }
   const unsigned items = k.tiles_x * k.tiles_y * k.N * k.pgroups;
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   const unsigned g = items < (unsigned)ncu ? items : (unsigned)ncu;
-  hipLaunchKernelGGL((conv_tp_kernel<NKC, R, A, M>), dim3(g), dim3(256), SM_BYTES, st, k, zp, zp + 128);
+  if (S) {
+    k.part_ld = k.coutp + 8;
+    k.part = csbsr_red_scratch((long)g * k.part_ld);
+    CSBSR_CHECK(k.part, "conv_tp: the fused activation-gradient sums need the reduction scratch (csbsr_set_reduction_scratch)");
+  }
+  hipLaunchKernelGGL((conv_tp_kernel<NKC, R, A, M, S>), dim3(g), dim3(256), SM_BYTES, st, k, zp, zp + 128);
+  if (S) {
+    if (dbias) csbsr_sum_partials(k.part, (int)g, k.part_ld, k.cout, dbias, st);
+    if (dprelu) csbsr_sum_partials(k.part + k.coutp, (int)g, k.part_ld, 1, dprelu, st);
+  }
   CSBSR_LAUNCH_CHECK("csbsr_conv_tp_forward");
   return 0;
 }
@@ -433,6 +514,7 @@ extern "C" int csbsr_conv_tp_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   k.res_mode = d->res_mode; k.res = reinterpret_cast<const half_t*>(d->res); k.r_sn = d->r_sn; k.r_sy = d->r_sy; k.r_sx = d->r_sx;
   k.accumulate = d->accumulate;
   k.mask = reinterpret_cast<const half_t*>(d->mask); k.m_sn = d->m_sn; k.m_sy = d->m_sy; k.m_sx = d->m_sx; k.mask_slope = d->mask_slope;
+  k.mask_prelu = d->mask_prelu; k.part = nullptr; k.part_ld = 0;
   k.tiles_x = (unsigned)((d->W + TP_TW - 1) / TP_TW); k.tiles_y = (unsigned)((d->H + TP_TH - 1) / TP_TH);
   const unsigned nphase = (unsigned)(d->stride * d->stride);
   k.pg = nphase < TP_MAXPG ? nphase : TP_MAXPG;
@@ -450,11 +532,13 @@ extern "C" int csbsr_conv_tp_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   half_t* zp = g_tp_zero_page[dev];
   const bool r = d->res_mode != CSBSR_RES_NONE, a = d->accumulate != 0, m = d->mask != nullptr;
   // the instantiated epilogues: forward (plain / residual), dgrad (plain / accumulate / mask / accumulate + mask)
-  if (!r && !a && !m) return launch_tp<2, false, false, false>(k, st, zp);
-  if (r && !a && !m) return launch_tp<2, true, false, false>(k, st, zp);
-  if (!r && a && !m) return launch_tp<2, false, true, false>(k, st, zp);
-  if (!r && !a && m) return launch_tp<2, false, false, true>(k, st, zp);
-  if (!r && a && m) return launch_tp<2, false, true, true>(k, st, zp);
+  const bool st_ = d->dact_bias || d->dact_prelu;
+  if (!r && !a && !m) return launch_tp<2, false, false, false, false>(k, st, zp, nullptr, nullptr);
+  if (r && !a && !m) return launch_tp<2, true, false, false, false>(k, st, zp, nullptr, nullptr);
+  if (!r && a && !m) return launch_tp<2, false, true, false, false>(k, st, zp, nullptr, nullptr);
+  if (!r && !a && m) return launch_tp<2, false, false, true, false>(k, st, zp, nullptr, nullptr);
+  if (!r && a && m && !st_) return launch_tp<2, false, true, true, false>(k, st, zp, nullptr, nullptr);
+  if (!r && a && m && st_) return launch_tp<2, false, true, true, true>(k, st, zp, d->dact_bias, d->dact_prelu);
   csbsr_set_error("conv_tp: residual together with accumulate / mask is not instantiated");
   return 1;
 }

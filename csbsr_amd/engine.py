@@ -252,7 +252,7 @@ class Conv:
         return (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
 
     def _launch(self, xs, wt, transposed, k, stride, pad, dil, H, W, OH, OW, cout, out, out32, bias, act, slope, prelu, res, res2,
-                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None, hr=None, tp=None):
+                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None, hr=None, tp=None, dact=None):
         d = L.ConvDesc()
         x0 = xs[0]
         if x0.lo:                       # split-fp16 input: [hi | lo] + hi again, weights from _pack_split
@@ -287,6 +287,22 @@ class Conv:
             assert out is not None and mfm.cp == d.coutp and (mfm.H, mfm.W) == (OH, OW) and not mfm.bcast
             sn, sy, sx = mfm.strides()
             d.mask, d.m_sn, d.m_sy, d.m_sx, d.mask_slope = _ptr(mfm.t), sn, sy, sx, float(mslope)
+        self.last_fused = False
+        use_tp = tp is not None and self.eng.use_tp
+        if dact is not None:
+            # the layer below (a Conv with PReLU / bias) whose activation derivative AND bias / slope gradient sums this launch would
+            # take over from the stand-alone epilogue-backward pass: only the phase-decomposed transposed kernel can (csrc/conv_tp.hip)
+            below, saved = dact
+            fz = getattr(below, "frozen", False)
+            sn, sy, sx = saved.strides()
+            d.mask, d.m_sn, d.m_sy, d.m_sx, d.mask_slope = _ptr(saved.t), sn, sy, sx, float(below.slope)
+            d.mask_prelu = _ptr(below.prelu)
+            d.dact_bias = None if (below.b is None or fz) else _ptr(grad_acc(below.b))
+            d.dact_prelu = None if (below.prelu is None or fz) else _ptr(grad_acc(below.prelu))
+            if use_tp and L.load().csbsr_conv_tp_eligible(C.byref(d)):
+                self.last_fused = True
+            else:
+                d.mask, d.mask_prelu, d.dact_bias, d.dact_prelu = None, None, None, None
         tm = self.eng.timing
         if tm is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -303,7 +319,7 @@ class Conv:
                 self._packed[key] = dst
             d.wt = _ptr(self._packed[key])
             L.call("csbsr_conv_hr_forward", C.byref(d), self.eng.stream)
-        elif tp is not None and self.eng.use_tp and L.load().csbsr_conv_tp_eligible(C.byref(d)):
+        elif use_tp and L.load().csbsr_conv_tp_eligible(C.byref(d)):
             # 2x2-tap transposed layers (8x8 stride 4 / 12x12 stride 8): resident halo tile + streamed fragment-ordered weights (csrc/conv_tp.hip)
             c_real, rows_real, row_off, k_off = tp
             key = ("tp", row_off, k_off)
@@ -348,10 +364,13 @@ class Conv:
                      tp=(self.cin, self.cout, 0, 0) if (self.transposed and len(xs) == 1 and not sp) else None)
         return out
 
-    def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None, mask=None):
+    def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None, mask=None, dact=None):
         """dgrad wrt input segment ``seg``; dpre: gradient wrt the pre-activation output (FM, may be bcast).
         ``mask`` = (saved output FM of the layer that produced this input, its negative slope): the activation derivative of that layer
-        is applied in the epilogue, so what leaves is its dPre (only on the launch that completes the gradient)."""
+        is applied in the epilogue, so what leaves is its dPre (only on the launch that completes the gradient).
+        ``dact`` = (Conv of the layer below, its saved output FM): like ``mask`` but also that layer's bias / PReLU-slope gradient sums,
+        i.e. its whole epilogue-backward pass; taken only where the fused kernel exists -- ``self.last_fused`` tells the caller
+        whether it still has to run that pass."""
         c_seg = self.split[seg]
         row_off = 0 if seg == 0 else self.split[0]
         k, s, p, d = self.k, self.stride, self.pad, self.dil
@@ -386,7 +405,7 @@ class Conv:
         self._launch((dpre, dpre) if hp else (dpre,), wt, tr, k, ps, pp, dd, H, W, OH, OW, c_seg, out, out32, None, L.ACT_NONE, 0.0, None,
                      None, None, L.RES_NONE, accumulate, stat, L.STAT_SAMPLE_SUM if stat is not None else L.STAT_NONE,
                      1.0 / self.WSCALE if hp else 1.0, mask=mask, hr=hr,
-                     tp=(self.cout, c_seg, row_off, 0) if (tr and not hp and stat is None) else None)
+                     tp=(self.cout, c_seg, row_off, 0) if (tr and not hp and stat is None) else None, dact=dact)
         return out
 
     # -- exact folding of a spatially constant second input segment (SFT conv0: cat(features, kernel code), kbpn.py:513)

@@ -300,9 +300,10 @@ class KBPN:
                 del ddd
                 self._act_bwd(st.down1, dl0, q["l0"])
                 self._wg(st.down1, dl0, q["xd"])
-                st.down1.bwd_input(dl0, out=dxd, accumulate=True, in_hw=(H, W))
+                st.down1.bwd_input(dl0, out=dxd, accumulate=True, in_hw=(H, W), dact=(st.down_conv, q["xd"]))
                 del dl0
-                self._act_bwd(st.down_conv, dxd, q["xd"])
+                if not st.down1.last_fused:
+                    self._act_bwd(st.down_conv, dxd, q["xd"])
                 chp = concat_h.slice(0, 128 * s)
                 self._wg(st.down_conv, dxd, chp)
                 st.down_conv.bwd_input(dxd, out=dch.slice(0, 128 * s), accumulate=True)
@@ -352,9 +353,12 @@ class KBPN:
             dxu = e.new(B, h, w, 128)
             self._act_bwd(st.up2, dd_, q["d"], res=q["xu"], res_mode=L.RES_SUB, dres=dxu)
             self._wg(st.up2, dd_, q["h0"])
-            st.up2.bwd_input(dd_, out=dh0, accumulate=True, in_hw=(H, W))
+            # (the dgrad that completes dh0 also applies up1's PReLU derivative and sums its bias / slope gradients where the
+            # phase-decomposed kernel takes the launch: no epilogue-backward pass over the HR map)
+            st.up2.bwd_input(dd_, out=dh0, accumulate=True, in_hw=(H, W), dact=(st.up1, q["h0"]))
             del dd_
-            self._act_bwd(st.up1, dh0, q["h0"])
+            if not st.up2.last_fused:
+                self._act_bwd(st.up1, dh0, q["h0"])
             self._wg(st.up1, dh0, q["xu"])
             st.up1.bwd_input(dh0, out=dxu, accumulate=True, in_hw=(h, w))
             del dh0

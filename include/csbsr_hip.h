@@ -87,6 +87,11 @@ typedef struct {
    * (ReLU: slope 0; LeakyReLU / PReLU: the slope): autograd of F.relu / F.leaky_relu (kbpn.py:236-247) without a pass of its own.
    * Only valid on the launch that completes the gradient (the last accumulating contribution).  NULL = off. */
   const void* mask; int64_t m_sn, m_sy, m_sx; float mask_slope; int32_t _pad_mask;
+  /* csbsr_conv_tp_forward only (NULL elsewhere): the masking layer's PReLU slope on the device (overrides mask_slope), and where its
+   * bias / PReLU-slope gradients go -- dact_bias[c] += sum over pixels of the masked result, dact_prelu[0] += sum over the pixels
+   * with mask <= 0 of (unmasked result) x mask / slope, i.e. exactly what csbsr_epilogue_backward adds for that layer
+   * (kbpn.py:230-262: the PReLU of a DeconvBlock / ConvBlock whose input gradient this launch completes) */
+  const float* mask_prelu; float* dact_bias; float* dact_prelu;
 } csbsr_conv_desc_t;
 
 int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);

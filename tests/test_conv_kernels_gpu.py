@@ -307,3 +307,58 @@ def test_phase_decomposed_strided_dgrad(cin, cout, H, W, acc, masked):
         outs.append(from_fm(out))
         assert relmax(outs[-1], ref) < 2e-3
     assert relmax(outs[0], outs[1]) < 1e-3
+
+
+@pytest.mark.parametrize("H,W,frozen", [(16, 32, False), (8, 64, False), (16, 32, True), (12, 32, False)])
+def test_phase_decomposed_dgrad_takes_over_the_epilogue_backward(H, W, frozen):
+    """The dgrad of an 8x8 stride-4 conv that completes a gradient (accumulate) and is handed the layer below (``dact``): csrc/conv_tp.hip
+    applies that layer's PReLU derivative from its saved output and adds its bias / PReLU-slope gradient sums -- everything
+    csbsr_epilogue_backward would do in a pass of its own -- against torch autograd of  conv2d(prelu(z + b, a)) ; (12, 32) is not
+    whole tiles: the launch must decline (``last_fused`` False) and leave the gradient unmasked for the stand-alone pass."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv, grad_acc
+    torch.manual_seed(H * W + int(frozen))
+    eng = _eng()
+    lib = L.load()
+    N, C, k, s, p = 2, 128, 8, 4, 2
+    IH, IW = s * H, s * W
+    w = (torch.randn(C, C, k, k) / (C * 4) ** 0.5).half().float()
+    conv = Conv(eng, "l", {"l.weight": w.cuda()}, k, s, p, 1, bias=False, act=L.ACT_NONE)
+    a0, b0 = torch.tensor([0.25]), (torch.randn(C) * 0.1)
+    pb = {"b.weight": torch.zeros(C, C, k, k).cuda(), "b.bias": b0.clone().cuda(), "a": a0.clone().cuda()}
+    below = Conv(eng, "b", pb, k, s, p, 1, transposed=True, bias=True, act=L.ACT_PRELU, prelu="a")
+    below.frozen = frozen
+    z = torch.randn(N, C, IH, IW, requires_grad=True)
+    b = b0.clone().requires_grad_(True)
+    a = a0.clone().requires_grad_(True)
+    y = F.prelu(z + b[None, :, None, None], a)
+    y16 = y.detach().half().float()                      # the saved output as the kernels see it
+    dpre = torch.randn(N, C, H, W).half().float()
+    old = torch.randn(N, C, IH, IW).half().float()
+    # reference on the fp16-rounded saved output (the mask / slope sums read that)
+    yr = y16.clone().requires_grad_(True)
+    (F.conv2d(yr, w, None, s, p) * dpre).sum().backward()
+    dy = yr.grad + old
+    neg = ~(y16 > 0)
+    ref_dz = torch.where(neg, dy * a0, dy)
+    ref_db = ref_dz.sum((0, 2, 3))
+    ref_da = (dy * (y16 / a0))[neg].sum()
+    lib.csbsr_debug_set_conv_tp(2)
+    try:
+        out = to_fm(eng, old)
+        conv.bwd_input(to_fm(eng, dpre), out=out, accumulate=True, in_hw=(IH, IW), dact=(below, to_fm(eng, y16)))
+        torch.cuda.synchronize()
+    finally:
+        lib.csbsr_debug_set_conv_tp(1)
+    whole = H % 8 == 0 and W % 32 == 0
+    assert conv.last_fused == whole
+    if not whole:
+        assert relmax(from_fm(out), dy) < 2e-3              # plain dgrad + old: the caller runs the epilogue-backward pass itself
+        return
+    assert lib.csbsr_debug_last_conv_kernel() == 9
+    assert relmax(from_fm(out), ref_dz) < 2e-3
+    if frozen:
+        assert getattr(pb["b.bias"], "gacc", None) is None and getattr(pb["a"], "gacc", None) is None
+    else:
+        assert relmax(grad_acc(pb["b.bias"]).cpu(), ref_db) < 2e-3
+        assert abs(float(grad_acc(pb["a"]).cpu()) - float(ref_da)) < 2e-3 * float((dy * (y16 / a0))[neg].abs().sum()) ** 0.5 + 2e-3 * abs(float(ref_da))

@@ -335,3 +335,44 @@ def test_joint_model_inference_matches_oracle(case):
     assert e < SEG_BOUND[oc.detector][0]
     if oc.detector != "HRNet_OCR":             # (random-weight HRNet-OCR: most probabilities sit within 1e-2 of the 0.5 threshold)
         assert iou > SEG_BOUND[oc.detector][3]
+
+
+@pytest.mark.parametrize("it", [1, 20001])
+def test_specialised_kernel_paths_agree_with_the_general_kernels(it):
+    """csrc/conv_tp.hip only takes large launches by default: here the phase-decomposed transposed convs, incl. the dgrads that take
+    over up_conv1's / down.conv's epilogue-backward pass, are forced onto a whole training step at LR 32x32 (whole 8x32 tiles),
+    against the same step through the general implicit-GEMM kernels + stand-alone epilogue-backward passes: same model, same
+    batch, every output and every KBPN gradient tensor, in the two SR-loss-driven phases (in the joint phase the random-weight
+    detector at this size turns run-to-run summation-order noise into O(1) gradient differences, whichever kernels run)."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.data.synthetic import make_batch
+    g = load_golden("e2e_pspnet_it40000")
+    lib = L.load()
+    x, hr, mask, k = make_batch(2, 32, seed=5)
+    res = []
+    for mode in (2, 0):
+        lib.csbsr_debug_set_conv_tp(mode)
+        try:
+            m, cfg = build_model(g)
+            seg_l, sr_l, seg, sr, kp = m(it, x, sr_targets=hr, segment_targets=mask, kernel_targets=k)
+            sr_l.mean().backward()
+            torch.cuda.synchronize()
+            fused = [s_.up2.last_fused for s_ in m._runtime()["kbpn"].stages]
+        finally:
+            lib.csbsr_debug_set_conv_tp(1)
+        assert all(fused) == (mode == 2)
+        grads = {n: v.grad.detach().cpu() for n, v in m._named_full() if isinstance(v, torch.nn.Parameter) and v.grad is not None}
+        res.append((sr.cpu(), kp.cpu(), sr_l.detach().cpu(), grads))
+    (sr_a, kp_a, l_a, g_a), (sr_b, kp_b, l_b, g_b) = res
+    assert max_rel_to_scale(sr_a, sr_b) < 5e-4 and max_rel_to_scale(kp_a, kp_b) < 5e-4 and max_rel_to_scale(l_a, l_b) < 5e-4
+    assert g_a.keys() == g_b.keys()
+    errs = {n: float((g_a[n] - g_b[n]).norm() / (g_b[n].norm() + 1e-30)) for n in g_a if n.startswith("sr_model") and g_b[n].numel() > 1}
+    worst = max(errs, key=errs.get)
+    print(f"it {it}: {len(errs)} KBPN gradient tensors, fused vs general kernels: median {np.median(list(errs.values())):.2e} worst {errs[worst]:.2e} ({worst})")
+    # the two paths differ by the fp16 rounding of one intermediate per fused pass (measured: median 6.7e-4, worst 1.1e-3)
+    assert errs[worst] < 5e-3 and np.median(list(errs.values())) < 2e-3
+    # PReLU slopes (scalars; those of up_conv1 / down.conv now come out of the dgrad epilogue): signed sums with heavy cancellation --
+    # the reference's own fp32 evaluation orders differ by ~10 % on them (tests/test_oracle_golden.py) -- so 15 % like everywhere else
+    for n in g_a:
+        if n.startswith("sr_model") and g_b[n].numel() == 1:
+            assert abs(float(g_a[n]) - float(g_b[n])) < 0.15 * abs(float(g_b[n])) + 1e-6 * float(l_b.abs().max()), n
