@@ -71,6 +71,10 @@ SIGNATURES = {
     "csbsr_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp]),
     "csbsr_conv_hr_eligible": (i32, [C.POINTER(ConvDesc)]),
     "csbsr_conv_hr_forward": (i32, [C.POINTER(ConvDesc), vp]),
+    "csbsr_conv_x3_eligible": (i32, [C.POINTER(ConvDesc)]),
+    "csbsr_conv_x3_forward": (i32, [C.POINTER(ConvDesc), vp]),
+    "csbsr_packed_weight_elems_x3": (i64, [i32, i32]),
+    "csbsr_pack_weights_x3": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "csbsr_conv_tp_eligible": (i32, [C.POINTER(ConvDesc)]),
     "csbsr_conv_tp_forward": (i32, [C.POINTER(ConvDesc), vp]),
     "csbsr_packed_weight_elems_tp": (i64, [i32, i32]),
@@ -137,6 +141,7 @@ DEBUG_SIGNATURES = {
     "csbsr_debug_set_wgrad_tr": (None, [i32]),
     "csbsr_debug_set_conv_glds": (None, [i32]),
     "csbsr_debug_set_conv_tp": (None, [i32]),
+    "csbsr_debug_set_conv_x3": (None, [i32]),
     "csbsr_debug_last_conv_kernel": (i32, []),
     "csbsr_debug_last_wgrad_kernel": (i32, []),
 }
@@ -164,6 +169,8 @@ def load():
     _lib = lib
     if os.environ.get("CSBSR_WGRAD_DBG"):          # A/B hook: bit0 transpose reads, 2 no thin, 4 no tap order, 8 no flat grid, 16 flat everywhere
         lib.csbsr_debug_set_wgrad_tr(int(os.environ["CSBSR_WGRAD_DBG"]))
+    if os.environ.get("CSBSR_CONV_X3"):            # A/B hook: 0 off, 1 default, 2 every eligible launch
+        lib.csbsr_debug_set_conv_x3(int(os.environ["CSBSR_CONV_X3"]))
     if os.environ.get("CSBSR_CONV_TP"):            # A/B hook: 0 off, 1 default, 2 every eligible launch
         lib.csbsr_debug_set_conv_tp(int(os.environ["CSBSR_CONV_TP"]))
     if os.environ.get("CSBSR_CONV_GLDS"):          # A/B hook for kernel selection experiments

@@ -417,7 +417,8 @@ static int launch_conv(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   return 0;
 }
 
-extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) {
+// descriptor -> kernel-argument block (validation included); shared with csrc/conv_x3.hip
+int conv_desc_to_k(const csbsr_conv_desc_t* d, ConvK& k) {
   CSBSR_CHECK(d && d->in[0].ptr && d->wt, "conv: null pointer");
   CSBSR_CHECK(d->in[0].c > 0 && d->in[0].c % 8 == 0 && d->in[1].c % 8 == 0, "conv: segment channels must be multiples of 8");
   CSBSR_CHECK(d->coutp % 8 == 0 && d->cout <= d->coutp && d->cout > 0, "conv: bad cout/coutp");
@@ -427,7 +428,6 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   CSBSR_CHECK(!d->cbias || (!d->transposed && d->stride == 1), "conv: border-class bias needs a stride-1 convolution");
   CSBSR_CHECK(d->act != CSBSR_ACT_PRELU || d->prelu, "conv: PReLU needs a slope pointer");
   CSBSR_CHECK(d->res_mode == CSBSR_RES_NONE || d->res, "conv: res_mode set without res");
-  ConvK k;
   k.in[0] = d->in[0]; k.in[1] = d->in[1];
   if (k.in[1].c == 0) k.in[1] = k.in[0];
   k.N = d->N; k.H = d->H; k.W = d->W; k.OH = d->OH; k.OW = d->OW;
@@ -457,6 +457,12 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   CSBSR_CHECK(!d->o_lo || d->out16, "conv: o_lo without out16");
   k.tile2d = 0; k.nphase_flat = 0; k.tap_group = 0;
   CSBSR_CHECK(d->stat_mode == CSBSR_STAT_NONE || d->stat, "conv: stat_mode set without stat buffer");
+  return 0;
+}
+
+extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) {
+  ConvK k;
+  if (int rc = conv_desc_to_k(d, k)) return rc;
   int nphase = 1;
   long maxM;
   if (d->transposed) {

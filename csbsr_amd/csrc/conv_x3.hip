@@ -1,0 +1,284 @@
+// 3x3 stride-1 convolution for the wide LOW-resolution layers -- the SFT scale / shift convolutions (kbpn.py:505-520: 128 s -> 128 s + 441
+// and back, i.e. 384 -> 825 -> 384 at stage 3) and their dgrads, 22 % of the training step -- built like csrc/conv_tp.hip instead of
+// as an implicit GEMM through an LDS ring:
+//
+//  * one persistent workgroup per CU (4 waves, one per SIMD) computes an 8 x 32 pixel x 128 cout tile; a wave owns 64 couts x 4 rows x 32
+//    pixels (2 x 4 MFMA tiles, 128 accumulator registers);
+//  * the pixel operand is staged per 64-channel chunk: the chunk's (8+2) x (32+2) halo goes HBM/L2 -> LDS with
+//    global_load_lds_dwordx4 (zero page outside the image) into one of two 48 KB buffers while the previous chunk's nine taps are
+//    being multiplied -- every tap reads the same LDS tile at a different offset, so the input crosses the fabric 1.3 times per cout
+//    tile instead of 9;
+//  * the weight operand never touches LDS: packed in MFMA-fragment order (csbsr_pack_weights_x3, couts permuted so that a lane's
+//    accumulators are consecutive channels), 8 KB per wave and K step straight from L2 into registers, two steps ahead; work is
+//    ordered cout-tile-major so the 128-cout weight slice everybody streams (0.9 MB for 384 input channels) stays L2-resident;
+//  * synchronisation: one barrier per CHUNK (nine K steps), none per step; one counted s_waitcnt per chunk for the halo DMA;
+//  * epilogue: the general fused row of conv_common.h (bias, per-border-class bias of the folded constant segment, activations,
+//    residual add / sub / mul / fma, accumulate, activation mask) straight from registers, once per 54-117 K steps.
+#include "common.h"
+#include "conv_common.h"
+#include "csbsr_debug.h"
+#include <cstdlib>
+
+#define X3_TH 8
+#define X3_TW 32
+#define X3_HW (X3_TW + 2)
+#define X3_HH (X3_TH + 2)
+#define X3_NPIX (X3_HH * X3_HW)           // 340 halo pixels
+#define X3_SLOTS 9                        // 64 channels = 8 sixteen-byte slots + 1 pad slot: odd pitch, conflict-free rows of pixels
+#define X3_PITCH (X3_SLOTS * 16)
+#define X3_NINST ((X3_NPIX * X3_SLOTS + 63) / 64)       // 48 wave instructions fill one chunk buffer
+#define X3_BUF (X3_NINST * 1024)
+#define X3_WSTEP 16384                    // bytes of one K step's weights for the 128-cout tile: [wave mt][k-slice kk][lane][8]
+
+struct X3Extra {
+  unsigned tiles_x, tiles_y, nct, nch;   // pixel tiles, 128-cout tiles, 64-channel chunks
+  int dbg;                               // ablation (CSBSR_X3_DBG): 1 every K step loads the SAME weights (are the weight loads the stall?)
+};
+
+__global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Extra q, const half_t* __restrict__ zero_page) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pix = lane & 31, hi = lane >> 5;
+  const half_t* zp = zero_page + (lane & 7) * 8;
+  const unsigned per_img = q.tiles_x * q.tiles_y, ntiles = per_img * (unsigned)p.N, items = ntiles * q.nct;
+  unsigned it = blockIdx.x;
+  if (it >= items) return;
+  const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
+  const half_t* in0 = reinterpret_cast<const half_t*>(p.in[0].ptr);
+  const int isy = (int)p.in[0].sy, isx = (int)p.in[0].sx;
+
+  // halo DMA roles (same for every tile and chunk): chunk-slot g = (wid + 4 i) * 64 + lane = (halo pixel, slot)
+  int f_ty0, f_tx0, f_c0;
+  {
+    const int g = wid * 64 + lane;
+    const int hq = g / X3_SLOTS;
+    f_c0 = g - hq * X3_SLOTS;
+    f_ty0 = hq / X3_HW;
+    f_tx0 = hq - f_ty0 * X3_HW;
+  }
+  constexpr int NFI = X3_NINST / 4;                  // 12 instructions per wave (48 = 4 x 12 exactly)
+  constexpr int DQ = 256 / X3_SLOTS, DC = 256 % X3_SLOTS;
+  auto issue_x = [&](int n, int Y0, int X0, int chunk, int buf) {
+    const half_t* tbase = in0 + n * p.in[0].sn + (long)(Y0 - 1) * p.in[0].sy + (long)(X0 - 1) * p.in[0].sx + chunk * 64;
+    int ty = f_ty0, tx = f_tx0, c = f_c0;
+#pragma unroll 2
+    for (int i = 0; i < NFI; ++i) {
+      const int inst = wid + 4 * i;
+      const int iy = Y0 - 1 + ty, ix = X0 - 1 + tx;
+      const bool ok = ty < X3_HH && c < 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const half_t* src = ok ? tbase + (ty * isy + tx * isx + c * 8) : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + buf * X3_BUF + inst * 1024), 16, 0, 0);
+      c += DC; tx += DQ;
+      if (c >= X3_SLOTS) { c -= X3_SLOTS; ++tx; }
+      if (tx >= X3_HW) { tx -= X3_HW; ++ty; }
+      if (tx >= X3_HW) { tx -= X3_HW; ++ty; }
+    }
+  };
+  auto decode = [&](unsigned item, int& ct, int& n, int& Y0, int& X0) {
+    ct = item / ntiles;                                  // cout-tile-major: everybody streams the same weight slice
+    const unsigned tile = item - ct * ntiles;
+    n = tile / per_img;
+    const unsigned r_ = tile - n * per_img;
+    Y0 = (r_ / q.tiles_x) * X3_TH; X0 = (r_ % q.tiles_x) * X3_TW;
+  };
+  // a wave's weights of K step (ct, chunk, tap): 4 fragment-ordered KB, one 16-byte load per lane each
+  // (a wave = 64 couts x 4 rows x 32 pixels: two A fragments per k-slice from L2, four B fragments from LDS for eight MFMAs -- half the
+  // LDS reads per MFMA of a 32-cout x 256-pixel wave, which ran LDS-bound: one ds_read_b128 per MFMA per wave is 128 B/clk per CU)
+  const int mh = wid & 1, rq = wid >> 1;
+  const unsigned wlane = (unsigned)(mh * 8192 + lane * 16);
+  auto load_w = [&](int ct, int step, h8 (&w)[2][4]) __attribute__((always_inline)) {
+    const char* b = reinterpret_cast<const char*>(p.wt) + ((q.dbg & 1) ? (size_t)0 : ((size_t)ct * q.nch * 9 + step) * X3_WSTEP);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) w[mt][kk] = *reinterpret_cast<const h8*>(b + (wlane + mt * 4096 + kk * 1024));
+  };
+  const char* xl = smem + ((4 * rq) * X3_HW + pix) * X3_PITCH + hi * 16;      // the wave's first row of the halo tile
+
+  int ct, n, Y0, X0;
+  decode(it, ct, n, Y0, X0);
+  issue_x(n, Y0, X0, 0, 0);
+  h8 wreg[3][2][4];                                       // K step g = chunk * 9 + tap lives in wreg[tap % 3] (9 % 3 == 0)
+  load_w(ct, 0, wreg[0]);
+  load_w(ct, 1, wreg[1]);
+  const int nsteps = (int)q.nch * 9;
+
+  for (; it < items; it += gridDim.x) {
+    const unsigned itn = it + gridDim.x;
+    int ctn = ct, nn = n, Y0n = Y0, X0n = X0;
+    if (itn < items) decode(itn, ctn, nn, Y0n, X0n);
+    const unsigned par = ((it - blockIdx.x) / gridDim.x) * q.nch;     // chunk c of this tile lives in buffer (par + c) & 1
+    f16v acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int c = 0; c < (int)q.nch; ++c) {
+      // chunk c's halo has landed everywhere, and every wave is done with the other buffer (chunk c - 1): refill that one.  The only
+      // vector-memory instructions issued after this chunk's DMA (a whole chunk ago) and possibly still in flight are the weight
+      // loads of the next two K steps (16) -- except right after an epilogue, where the count is simply drained.
+      if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int bnext = (int)((par + c + 1) & 1);
+      if (c + 1 < (int)q.nch) issue_x(n, Y0, X0, c + 1, bnext);
+      else if (itn < items) issue_x(nn, Y0n, X0n, 0, bnext);             // the next tile's first chunk
+      else issue_x(n, Y0, X0, 0, bnext);                                // keep the instruction count uniform (harmless refetch)
+      asm volatile("" ::: "memory");
+      const char* xb = xl + ((par + c) & 1) * X3_BUF;
+      h8 bfr[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bfr[nt] = *reinterpret_cast<const h8*>(xb + (nt * X3_HW) * X3_PITCH);      // tap (0,0), k-slice 0
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        // weights two K steps ahead (past the tile's last step: the next tile's first ones)
+        {
+          const int g = c * 9 + tap + 2;
+          if (g < nsteps) load_w(ct, g, wreg[(tap + 2) % 3]);
+          else load_w(ctn, g - nsteps, wreg[(tap + 2) % 3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap % 3][0][kk], bfr[i], acc[0][i], 0, 0, 0);
+            acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap % 3][1][kk], bfr[i], acc[1][i], 0, 0, 0);
+            // the same row's fragment of the next k-slice / next tap (the next chunk starts over after its barrier)
+            if (kk < 3) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + ky) * X3_HW + kx) * X3_PITCH + (kk + 1) * 32);
+            else if (tap < 8) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + (tap + 1) / 3) * X3_HW + (tap + 1) % 3) * X3_PITCH);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: acc[mt][nt][8 pair + e] = cout 128 ct + 64 mh + 32 mt + 16 pair + 8 hi + e of pixel (row 4 rq + nt, column pix)
+    const int ox = X0 + pix;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int oy = Y0 + 4 * rq + nt;
+#pragma unroll
+      for (int mp = 0; mp < 4; ++mp) {
+        const int mt = mp >> 1, pair = mp & 1;
+        const int co = 128 * ct + 64 * mh + 32 * mt + 16 * pair + 8 * hi;
+        if (oy >= p.OH || ox >= p.OW || co >= p.coutp) continue;
+        float v[8], bias[8], s0[8], s1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = acc[mt][nt][8 * pair + e];
+          bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f;
+        }
+        int cur_n = -1;
+        conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, true, cur_n, s0, s1);
+      }
+    }
+    ct = ctn; n = nn; Y0 = Y0n; X0 = X0n;
+  }
+}
+
+// ---- weights in K-step order: dst[ct][chunk][tap][mt][kk][lane][e] = W(row 128 ct + 32 mt + perm(lane % 32), channel 64 chunk + 16 kk
+// + 8 (lane / 32) + e, tap), perm(8 q + 4 h + j) = 16 (q / 2) + 8 h + 4 (q % 2) + j (a lane's accumulator registers 8 pair .. 8 pair + 7
+// are then consecutive channels).  kind 0: forward, W is OIHW [row][channel][ky][kx]; kind 1: dgrad of the stride-1 conv: rows are the
+// conv's input channels, contracted channels its outputs, taps flipped (W[channel][row][2 - ky][2 - kx]).
+struct PackX3K { const float* w; half_t* dst; int kind, D1, nch, nct, c_real, rows_real, row_off, k_off; };
+__global__ void pack_weights_x3_kernel(const PackX3K p, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), blk = (int)((i >> 9) & 15);
+    const long stage = i >> 13;
+    const int tap = (int)(stage % 9);
+    const long t2 = stage / 9;
+    const int chunk = (int)(t2 % p.nch), ct = (int)(t2 / p.nch);
+    const int mt = blk >> 2, kk = blk & 3;
+    const int m = lane & 31, q_ = m >> 3, h_ = (m >> 2) & 1;
+    const int row = 128 * ct + 32 * mt + 16 * (q_ >> 1) + 8 * h_ + 4 * (q_ & 1) + (m & 3);
+    const int c = 64 * chunk + 16 * kk + 8 * (lane >> 5) + e;
+    const int ky = tap / 3, kx = tap % 3;
+    float v = 0.f;
+    if (row < p.rows_real && c < p.c_real) {
+      const int rr = p.row_off + row, cc = p.k_off + c;
+      if (p.kind == 0) v = p.w[(((long)rr * p.D1 + cc) * 3 + ky) * 3 + kx];
+      else v = p.w[(((long)cc * p.D1 + rr) * 3 + (2 - ky)) * 3 + (2 - kx)];
+    }
+    p.dst[i] = (half_t)v;
+  }
+}
+
+extern "C" int64_t csbsr_packed_weight_elems_x3(int32_t c_real, int32_t rows_real) {
+  const int nch = (round_up(c_real, 8) + 63) / 64, nct = (round_up(rows_real, 8) + 127) / 128;
+  return (int64_t)nct * nch * 9 * (X3_WSTEP / 2);
+}
+
+extern "C" int csbsr_pack_weights_x3(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
+                                     int32_t row_off, int32_t k_off, csbsr_stream_t s) {
+  CSBSR_CHECK(w && dst && (kind == 0 || kind == 1), "pack_x3: bad args");
+  const int kdim = kind == 0 ? D1 : D0, rdim = kind == 0 ? D0 : D1;
+  CSBSR_CHECK(c_real >= 1 && rows_real >= 1 && k_off >= 0 && k_off + c_real <= kdim && row_off >= 0 && row_off + rows_real <= rdim,
+              "pack_x3: range out of bounds");
+  PackX3K p;
+  p.w = w; p.dst = reinterpret_cast<half_t*>(dst); p.kind = kind; p.D1 = D1;
+  p.nch = (round_up(c_real, 8) + 63) / 64; p.nct = (round_up(rows_real, 8) + 127) / 128;
+  p.c_real = c_real; p.rows_real = rows_real; p.row_off = row_off; p.k_off = k_off;
+  const long total = csbsr_packed_weight_elems_x3(c_real, rows_real);
+  const long nb = (total + 255) / 256;
+  hipLaunchKernelGGL(pack_weights_x3_kernel, dim3((int)(nb > 8192 ? 8192 : nb)), dim3(256), 0, reinterpret_cast<hipStream_t>(s), p, total);
+  CSBSR_LAUNCH_CHECK("csbsr_pack_weights_x3");
+  return 0;
+}
+
+static int g_conv_x3_mode = 1;      // 0 off, 1 launches that fill the chip, 2 every eligible launch (tests)
+extern "C" void csbsr_debug_set_conv_x3(int mode) { g_conv_x3_mode = mode; }
+
+// Which launches take this kernel: 3x3, stride 1, pad 1, dilation 1, ONE plain-fp16 input segment whose padded channels are a multiple
+// of 64 (>= 512 by default -- measured at N = 4, 448^2: 825 -> 384 875 -> 939 TF/s, its dgrad-shaped twin 921 -> 984, 569 -> 128
+// 693 -> 738, but 384 -> 825 800 -> 714 and 256 -> 697 817 -> 578: with few chunks the per-tile epilogue and pipeline restart outweigh
+// the K loop's gain; >= 128 when forced by csbsr_debug_set_conv_x3(2)), >= 72 padded output channels, fp16 output; any fused epilogue of the general kernels except statistics, the fp32 side
+// output and split (hi + lo) operands.
+extern "C" int32_t csbsr_conv_x3_eligible(const csbsr_conv_desc_t* d) {
+  if (!d || !g_conv_x3_mode || d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->dil != 1) return 0;
+  if (d->in[1].c != 0 || d->in[0].sx == 0 || d->in[0].c < (g_conv_x3_mode == 2 ? 128 : 512) || d->in[0].c % 64 != 0) return 0;
+  if (d->coutp < 72 || !d->out16 || d->out32 || d->o_lo || d->r_lo || d->r2_lo) return 0;
+  if (d->stat_mode != CSBSR_STAT_NONE || d->OH != d->H || d->OW != d->W) return 0;
+  if (d->mask_prelu || d->dact_bias || d->dact_prelu) return 0;
+  if (d->in[0].sy >= (1l << 31) / 2) return 0;
+  if (g_conv_x3_mode == 1 && (long)d->N * d->H * d->W * ((d->coutp + 127) / 128) < 512L * X3_TH * X3_TW) return 0;
+  return 1;
+}
+
+static half_t* g_x3_zero_page[CSBSR_MAX_DEVICES] = {};
+
+extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) {
+  CSBSR_CHECK(csbsr_conv_x3_eligible(d), "conv_x3: launch not eligible (see csbsr_conv_x3_eligible)");
+  ConvK k;
+  if (int rc = conv_desc_to_k(d, k)) return rc;
+  X3Extra q;
+  q.tiles_x = (unsigned)((d->W + X3_TW - 1) / X3_TW); q.tiles_y = (unsigned)((d->H + X3_TH - 1) / X3_TH);
+  q.nct = (unsigned)((d->coutp + 127) / 128); q.nch = (unsigned)(d->in[0].c / 64);
+  { const char* e = getenv("CSBSR_X3_DBG"); q.dbg = e ? atoi(e) : 0; }
+  int dev = 0, ncu = 256;
+  CSBSR_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CSBSR_MAX_DEVICES, "conv_x3: no current device");
+  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (!g_x3_zero_page[dev]) {
+    CSBSR_CHECK(hipMalloc(reinterpret_cast<void**>(&g_x3_zero_page[dev]), 256) == hipSuccess, "conv_x3: zero page alloc failed");
+    (void)hipMemset(g_x3_zero_page[dev], 0, 256);
+  }
+  constexpr int SM_BYTES = 2 * X3_BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
+    attr_set = true;
+  }
+  const unsigned items = q.tiles_x * q.tiles_y * (unsigned)d->N * q.nct;
+  const unsigned g = items < (unsigned)ncu ? items : (unsigned)ncu;
+  g_last_conv_kernel = CONVK_X3;
+  hipLaunchKernelGGL(conv_x3_kernel, dim3(g), dim3(256), SM_BYTES, reinterpret_cast<hipStream_t>(s), k, q, g_x3_zero_page[dev]);
+  CSBSR_LAUNCH_CHECK("csbsr_conv_x3_forward");
+  return 0;
+}

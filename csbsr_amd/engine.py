@@ -113,6 +113,7 @@ class Engine:
         self._red = _reduction_scratch(self.device) if torch.cuda.is_available() else None
         self.training = True
         self.use_hr = os.environ.get("CSBSR_CONV_HR", "1") != "0"       # A/B hook: 0 routes the HR small-channel layers through the implicit-GEMM kernels
+        self.use_x3 = os.environ.get("CSBSR_CONV_X3", "1") != "0"       # A/B hook: 0 routes the wide 3x3 layers through the implicit-GEMM kernels
         self.use_tp = os.environ.get("CSBSR_CONV_TP", "1") != "0"       # A/B hook: 0 routes the 2x2-tap transposed layers through the implicit-GEMM kernels
         self.timing = None              # list of (kind, flops, bytes, start_event, end_event) when profiling is on
 
@@ -252,7 +253,7 @@ class Conv:
         return (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
 
     def _launch(self, xs, wt, transposed, k, stride, pad, dil, H, W, OH, OW, cout, out, out32, bias, act, slope, prelu, res, res2,
-                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None, hr=None, tp=None, dact=None):
+                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None, hr=None, tp=None, dact=None, x3=None):
         d = L.ConvDesc()
         x0 = xs[0]
         if x0.lo:                       # split-fp16 input: [hi | lo] + hi again, weights from _pack_split
@@ -319,6 +320,18 @@ class Conv:
                 self._packed[key] = dst
             d.wt = _ptr(self._packed[key])
             L.call("csbsr_conv_hr_forward", C.byref(d), self.eng.stream)
+        elif x3 is not None and self.eng.use_x3 and L.load().csbsr_conv_x3_eligible(C.byref(d)):
+            # wide low-resolution 3x3 layers (SFT convs and their dgrads): per-chunk halo tile + fragment-ordered weights from L2 (csrc/conv_x3.hip)
+            kind, c_real, rows_real, row_off, k_off = x3
+            key = ("x3", kind, row_off, k_off, c_real)
+            if key not in self._packed:
+                n = L.load().csbsr_packed_weight_elems_x3(c_real, rows_real)
+                dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
+                L.call("csbsr_pack_weights_x3", _ptr(self.w), _ptr(dst), kind, self.w.shape[0], self.w.shape[1], c_real, rows_real, row_off,
+                       k_off, self.eng.stream)
+                self._packed[key] = dst
+            d.wt = _ptr(self._packed[key])
+            L.call("csbsr_conv_x3_forward", C.byref(d), self.eng.stream)
         elif use_tp and L.load().csbsr_conv_tp_eligible(C.byref(d)):
             # 2x2-tap transposed layers (8x8 stride 4 / 12x12 stride 8): resident halo tile + streamed fragment-ordered weights (csrc/conv_tp.hip)
             c_real, rows_real, row_off, k_off = tp
@@ -361,7 +374,8 @@ class Conv:
         hr = (0, self.cin, self.cout, 0) if (not sp and not self.transposed and self.k in (1, 3) and len(xs) == 1 and self.prelu is None) else None
         self._launch(xs, wt, self.transposed, self.k, self.stride, self.pad, self.dil, H, W, OH, OW, self.cout, out, out32, self.b,
                      self.act, self.slope, self.prelu, res, res2, res_mode, False, stat, stat_mode, 1.0 / self.WSCALE if sp else 1.0, hr=hr,
-                     tp=(self.cin, self.cout, 0, 0) if (self.transposed and len(xs) == 1 and not sp) else None)
+                     tp=(self.cin, self.cout, 0, 0) if (self.transposed and len(xs) == 1 and not sp) else None,
+                     x3=(0, self.cin, self.cout, 0, 0) if (not sp and not self.transposed and self.k == 3 and len(xs) == 1) else None)
         return out
 
     def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None, mask=None, dact=None):
@@ -405,7 +419,8 @@ class Conv:
         self._launch((dpre, dpre) if hp else (dpre,), wt, tr, k, ps, pp, dd, H, W, OH, OW, c_seg, out, out32, None, L.ACT_NONE, 0.0, None,
                      None, None, L.RES_NONE, accumulate, stat, L.STAT_SAMPLE_SUM if stat is not None else L.STAT_NONE,
                      1.0 / self.WSCALE if hp else 1.0, mask=mask, hr=hr,
-                     tp=(self.cout, c_seg, row_off, 0) if (tr and not hp and stat is None) else None, dact=dact)
+                     tp=(self.cout, c_seg, row_off, 0) if (tr and not hp and stat is None) else None, dact=dact,
+                     x3=(1, self.cout, c_seg, row_off, 0) if (not hp and not self.transposed and s == 1 and k == 3 and stat is None) else None)
         return out
 
     # -- exact folding of a spatially constant second input segment (SFT conv0: cat(features, kernel code), kbpn.py:513)

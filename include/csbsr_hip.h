@@ -123,6 +123,18 @@ int64_t csbsr_packed_weight_elems_tp(int32_t stride, int32_t c_real);
 int csbsr_pack_weights_tp(const float* w, void* dst, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                           int32_t c_real, int32_t rows_real, int32_t row_off, int32_t k_off, csbsr_stream_t s);
 
+/* 3x3 stride-1 convolution of the wide low-resolution layers (the SFT scale / shift convolutions F.conv2d(cat(fea, k), w, b, 1, 1) of
+ * /root/reference/model/modeling/kbpn.py:505-520 and their dgrads): per-chunk halo tile in LDS shared by the nine taps, fragment-ordered
+ * weights (csbsr_pack_weights_x3) straight from L2 into registers, one barrier per nine K steps -- see csrc/conv_x3.hip.  Same
+ * descriptor and fused epilogue as csbsr_conv_forward except d->wt; csbsr_conv_x3_eligible says whether a launch qualifies (one plain
+ * fp16 input segment of >= 128 channels padded to a multiple of 64, >= 72 padded output channels, no statistics / fp32 output / split). */
+int32_t csbsr_conv_x3_eligible(const csbsr_conv_desc_t* d);
+int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
+/* kind 0 forward (w = OIHW), 1 dgrad of the stride-1 conv (rows = its input channels, taps flipped) */
+int64_t csbsr_packed_weight_elems_x3(int32_t c_real, int32_t rows_real);
+int csbsr_pack_weights_x3(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
+                          int32_t row_off, int32_t k_off, csbsr_stream_t s);
+
 /* Weight-gradient GEMM: G[split][a][tap][b] = sum over the split's pixels of A[pix][a] * B[pix @ tap][b]  (fp32; the pixel
  * range is cut into csbsr_wgrad_splits() slabs, each written once -- no atomics, no zero-fill; csbsr_unpack_wgrad sums them).
  * Conv: A = dPre (output side), B = input.  Transposed conv: A = its input (LR side), B = dOut (HR side).

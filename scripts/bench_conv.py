@@ -9,9 +9,9 @@ from csbsr_amd.engine import Engine, Conv, FM, pad8
 def run(name, N, H, W, cin, cout, k, s, p, d=1, tr=False, iters=10, what=("fwd", "fwd_noepi")):
     eng = Engine()
     wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
-    params = {"l.weight": (torch.randn(wshape, device="cuda") / (cin * k * k) ** 0.5), "l.bias": torch.zeros(cout, device="cuda")}
+    params = {"l.weight": (torch.randn(wshape, device="cuda") / (cin * k * k) ** 0.5) * (0.0 if os.environ.get("BENCH_ZERO") else 1.0), "l.bias": torch.zeros(cout, device="cuda")}
     conv = Conv(eng, "l", params, k, s, p, d, transposed=tr, bias=os.environ.get("BENCH_NOBIAS") is None, act=L.ACT_LRELU, slope=0.1)
-    x = FM(torch.randn(N, H, W, pad8(cin), device="cuda", dtype=torch.float16), cin)
+    x = FM(torch.randn(N, H, W, pad8(cin), device="cuda", dtype=torch.float16) * (0.0 if os.environ.get("BENCH_ZERO") else 1.0), cin)
     OH, OW = conv.out_size(H, W)
     y = eng.new(N, OH, OW, cout)
     dy = FM(torch.randn(N, OH, OW, pad8(cout), device="cuda", dtype=torch.float16), cout)
@@ -40,6 +40,10 @@ if __name__ == "__main__":
     nb = int(sys.argv[5]) if len(sys.argv) > 5 else None
     shapes = {
         "sft825": (1, 448, 448, 825, 825, 3, 1, 1),
+        "sft384_825": (1, 448, 448, 384, 825, 3, 1, 1),
+        "sft825_384": (1, 448, 448, 825, 384, 3, 1, 1),
+        "sft256_697": (1, 448, 448, 256, 697, 3, 1, 1),
+        "sft569_128": (1, 448, 448, 569, 128, 3, 1, 1),
         "conv8s4": (1, 1792, 1792, 128, 128, 8, 4, 2),
         "deconv8s4": (1, 448, 448, 128, 128, 8, 4, 2, 1, True),
         "res512": (8, 224, 224, 512, 512, 3, 1, 1),

@@ -362,3 +362,60 @@ def test_phase_decomposed_dgrad_takes_over_the_epilogue_backward(H, W, frozen):
     else:
         assert relmax(grad_acc(pb["b.bias"]).cpu(), ref_db) < 2e-3
         assert abs(float(grad_acc(pb["a"]).cpu()) - float(ref_da)) < 2e-3 * float((dy * (y16 / a0))[neg].abs().sum()) ** 0.5 + 2e-3 * abs(float(ref_da))
+
+
+@pytest.mark.parametrize("cin,cout,H,W,mode", [
+    (128, 128, 19, 45, "lrelu"),            # ragged tiles on both axes, two 64-channel chunks
+    (384, 825, 16, 32, "lrelu"),            # SFT conv0 shape: 6 chunks, 7 cout tiles (the last one 57 wide)
+    (825, 384, 9, 40, "none_fma"),          # SFT conv1 shape: 825 -> 832 padded input channels (13 chunks), out = conv + res * res2
+    (192, 100, 24, 33, "relu_add"),         # three chunks (odd: the chunk buffers alternate across tiles), padded couts, residual add
+    (256, 256, 8, 64, "none"),
+])
+def test_wide_3x3_kernel(cin, cout, H, W, mode):
+    """csrc/conv_x3.hip (per-chunk halo tile in LDS, fragment-ordered weights from L2, general fused epilogue) against F.conv2d on the
+    same fp16-rounded operands and against the implicit-GEMM kernels: forward with the fused epilogue modes the SFT layers use, and
+    the dgrad (flipped, transposed weights) accumulating into an existing gradient."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    torch.manual_seed(cin + cout + H)
+    eng = _eng()
+    lib = L.load()
+    N = 2
+    x = torch.randn(N, cin, H, W).half().float()
+    w = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).half().float()
+    b = torch.randn(cout) * 0.1
+    act = {"lrelu": L.ACT_LRELU, "relu": L.ACT_RELU, "none": L.ACT_NONE}[mode.split("_")[0]]
+    conv = Conv(eng, "l", {"l.weight": w.cuda(), "l.bias": b.cuda()}, 3, 1, 1, 1, bias=True, act=act, slope=0.1)
+    pre = F.conv2d(x, w, b, 1, 1)
+    ref = {L.ACT_LRELU: F.leaky_relu(pre, 0.1), L.ACT_RELU: F.relu(pre), L.ACT_NONE: pre}[act]
+    res = torch.randn_like(ref).half().float()
+    res2 = torch.randn_like(ref).half().float()
+    kw = {}
+    if mode.endswith("_add"):
+        ref = ref + res; kw = dict(res=res, res_mode=L.RES_ADD)
+    if mode.endswith("_fma"):
+        ref = ref + res * res2; kw = dict(res=res, res2=res2, res_mode=L.RES_FMA)
+    dpre = torch.randn(N, cout, H, W).half().float()
+    old = torch.randn(N, cin, H, W).half().float()
+    xr = torch.zeros(N, cin, H, W, requires_grad=True)
+    F.conv2d(xr, w, None, 1, 1).backward(dpre)
+    refd = xr.grad + old
+    outs = []
+    for x3_mode in (2, 0):
+        lib.csbsr_debug_set_conv_x3(x3_mode)
+        try:
+            conv.invalidate()
+            y = conv.fwd(to_fm(eng, x), **{k_: (to_fm(eng, v) if isinstance(v, torch.Tensor) else v) for k_, v in kw.items()})
+            torch.cuda.synchronize()
+            assert (lib.csbsr_debug_last_conv_kernel() == 10) == (x3_mode == 2 and cin % 64 == 0 or x3_mode == 2 and cin == 825)
+            dx = to_fm(eng, old)
+            conv.bwd_input(to_fm(eng, dpre), out=dx, accumulate=True)
+            torch.cuda.synchronize()
+            from csbsr_amd.engine import pad8
+            assert (lib.csbsr_debug_last_conv_kernel() == 10) == (x3_mode == 2 and pad8(cout) % 64 == 0 and pad8(cout) >= 128)
+        finally:
+            lib.csbsr_debug_set_conv_x3(1)
+        outs.append((from_fm(y), from_fm(dx)))
+        assert relmax(outs[-1][0], ref) < 2e-3
+        assert relmax(outs[-1][1], refd) < 2e-3
+    assert relmax(outs[0][0], outs[1][0]) < 1e-3 and relmax(outs[0][1], outs[1][1]) < 1e-3
