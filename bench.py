@@ -97,7 +97,10 @@ def main():
         local = int(os.environ["CSBSR_FORCE_DEVICE"])
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
-    if world > 1:
+    # test hook: CSBSR_FORCE_DIST=1 runs the N > 1 code path (process group, broadcast, bucket reducer on the side stream, barrier,
+    # max-over-ranks timing) with world size 1 -- on a one-GPU box that is the only way to put the RCCL backend itself under the calls
+    dist_on = world > 1 or os.environ.get("CSBSR_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -125,7 +128,7 @@ def main():
     model.max_resident = None if args.max_resident < 0 else args.max_resident     # None: as many as the free HBM allows
     model.train()
     rt = model._runtime()
-    if world > 1:
+    if dist_on:
         broadcast_parameters(model)
         model.reducer = GradBucketReducer(side_stream=torch.cuda.Stream(dev))
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.SOLVER.LR, betas=(0.9, 0.999), eps=1e-8)    # train.py:91
@@ -160,7 +163,7 @@ def main():
     eng = rt["eng"]
     if not args.no_kernel_timing:
         eng.timing = []
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -168,10 +171,10 @@ def main():
     for _ in range(args.steps):
         last = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
@@ -257,7 +260,7 @@ def main():
         if not args.no_cpu_baseline and world == 1 and not other:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_lr)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
