@@ -225,7 +225,7 @@ __device__ __forceinline__ void conv_epilogue_flush_stats(const ConvK& p, float*
 // from global memory here -- 8 dependent L2 round trips per call, which is most of a short tile's epilogue.
 __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const f16v& acc, int cbase /*first cout of the 32-wide tile*/,
                                                           float slope, int n, int oy, int ox, const float* bias_tab = nullptr,
-                                                          const EpiFast* fe = nullptr, const h8* pre_old = nullptr) {
+                                                          const EpiFast* fe = nullptr) {
   if (n < 0) return;
   const int hi = (threadIdx.x & 63) >> 5;
 #pragma unroll
@@ -249,7 +249,7 @@ __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const 
       half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
       h8 rr = {0, 0, 0, 0, 0, 0, 0, 0}, oo = {0, 0, 0, 0, 0, 0, 0, 0};
       if (fe->has_res) rr = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
-      if (fe->has_old) oo = pre_old ? pre_old[pair] : *reinterpret_cast<const h8*>(o);      // (pre_old: the caller requested it earlier)
+      if (fe->has_old) oo = *reinterpret_cast<const h8*>(o);
       if (fe->has_res || fe->has_old) conv_epilogue_fast_row<true, false>(*fe, v, bias, co, o, rr, oo, s0, s1);
       else conv_epilogue_fast_row<false, false>(*fe, v, bias, co, o, rr, oo, s0, s1);
       continue;

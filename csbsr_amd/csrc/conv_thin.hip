@@ -232,37 +232,17 @@ __global__ __launch_bounds__(256) void conv_thin_cin_kernel(const ConvK p, int t
         pf[s][e] = tap < 9 ? sIn[((oyl + ky) * TN_HW + oxl + kx) * 4 + c] : (half_t)0;
       }
     const int nn = (oy < p.OH && ox < p.OW) ? n : -1;
-    // accumulating launches (the dgrads of kb.sr_reconst into the concatenated gradient buffer): the kernel is a read-modify-write
-    // stream, and with one old-output load in flight per wave it ran at 3.1-3.4 TB/s -- latency x memory-level parallelism, not
-    // bandwidth.  The old values of four cout tiles (8 loads per lane) are requested before their MFMAs / epilogues.
-    const bool pre = fe.ok && !fe.bn && fe.has_old;
-    const half_t* obase = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + 8 * hi;
-#pragma unroll 1
-    for (int ct0 = 0; ct0 < nct; ct0 += 4) {
-      h8 oldv[4][2];
-      if (pre && nn >= 0) {
+#pragma unroll 4
+    for (int ct = 0; ct < nct; ++ct) {
+      const half_t* wrow = sWt + (size_t)(ct * 32 + (lane & 31)) * TK_WLD + 8 * hi;
+      const h8 w0 = *reinterpret_cast<const h8*>(wrow);
+      const h8 w1 = *reinterpret_cast<const h8*>(wrow + 16);
+      f16v acc;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int pair = 0; pair < 2; ++pair) {
-            const int co = (ct0 + j) * 32 + 16 * pair + 8 * hi;
-            if (co < p.coutp) oldv[j][pair] = *reinterpret_cast<const h8*>(obase + (ct0 + j) * 32 + 16 * pair);
-          }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ct = ct0 + j;
-        if (ct >= nct) break;
-        const half_t* wrow = sWt + (size_t)(ct * 32 + (lane & 31)) * TK_WLD + 8 * hi;
-        const h8 w0 = *reinterpret_cast<const h8*>(wrow);
-        const h8 w1 = *reinterpret_cast<const h8*>(wrow + 16);
-        f16v acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, pf[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, pf[1], acc, 0, 0, 0);
-        conv_epilogue_direct_tile(p, acc, ct * 32, slope, nn, oy, ox, sBias, &fe, pre ? oldv[j] : nullptr);
-      }
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, pf[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, pf[1], acc, 0, 0, 0);
+      conv_epilogue_direct_tile(p, acc, ct * 32, slope, nn, oy, ox, sBias, &fe);
     }
   }
   }
