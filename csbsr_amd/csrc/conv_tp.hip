@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     for (int d = 0; d < WD; ++d) load_w(w0 + d * stage_elems, wreg[d]);
   }
   h8 bfr[8];                                              // B fragments of the k-slice in flight: pixel row nt, one read per MFMA
-  h8 ql[PIPE ? 1 : 8], qm[PIPE ? 1 : 8];                  // (!PIPE) old-output / mask operands of eight pieces
+  h8 ql[PIPE ? 1 : 16], qm[PIPE ? 1 : 16];                // (!PIPE) old-output / mask operands of the phase's sixteen pieces
 
   unsigned pgi = 0, itn = 0;
   int n = 0, Y0 = 0, X0 = 0;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     if (!PIPE) {
       h8 r_;
 #pragma unroll
-      for (int pi = 0; pi < 8; ++pi) piece_loads(cur, pi, r_, ql[pi], qm[pi]);
+      for (int pi = 0; pi < 16; ++pi) piece_loads(cur, pi, r_, ql[pi], qm[pi]);
     }
 
 #pragma unroll
@@ -312,8 +312,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     }
     pend = cur;
     if (!PIPE) {
-      // one accumulator set: this phase's 16 pieces now.  Pieces 0..7 had their operands requested before the K loop (ql / qm), the
-      // operands of piece i + 8 are requested as piece i retires
+      // one accumulator set: this phase's 16 pieces now; their operands were requested before the K loop (ql / qm)
 #pragma unroll
       for (int pi = 0; pi < 16; ++pi) {
         float v[8];
@@ -322,9 +321,8 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
 #pragma unroll
         for (int c = 0; c < 4; ++c) act_chunk(acc, pi, c, v, bq);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) store_chunk(pi & 1, c, v, r, ql[pi & 7], qm[pi & 7]);
+        for (int c = 0; c < 4; ++c) store_chunk(pi & 1, c, v, r, ql[pi], qm[pi]);
         store_fin(cur, pi, v);
-        if (pi < 8) piece_loads(cur, pi + 8, r, ql[pi], qm[pi]);
       }
     }
   };
