@@ -74,6 +74,124 @@ __global__ void blur_bwd_input_kernel(const float* dy, const float* kvec, float*
   }
 }
 
+// The stride-1 case (the SR loss's pseudo-LR blur of the whole SR batch, sr_loss_functions.py:74-88, once per step at HR): a full 21x21
+// correlation with the flipped kernel, 441 MACs per pixel.  The gather form above ran it at 5 TFLOP/s (13 ms per step); here a
+// workgroup owns 16 rows x 128 columns, stages the (16+20) x (128+20) window of dy and the 441 taps in LDS, and a thread produces a
+// 1 x 8 strip: per kernel row one 28-float slice of the window in registers and 21 x 8 FMAs against broadcast tap reads.
+template <int K>
+__global__ __launch_bounds__(256) void blur_bwd_input_s1_kernel(const float* dy, const float* kvec, float* dx, int accumulate, int C, int H, int W,
+                                                                int tiles_x, int tiles_y) {
+  constexpr int P = (K - 1) / 2, TR = 16, TC = 128, WC = TC + K - 1, WR = TR + K - 1, WCP = WC + 4;     // 148 (+4 pad) x 36
+  __shared__ __attribute__((aligned(16))) float sK[K * K + 3];
+  __shared__ __attribute__((aligned(16))) float sD[WR * WCP];
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y;
+  const long plane = b / tiles_y;
+  const int n = (int)(plane / C);
+  // dx[iy][ix] = sum dy[iy + P - ky][ix + P - kx] k[ky][kx] = sum_{a,b} dy[iy - P + a][ix - P + b] kf[a][b], kf = k flipped both ways
+  for (int i = tid; i < K * K; i += 256) sK[i] = kvec[(long)n * K * K + (K * K - 1 - i)];
+  const float* dyp = dy + plane * H * W;
+  const int y0 = ty * TR, x0 = tx * TC;
+  for (int i = tid; i < WR * WC; i += 256) {
+    const int r = i / WC, c = i - r * WC;
+    const int yy = y0 - P + r, xx = x0 - P + c;
+    sD[r * WCP + c] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? dyp[(long)yy * W + xx] : 0.f;
+  }
+  __syncthreads();
+  const int lr = tid >> 4, lc = (tid & 15) * 8;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll 1
+  for (int a = 0; a < K; ++a) {
+    float w[8 + K - 1];
+    const float* row = sD + (lr + a) * WCP + lc;
+#pragma unroll
+    for (int j = 0; j < (8 + K - 1) / 4; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(row + 4 * j);
+      w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+    }
+#pragma unroll
+    for (int bb = 0; bb < K; ++bb) {
+      const float t = sK[a * K + bb];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += w[bb + e] * t;
+    }
+  }
+  const int iy = y0 + lr, ix = x0 + lc;
+  if (iy >= H) return;
+  float* o = dx + plane * H * W + (long)iy * W + ix;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (ix + e < W) o[e] = accumulate ? o[e] + acc[e] : acc[e];
+}
+
+// The stride-4 case of the above (the KBlock blur of the x4 model, kbpn.py:497-500, four times per micro-batch at HR), tiled: the
+// gather form walked ~30 taps per HR pixel with two global loads and an integer division each (1.95 ms per launch at N = 4, 79 GB/s).
+// Per output phase (iy % 4, ix % 4) the backward is a <= 6x6 convolution of the LOW-resolution dy with that phase's taps
+// (ky = r + 4 j, r = (py + P) % 4), and all 16 phases of one low-resolution position read the same 7x7 window of dy.  A workgroup
+// owns a 16x16 tile of low-resolution positions of one plane: dy tile (22x22, zero outside) and the 441 taps in LDS, a thread keeps
+// its 7x7 window in registers and produces its 4x4 block of HR pixels (tap reads are wave-wide broadcasts), stored as four float4 rows.
+template <int K>
+__global__ __launch_bounds__(256) void blur_bwd_input_s4_kernel(const float* dy, const float* kvec, float* dx, int accumulate, int C, int H, int W,
+                                                                int OH, int OW, int tiles_x, int tiles_y) {
+  constexpr int P = (K - 1) / 2, S = 4, TL = 16, WIN = 7, TD = TL + WIN - 1;      // 22
+  __shared__ float sK[K * K];
+  __shared__ float sD[TD * TD];
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y;
+  const long plane = b / tiles_y;
+  const int n = (int)(plane / C);
+  for (int i = tid; i < K * K; i += 256) sK[i] = kvec[(long)n * K * K + i];
+  const float* dyp = dy + plane * OH * OW;
+  const int a0 = ty * TL, b0 = tx * TL;
+  for (int i = tid; i < TD * TD; i += 256) {
+    const int r = i / TD, c = i - r * TD;
+    const int oy = a0 - 3 + r, ox = b0 - 3 + c;
+    sD[i] = ((unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW) ? dyp[(long)oy * OW + ox] : 0.f;
+  }
+  __syncthreads();
+  const int la = tid >> 4, lb = tid & 15;
+  float win[WIN][WIN];                                  // dy[a - 3 .. a + 3][b - 3 .. b + 3]
+#pragma unroll
+  for (int r = 0; r < WIN; ++r)
+#pragma unroll
+    for (int c = 0; c < WIN; ++c) win[r][c] = sD[(la + r) * TD + lb + c];
+  const int a = a0 + la, bb = b0 + lb;
+  if (a >= OH || bb >= OW) return;
+  float* dxp = dx + plane * H * W + (long)(S * a) * W + S * bb;
+#pragma unroll
+  for (int py = 0; py < S; ++py) {
+    constexpr int dummy = 0; (void)dummy;
+    const int ry = (py + P) % S, cy = (py + P) / S;     // ky = ry + 4 j, dy row a + cy - j -> window row 3 + cy - j
+    float out[S];
+#pragma unroll
+    for (int px = 0; px < S; ++px) {
+      const int rx = (px + P) % S, cx = (px + P) / S;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int ky = ry + S * j;
+        if (ky >= K) continue;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int kx = rx + S * i;
+          if (kx >= K) continue;
+          acc += win[3 + cy - j][3 + cx - i] * sK[ky * K + kx];
+        }
+      }
+      out[px] = acc;
+    }
+    float4* o = reinterpret_cast<float4*>(dxp + (long)py * W);
+    if (accumulate) { const float4 old = *o; out[0] += old.x; out[1] += old.y; out[2] += old.z; out[3] += old.w; }
+    *o = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
 // dk[n][ky*K+kx] += sum_{c,oy,ox} dy[n,c,oy,ox] * x[n,c,oy*s-P+ky, ox*s-P+kx]
 // grid: (K*K taps, chunks, N); block reduces over its chunk of (c,oy,ox)
 // dk[n][ky*K+kx] = sum_{c,oy,ox} dy[n,c,oy,ox] * x[n,c,oy*s-P+ky, ox*s-P+kx]
@@ -167,6 +285,20 @@ extern "C" int csbsr_blur_bwd_input(const float* dy, const float* kvec, float* d
   CSBSR_CHECK(dy && kvec && dx, "blur_bwd_input: null");
   const int P = (K - 1) / 2;
   const int OH = (H + 2 * P - K) / stride + 1, OW = (W + 2 * P - K) / stride + 1;
+  if (stride == 1 && K == 21) {
+    const int tiles_x = (W + 127) / 128, tiles_y = (H + 15) / 16;
+    hipLaunchKernelGGL((blur_bwd_input_s1_kernel<21>), dim3((unsigned)((long)N * C * tiles_y * tiles_x)), dim3(256), 0, ST(s), dy, kvec, dx,
+                       accumulate, C, H, W, tiles_x, tiles_y);
+    CSBSR_LAUNCH_CHECK("csbsr_blur_bwd_input");
+    return 0;
+  }
+  if (stride == 4 && K == 21 && H == 4 * OH && W == 4 * OW && W % 4 == 0) {
+    const int tiles_x = (OW + 15) / 16, tiles_y = (OH + 15) / 16;
+    hipLaunchKernelGGL((blur_bwd_input_s4_kernel<21>), dim3((unsigned)((long)N * C * tiles_y * tiles_x)), dim3(256), 0, ST(s), dy, kvec, dx,
+                       accumulate, C, H, W, OH, OW, tiles_x, tiles_y);
+    CSBSR_LAUNCH_CHECK("csbsr_blur_bwd_input");
+    return 0;
+  }
   BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_bwd_input_kernel<KK>), dim3(grid_for((long)N * C * H * W)), dim3(256), 0, ST(s), dy, kvec, dx,
                                       accumulate, N, C, H, W, OH, OW, stride));
   CSBSR_LAUNCH_CHECK("csbsr_blur_bwd_input");
@@ -357,6 +489,53 @@ __global__ void aa_down_bwd_kernel(const float* dy, float* dx, int accumulate, i
     dx[i] = accumulate ? dx[i] + acc : acc;
   }
 }
+// Antialiased case, table-driven: the weights are separable and depend only on the input row (column) index, so a first tiny kernel
+// writes, for every input row and column, the 7 weights of its candidate outputs (i / f - 3 .. i / f + 3; zero where the output does not
+// exist or its footprint misses the pixel) -- the per-pixel kernel above re-derived them with the normalisation loop of aa_range 14
+// times per pixel (8.2 ms per step at HR); the main pass is then 49 FMAs per input pixel.
+__global__ void aa_weight_tables_kernel(float* tab, int H, int W, int f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H + W) return;
+  const bool isrow = i < H;
+  const int idx = isrow ? i : i - H, in = isrow ? H : W, on = in / f;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int o = idx / f - 3 + j;
+    float w = 0.f;
+    if (o >= 0 && o < on) {
+      int lo, hi; float c, nrm; aa_range(o, in, f, lo, hi, c, nrm);
+      if (idx >= lo && idx < hi) w = aa_filter((idx - c + 0.5f) / f) * nrm;
+    }
+    tab[(long)i * 8 + j] = w;
+  }
+  tab[(long)i * 8 + 7] = 0.f;
+}
+__global__ void aa_down_bwd_tab_kernel(const float* dy, float* dx, const float* tab, int accumulate, int planes, int H, int W, int f) {
+  const int OH = H / f, OW = W / f;
+  const long total = (long)planes * H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % W); long t = i / W;
+    const int iy = (int)(t % H); const long pl = t / H;
+    const float* gp = dy + pl * OH * OW;
+    const float4 y0 = *reinterpret_cast<const float4*>(tab + (long)iy * 8), y1 = *reinterpret_cast<const float4*>(tab + (long)iy * 8 + 4);
+    const float4 x0 = *reinterpret_cast<const float4*>(tab + (long)(H + ix) * 8), x1 = *reinterpret_cast<const float4*>(tab + (long)(H + ix) * 8 + 4);
+    const float wy[7] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z}, wx[7] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z};
+    const int oy0 = iy / f - 3, ox0 = ix / f - 3;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      int oy = oy0 + j; oy = oy < 0 ? 0 : (oy > OH - 1 ? OH - 1 : oy);        // (weights of non-existent outputs are zero)
+      float r = 0.f;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        int ox = ox0 + k; ox = ox < 0 ? 0 : (ox > OW - 1 ? OW - 1 : ox);
+        r += wx[k] * gp[(long)oy * OW + ox];
+      }
+      acc += wy[j] * r;
+    }
+    dx[i] = accumulate ? dx[i] + acc : acc;
+  }
+}
 extern "C" int csbsr_aa_bicubic_down_fwd(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t f, int32_t antialias,
                                          csbsr_stream_t s) {
   CSBSR_CHECK(x && y && f >= 1, "aa_down_fwd: bad args");
@@ -367,6 +546,13 @@ extern "C" int csbsr_aa_bicubic_down_fwd(const float* x, float* y, int32_t plane
 extern "C" int csbsr_aa_bicubic_down_bwd(const float* dy, float* dx, int32_t accumulate, int32_t planes, int32_t H, int32_t W, int32_t f,
                                          int32_t antialias, csbsr_stream_t s) {
   CSBSR_CHECK(dy && dx && f >= 1, "aa_down_bwd: bad args");
+  float* tab = antialias ? csbsr_red_scratch((long)(H + W) * 8) : nullptr;
+  if (tab) {
+    hipLaunchKernelGGL(aa_weight_tables_kernel, dim3((H + W + 255) / 256), dim3(256), 0, ST(s), tab, H, W, f);
+    hipLaunchKernelGGL(aa_down_bwd_tab_kernel, dim3(grid_for((long)planes * H * W)), dim3(256), 0, ST(s), dy, dx, tab, accumulate, planes, H, W, f);
+    CSBSR_LAUNCH_CHECK("csbsr_aa_bicubic_down_bwd");
+    return 0;
+  }
   hipLaunchKernelGGL(aa_down_bwd_kernel, dim3(grid_for((long)planes * H * W)), dim3(256), 0, ST(s), dy, dx, accumulate, planes, H, W, f, antialias);
   CSBSR_LAUNCH_CHECK("csbsr_aa_bicubic_down_bwd");
   return 0;

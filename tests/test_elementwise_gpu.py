@@ -232,6 +232,11 @@ def test_blur_fwd_bwd(stride):
     assert relmax(o.cpu(), (y - sub).detach()) < 1e-5
     assert relmax(dx.cpu(), x.grad) < 1e-5
     assert relmax(dk.cpu(), k.grad) < 1e-4
+    # accumulate into an existing gradient (the tiled stride-4 kernel has its own read-modify-write path)
+    dx2 = torch.ones(N, 3, H, W, device="cuda")
+    L.call("csbsr_blur_bwd_input", P(dy.cuda()), P(kc), P(dx2), 1, N, 3, H, W, K, stride, eng.stream)
+    torch.cuda.synchronize()
+    assert relmax(dx2.cpu() - 1, x.grad) < 1e-5
 
 
 @pytest.mark.parametrize("aa", [1, 0])
