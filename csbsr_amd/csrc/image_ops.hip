@@ -78,9 +78,10 @@ __global__ void blur_bwd_input_kernel(const float* dy, const float* kvec, float*
 // correlation with the flipped kernel, 441 MACs per pixel.  The gather form above ran it at 5 TFLOP/s (13 ms per step); here a
 // workgroup owns 16 rows x 128 columns, stages the (16+20) x (128+20) window of dy and the 441 taps in LDS, and a thread produces a
 // 1 x 8 strip: per kernel row one 28-float slice of the window in registers and 21 x 8 FMAs against broadcast tap reads.
-template <int K>
+// FWD: the same tiling for the forward blur at stride 1 (unflipped taps; optional subtrahend, fp32 planar and / or fp16 NHWC output)
+template <int K, bool FWD>
 __global__ __launch_bounds__(256) void blur_bwd_input_s1_kernel(const float* dy, const float* kvec, float* dx, int accumulate, int C, int H, int W,
-                                                                int tiles_x, int tiles_y) {
+                                                                int tiles_x, int tiles_y, const float* sub, half_t* y16, long y16_ld) {
   constexpr int P = (K - 1) / 2, TR = 16, TC = 128, WC = TC + K - 1, WR = TR + K - 1, WCP = WC + 4;     // 148 (+4 pad) x 36
   __shared__ __attribute__((aligned(16))) float sK[K * K + 3];
   __shared__ __attribute__((aligned(16))) float sD[WR * WCP];
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void blur_bwd_input_s1_kernel(const float* dy,
   const long plane = b / tiles_y;
   const int n = (int)(plane / C);
   // dx[iy][ix] = sum dy[iy + P - ky][ix + P - kx] k[ky][kx] = sum_{a,b} dy[iy - P + a][ix - P + b] kf[a][b], kf = k flipped both ways
-  for (int i = tid; i < K * K; i += 256) sK[i] = kvec[(long)n * K * K + (K * K - 1 - i)];
+  for (int i = tid; i < K * K; i += 256) sK[i] = kvec[(long)n * K * K + (FWD ? i : K * K - 1 - i)];
   const float* dyp = dy + plane * H * W;
   const int y0 = ty * TR, x0 = tx * TC;
   for (int i = tid; i < WR * WC; i += 256) {
@@ -122,7 +123,20 @@ __global__ __launch_bounds__(256) void blur_bwd_input_s1_kernel(const float* dy,
   }
   const int iy = y0 + lr, ix = x0 + lc;
   if (iy >= H) return;
-  float* o = dx + plane * H * W + (long)iy * W + ix;
+  const long oi = plane * H * W + (long)iy * W + ix;
+  if (FWD) {
+    const int c = (int)(plane - (long)n * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (ix + e < W) {
+        float v = acc[e];
+        if (sub) v -= sub[oi + e];
+        if (dx) dx[oi + e] = v;
+        if (y16) y16[(((long)n * H + iy) * W + ix + e) * y16_ld + c] = (half_t)v;
+      }
+    return;
+  }
+  float* o = dx + oi;
 #pragma unroll
   for (int e = 0; e < 8; ++e)
     if (ix + e < W) o[e] = accumulate ? o[e] + acc[e] : acc[e];
@@ -267,6 +281,13 @@ extern "C" int csbsr_blur_fwd(const float* x, const float* kvec, int32_t N, int3
   CSBSR_CHECK(x && kvec && (y32 || y16), "blur_fwd: null");
   const int P = (K - 1) / 2;
   const int OH = (H + 2 * P - K) / stride + 1, OW = (W + 2 * P - K) / stride + 1;
+  if (stride == 1 && K == 21) {      // register-blocked 16 x 128 tiles (see blur_bwd_input_s1_kernel): 5.5 -> ~2 ms at HR, B = 8
+    const int tiles_x = (W + 127) / 128, tiles_y = (H + 15) / 16;
+    hipLaunchKernelGGL((blur_bwd_input_s1_kernel<21, true>), dim3((unsigned)((long)N * C * tiles_y * tiles_x)), dim3(256), 0, ST(s), x, kvec, y32, 0,
+                       C, H, W, tiles_x, tiles_y, sub, (half_t*)y16, (long)y16_ld);
+    CSBSR_LAUNCH_CHECK("csbsr_blur_fwd");
+    return 0;
+  }
   const int TW = 15 * stride + K;
   const size_t smem = (size_t)(K * K + TW * TW) * 4;
   dim3 grid((OW + 15) / 16, (OH + 15) / 16, N * C);
@@ -287,8 +308,8 @@ extern "C" int csbsr_blur_bwd_input(const float* dy, const float* kvec, float* d
   const int OH = (H + 2 * P - K) / stride + 1, OW = (W + 2 * P - K) / stride + 1;
   if (stride == 1 && K == 21) {
     const int tiles_x = (W + 127) / 128, tiles_y = (H + 15) / 16;
-    hipLaunchKernelGGL((blur_bwd_input_s1_kernel<21>), dim3((unsigned)((long)N * C * tiles_y * tiles_x)), dim3(256), 0, ST(s), dy, kvec, dx,
-                       accumulate, C, H, W, tiles_x, tiles_y);
+    hipLaunchKernelGGL((blur_bwd_input_s1_kernel<21, false>), dim3((unsigned)((long)N * C * tiles_y * tiles_x)), dim3(256), 0, ST(s), dy, kvec, dx,
+                       accumulate, C, H, W, tiles_x, tiles_y, nullptr, nullptr, 0l);
     CSBSR_LAUNCH_CHECK("csbsr_blur_bwd_input");
     return 0;
   }
