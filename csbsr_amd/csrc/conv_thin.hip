@@ -276,3 +276,114 @@ int conv_thin_cin_launch(const ConvK& k, int creal, hipStream_t st) {
   CSBSR_LAUNCH_CHECK("csbsr_conv_forward(thin-in)");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Thin-input TRANSPOSED convolution (kernel <= 2 x stride: 2 x 2 taps per output phase) from a 3-channel image: kb.up_conv1 of every
+// back-projection stage (DeconvBlock 3 -> 128, 8x8 stride 4, PReLU, + residual; kbpn.py:497-503).  12 MACs per output value: the
+// padded implicit GEMM ran it at 22 TFLOP/s (2.8 ms per launch for a 1.3 ms read + write stream).  Streaming VALU kernel: a thread owns
+// one output phase column (ox % s) and one channel octet, keeps that phase's 4 taps x 3 channels x 8 couts of weights in registers
+// (fp16-rounded, straight from the standard phase-major pack) and walks the pixels of its phase along a group of rows with equal
+// oy % s; the 16 octet-threads of a pixel share its four 16-byte input loads and write one contiguous 256-byte pixel.
+template <int CI>
+__global__ __launch_bounds__(256) void conv_thin_tp_kernel(const ConvK p, int groups_per_phase) {
+  const int tid = threadIdx.x;
+  const int c8 = p.coutp >> 3;                          // channel octets (<= 16)
+  const int oct = tid % c8, pl = tid / c8;              // pixel lanes: 256 / c8
+  const int npl = 256 / c8;
+  if (pl >= npl) return;
+  const int s = p.stride;
+  int b = blockIdx.x;
+  const int rg = b % groups_per_phase; b /= groups_per_phase;
+  const int py = b % s;
+  const int n = b / s;
+  const int px = pl % s, sub = pl / s, nsub = npl / s;  // (npl is a multiple of s: launcher)
+  const int by = (py + p.pad) / s, bx = (px + p.pad) / s;
+  const int ph = py * s + px;
+  const int co = oct * 8;
+  float w[4][CI][8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int c = 0; c < CI; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[t][c][e] = (float)p.wt[((size_t)ph * p.rows_p + co + e) * p.Kp + t * p.ctot + c];
+  float bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f;
+  const float slope = p.act == CSBSR_ACT_PRELU ? *p.prelu : (p.act == CSBSR_ACT_RELU ? 0.f : (p.act == CSBSR_ACT_NONE ? 1.f : p.act_slope));
+  const float rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
+  const half_t* in0 = reinterpret_cast<const half_t*>(p.in[0].ptr) + (long)n * p.in[0].sn;
+  const int rows_per_group = (p.OH / s + groups_per_phase - 1) / groups_per_phase;
+  for (int r = 0; r < rows_per_group; ++r) {
+    const int qy = rg * rows_per_group + r;
+    const int oy = qy * s + py;
+    if (oy >= p.OH) break;
+    // four pixels per pass: their 16 input loads and 4 residual loads are in flight together (the loop is latency-bound otherwise:
+    // stores to out16 may alias every load as far as the compiler knows, so it would not hoist the next pixel's loads itself)
+    for (int qx0 = sub; qx0 * s + px < p.OW; qx0 += 4 * nsub) {
+      h8 xv[4][4], rr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int qx = qx0 + u * nsub, ox = qx * s + px;
+        const bool live = ox < p.OW;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int iy = qy + by - (t >> 1), ix = qx + bx - (t & 1);
+          xv[u][t] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+          if (live && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            xv[u][t] = *reinterpret_cast<const h8*>(in0 + (long)iy * p.in[0].sy + (long)ix * p.in[0].sx);
+        }
+        rr[u] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (live && rsign != 0.f) rr[u] = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + (long)oy * p.r_sy + (long)ox * p.r_sx + co);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int qx = qx0 + u * nsub, ox = qx * s + px;
+        if (ox >= p.OW) break;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int c = 0; c < CI; ++c) {
+            const float xf = (float)xv[u][t][c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += xf * w[t][c][e];
+          }
+        h8 hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t_ = acc[e] * p.out_scale + bias[e];
+          t_ = t_ > 0.f ? t_ : t_ * slope;
+          if (co + e >= p.cout) t_ = 0.f;
+          t_ += rsign * (float)rr[u][e];
+          hv[e] = (half_t)t_;
+        }
+        *reinterpret_cast<h8*>(p.out16 + n * p.o_sn + (long)oy * p.o_sy + (long)ox * p.o_sx + co) = hv;
+      }
+    }
+  }
+}
+
+bool conv_thin_tp_eligible(const ConvK& k, int creal, bool second_seg) {
+  if (!g_conv_thin || !k.transposed || second_seg) return false;
+  if (k.KHt != 2 || k.KWt != 2 || k.stride < 2 || k.dil != 1 || k.pad >= k.stride) return false;
+  if (k.ctot != 8 || creal != 3 || k.in[0].sx == 0) return false;
+  if (k.OH != k.H * k.stride || k.OW != k.W * k.stride) return false;
+  if (k.coutp < 8 || k.coutp > 128 || (256 / (k.coutp / 8)) % k.stride != 0 || 256 % (k.coutp / 8) != 0) return false;
+  if (!k.out16 || k.out32 || k.o_lo || k.r_lo || k.cbias || k.mask || k.accumulate || k.stat_mode != CSBSR_STAT_NONE) return false;
+  if (k.act == CSBSR_ACT_SIGMOID || (k.res_mode != CSBSR_RES_NONE && k.res_mode != CSBSR_RES_ADD && k.res_mode != CSBSR_RES_SUB)) return false;
+  return true;
+}
+
+int conv_thin_tp_launch(const ConvK& k, hipStream_t st) {
+  // row groups per (sample, row phase): enough workgroups to fill the chip several times over, at least ~4 rows each
+  const int rows = k.OH / k.stride;
+  int gpp = (8 * 256 + k.N * k.stride - 1) / (k.N * k.stride);
+  if (gpp > rows / 4) gpp = rows / 4;
+  if (gpp < 1) gpp = 1;
+  hipLaunchKernelGGL((conv_thin_tp_kernel<3>), dim3((unsigned)(k.N * k.stride * gpp)), dim3(256), 0, st, k, gpp);
+  CSBSR_LAUNCH_CHECK("csbsr_conv_forward(thin transposed)");
+  return 0;
+}

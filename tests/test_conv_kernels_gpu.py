@@ -419,3 +419,34 @@ def test_wide_3x3_kernel(cin, cout, H, W, mode):
         assert relmax(outs[-1][0], ref) < 2e-3
         assert relmax(outs[-1][1], refd) < 2e-3
     assert relmax(outs[0][0], outs[1][0]) < 1e-3 and relmax(outs[0][1], outs[1][1]) < 1e-3
+
+
+@pytest.mark.parametrize("k,s,p,cout,H,W,mode", [(8, 4, 2, 128, 13, 21, "prelu_add"), (8, 4, 2, 128, 16, 16, "prelu"), (12, 8, 2, 128, 7, 9, "prelu_add"),
+                                               (8, 4, 2, 64, 10, 12, "none_sub"), (8, 4, 2, 49, 10, 12, "prelu")])
+def test_thin_transposed_conv_from_image(k, s, p, cout, H, W, mode):
+    """kb.up_conv1 (DeconvBlock 3 -> 128, 8x8 stride 4 / 12x12 stride 8, PReLU, + residual): the streaming kernel
+    conv_thin_tp_kernel (csrc/conv_thin.hip) against conv_transpose2d on fp16-rounded operands; 49 couts (7 octets) is not eligible
+    and must come out right through the general kernel."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv, pad8
+    torch.manual_seed(k + cout + H)
+    eng = _eng()
+    N, cin = 2, 3
+    x = torch.randn(N, cin, H, W).half().float()
+    w = (torch.randn(cin, cout, k, k) / (cin * 4) ** 0.5).half().float()
+    b = torch.randn(cout) * 0.1
+    a = torch.tensor([0.25])
+    act = {"prelu": L.ACT_PRELU, "none": L.ACT_NONE}[mode.split("_")[0]]
+    conv = Conv(eng, "l", {"l.weight": w.cuda(), "l.bias": b.cuda(), "a": a.cuda()}, k, s, p, 1, transposed=True, bias=True, act=act,
+                prelu="a" if act == L.ACT_PRELU else False)
+    pre = F.conv_transpose2d(x, w, b, s, p)
+    ref = F.prelu(pre, a) if act == L.ACT_PRELU else pre
+    res = torch.randn_like(ref).half().float()
+    rm = L.RES_ADD if mode.endswith("_add") else (L.RES_SUB if mode.endswith("_sub") else L.RES_NONE)
+    if rm == L.RES_ADD: ref = ref + res
+    if rm == L.RES_SUB: ref = ref - res
+    y = conv.fwd(to_fm(eng, x), res=to_fm(eng, res) if rm != L.RES_NONE else None, res_mode=rm)
+    torch.cuda.synchronize()
+    c8 = pad8(cout) // 8
+    assert (L.load().csbsr_debug_last_conv_kernel() == 11) == (256 % c8 == 0 and (256 // c8) % s == 0)
+    assert relmax(from_fm(y), ref) < 2e-3
