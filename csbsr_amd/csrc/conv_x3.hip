@@ -11,13 +11,13 @@
 //  * the weight operand never touches LDS: packed in MFMA-fragment order (csbsr_pack_weights_x3, couts permuted so that a lane's
 //    accumulators are consecutive channels), 8 KB per wave and K step straight from L2 into registers, two steps ahead; work is
 //    ordered cout-tile-major so the 128-cout weight slice everybody streams (0.9 MB for 384 input channels) stays L2-resident;
+//    (ablation: all K steps loading the same, L1-resident weights changed 908 -> 926 TF/s: the weight stream is not the stall);
 //  * synchronisation: one barrier per CHUNK (nine K steps), none per step; one counted s_waitcnt per chunk for the halo DMA;
 //  * epilogue: the general fused row of conv_common.h (bias, per-border-class bias of the folded constant segment, activations,
 //    residual add / sub / mul / fma, accumulate, activation mask) straight from registers, once per 54-117 K steps.
 #include "common.h"
 #include "conv_common.h"
 #include "csbsr_debug.h"
-#include <cstdlib>
 
 #define X3_TH 8
 #define X3_TW 32
@@ -32,7 +32,6 @@
 
 struct X3Extra {
   unsigned tiles_x, tiles_y, nct, nch;   // pixel tiles, 128-cout tiles, 64-channel chunks
-  int dbg;                               // ablation (CSBSR_X3_DBG): 1 every K step loads the SAME weights (are the weight loads the stall?)
 };
 
 __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Extra q, const half_t* __restrict__ zero_page) {
@@ -89,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
   const int mh = wid & 1, rq = wid >> 1;
   const unsigned wlane = (unsigned)(mh * 8192 + lane * 16);
   auto load_w = [&](int ct, int step, h8 (&w)[2][4]) __attribute__((always_inline)) {
-    const char* b = reinterpret_cast<const char*>(p.wt) + ((q.dbg & 1) ? (size_t)0 : ((size_t)ct * q.nch * 9 + step) * X3_WSTEP);
+    const char* b = reinterpret_cast<const char*>(p.wt) + ((size_t)ct * q.nch * 9 + step) * X3_WSTEP;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -261,7 +260,6 @@ extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   X3Extra q;
   q.tiles_x = (unsigned)((d->W + X3_TW - 1) / X3_TW); q.tiles_y = (unsigned)((d->H + X3_TH - 1) / X3_TH);
   q.nct = (unsigned)((d->coutp + 127) / 128); q.nch = (unsigned)(d->in[0].c / 64);
-  { const char* e = getenv("CSBSR_X3_DBG"); q.dbg = e ? atoi(e) : 0; }
   int dev = 0, ncu = 256;
   CSBSR_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CSBSR_MAX_DEVICES, "conv_x3: no current device");
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
