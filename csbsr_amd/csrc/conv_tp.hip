@@ -194,9 +194,13 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   cur.mb = pend.mb = reinterpret_cast<const char*>(has_mask ? p.mask : p.out16);
   cur.to = cur.tr = cur.tm = pend.to = pend.tr = pend.tm = 0u;
   cur.xlim = cur.ylim = pend.xlim = pend.ylim = 0;        // nothing pending yet: its pieces load offset 0 and store to the sink
-  h8 lr[2][PPS], lo[2][PPS], lm[2][PPS];
+  // piece operands are requested LD K steps before the piece retires (LD + 1 register buffers; 8 % (LD + 1) == 0 keeps the indices
+  // compile-time across phases): three steps (~1.7 us) ahead when only one operand is read, one step when two are (register budget)
+  constexpr int NLOAD = (int)HAS_RES + (int)HAS_ACC + (int)HAS_MASK;
+  constexpr int LD = NLOAD <= 1 ? 3 : 1, NB = LD + 1;
+  h8 lr[NB][PPS], lo[NB][PPS], lm[NB][PPS];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NB; ++a)
 #pragma unroll
     for (int b = 0; b < PPS; ++b) lr[a][b] = lo[a][b] = lm[a][b] = h8{0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -273,13 +277,13 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
 
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      // the next step's pieces: operands on their way one step ahead
+      // the pieces of LD steps ahead: their operands' requests
       if (PIPE)
 #pragma unroll
       for (int pp = 0; pp < PPS; ++pp) {
-        const int pn_ = (ks + 1) * PPS + pp;
-        if (pn_ < 16) piece_loads(pend, pn_, lr[(ks + 1) & 1][pp], lo[(ks + 1) & 1][pp], lm[(ks + 1) & 1][pp]);
-        else piece_loads(cur, pn_ - 16, lr[(ks + 1) & 1][pp], lo[(ks + 1) & 1][pp], lm[(ks + 1) & 1][pp]);
+        const int pn_ = (ks + LD) * PPS + pp;
+        if (pn_ < 16) piece_loads(pend, pn_, lr[(ks + LD) % NB][pp], lo[(ks + LD) % NB][pp], lm[(ks + LD) % NB][pp]);
+        else piece_loads(cur, pn_ - 16, lr[(ks + LD) % NB][pp], lo[(ks + LD) % NB][pp], lm[(ks + LD) % NB][pp]);
       }
       // the weight stage WD steps ahead
       load_w(ks + WD < NKS ? wcur + (ks + WD) * stage_elems : wnext + (ks + WD - NKS) * stage_elems, wreg[(ks + WD) % (WD + 1)]);
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
           for (int pp = 0; pp < PPS; ++pp) {
             const int k_act = 2 * pp, k_st = k_act + 1;
             if (kk == k_act && i < 4) act_chunk(pd, ks * PPS + pp, i, v[pp], bq[pp]);
-            if (kk == k_st && i < 4) store_chunk((ks * PPS + pp) & 1, i, v[pp], lr[ks & 1][pp], lo[ks & 1][pp], lm[ks & 1][pp]);
+            if (kk == k_st && i < 4) store_chunk((ks * PPS + pp) & 1, i, v[pp], lr[ks % NB][pp], lo[ks % NB][pp], lm[ks % NB][pp]);
             if (kk == k_st && i == 4) store_fin(pend, ks * PPS + pp, v[pp]);
           }
           __builtin_amdgcn_sched_barrier(0);
