@@ -33,7 +33,8 @@ class ConvDesc(C.Structure):
                 ("accumulate", i32), ("stat_mode", i32), ("stat", vp), ("out_scale", f32),
                 ("o_lo", i64), ("r_lo", i64), ("r2_lo", i64),
                 ("mask", vp), ("m_sn", i64), ("m_sy", i64), ("m_sx", i64), ("mask_slope", f32), ("_pad_mask", i32),
-                ("mask_prelu", vp), ("dact_bias", vp), ("dact_prelu", vp)]
+                ("mask_prelu", vp), ("dact_bias", vp), ("dact_prelu", vp),
+                ("dres", vp), ("dr_sn", i64), ("dr_sy", i64), ("dr_sx", i64)]
 
 
 class WgradDesc(C.Structure):

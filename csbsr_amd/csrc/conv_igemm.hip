@@ -452,7 +452,7 @@ int conv_desc_to_k(const csbsr_conv_desc_t* d, ConvK& k) {
   k.o_lo = d->o_lo; k.r_lo = d->r_lo; k.r2_lo = d->r2_lo;
   k.mask = reinterpret_cast<const half_t*>(d->mask); k.m_sn = d->m_sn; k.m_sy = d->m_sy; k.m_sx = d->m_sx; k.mask_slope = d->mask_slope;
   CSBSR_CHECK(!d->mask || (d->out16 && !d->o_lo), "conv: the activation mask applies to a plain fp16 output");
-  CSBSR_CHECK(!d->mask_prelu && !d->dact_bias && !d->dact_prelu, "conv: mask_prelu / dact_* are csbsr_conv_tp_forward fields");
+  CSBSR_CHECK(!d->mask_prelu && !d->dact_bias && !d->dact_prelu && !d->dres, "conv: mask_prelu / dact_* / dres are csbsr_conv_tp_forward fields");
   CSBSR_CHECK(!(d->o_lo && d->accumulate), "conv: a split (hi + lo) output cannot accumulate");
   CSBSR_CHECK(!d->o_lo || d->out16, "conv: o_lo without out16");
   k.tile2d = 0; k.nphase_flat = 0; k.tap_group = 0;

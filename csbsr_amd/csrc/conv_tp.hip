@@ -49,6 +49,7 @@ struct ConvTpK {
   int res_mode; const half_t* res; long r_sn, r_sy, r_sx;
   int accumulate;
   const half_t* mask; long m_sn, m_sy, m_sx; float mask_slope; const float* mask_prelu;
+  half_t* dres; long d_sn, d_sy, d_sx;   // HAS_STAT + residual: gradient wrt the masking layer's residual operand (second output)
   float* part; long part_ld;        // HAS_STAT: per-workgroup partial rows [gridDim.x][part_ld]: bias-gradient sums in [0, coutp), PReLU-slope sum at coutp
   unsigned tiles_x, tiles_y, pg, pgroups;     // phases per work item, items per tile
   int dbg;                          // ablation bit (CSBSR_TP_DBG): 1 stores go to the sink
@@ -164,13 +165,17 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   float sb[HAS_STAT ? 16 : 1], sp = 0.f;
 #pragma unroll
   for (int e = 0; e < (HAS_STAT ? 16 : 1); ++e) sb[e] = 0.f;
+  // HAS_STAT with a residual operand: the masking layer was out = act(pre) +- res (DownBlock's down_conv2, kbpn.py:254-256), so its
+  // activation is (mask -+ res), the residual does NOT enter this launch's result, and d(res) = +- (unmasked result) is a second output
+  float vd[(HAS_STAT && HAS_RES) ? 8 : 1];
   auto store_chunk = [&](int pair, int c, float (&v)[8], const h8& r, const h8& o, const h8& m) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = c; e < 8; e += 4) {
-      if (has_res) v[e] += rsign * (float)r[e];
+      if (has_res && !HAS_STAT) v[e] += rsign * (float)r[e];
       if (has_acc) v[e] += (float)o[e];
+      if (HAS_STAT && HAS_RES) vd[e] = rsign * v[e];
       if (has_mask) {
-        const float mk = (float)m[e];
+        const float mk = (HAS_STAT && HAS_RES) ? (float)m[e] - rsign * (float)r[e] : (float)m[e];
         if (HAS_STAT) sp += mk > 0.f ? 0.f : v[e] * mk;
         v[e] *= (mk > 0.f ? 1.f : mslope);
         if (HAS_STAT) sb[8 * pair + e] += v[e];
@@ -211,7 +216,8 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     for (int d = 0; d < WD; ++d) load_w(w0 + d * stage_elems, wreg[d]);
   }
   h8 bfr[8];                                              // B fragments of the k-slice in flight: pixel row nt, one read per MFMA
-  h8 ql[PIPE ? 1 : 16], qm[PIPE ? 1 : 16];                // (!PIPE) old-output / mask operands of the phase's sixteen pieces
+  constexpr int NQ = HAS_RES ? 8 : 16;                   // (!PIPE) pieces whose operands are requested before the K loop (the residual
+  h8 ql[PIPE ? 1 : NQ], qm[PIPE ? 1 : NQ];                // variant has the second output's registers to pay for: the other 8 as pieces retire)
 
   unsigned pgi = 0, itn = 0;
   int n = 0, Y0 = 0, X0 = 0;
@@ -272,7 +278,10 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     if (!PIPE) {
       h8 r_;
 #pragma unroll
-      for (int pi = 0; pi < 16; ++pi) piece_loads(cur, pi, r_, ql[pi], qm[pi]);
+      for (int pi = 0; pi < NQ; ++pi) {
+        if (HAS_RES) piece_loads(cur, pi, ql[pi], r_, qm[pi]);
+        else piece_loads(cur, pi, r_, ql[pi], qm[pi]);
+      }
     }
 
 #pragma unroll
@@ -325,8 +334,24 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
 #pragma unroll
         for (int c = 0; c < 4; ++c) act_chunk(acc, pi, c, v, bq);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) store_chunk(pi & 1, c, v, r, ql[pi], qm[pi]);
+        for (int c = 0; c < 4; ++c) {
+          if (HAS_RES) store_chunk(pi & 1, c, v, ql[pi % NQ], r, qm[pi % NQ]);      // (ql holds the residual operand in this variant)
+          else store_chunk(pi & 1, c, v, r, ql[pi % NQ], qm[pi % NQ]);
+        }
         store_fin(cur, pi, v);
+        if (HAS_RES) {
+          const int nt = pi >> 1, pair = pi & 1;
+          h8 hd;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hd[e] = (half_t)vd[e];
+          const unsigned off = 2u * (unsigned)((s * pix) * (int)p.d_sx + 32 * wid + 8 * hi) +
+                               2u * (unsigned)((s * Y0 + py) * (int)p.d_sy + (s * X0 + px) * (int)p.d_sx) + nt * 2u * (unsigned)(s * (int)p.d_sy) + 32 * pair;
+          *reinterpret_cast<h8*>(reinterpret_cast<char*>(p.dres + n * p.d_sn) + off) = hd;
+        }
+        if (pi + NQ < 16) {
+          if (HAS_RES) piece_loads(cur, pi + NQ, ql[pi % NQ], r, qm[pi % NQ]);
+          else piece_loads(cur, pi + NQ, r, ql[pi % NQ], qm[pi % NQ]);
+        }
       }
     }
   };
@@ -456,10 +481,13 @@ extern "C" int32_t csbsr_conv_tp_eligible(const csbsr_conv_desc_t* d) {
   if (d->in[1].c != 0 || d->in[0].sx == 0 || d->in[0].c != 128) return 0;
   if (d->coutp <= 64 || d->coutp > 128 || !d->out16 || d->out32 || d->cbias || d->o_lo || d->r_lo || d->r2_lo) return 0;
   if (d->stat_mode != CSBSR_STAT_NONE) return 0;
-  if (d->res_mode != CSBSR_RES_NONE && (d->accumulate || d->mask)) return 0;
+  // residual together with a mask: only as the masking layer's own residual (dres given: its gradient leaves as a second output)
+  if (d->res_mode != CSBSR_RES_NONE && (d->accumulate || (d->mask && !d->dres))) return 0;
+  if (d->dres && !(d->mask && d->res_mode != CSBSR_RES_NONE && !d->accumulate && d->H % TP_TH == 0 && d->W % TP_TW == 0 &&
+                   (long)d->OH * d->dr_sy < (1l << 31))) return 0;
   if ((d->accumulate || d->mask) && (d->bias || d->act != CSBSR_ACT_NONE)) return 0;
   // the fused bias / PReLU-slope sums: accumulate + mask launches over whole tiles (a dead lane would add its garbage to the sums)
-  if ((d->dact_bias || d->dact_prelu) && !(d->accumulate && d->mask && d->H % TP_TH == 0 && d->W % TP_TW == 0)) return 0;
+  if ((d->dact_bias || d->dact_prelu) && !((d->accumulate || d->dres) && d->mask && d->H % TP_TH == 0 && d->W % TP_TW == 0)) return 0;
   if (d->mask_prelu && !d->mask) return 0;
   if (d->res_mode != CSBSR_RES_NONE && d->res_mode != CSBSR_RES_ADD && d->res_mode != CSBSR_RES_SUB) return 0;
   if (d->act == CSBSR_ACT_SIGMOID) return 0;
@@ -517,6 +545,7 @@ extern "C" int csbsr_conv_tp_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   k.accumulate = d->accumulate;
   k.mask = reinterpret_cast<const half_t*>(d->mask); k.m_sn = d->m_sn; k.m_sy = d->m_sy; k.m_sx = d->m_sx; k.mask_slope = d->mask_slope;
   k.mask_prelu = d->mask_prelu; k.part = nullptr; k.part_ld = 0;
+  k.dres = reinterpret_cast<half_t*>(d->dres); k.d_sn = d->dr_sn; k.d_sy = d->dr_sy; k.d_sx = d->dr_sx;
   k.tiles_x = (unsigned)((d->W + TP_TW - 1) / TP_TW); k.tiles_y = (unsigned)((d->H + TP_TH - 1) / TP_TH);
   const unsigned nphase = (unsigned)(d->stride * d->stride);
   k.pg = nphase < TP_MAXPG ? nphase : TP_MAXPG;
@@ -541,6 +570,7 @@ extern "C" int csbsr_conv_tp_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   if (!r && !a && m) return launch_tp<2, false, false, true, false>(k, st, zp, nullptr, nullptr);
   if (!r && a && m && !st_) return launch_tp<2, false, true, true, false>(k, st, zp, nullptr, nullptr);
   if (!r && a && m && st_) return launch_tp<2, false, true, true, true>(k, st, zp, d->dact_bias, d->dact_prelu);
+  if (r && !a && m && d->dres) return launch_tp<2, true, false, true, true>(k, st, zp, d->dact_bias, d->dact_prelu);
   csbsr_set_error("conv_tp: residual together with accumulate / mask is not instantiated");
   return 1;
 }

@@ -253,7 +253,7 @@ class Conv:
         return (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
 
     def _launch(self, xs, wt, transposed, k, stride, pad, dil, H, W, OH, OW, cout, out, out32, bias, act, slope, prelu, res, res2,
-                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None, hr=None, tp=None, dact=None, x3=None):
+                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None, hr=None, tp=None, dact=None, x3=None, dres=None):
         d = L.ConvDesc()
         x0 = xs[0]
         if x0.lo:                       # split-fp16 input: [hi | lo] + hi again, weights from _pack_split
@@ -300,10 +300,18 @@ class Conv:
             d.mask_prelu = _ptr(below.prelu)
             d.dact_bias = None if (below.b is None or fz) else _ptr(grad_acc(below.b))
             d.dact_prelu = None if (below.prelu is None or fz) else _ptr(grad_acc(below.prelu))
+            if dres is not None:        # the layer below was out = act(pre) +- res: (res FM, FM receiving d(res), its res_mode)
+                rfm, dfm, rmode = dres
+                sn, sy, sx = rfm.strides()
+                d.res_mode, d.res, d.r_sn, d.r_sy, d.r_sx = rmode, _ptr(rfm.t), sn, sy, sx
+                sn, sy, sx = dfm.strides()
+                d.dres, d.dr_sn, d.dr_sy, d.dr_sx = _ptr(dfm.t), sn, sy, sx
             if use_tp and L.load().csbsr_conv_tp_eligible(C.byref(d)):
                 self.last_fused = True
             else:
                 d.mask, d.mask_prelu, d.dact_bias, d.dact_prelu = None, None, None, None
+                if dres is not None:
+                    d.res_mode, d.res, d.dres = L.RES_NONE, None, None
         tm = self.eng.timing
         if tm is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -378,13 +386,13 @@ class Conv:
                      x3=(0, self.cin, self.cout, 0, 0) if (not sp and not self.transposed and self.k == 3 and len(xs) == 1) else None)
         return out
 
-    def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None, mask=None, dact=None):
+    def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None, mask=None, dact=None, dres=None):
         """dgrad wrt input segment ``seg``; dpre: gradient wrt the pre-activation output (FM, may be bcast).
         ``mask`` = (saved output FM of the layer that produced this input, its negative slope): the activation derivative of that layer
         is applied in the epilogue, so what leaves is its dPre (only on the launch that completes the gradient).
         ``dact`` = (Conv of the layer below, its saved output FM): like ``mask`` but also that layer's bias / PReLU-slope gradient sums,
         i.e. its whole epilogue-backward pass; taken only where the fused kernel exists -- ``self.last_fused`` tells the caller
-        whether it still has to run that pass."""
+        whether it still has to run that pass.  ``dres`` = (res FM, FM for d(res), res_mode) when that layer was out = act(pre) +- res."""
         c_seg = self.split[seg]
         row_off = 0 if seg == 0 else self.split[0]
         k, s, p, d = self.k, self.stride, self.pad, self.dil
@@ -419,7 +427,7 @@ class Conv:
         self._launch((dpre, dpre) if hp else (dpre,), wt, tr, k, ps, pp, dd, H, W, OH, OW, c_seg, out, out32, None, L.ACT_NONE, 0.0, None,
                      None, None, L.RES_NONE, accumulate, stat, L.STAT_SAMPLE_SUM if stat is not None else L.STAT_NONE,
                      1.0 / self.WSCALE if hp else 1.0, mask=mask, hr=hr,
-                     tp=(self.cout, c_seg, row_off, 0) if (tr and not hp and stat is None) else None, dact=dact,
+                     tp=(self.cout, c_seg, row_off, 0) if (tr and not hp and stat is None) else None, dact=dact, dres=dres,
                      x3=(1, self.cout, c_seg, row_off, 0) if (not hp and not self.transposed and s == 1 and k == 3 and stat is None) else None)
         return out
 

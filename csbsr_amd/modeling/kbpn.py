@@ -292,9 +292,12 @@ class KBPN:
                 dl0 = e.new(B, h, w, 128)
                 self._act_bwd(st.down3, dlow_s, lows, res=q["l0"], res_mode=L.RES_ADD, dres=dl0)
                 self._wg(st.down3, dlow_s, q["dd"])
-                ddd = st.down3.bwd_input(dlow_s, in_hw=(H, W))
+                # (down_conv2's epilogue-backward pass -- PReLU derivative from dd + xd, bias / slope sums, d(xd) = -dOut -- rides on
+                # down_conv3's dgrad where the phase-decomposed kernel takes the launch)
                 dxd = e.new(B, H, W, 128)
-                self._act_bwd(st.down2, ddd, q["dd"], res=q["xd"], res_mode=L.RES_SUB, dres=dxd)
+                ddd = st.down3.bwd_input(dlow_s, in_hw=(H, W), dact=(st.down2, q["dd"]), dres=(q["xd"], dxd, L.RES_SUB))
+                if not st.down3.last_fused:
+                    self._act_bwd(st.down2, ddd, q["dd"], res=q["xd"], res_mode=L.RES_SUB, dres=dxd)
                 self._wg(st.down2, ddd, q["l0"])
                 st.down2.bwd_input(ddd, out=dl0, accumulate=True, in_hw=(h, w))
                 del ddd

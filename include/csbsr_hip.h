@@ -92,6 +92,10 @@ typedef struct {
    * with mask <= 0 of (unmasked result) x mask / slope, i.e. exactly what csbsr_epilogue_backward adds for that layer
    * (kbpn.py:230-262: the PReLU of a DeconvBlock / ConvBlock whose input gradient this launch completes) */
   const float* mask_prelu; float* dact_bias; float* dact_prelu;
+  /* csbsr_conv_tp_forward only: the masking layer had a residual (out = act(pre) +- res: res / res_mode describe IT, not this launch):
+   * its activation is rebuilt as mask -+ res, and dres (fp16 NHWC, same geometry as out16) receives d(res) = +- the unmasked result
+   * (kbpn.py:254-256, DownBlock: l1 = down_conv3(h0 - x)) */
+  void* dres; int64_t dr_sn, dr_sy, dr_sx;
 } csbsr_conv_desc_t;
 
 int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);

@@ -450,3 +450,47 @@ def test_thin_transposed_conv_from_image(k, s, p, cout, H, W, mode):
     c8 = pad8(cout) // 8
     assert (L.load().csbsr_debug_last_conv_kernel() == 11) == (256 % c8 == 0 and (256 // c8) % s == 0)
     assert relmax(from_fm(y), ref) < 2e-3
+
+
+@pytest.mark.parametrize("H,W", [(16, 32), (8, 64)])
+def test_phase_decomposed_dgrad_with_the_residual_layers_epilogue_backward(H, W):
+    """down_conv3's dgrad completing d(dd) where the layer below is down_conv2, out = PReLU(deconv + b) - xd (kbpn.py:254-256): the
+    activation is rebuilt as (dd + xd), the masked gradient + bias / slope sums leave as for the plain case, and d(xd) = -dOut is the
+    second output -- against torch autograd of  conv2d(prelu(z + b, a) - xd)."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv, grad_acc
+    torch.manual_seed(H + W)
+    eng = _eng()
+    lib = L.load()
+    N, C, k, s, p = 2, 128, 8, 4, 2
+    IH, IW = s * H, s * W
+    w = (torch.randn(C, C, k, k) / (C * 4) ** 0.5).half().float()
+    conv = Conv(eng, "l", {"l.weight": w.cuda()}, k, s, p, 1, bias=False, act=L.ACT_NONE)
+    a0, b0 = torch.tensor([0.25]), (torch.randn(C) * 0.1)
+    pb = {"b.weight": torch.zeros(C, C, k, k).cuda(), "b.bias": b0.clone().cuda(), "a": a0.clone().cuda()}
+    below = Conv(eng, "b", pb, k, s, p, 1, transposed=True, bias=True, act=L.ACT_PRELU, prelu="a")
+    below.frozen = False
+    act16 = F.prelu(torch.randn(N, C, IH, IW) + b0[None, :, None, None], a0).half().float()       # act(pre) as stored
+    xd = torch.randn(N, C, IH, IW).half().float()
+    dd = (act16 - xd).half().float()                     # the saved output of the layer below
+    y = dd + xd                                          # what the kernel rebuilds the activation from
+    dpre = torch.randn(N, C, H, W).half().float()
+    ddr = dd.clone().requires_grad_(True)
+    (F.conv2d(ddr, w, None, s, p) * dpre).sum().backward()
+    dy = ddr.grad                                        # d(dd): no accumulate in this launch
+    neg = ~(y > 0)
+    ref_dz = torch.where(neg, dy * a0, dy)
+    ref_db = ref_dz.sum((0, 2, 3))
+    ref_da = (dy * (y / a0))[neg].sum()
+    lib.csbsr_debug_set_conv_tp(2)
+    try:
+        dxd = to_fm(eng, torch.zeros_like(xd))
+        out = conv.bwd_input(to_fm(eng, dpre), in_hw=(IH, IW), dact=(below, to_fm(eng, dd)), dres=(to_fm(eng, xd), dxd, L.RES_SUB))
+        torch.cuda.synchronize()
+    finally:
+        lib.csbsr_debug_set_conv_tp(1)
+    assert conv.last_fused and lib.csbsr_debug_last_conv_kernel() == 9
+    assert relmax(from_fm(out), ref_dz) < 2e-3
+    assert relmax(from_fm(dxd), -dy) < 2e-3
+    assert relmax(grad_acc(pb["b.bias"]).cpu(), ref_db) < 2e-3
+    assert abs(float(grad_acc(pb["a"]).cpu()) - float(ref_da)) < 2e-3 * float((dy * (y / a0))[neg].abs().sum()) ** 0.5 + 2e-3 * abs(float(ref_da))
