@@ -62,14 +62,14 @@ __device__ __forceinline__ void tp_wait_barrier_all() {
 }
 // where one phase of one tile lands: image bases + byte offset of the tile's first pixel of that phase + what part of it is inside
 struct TpCtx {
-  const char *ob, *rb, *mb;
-  unsigned to, tr, tm;
+  const char *ob, *rb, *mb, *db;
+  unsigned to, tr, tm, td;
   int xlim, ylim;                   // lane live iff pix < xlim; the wave's row nt live iff nt < ylim
 };
 
-// HAS_STAT (accumulate + mask launches): also the masking layer's bias / PReLU-slope gradient sums.  Their 17 per-lane accumulators do
-// not fit next to two accumulator sets (256 of the 512 registers are AGPRs, which only MFMA results can live in), so that variant is
-// NOT software-pipelined: one accumulator set, the epilogue of a phase runs right after its K loop.
+// HAS_STAT (accumulate / residual + mask launches): also the masking layer's bias / PReLU-slope gradient sums.  The 16 per-lane bias
+// sums do not fit next to two accumulator sets in the 256 arch VGPRs (the other 256 registers are AGPRs, which only MFMA results can
+// live in), so they live in LDS: the lane read-modify-writes its own slots once per piece.
 template <int NKC, bool HAS_RES, bool HAS_ACC, bool HAS_MASK, bool HAS_STAT>
 __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const half_t* __restrict__ zero_page, half_t* __restrict__ sink) {
   constexpr int SLOTS = NKC * 8 + 1;                    // 16-byte slots per pixel: odd -> consecutive pixels walk all banks
@@ -79,11 +79,12 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   constexpr int XBYTES = NINST * 1024;
   constexpr int BOFF = XBYTES;                          // 128 biases
   constexpr int DOFF = BOFF + 512;                      // 1 KB landing area for the halo DMA's padding instructions
+  constexpr int SOFF = DOFF + 1024;                     // HAS_STAT: per-lane bias-gradient partial sums, [wave][octet half 0..3][lane] float4
   constexpr int NKS = 4 * NKC;                          // K steps per phase (64 channels of one tap each)
   constexpr int PPS = 16 / NKS;                         // epilogue pieces (of the previous phase) drained per K step
   constexpr int NFI = (NINST + 3) / 4;
   constexpr int DQ = 256 / SLOTS, DC = 256 % SLOTS;
-  constexpr bool PIPE = !HAS_STAT;
+  constexpr bool PIPE = true;
   constexpr int WD = PIPE ? 3 : 1;                      // weight stages in flight ahead of the MFMAs (WD + 1 register buffers)
   static_assert(NKS % (WD + 1) == 0 && PPS == 2, "buffer indices must be compile-time across phases");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -109,6 +110,8 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   const unsigned lane_r = 2u * (unsigned)((s * pix) * (int)p.r_sx + 32 * wid + 8 * hi);
   const unsigned lane_m = 2u * (unsigned)((s * pix) * (int)p.m_sx + 32 * wid + 8 * hi);
   const unsigned row_o = 2u * (unsigned)(s * (int)p.o_sy), row_r = 2u * (unsigned)(s * (int)p.r_sy), row_m = 2u * (unsigned)(s * (int)p.m_sy);
+  const unsigned lane_d = 2u * (unsigned)((s * pix) * (int)p.d_sx + 32 * wid + 8 * hi), row_d = 2u * (unsigned)(s * (int)p.d_sy);
+  f4* const sSb = reinterpret_cast<f4*>(smem + SOFF) + wid * 256 + lane;      // this lane's four float4 slots: + 64 * (2 * pair + half)
   char* const sink_l = reinterpret_cast<char*>(sink) + lane * 16;
 
   // halo-tile DMA roles (same for every tile): chunk g = (wid + 4 i) * 64 + lane = (halo pixel q, slot c)
@@ -162,13 +165,19 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   // store chunk c = 0..3: residual / old output / activation mask on couts c and 4 + c
   // (HAS_STAT: the masking layer's bias gradient = per-channel sum of the masked result, its PReLU-slope gradient = sum over the
   // pixels with mask <= 0 of (unmasked result) x mask, divided by the slope at the end -- csbsr_epilogue_backward's sums, per lane)
-  float sb[HAS_STAT ? 16 : 1], sp = 0.f;
+  // The 16 bias-gradient sums of a lane live in LDS (read-modify-write of the lane's own slots once per piece): next to two accumulator
+  // sets there is no room for them in the 256 arch VGPRs -- and a loop-carried register for the slope sum alone costs 140 spills, so
+  // that one is summed per piece (vd[8] / spl) and added to an LDS slot too.
+  float* const sSpL = reinterpret_cast<float*>(smem + SOFF + 4 * 256 * 16) + wid * 64 + lane;
+  if (HAS_STAT) {
 #pragma unroll
-  for (int e = 0; e < (HAS_STAT ? 16 : 1); ++e) sb[e] = 0.f;
+    for (int q = 0; q < 4; ++q) sSb[64 * q] = f4{0.f, 0.f, 0.f, 0.f};
+    *sSpL = 0.f;
+  }
   // HAS_STAT with a residual operand: the masking layer was out = act(pre) +- res (DownBlock's down_conv2, kbpn.py:254-256), so its
   // activation is (mask -+ res), the residual does NOT enter this launch's result, and d(res) = +- (unmasked result) is a second output
-  float vd[(HAS_STAT && HAS_RES) ? 8 : 1];
-  auto store_chunk = [&](int pair, int c, float (&v)[8], const h8& r, const h8& o, const h8& m) __attribute__((always_inline)) {
+  auto store_chunk = [&](int pair, int c, float (&v)[8], float (&vd)[9], const h8& r, const h8& o, const h8& m) __attribute__((always_inline)) {
+    if (HAS_STAT && c == 0) vd[8] = 0.f;
 #pragma unroll
     for (int e = c; e < 8; e += 4) {
       if (has_res && !HAS_STAT) v[e] += rsign * (float)r[e];
@@ -176,13 +185,12 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
       if (HAS_STAT && HAS_RES) vd[e] = rsign * v[e];
       if (has_mask) {
         const float mk = (HAS_STAT && HAS_RES) ? (float)m[e] - rsign * (float)r[e] : (float)m[e];
-        if (HAS_STAT) sp += mk > 0.f ? 0.f : v[e] * mk;
+        if (HAS_STAT) vd[8] += mk > 0.f ? 0.f : v[e] * mk;
         v[e] *= (mk > 0.f ? 1.f : mslope);
-        if (HAS_STAT) sb[8 * pair + e] += v[e];
       }
     }
   };
-  auto store_fin = [&](const TpCtx& c, int pi, const float (&v)[8]) __attribute__((always_inline)) {
+  auto store_fin = [&](const TpCtx& c, int pi, const float (&v)[8], const float (&vd)[9]) __attribute__((always_inline)) {
     const int nt = pi >> 1, pair = pi & 1;
     h8 hv;
 #pragma unroll
@@ -191,13 +199,31 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     const unsigned off = lane_o + c.to + nt * row_o + 32 * pair;
     char* dst = lv ? const_cast<char*>(c.ob) + off : sink_l;
     *reinterpret_cast<h8*>(dst) = hv;
+    if (HAS_STAT) {
+      f4 a = sSb[64 * (2 * pair)], b = sSb[64 * (2 * pair + 1)];
+      a += f4{v[0], v[1], v[2], v[3]}; b += f4{v[4], v[5], v[6], v[7]};
+      sSb[64 * (2 * pair)] = a; sSb[64 * (2 * pair + 1)] = b;
+      *sSpL += vd[8];
+    }
+    if (HAS_STAT && HAS_RES) {
+      h8 hd;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) hd[e] = (half_t)vd[e];
+      const unsigned offd = lane_d + c.td + nt * row_d + 32 * pair;
+      char* dd = lv ? const_cast<char*>(c.db) + offd : sink_l;
+      *reinterpret_cast<h8*>(dd) = hd;
+    }
   };
 
   TpCtx cur, pend;
   cur.ob = pend.ob = reinterpret_cast<const char*>(p.out16);
   cur.rb = pend.rb = reinterpret_cast<const char*>(has_res ? p.res : p.out16);
   cur.mb = pend.mb = reinterpret_cast<const char*>(has_mask ? p.mask : p.out16);
-  cur.to = cur.tr = cur.tm = pend.to = pend.tr = pend.tm = 0u;
+  cur.db = pend.db = reinterpret_cast<const char*>(p.out16);
+  cur.to = cur.tr = cur.tm = cur.td = pend.to = pend.tr = pend.tm = pend.td = 0u;
+  if (HAS_STAT) {      // the not-yet-existing pending tile must add exact zeros to the sums: its operand loads hit the zero page (its
+    pend.ob = pend.mb = pend.rb = reinterpret_cast<const char*>(zero_page);      // accumulators are zero, its stores go to the sink)
+  }
   cur.xlim = cur.ylim = pend.xlim = pend.ylim = 0;        // nothing pending yet: its pieces load offset 0 and store to the sink
   // piece operands are requested LD K steps before the piece retires (LD + 1 register buffers; 8 % (LD + 1) == 0 keeps the indices
   // compile-time across phases): three steps (~1.7 us) ahead when only one operand is read, one step when two are (register budget)
@@ -216,8 +242,6 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     for (int d = 0; d < WD; ++d) load_w(w0 + d * stage_elems, wreg[d]);
   }
   h8 bfr[8];                                              // B fragments of the k-slice in flight: pixel row nt, one read per MFMA
-  constexpr int NQ = HAS_RES ? 8 : 16;                   // (!PIPE) pieces whose operands are requested before the K loop (the residual
-  h8 ql[PIPE ? 1 : NQ], qm[PIPE ? 1 : NQ];                // variant has the second output's registers to pay for: the other 8 as pieces retire)
 
   unsigned pgi = 0, itn = 0;
   int n = 0, Y0 = 0, X0 = 0;
@@ -241,6 +265,10 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     cur.to = 2u * (unsigned)((s * Y0 + py) * (int)p.o_sy + (s * X0 + px) * (int)p.o_sx);
     cur.tr = 2u * (unsigned)((s * Y0 + py) * (int)p.r_sy + (s * X0 + px) * (int)p.r_sx);
     cur.tm = 2u * (unsigned)((s * Y0 + py) * (int)p.m_sy + (s * X0 + px) * (int)p.m_sx);
+    if (HAS_STAT && HAS_RES) {
+      cur.db = reinterpret_cast<const char*>(p.dres + n * p.d_sn);
+      cur.td = 2u * (unsigned)((s * Y0 + py) * (int)p.d_sy + (s * X0 + px) * (int)p.d_sx);
+    }
     cur.xlim = p.W - X0; cur.ylim = p.H - Y0;
     // B fragment (row nt) of k-slice (ks, kk) of the phase whose lane base is xb
     auto rdb = [&](const char* xb, int ks, int kk, int nt) __attribute__((always_inline)) {
@@ -275,14 +303,6 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     for (int a = 0; a < 8; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-    if (!PIPE) {
-      h8 r_;
-#pragma unroll
-      for (int pi = 0; pi < NQ; ++pi) {
-        if (HAS_RES) piece_loads(cur, pi, ql[pi], r_, qm[pi]);
-        else piece_loads(cur, pi, r_, ql[pi], qm[pi]);
-      }
-    }
 
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
@@ -297,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
       // the weight stage WD steps ahead
       load_w(ks + WD < NKS ? wcur + (ks + WD) * stage_elems : wnext + (ks + WD - NKS) * stage_elems, wreg[(ks + WD) % (WD + 1)]);
       __builtin_amdgcn_sched_barrier(0);
-      float v[PPS][8];
+      float v[PPS][8], vdd[HAS_STAT ? PPS : 1][9];     // [8]: the piece's slope-gradient sum
       f4 bq[PPS][2];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -316,44 +336,14 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
           for (int pp = 0; pp < PPS; ++pp) {
             const int k_act = 2 * pp, k_st = k_act + 1;
             if (kk == k_act && i < 4) act_chunk(pd, ks * PPS + pp, i, v[pp], bq[pp]);
-            if (kk == k_st && i < 4) store_chunk((ks * PPS + pp) & 1, i, v[pp], lr[ks % NB][pp], lo[ks % NB][pp], lm[ks % NB][pp]);
-            if (kk == k_st && i == 4) store_fin(pend, ks * PPS + pp, v[pp]);
+            if (kk == k_st && i < 4) store_chunk((ks * PPS + pp) & 1, i, v[pp], vdd[HAS_STAT ? pp : 0], lr[ks % NB][pp], lo[ks % NB][pp], lm[ks % NB][pp]);
+            if (kk == k_st && i == 4) store_fin(pend, ks * PPS + pp, v[pp], vdd[HAS_STAT ? pp : 0]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
     pend = cur;
-    if (!PIPE) {
-      // one accumulator set: this phase's 16 pieces now; their operands were requested before the K loop (ql / qm)
-#pragma unroll
-      for (int pi = 0; pi < 16; ++pi) {
-        float v[8];
-        f4 bq[2];
-        h8 r = h8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) act_chunk(acc, pi, c, v, bq);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if (HAS_RES) store_chunk(pi & 1, c, v, ql[pi % NQ], r, qm[pi % NQ]);      // (ql holds the residual operand in this variant)
-          else store_chunk(pi & 1, c, v, r, ql[pi % NQ], qm[pi % NQ]);
-        }
-        store_fin(cur, pi, v);
-        if (HAS_RES) {
-          const int nt = pi >> 1, pair = pi & 1;
-          h8 hd;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) hd[e] = (half_t)vd[e];
-          const unsigned off = 2u * (unsigned)((s * pix) * (int)p.d_sx + 32 * wid + 8 * hi) +
-                               2u * (unsigned)((s * Y0 + py) * (int)p.d_sy + (s * X0 + px) * (int)p.d_sx) + nt * 2u * (unsigned)(s * (int)p.d_sy) + 32 * pair;
-          *reinterpret_cast<h8*>(reinterpret_cast<char*>(p.dres + n * p.d_sn) + off) = hd;
-        }
-        if (pi + NQ < 16) {
-          if (HAS_RES) piece_loads(cur, pi + NQ, ql[pi % NQ], r, qm[pi % NQ]);
-          else piece_loads(cur, pi + NQ, r, ql[pi % NQ], qm[pi % NQ]);
-        }
-      }
-    }
   };
 
   f16v accA[8], accB[8];
@@ -369,13 +359,9 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     const unsigned r_ = tile - n * per_img;
     Y0 = (r_ / p.tiles_x) * TP_TH; X0 = (r_ % p.tiles_x) * TP_TW;
     itn = it + gridDim.x;
-    if (PIPE) {
-      for (unsigned j = 0; j < p.pg; j += 2) {           // (pg is even: the accumulator sets alternate)
-        phase(accA, accB, j, j == 0);
-        phase(accB, accA, j + 1, false);
-      }
-    } else {
-      for (unsigned j = 0; j < p.pg; ++j) phase(accA, accA, j, j == 0);
+    for (unsigned j = 0; j < p.pg; j += 2) {             // (pg is even: the accumulator sets alternate)
+      phase(accA, accB, j, j == 0);
+      phase(accB, accA, j + 1, false);
     }
   }
   // ---- the last phase's accumulators (in accB) drain on their own
@@ -388,18 +374,25 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     piece_loads(pend, pi, r, o, m);
 #pragma unroll
     for (int c = 0; c < 4; ++c) act_chunk(accB, pi, c, v, bq);
+    float vd[9];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) store_chunk(pi & 1, c, v, r, o, m);
-    store_fin(pend, pi, v);
+    for (int c = 0; c < 4; ++c) store_chunk(pi & 1, c, v, vd, r, o, m);
+    store_fin(pend, pi, v, vd);
   }
   if (HAS_STAT) {
     // lanes of one half-wave hold the same couts (32 wid + 16 pair + 8 hi + e at sb[8 pair + e]) for 32 different pixels
+    float sb[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f4 t = sSb[64 * q];
+      sb[4 * q] = t[0]; sb[4 * q + 1] = t[1]; sb[4 * q + 2] = t[2]; sb[4 * q + 3] = t[3];
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
 #pragma unroll
       for (int o = 1; o < 32; o <<= 1) sb[e] += __shfl_xor(sb[e], o, 64);
     }
-    sp = wave_sum(sp);
+    float sp = wave_sum(*sSpL);
     float* row = p.part + (size_t)blockIdx.x * p.part_ld;
     float* sSp = reinterpret_cast<float*>(smem + DOFF);           // (the halo DMA's padding KB is idle by now)
     __syncthreads();
@@ -505,7 +498,7 @@ template <int NKC, bool R, bool A, bool M, bool S>
 static int launch_tp(ConvTpK& k, hipStream_t st, half_t* zp, float* dbias, float* dprelu) {
   constexpr int SLOTS = NKC * 8 + 1;
   constexpr int NINST = (TP_NPIX * SLOTS + 63) / 64;
-  constexpr int SM_BYTES = NINST * 1024 + 128 * 4 + 1024;
+  constexpr int SM_BYTES = NINST * 1024 + 128 * 4 + 1024 + 4 * 256 * 16 + 1024;
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
