@@ -76,6 +76,8 @@ SIGNATURES = {
     "csbsr_conv_x3_forward": (i32, [C.POINTER(ConvDesc), vp]),
     "csbsr_packed_weight_elems_x3": (i64, [i32, i32]),
     "csbsr_pack_weights_x3": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "csbsr_packed_weight_elems_x3_strided": (i64, [i32, i32, i32]),
+    "csbsr_pack_weights_x3_strided": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "csbsr_conv_tp_eligible": (i32, [C.POINTER(ConvDesc)]),
     "csbsr_conv_tp_forward": (i32, [C.POINTER(ConvDesc), vp]),
     "csbsr_packed_weight_elems_tp": (i64, [i32, i32]),

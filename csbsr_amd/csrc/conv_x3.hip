@@ -19,22 +19,44 @@
 #include "conv_common.h"
 #include "csbsr_debug.h"
 
+//
+// KS = 2: the same machine for the 8x8 stride-4 convolutions (k = 2 x stride: DownBlock / UpBlock strided convs and the dgrads of the
+// 8x8 stride-4 deconvolutions, kbpn.py:215-262 -- the step's dominant MFMA launches).  Output pixel (y, x) reads input
+// (s (y + jy) + py - pad, s (x + jx) + px - pad) for kernel offset (s jy + py, s jx + px): for one input PHASE (py, px) that is a 2 x 2-tap
+// stride-1 convolution of the phase's sub-sampled grid, so a chunk is (phase, 64 channels), its halo the (8+1) x (32+1) sub-grid
+// pixels of the tile (every input pixel crosses the fabric ONCE per tile instead of once per tap it belongs to), and the accumulators
+// simply run over all s^2 x cin/64 chunks: K = 64 s^2 cin/64 x 4 taps = 8192 for 128 channels.
 #define X3_TH 8
 #define X3_TW 32
-#define X3_HW (X3_TW + 2)
-#define X3_HH (X3_TH + 2)
-#define X3_NPIX (X3_HH * X3_HW)           // 340 halo pixels
 #define X3_SLOTS 9                        // 64 channels = 8 sixteen-byte slots + 1 pad slot: odd pitch, conflict-free rows of pixels
 #define X3_PITCH (X3_SLOTS * 16)
-#define X3_NINST ((X3_NPIX * X3_SLOTS + 63) / 64)       // 48 wave instructions fill one chunk buffer
-#define X3_BUF (X3_NINST * 1024)
 #define X3_WSTEP 16384                    // bytes of one K step's weights for the 128-cout tile: [wave mt][k-slice kk][lane][8]
+// KS x KS taps per chunk: halo (8 + KS - 1) x (32 + KS - 1) pixels (340 / 297), filled by 48 / 44 wave instructions (a multiple of 4)
+constexpr int x3_ninst(int KS) { return (((X3_TH + KS - 1) * (X3_TW + KS - 1) * X3_SLOTS + 63) / 64 + 3) / 4 * 4; }
+constexpr int x3_buf(int KS) { return x3_ninst(KS) * 1024; }
 
 struct X3Extra {
-  unsigned tiles_x, tiles_y, nct, nch;   // pixel tiles, 128-cout tiles, 64-channel chunks
+  unsigned tiles_x, tiles_y, nct, nch;   // pixel tiles, 128-cout tiles, chunks (64 channels [x input phase])
+  unsigned ncc;                          // 64-channel chunks per input phase (KS = 2)
 };
 
+// (the buffer-descriptor type and builtins exist in the device pass only: the host pass sees an empty kernel body and emits the stub)
+#if defined(__HIP_DEVICE_COMPILE__)
+// buffer descriptor over [base, base + 2 GB) built from provably wave-uniform halves (offsets >= 0x7fffffff read as zeros)
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_make_rs(const half_t* base) {
+  const unsigned long a = reinterpret_cast<unsigned long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long)hi_ << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+#endif
+
+template <int KS>
 __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Extra q, const half_t* __restrict__ zero_page) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int X3_HW = X3_TW + KS - 1, X3_HH = X3_TH + KS - 1;
+  constexpr int X3_NINST = x3_ninst(KS), X3_BUF = x3_buf(KS);
+  constexpr int NT = KS * KS;                           // K steps (taps) per chunk
+  constexpr int RING = NT % 3 == 0 ? 3 : 4, DIST = RING - 1;      // weight register ring; loads run DIST K steps ahead (NT % RING == 0)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,24 +78,48 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
     f_ty0 = hq / X3_HW;
     f_tx0 = hq - f_ty0 * X3_HW;
   }
-  constexpr int NFI = X3_NINST / 4;                  // 12 instructions per wave (48 = 4 x 12 exactly)
+  constexpr int NFI = X3_NINST / 4;                  // 12 / 11 instructions per wave
   constexpr int DQ = 256 / X3_SLOTS, DC = 256 % X3_SLOTS;
-  auto issue_x = [&](int n, int Y0, int X0, int chunk, int buf) {
-    const half_t* tbase = in0 + n * p.in[0].sn + (long)(Y0 - 1) * p.in[0].sy + (long)(X0 - 1) * p.in[0].sx + chunk * 64;
+  // The DMA of a chunk is issued one instruction per k-slice INSIDE the previous chunk's K loop (a burst of 11-12 address computations
+  // + LDS-DMA issues at the chunk boundary idles the MFMA pipe for ~1.5k cycles, a third of a 2 x 2-tap chunk), as buffer loads: the
+  // per-lane byte offset and halo coordinates of each instruction are kernel constants, the chunk enters through the (uniform) base
+  // of the buffer descriptor, and lanes outside the image get an out-of-range offset, i.e. zeros, from the hardware bounds check.
+  const int st = KS == 3 ? 1 : p.stride;               // input pixels per halo pixel
+  int voff[NFI], iy0[NFI], ix0[NFI];
+  {
     int ty = f_ty0, tx = f_tx0, c = f_c0;
-#pragma unroll 2
+#pragma unroll
     for (int i = 0; i < NFI; ++i) {
-      const int inst = wid + 4 * i;
-      const int iy = Y0 - 1 + ty, ix = X0 - 1 + tx;
-      const bool ok = ty < X3_HH && c < 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const half_t* src = ok ? tbase + (ty * isy + tx * isx + c * 8) : zp;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(smem + buf * X3_BUF + inst * 1024), 16, 0, 0);
+      const bool in = ty < X3_HH && c < 8;
+      voff[i] = 2 * (ty * st * isy + tx * st * isx + c * 8);
+      iy0[i] = in ? st * ty : 0x40000000;
+      ix0[i] = st * tx;
       c += DC; tx += DQ;
       if (c >= X3_SLOTS) { c -= X3_SLOTS; ++tx; }
       if (tx >= X3_HW) { tx -= X3_HW; ++ty; }
       if (tx >= X3_HW) { tx -= X3_HW; ++ty; }
     }
+  }
+  // (uniform) source of chunk `chunk` of tile (n, Y0, X0): the input coordinates of halo pixel (0, 0) and its address
+  auto chunk_src = [&](int n, int Y0, int X0, int chunk, int& by, int& bx) -> const half_t* {
+    int coff;
+    if (KS == 3) { by = Y0 - 1; bx = X0 - 1; coff = chunk * 64; }
+    else {
+      const int ph = chunk / (int)q.ncc, py = ph / p.stride;
+      by = Y0 * p.stride + py - p.pad; bx = X0 * p.stride + (ph - py * p.stride) - p.pad; coff = (chunk - ph * (int)q.ncc) * 64;
+    }
+    return in0 + n * p.in[0].sn + (long)by * p.in[0].sy + (long)bx * p.in[0].sx + coff;
+  };
+  auto issue_one = [&](__amdgpu_buffer_rsrc_t rs, int by, int bx, int i, int buf) __attribute__((always_inline)) {
+    const bool ok = (unsigned)(iy0[i] + by) < (unsigned)p.H && (unsigned)(ix0[i] + bx) < (unsigned)p.W;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + buf * X3_BUF + (wid + 4 * i) * 1024), 16,
+                                             ok ? voff[i] : -1, 0, 0, 0);
+  };
+  auto issue_x = [&](int n, int Y0, int X0, int chunk, int buf) {
+    int by, bx;
+    const __amdgpu_buffer_rsrc_t rs = x3_make_rs(chunk_src(n, Y0, X0, chunk, by, bx));
+#pragma unroll
+    for (int i = 0; i < NFI; ++i) issue_one(rs, by, bx, i, buf);
   };
   auto decode = [&](unsigned item, int& ct, int& n, int& Y0, int& X0) {
     ct = item / ntiles;                                  // cout-tile-major: everybody streams the same weight slice
@@ -88,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
   const int mh = wid & 1, rq = wid >> 1;
   const unsigned wlane = (unsigned)(mh * 8192 + lane * 16);
   auto load_w = [&](int ct, int step, h8 (&w)[2][4]) __attribute__((always_inline)) {
-    const char* b = reinterpret_cast<const char*>(p.wt) + ((size_t)ct * q.nch * 9 + step) * X3_WSTEP;
+    const char* b = reinterpret_cast<const char*>(p.wt) + ((size_t)ct * q.nch * NT + step) * X3_WSTEP;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -99,10 +145,10 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
   int ct, n, Y0, X0;
   decode(it, ct, n, Y0, X0);
   issue_x(n, Y0, X0, 0, 0);
-  h8 wreg[3][2][4];                                       // K step g = chunk * 9 + tap lives in wreg[tap % 3] (9 % 3 == 0)
-  load_w(ct, 0, wreg[0]);
-  load_w(ct, 1, wreg[1]);
-  const int nsteps = (int)q.nch * 9;
+  h8 wreg[RING][2][4];                                    // K step g = chunk * NT + tap lives in wreg[tap % RING] (NT % RING == 0)
+#pragma unroll
+  for (int g = 0; g < DIST; ++g) load_w(ct, g, wreg[g]);
+  const int nsteps = (int)q.nch * NT;
 
   for (; it < items; it += gridDim.x) {
     const unsigned itn = it + gridDim.x;
@@ -119,40 +165,44 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
 
     for (int c = 0; c < (int)q.nch; ++c) {
       // chunk c's halo has landed everywhere, and every wave is done with the other buffer (chunk c - 1): refill that one.  The only
-      // vector-memory instructions issued after this chunk's DMA (a whole chunk ago) and possibly still in flight are the weight
-      // loads of the next two K steps (16) -- except right after an epilogue, where the count is simply drained.
+      // vector-memory instructions issued after this chunk's last DMA piece (k-slice NFI - 1 of the previous chunk) are the weight
+      // loads of the taps that followed it (8 each) -- except right after an epilogue, where the count is simply drained.
       if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NT - 1 - (NFI - 1) / 4)) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const int bnext = (int)((par + c + 1) & 1);
-      if (c + 1 < (int)q.nch) issue_x(n, Y0, X0, c + 1, bnext);
-      else if (itn < items) issue_x(nn, Y0n, X0n, 0, bnext);             // the next tile's first chunk
-      else issue_x(n, Y0, X0, 0, bnext);                                // keep the instruction count uniform (harmless refetch)
+      // the next chunk (past the tile's last one: the next tile's first; past the last tile: a harmless refetch that keeps the
+      // instruction count uniform), issued piece by piece below
+      int nby, nbx;
+      const half_t* nsrc = c + 1 < (int)q.nch ? chunk_src(n, Y0, X0, c + 1, nby, nbx)
+                                              : (itn < items ? chunk_src(nn, Y0n, X0n, 0, nby, nbx) : chunk_src(n, Y0, X0, 0, nby, nbx));
+      const __amdgpu_buffer_rsrc_t nrs = x3_make_rs(nsrc);
       asm volatile("" ::: "memory");
       const char* xb = xl + ((par + c) & 1) * X3_BUF;
       h8 bfr[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) bfr[nt] = *reinterpret_cast<const h8*>(xb + (nt * X3_HW) * X3_PITCH);      // tap (0,0), k-slice 0
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        // weights two K steps ahead (past the tile's last step: the next tile's first ones)
+      for (int tap = 0; tap < NT; ++tap) {
+        // weights DIST K steps ahead (past the tile's last step: the next tile's first ones)
         {
-          const int g = c * 9 + tap + 2;
-          if (g < nsteps) load_w(ct, g, wreg[(tap + 2) % 3]);
-          else load_w(ctn, g - nsteps, wreg[(tap + 2) % 3]);
+          const int g = c * NT + tap + DIST;
+          if (g < nsteps) load_w(ct, g, wreg[(tap + DIST) % RING]);
+          else load_w(ctn, g - nsteps, wreg[(tap + DIST) % RING]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const int ky = tap / 3, kx = tap % 3;
+        const int ky = tap / KS, kx = tap % KS;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap % 3][0][kk], bfr[i], acc[0][i], 0, 0, 0);
-            acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap % 3][1][kk], bfr[i], acc[1][i], 0, 0, 0);
+            acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap % RING][0][kk], bfr[i], acc[0][i], 0, 0, 0);
+            acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap % RING][1][kk], bfr[i], acc[1][i], 0, 0, 0);
             // the same row's fragment of the next k-slice / next tap (the next chunk starts over after its barrier)
             if (kk < 3) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + ky) * X3_HW + kx) * X3_PITCH + (kk + 1) * 32);
-            else if (tap < 8) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + (tap + 1) / 3) * X3_HW + (tap + 1) % 3) * X3_PITCH);
+            else if (tap < NT - 1) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + (tap + 1) / KS) * X3_HW + (tap + 1) % KS) * X3_PITCH);
+            if (i == 1 && tap * 4 + kk < NFI) issue_one(nrs, nby, nbx, tap * 4 + kk, bnext);       // one DMA piece per k-slice
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -181,30 +231,41 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
     }
     ct = ctn; n = nn; Y0 = Y0n; X0 = X0n;
   }
+#endif
 }
 
 // ---- weights in K-step order: dst[ct][chunk][tap][mt][kk][lane][e] = W(row 128 ct + 32 mt + perm(lane % 32), channel 64 chunk + 16 kk
 // + 8 (lane / 32) + e, tap), perm(8 q + 4 h + j) = 16 (q / 2) + 8 h + 4 (q % 2) + j (a lane's accumulator registers 8 pair .. 8 pair + 7
 // are then consecutive channels).  kind 0: forward, W is OIHW [row][channel][ky][kx]; kind 1: dgrad of the stride-1 conv: rows are the
 // conv's input channels, contracted channels its outputs, taps flipped (W[channel][row][2 - ky][2 - kx]).
-struct PackX3K { const float* w; half_t* dst; int kind, D1, nch, nct, c_real, rows_real, row_off, k_off; };
+struct PackX3K { const float* w; half_t* dst; int kind, D1, nch, nct, c_real, rows_real, row_off, k_off, ksize, stride, ncc; };
 __global__ void pack_weights_x3_kernel(const PackX3K p, long total) {
+  const int NT = p.kind == 2 ? 4 : 9;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), blk = (int)((i >> 9) & 15);
     const long stage = i >> 13;
-    const int tap = (int)(stage % 9);
-    const long t2 = stage / 9;
+    const int tap = (int)(stage % NT);
+    const long t2 = stage / NT;
     const int chunk = (int)(t2 % p.nch), ct = (int)(t2 / p.nch);
     const int mt = blk >> 2, kk = blk & 3;
     const int m = lane & 31, q_ = m >> 3, h_ = (m >> 2) & 1;
     const int row = 128 * ct + 32 * mt + 16 * (q_ >> 1) + 8 * h_ + 4 * (q_ & 1) + (m & 3);
-    const int c = 64 * chunk + 16 * kk + 8 * (lane >> 5) + e;
-    const int ky = tap / 3, kx = tap % 3;
     float v = 0.f;
-    if (row < p.rows_real && c < p.c_real) {
-      const int rr = p.row_off + row, cc = p.k_off + c;
-      if (p.kind == 0) v = p.w[(((long)rr * p.D1 + cc) * 3 + ky) * 3 + kx];
-      else v = p.w[(((long)cc * p.D1 + rr) * 3 + (2 - ky)) * 3 + (2 - kx)];
+    if (p.kind == 2) {
+      // chunk = (input phase, 64 channels); tap (jy, jx) is kernel offset (s jy + py, s jx + px)
+      const int ph = chunk / p.ncc, cc = chunk - ph * p.ncc;
+      const int c = 64 * cc + 16 * kk + 8 * (lane >> 5) + e;
+      const int kh = p.stride * (tap >> 1) + ph / p.stride, kw = p.stride * (tap & 1) + ph % p.stride;
+      if (row < p.rows_real && c < p.c_real)
+        v = p.w[(((long)(p.row_off + row) * p.D1 + p.k_off + c) * p.ksize + kh) * p.ksize + kw];
+    } else {
+      const int c = 64 * chunk + 16 * kk + 8 * (lane >> 5) + e;
+      const int ky = tap / 3, kx = tap % 3;
+      if (row < p.rows_real && c < p.c_real) {
+        const int rr = p.row_off + row, cc = p.k_off + c;
+        if (p.kind == 0) v = p.w[(((long)rr * p.D1 + cc) * 3 + ky) * 3 + kx];
+        else v = p.w[(((long)cc * p.D1 + rr) * 3 + (2 - ky)) * 3 + (2 - kx)];
+      }
     }
     p.dst[i] = (half_t)v;
   }
@@ -213,6 +274,18 @@ __global__ void pack_weights_x3_kernel(const PackX3K p, long total) {
 extern "C" int64_t csbsr_packed_weight_elems_x3(int32_t c_real, int32_t rows_real) {
   const int nch = (round_up(c_real, 8) + 63) / 64, nct = (round_up(rows_real, 8) + 127) / 128;
   return (int64_t)nct * nch * 9 * (X3_WSTEP / 2);
+}
+
+extern "C" int64_t csbsr_packed_weight_elems_x3_strided(int32_t stride, int32_t c_real, int32_t rows_real) {
+  const int ncc = (round_up(c_real, 8) + 63) / 64, nct = (round_up(rows_real, 8) + 127) / 128;
+  return (int64_t)nct * stride * stride * ncc * 4 * (X3_WSTEP / 2);
+}
+
+static int pack_x3_launch(PackX3K& p, long total, csbsr_stream_t s, const char* what) {
+  const long nb = (total + 255) / 256;
+  hipLaunchKernelGGL(pack_weights_x3_kernel, dim3((int)(nb > 8192 ? 8192 : nb)), dim3(256), 0, reinterpret_cast<hipStream_t>(s), p, total);
+  CSBSR_LAUNCH_CHECK(what);
+  return 0;
 }
 
 extern "C" int csbsr_pack_weights_x3(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
@@ -225,11 +298,23 @@ extern "C" int csbsr_pack_weights_x3(const float* w, void* dst, int32_t kind, in
   p.w = w; p.dst = reinterpret_cast<half_t*>(dst); p.kind = kind; p.D1 = D1;
   p.nch = (round_up(c_real, 8) + 63) / 64; p.nct = (round_up(rows_real, 8) + 127) / 128;
   p.c_real = c_real; p.rows_real = rows_real; p.row_off = row_off; p.k_off = k_off;
-  const long total = csbsr_packed_weight_elems_x3(c_real, rows_real);
-  const long nb = (total + 255) / 256;
-  hipLaunchKernelGGL(pack_weights_x3_kernel, dim3((int)(nb > 8192 ? 8192 : nb)), dim3(256), 0, reinterpret_cast<hipStream_t>(s), p, total);
-  CSBSR_LAUNCH_CHECK("csbsr_pack_weights_x3");
-  return 0;
+  p.ksize = 3; p.stride = 1; p.ncc = p.nch;
+  return pack_x3_launch(p, csbsr_packed_weight_elems_x3(c_real, rows_real), s, "csbsr_pack_weights_x3");
+}
+
+// k = 2 x stride convolution (or the dgrad of such a ConvTranspose2d): W is [row][contracted channel][kh][kw] -- a Conv2d's OIHW
+// parameter, or a ConvTranspose2d's IOHW parameter seen from its dgrad (rows = its input channels, contracted = its outputs)
+extern "C" int csbsr_pack_weights_x3_strided(const float* w, void* dst, int32_t D0, int32_t D1, int32_t ksize, int32_t stride,
+                                             int32_t c_real, int32_t rows_real, int32_t row_off, int32_t k_off, csbsr_stream_t s) {
+  CSBSR_CHECK(w && dst && stride >= 2 && ksize == 2 * stride, "pack_x3_strided: bad args (kernel size must be 2 x stride)");
+  CSBSR_CHECK(c_real >= 1 && rows_real >= 1 && k_off >= 0 && k_off + c_real <= D1 && row_off >= 0 && row_off + rows_real <= D0,
+              "pack_x3_strided: range out of bounds");
+  PackX3K p;
+  p.w = w; p.dst = reinterpret_cast<half_t*>(dst); p.kind = 2; p.D1 = D1;
+  p.ncc = (round_up(c_real, 8) + 63) / 64; p.nch = stride * stride * p.ncc; p.nct = (round_up(rows_real, 8) + 127) / 128;
+  p.c_real = c_real; p.rows_real = rows_real; p.row_off = row_off; p.k_off = k_off;
+  p.ksize = ksize; p.stride = stride;
+  return pack_x3_launch(p, csbsr_packed_weight_elems_x3_strided(stride, c_real, rows_real), s, "csbsr_pack_weights_x3_strided");
 }
 
 static int g_conv_x3_mode = 1;      // 0 off, 1 launches that fill the chip, 2 every eligible launch (tests)
@@ -240,26 +325,53 @@ extern "C" void csbsr_debug_set_conv_x3(int mode) { g_conv_x3_mode = mode; }
 // 693 -> 738, but 384 -> 825 800 -> 714 and 256 -> 697 817 -> 578: with few chunks the per-tile epilogue and pipeline restart outweigh
 // the K loop's gain; >= 128 when forced by csbsr_debug_set_conv_x3(2)), >= 72 padded output channels, fp16 output; any fused epilogue of the general kernels except statistics, the fp32 side
 // output and split (hi + lo) operands.
+static bool x3_is_strided(const csbsr_conv_desc_t* d) { return d->stride >= 2 && d->KH == 2 * d->stride; }
+
 extern "C" int32_t csbsr_conv_x3_eligible(const csbsr_conv_desc_t* d) {
-  if (!d || !g_conv_x3_mode || d->transposed || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != 1 || d->dil != 1) return 0;
-  if (d->in[1].c != 0 || d->in[0].sx == 0 || d->in[0].c < (g_conv_x3_mode == 2 ? 128 : 512) || d->in[0].c % 64 != 0) return 0;
+  if (!d || !g_conv_x3_mode || d->transposed || d->KH != d->KW || d->dil != 1) return 0;
+  const bool strided = x3_is_strided(d);
+  if (strided) {
+    // k = 2 x stride (8x8 stride 4): 64 .. 512 padded input channels in whole chunks, pad < stride, the exact strided output size
+    if (d->pad < 0 || d->pad >= d->stride || d->stride > 4) return 0;
+    if (d->OH != (d->H + 2 * d->pad - d->KH) / d->stride + 1 || d->OW != (d->W + 2 * d->pad - d->KW) / d->stride + 1) return 0;
+    if (d->in[0].c < 64 || d->in[0].c > 512 || d->in[0].c % 64 != 0) return 0;
+  } else {
+    if (d->KH != 3 || d->stride != 1 || d->pad != 1 || d->OH != d->H || d->OW != d->W) return 0;
+    if (d->in[0].c < (g_conv_x3_mode == 2 ? 128 : 512) || d->in[0].c % 64 != 0) return 0;
+  }
+  if (d->in[1].c != 0 || d->in[0].sx == 0) return 0;
   if (d->coutp < 72 || !d->out16 || d->out32 || d->o_lo || d->r_lo || d->r2_lo) return 0;
-  if (d->stat_mode != CSBSR_STAT_NONE || d->OH != d->H || d->OW != d->W) return 0;
+  if (d->stat_mode != CSBSR_STAT_NONE) return 0;
   if (d->mask_prelu || d->dact_bias || d->dact_prelu || d->dres) return 0;
-  if (d->in[0].sy >= (1l << 31) / 2) return 0;
-  if (g_conv_x3_mode == 1 && (long)d->N * d->H * d->W * ((d->coutp + 127) / 128) < 512L * X3_TH * X3_TW) return 0;
+  if (d->in[0].sy >= (1l << 31) / 2 / (strided ? 4 * (X3_TH + 1) : 1)) return 0;
+  if (g_conv_x3_mode == 1 && (long)d->N * d->OH * d->OW * ((d->coutp + 127) / 128) < 512L * X3_TH * X3_TW) return 0;
   return 1;
 }
 
 static half_t* g_x3_zero_page[CSBSR_MAX_DEVICES] = {};
 
+template <int KS>
+static int launch_x3(const ConvK& k, const X3Extra& q, unsigned g, const half_t* zp, hipStream_t st) {
+  constexpr int SM_BYTES = 2 * x3_buf(KS);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_x3_kernel<KS>, dim3(g), dim3(256), SM_BYTES, st, k, q, zp);
+  CSBSR_LAUNCH_CHECK("csbsr_conv_x3_forward");
+  return 0;
+}
+
 extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) {
   CSBSR_CHECK(csbsr_conv_x3_eligible(d), "conv_x3: launch not eligible (see csbsr_conv_x3_eligible)");
   ConvK k;
   if (int rc = conv_desc_to_k(d, k)) return rc;
+  const bool strided = x3_is_strided(d);
   X3Extra q;
-  q.tiles_x = (unsigned)((d->W + X3_TW - 1) / X3_TW); q.tiles_y = (unsigned)((d->H + X3_TH - 1) / X3_TH);
-  q.nct = (unsigned)((d->coutp + 127) / 128); q.nch = (unsigned)(d->in[0].c / 64);
+  q.tiles_x = (unsigned)((d->OW + X3_TW - 1) / X3_TW); q.tiles_y = (unsigned)((d->OH + X3_TH - 1) / X3_TH);
+  q.nct = (unsigned)((d->coutp + 127) / 128); q.ncc = (unsigned)(d->in[0].c / 64);
+  q.nch = strided ? q.ncc * (unsigned)(d->stride * d->stride) : q.ncc;
   int dev = 0, ncu = 256;
   CSBSR_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CSBSR_MAX_DEVICES, "conv_x3: no current device");
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -267,16 +379,9 @@ extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
     CSBSR_CHECK(hipMalloc(reinterpret_cast<void**>(&g_x3_zero_page[dev]), 256) == hipSuccess, "conv_x3: zero page alloc failed");
     (void)hipMemset(g_x3_zero_page[dev], 0, 256);
   }
-  constexpr int SM_BYTES = 2 * X3_BUF;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
-    attr_set = true;
-  }
   const unsigned items = q.tiles_x * q.tiles_y * (unsigned)d->N * q.nct;
   const unsigned g = items < (unsigned)ncu ? items : (unsigned)ncu;
-  g_last_conv_kernel = CONVK_X3;
-  hipLaunchKernelGGL(conv_x3_kernel, dim3(g), dim3(256), SM_BYTES, reinterpret_cast<hipStream_t>(s), k, q, g_x3_zero_page[dev]);
-  CSBSR_LAUNCH_CHECK("csbsr_conv_x3_forward");
-  return 0;
+  g_last_conv_kernel = strided ? CONVK_X3S : CONVK_X3;
+  return strided ? launch_x3<2>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s))
+                 : launch_x3<3>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s));
 }

@@ -330,13 +330,20 @@ class Conv:
             L.call("csbsr_conv_hr_forward", C.byref(d), self.eng.stream)
         elif x3 is not None and self.eng.use_x3 and L.load().csbsr_conv_x3_eligible(C.byref(d)):
             # wide low-resolution 3x3 layers (SFT convs and their dgrads): per-chunk halo tile + fragment-ordered weights from L2 (csrc/conv_x3.hip)
+            # ... and the k = 2 x stride strided layers (kind 2: 8x8 stride-4 convs, dgrads of the 8x8 stride-4 deconvs): chunk = input phase
             kind, c_real, rows_real, row_off, k_off = x3
             key = ("x3", kind, row_off, k_off, c_real)
             if key not in self._packed:
-                n = L.load().csbsr_packed_weight_elems_x3(c_real, rows_real)
-                dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
-                L.call("csbsr_pack_weights_x3", _ptr(self.w), _ptr(dst), kind, self.w.shape[0], self.w.shape[1], c_real, rows_real, row_off,
-                       k_off, self.eng.stream)
+                if kind == 2:
+                    n = L.load().csbsr_packed_weight_elems_x3_strided(stride, c_real, rows_real)
+                    dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
+                    L.call("csbsr_pack_weights_x3_strided", _ptr(self.w), _ptr(dst), self.w.shape[0], self.w.shape[1], k, stride, c_real,
+                           rows_real, row_off, k_off, self.eng.stream)
+                else:
+                    n = L.load().csbsr_packed_weight_elems_x3(c_real, rows_real)
+                    dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
+                    L.call("csbsr_pack_weights_x3", _ptr(self.w), _ptr(dst), kind, self.w.shape[0], self.w.shape[1], c_real, rows_real, row_off,
+                           k_off, self.eng.stream)
                 self._packed[key] = dst
             d.wt = _ptr(self._packed[key])
             L.call("csbsr_conv_x3_forward", C.byref(d), self.eng.stream)
@@ -383,7 +390,8 @@ class Conv:
         self._launch(xs, wt, self.transposed, self.k, self.stride, self.pad, self.dil, H, W, OH, OW, self.cout, out, out32, self.b,
                      self.act, self.slope, self.prelu, res, res2, res_mode, False, stat, stat_mode, 1.0 / self.WSCALE if sp else 1.0, hr=hr,
                      tp=(self.cin, self.cout, 0, 0) if (self.transposed and len(xs) == 1 and not sp) else None,
-                     x3=(0, self.cin, self.cout, 0, 0) if (not sp and not self.transposed and self.k == 3 and len(xs) == 1) else None)
+                     x3=((0 if self.k == 3 else 2, self.cin, self.cout, 0, 0)
+                         if (not sp and not self.transposed and len(xs) == 1 and (self.k == 3 or self.k == 2 * self.stride)) else None))
         return out
 
     def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None, mask=None, dact=None, dres=None):
@@ -428,7 +436,8 @@ class Conv:
                      None, None, L.RES_NONE, accumulate, stat, L.STAT_SAMPLE_SUM if stat is not None else L.STAT_NONE,
                      1.0 / self.WSCALE if hp else 1.0, mask=mask, hr=hr,
                      tp=(self.cout, c_seg, row_off, 0) if (tr and not hp and stat is None) else None, dact=dact, dres=dres,
-                     x3=(1, self.cout, c_seg, row_off, 0) if (not hp and not self.transposed and s == 1 and k == 3 and stat is None) else None)
+                     x3=((2, self.cout, c_seg, row_off, 0) if (self.transposed and not hp and stat is None and k == 2 * s) else
+                         (1, self.cout, c_seg, row_off, 0) if (not hp and not self.transposed and s == 1 and k == 3 and stat is None) else None))
         return out
 
     # -- exact folding of a spatially constant second input segment (SFT conv0: cat(features, kernel code), kbpn.py:513)

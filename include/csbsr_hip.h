@@ -138,6 +138,15 @@ int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
 int64_t csbsr_packed_weight_elems_x3(int32_t c_real, int32_t rows_real);
 int csbsr_pack_weights_x3(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
                           int32_t row_off, int32_t k_off, csbsr_stream_t s);
+/* The same kernel family also takes the k = 2 x stride strided convolutions -- the 8x8 stride-4 Conv2d's of DownBlock / UpBlock
+ * (kbpn.py:215-262) and the dgrads of the 8x8 stride-4 ConvTranspose2d's: a chunk is then (input phase, 64 channels), i.e. the
+ * sub-sampled grid every kernel offset with the same residue modulo the stride reads, shared by its 2 x 2 taps (csbsr_conv_x3_eligible
+ * / csbsr_conv_x3_forward accept both shapes; stride <= 4, pad < stride, 64..512 padded input channels in whole chunks).  Weights:
+ * w is [row][contracted channel][kh][kw] with dims D0 x D1 -- a Conv2d's OIHW parameter, or a ConvTranspose2d's IOHW parameter seen
+ * from its dgrad (rows = its input channels). */
+int64_t csbsr_packed_weight_elems_x3_strided(int32_t stride, int32_t c_real, int32_t rows_real);
+int csbsr_pack_weights_x3_strided(const float* w, void* dst, int32_t D0, int32_t D1, int32_t ksize, int32_t stride, int32_t c_real,
+                                  int32_t rows_real, int32_t row_off, int32_t k_off, csbsr_stream_t s);
 
 /* Weight-gradient GEMM: G[split][a][tap][b] = sum over the split's pixels of A[pix][a] * B[pix @ tap][b]  (fp32; the pixel
  * range is cut into csbsr_wgrad_splits() slabs, each written once -- no atomics, no zero-fill; csbsr_unpack_wgrad sums them).

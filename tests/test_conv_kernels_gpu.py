@@ -421,6 +421,72 @@ def test_wide_3x3_kernel(cin, cout, H, W, mode):
     assert relmax(outs[0][0], outs[1][0]) < 1e-3 and relmax(outs[0][1], outs[1][1]) < 1e-3
 
 
+@pytest.mark.parametrize("cin,cout,k,s,p,OH,OW,mode", [
+    (128, 128, 8, 4, 2, 19, 45, "prelu_sub"),      # up_conv2 / down_conv shapes, ragged tiles on both axes
+    (128, 128, 8, 4, 2, 16, 64, "prelu_add"),      # whole tiles
+    (64, 128, 8, 4, 2, 8, 32, "none"),             # one 64-channel chunk per phase
+    (192, 100, 8, 4, 1, 9, 40, "lrelu"),           # three chunks per phase (odd chunk count), padded couts, another padding
+    (256, 200, 4, 2, 1, 12, 33, "none_add"),       # 4x4 stride 2: four phases, two cout tiles
+])
+def test_phase_accumulated_strided_conv(cin, cout, k, s, p, OH, OW, mode):
+    """The k = 2 x stride convolutions (8x8 stride 4: DownBlock / UpBlock strided convs, dgrads of the deconvolutions) through
+    conv_x3_kernel<2> (csrc/conv_x3.hip: one chunk per input phase and 64 channels, 2 x 2 taps on the phase's sub-sampled halo tile)
+    against F.conv2d on the same fp16-rounded operands and against the implicit-GEMM kernel: forward with the fused epilogues the
+    blocks use, and the dgrad of the matching ConvTranspose2d accumulating into an existing gradient."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv, pad8
+    torch.manual_seed(cin + cout + OH * OW)
+    eng = _eng()
+    lib = L.load()
+    N = 2
+    H, W = s * (OH - 1) + k - 2 * p, s * (OW - 1) + k - 2 * p
+    x = torch.randn(N, cin, H, W).half().float()
+    w = (torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5).half().float()
+    b = torch.randn(cout) * 0.1
+    a0 = torch.tensor([0.25])
+    actn = mode.split("_")[0]
+    act = {"prelu": L.ACT_PRELU, "lrelu": L.ACT_LRELU, "none": L.ACT_NONE}[actn]
+    params = {"l.weight": w.cuda(), "l.bias": b.cuda(), "a": a0.clone().cuda()}
+    conv = Conv(eng, "l", params, k, s, p, 1, bias=True, act=act, slope=0.1, prelu="a" if act == L.ACT_PRELU else None)
+    pre = F.conv2d(x, w, b, s, p)
+    assert pre.shape[-2:] == (OH, OW)
+    ref = {"prelu": F.prelu(pre, a0), "lrelu": F.leaky_relu(pre, 0.1), "none": pre}[actn]
+    res = torch.randn_like(ref).half().float()
+    kw = {}
+    if mode.endswith("_add"):
+        ref = ref + res; kw = dict(res=res, res_mode=L.RES_ADD)
+    if mode.endswith("_sub"):
+        ref = ref - res; kw = dict(res=res, res_mode=L.RES_SUB)
+    # the dgrad of ConvTranspose2d(cout -> cin) with an IOHW weight [cout][cin]: a strided conv over dOut contracting its cin
+    wt = (torch.randn(cout, cin, k, k) / (cin * 4) ** 0.5).half().float()
+    tconv = Conv(eng, "t", {"t.weight": wt.cuda()}, k, s, p, 1, transposed=True, bias=False, act=L.ACT_NONE)
+    dpre = torch.randn(N, cin, H, W).half().float()          # gradient wrt the deconv's (H x W) output
+    old = torch.randn(N, cout, OH, OW).half().float()
+    zr = torch.zeros(N, cout, OH, OW, requires_grad=True)
+    yt = F.conv_transpose2d(zr, wt, None, s, p)
+    assert yt.shape[-2:] == (H, W)
+    yt.backward(dpre)
+    refd = zr.grad + old
+    outs = []
+    for x3_mode in (2, 0):
+        lib.csbsr_debug_set_conv_x3(x3_mode)
+        try:
+            conv.invalidate(); tconv.invalidate()
+            y = conv.fwd(to_fm(eng, x), **{k_: (to_fm(eng, v) if isinstance(v, torch.Tensor) else v) for k_, v in kw.items()})
+            torch.cuda.synchronize()
+            assert (lib.csbsr_debug_last_conv_kernel() == 12) == (x3_mode == 2 and pad8(cout) >= 72)
+            dz = to_fm(eng, old)
+            tconv.bwd_input(to_fm(eng, dpre), out=dz, accumulate=True, in_hw=(OH, OW))
+            torch.cuda.synchronize()
+            assert (lib.csbsr_debug_last_conv_kernel() == 12) == (x3_mode == 2 and pad8(cout) >= 72)
+        finally:
+            lib.csbsr_debug_set_conv_x3(1)
+        outs.append((from_fm(y), from_fm(dz)))
+        assert relmax(outs[-1][0], ref) < 2e-3
+        assert relmax(outs[-1][1], refd) < 2e-3
+    assert relmax(outs[0][0], outs[1][0]) < 1e-3 and relmax(outs[0][1], outs[1][1]) < 1e-3
+
+
 @pytest.mark.parametrize("k,s,p,cout,H,W,mode", [(8, 4, 2, 128, 13, 21, "prelu_add"), (8, 4, 2, 128, 16, 16, "prelu"), (12, 8, 2, 128, 7, 9, "prelu_add"),
                                                (8, 4, 2, 64, 10, 12, "none_sub"), (8, 4, 2, 49, 10, 12, "prelu")])
 def test_thin_transposed_conv_from_image(k, s, p, cout, H, W, mode):
