@@ -145,6 +145,7 @@ DEBUG_SIGNATURES = {
     "csbsr_debug_set_conv_glds": (None, [i32]),
     "csbsr_debug_set_conv_tp": (None, [i32]),
     "csbsr_debug_set_conv_x3": (None, [i32]),
+    "csbsr_debug_set_wgrad_hr": (None, [i32]),
     "csbsr_debug_last_conv_kernel": (i32, []),
     "csbsr_debug_last_wgrad_kernel": (i32, []),
 }
@@ -174,6 +175,8 @@ def load():
         lib.csbsr_debug_set_wgrad_tr(int(os.environ["CSBSR_WGRAD_DBG"]))
     if os.environ.get("CSBSR_CONV_X3"):            # A/B hook: 0 off, 1 default, 2 every eligible launch
         lib.csbsr_debug_set_conv_x3(int(os.environ["CSBSR_CONV_X3"]))
+    if os.environ.get("CSBSR_WGRAD_HR"):           # A/B hook: 0 off, 1 default, 2 every eligible launch
+        lib.csbsr_debug_set_wgrad_hr(int(os.environ["CSBSR_WGRAD_HR"]))
     if os.environ.get("CSBSR_CONV_TP"):            # A/B hook: 0 off, 1 default, 2 every eligible launch
         lib.csbsr_debug_set_conv_tp(int(os.environ["CSBSR_CONV_TP"]))
     if os.environ.get("CSBSR_CONV_GLDS"):          # A/B hook for kernel selection experiments

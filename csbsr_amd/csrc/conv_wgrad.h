@@ -34,3 +34,8 @@ int wgrad_glds_tile_n(const WgradK& k);                  // 128 or 256 columns p
 int wgrad_glds_tile_a(const WgradK& k);                  // 256: rows [0, ca / 256 * 256) run on 256 x 256 tiles, the rest on 128-row tiles
 int wgrad_glds_launch(const WgradK& k, int ta, int tn, int splits, hipStream_t st);
 extern int g_wgrad_glds;                                 // 0: off (A/B timing, csbsr_debug_set_wgrad_tr bit 7)
+
+// conv_wgrad_hr.hip: full-resolution 3x3 layers with <= 64 channels on both sides (one slab per workgroup)
+bool wgrad_hr_eligible(const csbsr_wgrad_desc_t* d);
+int32_t wgrad_hr_splits(const csbsr_wgrad_desc_t* d);
+int wgrad_hr_launch(const csbsr_wgrad_desc_t* d, hipStream_t st);

@@ -429,6 +429,7 @@ extern "C" int32_t csbsr_wgrad_splits_desc(const csbsr_wgrad_desc_t* d) {
   const int ktot = d->KH * d->KW * cbtot;
   if (wgrad_is_thin(d))
     return (int32_t)wgrad_splits_for((cbtot + WG_BN - 1) / WG_BN, (long)d->ca * ktot, (long)d->N * d->BH * d->BW);
+  if (wgrad_hr_eligible(d)) return wgrad_hr_splits(d);
   const bool perm8 = g_wgrad_tap_perm && d->KH == 8 && d->KW == 8 && d->stride == 4 && cbtot == WG_BN && d->ca <= 128;
   return wgrad_splits_impl(d->ca, ktot, (long)d->N * d->AH * d->AW, perm8);
 }
@@ -496,6 +497,7 @@ extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
     CSBSR_LAUNCH_CHECK("csbsr_conv_wgrad(thin)");
     return 0;
   }
+  if (wgrad_hr_eligible(d)) { g_last_wgrad_kernel = 8; return wgrad_hr_launch(d, st); }
   // LDS-DMA kernel: measured (scripts/bench_wgrad_ab.sh, N = 4) it only matches the register-staged kernel at equal tile size (and
   // trails it by 6 % on the 128 x 128 tap-permuted 8x8 stride-4 layers), so it is used for what only it can hold, the 256 x 256
   // tile.  CSBSR_WGRAD_DBG bit 10 forces it for the other tiles too (A/B timing, tests).

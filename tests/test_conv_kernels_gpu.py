@@ -113,6 +113,38 @@ def test_conv_fwd_dgrad_wgrad(case, use_tr):
     L.load().csbsr_debug_set_wgrad_tr(1)
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(32, 32, 19, 45), (32, 32, 16, 64), (49, 32, 24, 33), (32, 49, 9, 40), (49, 49, 17, 70), (64, 64, 8, 32)])
+def test_full_resolution_thin_wgrad(cin, cout, H, W):
+    """csrc/conv_wgrad_hr.hip (dPre tile + input halo tile in LDS once per 8 x 32 pixels, nine taps from the one halo, one slab per
+    workgroup) against torch autograd on fp16-rounded operands and against the tiled GEMM kernel: the 32 / 49 / 64-channel 3x3 layers of
+    the kernel predictor and the decoder head, ragged tiles included."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    torch.manual_seed(cin * 100 + cout + H)
+    eng = _eng()
+    lib = L.load()
+    N = 3
+    x = torch.randn(N, cin, H, W).half().float()
+    w = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).half().float()
+    dpre = torch.randn(N, cout, H, W).half().float()
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, None, 1, 1).backward(dpre)
+    grads = []
+    for mode in (2, 0):
+        lib.csbsr_debug_set_wgrad_hr(mode)
+        try:
+            params = {"l.weight": w.clone().cuda()}
+            conv = Conv(eng, "l", params, 3, 1, 1, 1, bias=False, act=L.ACT_NONE)
+            conv.bwd_weights(to_fm(eng, dpre), to_fm(eng, x))
+            torch.cuda.synchronize()
+            assert (lib.csbsr_debug_last_wgrad_kernel() == 8) == (mode == 2)
+        finally:
+            lib.csbsr_debug_set_wgrad_hr(1)
+        grads.append(params["l.weight"].gacc.cpu())
+        assert relmax(grads[-1], wr.grad) < 2e-3
+    assert relmax(grads[0], grads[1]) < 1e-3
+
+
 def test_two_segment_broadcast_and_epilogue():
     """cat(features, spatially-constant code) conv with FMA epilogue, fp32 planar side output and GAP stat."""
     from csbsr_amd import _lib as L
