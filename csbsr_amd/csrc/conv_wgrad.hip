@@ -252,8 +252,10 @@ extern "C" void csbsr_debug_set_wgrad_tr(int v) {
   g_wgrad_use_tr = v & 1; g_wgrad_thin = !(v & 2); g_wgrad_tap_perm = !(v & 4); g_wgrad_flat = (v & 8) ? 0 : ((v & 16) ? 2 : 1);
   g_wgrad_row_shift = !(v & 32); g_wgrad_wide = !(v & 64);
   // bit 7: register-staged kernel everywhere; bit 0 clear (scalar LDS transposition) implies it -- the LDS-DMA kernel only has the
-  // hardware-transpose read; bits 8..9: LDS-DMA tile menu (256: no 256 x 256 tile, 512: no 128 x 256 tile)
-  g_wgrad_glds = ((v & 128) || !(v & 1)) ? 0 : (1 | ((v & 256) ? 0 : 2) | ((v & 512) ? 4 : 0) | ((v & 1024) ? 8 : 0));
+  // hardware-transpose read; bits 8..9: LDS-DMA tile menu (256: no 256 x 256 tile, 512: no 128 x 256 tile); bit 10: LDS-DMA kernel only where the
+  // 256-row tile applies (register-staged elsewhere: the default until the DMA pieces became inline assembly); bit 21: square tiles
+  // for the tap-permuted 8x8 stride-4 layers
+  g_wgrad_glds = ((v & 128) || !(v & 1)) ? 0 : (1 | ((v & 256) ? 0 : 2) | ((v & 512) ? 4 : 0) | ((v & 1024) ? 0 : 8) | ((v & (1 << 21)) ? 0 : 64));
   g_wgrad_extra_lds = ((v >> 12) & 0xff) * 1024;
 }
 
@@ -498,9 +500,10 @@ extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
     return 0;
   }
   if (wgrad_hr_eligible(d)) { g_last_wgrad_kernel = 8; return wgrad_hr_launch(d, st); }
-  // LDS-DMA kernel: measured (scripts/bench_wgrad_ab.sh, N = 4) it only matches the register-staged kernel at equal tile size (and
-  // trails it by 6 % on the 128 x 128 tap-permuted 8x8 stride-4 layers), so it is used for what only it can hold, the 256 x 256
-  // tile.  CSBSR_WGRAD_DBG bit 10 forces it for the other tiles too (A/B timing, tests).
+  // LDS-DMA kernel for every problem with > 64 A-channels.  (While its DMA pieces were the compiler's global_load_lds builtin, hipcc put
+  // an s_waitcnt vmcnt(0) before each stage's first transposing read and the ring never overlapped: the kernel then only matched the
+  // register-staged one at equal tile size.  With the pieces as inline assembly, N = 4: SFT 825->384 747 -> 884 TF/s, 384->825 712 -> 808,
+  // ResNet 512 728 -> 802, 256 631 -> 701, up_1 1024->256 793 -> 958, 8x8 stride 4 (128 x 256 tap-pair tiles) 650 -> 739.)
   const bool glds_all = wgrad_glds_eligible(k) && (g_wgrad_glds & 8);
   if (wgrad_glds_eligible(k) && (glds_all || wgrad_glds_tile_a(k) == 256)) {
     const int ta = wgrad_glds_tile_a(k), tn = wgrad_glds_tile_n(k);

@@ -20,10 +20,22 @@
 #include "csbsr_debug.h"
 #include "conv_wgrad.h"
 
-int g_wgrad_glds = 3;      // bit 0 kernel enabled, bit 1 256 x 256 tile, bit 2 no 128 x 256 tile, bit 3 every eligible problem (csbsr_debug_set_wgrad_tr)
+int g_wgrad_glds = 75;     // bit 0 kernel enabled, bit 1 256 x 256 tile, bit 2 no 128 x 256 tile, bit 3 every eligible problem, bit 6 128 x 256 tap-pair
+                           // tiles for the 8x8 stride-4 layers (csbsr_debug_set_wgrad_tr)
+
+// One LDS-DMA piece (64 lanes x 16 bytes -> LDS bytes [lds_addr, lds_addr + 1024)) as inline assembly: behind the compiler's own
+// global_load_lds builtin hipcc puts an s_waitcnt vmcnt(0) in front of the next transposing LDS read (it cannot tell the ring stages
+// apart), i.e. the stage just requested had to LAND before the current one could be multiplied -- the ring never overlapped within a
+// wave.  The pieces' completion is counted by hand below (vmcnt(N) + barrier per stage).
+static __device__ __forceinline__ void wg_dma16(const half_t* src, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_addr));
+}
 
 template <int BA, int BN, int NWA, int NWB, int NSTAGE>
 __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const WgradK p, const half_t* __restrict__ zero_page) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the inline assembly has no host form: the host pass emits only the launch stub)
   constexpr int NW = NWA * NWB;
   constexpr int AWv = BA / NWA, BWv = BN / NWB;      // rows / columns per wave
   constexpr int TA = AWv / 32, TB = BWv / 32;
@@ -118,14 +130,14 @@ __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const W
   const half_t* zp = zero_page + (lane & 7) * 8;
   long m_issue = mbeg;                       // first pixel of the stage being ISSUED
 
+  const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem) + (unsigned)wid * 1024u;
   auto issue = [&](int kt) {
-    char* sbase = smem + (kt % NSTAGE) * STAGE_BYTES;
+    const unsigned sbase = lds0 + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
       const bool ok = a_ok && m_issue + rowA0 + DA * i < mend;
       const half_t* src = ok ? a_base + ca_.off : zp;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sbase + (wid + NW * i) * 1024), 16, 0, 0);
+      wg_dma16(src, sbase + (unsigned)(NW * i * 1024));
       advance(ca_, DA, a_dx, a_rowfix, a_imgfix);
     }
 #pragma unroll
@@ -133,8 +145,7 @@ __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const W
       const int by = cb.y * p.stride + b_ky, bx = cb.x * p.stride + b_kx;
       const bool ok = b_ok && m_issue + rowB0 + DB * i < mend && (unsigned)by < (unsigned)p.BH && (unsigned)bx < (unsigned)p.BW;
       const half_t* src = ok ? b_base + cb.off : zp;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (wid + NW * i) * 1024), 16, 0, 0);
+      wg_dma16(src, sbase + (unsigned)(A_BYTES + NW * i * 1024));
       advance(cb, DB, b_dx, b_rowfix, b_imgfix);
     }
     m_issue += BP;
@@ -216,6 +227,7 @@ __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const W
         slab[(size_t)row * p.ktot + col] = acc[a][b][r];
       }
     }
+#endif
 }
 
 static half_t* g_wg_zero_page[CSBSR_MAX_DEVICES] = {};
@@ -256,18 +268,17 @@ static int launch_wgrad_glds(const WgradK& k, int splits, hipStream_t st) {
 }
 
 bool wgrad_glds_eligible(const WgradK& k) { return g_wgrad_glds != 0 && k.ca > 64; }
-// Measured at N = 4 (scripts/bench_wgrad_ab.sh): at equal tile size the LDS-DMA kernel only matches the register-staged one (the CU's
-// load path, ~16 B/clk, bounds both: 64 flop per staged byte at 128 x 128, 85 at 128 x 256) -- what it buys is the 256 x 256 tile
-// (128 flop/B; 8 waves, two 64 KB stages) that the register-staged kernel cannot hold: ResNet 512 3x3 560 -> 730 TF/s, up_1 1024 -> 256
-// 651 -> 808, ResNet 256 524 -> 637.  So: 256-row tiles for the multiple-of-256 part of the A channels wherever the columns fill
-// 256-wide tiles about as well as 128-wide ones (the caller runs the remaining rows as a second, 128-row launch); 128 x 256 for the
-// layers with thousands of columns; 128 x 128 otherwise (tap-permuted 8x8 stride-4 layers included).
+// Tile menu (measured at N = 4, scripts/bench_wgrad_ab.sh): 256-row tiles (8 waves, two 64 KB stages) for the multiple-of-256 part of
+// the A channels wherever the columns fill 256-wide tiles about as well as 128-wide ones (the caller runs the remaining rows as a
+// second, 128-row launch); 128 x 256 for the layers with thousands of columns and for the tap-permuted 8x8 stride-4 layers (one tile =
+// the tap pair (ky, kx0), (ky, kx0 + 1): 697 -> 739 TF/s against the square tile); 128 x 128 otherwise (two workgroups per CU: a
+// four-stage ring with one workgroup per CU measured 548 instead of 697).
 static bool pad_ok(int c, int t) { const int p128 = (c + 127) / 128 * 128, pt = (c + t - 1) / t * t; return pt * 8 <= p128 * 9; }
 int wgrad_glds_tile_a(const WgradK& k) {
   return (g_wgrad_glds & 2) && k.ca >= 256 && k.ktot >= 1024 && pad_ok(k.ktot, 256) && !k.tap_perm ? 256 : 128;
 }
 int wgrad_glds_tile_n(const WgradK& k) {
-  return (k.ktot >= 6144 && !k.tap_perm && !(g_wgrad_glds & 4)) ? 256 : 128;
+  return (k.ktot >= 6144 && (!k.tap_perm || (g_wgrad_glds & 64)) && !(g_wgrad_glds & 4)) ? 256 : 128;
 }
 int wgrad_glds_launch(const WgradK& k, int ta, int tn, int splits, hipStream_t st) {
   if (ta == 256) return launch_wgrad_glds<256, 256, 2, 4, 2>(k, splits, st);

@@ -72,8 +72,8 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-# wgrad: default (LDS-DMA 256x256 tiles where eligible, register-staged elsewhere) | register-staged, scalar LDS transposition |
-# register-staged, hardware transpose | LDS-DMA kernel for every eligible problem (128x128 / 128x256 / 256x256 tiles)
+# wgrad: default (LDS-DMA kernel for every eligible problem: 128x128 / 128x256 / 256x256 tiles) | register-staged, scalar LDS transposition |
+# register-staged, hardware transpose | LDS-DMA 256x256 tiles where eligible, register-staged elsewhere
 @pytest.mark.parametrize("use_tr", [1, 0, 129, 1025])
 def test_conv_fwd_dgrad_wgrad(case, use_tr):
     from csbsr_amd import _lib as L
