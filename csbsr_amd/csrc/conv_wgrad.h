@@ -25,6 +25,7 @@ struct WgradK {
   // the A channels, a second launch the rest): ``a`` already points at channel row0, slabs are slab_stride elements apart
   long slab_stride;          // elements per pixel-split slab = (all A channels) * ktot
   int row0;
+  int tw_log, gx, gy;        // LDS-DMA kernel, 2-D stages: log2 of the rectangle width, rectangles per row / per image column
 };
 
 

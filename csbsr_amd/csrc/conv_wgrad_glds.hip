@@ -20,8 +20,8 @@
 #include "csbsr_debug.h"
 #include "conv_wgrad.h"
 
-int g_wgrad_glds = 75;     // bit 0 kernel enabled, bit 1 256 x 256 tile, bit 2 no 128 x 256 tile, bit 3 every eligible problem, bit 6 128 x 256 tap-pair
-                           // tiles for the 8x8 stride-4 layers (csbsr_debug_set_wgrad_tr)
+int g_wgrad_glds = 203;    // bit 0 kernel enabled, bit 1 256 x 256 tile, bit 2 no 128 x 256 tile, bit 3 every eligible problem, bit 6 128 x 256 tap-pair
+                           // tiles for the 8x8 stride-4 layers, bit 7 2-D stage rectangles (csbsr_debug_set_wgrad_tr)
 
 // One LDS-DMA piece (64 lanes x 16 bytes -> LDS bytes [lds_addr, lds_addr + 1024)) as inline assembly: behind the compiler's own
 // global_load_lds builtin hipcc puts an s_waitcnt vmcnt(0) in front of the next transposing LDS read (it cannot tell the ring stages
@@ -33,7 +33,30 @@ static __device__ __forceinline__ void wg_dma16(const half_t* src, unsigned lds_
                : "=&s"(keep) : "v"(src), "s"(lds_addr));
 }
 
-template <int BA, int BN, int NWA, int NWB, int NSTAGE>
+// The same piece through a buffer descriptor: per-lane 32-bit byte offset, out-of-range offsets (-1) read as zeros.
+typedef int wg_v4i __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ void wg_dma16_buf(wg_v4i rs, int voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_addr));
+}
+static __device__ __forceinline__ wg_v4i wg_make_rs(const half_t* base) {      // [base, base + 2 GB), from provably uniform halves
+  const unsigned long a = reinterpret_cast<unsigned long>(base);
+  wg_v4i r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+  r[2] = 0x7fffffff;
+  r[3] = 0x00020000;
+  return r;
+}
+
+// T2D: the 64 pixels of a stage are a (64 >> tw_log) x (1 << tw_log) rectangle of the A grid instead of 64 consecutive pixels (the host
+// picks the widest power-of-two width that divides AW; the rows must divide AH).  A lane's position inside the rectangle -- and with
+// it the byte offset of every DMA piece it issues and the tap-shifted coordinates it has to bounds-check -- is then a kernel constant,
+// the stage enters through the (uniform, scalar-ALU) base of a buffer descriptor, and a piece costs ~7 vector instructions instead of
+// the ~50 of the running (n, y, x) bookkeeping with its wrap-around loops: per stage and wave that code was 330 instructions beside 16
+// MFMAs, i.e. the kernel was bound by instruction issue, not by the matrix pipe or the loads.
+template <int BA, int BN, int NWA, int NWB, int NSTAGE, bool T2D>
 __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const WgradK p, const half_t* __restrict__ zero_page) {
 #if defined(__HIP_DEVICE_COMPILE__)      // (the inline assembly has no host form: the host pass emits only the launch stub)
   constexpr int NW = NWA * NWB;
@@ -131,7 +154,59 @@ __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const W
   long m_issue = mbeg;                       // first pixel of the stage being ISSUED
 
   const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem) + (unsigned)wid * 1024u;
+  // ---- T2D: kernel-constant piece offsets / tap-shifted coordinates, uniform stage position
+  int voffA[NIA], voffB[NIB], cy[NIB], cx[NIB];
+  int t_n = 0, t_y = 0, t_x = 0;                       // the stage being ISSUED: image, tile row, tile column
+  if (T2D) {
+    const int twm = (1 << p.tw_log) - 1;
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int r = rowA0 + DA * i, py = r >> p.tw_log, px = r & twm;
+      voffA[i] = a_ok ? 2 * (int)(py * p.a_sy + px * p.a_sx + chA) : -1;
+    }
+    const int c_b = b_ok ? (col0 + chB) % p.cbtot : 0;
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const int r = rowB0 + DB * i, py = r >> p.tw_log, px = r & twm;
+      cy[i] = b_ok ? py * p.stride + b_ky : 0x40000000;
+      cx[i] = px * p.stride + b_kx;
+      voffB[i] = 2 * (int)((py * p.stride + b_ky + p.pad) * b_sy + (px * p.stride + b_kx + p.pad) * b_sx + c_b);
+    }
+    const unsigned s0 = (unsigned)(mbeg / BP), per_img = (unsigned)(p.gx * p.gy);
+    t_n = __builtin_amdgcn_readfirstlane((int)(s0 / per_img));
+    const unsigned r_ = s0 - (unsigned)t_n * per_img;
+    t_y = __builtin_amdgcn_readfirstlane((int)(r_ / (unsigned)p.gx));
+    t_x = __builtin_amdgcn_readfirstlane((int)(r_ - (unsigned)t_y * (unsigned)p.gx));
+  }
+  // (uniform) running position of the stage being issued: descriptor bases and the gathered side's first row / column, stepped by
+  // scalar adds -- next rectangle in the row, first one of the next rectangle row, of the next image
+  const int tw_ = 1 << p.tw_log, th_ = 64 >> p.tw_log;
+  const half_t* base_a = p.a + a0 + t_n * p.a_sn + (long)(t_y * th_) * p.a_sy + (long)(t_x * tw_) * p.a_sx;
+  const half_t* base_b = reinterpret_cast<const half_t*>(p.b[0].ptr) + t_n * p.b[0].sn + (long)(t_y * th_ * p.stride - p.pad) * p.b[0].sy +
+                         (long)(t_x * tw_ * p.stride - p.pad) * p.b[0].sx;
+  int Ys = t_y * th_ * p.stride, Xs = t_x * tw_ * p.stride;
+  const long da_x = (long)tw_ * p.a_sx, da_y = (long)th_ * p.a_sy - (long)p.gx * da_x, da_n = p.a_sn - (long)p.gy * th_ * p.a_sy;
+  const long db_x = (long)tw_ * p.stride * p.b[0].sx, db_y = (long)th_ * p.stride * p.b[0].sy - (long)p.gx * db_x,
+             db_n = p.b[0].sn - (long)p.gy * th_ * p.stride * p.b[0].sy;
+  const int dXs = tw_ * p.stride, dYs = th_ * p.stride;
+  auto issue2d = [&](int kt) {
+    const unsigned sbase = lds0 + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
+    const wg_v4i rsa = wg_make_rs(base_a), rsb = wg_make_rs(base_b);
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) wg_dma16_buf(rsa, voffA[i], sbase + (unsigned)(NW * i * 1024));
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) {
+      const bool ok = (unsigned)(cy[i] + Ys) < (unsigned)p.BH && (unsigned)(cx[i] + Xs) < (unsigned)p.BW;
+      wg_dma16_buf(rsb, ok ? voffB[i] : -1, sbase + (unsigned)(A_BYTES + NW * i * 1024));
+    }
+    base_a += da_x; base_b += db_x; Xs += dXs;
+    if (++t_x == p.gx) {
+      t_x = 0; Xs = 0; base_a += da_y; base_b += db_y; Ys += dYs;
+      if (++t_y == p.gy) { t_y = 0; Ys = 0; base_a += da_n; base_b += db_n; }
+    }
+  };
   auto issue = [&](int kt) {
+    if (T2D) { issue2d(kt); return; }
     const unsigned sbase = lds0 + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
@@ -232,8 +307,8 @@ __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const W
 
 static half_t* g_wg_zero_page[CSBSR_MAX_DEVICES] = {};
 
-template <int BA, int BN, int NWA, int NWB, int NSTAGE>
-static int launch_wgrad_glds(const WgradK& k, int splits, hipStream_t st) {
+template <int BA, int BN, int NWA, int NWB, int NSTAGE, bool T2D>
+static int launch_wgrad_glds_t(const WgradK& k, int splits, hipStream_t st) {
   WgradK p = k;
   p.tiles_a = (unsigned)((k.ca + BA - 1) / BA);
   p.tiles_b = (unsigned)((k.ktot + BN - 1) / BN);
@@ -248,7 +323,7 @@ static int launch_wgrad_glds(const WgradK& k, int splits, hipStream_t st) {
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_glds_kernel<BA, BN, NWA, NWB, NSTAGE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_glds_kernel<BA, BN, NWA, NWB, NSTAGE, T2D>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES) != hipSuccess) {
       csbsr_set_error("wgrad(glds): cannot reserve %d bytes of LDS", SM_BYTES);
       return 2;
@@ -262,9 +337,32 @@ static int launch_wgrad_glds(const WgradK& k, int splits, hipStream_t st) {
     (void)hipMemset(g_wg_zero_page[dev], 0, 256);
   }
   dim3 grid(p.flat ? ntile * splits : ntile, 1, p.flat ? 1 : splits);
-  hipLaunchKernelGGL((conv_wgrad_glds_kernel<BA, BN, NWA, NWB, NSTAGE>), grid, dim3(64 * NWA * NWB), SM_BYTES, st, p, g_wg_zero_page[dev]);
+  hipLaunchKernelGGL((conv_wgrad_glds_kernel<BA, BN, NWA, NWB, NSTAGE, T2D>), grid, dim3(64 * NWA * NWB), SM_BYTES, st, p, g_wg_zero_page[dev]);
   CSBSR_LAUNCH_CHECK("csbsr_conv_wgrad(glds)");
   return 0;
+}
+
+// 2-D stage rectangles (see the kernel): one gathered segment, a power-of-two width <= 64 that divides AW with the matching height
+// dividing AH (then every split is a whole number of rectangles), single-row rectangles where the row shift is on, 32-bit piece offsets
+static bool wgrad_glds_t2d(WgradK& p) {
+  p.tw_log = 0; p.gx = p.gy = 0;
+  if (!(g_wgrad_glds & 128) || p.b[1].ptr != p.b[0].ptr || p.cb0 != p.cbtot) return false;
+  int tw = 1;
+  while (tw < 64 && p.AW % (tw * 2) == 0) tw *= 2;
+  const int th = 64 / tw;
+  if (tw < 4 || p.AH % th != 0 || (p.row_shift && th != 1)) return false;
+  if (p.a_sy * (long)th >= (1l << 29) || p.b[0].sy * (long)(th * p.stride + p.KH * p.dil) >= (1l << 29)) return false;
+  int l = 0;
+  while ((1 << l) < tw) ++l;
+  p.tw_log = l; p.gx = p.AW / tw; p.gy = p.AH / th;
+  return true;
+}
+
+template <int BA, int BN, int NWA, int NWB, int NSTAGE>
+static int launch_wgrad_glds(const WgradK& k, int splits, hipStream_t st) {
+  WgradK p = k;
+  if (wgrad_glds_t2d(p)) return launch_wgrad_glds_t<BA, BN, NWA, NWB, NSTAGE, true>(p, splits, st);
+  return launch_wgrad_glds_t<BA, BN, NWA, NWB, NSTAGE, false>(p, splits, st);
 }
 
 bool wgrad_glds_eligible(const WgradK& k) { return g_wgrad_glds != 0 && k.ca > 64; }
