@@ -24,6 +24,9 @@
 
 #define HR_TH 16
 #define HR_TW 32
+// waves per workgroup: 8 (two per SIMD: one wave's epilogue runs beside the other's K loop) except for the 56-channel 3x3 layers, whose
+// 32 weight fragments per lane do not fit 256 registers next to the rest (4 waves, 512 registers each)
+constexpr int hr_nw(int CH8, int TAPS) { return (CH8 == 7 && TAPS == 9) ? 4 : 8; }
 
 struct ConvHrK {
   const half_t* in; long i_sn, i_sy, i_sx;
@@ -35,147 +38,225 @@ struct ConvHrK {
   const half_t* mask; long m_sn, m_sy, m_sx; float mask_slope;
   float* stat;                      // optional [N][coutp] per-sample channel sums of act(conv) (global average pool)
   unsigned tiles_x, tiles_y;
-  int dbg;                          // ablation bits (CSBSR_HR_DBG): 1 no stores, 2 no K loop, 4 no tile DMA
 };
 
+// Ring depth: as many halo tiles as fit the 160 KB of LDS, at most 3 (the tiles NBUF - 1 ahead are in flight while one is multiplied)
+constexpr int hr_ninst(int CH8, int TAPS) {
+  const int halo = TAPS == 9 ? 1 : 0, slots = (CH8 % 2) ? CH8 : CH8 + 1, HR_NW = hr_nw(CH8, TAPS);
+  return (((HR_TH + 2 * halo) * (HR_TW + 2 * halo) * slots + 63) / 64 + HR_NW - 1) / HR_NW * HR_NW;
+}
+constexpr int hr_nbuf(int CH8, int TAPS) { return 3 * hr_ninst(CH8, TAPS) * 1024 + 1024 <= 160 * 1024 ? 3 : 2; }
+constexpr int hr_smem(int CH8, int TAPS) { return hr_nbuf(CH8, TAPS) * hr_ninst(CH8, TAPS) * 1024 + 16 + 64 * 4; }
+
 // TAPS = 9 (3x3, one-pixel halo) or 1 (the 1x1 layers of the same chains -- fe_SR.1, fe_cat.0 and their dgrads: no halo, two or four
-// MFMA K steps per 32 pixels, a pure HBM stream)
-template <int CH8, bool STAT, int TAPS>
-__global__ __launch_bounds__(256, (CH8 == 4 ? 3 : 2)) void conv_hr_kernel(const ConvHrK p, const half_t* __restrict__ zero_page) {
+// MFMA K steps per 32 pixels, a pure HBM stream).  NCT = 32-cout tiles a workgroup computes from ONE halo tile (2: waves 0-1 take the
+// first, waves 2-3 the second, eight rows each -- a 49-cout layer reads its input once instead of once per cout tile).
+// One persistent workgroup per CU walks its tiles through a ring of NBUF halo buffers: the DMA of the tile NBUF - 1 ahead is issued one
+// piece at a time between the MFMAs (buffer loads with kernel-constant per-lane offsets, out-of-image pixels zero-filled by the
+// descriptor's bounds check), so ~100 KB per CU are under way at any time -- with one tile per workgroup and 2-3 workgroups per CU the
+// loads of a workgroup were never in flight while it multiplied, and the layers ran at 2-3.6 TB/s.
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t hr_make_rs(const half_t* base) {
+  const unsigned long a = reinterpret_cast<unsigned long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long)hi_ << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+#endif
+
+template <int CH8, bool STAT, int TAPS, int NCT, bool MASK>
+__global__ __launch_bounds__(64 * hr_nw(CH8, TAPS)) void conv_hr_kernel(const ConvHrK p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int HR_NW = hr_nw(CH8, TAPS);
   constexpr int HALO = TAPS == 9 ? 1 : 0;
-  constexpr int HR_HW = HR_TW + 2 * HALO, HR_NPIX = (HR_TH + 2 * HALO) * HR_HW;      // 18 x 34 = 612 halo pixels (3x3)
+  constexpr int HR_HW = HR_TW + 2 * HALO, HR_HH = HR_TH + 2 * HALO, HR_NPIX = HR_HH * HR_HW;      // 18 x 34 = 612 halo pixels (3x3)
   constexpr int NCHUNK = TAPS * CH8;                    // K in 8-channel chunks
   constexpr int NKS = (NCHUNK + 1) / 2;                 // MFMA K steps (16 channels = two chunks)
   constexpr int SLOTS = (CH8 % 2) ? CH8 : CH8 + 1;      // 16-byte slots per pixel in LDS: odd, so consecutive pixels walk all banks
   constexpr int PIXB = SLOTS * 16;                      // bytes per pixel in LDS
-  constexpr int NG = HR_NPIX * SLOTS;                   // 16-byte chunks of the halo tile (incl. the pad slots)
-  constexpr int NINST = (NG + 63) / 64;                 // wave instructions to fill it
-  constexpr int TILE_BYTES = NINST * 1024;              // (rounded up: overhang lanes fetch the zero page)
-  constexpr int ZERO_OFF = TILE_BYTES;                  // one zero chunk for the padded half K step
+  constexpr int NINST = hr_ninst(CH8, TAPS);            // wave instructions (pieces) per tile, a multiple of 4
+  constexpr int NFI = NINST / HR_NW;                    // per wave
+  constexpr int TILE_BYTES = NINST * 1024;
+  constexpr int NBUF = hr_nbuf(CH8, TAPS);
+  constexpr int ZERO_OFF = NBUF * TILE_BYTES;           // one zero chunk for the padded half K step
+  constexpr int R = HR_TH / (HR_NW / NCT);              // tile rows per wave
+  constexpr int NMF = R * NKS;                          // MFMAs per wave and tile: the pieces are spread over them
+  constexpr int SP = NMF >= NFI ? NMF / NFI : 1, PP = NMF >= NFI ? 1 : (NFI + NMF - 1) / NMF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sStat = reinterpret_cast<float*>(smem + ZERO_OFF + 16);      // [32] per-cout sums of the current tile
+  float* sStat = reinterpret_cast<float*>(smem + ZERO_OFF + 16);      // [64] per-cout sums of the current tile
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pix = lane & 31, hi = lane >> 5;
-  const float slope = p.slope;
-  const half_t* zp = zero_page + (lane & 7) * 8;
-  // ---- persistent workgroup: ONE 32-cout tile's weights stay in registers (NKS fragments per lane, straight from the
-  // fragment-ordered pack) while the workgroup walks its share of the pixel tiles -- reloading them per tile cost as many bytes
-  // through the CU's load path as the tile itself.  Workgroups whose blockIdx / 8 agree modulo ntile_c share a cout tile; a
-  // workgroup's virtual block ids vb = j0, j0 + G', ... keep vb % 8 == blockIdx % 8, so xcd_remap still hands every XCD one
-  // contiguous run of the (row-major) tile order and neighbouring tiles' halos meet in its L2.
-  const int ct = (blockIdx.x >> 3) % p.ntile_c;
-  const unsigned gsub = gridDim.x / p.ntile_c;                          // workgroups per cout tile (launcher: a multiple of 8)
-  const unsigned j0 = ((blockIdx.x >> 3) / p.ntile_c) * 8 + (blockIdx.x & 7);
+  const float aslope = p.act == CSBSR_ACT_RELU ? 0.f : (p.act == CSBSR_ACT_LRELU ? p.slope : 1.f);
+  const bool has_out = p.out16 != nullptr;
+  const int ctl = NCT == 2 ? wid / (HR_NW / 2) : 0, row0 = NCT == 2 ? (wid % (HR_NW / 2)) * R : wid * R;
+  // ---- persistent workgroup: its cout tiles' weights stay in registers (NKS fragments per lane, straight from the fragment-ordered
+  // pack).  Workgroups whose blockIdx / 8 agree modulo the number of cout-tile groups share a group; a workgroup's virtual block ids
+  // vb = j0, j0 + G', ... keep vb % 8 == blockIdx % 8, so xcd_remap still hands every XCD one contiguous run of the (row-major) tile
+  // order and neighbouring tiles' halos meet in its L2.
+  const int groups = (p.ntile_c + NCT - 1) / NCT;
+  const int ct = ((blockIdx.x >> 3) % groups) * NCT + ctl;
+  const int ct_ld = ct < p.ntile_c ? ct : p.ntile_c - 1;
+  const unsigned gsub = gridDim.x / groups;                             // workgroups per group (launcher: a multiple of 8)
+  const unsigned j0 = ((blockIdx.x >> 3) / groups) * 8 + (blockIdx.x & 7);
   h8 wf[NKS];
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) wf[ks] = *reinterpret_cast<const h8*>(p.wt + ((size_t)(ct * NKS + ks) * 64 + lane) * 8);
+  for (int ks = 0; ks < NKS; ++ks) wf[ks] = *reinterpret_cast<const h8*>(p.wt + ((size_t)(ct_ld * NKS + ks) * 64 + lane) * 8);
   if (tid < 4) reinterpret_cast<float*>(smem + ZERO_OFF)[tid] = 0.f;
+  if (STAT && tid < 64) sStat[tid] = 0.f;
   const unsigned per_img = p.tiles_x * p.tiles_y, total = per_img * (unsigned)p.N;
-  const char* lbase = smem + pix * PIXB;               // per-lane base: every fragment address below is lbase + a compile-time constant
-  // DMA roles are the same for every tile: chunk g = (wid + 4 i) * 64 + lane of the halo tile = (halo row ty, halo column tx, slot
-  // c).  The first instruction's role is computed once; consecutive instructions of a lane are 256 chunks apart, i.e. a fixed
-  // (DQ pixels, DC slots) step with carries -- a handful of compares instead of two integer divisions per instruction.
-  constexpr int NFI = (NINST + 3) / 4;
-  constexpr int DQ = 256 / SLOTS, DC = 256 % SLOTS;
-  int f_ty0, f_tx0, f_c0;
-  {
-    const int g = wid * 64 + lane;
-    const int q = g / SLOTS;
-    f_c0 = g - q * SLOTS;
-    f_ty0 = q / HR_HW;
-    f_tx0 = q - f_ty0 * HR_HW;
-  }
-  const int isy = (int)p.i_sy, isx = (int)p.i_sx;        // (within one image: < 2^31 elements, launcher checks)
+  const char* lbase = smem + pix * PIXB;               // per-lane base: every fragment address below is lbase + buffer + a compile-time constant
 
-  for (unsigned vb = j0; vb < total; vb += gsub) {
+  // ---- DMA roles, the same for every tile: piece i of a wave is wave instruction wid + HR_NW i, its lane fills 16-byte chunk
+  // g = (wid + HR_NW i) * 64 + lane of the halo tile = (halo row ty, halo column tx, slot c)
+  int voff[NFI], iy0[NFI], ix0[NFI];
+#pragma unroll
+  for (int i = 0; i < NFI; ++i) {
+    const int g = (wid + HR_NW * i) * 64 + lane, q = g / SLOTS, c = g - q * SLOTS;
+    const int ty = q / HR_HW, tx = q - ty * HR_HW;
+    voff[i] = 2 * (int)(ty * p.i_sy + tx * p.i_sx + c * 8);
+    iy0[i] = (ty < HR_HH && c < CH8) ? ty : 0x40000000;
+    ix0[i] = tx;
+  }
+  auto tile_at = [&](unsigned vb, int& n, int& y0, int& x0) {
+    if (vb >= total) vb -= ((vb - total) / gsub + 1) * gsub;      // past the last tile: refetch the last one (uniform instruction counts)
     const unsigned lt = xcd_remap(vb, total);
-    const int n = lt / per_img;
+    n = lt / per_img;
     const unsigned r_ = lt - n * per_img;
-    const int y0 = (r_ / p.tiles_x) * HR_TH, x0 = (r_ % p.tiles_x) * HR_TW;
-    if (vb != j0) __syncthreads();                     // every wave is done reading the previous tile (and its sums are flushed)
-    // ---- halo tile -> LDS
-    const half_t* tbase = p.in + n * p.i_sn + (long)(y0 - HALO) * p.i_sy + (long)(x0 - HALO) * p.i_sx;      // wave-uniform
-    int ty = f_ty0, tx = f_tx0, c = f_c0;
-#pragma unroll 2      // (fully unrolled the scheduler computes every 64-bit source address up front: 2 x NFI registers)
-    for (int i = 0; i < NFI; ++i) {
-      const int inst = wid + 4 * i;
-      if (inst < NINST) {
-        const int iy = y0 - HALO + ty, ix = x0 - HALO + tx;
-        const bool ok = ty < HR_TH + 2 * HALO && c < CH8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && !(p.dbg & 4);
-        const half_t* src = ok ? tbase + (ty * isy + tx * isx + c * 8) : zp;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(smem + inst * 1024), 16, 0, 0);
-      }
-      c += DC; tx += DQ;
-      if (c >= SLOTS) { c -= SLOTS; ++tx; }
-      if (tx >= HR_HW) { tx -= HR_HW; ++ty; }
-      if (tx >= HR_HW) { tx -= HR_HW; ++ty; }
+    y0 = (r_ / p.tiles_x) * HR_TH; x0 = (r_ % p.tiles_x) * HR_TW;
+  };
+  auto tile_rs = [&](int n, int y0, int x0) {
+    return hr_make_rs(p.in + n * p.i_sn + (long)(y0 - HALO) * p.i_sy + (long)(x0 - HALO) * p.i_sx);
+  };
+  auto issue_piece = [&](__amdgpu_buffer_rsrc_t rs, int y0, int x0, int i, int buf) __attribute__((always_inline)) {
+    const bool ok = (unsigned)(iy0[i] + y0 - HALO) < (unsigned)p.H && (unsigned)(ix0[i] + x0 - HALO) < (unsigned)p.W;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + buf * TILE_BYTES + (wid + HR_NW * i) * 1024), 16,
+                                             ok ? voff[i] : -1, 0, 0, 0);
+  };
+
+  if (j0 >= total) return;
+#pragma unroll
+  for (int k = 0; k < NBUF - 1; ++k) {
+    int n, y0, x0;
+    tile_at(j0 + k * gsub, n, y0, x0);
+    const __amdgpu_buffer_rsrc_t rs = tile_rs(n, y0, x0);
+#pragma unroll
+    for (int i = 0; i < NFI; ++i) issue_piece(rs, y0, x0, i, k);
+  }
+  int buf = 0;
+  for (unsigned vb = j0; vb < total; vb += gsub) {
+    int n, y0, x0, nn, y0n, x0n;
+    tile_at(vb, n, y0, x0);
+    tile_at(vb + (NBUF - 1) * gsub, nn, y0n, x0n);
+    const __amdgpu_buffer_rsrc_t rsn = tile_rs(nn, y0n, x0n);
+    const int bfill = buf == 0 ? NBUF - 1 : buf - 1;
+    // the activation-derivative masks of this wave's rows, requested before any of this tile's DMA pieces: waiting for them then only
+    // drains requests that are older anyway
+    // (MASK is a template parameter and the loads are unconditional -- dead lanes re-read an in-range element: a branch around them
+    // made hipcc drain vmcnt to 0 at the join, i.e. wait for every DMA piece in flight at the top of each tile)
+    h8 mk[MASK ? R : 1][2];
+    if (MASK) {
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+          int oy = y0 + row0 + rr, ox = x0 + pix, co = ct * 32 + 16 * pair + 8 * hi;
+          oy = oy < p.H ? oy : p.H - 1; ox = ox < p.W ? ox : p.W - 1; co = co < p.coutp ? co : 0;
+          mk[rr][pair] = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oy * p.m_sy + ox * p.m_sx + co);
+        }
     }
-    if (STAT && tid < 32) sStat[tid] = 0.f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // this tile has landed everywhere (the NBUF - 2 tiles after it may still be in flight) and every wave is done with the buffer of
+    // the previous tile: the tile NBUF - 1 ahead goes there, piece by piece, below
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NFI) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
     float gsum[STAT ? 16 : 1];
 #pragma unroll
     for (int e = 0; e < (STAT ? 16 : 1); ++e) gsum[e] = 0.f;
-#pragma unroll 1      // (rows unrolled: the scheduler hoists every row's NKS fragment reads and spills the weights)
-    for (int rr = 0; rr < HR_TH / 4; ++rr) {
-      const int row = (HR_TH / 4) * wid + rr;            // output row of the tile
-      const char* rbase = lbase + row * HR_HW * PIXB;
-      f16v acc;
+    const char* tb = lbase + buf * TILE_BYTES;
+    // four rows at a time: four independent accumulator chains, each row's next fragment requested right after the MFMA that consumed
+    // the current one (four MFMAs = 128 cycles of cover for the LDS latency -- with ONE wave per SIMD nothing else hides it; left to
+    // the compiler the read sat directly in front of its MFMA and the K loop ran at LDS-latency pace)
+    constexpr int RG = R < 4 ? R : 4;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      if (!(p.dbg & 2))
+    for (int rp = 0; rp < R / RG; ++rp) {
+      f16v acc[RG];
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
+      for (int q = 0; q < RG; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+      auto frag = [&](int q, int ks) __attribute__((always_inline)) {
         // chunk kc = 2 ks + hi of the flattened (tap, chunk) axis: compile-time for each half-wave
         const int kc0 = 2 * ks, kc1 = 2 * ks + 1;
         const int t0 = kc0 / CH8, c0 = kc0 % CH8, t1 = kc1 / CH8, c1 = kc1 % CH8;
         const int a0 = ((t0 / 3) * HR_HW + (t0 % 3)) * PIXB + (c0 << 4);
         const int a1 = ((t1 / 3) * HR_HW + (t1 % 3)) * PIXB + (c1 << 4);
+        const char* rbase = tb + (row0 + RG * rp + q) * HR_HW * PIXB;
         // odd chunk count: the last step's upper half reads the zero chunk
         const char* addr = (kc1 >= NCHUNK) ? (hi ? smem + ZERO_OFF : rbase + a0) : rbase + (hi ? a1 : a0);
-        const h8 bf = *reinterpret_cast<const h8*>(addr);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], bf, acc, 0, 0, 0);
+        return *reinterpret_cast<const h8*>(addr);
+      };
+      h8 bfr[RG];
+#pragma unroll
+      for (int q = 0; q < RG; ++q) bfr[q] = frag(q, 0);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+        for (int q = 0; q < RG; ++q) {
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], bfr[q], acc[q], 0, 0, 0);
+          if (ks + 1 < NKS) bfr[q] = frag(q, ks + 1);
+          const int idx = (rp * NKS + ks) * RG + q;      // (the pieces are spread over the tile's MFMAs in this order)
+          if (PP == 1) {
+            if (idx % SP == 0 && idx / SP < NFI) issue_piece(rsn, y0n, x0n, idx / SP, bfill);
+          } else {
+#pragma unroll
+            for (int u = 0; u < PP; ++u)
+              if (idx * PP + u < NFI) issue_piece(rsn, y0n, x0n, idx * PP + u, bfill);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
       // ---- epilogue: acc[4q + j] = cout 8q + 4 hi + j of pixel `pix`; swap pairs -> 8 consecutive couts per lane
-      const int oy = y0 + row, ox = x0 + pix;
-      const bool live = oy < p.H && ox < p.W;
 #pragma unroll
-      for (int pair = 0; pair < 2; ++pair) {
-        float v[8];
+      for (int q = 0; q < RG; ++q) {
+        const int rr = RG * rp + q, row = row0 + rr;
+        const int oy = y0 + row, ox = x0 + pix;
+        const bool live = oy < p.H && ox < p.W;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const unsigned a = __float_as_uint(acc[8 * pair + j]), b = __float_as_uint(acc[8 * pair + 4 + j]);
-          auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-          v[j] = __uint_as_float(r[0]);
-          v[4 + j] = __uint_as_float(r[1]);
-        }
-        const int co = ct * 32 + 16 * pair + 8 * hi;
-        if (co >= p.coutp || !live) continue;
+        for (int pair = 0; pair < 2; ++pair) {
+          float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float t = v[e];
-          if (p.act == CSBSR_ACT_RELU) t = fmaxf(t, 0.f);
-          else if (p.act == CSBSR_ACT_LRELU) t = fmaxf(t, t * slope);
-          v[e] = (co + e < p.cout) ? t : 0.f;
-        }
-        if constexpr (STAT) {
+          for (int j = 0; j < 4; ++j) {
+            const unsigned a = __float_as_uint(acc[q][8 * pair + j]), b = __float_as_uint(acc[q][8 * pair + 4 + j]);
+            auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+            v[j] = __uint_as_float(r[0]);
+            v[4 + j] = __uint_as_float(r[1]);
+          }
+          // branch-free: none / ReLU / LeakyReLU are max(t, t * aslope) with aslope = 1 / 0 / slope; output channels past cout need no
+          // zeroing (their packed weight rows are zero); dead lanes (past the image edge, past coutp) only skip the store and the sums.
+          // (With the activation chosen by uniform branches per element this epilogue was ~400 scalar branches per tile and wave --
+          // 2/3 of the tile time once a single wave per SIMD had to run it.)
+          const int co = ct * 32 + 16 * pair + 8 * hi;
+          const bool st_ok = live && co < p.coutp;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) gsum[8 * pair + e] += v[e];
-        }
-        if (p.mask) {
-          const h8 mk = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oy * p.m_sy + ox * p.m_sx + co);
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * aslope);
+          if constexpr (STAT) {
+            const float lf = st_ok ? 1.f : 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= ((float)mk[e] > 0.f ? 1.f : p.mask_slope);
-        }
-        if (p.out16 && (!(p.dbg & 1) || v[0] == 12345.678f)) {
-          h8 hv;
+            for (int e = 0; e < 8; ++e) gsum[8 * pair + e] += v[e] * lf;
+          }
+          if (MASK) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-          *reinterpret_cast<h8*>(p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co) = hv;
+            for (int e = 0; e < 8; ++e) v[e] *= ((float)mk[MASK ? rr : 0][pair][e] > 0.f ? 1.f : p.mask_slope);
+          }
+          if (has_out && st_ok) {
+            h8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
+            *reinterpret_cast<h8*>(p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co) = hv;
+          }
         }
       }
     }
@@ -191,12 +272,18 @@ __global__ __launch_bounds__(256, (CH8 == 4 ? 3 : 2)) void conv_hr_kernel(const 
 #pragma unroll
         for (int pair = 0; pair < 2; ++pair)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) atomicAdd(&sStat[16 * pair + 8 * hi + e], gsum[8 * pair + e]);
+          for (int e = 0; e < 8; ++e) atomicAdd(&sStat[32 * ctl + 16 * pair + 8 * hi + e], gsum[8 * pair + e]);
       }
       __syncthreads();
-      if (tid < 32 && ct * 32 + tid < p.coutp) atomicAdd(p.stat + (size_t)n * p.coutp + ct * 32 + tid, sStat[tid]);
+      if (tid < 32 * NCT) {      // flush this tile's sums and clear the bins for the next one (whose atomics come after its barrier)
+        const int co = (ct - ctl) * 32 + tid;
+        if (co < p.coutp) atomicAdd(p.stat + (size_t)n * p.coutp + co, sStat[tid]);
+        sStat[tid] = 0.f;
+      }
     }
+    buf = buf + 1 == NBUF ? 0 : buf + 1;
   }      // tiles
+#endif
 }
 
 // ---- weights in fragment order:  dst[ct][ks][lane][e] = W(cout = 32 ct + lane%32, chunk kc = 2 ks + lane/32, channel 8 (kc % CH8) + e)
@@ -268,34 +355,32 @@ extern "C" int32_t csbsr_conv_hr_eligible(const csbsr_conv_desc_t* d) {
   if (d->bias || d->cbias || d->res_mode != CSBSR_RES_NONE || d->accumulate || d->out32 || d->o_lo) return 0;
   if (d->act != CSBSR_ACT_NONE && d->act != CSBSR_ACT_RELU && d->act != CSBSR_ACT_LRELU) return 0;
   if (d->stat_mode == CSBSR_STAT_BN || d->out_scale != 1.0f) return 0;
+  if (d->mask && d->stat_mode != CSBSR_STAT_NONE) return 0;
   if ((long)d->N * d->H * d->W < 256L * 1024) return 0;
   return 1;
 }
 
-static half_t* g_hr_zero_page[CSBSR_MAX_DEVICES] = {};
-
-template <int CH8, int TAPS>
-static int launch_hr(const ConvHrK& k, hipStream_t st, const half_t* zp) {
-  constexpr int SLOTS = (CH8 % 2) ? CH8 : CH8 + 1;
-  constexpr int HALO = TAPS == 9 ? 1 : 0;
-  constexpr int NG = (HR_TH + 2 * HALO) * (HR_TW + 2 * HALO) * SLOTS, NINST = (NG + 63) / 64;
-  constexpr int SM_BYTES = NINST * 1024 + 16 + 64 * 4;
-  static_assert(SM_BYTES <= 80 * 1024, "two workgroups per CU must fit");
+template <int CH8, int TAPS, int NCT>
+static int launch_hr(const ConvHrK& k, hipStream_t st) {
+  constexpr int SM_BYTES = hr_smem(CH8, TAPS);
+  static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, true, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, false, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, true, TAPS, NCT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, false, TAPS, NCT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, false, TAPS, NCT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
     attr_set = true;
   }
-  // persistent: (workgroups per CU the registers admit) x 256 CUs, a multiple of 8 x ntile_c; never more than there is work
+  // persistent: one workgroup per CU (the ring of halo tiles takes the LDS), a multiple of 8 x (cout-tile groups); never more than there is work
   const unsigned total = k.tiles_x * k.tiles_y * k.N;
-  const unsigned unit = 8u * k.ntile_c;
-  unsigned g = 256u * (CH8 == 4 ? 3u : 2u);
-  if (g > total * k.ntile_c) g = total * k.ntile_c;
+  const unsigned groups = (unsigned)((k.ntile_c + NCT - 1) / NCT), unit = 8u * groups;
+  unsigned g = 256u;
+  if (g > total * groups) g = total * groups;
   g = (g + unit - 1) / unit * unit;
   dim3 grid(g);
-  if (k.stat) hipLaunchKernelGGL((conv_hr_kernel<CH8, true, TAPS>), grid, dim3(256), SM_BYTES, st, k, zp);
-  else hipLaunchKernelGGL((conv_hr_kernel<CH8, false, TAPS>), grid, dim3(256), SM_BYTES, st, k, zp);
+  if (k.stat) hipLaunchKernelGGL((conv_hr_kernel<CH8, true, TAPS, NCT, false>), grid, dim3(64 * hr_nw(CH8, TAPS)), SM_BYTES, st, k);
+  else if (k.mask) hipLaunchKernelGGL((conv_hr_kernel<CH8, false, TAPS, NCT, true>), grid, dim3(64 * hr_nw(CH8, TAPS)), SM_BYTES, st, k);
+  else hipLaunchKernelGGL((conv_hr_kernel<CH8, false, TAPS, NCT, false>), grid, dim3(64 * hr_nw(CH8, TAPS)), SM_BYTES, st, k);
   CSBSR_LAUNCH_CHECK("csbsr_conv_hr_forward");
   return 0;
 }
@@ -313,19 +398,14 @@ extern "C" int csbsr_conv_hr_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   k.mask = reinterpret_cast<const half_t*>(d->mask); k.m_sn = d->m_sn; k.m_sy = d->m_sy; k.m_sx = d->m_sx; k.mask_slope = d->mask_slope;
   k.stat = d->stat_mode == CSBSR_STAT_SAMPLE_SUM ? d->stat : nullptr;
   k.tiles_x = (unsigned)((d->W + HR_TW - 1) / HR_TW); k.tiles_y = (unsigned)((d->H + HR_TH - 1) / HR_TH);
-  { const char* e = getenv("CSBSR_HR_DBG"); k.dbg = e ? atoi(e) : 0; }
-  int dev = 0;
-  CSBSR_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CSBSR_MAX_DEVICES, "conv_hr: no current device");
-  if (!g_hr_zero_page[dev]) {
-    CSBSR_CHECK(hipMalloc(reinterpret_cast<void**>(&g_hr_zero_page[dev]), 256) == hipSuccess, "conv_hr: zero page alloc failed");
-    (void)hipMemset(g_hr_zero_page[dev], 0, 256);
-  }
+  CSBSR_CHECK(d->in[0].sy < (1l << 31) / 64, "conv_hr: row stride too large for 32-bit piece offsets");
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   g_last_conv_kernel = CONVK_HR;
+  const bool two = k.ntile_c == 2;
   if (d->KH == 3) {
-    if (d->in[0].c == 32) return launch_hr<4, 9>(k, st, g_hr_zero_page[dev]);
-    return launch_hr<7, 9>(k, st, g_hr_zero_page[dev]);
+    if (d->in[0].c == 32) return two ? launch_hr<4, 9, 2>(k, st) : launch_hr<4, 9, 1>(k, st);
+    return two ? launch_hr<7, 9, 2>(k, st) : launch_hr<7, 9, 1>(k, st);
   }
-  if (d->in[0].c == 32) return launch_hr<4, 1>(k, st, g_hr_zero_page[dev]);
-  return launch_hr<7, 1>(k, st, g_hr_zero_page[dev]);
+  if (d->in[0].c == 32) return two ? launch_hr<4, 1, 2>(k, st) : launch_hr<4, 1, 1>(k, st);
+  return two ? launch_hr<7, 1, 2>(k, st) : launch_hr<7, 1, 1>(k, st);
 }

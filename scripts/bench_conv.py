@@ -52,6 +52,7 @@ if __name__ == "__main__":
         "hr49": (1, 1792, 1792, 49, 49, 3, 1, 1),
         "hr32_49": (1, 1792, 1792, 32, 49, 3, 1, 1),
         "hr49_32": (1, 1792, 1792, 49, 32, 3, 1, 1),
+        "hr1x1_32_49": (1, 1792, 1792, 32, 49, 1, 1, 0),
         "thin3_128": (1, 1792, 1792, 3, 128, 3, 1, 1),
         "thin3_512": (1, 1792, 1792, 3, 512, 3, 1, 1),
         "conv8s4_small": (1, 448, 448, 128, 128, 8, 4, 2),
