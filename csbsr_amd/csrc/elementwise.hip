@@ -1165,7 +1165,8 @@ extern "C" int csbsr_bilinear_bwd(const void* dy, int64_t dy_ld, void* dx, int64
 // A zero-padded 3x3 convolution of a spatially constant map (kbpn.py:565-567: fe_kernel.0 applied to GAP(kernel).expand(HR))
 // takes only 16 distinct values per (sample, channel): one per border class (first/last row) x (first/last column).
 // class id = (y==0)*8 + (y==H-1)*4 + (x==0)*2 + (x==W-1).  fill: out[n,y,x,:] = V[n][class][:]
-__global__ void border_class_fill_kernel(const float* V, half_t* out, long ld, int N, int H, int W, int c8) {
+// (optional mask: out *= mask > 0 ? 1 : mslope -- the activation derivative of the layer whose saved output `mask` is, for the dgrad form)
+__global__ void border_class_fill_kernel(const float* V, half_t* out, long ld, int N, int H, int W, int c8, const half_t* mask, long mld, float mslope) {
   const long total = (long)N * H * W * c8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cc = (int)(i % c8); long t = i / c8;
@@ -1174,8 +1175,14 @@ __global__ void border_class_fill_kernel(const float* V, half_t* out, long ld, i
     const int cls = (y == 0) * 8 + (y == H - 1) * 4 + (x == 0) * 2 + (x == W - 1);
     const float* v = V + ((long)n * 16 + cls) * c8 * 8 + cc * 8;
     h8 o;
+    if (mask) {
+      const h8 m = *reinterpret_cast<const h8*>(mask + (((long)n * H + y) * W + x) * mld + cc * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)(v[e] * ((float)m[e] > 0.f ? 1.f : mslope));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+    }
     *reinterpret_cast<h8*>(out + (((long)n * H + y) * W + x) * ld + cc * 8) = o;
   }
 }
@@ -1223,8 +1230,17 @@ __global__ __launch_bounds__(256) void border_class_sums_kernel(const half_t* x,
 }
 extern "C" int csbsr_border_class_fill(const float* V, void* out, int64_t ld, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
   CSBSR_CHECK(V && out && c % 8 == 0, "border_class_fill: bad args");
-  hipLaunchKernelGGL(border_class_fill_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), V, (half_t*)out, (long)ld, N, H, W, c / 8);
+  hipLaunchKernelGGL(border_class_fill_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), V, (half_t*)out, (long)ld, N, H, W, c / 8,
+                     (const half_t*)nullptr, 0l, 0.f);
   CSBSR_LAUNCH_CHECK("csbsr_border_class_fill");
+  return 0;
+}
+extern "C" int csbsr_border_class_fill_masked(const float* V, void* out, int64_t ld, const void* mask, int64_t mask_ld, float mask_slope, int32_t N,
+                                              int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
+  CSBSR_CHECK(V && out && mask && c % 8 == 0, "border_class_fill_masked: bad args");
+  hipLaunchKernelGGL(border_class_fill_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), V, (half_t*)out, (long)ld, N, H, W, c / 8,
+                     (const half_t*)mask, (long)mask_ld, mask_slope);
+  CSBSR_LAUNCH_CHECK("csbsr_border_class_fill_masked");
   return 0;
 }
 // fast path for real image sizes: (1) plain total over all pixels, (2) the O(perimeter) border pixels binned per class in LDS by one

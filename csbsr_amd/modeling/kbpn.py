@@ -423,7 +423,7 @@ class KBPN:
         # dPre, and the ten stand-alone HR epilogue-backward passes per stage (read dOut, read out, write dPre) are gone.
         msk = lambda conv, out: (out, 0.0 if conv.act == A_RELU else conv.slope)
         self._wg(cat2, g, c2)
-        dc2 = cat2.bwd_input(g, mask=msk(cat1, c2))
+        dc2 = self._fold_const_dgrad(cat2, d49, msk(cat1, c2), H, W)
         self._wg(cat1, dc2, c1)
         dc1 = cat1.bwd_input(dc2, mask=msk(cat0, c1))
         del dc2
@@ -465,6 +465,27 @@ class KBPN:
         out = e.new(B, H, W, conv.cout)
         L.call("csbsr_border_class_fill", _ptr(Vp), _ptr(out.t), out.ld, B, H, W, cp, e.stream)
         return out, (w16, k16)
+
+    def _fold_const_dgrad(self, conv, gvec, mask, H, W):
+        """dgrad of a zero-padded 3x3 conv whose dOut is spatially constant per sample (``gvec`` [B, cout]: the backward of the global
+        average pool behind fe_cat.2, kbpn.py:573-578): dIn takes one value per border class -- T = g . W per tap, the 16 class
+        sums with the taps flipped -- times the activation derivative of the layer below (``mask`` = (its saved output, slope)).
+        Replaces a 2*H*W*cin*cout*9 FLOP convolution of a constant map by a masked fill."""
+        e = self.eng
+        B = gvec.shape[0]
+        w16 = conv.w.to(torch.float16).float()                      # same operand rounding as the MFMA path
+        g16 = gvec.to(torch.float16).float()
+        T = torch.einsum("no,ocyx->ncyx", g16, w16)                  # [B, cin, 3, 3]
+        mf = self.Mtap.flip(1)                                       # dIn(y) = sum_ky dOut(y - ky + 1) W(ky): tap 2 falls off the first row
+        V = torch.einsum("ncyx,ay,bx->nabc", T, mf, mf)              # [B, 4, 4, cin]
+        cp = pad8(conv.cin)
+        Vp = e.f32(B, 16, cp)
+        Vp[:, :, :conv.cin] = V.reshape(B, 16, conv.cin)
+        out = e.new(B, H, W, conv.cin)
+        mfm, mslope = mask
+        assert mfm.cp == cp and (mfm.H, mfm.W) == (H, W) and not mfm.bcast
+        L.call("csbsr_border_class_fill_masked", _ptr(Vp), _ptr(out.t), out.ld, _ptr(mfm.t), mfm.ld, float(mslope), B, H, W, cp, e.stream)
+        return out
 
     def _fold_const_conv_bwd(self, conv, dpre, saved, H, W):
         """adjoint of the above: 16 class sums of dPre -> per-tap sums S, dW += S (x) k, dk = W^T S."""

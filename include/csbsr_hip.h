@@ -284,6 +284,11 @@ int csbsr_instnorm_bwd(const void* dy, int64_t dy_ld, const float* x, const floa
  * fill: out[n,y,x,:] = V[n][class][:] (fp32 [N][16][c] -> fp16 NHWC);  sums: its adjoint (sums zeroed by the caller). */
 int csbsr_border_class_fill(const float* V, void* out, int64_t ld, int32_t N, int32_t H, int32_t W, int32_t c,
                             csbsr_stream_t s);
+/* The same fill for the adjoint direction: the dgrad of a 3x3 conv whose dOut is spatially constant (the backward of a global average
+ * pool) also takes one value per border class -- V from the taps flipped -- and the activation derivative of the layer below is applied
+ * on the way out: out *= mask > 0 ? 1 : mask_slope (mask = that layer's saved output, [N,H,W,c] with pixel pitch mask_ld). */
+int csbsr_border_class_fill_masked(const float* V, void* out, int64_t ld, const void* mask, int64_t mask_ld, float mask_slope, int32_t N,
+                                   int32_t H, int32_t W, int32_t c, csbsr_stream_t s);
 int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, int32_t N, int32_t H, int32_t W, int32_t c,
                             csbsr_stream_t s);
 

@@ -145,6 +145,38 @@ def test_full_resolution_thin_wgrad(cin, cout, H, W):
     assert relmax(grads[0], grads[1]) < 1e-3
 
 
+@pytest.mark.parametrize("H,W", [(9, 12), (1, 7), (16, 33)])
+def test_constant_gradient_dgrad_fold(H, W):
+    """KBPN._fold_const_dgrad (dgrad of fe_cat.2 behind the global average pool: one value per border class, masked fill) against the
+    convolution kernels run on the broadcast gradient, and against torch autograd."""
+    import types
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv, FM, pad8
+    from csbsr_amd.modeling.kbpn import KBPN
+    torch.manual_seed(H * 100 + W)
+    eng = _eng()
+    N, cin, cout, slope = 2, 32, 49, 0.1
+    w = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).half().float()
+    conv = Conv(eng, "l", {"l.weight": w.cuda()}, 3, 1, 1, 1, bias=False, act=L.ACT_LRELU, slope=slope)
+    g = (torch.randn(N, cout) * 0.01).half().float()
+    below = torch.randn(N, cin, H, W).half().float()
+    xr = torch.zeros(N, cin, H, W, requires_grad=True)
+    F.conv2d(xr, w, None, 1, 1).backward(g[:, :, None, None].expand(N, cout, H, W))
+    ref = xr.grad * torch.where(below > 0, torch.ones(()), torch.full((), slope))
+    m = torch.ones(4, 3)
+    m[2, 0] = m[3, 0] = 0.0
+    m[1, 2] = m[3, 2] = 0.0
+    stub = types.SimpleNamespace(eng=eng, Mtap=m.cuda())
+    mfm = to_fm(eng, below)
+    out = KBPN._fold_const_dgrad(stub, conv, g.cuda(), (mfm, slope), H, W)
+    t = torch.zeros(N, 1, 1, pad8(cout), dtype=torch.float16, device="cuda")
+    t[:, 0, 0, :cout] = g.cuda().half()
+    out2 = conv.bwd_input(FM(t, cout, bcast=True, H=H, W=W), mask=(mfm, slope))
+    torch.cuda.synchronize()
+    assert relmax(from_fm(out), ref) < 2e-3
+    assert relmax(from_fm(out), from_fm(out2)) < 2e-3
+
+
 def test_two_segment_broadcast_and_epilogue():
     """cat(features, spatially-constant code) conv with FMA epilogue, fp32 planar side output and GAP stat."""
     from csbsr_amd import _lib as L
