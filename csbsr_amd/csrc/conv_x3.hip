@@ -320,11 +320,12 @@ extern "C" int csbsr_pack_weights_x3_strided(const float* w, void* dst, int32_t 
 static int g_conv_x3_mode = 1;      // 0 off, 1 launches that fill the chip, 2 every eligible launch (tests)
 extern "C" void csbsr_debug_set_conv_x3(int mode) { g_conv_x3_mode = mode; }
 
-// Which launches take this kernel: 3x3, stride 1, pad 1, dilation 1, ONE plain-fp16 input segment whose padded channels are a multiple
-// of 64 (>= 512 by default -- measured at N = 4, 448^2: 825 -> 384 875 -> 939 TF/s, its dgrad-shaped twin 921 -> 984, 569 -> 128
-// 693 -> 738, but 384 -> 825 800 -> 714 and 256 -> 697 817 -> 578: with few chunks the per-tile epilogue and pipeline restart outweigh
-// the K loop's gain; >= 128 when forced by csbsr_debug_set_conv_x3(2)), >= 72 padded output channels, fp16 output; any fused epilogue of the general kernels except statistics, the fp32 side
-// output and split (hi + lo) operands.
+// Which launches take this kernel.  3x3, stride 1, pad 1, dilation 1: ONE plain-fp16 input segment whose padded channels are a multiple of
+// 64, >= 384 by default (measured at N = 4, 448^2, with the halo DMA issued inside the K loop: 825 -> 384 1041 TF/s against 899 for the
+// LDS-ring implicit GEMM, its dgrad-shaped twin 1069, 384 -> 825 809 against 800, but 256 -> 697 641 against 817: with few chunks the
+// per-tile epilogue and pipeline restart outweigh the K loop's gain; >= 128 when forced by csbsr_debug_set_conv_x3(2)).  k = 2 x stride
+// (8x8 stride 4): see below.  Both: >= 72 padded output channels, fp16 output; any fused epilogue of the general kernels except
+// statistics, the fp32 side output and split (hi + lo) operands.
 static bool x3_is_strided(const csbsr_conv_desc_t* d) { return d->stride >= 2 && d->KH == 2 * d->stride; }
 
 extern "C" int32_t csbsr_conv_x3_eligible(const csbsr_conv_desc_t* d) {
@@ -337,7 +338,7 @@ extern "C" int32_t csbsr_conv_x3_eligible(const csbsr_conv_desc_t* d) {
     if (d->in[0].c < 64 || d->in[0].c > 512 || d->in[0].c % 64 != 0) return 0;
   } else {
     if (d->KH != 3 || d->stride != 1 || d->pad != 1 || d->OH != d->H || d->OW != d->W) return 0;
-    if (d->in[0].c < (g_conv_x3_mode == 2 ? 128 : 512) || d->in[0].c % 64 != 0) return 0;
+    if (d->in[0].c < (g_conv_x3_mode == 2 ? 128 : 384) || d->in[0].c % 64 != 0) return 0;
   }
   if (d->in[1].c != 0 || d->in[0].sx == 0) return 0;
   if (d->coutp < 72 || !d->out16 || d->out32 || d->o_lo || d->r_lo || d->r2_lo) return 0;

@@ -460,7 +460,8 @@ class Conv:
         if out is None:
             out = self.eng.new(B, H, W, self.cout, split=sp)
         self._launch((x,), wt, False, 3, 1, self.pad, self.dil, H, W, H, W, self.cout, out, None, self.b, self.act, self.slope, self.prelu,
-                     None, None, L.RES_NONE, False, None, L.STAT_NONE, 1.0 / self.WSCALE if sp else 1.0, cbias=cb)
+                     None, None, L.RES_NONE, False, None, L.STAT_NONE, 1.0 / self.WSCALE if sp else 1.0, cbias=cb,
+                     x3=None if sp else (0, cf, self.cout, 0, 0))
         return out, (w16c, k16)
 
     def fwd_const_1x1(self, cvec, x, out=None, stat=None, stat_mode=L.STAT_NONE):

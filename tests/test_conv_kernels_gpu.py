@@ -485,6 +485,38 @@ def test_wide_3x3_kernel(cin, cout, H, W, mode):
     assert relmax(outs[0][0], outs[1][0]) < 1e-3 and relmax(outs[0][1], outs[1][1]) < 1e-3
 
 
+def test_wide_3x3_kernel_with_folded_constant_segment():
+    """SFT conv0 as the model runs it (Conv.fwd_folded: features through the conv kernel, the spatially constant kernel-code segment as a
+    per-border-class bias) on conv_x3_kernel<3> against the implicit-GEMM kernel and against F.conv2d on the concatenated input."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    torch.manual_seed(11)
+    eng = _eng()
+    lib = L.load()
+    N, cf, cc, cout, H, W = 2, 384, 21, 100, 12, 40
+    x = torch.randn(N, cf, H, W).half().float()
+    kv = (torch.rand(N, cc) / cc).half().float()
+    w = (torch.randn(cout, cf + cc, 3, 3) / ((cf + cc) * 9) ** 0.5).half().float()
+    b = torch.randn(cout) * 0.1
+    ref = F.leaky_relu(F.conv2d(torch.cat([x, kv[:, :, None, None].expand(N, cc, H, W)], 1), w, b, 1, 1), 0.1)
+    m = torch.ones(4, 3)
+    m[2, 0] = m[3, 0] = 0.0
+    m[1, 2] = m[3, 2] = 0.0
+    outs = []
+    for x3_mode in (2, 0):
+        lib.csbsr_debug_set_conv_x3(x3_mode)
+        try:
+            conv = Conv(eng, "l", {"l.weight": w.cuda(), "l.bias": b.cuda()}, 3, 1, 1, 1, bias=True, act=L.ACT_LRELU, slope=0.1, split=(cf, cc))
+            y, _ = conv.fwd_folded(to_fm(eng, x), kv.cuda(), m.cuda())
+            torch.cuda.synchronize()
+            assert (lib.csbsr_debug_last_conv_kernel() == 10) == (x3_mode == 2)
+        finally:
+            lib.csbsr_debug_set_conv_x3(1)
+        outs.append(from_fm(y))
+        assert relmax(outs[-1], ref) < 2e-3
+    assert relmax(outs[0], outs[1]) < 1e-3
+
+
 @pytest.mark.parametrize("cin,cout,k,s,p,OH,OW,mode", [
     (128, 128, 8, 4, 2, 19, 45, "prelu_sub"),      # up_conv2 / down_conv shapes, ragged tiles on both axes
     (128, 128, 8, 4, 2, 16, 64, "prelu_add"),      # whole tiles
