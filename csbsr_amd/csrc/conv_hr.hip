@@ -135,6 +135,24 @@ __global__ __launch_bounds__(64 * hr_nw(CH8, TAPS)) void conv_hr_kernel(const Co
   };
 
   if (j0 >= total) return;
+  // (MASK is a template parameter and the loads are unconditional -- dead lanes re-read an in-range element: a branch around them
+  // made hipcc drain vmcnt to 0 at the join, i.e. wait for every DMA piece in flight at the top of each tile)
+  h8 mk[MASK ? R : 1][2], mkn[MASK ? R : 1][2];
+  auto load_masks = [&](h8 (&m)[MASK ? R : 1][2], int n, int y0, int x0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rr = 0; rr < (MASK ? R : 1); ++rr)
+#pragma unroll
+      for (int pair = 0; pair < 2; ++pair) {
+        int oy = y0 + row0 + rr, ox = x0 + pix, co = ct * 32 + 16 * pair + 8 * hi;
+        oy = oy < p.H ? oy : p.H - 1; ox = ox < p.W ? ox : p.W - 1; co = co < p.coutp ? co : 0;
+        m[rr][pair] = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oy * p.m_sy + ox * p.m_sx + co);
+      }
+  };
+  if (MASK) {
+    int n, y0, x0;
+    tile_at(j0, n, y0, x0);
+    load_masks(mkn, n, y0, x0);
+  }
 #pragma unroll
   for (int k = 0; k < NBUF - 1; ++k) {
     int n, y0, x0;
@@ -150,20 +168,18 @@ __global__ __launch_bounds__(64 * hr_nw(CH8, TAPS)) void conv_hr_kernel(const Co
     tile_at(vb + (NBUF - 1) * gsub, nn, y0n, x0n);
     const __amdgpu_buffer_rsrc_t rsn = tile_rs(nn, y0n, x0n);
     const int bfill = buf == 0 ? NBUF - 1 : buf - 1;
-    // the activation-derivative masks of this wave's rows, requested before any of this tile's DMA pieces: waiting for them then only
-    // drains requests that are older anyway
-    // (MASK is a template parameter and the loads are unconditional -- dead lanes re-read an in-range element: a branch around them
-    // made hipcc drain vmcnt to 0 at the join, i.e. wait for every DMA piece in flight at the top of each tile)
-    h8 mk[MASK ? R : 1][2];
     if (MASK) {
 #pragma unroll
-      for (int rr = 0; rr < R; ++rr)
-#pragma unroll
-        for (int pair = 0; pair < 2; ++pair) {
-          int oy = y0 + row0 + rr, ox = x0 + pix, co = ct * 32 + 16 * pair + 8 * hi;
-          oy = oy < p.H ? oy : p.H - 1; ox = ox < p.W ? ox : p.W - 1; co = co < p.coutp ? co : 0;
-          mk[rr][pair] = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oy * p.m_sy + ox * p.m_sx + co);
-        }
+      for (int rr = 0; rr < R; ++rr) { mk[rr][0] = mkn[rr][0]; mk[rr][1] = mkn[rr][1]; }
+    }
+    // the activation-derivative masks are requested ONE TILE AHEAD (those of the next tile here, before any of this tile's DMA pieces):
+    // the wait in front of their first use then only drains requests older than they are -- the previous tile's pieces, due anyway --
+    // and the pieces issued since stay in flight.  (Requested at the top of their own tile they forced the tile one ahead to land
+    // first: half the prefetch depth, 0.87 instead of 0.45 ms on the masked 1x1 layers.)
+    if (MASK) {
+      int n1, y01, x01;
+      tile_at(vb + gsub, n1, y01, x01);
+      load_masks(mkn, n1, y01, x01);
     }
     // this tile has landed everywhere (the NBUF - 2 tiles after it may still be in flight) and every wave is done with the buffer of
     // the previous tile: the tile NBUF - 1 ahead goes there, piece by piece, below
