@@ -474,6 +474,10 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   const bool split_io = d->o_lo || d->r_lo || d->r2_lo || d->mask;     // the thin kernels have their own epilogues: plain fp16, no mask
   if (!split_io && conv_thin_eligible(k)) { g_last_conv_kernel = CONVK_THIN_COUT; return conv_thin_launch(k, st); }
+  if (!split_io && d->in[1].c == 0 && conv_thin_cin2_eligible(k, d->in[0].creal)) {
+    g_last_conv_kernel = CONVK_THIN_CIN2;
+    return conv_thin_cin2_launch(k, d->in[0].creal, st);
+  }
   if (!split_io && d->in[1].c == 0 && conv_thin_cin_eligible(k, d->in[0].creal)) {
     g_last_conv_kernel = CONVK_THIN_CIN;
     return conv_thin_cin_launch(k, d->in[0].creal, st);

@@ -474,6 +474,7 @@ extern "C" void csbsr_debug_set_conv_glds(int mode) {
   g_glds_tile2d = (mode & 64) ? 0 : 1;           // bit 6: linear pixel tiles everywhere (A/B timing)     // bit 5: phases back on grid.z (A/B timing)
   g_glds_wide = (mode & 256) ? 0 : 1;            // bit 8: no 256-cout tile (A/B timing)
   conv_thin_enable((mode & 16) ? 0 : 1);      // bit 4: route the 3-channel heads through the generic kernel (A/B timing)
+  conv_thin_cin2_enable((mode & 512) ? 0 : 1);  // bit 9: no streaming variant of the 3-channel-input kernel (A/B timing, tests)
 }
 
 // eligibility: MFMA-bound shapes only

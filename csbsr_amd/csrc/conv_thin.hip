@@ -278,6 +278,162 @@ int conv_thin_cin_launch(const ConvK& k, int creal, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The same layers where the epilogue is plain -- no bias, no residual, no mask, no statistics; optionally ACCUMULATING into the output
+// (the dgrads of kb.sr_reconst / output_conv into the concatenated feature gradient, fe_SR.0 forward): a lean streaming kernel.  These
+// launches are 5 % of the training step and pure HBM streams (read old + write: 6.6 GB at 128 channels, N = 4), which the kernel above
+// moves at ~3 TB/s: its general epilogue costs 236 VGPRs (two workgroups per CU) and requests each old-output piece right before its
+// use, so ~16 KB per CU are in flight.  Here: one row of 32 pixels per wave, 8 waves, the old-output pieces of the NEXT four 32-cout
+// tiles always requested (a rolling register ring refilled right after each piece is consumed), activation as max(t, t * a),
+// persistent workgroups with the tiny 3-channel halo tile double-buffered in LDS one tile ahead.
+#define TC2_D 4                              // cout tiles of old output in flight per wave
+__global__ __launch_bounds__(512, 2) void conv_thin_cin2_kernel(const ConvK p, int tiles_x, int tiles_y, int CI, int has_old) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nct = (p.cout + 31) / 32;
+  half_t* sWt = reinterpret_cast<half_t*>(smem);                     // [nct*32][TK_WLD], k = tap*CI + c
+  half_t* sIn = sWt + (size_t)nct * 32 * TK_WLD;                      // [2][TN_HP][8]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, pix = lane & 31;
+  for (int id = tid; id < nct * 32 * (TK_WLD / 8); id += 512) {
+    const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *reinterpret_cast<h8*>(sWt + id * 8) = z;
+  }
+  __syncthreads();
+  for (int id = tid; id < nct * 32 * 9; id += 512) {
+    const int co = id / 9, tap = id - co * 9;
+    const h8 v = *reinterpret_cast<const h8*>(p.wt + (size_t)co * p.Kp + tap * 8);
+    for (int c = 0; c < CI; ++c) sWt[co * TK_WLD + tap * CI + c] = v[c];
+  }
+  const float aslope = p.act == CSBSR_ACT_RELU ? 0.f : (p.act == CSBSR_ACT_LRELU ? p.act_slope : 1.f);
+  const half_t* in0 = reinterpret_cast<const half_t*>(p.in[0].ptr);
+  const unsigned per_img = (unsigned)(tiles_x * tiles_y), total = per_img * (unsigned)p.N;
+  // halo pixel of this thread (threads < TN_HP) for a tile: one 16-byte load, out-of-image pixels zero
+  auto halo_load = [&](unsigned t) {
+    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tid < TN_HP && t < total) {
+      const int n = t / per_img;
+      const unsigned r = t - n * per_img;
+      const int hy = tid / TN_HW, hx = tid - hy * TN_HW;
+      const int iy = (int)(r / tiles_x) * TN_TH + hy - 1, ix = (int)(r % tiles_x) * TN_TW + hx - 1;
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        v = *reinterpret_cast<const h8*>(in0 + (long)n * p.in[0].sn + (long)iy * p.in[0].sy + (long)ix * p.in[0].sx);
+    }
+    return v;
+  };
+  unsigned t = blockIdx.x;
+  if (t >= total) return;
+  {
+    const h8 v = halo_load(t);
+    if (tid < TN_HP) *reinterpret_cast<h8*>(sIn + tid * 8) = v;
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; t < total; t += gridDim.x) {
+    const h8 hnext = halo_load(t + gridDim.x);                        // the next tile's halo pixel, stored after this tile's MFMAs
+    const int n = t / per_img;
+    const unsigned r_ = t - n * per_img;
+    const int oy = (int)(r_ / tiles_x) * TN_TH + wid, ox = (int)(r_ % tiles_x) * TN_TW + pix;
+    const bool live = oy < p.OH && ox < p.OW;
+    // the row's pixel operand: K = (tap, channel) dense, 27 -> 32
+    const half_t* sI = sIn + buf * (TN_HP * 8);
+    h8 pf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * s + 8 * hi + e;
+        const int tap = k / CI, c = k - tap * CI;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        pf[s][e] = tap < 9 ? sI[((wid + ky) * TN_HW + pix + kx) * 8 + c] : (half_t)0;
+      }
+    // output pointer of this lane: couts 8 hi .. of its pixel; piece (ct, pair) at + 32 ct + 16 pair (dead lanes re-read pixel 0)
+    half_t* o = p.out16 + (live ? n * p.o_sn + oy * p.o_sy + ox * p.o_sx : 0) + 8 * hi;
+    h8 ring[TC2_D][2];
+    auto piece_ok = [&](int ct, int pair) { return 32 * ct + 16 * pair + 8 * hi < p.coutp; };
+    if (has_old) {
+#pragma unroll
+      for (int j = 0; j < TC2_D; ++j)
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair)
+          ring[j][pair] = *reinterpret_cast<const h8*>(o + (piece_ok(j, pair) ? 32 * j + 16 * pair : 0));
+    }
+    for (int c4 = 0; c4 < nct; c4 += TC2_D) {
+#pragma unroll
+      for (int j = 0; j < TC2_D; ++j) {
+        const int ct = c4 + j;
+        const int ctc = ct < nct ? ct : nct - 1;
+        const half_t* wrow = sWt + (size_t)(ctc * 32 + pix) * TK_WLD + 8 * hi;
+        const h8 w0 = *reinterpret_cast<const h8*>(wrow);
+        const h8 w1 = *reinterpret_cast<const h8*>(wrow + 16);
+        f16v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, pf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, pf[1], acc, 0, 0, 0);
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const unsigned a = __float_as_uint(acc[8 * pair + q]), b = __float_as_uint(acc[8 * pair + 4 + q]);
+            auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+            v[q] = __uint_as_float(r[0]);
+            v[4 + q] = __uint_as_float(r[1]);
+          }
+          const h8 old = ring[j][pair];
+          // refill this ring slot with the piece TC2_D cout tiles on (clamped: harmless re-read past the last tile)
+          if (has_old) {
+            const int ctn = ct + TC2_D;
+            ring[j][pair] = *reinterpret_cast<const h8*>(o + ((ctn < nct && piece_ok(ctn, pair)) ? 32 * ctn + 16 * pair : 0));
+          }
+          h8 hv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float tv = v[e] * p.out_scale;
+            tv = fmaxf(tv, tv * aslope);
+            if (has_old) tv += (float)old[e];
+            hv[e] = (half_t)tv;
+          }
+          if (live && ct < nct && piece_ok(ct, pair)) *reinterpret_cast<h8*>(o + 32 * ct + 16 * pair) = hv;
+        }
+      }
+    }
+    // next tile's halo into the other buffer (nobody reads it during this tile), then one barrier per tile
+    if (tid < TN_HP) *reinterpret_cast<h8*>(sIn + (buf ^ 1) * (TN_HP * 8) + tid * 8) = hnext;
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+static int g_conv_thin2 = 1;
+void conv_thin_cin2_enable(int on) { g_conv_thin2 = on; }
+
+bool conv_thin_cin2_eligible(const ConvK& k, int creal) {
+  if (!g_conv_thin2 || !conv_thin_cin_eligible(k, creal)) return false;
+  if (k.bias || k.cbias || k.res_mode != CSBSR_RES_NONE || k.mask || k.out32 || !k.out16 || k.o_lo) return false;
+  if (k.act != CSBSR_ACT_NONE && k.act != CSBSR_ACT_RELU && k.act != CSBSR_ACT_LRELU) return false;
+  if (k.coutp % 8 != 0 || k.o_sx < k.coutp) return false;
+  return true;
+}
+
+int conv_thin_cin2_launch(const ConvK& k, int creal, hipStream_t st) {
+  const int tiles_x = (k.OW + TN_TW - 1) / TN_TW, tiles_y = (k.OH + TN_TH - 1) / TN_TH;
+  const int nct = (k.cout + 31) / 32;
+  const size_t smem = ((size_t)nct * 32 * TK_WLD + (size_t)2 * TN_HP * 8) * sizeof(half_t);
+  static size_t configured = 0;
+  if (smem > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_cin2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+      csbsr_set_error("conv(thin-in, streaming): cannot reserve %zu bytes of LDS", smem);
+      return 1;
+    }
+    configured = smem;
+  }
+  const long total = (long)k.N * tiles_x * tiles_y;
+  const unsigned g = (unsigned)(total < 512 ? total : 512);
+  hipLaunchKernelGGL(conv_thin_cin2_kernel, dim3(g), dim3(512), smem, st, k, tiles_x, tiles_y, creal, k.accumulate ? 1 : 0);
+  CSBSR_LAUNCH_CHECK("csbsr_conv_forward(thin-in, streaming)");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Thin-input TRANSPOSED convolution (kernel <= 2 x stride: 2 x 2 taps per output phase) from a 3-channel image: kb.up_conv1 of every
 // back-projection stage (DeconvBlock 3 -> 128, 8x8 stride 4, PReLU, + residual; kbpn.py:497-503).  12 MACs per output value: the
 // padded implicit GEMM ran it at 22 TFLOP/s (2.8 ms per launch for a 1.3 ms read + write stream).  Streaming VALU kernel: a thread owns

@@ -50,7 +50,7 @@ def canon(name):
     m = re.search(r"conv_x3_kernelILi(\d)E", name) or re.search(r"conv_x3_kernel<(\d)>", name)
     if m:
         return "conv_x3_kernel<%s>" % m.group(1)
-    for k in ("conv_wgrad_hr_kernel", "conv_wgrad_thin_kernel", "conv_wgrad_kernel", "conv_thin_cout_kernel", "conv_thin_cin_kernel", "epilogue_bwd_kernel",
+    for k in ("conv_wgrad_hr_kernel", "conv_wgrad_thin_kernel", "conv_wgrad_kernel", "conv_thin_cout_kernel", "conv_thin_cin2_kernel", "conv_thin_cin_kernel", "epilogue_bwd_kernel",
               "unpack_wgrad_kernel", "bn_bwd_apply_kernel", "bn_bwd_reduce_kernel", "bn_apply_kernel"):
         if k in name:
             return k

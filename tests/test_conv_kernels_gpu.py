@@ -177,6 +177,52 @@ def test_constant_gradient_dgrad_fold(H, W):
     assert relmax(from_fm(out), from_fm(out2)) < 2e-3
 
 
+@pytest.mark.parametrize("cout,H,W,acc,act", [(128, 19, 45, True, "none"), (49, 16, 64, False, "relu"), (200, 9, 40, True, "none"),
+                                              (384, 8, 32, False, "lrelu"), (32, 11, 33, True, "none")])
+def test_streaming_thin_input_kernel(cout, H, W, acc, act):
+    """conv_thin_cin2_kernel (3-channel image -> cout channels, 3x3, plain or accumulating epilogue; the dgrads of kb.sr_reconst /
+    output_conv into the feature gradient and fe_SR.0 forward) against F.conv2d on fp16-rounded operands and against the
+    general-epilogue kernel it takes these launches from."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    torch.manual_seed(cout + H * W)
+    eng = _eng()
+    lib = L.load()
+    N = 2
+    # as a dgrad: the layer is Conv2d(cout -> 3); its input gradient = conv of dPre (3 channels) with the flipped, transposed weights
+    w = (torch.randn(3, cout, 3, 3) / (cout * 9) ** 0.5).half().float()
+    conv = Conv(eng, "l", {"l.weight": w.cuda()}, 3, 1, 1, 1, bias=False, act=L.ACT_NONE)
+    dpre = torch.randn(N, 3, H, W).half().float()
+    old = torch.randn(N, cout, H, W).half().float()
+    xr = torch.zeros(N, cout, H, W, requires_grad=True)
+    F.conv2d(xr, w, None, 1, 1).backward(dpre)
+    refd = xr.grad + (old if acc else 0.0)
+    # as a forward: Conv2d(3 -> cout), no bias, activation
+    wf = (torch.randn(cout, 3, 3, 3) / 27 ** 0.5).half().float()
+    a = {"none": L.ACT_NONE, "relu": L.ACT_RELU, "lrelu": L.ACT_LRELU}[act]
+    fconv = Conv(eng, "f", {"f.weight": wf.cuda()}, 3, 1, 1, 1, bias=False, act=a, slope=0.1)
+    x = torch.randn(N, 3, H, W).half().float()
+    pre = F.conv2d(x, wf, None, 1, 1)
+    reff = {"none": pre, "relu": F.relu(pre), "lrelu": F.leaky_relu(pre, 0.1)}[act]
+    outs = []
+    for mode in (2, 2 | 512):            # csbsr_debug_set_conv_glds: default, streaming variant off
+        lib.csbsr_debug_set_conv_glds(mode)
+        try:
+            dx = to_fm(eng, old)
+            conv.bwd_input(to_fm(eng, dpre), out=dx, accumulate=acc)
+            torch.cuda.synchronize()
+            assert lib.csbsr_debug_last_conv_kernel() == (13 if mode == 2 else 6)
+            y = fconv.fwd(to_fm(eng, x))
+            torch.cuda.synchronize()
+            assert lib.csbsr_debug_last_conv_kernel() == (13 if mode == 2 else 6)
+        finally:
+            lib.csbsr_debug_set_conv_glds(2)
+        outs.append((from_fm(dx), from_fm(y)))
+        assert relmax(outs[-1][0], refd) < 2e-3
+        assert relmax(outs[-1][1], reff) < 2e-3
+    assert relmax(outs[0][0], outs[1][0]) < 1e-3 and relmax(outs[0][1], outs[1][1]) < 1e-3
+
+
 def test_two_segment_broadcast_and_epilogue():
     """cat(features, spatially-constant code) conv with FMA epilogue, fp32 planar side output and GAP stat."""
     from csbsr_amd import _lib as L
