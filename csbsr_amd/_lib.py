@@ -174,7 +174,7 @@ def load():
     _lib = lib
     if os.environ.get("CSBSR_WGRAD_DBG"):          # A/B hook: bit0 transpose reads, 2 no thin, 4 no tap order, 8 no flat grid, 16 flat everywhere
         lib.csbsr_debug_set_wgrad_tr(int(os.environ["CSBSR_WGRAD_DBG"]))
-    if os.environ.get("CSBSR_CONV_X3"):            # A/B hook: 0 off, 1 default, 2 every eligible launch; +4 pixel-tile-resident work order
+    if os.environ.get("CSBSR_CONV_X3"):            # A/B hook: 0 off, 1 default, 2 every eligible launch
         lib.csbsr_debug_set_conv_x3(int(os.environ["CSBSR_CONV_X3"]))
     if os.environ.get("CSBSR_WGRAD_HR"):           # A/B hook: 0 off, 1 default, 2 every eligible launch
         lib.csbsr_debug_set_wgrad_hr(int(os.environ["CSBSR_WGRAD_HR"]))

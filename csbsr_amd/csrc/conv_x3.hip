@@ -38,7 +38,6 @@ constexpr int x3_buf(int KS) { return x3_ninst(KS) * 1024; }
 struct X3Extra {
   unsigned tiles_x, tiles_y, nct, nch;   // pixel tiles, 128-cout tiles, chunks (64 channels [x input phase])
   unsigned ncc;                          // 64-channel chunks per input phase (KS = 2)
-  unsigned ct_major;                     // 1 (default): cout-tile-major over all pixel tiles; 0: csbsr_debug_set_conv_x3 bit 2
 };
 
 // (the buffer-descriptor type and builtins exist in the device pass only: the host pass sees an empty kernel body and emits the stub)
@@ -63,9 +62,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pix = lane & 31, hi = lane >> 5;
   const half_t* zp = zero_page + (lane & 7) * 8;
-  const unsigned per_img = q.tiles_x * q.tiles_y, ntiles = per_img * (unsigned)p.N;
-  unsigned it = blockIdx.x;                              // item id = blockIdx.x + k * gridDim.x, k = this workgroup's k-th (pixel tile, cout tile)
-  if (it >= ntiles) return;
+  const unsigned per_img = q.tiles_x * q.tiles_y, ntiles = per_img * (unsigned)p.N, items = ntiles * q.nct;
+  unsigned it = blockIdx.x;
+  if (it >= items) return;
   const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
   const half_t* in0 = reinterpret_cast<const half_t*>(p.in[0].ptr);
   const int isy = (int)p.in[0].sy, isx = (int)p.in[0].sx;
@@ -122,20 +121,9 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
 #pragma unroll
     for (int i = 0; i < NFI; ++i) issue_one(rs, by, bx, i, buf);
   };
-  // Work order.  Default (ct_major): cout-tile-major over ALL pixel tiles -- everybody streams the same weight slice, the input is
-  // re-read once per cout tile (PMC: 4.8 GB fetched per launch for 1.6 GB of operands on the 825-cout layers, half of it absorbed by
-  // L2 / MALL).  Alternative (csbsr_debug_set_conv_x3 bit 2): a workgroup keeps ONE pixel tile for all cout tiles in a row, then moves
-  // gridDim.x tiles on -- still one cout tile at a time chip-wide, the halo chunks of cout tiles 2..nct re-read from L2.  Measured in
-  // one run at N = 4: 3 % SLOWER (825 -> 384 1029 vs 1058 TF/s, 384 -> 825 806 vs 829, dgrad-shaped 1025 vs 1069), so it is not the
-  // default; its HBM-traffic saving (~29 GB per image-step by the arithmetic above) would put the step under 400 GB.
-  auto tile_of = [&](unsigned item) {
-    if (q.ct_major) return item < ntiles * q.nct ? item % ntiles : ntiles;
-    return ((item - blockIdx.x) / gridDim.x / q.nct) * gridDim.x + blockIdx.x;
-  };
   auto decode = [&](unsigned item, int& ct, int& n, int& Y0, int& X0) {
-    const unsigned k = (item - blockIdx.x) / gridDim.x, band = k / q.nct;
-    ct = q.ct_major ? (int)(item / ntiles) : (int)(k - band * q.nct);
-    const unsigned tile = q.ct_major ? item - (unsigned)ct * ntiles : band * gridDim.x + blockIdx.x;
+    ct = item / ntiles;                                  // cout-tile-major: everybody streams the same weight slice
+    const unsigned tile = item - ct * ntiles;
     n = tile / per_img;
     const unsigned r_ = tile - n * per_img;
     Y0 = (r_ / q.tiles_x) * X3_TH; X0 = (r_ % q.tiles_x) * X3_TW;
@@ -162,11 +150,10 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
   for (int g = 0; g < DIST; ++g) load_w(ct, g, wreg[g]);
   const int nsteps = (int)q.nch * NT;
 
-  for (; tile_of(it) < ntiles; it += gridDim.x) {
+  for (; it < items; it += gridDim.x) {
     const unsigned itn = it + gridDim.x;
-    const bool more = tile_of(itn) < ntiles;
     int ctn = ct, nn = n, Y0n = Y0, X0n = X0;
-    if (more) decode(itn, ctn, nn, Y0n, X0n);
+    if (itn < items) decode(itn, ctn, nn, Y0n, X0n);
     const unsigned par = ((it - blockIdx.x) / gridDim.x) * q.nch;     // chunk c of this tile lives in buffer (par + c) & 1
     f16v acc[2][4];
 #pragma unroll
@@ -189,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
       // instruction count uniform), issued piece by piece below
       int nby, nbx;
       const half_t* nsrc = c + 1 < (int)q.nch ? chunk_src(n, Y0, X0, c + 1, nby, nbx)
-                                              : (more ? chunk_src(nn, Y0n, X0n, 0, nby, nbx) : chunk_src(n, Y0, X0, 0, nby, nbx));
+                                              : (itn < items ? chunk_src(nn, Y0n, X0n, 0, nby, nbx) : chunk_src(n, Y0, X0, 0, nby, nbx));
       const __amdgpu_buffer_rsrc_t nrs = x3_make_rs(nsrc);
       asm volatile("" ::: "memory");
       const char* xb = xl + ((par + c) & 1) * X3_BUF;
@@ -331,8 +318,7 @@ extern "C" int csbsr_pack_weights_x3_strided(const float* w, void* dst, int32_t 
 }
 
 static int g_conv_x3_mode = 1;      // 0 off, 1 launches that fill the chip, 2 every eligible launch (tests)
-static int g_conv_x3_ct_major = 1;  // bit 2 of the mode selects the pixel-tile-resident work order instead (see the kernel)
-extern "C" void csbsr_debug_set_conv_x3(int mode) { g_conv_x3_mode = mode & 3; g_conv_x3_ct_major = (mode & 4) ? 0 : 1; }
+extern "C" void csbsr_debug_set_conv_x3(int mode) { g_conv_x3_mode = mode; }
 
 // Which launches take this kernel.  3x3, stride 1, pad 1, dilation 1: ONE plain-fp16 input segment whose padded channels are a multiple of
 // 64, >= 384 by default (measured at N = 4, 448^2, with the halo DMA issued inside the K loop: 825 -> 384 1041 TF/s against 899 for the
@@ -387,7 +373,6 @@ extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   q.tiles_x = (unsigned)((d->OW + X3_TW - 1) / X3_TW); q.tiles_y = (unsigned)((d->OH + X3_TH - 1) / X3_TH);
   q.nct = (unsigned)((d->coutp + 127) / 128); q.ncc = (unsigned)(d->in[0].c / 64);
   q.nch = strided ? q.ncc * (unsigned)(d->stride * d->stride) : q.ncc;
-  q.ct_major = (unsigned)g_conv_x3_ct_major;
   int dev = 0, ncu = 256;
   CSBSR_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CSBSR_MAX_DEVICES, "conv_x3: no current device");
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -395,8 +380,8 @@ extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
     CSBSR_CHECK(hipMalloc(reinterpret_cast<void**>(&g_x3_zero_page[dev]), 256) == hipSuccess, "conv_x3: zero page alloc failed");
     (void)hipMemset(g_x3_zero_page[dev], 0, 256);
   }
-  const unsigned ntiles = q.tiles_x * q.tiles_y * (unsigned)d->N;      // (a workgroup walks all cout tiles of its pixel tiles)
-  const unsigned g = ntiles < (unsigned)ncu ? ntiles : (unsigned)ncu;
+  const unsigned items = q.tiles_x * q.tiles_y * (unsigned)d->N * q.nct;
+  const unsigned g = items < (unsigned)ncu ? items : (unsigned)ncu;
   g_last_conv_kernel = strided ? CONVK_X3S : CONVK_X3;
   return strided ? launch_x3<2>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s))
                  : launch_x3<3>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s));

@@ -25,8 +25,7 @@ void csbsr_debug_set_wgrad_tr(int flags);
 void csbsr_debug_set_conv_glds(int mode);
 /* phase-decomposed transposed-conv kernel (csrc/conv_tp.hip): 0 never eligible, 1 problems of >= 128 tiles (default), 2 every eligible launch */
 void csbsr_debug_set_conv_tp(int mode);
-/* wide 3x3 / strided kernel (csrc/conv_x3.hip): bits 0-1: 0 never eligible, 1 launches of >= 512 tile x cout-tile items (default), 2 every
- * eligible launch; bit 2: pixel-tile-resident work order instead of cout-tile-major (A/B) */
+/* wide 3x3 kernel (csrc/conv_x3.hip): 0 never eligible, 1 launches of >= 512 tile x cout-tile items (default), 2 every eligible launch */
 void csbsr_debug_set_conv_x3(int mode);
 /* full-resolution thin 3x3 weight-gradient kernel (csrc/conv_wgrad_hr.hip): 0 never, 1 launches of >= 1024 tiles (default), 2 every eligible launch */
 void csbsr_debug_set_wgrad_hr(int mode);
