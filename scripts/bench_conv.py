@@ -44,6 +44,7 @@ if __name__ == "__main__":
         "sft825_384": (1, 448, 448, 825, 384, 3, 1, 1),
         "sft256_697": (1, 448, 448, 256, 697, 3, 1, 1),
         "sft569_128": (1, 448, 448, 569, 128, 3, 1, 1),
+        "sft128_569": (1, 448, 448, 128, 569, 3, 1, 1),
         "conv8s4": (1, 1792, 1792, 128, 128, 8, 4, 2),
         "deconv8s4": (1, 448, 448, 128, 128, 8, 4, 2, 1, True),
         "res512": (8, 224, 224, 512, 512, 3, 1, 1),
