@@ -135,37 +135,54 @@ extern "C" int csbsr_pack_weights_split(const float* w, void* dst, int32_t kind,
 
 // G[a][tap][bpad]  ->  grad[a_off + a][b][kh][kw] += ...   (grad is [D0][D1][KH][KW]; a indexes D0 unless
 // transpose_ab, in which case a indexes D1 and b indexes D0)
-__global__ void unpack_wgrad_kernel(const float* g, float* grad, int A, int Breal, int KH, int KW, int seg0_real,
-                                    int seg0_p, int segtot_p, int D0, int D1, int transpose_ab, int b_off, float scale, int splits,
-                                    long slab) {
-  // one thread per FOUR consecutive elements of the packed layout [a][tap][b_padded] (b_padded is a multiple of 8, so the four share
-  // row, tap and segment): 16-byte loads, the slab loop unrolled over independent accumulators; the writes go to OIHW / IOHW
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* g, float* grad, int A, int Breal, int KH, int KW, int seg0_real,
+                                                           int seg0_p, int segtot_p, int D0, int D1, int transpose_ab, int b_off, float scale,
+                                                           int splits, long slab) {
+  // A workgroup = 32 groups of FOUR consecutive elements of the packed layout [a][tap][b_padded] (b_padded is a multiple of 8, so the
+  // four share row, tap and segment) x 8 slab lanes: lane s sums slabs s, s + 8, ... with 16-byte loads (32 consecutive groups = 512
+  // contiguous bytes per slab), the eight partial sums meet in LDS, lane 0 writes OIHW / IOHW.  (One thread per group walking all
+  // 256-1024 slabs two at a time was latency-bound: 65 us per call on 36 KB slabs, 230 calls per step.)
+  __shared__ f4 red[256];
   const int ktot = KH * KW * segtot_p;
   const long total4 = (long)A * ktot / 4;
   const f4* g4 = reinterpret_cast<const f4*>(g);
   const long slab4 = slab / 4;
-  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total4; q += (long)gridDim.x * blockDim.x) {
-    const long gi = q * 4;
-    const int a = (int)(gi / ktot);
-    const int r = (int)(gi - (long)a * ktot);
-    const int tap = r / segtot_p, bp = r - tap * segtot_p;
-    int b;
-    if (bp < seg0_p) { if (bp >= seg0_real) continue; b = bp; }
-    else { b = seg0_real + (bp - seg0_p); if (b >= Breal) continue; }
-    f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-    int sp = 0;
-    for (; sp + 1 < splits; sp += 2) { v0 += g4[(long)sp * slab4 + q]; v1 += g4[(long)(sp + 1) * slab4 + q]; }
-    if (sp < splits) v0 += g4[(long)sp * slab4 + q];
-    v0 += v1;
-    const int kh = tap / KW, kw = tap - kh * KW;
-    const int lim = bp < seg0_p ? seg0_real : Breal;      // real channels end inside this group of four?
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (b + e >= lim) break;
-      const int bb = b + e + b_off;
-      const long di = transpose_ab ? ((((long)bb * D1 + a) * KH + kh) * KW + kw) : ((((long)a * D1 + bb) * KH + kh) * KW + kw);
-      grad[di] += v0[e] * scale;
+  const int ql = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  for (long qb = (long)blockIdx.x * 32; qb < total4; qb += (long)gridDim.x * 32) {
+    const long q = qb + ql;
+    bool valid = q < total4;
+    int a = 0, tap = 0, bp = 0, b = 0;
+    if (valid) {
+      const long gi = q * 4;
+      a = (int)(gi / ktot);
+      const int r = (int)(gi - (long)a * ktot);
+      tap = r / segtot_p; bp = r - tap * segtot_p;
+      if (bp < seg0_p) { b = bp; valid = bp < seg0_real; }
+      else { b = seg0_real + (bp - seg0_p); valid = b < Breal; }
     }
+    f4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      int sp = sl;
+      for (; sp + 8 < splits; sp += 16) { v0 += g4[(long)sp * slab4 + q]; v1 += g4[(long)(sp + 8) * slab4 + q]; }
+      if (sp < splits) v0 += g4[(long)sp * slab4 + q];
+    }
+    red[threadIdx.x] = v0 + v1;
+    __syncthreads();
+    if (sl == 0 && valid) {
+      f4 v = red[ql];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) v += red[32 * j + ql];
+      const int kh = tap / KW, kw = tap - kh * KW;
+      const int lim = bp < seg0_p ? seg0_real : Breal;      // real channels end inside this group of four?
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (b + e >= lim) break;
+        const int bb = b + e + b_off;
+        const long di = transpose_ab ? ((((long)bb * D1 + a) * KH + kh) * KW + kw) : ((((long)a * D1 + bb) * KH + kh) * KW + kw);
+        grad[di] += v[e] * scale;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -177,7 +194,7 @@ extern "C" int csbsr_unpack_wgrad(const float* g, float* grad, int32_t A, int32_
   const int segtot_p = seg0_p + (seg1_real > 0 ? round_up(seg1_real, 8) : 0);
   const int Breal = seg0_real + seg1_real;
   const long total = (long)A * KH * KW * segtot_p;
-  int blocks = (int)((total / 4 + 255) / 256);
+  int blocks = (int)((total / 4 + 31) / 32);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(s), g, grad, A,
                      Breal, KH, KW, seg0_real, seg0_p, segtot_p, D0, D1, transpose_ab, b_off, scale, splits,
