@@ -3,19 +3,23 @@
 // implicit-GEMM kernels ran ~4x off their byte roofline (each of the 9 taps re-gathers the pixel operand through the L1/LDS path and
 // every fragment pair is read from LDS: a 32-cout K slice is 4 MFMAs per wave against ~60 address instructions).
 //
-//  * one workgroup (4 waves) = 16 x 32 output tiles; a tile's (16+2) x (32+2) input halo goes HBM -> LDS ONCE with
-//    global_load_lds_dwordx4 (16-byte channel chunks, zero page for out-of-image pixels) -- 1.2x the tile's own bytes instead of 9x;
+//  * ONE persistent workgroup per CU walks 16 x 32 output tiles; a tile's (16+2) x (32+2) input halo goes HBM -> LDS ONCE (16-byte
+//    channel chunks, out-of-image pixels zero-filled by the buffer descriptor's bounds check) -- 1.2x the tile's own bytes instead of
+//    9x -- into a ring of 2-3 tile buffers: the pieces of the tile two ahead are issued one at a time between the MFMAs of the current
+//    one, so ~100 KB per CU are always under way (see the kernel's comment for what the first version -- one tile per workgroup, 2-3
+//    workgroups per CU -- lost);
 //  * the WEIGHTS never touch LDS: they are packed in MFMA-fragment order (csbsr_pack_weights_hr) and each lane keeps its A fragments
 //    of all K steps of one 32-cout tile in registers (18 steps x 4 VGPRs for 32 channels, 32 x 4 for 49 -> 56), so the K loop is one
 //    ds_read_b128 of the pixel operand per MFMA and nothing else;
 //  * K is flattened over (tap, 8-channel chunk): an MFMA K step = two chunks, one per half-wave, each half-wave addressing its own
 //    (tap, chunk) -- 56-channel maps need no padding to 64 (63 chunks -> 32 steps);
 //  * bank conflicts: a 64-byte pixel pitch (32 channels) would put pixels p and p + 4 on the same 16-byte slots, so a 32-channel
-//    pixel is laid out on FIVE slots (80 bytes, the fifth fetched from the zero page): an odd pitch in 16-byte slots is conflict-free
+//    pixel is laid out on FIVE slots (80 bytes, the fifth slot zero-filled): an odd pitch in 16-byte slots is conflict-free
 //    for the 16 consecutive-pixel lanes of a ds_read_b128 group, as the 112-byte pitch of 56 channels already is -- and with no XOR
 //    swizzle every fragment address is one per-lane base register plus a compile-time offset (no address arithmetic in the K loop);
-//  * epilogue in registers: v_permlane32_swap turns the MFMA layout into 8 consecutive couts per lane, activation, optional fused
-//    activation-derivative mask (dgrads), optional global-average-pool sums (fe_cat.2), 16-byte stores.
+//  * epilogue in registers: v_permlane32_swap turns the MFMA layout into 8 consecutive couts per lane, branch-free activation, optional
+//    fused activation-derivative mask (dgrads; requested one tile ahead), optional global-average-pool sums (fe_cat.2), 16-byte stores;
+//  * a 49-cout layer's two 32-cout tiles are computed from the same halo tile (the waves split by cout tile).
 //
 // Replaces F.conv2d at kbpn.py:536-547 (via ConvBlock) and its autograd dgrad for the eligible layers.
 #include "common.h"

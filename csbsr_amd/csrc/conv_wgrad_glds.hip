@@ -2,7 +2,7 @@
 //
 // Same math, grid and slab contract as conv_wgrad.hip; different data movement.  The register-staged kernel spends 55 % of a
 // workgroup's life issuing the next step's loads (address arithmetic, predicated 16-byte loads into staging VGPRs, a ds_write
-// pass): here both operand tiles go HBM -> LDS with global_load_lds_dwordx4 into an NSTAGE-deep ring (counted s_waitcnt vmcnt(N) +
+// pass): here both operand tiles go HBM -> LDS with global_load_lds_dwordx4 / buffer_load_dwordx4 ... lds into an NSTAGE-deep ring (counted s_waitcnt vmcnt(N) +
 // raw s_barrier, DMAs stay in flight across barriers), exactly as conv_igemm_glds.hip stages the forward operands.
 //
 //  * a stage = 64 reduction pixels of the A tile ([pixel][BA channels]) followed by 64 pixels of the B tile ([pixel][BN columns]);
@@ -12,7 +12,10 @@
 //    256 / 512 bytes = a whole number of bank sweeps, so the four rows of a block would sit on the same banks: the 32-byte unit a
 //    lane FETCHES is permuted instead -- position (row, unit') holds channel unit  unit' ^ ((row & 3) << 1)  -- and the fragment
 //    reads apply the same XOR (cdna guide rule 21): the 8 row pieces a 32-lane group touches land on 8 distinct 32-byte bank groups;
-//  * out-of-image taps, pixels past the split's end and channel / column overhang fetch a 256-byte zero page;
+//  * out-of-image taps, pixels past the split's end and channel / column overhang read as zeros (a 256-byte zero page in the linear-stage
+//    form, the buffer descriptor's bounds check in the 2-D-stage form -- see the kernel template);
+//  * the DMA pieces are inline assembly: behind its own LDS-DMA builtins hipcc waits vmcnt(0) before the next transposing LDS read, which
+//    serialised the ring (see wg_dma16);
 //  * tile order, tap permutation, row shift and the flat (split, tile) grid are those of conv_wgrad.hip.
 //
 // Autograd wgrad of F.conv2d / F.conv_transpose2d at the call sites listed in conv_igemm.hip.
