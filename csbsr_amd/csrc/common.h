@@ -52,13 +52,35 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// Caller-owned scratch for two-stage per-channel reductions (csbsr_set_reduction_scratch).  Device-scope fp32 atomics are
-// resolved at the memory side on this part (~190 ns each, serialised per address: 1500 workgroups x 128 channels of bias-gradient
-// atomics cost 290 us on top of a 36 us streaming pass), so the reducing kernels write per-workgroup partial rows here and
-// csbsr_sum_partials folds them; without a registered scratch they fall back to atomics.
+// Caller-owned scratch for two-stage reductions (csbsr_set_reduction_scratch).  EVERY floating-point reduction of the library is
+// order-fixed: a reducing kernel writes per-workgroup (or per-tile) partial rows here and csbsr_sum_partials* folds them in a fixed
+// tree, so two runs on the same input are bit-identical (no fp32 atomics anywhere on the path; besides, device-scope fp32 atomics
+// are resolved at the memory side on this part, ~190 ns each and serialised per address: 1500 workgroups x 128 channels of
+// bias-gradient atomics cost 290 us on top of a 36 us streaming pass).  No registered scratch = error, never an atomic fallback.
 #define CSBSR_MAX_DEVICES 16
-float* csbsr_red_scratch(long need_elems);   // the current device's registered scratch if it holds need_elems floats, else nullptr
-int csbsr_sum_partials(const float* part, int nblk, long ld, int count, float* dst, hipStream_t st);   // dst[j] += sum_b part[b*ld+j]
+#define CSBSR_RED_TAIL (4l << 20)            // floats at the end of the scratch reserved for the second level of csbsr_sum_partials*
+float* csbsr_red_scratch(long need_elems);   // the current device's registered scratch if it holds need_elems floats (+ the tail), else nullptr (error set)
+// dst[b * dst_bs + j] += sum_{r < rows} part[(b * rows + r) * ld + j],  j < count, b < batch -- fixed summation order
+int csbsr_sum_partials_batched(const float* part, int rows, long ld, int count, float* dst, int batch, long dst_bs, hipStream_t st);
+static inline int csbsr_sum_partials(const float* part, int nblk, long ld, int count, float* dst, hipStream_t st) {
+  return csbsr_sum_partials_batched(part, nblk, ld, count, dst, 1, 0, st);
+}
+#define CSBSR_NEED_SCRATCH(ptr, what) CSBSR_CHECK((ptr) != nullptr, "%s: reduction scratch missing or too small (csbsr_set_reduction_scratch)", what)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: every launcher keeps one of these per kernel
+// instance (a process-wide bool would leave the second GPU of a process with the 64 KB default and a failed launch)
+struct LdsAttrOnce { bool done[CSBSR_MAX_DEVICES] = {}; };
+static inline int csbsr_lds_attr(LdsAttrOnce& o, const void* fn, int bytes, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CSBSR_MAX_DEVICES) { csbsr_set_error("%s: no current device", what); return 2; }
+  if (o.done[dev]) return 0;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    csbsr_set_error("%s: cannot reserve %d bytes of LDS", what, bytes);
+    return 2;
+  }
+  o.done[dev] = true;
+  return 0;
+}
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -34,6 +34,11 @@ struct ConvK {
   // (mask > 0 ? 1 : mask_slope), mask = the saved forward output of the layer whose input gradient this launch produces --
   // i.e. dPre of that layer leaves this kernel directly and the stand-alone epilogue-backward pass is skipped
   const half_t* mask; long m_sn, m_sy, m_sx; float mask_slope;
+  // fused statistics, order-fixed: every workgroup writes ITS sums as one partial row stat_part[(phase * tiles_m + tile_m) * stat_ld + ...]
+  // ([sum | sumsq] for CSBSR_STAT_BN, [sum] for CSBSR_STAT_SAMPLE_SUM); the launcher folds the rows into ``stat`` with
+  // csbsr_sum_partials* (no atomics: two runs are bit-identical).  hw_pad > 0: the linear pixel index is laid out per sample,
+  // each sample padded to hw_pad (a multiple of the pixel tile) positions, so a tile never straddles two samples.
+  float* stat_part; long stat_ld; int hw_pad;
 };
 
 // value -> (hi, lo) fp16 pair with hi + lo == value to ~2^-22 relative (lo is exact down to fp16's subnormal spacing, 6e-8)
@@ -69,8 +74,7 @@ __device__ __forceinline__ void conv_epilogue_prefetch(const ConvK& p, int co, i
 
 // one output pixel x 8 consecutive channels: scale + bias + activation, fused statistics, residual combine, stores
 __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8], const float (&bias)[8], float slope, int co, int n, int oy,
-                                                  int ox, bool uniform_n, int& cur_n, float (&ssum)[8], float (&ssq)[8],
-                                                  const EpiPre* pre = nullptr) {
+                                                  int ox, float (&ssum)[8], float (&ssq)[8], const EpiPre* pre = nullptr) {
   const float* cb = nullptr;
   if (p.cbias) {
     const int cls = (oy == 0) * 8 + (oy == p.OH - 1) * 4 + (ox == 0) * 2 + (ox == p.OW - 1);
@@ -86,13 +90,7 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
   if (p.stat_mode == CSBSR_STAT_BN) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
-  } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM) {
-    if (!uniform_n && n != cur_n) {
-      if (cur_n >= 0)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { atomicAdd(p.stat + (size_t)cur_n * p.coutp + co + e, ssum[e]); ssum[e] = 0.f; }
-      cur_n = n;
-    }
+  } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM) {      // a tile holds pixels of ONE sample (ConvK::hw_pad / 2-D tiles)
 #pragma unroll
     for (int e = 0; e < 8; ++e) ssum[e] += v[e];
   }
@@ -190,32 +188,72 @@ __device__ __forceinline__ void conv_epilogue_fast_row(const EpiFast& f, const f
   split_store(o, f.o_lo, t);
 }
 
-// per-thread partial statistics -> LDS bins (uniform sample per tile) or straight to global (tile straddles samples)
+// per-thread partial statistics -> the workgroup's LDS bins sStat[2][BN], in a FIXED order.
 // CPR = channel chunks per staged row: lanes l, l+CPR, l+2CPR .. of a wave own the same 8 channels, so they are folded with
-// xor-shuffles first and only the first CPR lanes of each wave touch the LDS bins (4-way instead of 32-way same-address atomics)
-template <int CPR>
-__device__ __forceinline__ void conv_epilogue_flush_stats(const ConvK& p, float* sStat, int BN, int local_col, int co, bool uniform_n, int cur_n,
-                                                          float (&ssum)[8], float (&ssq)[8]) {
-  if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
-    const bool sq = p.stat_mode == CSBSR_STAT_BN;
+// xor-shuffles first; then the NW waves add their sums to the bins one wave after the other (wave order = summation order; LDS
+// atomics would add them in arrival order).  Called by every thread of the workgroup (barriers inside).
+template <int CPR, int NW>
+__device__ __forceinline__ void conv_epilogue_flush_stats(const ConvK& p, float* sStat, int BN, int local_col, int co, float (&ssum)[8], float (&ssq)[8]) {
+  if (p.stat_mode == CSBSR_STAT_NONE) return;
+  const bool sq = p.stat_mode == CSBSR_STAT_BN;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float a = co < p.coutp ? ssum[e] : 0.f, b = (sq && co < p.coutp) ? ssq[e] : 0.f;
+  for (int e = 0; e < 8; ++e) {
+    float a = co < p.coutp ? ssum[e] : 0.f, b = (sq && co < p.coutp) ? ssq[e] : 0.f;
 #pragma unroll
-      for (int o = CPR; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); if (sq) b += __shfl_xor(b, o, 64); }
-      ssum[e] = a; ssq[e] = b;
-    }
-    if ((threadIdx.x & 63) < CPR && co < p.coutp) {
+    for (int o = CPR; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); if (sq) b += __shfl_xor(b, o, 64); }
+    ssum[e] = a; ssq[e] = b;
+  }
+  const int wid = threadIdx.x >> 6;
+  const bool mine = (threadIdx.x & 63) < CPR && co < p.coutp;
+#pragma unroll 1
+  for (int w = 0; w < NW; ++w) {
+    if (wid == w && mine) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        atomicAdd(&sStat[local_col + e], ssum[e]);
-        if (sq) atomicAdd(&sStat[BN + local_col + e], ssq[e]);
+        sStat[local_col + e] += ssum[e];
+        if (sq) sStat[BN + local_col + e] += ssq[e];
       }
     }
-  } else if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && cur_n >= 0 && co < p.coutp) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(p.stat + (size_t)cur_n * p.coutp + co + e, ssum[e]);
+    lds_barrier();
   }
+}
+// the workgroup's bins -> its partial row (one thread per cout of the tile)
+__device__ __forceinline__ void conv_epilogue_store_stats(const ConvK& p, const float* sStat, int BN, int cout0, size_t row) {
+  const int tid = threadIdx.x;
+  if (p.stat_mode == CSBSR_STAT_NONE || tid >= BN || cout0 + tid >= p.coutp) return;
+  float* r = p.stat_part + row * p.stat_ld + cout0 + tid;
+  r[0] = sStat[tid];
+  if (p.stat_mode == CSBSR_STAT_BN) r[p.coutp] = sStat[BN + tid];
+}
+// host side of the above: partial-row geometry before the launch, the fixed-order fold after it
+struct ConvStatPlan { long rows; int tps; };
+static inline int conv_stat_prepare(ConvK& p, int BM, int nphase, ConvStatPlan& pl, hipStream_t st) {
+  pl.rows = 0; pl.tps = 0;
+  p.stat_part = nullptr; p.stat_ld = 0; p.hw_pad = 0;
+  if (p.stat_mode == CSBSR_STAT_NONE) return 0;
+  if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM) {
+    CSBSR_CHECK(!p.transposed, "conv: per-sample sums of a transposed convolution are not built");
+    if (p.tile2d) pl.tps = (p.OW / 16) * (p.OH / (BM / 16));
+    else {
+      p.hw_pad = round_up(p.OH * p.OW, BM);
+      pl.tps = p.hw_pad / BM;
+      p.tiles_m = (unsigned)(p.N * pl.tps);
+    }
+  }
+  pl.rows = (long)p.tiles_m * nphase;
+  p.stat_ld = (p.stat_mode == CSBSR_STAT_BN ? 2 : 1) * (long)p.coutp;
+  p.stat_part = csbsr_red_scratch(pl.rows * p.stat_ld);
+  CSBSR_NEED_SCRATCH(p.stat_part, "conv (fused statistics)");
+  if (p.transposed && hipMemsetAsync(p.stat_part, 0, (size_t)pl.rows * p.stat_ld * 4, st) != hipSuccess) {      // phases of unequal size leave tiles unvisited
+    csbsr_set_error("conv: memset of the statistics rows failed");
+    return 2;
+  }
+  return 0;
+}
+static inline int conv_stat_finish(const ConvK& p, const ConvStatPlan& pl, hipStream_t st) {
+  if (p.stat_mode == CSBSR_STAT_BN) return csbsr_sum_partials(p.stat_part, (int)pl.rows, p.stat_ld, 2 * p.coutp, p.stat, st);
+  if (p.stat_mode == CSBSR_STAT_SAMPLE_SUM) return csbsr_sum_partials_batched(p.stat_part, pl.tps, p.stat_ld, p.coutp, p.stat, p.N, p.coutp, st);
+  return 0;
 }
 
 // Register-direct epilogue for one 32x32 accumulator tile (no statistics requested): v_permlane32_swap pairs turn the MFMA
@@ -254,8 +292,7 @@ __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const 
       else conv_epilogue_fast_row<false, false>(*fe, v, bias, co, o, rr, oo, s0, s1);
       continue;
     }
-    int cur_n = -1;
-    conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, true, cur_n, s0, s1);
+    conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, s0, s1);
   }
 }
 

@@ -41,6 +41,7 @@ struct ConvHrK {
   int act; float slope;
   const half_t* mask; long m_sn, m_sy, m_sx; float mask_slope;
   float* stat;                      // optional [N][coutp] per-sample channel sums of act(conv) (global average pool)
+  float* stat_part;                 // ... as order-fixed partial rows [N][workgroups][waves][coutp] (launcher: zeroed before, folded after)
   unsigned tiles_x, tiles_y;
 };
 
@@ -86,7 +87,6 @@ __global__ __launch_bounds__(64 * hr_nw(CH8, TAPS)) void conv_hr_kernel(const Co
   constexpr int NMF = R * NKS;                          // MFMAs per wave and tile: the pieces are spread over them
   constexpr int SP = NMF >= NFI ? NMF / NFI : 1, PP = NMF >= NFI ? 1 : (NFI + NMF - 1) / NMF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sStat = reinterpret_cast<float*>(smem + ZERO_OFF + 16);      // [64] per-cout sums of the current tile
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,7 +107,6 @@ __global__ __launch_bounds__(64 * hr_nw(CH8, TAPS)) void conv_hr_kernel(const Co
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) wf[ks] = *reinterpret_cast<const h8*>(p.wt + ((size_t)(ct_ld * NKS + ks) * 64 + lane) * 8);
   if (tid < 4) reinterpret_cast<float*>(smem + ZERO_OFF)[tid] = 0.f;
-  if (STAT && tid < 64) sStat[tid] = 0.f;
   const unsigned per_img = p.tiles_x * p.tiles_y, total = per_img * (unsigned)p.N;
   const char* lbase = smem + pix * PIXB;               // per-lane base: every fragment address below is lbase + buffer + a compile-time constant
 
@@ -166,6 +165,35 @@ __global__ __launch_bounds__(64 * hr_nw(CH8, TAPS)) void conv_hr_kernel(const Co
     for (int i = 0; i < NFI; ++i) issue_piece(rs, y0, x0, i, k);
   }
   int buf = 0;
+  // STAT: per-sample sums of the outputs (the global average pool behind fe_cat.2).  A wave keeps its 16 per-lane sums in registers
+  // across ALL its tiles of a sample and adds them -- folded over the 32 pixels -- to its own partial row
+  // stat_part[(n * gridDim.x + blockIdx.x) * HR_NW + wid][coutp] when the sample changes: one writer per row, a fixed tile order
+  // (the launcher zeroes the rows and folds them per sample with csbsr_sum_partials_batched), so two runs are bit-identical.
+  float gsum[STAT ? 16 : 1];
+#pragma unroll
+  for (int e = 0; e < (STAT ? 16 : 1); ++e) gsum[e] = 0.f;
+  int cur_n = -1;
+  auto flush_stat = [&](int n_) {
+#pragma unroll
+    for (int e = 0; e < (STAT ? 16 : 1); ++e) {
+      float a = gsum[e];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) a += __shfl_xor(a, o, 64);
+      gsum[e] = a;
+    }
+    if (pix == 0) {
+      float* row = p.stat_part + (((size_t)n_ * gridDim.x + blockIdx.x) * HR_NW + wid) * p.coutp;
+#pragma unroll
+      for (int pair = 0; pair < 2; ++pair)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int co = ct * 32 + 16 * pair + 8 * hi + e;
+          if (STAT && co < p.coutp) row[co] += gsum[8 * pair + e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < (STAT ? 16 : 1); ++e) gsum[e] = 0.f;
+  };
   for (unsigned vb = j0; vb < total; vb += gsub) {
     int n, y0, x0, nn, y0n, x0n;
     tile_at(vb, n, y0, x0);
@@ -191,9 +219,12 @@ __global__ __launch_bounds__(64 * hr_nw(CH8, TAPS)) void conv_hr_kernel(const Co
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    float gsum[STAT ? 16 : 1];
-#pragma unroll
-    for (int e = 0; e < (STAT ? 16 : 1); ++e) gsum[e] = 0.f;
+    if constexpr (STAT) {
+      if (n != cur_n) {        // workgroup-uniform
+        if (cur_n >= 0) flush_stat(cur_n);
+        cur_n = n;
+      }
+    }
     const char* tb = lbase + buf * TILE_BYTES;
     // four rows at a time: four independent accumulator chains, each row's next fragment requested right after the MFMA that consumed
     // the current one (four MFMAs = 128 cycles of cover for the LDS latency -- with ONE wave per SIMD nothing else hides it; left to
@@ -280,29 +311,11 @@ __global__ __launch_bounds__(64 * hr_nw(CH8, TAPS)) void conv_hr_kernel(const Co
         }
       }
     }
-    if constexpr (STAT) {  // lanes with equal (hi, pair) hold the same couts for different pixels: fold the 32 pixels, then LDS bins
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float a = gsum[e];
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) a += __shfl_xor(a, o, 64);
-        gsum[e] = a;
-      }
-      if (pix == 0) {
-#pragma unroll
-        for (int pair = 0; pair < 2; ++pair)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) atomicAdd(&sStat[32 * ctl + 16 * pair + 8 * hi + e], gsum[8 * pair + e]);
-      }
-      __syncthreads();
-      if (tid < 32 * NCT) {      // flush this tile's sums and clear the bins for the next one (whose atomics come after its barrier)
-        const int co = (ct - ctl) * 32 + tid;
-        if (co < p.coutp) atomicAdd(p.stat + (size_t)n * p.coutp + co, sStat[tid]);
-        sStat[tid] = 0.f;
-      }
-    }
     buf = buf + 1 == NBUF ? 0 : buf + 1;
   }      // tiles
+  if constexpr (STAT) {
+    if (cur_n >= 0) flush_stat(cur_n);
+  }
 #endif
 }
 
@@ -384,13 +397,10 @@ template <int CH8, int TAPS, int NCT>
 static int launch_hr(const ConvHrK& k, hipStream_t st) {
   constexpr int SM_BYTES = hr_smem(CH8, TAPS);
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, true, TAPS, NCT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, false, TAPS, NCT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_hr_kernel<CH8, false, TAPS, NCT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
-    attr_set = true;
-  }
+  static LdsAttrOnce a0, a1, a2;
+  if (int e = csbsr_lds_attr(a0, reinterpret_cast<const void*>(conv_hr_kernel<CH8, true, TAPS, NCT, false>), SM_BYTES, "conv_hr")) return e;
+  if (int e = csbsr_lds_attr(a1, reinterpret_cast<const void*>(conv_hr_kernel<CH8, false, TAPS, NCT, false>), SM_BYTES, "conv_hr")) return e;
+  if (int e = csbsr_lds_attr(a2, reinterpret_cast<const void*>(conv_hr_kernel<CH8, false, TAPS, NCT, true>), SM_BYTES, "conv_hr")) return e;
   // persistent: one workgroup per CU (the ring of halo tiles takes the LDS), a multiple of 8 x (cout-tile groups); never more than there is work
   const unsigned total = k.tiles_x * k.tiles_y * k.N;
   const unsigned groups = (unsigned)((k.ntile_c + NCT - 1) / NCT), unit = 8u * groups;
@@ -398,8 +408,15 @@ static int launch_hr(const ConvHrK& k, hipStream_t st) {
   if (g > total * groups) g = total * groups;
   g = (g + unit - 1) / unit * unit;
   dim3 grid(g);
-  if (k.stat) hipLaunchKernelGGL((conv_hr_kernel<CH8, true, TAPS, NCT, false>), grid, dim3(64 * hr_nw(CH8, TAPS)), SM_BYTES, st, k);
-  else if (k.mask) hipLaunchKernelGGL((conv_hr_kernel<CH8, false, TAPS, NCT, true>), grid, dim3(64 * hr_nw(CH8, TAPS)), SM_BYTES, st, k);
+  if (k.stat) {
+    const long rows_n = (long)g * hr_nw(CH8, TAPS), elems = (long)k.N * rows_n * k.coutp;
+    ConvHrK ks = k;
+    ks.stat_part = csbsr_red_scratch(elems);
+    CSBSR_NEED_SCRATCH(ks.stat_part, "conv_hr (per-sample sums)");
+    if (hipMemsetAsync(ks.stat_part, 0, (size_t)elems * 4, st) != hipSuccess) { csbsr_set_error("conv_hr: memset of the partial rows failed"); return 2; }
+    hipLaunchKernelGGL((conv_hr_kernel<CH8, true, TAPS, NCT, false>), grid, dim3(64 * hr_nw(CH8, TAPS)), SM_BYTES, st, ks);
+    if (int e = csbsr_sum_partials_batched(ks.stat_part, (int)rows_n, k.coutp, k.coutp, k.stat, k.N, k.coutp, st)) return e;
+  } else if (k.mask) hipLaunchKernelGGL((conv_hr_kernel<CH8, false, TAPS, NCT, true>), grid, dim3(64 * hr_nw(CH8, TAPS)), SM_BYTES, st, k);
   else hipLaunchKernelGGL((conv_hr_kernel<CH8, false, TAPS, NCT, false>), grid, dim3(64 * hr_nw(CH8, TAPS)), SM_BYTES, st, k);
   CSBSR_LAUNCH_CHECK("csbsr_conv_hr_forward");
   return 0;
@@ -416,7 +433,7 @@ extern "C" int csbsr_conv_hr_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   k.out16 = reinterpret_cast<half_t*>(d->out16); k.o_sn = d->o_sn; k.o_sy = d->o_sy; k.o_sx = d->o_sx;
   k.act = d->act; k.slope = d->act_slope;
   k.mask = reinterpret_cast<const half_t*>(d->mask); k.m_sn = d->m_sn; k.m_sy = d->m_sy; k.m_sx = d->m_sx; k.mask_slope = d->mask_slope;
-  k.stat = d->stat_mode == CSBSR_STAT_SAMPLE_SUM ? d->stat : nullptr;
+  k.stat = d->stat_mode == CSBSR_STAT_SAMPLE_SUM ? d->stat : nullptr; k.stat_part = nullptr;
   k.tiles_x = (unsigned)((d->W + HR_TW - 1) / HR_TW); k.tiles_y = (unsigned)((d->H + HR_TH - 1) / HR_TH);
   CSBSR_CHECK(d->in[0].sy < (1l << 31) / 64, "conv_hr: row stride too large for 32-bit piece offsets");
   hipStream_t st = reinterpret_cast<hipStream_t>(s);

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
     in_step = 1; tap_step = -1; o_step = p.stride;
     base_y = (py + p.pad) / p.stride; base_x = (px + p.pad) / p.stride;
   }
-  const long M = (long)p.N * OHp * OWp;
+  const long M = p.hw_pad ? (long)p.N * p.hw_pad : (long)p.N * OHp * OWp;      // hw_pad: per-sample padded pixel index (fused per-sample sums)
   const long m0 = (long)tile_m * BM;
   if (m0 >= M) return;
   const half_t* wt = p.wt + (size_t)blockIdx.z * p.rows_p * p.Kp;
@@ -88,11 +88,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
     if (m < M) {
       int rem;
       if (M < (1l << 31)) {      // 32-bit divisions (the 64-bit one is a ~100-instruction routine in front of the prologue barrier)
-        const unsigned hw = (unsigned)(OHp * OWp);
+        const unsigned hw = p.hw_pad ? (unsigned)p.hw_pad : (unsigned)(OHp * OWp);
         n = (int)((unsigned)m / hw); rem = (int)((unsigned)m - (unsigned)n * hw);
       } else {
-        n = (int)(m / ((long)OHp * OWp)); rem = (int)(m - (long)n * OHp * OWp);
+        const long hw = p.hw_pad ? (long)p.hw_pad : (long)OHp * OWp;
+        n = (int)(m / hw); rem = (int)(m - (long)n * hw);
       }
+      if (rem >= OHp * OWp) { n = -1; rem = 0; }      // padding position of a per-sample layout
       oy = (int)((unsigned)rem / (unsigned)OWp); ox = rem - oy * OWp;
     }
     sRow[tid * 3 + 0] = n; sRow[tid * 3 + 1] = oy; sRow[tid * 3 + 2] = ox;
@@ -266,13 +268,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
   // ---- epilogue: fp32 tile -> LDS [pixel][cout] in halves of HB couts (keeps LDS <= the main-loop footprint so three
   // workgroups fit per CU), then channel-contiguous 8-wide processing
   float* sO = reinterpret_cast<float*>(smem);
-  const int n_first = sRow[0];
-  int n_last = n_first;
-  {
-    long ml = (m0 + BM - 1 < M - 1) ? m0 + BM - 1 : M - 1;
-    n_last = (int)(ml / ((long)OHp * OWp));
-  }
-  const bool uniform_n = (n_first == n_last);
   const EpiFast fe = conv_epilogue_fast_setup(p, slope);
   constexpr int CPR = HB / 8;                 // 8-channel chunks per staged row
   const int cc8 = tid % CPR;                  // fixed per thread (256 % CPR == 0)
@@ -305,7 +300,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
     float ssum[8], ssq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) ssum[e] = ssq[e] = 0.f;
-    int cur_n = -1;
 
     constexpr int RSTEP = 256 / CPR;
     if (fe.ok) {          // straight-line rows (conv_common.h)
@@ -349,7 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
       const bool extra = fe.has_res || fe.has_old || fe.has_mask;
       if (fe.bn) { if (extra) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{}); }
       else { if (extra) rows(std::true_type{}, std::false_type{}); else rows(std::false_type{}, std::false_type{}); }
-      if (fe.bn) conv_epilogue_flush_stats<CPR>(p, sStat, BN, hh * HB + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
+      if (fe.bn) conv_epilogue_flush_stats<CPR, 4>(p, sStat, BN, hh * HB + cc8 * 8, co, ssum, ssq);
       continue;
     }
     // rows in groups of EG: the group's residual / old-output loads are all issued before the first row is combined
@@ -375,25 +369,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
         const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
         const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
         v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
-        conv_epilogue_row(p, v, bias, slope, co, rn[i], roy[i], rox[i], uniform_n, cur_n, ssum, ssq, &pre[i]);
+        conv_epilogue_row(p, v, bias, slope, co, rn[i], roy[i], rox[i], ssum, ssq, &pre[i]);
       }
     }
 
-    conv_epilogue_flush_stats<CPR>(p, sStat, BN, hh * HB + cc8 * 8, co, uniform_n, cur_n, ssum, ssq);
+    conv_epilogue_flush_stats<CPR, 4>(p, sStat, BN, hh * HB + cc8 * 8, co, ssum, ssq);
   }
 
   ITS(6);
-  if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
-    __syncthreads();
-    if (tid < BN && cout0 + tid < p.coutp) {
-      if (p.stat_mode == CSBSR_STAT_BN) {
-        atomicAdd(p.stat + cout0 + tid, sStat[tid]);
-        atomicAdd(p.stat + p.coutp + cout0 + tid, sStat[BN + tid]);
-      } else if (n_first >= 0) {
-        atomicAdd(p.stat + (size_t)n_first * p.coutp + cout0 + tid, sStat[tid]);
-      }
-    }
-  }
+  conv_epilogue_store_stats(p, sStat, BN, cout0, (size_t)blockIdx.z * p.tiles_m + tile_m);      // (the last flush ended with a barrier)
 }
 
 template <int BN, int WP, int WC>
@@ -405,14 +389,13 @@ static int launch_conv(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   constexpr int MAIN_BYTES = (BN + BM) * LDS_LD * 2;
   constexpr int EPI_BYTES = BM * OUT_LD * 4;
   constexpr int SM_BYTES = (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES) + BM * 3 * 4 + 3 * BN * 4 + BM * 8 + NTAP_MAX * 20;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BN, WP, WC>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
-    attr_set = true;
-  }
+  static LdsAttrOnce attr;
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_igemm_kernel<BN, WP, WC>), SM_BYTES, "conv")) return e;
+  ConvStatPlan sp;
+  if (int e = conv_stat_prepare(p, BM, nphase, sp, st)) return e;
   dim3 grid(p.tiles_m * p.tiles_n, 1, nphase);
   hipLaunchKernelGGL((conv_igemm_kernel<BN, WP, WC>), grid, dim3(256), SM_BYTES, st, p);
+  if (int e = conv_stat_finish(p, sp, st)) return e;
   CSBSR_LAUNCH_CHECK("csbsr_conv_forward");
   return 0;
 }
@@ -456,6 +439,7 @@ int conv_desc_to_k(const csbsr_conv_desc_t* d, ConvK& k) {
   CSBSR_CHECK(!(d->o_lo && d->accumulate), "conv: a split (hi + lo) output cannot accumulate");
   CSBSR_CHECK(!d->o_lo || d->out16, "conv: o_lo without out16");
   k.tile2d = 0; k.nphase_flat = 0; k.tap_group = 0;
+  k.stat_part = nullptr; k.stat_ld = 0; k.hw_pad = 0;
   CSBSR_CHECK(d->stat_mode == CSBSR_STAT_NONE || d->stat, "conv: stat_mode set without stat buffer");
   return 0;
 }

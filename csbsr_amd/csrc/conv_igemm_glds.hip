@@ -75,7 +75,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     in_step = 1; tap_step = -1; o_step = p.stride;
     base_y = (py + p.pad) / p.stride; base_x = (px + p.pad) / p.stride;
   }
-  const long M = (long)p.N * OHp * OWp;
+  const long M = p.hw_pad ? (long)p.N * p.hw_pad : (long)p.N * OHp * OWp;      // hw_pad: per-sample padded pixel index (fused per-sample sums)
   const long m0 = (long)tile_m * BM;
   // 2-D pixel tiles (16 wide, BM/16 high) for the spatial layers whose output divides evenly: a BM-pixel run of one output row needs
   // KH input rows x (BM*stride + K) columns, the 2-D tile (BM/16*stride + K) x (16*stride + K) -- 2448 instead of 4128 input pixels
@@ -103,11 +103,13 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     } else if (m < M) {
       int rem;
       if (M < (1l << 31)) {      // 32-bit divisions (the 64-bit one is a ~100-instruction routine in front of the prologue barrier)
-        const unsigned hw = (unsigned)(OHp * OWp);
+        const unsigned hw = p.hw_pad ? (unsigned)p.hw_pad : (unsigned)(OHp * OWp);
         n = (int)((unsigned)m / hw); rem = (int)((unsigned)m - (unsigned)n * hw);
       } else {
-        n = (int)(m / ((long)OHp * OWp)); rem = (int)(m - (long)n * OHp * OWp);
+        const long hw = p.hw_pad ? (long)p.hw_pad : (long)OHp * OWp;
+        n = (int)(m / hw); rem = (int)(m - (long)n * hw);
       }
+      if (rem >= OHp * OWp) { n = -1; rem = 0; }      // padding position of a per-sample layout
       oy = (int)((unsigned)rem / (unsigned)OWp); ox = rem - oy * OWp;
     }
     sRow[tid * 3 + 0] = n; sRow[tid * 3 + 1] = oy; sRow[tid * 3 + 2] = ox;
@@ -300,13 +302,6 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   // transposed conv.)
   static_assert(BM * 128 * 4 <= RING_BYTES, "the staged tile must fit the ring");
   float* sO = reinterpret_cast<float*>(smem);
-  const int n_first = sRow[0];
-  int n_last;
-  {
-    long ml = (m0 + BM - 1 < M - 1) ? m0 + BM - 1 : M - 1;
-    n_last = p.tile2d ? n_first : (int)(ml / ((long)OHp * OWp));
-  }
-  const bool uniform_n = (n_first == n_last);
   constexpr int CPR = 16;                     // 8-channel chunks per staged row (128 couts)
   const int cc8 = tid % CPR;
   constexpr int RSTEP = NT / CPR;
@@ -338,7 +333,6 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   float bias[8], ssum[8], ssq[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bias[e] = sBias[lcol + e]; ssum[e] = ssq[e] = 0.f; }
-  int cur_n = -1;
   if (fe.ok) {
     constexpr int RPT = BM / RSTEP, EG = CT == 2 ? 2 : 8;
     static_assert(RPT % EG == 0, "rows per thread must split into groups");
@@ -380,7 +374,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     const bool extra = fe.has_res || fe.has_old || fe.has_mask;
     if (fe.bn) { if (extra) rows(std::true_type{}, std::true_type{}); else rows(std::false_type{}, std::true_type{}); }
     else { if (extra) rows(std::true_type{}, std::false_type{}); else rows(std::false_type{}, std::false_type{}); }
-    if (fe.bn) conv_epilogue_flush_stats<CPR>(p, sStat, BN, lcol, co, uniform_n, cur_n, ssum, ssq);
+    if (fe.bn) conv_epilogue_flush_stats<CPR, NW>(p, sStat, BN, lcol, co, ssum, ssq);
   } else {
     // rows in groups of EG: the group's residual / old-output loads are all issued before the first row is combined
     constexpr int RPT = BM / RSTEP, EG = 2;
@@ -405,26 +399,16 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
         const f4 v0 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8) ^ (row & 15)) << 2));
         const f4 v1 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8 + 1) ^ (row & 15)) << 2));
         v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
-        conv_epilogue_row(p, v, bias, slope, co, rn[i], roy[i], rox[i], uniform_n, cur_n, ssum, ssq, &pre[i]);
+        conv_epilogue_row(p, v, bias, slope, co, rn[i], roy[i], rox[i], ssum, ssq, &pre[i]);
       }
     }
-    conv_epilogue_flush_stats<CPR>(p, sStat, BN, lcol, co, uniform_n, cur_n, ssum, ssq);
+    conv_epilogue_flush_stats<CPR, NW>(p, sStat, BN, lcol, co, ssum, ssq);
   }
   };      // epi_pass
   epi_pass(std::integral_constant<int, 0>{});
   if constexpr (CT == 2) epi_pass(std::integral_constant<int, 1>{});
   TS(6);
-  if (p.stat_mode == CSBSR_STAT_BN || (p.stat_mode == CSBSR_STAT_SAMPLE_SUM && uniform_n)) {
-    __syncthreads();
-    if (tid < BN && cout0 + tid < p.coutp) {
-      if (p.stat_mode == CSBSR_STAT_BN) {
-        atomicAdd(p.stat + cout0 + tid, sStat[tid]);
-        atomicAdd(p.stat + p.coutp + cout0 + tid, sStat[BN + tid]);
-      } else if (n_first >= 0) {
-        atomicAdd(p.stat + (size_t)n_first * p.coutp + cout0 + tid, sStat[tid]);
-      }
-    }
-  }
+  conv_epilogue_store_stats(p, sStat, BN, cout0, (size_t)zph * p.tiles_m + tile_m);      // (the last flush ended with a barrier)
 }
 
 static half_t* g_zero_page = nullptr;
@@ -446,22 +430,18 @@ static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   constexpr int EPI = BM * 128 * 4;
   constexpr int SM_BYTES = (RING > EPI ? RING : EPI) + BM * (4 * 8 + 3 * 4) + 3 * BN * 4;      // ring / staged tile + row tables + statistics + bias
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES) != hipSuccess) {
-      csbsr_set_error("conv(glds): cannot reserve %d bytes of LDS", SM_BYTES);
-      return 2;
-    }
-    attr_set = true;
-  }
+  static LdsAttrOnce attr;
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT>), SM_BYTES, "conv(glds)")) return e;
   if (!g_zero_page) {
     if (hipMalloc(reinterpret_cast<void**>(&g_zero_page), 256) != hipSuccess) { csbsr_set_error("conv(glds): zero page alloc failed"); return 2; }
     (void)hipMemset(g_zero_page, 0, 256);
   }
   p.nphase_flat = (g_glds_phase_flat && nphase > 1) ? nphase : 0;
+  ConvStatPlan sp;
+  if (int e = conv_stat_prepare(p, BM, nphase, sp, st)) return e;
   dim3 grid(p.tiles_m * p.tiles_n * (p.nphase_flat ? nphase : 1), 1, p.nphase_flat ? 1 : nphase);
   hipLaunchKernelGGL((conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT>), grid, dim3(NWM * 128), SM_BYTES, st, p, g_zero_page);
+  if (int e = conv_stat_finish(p, sp, st)) return e;
   CSBSR_LAUNCH_CHECK("csbsr_conv_forward(glds)");
   return 0;
 }

@@ -131,9 +131,8 @@ __global__ __launch_bounds__(256) void conv_thin_cout_kernel(const ConvK p, int 
       const float* y = sY + (size_t)((oyl + ky) * TN_HW + oxl + kx) * TN_YLD + (ky * 3 + kx) * CR;
       for (int co = 0; co < CR; ++co) v[co] += y[co];
     }
-  int cur_n = n;
   float ssum[8], ssq[8];
-  conv_epilogue_row(p, v, bias, slope, 0, n, oy, ox, true, cur_n, ssum, ssq);
+  conv_epilogue_row(p, v, bias, slope, 0, n, oy, ox, ssum, ssq);
   }
 }
 

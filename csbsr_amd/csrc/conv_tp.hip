@@ -396,8 +396,6 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     float* row = p.part + (size_t)blockIdx.x * p.part_ld;
     float* sSp = reinterpret_cast<float*>(smem + DOFF);           // (the halo DMA's padding KB is idle by now)
     __syncthreads();
-    if (tid == 0) sSp[0] = 0.f;
-    __syncthreads();
     if (pix == 0) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -405,9 +403,9 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
         if (co < p.coutp) row[co] = sb[e];
       }
     }
-    if (lane == 0) atomicAdd(sSp, sp);
+    if (lane == 0) sSp[wid] = sp;            // the four waves' sums are added in wave order (no LDS atomic: fixed order)
     __syncthreads();
-    if (tid == 0) row[p.coutp] = sSp[0] / mslope;
+    if (tid == 0) row[p.coutp] = (((sSp[0] + sSp[1]) + sSp[2]) + sSp[3]) / mslope;
   }
 }
 
@@ -500,11 +498,8 @@ static int launch_tp(ConvTpK& k, hipStream_t st, half_t* zp, float* dbias, float
   constexpr int NINST = (TP_NPIX * SLOTS + 63) / 64;
   constexpr int SM_BYTES = NINST * 1024 + 128 * 4 + 1024 + 4 * 256 * 16 + 1024;
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tp_kernel<NKC, R, A, M, S>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
-    attr_set = true;
-  }
+  static LdsAttrOnce attr;
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_tp_kernel<NKC, R, A, M, S>), SM_BYTES, "conv_tp")) return e;
   const unsigned items = k.tiles_x * k.tiles_y * k.N * k.pgroups;
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);

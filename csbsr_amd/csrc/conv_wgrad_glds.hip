@@ -324,15 +324,8 @@ static int launch_wgrad_glds_t(const WgradK& k, int splits, hipStream_t st) {
   p.splits = splits;
   constexpr int SM_BYTES = NSTAGE * WG_BP * (BA + BN) * 2;
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_glds_kernel<BA, BN, NWA, NWB, NSTAGE, T2D>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES) != hipSuccess) {
-      csbsr_set_error("wgrad(glds): cannot reserve %d bytes of LDS", SM_BYTES);
-      return 2;
-    }
-    attr_set = true;
-  }
+  static LdsAttrOnce attr;
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_wgrad_glds_kernel<BA, BN, NWA, NWB, NSTAGE, T2D>), SM_BYTES, "wgrad(glds)")) return e;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CSBSR_MAX_DEVICES) { csbsr_set_error("wgrad(glds): no current device"); return 2; }
   if (!g_wg_zero_page[dev]) {

@@ -241,15 +241,8 @@ template <int CA8, int CB8, int TH, int NBUF>
 static int launch_wgrad_hr(const WgradHrK& k, int splits, hipStream_t st) {
   constexpr int SM_BYTES = wh_smem(CA8, CB8, TH, NBUF);
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_hr_kernel<CA8, CB8, TH, NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES) !=
-        hipSuccess) {
-      csbsr_set_error("wgrad(hr): cannot reserve %d bytes of LDS", SM_BYTES);
-      return 2;
-    }
-    attr_set = true;
-  }
+  static LdsAttrOnce attr;
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_wgrad_hr_kernel<CA8, CB8, TH, NBUF>), SM_BYTES, "wgrad(hr)")) return e;
   hipLaunchKernelGGL((conv_wgrad_hr_kernel<CA8, CB8, TH, NBUF>), dim3(splits), dim3(256), SM_BYTES, st, k);
   CSBSR_LAUNCH_CHECK("csbsr_conv_wgrad(hr)");
   return 0;

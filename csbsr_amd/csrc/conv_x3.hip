@@ -225,8 +225,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
           v[e] = acc[mt][nt][8 * pair + e];
           bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f;
         }
-        int cur_n = -1;
-        conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, true, cur_n, s0, s1);
+        conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, s0, s1);
       }
     }
     ct = ctn; n = nn; Y0 = Y0n; X0 = X0n;
@@ -354,11 +353,8 @@ static half_t* g_x3_zero_page[CSBSR_MAX_DEVICES] = {};
 template <int KS>
 static int launch_x3(const ConvK& k, const X3Extra& q, unsigned g, const half_t* zp, hipStream_t st) {
   constexpr int SM_BYTES = 2 * x3_buf(KS);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_x3_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, SM_BYTES);
-    attr_set = true;
-  }
+  static LdsAttrOnce attr;
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_x3_kernel<KS>), SM_BYTES, "conv_x3")) return e;
   hipLaunchKernelGGL(conv_x3_kernel<KS>, dim3(g), dim3(256), SM_BYTES, st, k, q, zp);
   CSBSR_LAUNCH_CHECK("csbsr_conv_x3_forward");
   return 0;

@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void psnr_ssim_kernel(const float* a, const fl
   acc_se = wave_sum(acc_se); acc_ss = wave_sum(acc_ss);
   if ((tid & 63) == 0) { sred[tid >> 6][0] = acc_se; sred[tid >> 6][1] = acc_ss; }
   __syncthreads();
-  if (tid < 2) atomicAdd(sums + n * 2 + tid, sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid]);
+  if (tid < 2)       // partial row per workgroup, rows of one sample contiguous: folded in fixed order by csbsr_sum_partials_batched
+    sums[(((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 2 + tid] = sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid];
 }
 __global__ void psnr_ssim_finish_kernel(const float* sums, int N, float count, float* psnr, float* ssim) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -176,7 +177,11 @@ extern "C" int csbsr_psnr_ssim(const float* a, const float* b, int32_t N, int32_
   CSBSR_CHECK(a && b && sums && psnr && ssim && N > 0 && C > 0, "psnr_ssim: bad args");
   dim3 grid((W + SS_TX - 1) / SS_TX, (H + SS_TY - 1) / SS_TY, N * C);
   CSBSR_CHECK(grid.y <= 65535 && grid.z <= 65535, "psnr_ssim: image too large for the launch grid");
-  hipLaunchKernelGGL(psnr_ssim_kernel, grid, dim3(256), 0, ST(s), a, b, C, H, W, sums);
+  const int rows = (int)(C * grid.y * grid.x);
+  float* part = csbsr_red_scratch((long)N * rows * 2);
+  CSBSR_NEED_SCRATCH(part, "psnr_ssim");
+  hipLaunchKernelGGL(psnr_ssim_kernel, grid, dim3(256), 0, ST(s), a, b, C, H, W, part);
+  if (csbsr_sum_partials_batched(part, rows, 2, 2, sums, N, 2, ST(s))) return 1;
   hipLaunchKernelGGL(psnr_ssim_finish_kernel, dim3((N + 63) / 64), dim3(64), 0, ST(s), sums, N, (float)((long)C * H * W), psnr, ssim);
   CSBSR_LAUNCH_CHECK("csbsr_psnr_ssim");
   return 0;

@@ -1,6 +1,6 @@
 // HBM-bound kernels on fp16 channels-last activations: epilogue backward, batch-norm, pooling, bilinear resize,
 // layout converters.  Every thread moves 16 bytes (8 channels) per access; reductions go wave-shuffle ->
-// LDS -> one atomic per workgroup.  Reference call sites are cited per entry point in include/csbsr_hip.h.
+// LDS -> one partial row per workgroup -> csbsr_sum_partials (fixed order, no atomics: common.h).  Reference call sites are cited per entry point in include/csbsr_hip.h.
 #include "common.h"
 
 static inline int grid_for(long work, int block = 256, int cap = 8192) {
@@ -45,14 +45,22 @@ extern "C" int csbsr_set_reduction_scratch(float* buf, int64_t elems) {
 float* csbsr_red_scratch(long need_elems) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CSBSR_MAX_DEVICES) return nullptr;
-  return (g_red_buf[dev] && need_elems <= g_red_elems[dev]) ? g_red_buf[dev] : nullptr;
+  return (g_red_buf[dev] && need_elems + CSBSR_RED_TAIL <= g_red_elems[dev]) ? g_red_buf[dev] : nullptr;
 }
-// dst[j] += sum over the nblk partial rows; block = 32 columns x 8 row slices over a chunk of up to 1024 rows (grid.y chunks, one
-// atomic per column per chunk -- a handful per address)
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int nblk, long ld, int count, float* dst) {
+static float* red_tail() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CSBSR_MAX_DEVICES || !g_red_buf[dev] || g_red_elems[dev] < CSBSR_RED_TAIL) return nullptr;
+  return g_red_buf[dev] + (g_red_elems[dev] - CSBSR_RED_TAIL);
+}
+// Fixed-order fold of partial rows.  Block = 32 columns x 8 row slices; slice s adds rows s, s+8, ... of its chunk into four
+// interleaved accumulators, the slices meet in LDS and are added in slice order: the tree depends on (rows, rows_per_chunk) only.
+// grid = (column blocks, chunks, batch).  store: dst[...] = t (first level of a two-level fold), else dst[...] += t.
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, int rows, long ld, int count, float* dst, long part_bs, long dst_bs,
+                                                           long dst_cs, int rpc, int store) {
   __shared__ float sm[8][33];
   const int col = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
-  const int r0 = blockIdx.y * 1024, r1 = min(nblk, r0 + 1024);
+  const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
+  part += (long)blockIdx.z * part_bs;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (col < count) {
     int b = r0 + sl;
@@ -68,12 +76,25 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* part, in
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) t += sm[q][threadIdx.x & 31];
-    if (gridDim.y == 1) dst[col] += t;
-    else atomicAdd(dst + col, t);
+    float* d = dst + (long)blockIdx.z * dst_bs + (long)blockIdx.y * dst_cs + col;
+    *d = store ? t : *d + t;
   }
 }
-int csbsr_sum_partials(const float* part, int nblk, long ld, int count, float* dst, hipStream_t st) {
-  hipLaunchKernelGGL(sum_partials_kernel, dim3((count + 31) / 32, (nblk + 1023) / 1024), dim3(256), 0, st, part, nblk, ld, count, dst);
+int csbsr_sum_partials_batched(const float* part, int rows, long ld, int count, float* dst, int batch, long dst_bs, hipStream_t st) {
+  if (rows <= 0 || count <= 0 || batch <= 0) return 0;
+  const int RPC = 1024;
+  const int chunks = (rows + RPC - 1) / RPC;
+  const dim3 blk(256);
+  if (chunks == 1) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((count + 31) / 32, 1, batch), blk, 0, st, part, rows, ld, count, dst, (long)rows * ld, dst_bs, 0l, RPC, 0);
+    return 0;
+  }
+  float* tmp = red_tail();
+  CSBSR_CHECK(tmp && (long)batch * chunks * count <= CSBSR_RED_TAIL && chunks <= RPC, "sum_partials: %d x %d rows of %d columns exceed the scratch tail", batch, rows, count);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((count + 31) / 32, chunks, batch), blk, 0, st, part, rows, ld, count, tmp, (long)rows * ld,
+                     (long)chunks * count, (long)count, RPC, 1);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((count + 31) / 32, 1, batch), blk, 0, st, (const float*)tmp, chunks, (long)count, count, dst,
+                     (long)chunks * count, dst_bs, 0l, RPC, 0);
   return 0;
 }
 
@@ -169,8 +190,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const EpiK p) {
         for (int e = 0; e < 8; ++e) {
           float s = 0.f;
           for (int q = 0; q < ppb; ++q) s += sRed[(q * cpb + tid) * 8 + e];
-          if (p.part) p.part[(long)blockIdx.x * p.part_ld + (cbase + tid) * 8 + e] = s;
-          else if ((cbase + tid) * 8 + e < p.creal) atomicAdd(p.dbias + (cbase + tid) * 8 + e, s);
+          p.part[(long)blockIdx.x * p.part_ld + (cbase + tid) * 8 + e] = s;
         }
       }
       __syncthreads();
@@ -181,8 +201,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const EpiK p) {
     if ((tid & 63) == 0) sPre[tid >> 6] = dpr;
     __syncthreads();
     if (tid == 0) {
-      if (p.part) p.part[(long)blockIdx.x * p.part_ld + p.c8 * 8] = sPre[0] + sPre[1] + sPre[2] + sPre[3];
-      else atomicAdd(p.dprelu, sPre[0] + sPre[1] + sPre[2] + sPre[3]);
+      p.part[(long)blockIdx.x * p.part_ld + p.c8 * 8] = sPre[0] + sPre[1] + sPre[2] + sPre[3];
     }
   }
 }
@@ -207,7 +226,10 @@ extern "C" int csbsr_epilogue_backward(const csbsr_epi_bwd_desc_t* d, csbsr_stre
   const int ppb = 256 / cpb;
   int blocks = grid_for(d->npix, ppb * 8, 2048);
   k.part = nullptr; k.part_ld = d->c + 8;
-  if (k.dbias || k.dprelu) k.part = csbsr_red_scratch((long)blocks * k.part_ld);
+  if (k.dbias || k.dprelu) {
+    k.part = csbsr_red_scratch((long)blocks * k.part_ld);
+    CSBSR_NEED_SCRATCH(k.part, "epilogue_bwd");
+  }
   hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(blocks), dim3(256), 0, ST(s), k);
   if (k.part) {
     if (k.dbias) csbsr_sum_partials(k.part, blocks, k.part_ld, d->creal, k.dbias, ST(s));
@@ -288,14 +310,15 @@ extern "C" int csbsr_sum_act(int64_t npix, int32_t c, int32_t n, const void* con
 //   out[n][c] = sum_p w[n][p] * x[n][p][c]                       (fp32 accumulation, out must be zeroed by the caller)
 // and its adjoint:  dx[n][p][c] += w[n][p] * dout[n][c],   dw[n][p] = sum_c x[n][p][c] * dout[n][c].
 // One workgroup = 256 pixels x all channels of one sample; a thread owns 8 channels and strides over pixels.
-__global__ __launch_bounds__(256) void wpool_fwd_kernel(const half_t* x, long x_ld, const float* w, float* out, long hw, int c8, int chunks,
+__global__ __launch_bounds__(256) void wpool_fwd_kernel(const half_t* x, long x_ld, const float* w, float* part, long hw, int c8, int chunks,
                                                         long x_lo) {
+  __shared__ float sAcc[256][8];
   const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const long p0 = (long)chunk * 1024, p1 = min(hw, p0 + 1024);
   const int lanes_c = c8, groups = 256 / lanes_c;           // c8 <= 256 (launcher splits wider maps)
   const int cg = threadIdx.x % lanes_c, pg = threadIdx.x / lanes_c;
-  if (pg >= groups) return;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (pg < groups)
   for (long p = p0 + pg; p < p1; p += groups) {
     const float wv = w[(long)n * hw + p];
     float v[8];
@@ -303,14 +326,27 @@ __global__ __launch_bounds__(256) void wpool_fwd_kernel(const half_t* x, long x_
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] += wv * v[e];
   }
+  // the pixel groups of one channel octet meet in LDS and are added in group order; one partial row per (sample, chunk)
 #pragma unroll
-  for (int e = 0; e < 8; ++e) atomicAdd(out + (long)n * c8 * 8 + cg * 8 + e, acc[e]);
+  for (int e = 0; e < 8; ++e) sAcc[threadIdx.x][e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < lanes_c) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+      for (int q = 0; q < groups; ++q) t += sAcc[q * lanes_c + threadIdx.x][e];
+      part[(long)blockIdx.x * c8 * 8 + cg * 8 + e] = t;
+    }
+  }
 }
 extern "C" int csbsr_weighted_pool_fwd_split(const void* x, int64_t x_ld, int64_t x_lo, const float* w, float* out, int32_t N, int64_t hw,
                                              int32_t c, csbsr_stream_t s) {
   CSBSR_CHECK(x && w && out && c % 8 == 0 && c / 8 <= 256, "weighted_pool_fwd: bad args");
   const int chunks = (int)((hw + 1023) / 1024);
-  hipLaunchKernelGGL(wpool_fwd_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, x_ld, w, out, (long)hw, c / 8, chunks, x_lo);
+  float* part = csbsr_red_scratch((long)N * chunks * c);
+  CSBSR_NEED_SCRATCH(part, "weighted_pool_fwd");
+  hipLaunchKernelGGL(wpool_fwd_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, x_ld, w, part, (long)hw, c / 8, chunks, x_lo);
+  if (csbsr_sum_partials_batched(part, chunks, c, c, out, N, c, ST(s))) return 1;
   CSBSR_LAUNCH_CHECK("csbsr_weighted_pool_fwd");
   return 0;
 }
@@ -437,9 +473,9 @@ __global__ __launch_bounds__(256) void plane_reduce_kernel(const float* a, const
   x0 = wave_sum(x0); x1 = wave_sum(x1);
   if ((threadIdx.x & 63) == 0) { s0[threadIdx.x >> 6] = x0; s1[threadIdx.x >> 6] = x1; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    atomicAdd(out + plane * 2, s0[0] + s0[1] + s0[2] + s0[3]);
-    atomicAdd(out + plane * 2 + 1, s1[0] + s1[1] + s1[2] + s1[3]);
+  if (threadIdx.x == 0) {      // partial row per (plane, chunk)
+    out[(long)blockIdx.x * 2] = s0[0] + s0[1] + s0[2] + s0[3];
+    out[(long)blockIdx.x * 2 + 1] = s1[0] + s1[1] + s1[2] + s1[3];
   }
 }
 extern "C" int csbsr_plane_reduce(const float* a, const float* b, int32_t planes, int64_t hw, float* out /*[planes][2] zeroed*/,
@@ -447,7 +483,10 @@ extern "C" int csbsr_plane_reduce(const float* a, const float* b, int32_t planes
   CSBSR_CHECK(a && out, "plane_reduce: null");
   int chunks = (int)((hw + 65535) / 65536);
   if (chunks < 1) chunks = 1;
-  hipLaunchKernelGGL(plane_reduce_kernel, dim3(planes * chunks), dim3(256), 0, ST(s), a, b, hw, out, chunks);
+  float* part = csbsr_red_scratch((long)planes * chunks * 2);
+  CSBSR_NEED_SCRATCH(part, "plane_reduce");
+  hipLaunchKernelGGL(plane_reduce_kernel, dim3(planes * chunks), dim3(256), 0, ST(s), a, b, hw, part, chunks);
+  if (csbsr_sum_partials_batched(part, chunks, 2, 2, out, planes, 2, ST(s))) return 1;
   CSBSR_LAUNCH_CHECK("csbsr_plane_reduce");
   return 0;
 }
@@ -474,10 +513,10 @@ __global__ void instnorm_bwd_reduce_kernel(const half_t* dy, long dy_ld, const f
     if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][c][0] = v0; sm[threadIdx.x >> 6][c][1] = v1; }
   }
   __syncthreads();
-  if (threadIdx.x < C) {
+  if (threadIdx.x < C) {      // partial row per (sample, chunk): [C][2]
     const int c = threadIdx.x;
-    atomicAdd(red + (n * C + c) * 2, sm[0][c][0] + sm[1][c][0] + sm[2][c][0] + sm[3][c][0]);
-    atomicAdd(red + (n * C + c) * 2 + 1, sm[0][c][1] + sm[1][c][1] + sm[2][c][1] + sm[3][c][1]);
+    red[((long)blockIdx.x * C + c) * 2] = sm[0][c][0] + sm[1][c][0] + sm[2][c][0] + sm[3][c][0];
+    red[((long)blockIdx.x * C + c) * 2 + 1] = sm[0][c][1] + sm[1][c][1] + sm[2][c][1] + sm[3][c][1];
   }
 }
 __global__ void instnorm_bwd_apply_kernel(const half_t* dy, long dy_ld, const float* x, const float* mean, const float* invstd,
@@ -502,8 +541,11 @@ extern "C" int csbsr_instnorm_bwd(const void* dy, int64_t dy_ld, const float* x,
   CSBSR_CHECK(dy && x && dx && red && C <= 8, "instnorm_bwd: bad args");
   int chunks = (int)((hw + 65535) / 65536);
   if (chunks < 1) chunks = 1;
+  float* part = csbsr_red_scratch((long)N * chunks * C * 2);
+  CSBSR_NEED_SCRATCH(part, "instnorm_bwd");
   hipLaunchKernelGGL(instnorm_bwd_reduce_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)dy, dy_ld, x, mean, invstd, C,
-                     hw, red, chunks);
+                     hw, part, chunks);
+  if (csbsr_sum_partials_batched(part, chunks, 2 * C, 2 * C, red, N, 2 * C, ST(s))) return 1;
   hipLaunchKernelGGL(instnorm_bwd_apply_kernel, dim3(grid_for((long)N * hw)), dim3(256), 0, ST(s), (const half_t*)dy, dy_ld, x, mean,
                      invstd, red, N, C, hw, dx, accumulate);
   CSBSR_LAUNCH_CHECK("csbsr_instnorm_bwd");
@@ -649,13 +691,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnK p) {
       for (int e = 0; e < 8; ++e) {
         float a = 0.f, b = 0.f;
         for (int q = 0; q < ppb; ++q) { a += sRed[(q * cpb + tid) * 16 + e]; b += sRed[(q * cpb + tid) * 16 + 8 + e]; }
-        if (p.part) {
-          p.part[(long)blockIdx.x * p.part_ld + (cbase + tid) * 8 + e] = a;
-          p.part[(long)blockIdx.x * p.part_ld + p.cp + (cbase + tid) * 8 + e] = b;
-        } else {
-          atomicAdd(p.red + (cbase + tid) * 8 + e, a);
-          atomicAdd(p.red + p.cp + (cbase + tid) * 8 + e, b);
-        }
+        p.part[(long)blockIdx.x * p.part_ld + (cbase + tid) * 8 + e] = a;
+        p.part[(long)blockIdx.x * p.part_ld + p.cp + (cbase + tid) * 8 + e] = b;
       }
     }
     __syncthreads();
@@ -665,8 +702,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnK p) {
     if ((tid & 63) == 0) sPre[tid >> 6] = dsl;
     __syncthreads();
     if (tid == 0) {
-      if (p.part) p.part[(long)blockIdx.x * p.part_ld + 2 * p.cp] = sPre[0] + sPre[1] + sPre[2] + sPre[3];
-      else atomicAdd(p.dprelu, sPre[0] + sPre[1] + sPre[2] + sPre[3]);
+      p.part[(long)blockIdx.x * p.part_ld + 2 * p.cp] = sPre[0] + sPre[1] + sPre[2] + sPre[3];
     }
   }
 }
@@ -746,6 +782,7 @@ extern "C" int csbsr_bn_backward(const csbsr_bn_desc_t* d, csbsr_stream_t s) {
   const int rblocks = grid_for(k.npix, ppb * 8, 1024);
   k.part = nullptr; k.part_ld = 2 * k.cp + 8;
   k.part = csbsr_red_scratch((long)rblocks * k.part_ld);
+  CSBSR_NEED_SCRATCH(k.part, "bn_backward");
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rblocks), dim3(256), 0, ST(s), k);
   if (k.part) {
     csbsr_sum_partials(k.part, rblocks, k.part_ld, 2 * k.cp, k.red, ST(s));
@@ -1186,46 +1223,31 @@ __global__ void border_class_fill_kernel(const float* V, half_t* out, long ld, i
     *reinterpret_cast<h8*>(out + (((long)n * H + y) * W + x) * ld + cc * 8) = o;
   }
 }
-// adjoint: sums[n][class][:] += sum over the pixels of that class of x[n,y,x,:]   (interior reduced per block, the
-// O(perimeter) border pixels go straight to atomics)
-__global__ __launch_bounds__(256) void border_class_sums_kernel(const half_t* x, long ld, float* sums, int H, int W, int c8, int chunks) {
-  __shared__ float sred[256][8];
-  const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
-  const int cpb = c8 < 256 ? c8 : 256, ppb = 256 / cpb;
-  const int ch = threadIdx.x % cpb, pl = threadIdx.x / cpb;
-  const long hw = (long)H * W;
-  const long per = (hw + chunks - 1) / chunks;
-  const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;
-  for (int cbase = 0; cbase < c8; cbase += cpb) {
-    const int cc = cbase + ch;
-    float a[8];
+// adjoint: sums[n][class][:] += sum over the pixels of that class of x[n,y,x,:].  Degenerate / tiny maps: ONE workgroup per sample,
+// a thread owns a channel octet and walks the pixels in raster order (fixed order, no atomics).
+__global__ __launch_bounds__(256) void border_class_sums_small_kernel(const half_t* x, long ld, float* sums, int H, int W, int c8) {
+  const int n = blockIdx.x;
+  for (int cc = threadIdx.x; cc < c8; cc += 256) {
+    float a[16][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] = 0.f;
-    if (cc < c8 && pl < ppb)
-      for (long px = beg + pl; px < end; px += ppb) {
-        const int y = (int)(px / W), xx = (int)(px - (long)y * W);
-        const h8 v = *reinterpret_cast<const h8*>(x + ((long)n * hw + px) * ld + cc * 8);
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[k][e] = 0.f;
+    for (int y = 0; y < H; ++y)
+      for (int xx = 0; xx < W; ++xx) {
+        const h8 v = *reinterpret_cast<const h8*>(x + (((long)n * H + y) * W + xx) * ld + cc * 8);
         const int cls = (y == 0) * 8 + (y == H - 1) * 4 + (xx == 0) * 2 + (xx == W - 1);
-        if (cls == 0) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
-        } else {
+        for (int k = 0; k < 16; ++k)
+          if (k == cls) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) atomicAdd(sums + ((long)n * 16 + cls) * c8 * 8 + cc * 8 + e, (float)v[e]);
-        }
+            for (int e = 0; e < 8; ++e) a[k][e] += (float)v[e];
+          }
       }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sred[threadIdx.x][e] = a[e];
-    __syncthreads();
-    if (threadIdx.x < cpb && cbase + threadIdx.x < c8) {
+    for (int k = 0; k < 16; ++k)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float s_ = 0.f;
-        for (int q = 0; q < ppb; ++q) s_ += sred[q * cpb + threadIdx.x][e];
-        atomicAdd(sums + (long)n * 16 * c8 * 8 + (cbase + threadIdx.x) * 8 + e, s_);
-      }
-    }
-    __syncthreads();
+      for (int e = 0; e < 8; ++e) sums[((long)n * 16 + k) * c8 * 8 + cc * 8 + e] += a[k][e];
   }
 }
 extern "C" int csbsr_border_class_fill(const float* V, void* out, int64_t ld, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
@@ -1271,26 +1293,25 @@ __global__ __launch_bounds__(256) void bcs_total_kernel(const half_t* x, long ld
       for (int e = 0; e < 8; ++e) {
         float s_ = 0.f;
         for (int q = 0; q < ppb; ++q) s_ += sred[q * cpb + threadIdx.x][e];
-        if (part) part[(long)blockIdx.x * c8 * 8 + (cbase + threadIdx.x) * 8 + e] = s_;      // row per (sample, chunk): folded by csbsr_sum_partials
-        else atomicAdd(sums + (long)n * 16 * c8 * 8 + (cbase + threadIdx.x) * 8 + e, s_);
+        part[(long)blockIdx.x * c8 * 8 + (cbase + threadIdx.x) * 8 + e] = s_;      // row per (sample, chunk): folded by csbsr_sum_partials
       }
     }
     __syncthreads();
   }
 }
-// grid = N * 4 edges * groups of 32 channel chunks; block: 32 chunk lanes x 8 pixel lanes
-__global__ __launch_bounds__(256) void bcs_edges_kernel(const half_t* x, long ld, float* sums, int H, int W, int c8) {
-  __shared__ float sbin[3][32][8];           // this edge touches at most 3 classes: edge, its two corners
+// grid = N * 4 edges * groups of 32 channel chunks * SEG segments; block: 32 chunk lanes x 8 pixel lanes.  The 8 pixel lanes meet in
+// LDS and are added in lane order; every block writes its (edge class, two corner classes) sums as one partial row
+// part[((n * 4 + edge) * SEG + seg)][3][c], folded per class in segment order by bcs_edges_finish_kernel.
+constexpr int BCS_SEG = 8;
+__global__ __launch_bounds__(256) void bcs_edges_kernel(const half_t* x, long ld, float* part, int H, int W, int c8) {
+  __shared__ float sbin[8][3][32][8];
   const int groups = (c8 + 31) / 32;
-  constexpr int SEG = 8;                      // an edge is cut into 8 segments: 8 atomics per address instead of 16 workgroups in total
   int b = blockIdx.x;
-  const int seg = b % SEG; b /= SEG;
+  const int seg = b % BCS_SEG; b /= BCS_SEG;
   const int g = b % groups; b /= groups;
   const int edge = b % 4; const int n = b / 4;
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int cc = g * 32 + cl;
-  for (int i = threadIdx.x; i < 3 * 32 * 8; i += 256) (&sbin[0][0][0])[i] = 0.f;
-  __syncthreads();
   // edges: 0 top row, 1 bottom row (full rows incl. corners), 2 left col, 3 right col (rows 1..H-2 only: corners belong to the rows)
   const int len = edge < 2 ? W : H - 2;
   float a[3][8];
@@ -1298,7 +1319,7 @@ __global__ __launch_bounds__(256) void bcs_edges_kernel(const half_t* x, long ld
   for (int k = 0; k < 3; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[k][e] = 0.f;
-  const int i0 = (int)((long)len * seg / SEG), i1 = (int)((long)len * (seg + 1) / SEG);
+  const int i0 = (int)((long)len * seg / BCS_SEG), i1 = (int)((long)len * (seg + 1) / BCS_SEG);
   if (cc < c8)
     for (int i = i0 + pl; i < i1; i += 8) {
       int y, xx;
@@ -1306,26 +1327,43 @@ __global__ __launch_bounds__(256) void bcs_edges_kernel(const half_t* x, long ld
       const h8 v = *reinterpret_cast<const h8*>(x + (((long)n * H + y) * W + xx) * ld + cc * 8);
       const int k = (edge < 2) ? (xx == 0 ? 1 : (xx == W - 1 ? 2 : 0)) : 0;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[k][e] += (float)v[e];
+      for (int kk = 0; kk < 3; ++kk)
+        if (kk == k) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[kk][e] += (float)v[e];
+        }
     }
 #pragma unroll
   for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (a[k][e] != 0.f) atomicAdd(&sbin[k][cl][e], a[k][e]);
+    for (int e = 0; e < 8; ++e) sbin[pl][k][cl][e] = a[k][e];
   __syncthreads();
   if (pl == 0 && cc < c8) {
-    const int base_cls = edge == 0 ? 8 : (edge == 1 ? 4 : (edge == 2 ? 2 : 1));
+    float* row = part + (((long)n * 4 + edge) * BCS_SEG + seg) * 3 * c8 * 8;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (edge >= 2 && k > 0) break;
-      const int cls = base_cls + (k == 1 ? 2 : (k == 2 ? 1 : 0));
-      float* dst = sums + ((long)n * 16 + cls) * c8 * 8 + cc * 8;
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (sbin[k][cl][e] != 0.f) atomicAdd(dst + e, sbin[k][cl][e]);       // 8 segment blocks per (n, class, channel); sums is zeroed by the caller
-    }
+      for (int e = 0; e < 8; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += sbin[q][k][cl][e];
+        row[(long)k * c8 * 8 + cc * 8 + e] = t;
+      }
   }
+}
+// sums[n][cls][ch] += the edge / corner sums of the segments, in segment order (cls = border-class index of conv_epilogue_row)
+__global__ void bcs_edges_finish_kernel(const float* part, float* sums, int N, int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * 4 * 3 * c) return;
+  const int ch = i % c; int r = i / c;
+  const int k = r % 3; r /= 3;
+  const int edge = r % 4; const int n = r / 4;
+  if (edge >= 2 && k > 0) return;
+  const int base_cls = edge == 0 ? 8 : (edge == 1 ? 4 : (edge == 2 ? 2 : 1));
+  const int cls = base_cls + (k == 1 ? 2 : (k == 2 ? 1 : 0));
+  float t = 0.f;
+  for (int seg = 0; seg < BCS_SEG; ++seg) t += part[((((long)n * 4 + edge) * BCS_SEG + seg) * 3 + k) * c + ch];
+  sums[((long)n * 16 + cls) * c + ch] += t;
 }
 __global__ void bcs_fixup_kernel(float* sums, int N, int c) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1338,23 +1376,25 @@ __global__ void bcs_fixup_kernel(float* sums, int N, int c) {
 }
 extern "C" int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
   CSBSR_CHECK(x && sums && c % 8 == 0, "border_class_sums: bad args");
-  if (H >= 3 && W >= 3 && (long)H * W >= 4096) {
+  if (H >= 3 && W >= 3 && (long)H * W >= 1024) {
+    // (1) plain total over all pixels, (2) the O(perimeter) border pixels binned per class by one workgroup per (sample, edge, segment),
+    // (3) interior = total - sum of the border classes.  Every stage is a fixed-order fold of partial rows.
     const long hw = (long)H * W;
     int chunks = (int)((hw + 511) / 512);     // >= 392 workgroups at LR 448^2: the 4096-pixel chunks left 4/5 of the CUs idle
     if (chunks > 2048) chunks = 2048;
-    float* part = csbsr_red_scratch((long)N * chunks * c);
+    const long n_tot = (long)N * chunks * c, n_edge = (long)N * 4 * BCS_SEG * 3 * c;
+    float* part = csbsr_red_scratch(n_tot + n_edge);
+    CSBSR_NEED_SCRATCH(part, "border_class_sums");
     hipLaunchKernelGGL(bcs_total_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks, part);
-    if (part)
-      for (int n = 0; n < N; ++n) csbsr_sum_partials(part + (long)n * chunks * c, chunks, c, c, sums + (long)n * 16 * c, ST(s));
-    hipLaunchKernelGGL(bcs_edges_kernel, dim3(N * 4 * ((c / 8 + 31) / 32) * 8), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, H, W, c / 8);
+    if (csbsr_sum_partials_batched(part, chunks, c, c, sums, N, 16l * c, ST(s))) return 1;
+    float* epart = part + n_tot;
+    hipLaunchKernelGGL(bcs_edges_kernel, dim3(N * 4 * ((c / 8 + 31) / 32) * BCS_SEG), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, epart, H, W, c / 8);
+    hipLaunchKernelGGL(bcs_edges_finish_kernel, dim3((N * 12 * c + 255) / 256), dim3(256), 0, ST(s), (const float*)epart, sums, N, c);
     hipLaunchKernelGGL(bcs_fixup_kernel, dim3((N * c + 255) / 256), dim3(256), 0, ST(s), sums, N, c);
     CSBSR_LAUNCH_CHECK("csbsr_border_class_sums");
     return 0;
   }
-  int chunks = (int)(((long)H * W + 16383) / 16384);
-  if (chunks < 1) chunks = 1;
-  if (chunks > 512) chunks = 512;
-  hipLaunchKernelGGL(border_class_sums_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, H, W, c / 8, chunks);
+  hipLaunchKernelGGL(border_class_sums_small_kernel, dim3(N), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, H, W, c / 8);
   CSBSR_LAUNCH_CHECK("csbsr_border_class_sums");
   return 0;
 }

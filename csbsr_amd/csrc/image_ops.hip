@@ -260,12 +260,9 @@ __global__ __launch_bounds__(256) void blur_bwd_kernel_kernel(const float* dy, c
       }
     }
   }
-  if (part) {           // row per (sample, workgroup), 512 floats: folded by csbsr_sum_partials
+  {                     // row per (sample, workgroup), 512 floats: folded by csbsr_sum_partials
     float* row = part + ((long)n * gridDim.x + blockIdx.x) * 512;
     row[t0] = acc0; row[t1] = acc1;
-  } else {
-    if (v0) atomicAdd(dk + (long)n * K * K + t0, acc0);
-    if (v1) atomicAdd(dk + (long)n * K * K + t1, acc1);
   }
 }
 
@@ -341,10 +338,10 @@ extern "C" int csbsr_blur_bwd_kernel(const float* dy, const float* x, float* dk,
   if (tpw < 1) tpw = 1;
   dim3 grid((total + tpw - 1) / tpw, N);
   float* part = csbsr_red_scratch((long)N * grid.x * 512);
+  CSBSR_NEED_SCRATCH(part, "blur_bwd_kernel");
   BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_bwd_kernel_kernel<KK>), grid, dim3(256), smem, ST(s), dy, x, dk, C, H, W, OH, OW, stride, TO, lgTO,
                                       tiles_x, tiles_y, tpw, part));
-  if (part)
-    for (int n = 0; n < N; ++n) csbsr_sum_partials(part + (long)n * grid.x * 512, (int)grid.x, 512, K * K, dk + (long)n * K * K, ST(s));
+  if (csbsr_sum_partials_batched(part, (int)grid.x, 512, K * K, dk, N, (long)K * K, ST(s))) return 1;
   CSBSR_LAUNCH_CHECK("csbsr_blur_bwd_kernel");
   return 0;
 }
@@ -672,7 +669,7 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* a, const float* b,
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0 && sums) atomicAdd(sums + n, sred[0] + sred[1] + sred[2] + sred[3]);
+  if (threadIdx.x == 0 && sums) sums[blockIdx.x] = sred[0] + sred[1] + sred[2] + sred[3];      // partial per (sample, chunk)
 }
 extern "C" int csbsr_l1_fwd_bwd(const float* a, const float* b, const float* wmap, int32_t N, int32_t C, int64_t hw, float* sums,
                                 float gscale, const float* gs_n, float* da, int32_t da_accumulate, csbsr_stream_t s) {
@@ -680,7 +677,13 @@ extern "C" int csbsr_l1_fwd_bwd(const float* a, const float* b, const float* wma
   long total = (long)C * hw;
   int chunks = (int)((total + 65535) / 65536);
   if (chunks < 1) chunks = 1;
-  hipLaunchKernelGGL(l1_kernel, dim3(N * chunks), dim3(256), 0, ST(s), a, b, wmap, C, hw, sums, gscale, gs_n, da, da_accumulate, chunks);
+  float* part = nullptr;
+  if (sums) {
+    part = csbsr_red_scratch((long)N * chunks);
+    CSBSR_NEED_SCRATCH(part, "l1");
+  }
+  hipLaunchKernelGGL(l1_kernel, dim3(N * chunks), dim3(256), 0, ST(s), a, b, wmap, C, hw, part, gscale, gs_n, da, da_accumulate, chunks);
+  if (sums && csbsr_sum_partials_batched(part, chunks, 1, 1, sums, N, 1, ST(s))) return 1;
   CSBSR_LAUNCH_CHECK("csbsr_l1_fwd_bwd");
   return 0;
 }
@@ -707,7 +710,8 @@ __global__ __launch_bounds__(256) void segloss_reduce_kernel(const float* p, con
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6][k] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 5) atomicAdd(sums + n * 8 + threadIdx.x, sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+  if (threadIdx.x < 5)       // partial row per (sample, chunk)
+    sums[(long)blockIdx.x * 8 + threadIdx.x] = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
 }
 // loss[n] += weight * L ;  dp = gscale[n] * weight * dL/dp   where
 // L = alpha * (lw0*bce_mean + lw1*dice)/(lw0+lw1) + (1-alpha) * mean(p*sdf)
@@ -725,7 +729,7 @@ __global__ void segloss_finish_kernel(const float* p, const float* t, const floa
       const float bce = S[0] / pws / hw;
       const float dice = 1.f - num / den;
       const float L = alpha * (lw0 * bce + lw1 * dice) / lws + (1.f - alpha) * S[4] / hw;
-      atomicAdd(loss + n, weight * L);
+      loss[n] += weight * L;          // exactly one thread per sample and launch
     }
     if (dp) {
       const float praw = p[gi], tv = t[gi];
@@ -746,7 +750,10 @@ extern "C" int csbsr_segloss_reduce(const float* p, const float* t, const float*
   CSBSR_CHECK(p && t && sdf && sums, "segloss_reduce: null");
   int chunks = (int)((hw + 65535) / 65536);
   if (chunks < 1) chunks = 1;
-  hipLaunchKernelGGL(segloss_reduce_kernel, dim3(N * chunks), dim3(256), 0, ST(s), p, t, sdf, (long)hw, sums, pw0, pw1, chunks);
+  float* part = csbsr_red_scratch((long)N * chunks * 8);
+  CSBSR_NEED_SCRATCH(part, "segloss_reduce");
+  hipLaunchKernelGGL(segloss_reduce_kernel, dim3(N * chunks), dim3(256), 0, ST(s), p, t, sdf, (long)hw, part, pw0, pw1, chunks);
+  if (csbsr_sum_partials_batched(part, chunks, 8, 5, sums, N, 8, ST(s))) return 1;
   CSBSR_LAUNCH_CHECK("csbsr_segloss_reduce");
   return 0;
 }

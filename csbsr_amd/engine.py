@@ -84,7 +84,8 @@ class FM:
         return (not self.bcast) and t.stride(1) == t.shape[2] * t.stride(2) and t.stride(0) == t.shape[1] * t.stride(1)
 
 
-# Partial-row scratch of the two-stage reductions (csbsr_set_reduction_scratch): ONE buffer per device for the life of the process,
+# Partial-row scratch of the order-fixed two-stage reductions (csbsr_set_reduction_scratch; the library has no floating-point atomics,
+# every sum is a fixed tree over partial rows, so a step is bit-reproducible): ONE buffer per device for the life of the process,
 # shared by every Engine on that device and registered with the library under that device's index -- so a second model (an
 # evaluator next to the trainer, a replica on another GPU) neither steals the registration nor leaves a dangling pointer behind when
 # it is garbage-collected.  Launches on one device are stream-ordered per Engine; two Engines on one device must not run reducing
@@ -97,7 +98,9 @@ def _reduction_scratch(device):
     buf = _RED_SCRATCH.get(idx)
     if buf is None:
         # poisoned with NaN once: a fold that reads a slot its producer did not write shows up immediately instead of adding garbage
-        buf = torch.full((16 << 20,), float("nan"), dtype=torch.float32, device=torch.device("cuda", idx))
+        # 256 MB: the largest user is the BatchNorm-statistics rows of a 64-channel conv at HR 1792^2, B = 8 (one [sum | sumsq] row per
+        # 128-pixel tile: 26 M floats); the last 4 M floats are the second level of csbsr_sum_partials (csrc/common.h)
+        buf = torch.full((64 << 20,), float("nan"), dtype=torch.float32, device=torch.device("cuda", idx))
         _RED_SCRATCH[idx] = buf
         with torch.cuda.device(idx):
             L.call("csbsr_set_reduction_scratch", _ptr(buf), buf.numel())

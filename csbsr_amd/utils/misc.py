@@ -1,15 +1,18 @@
-"""Checkpoint interchange helpers: model/utils/misc.py:35-44."""
+"""Checkpoint interchange helper.  Same contract as the reference's
+``model/utils/misc.py:35-44`` (called from train.py:102, test.py:45,52, build_model.py:98,108): keys saved from an
+``nn.DataParallel`` wrapper lose their ``module.`` prefix, then ``len(addition_word)`` leading characters are dropped from every key
+(the reference slices by length without checking the text, so a key that does not start with the word is truncated all the same --
+kept, because released checkpoints are loaded through exactly that behaviour)."""
 from collections import OrderedDict
 
+_DP_PREFIX = "module."
 
-def fix_model_state_dict(state_dict, addition_word=''):
-    """strip nn.DataParallel's ``module.`` prefix (and an optional leading ``addition_word``) from every key"""
-    new_state_dict = OrderedDict()
-    for k, v in state_dict.items():
-        name = k
-        if name.startswith('module.'):
-            name = name[7:]
-        if len(addition_word) != 0:
-            name = name[len(addition_word):]
-        new_state_dict[name] = v
-    return new_state_dict
+
+def fix_model_state_dict(state_dict, addition_word=""):
+    cut = len(addition_word)
+
+    def rename(key):
+        key = key[len(_DP_PREFIX):] if key.startswith(_DP_PREFIX) else key
+        return key[cut:]
+
+    return OrderedDict((rename(key), value) for key, value in state_dict.items())

@@ -220,11 +220,15 @@ typedef struct {
   float* dprelu;                       /* fp32 scalar += or NULL */
 } csbsr_epi_bwd_desc_t;
 int csbsr_epilogue_backward(const csbsr_epi_bwd_desc_t* d, csbsr_stream_t s);
-/* Caller-owned fp32 scratch for the two-stage per-channel reductions of csbsr_epilogue_backward / csbsr_bn_backward (one partial row
- * per workgroup + a fold kernel instead of ~1e5 contended atomics per call).  Registered PER DEVICE: the call binds ``buf`` to the
- * calling thread's current HIP device and the reducing entry points look their device's buffer up at launch, so several models /
- * replicas in one process do not overwrite each other's registration.  Used by whatever stream the calls are issued on: one stream
- * at a time per device.  16 Mi floats cover every shape of the path; NULL (the default) keeps the atomics path. */
+/* Caller-owned fp32 scratch for the library's reductions.  EVERY floating-point sum of the path (conv-fused BatchNorm / per-sample
+ * statistics, bias / PReLU / BatchNorm gradient sums, loss sums, border-class sums, blur-kernel gradients, pooling) is order-fixed:
+ * the producing kernel writes one partial row per workgroup (or pixel tile) here and a fold kernel adds the rows in a fixed tree --
+ * no fp32 atomics anywhere, so two runs on the same inputs are bit-identical (the reference's CPU path is too).  Registered PER
+ * DEVICE: the call binds ``buf`` to the calling thread's current HIP device and the reducing entry points look their device's buffer
+ * up at launch, so several models / replicas in one process do not overwrite each other's registration.  Used by whatever stream
+ * the calls are issued on: one stream at a time per device.  64 Mi floats cover every shape of the path at B = 8, HR 1792^2 (the
+ * last 4 Mi are the second level of the fold).  Without a registered (or with too small a) buffer the reducing entry points FAIL
+ * (status 1, csbsr_last_error): there is no atomics fallback. */
 int csbsr_set_reduction_scratch(float* buf, int64_t elems);
 
 int csbsr_axpby(int64_t npix, int32_t c, const void* x, int64_t x_ld, float a, const void* z, int64_t z_ld,
