@@ -128,8 +128,9 @@ def main():
     model.max_resident = None if args.max_resident < 0 else args.max_resident     # None: as many as the free HBM allows
     model.train()
     rt = model._runtime()
+    n_bcast = 0
     if dist_on:
-        broadcast_parameters(model)
+        n_bcast = broadcast_parameters(model)
         model.reducer = GradBucketReducer(side_stream=torch.cuda.Stream(dev))
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.SOLVER.LR, betas=(0.9, 0.999), eps=1e-8)    # train.py:91
 
@@ -274,6 +275,8 @@ def main():
                "roofline": roof,
                "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                "with_h2d_inside_step": h2d}
+        if dist_on:      # what the gradient exchange did (per rank): collectives, how many rode the side stream, payload
+            out["reducer"] = dict(model.reducer.stats, broadcasts=n_bcast, backend=backend, world=world)
         if other:
             out["step_roofline"] = None          # the folded-work figures above are config 2's
         if not args.no_cpu_baseline and world == 1 and not other:

@@ -110,4 +110,6 @@ def path_config(c, antialias=True):
     p.oriented_w_iter = c.SOLVER.ORIENTED_WEIGHT_ITER
     p.sfo_sr_amp = float(c.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP)
     p.pixel_shuffle = bool(c.MODEL.SR_PIXEL_SHUFFLE)
+    p.residual_learning = bool(c.MODEL.SR_RESIDUAL_LEARNING)             # kbpn.py:32,69-70,112-116
+    p.only_kernel_loss = bool(c.SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN)    # sr_loss_functions.py:32,50-51
     return p

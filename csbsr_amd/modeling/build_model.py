@@ -104,6 +104,12 @@ class _JointBase(nn.Module):
                                       f"DETECTOR_TYPE={cfg.MODEL.DETECTOR_TYPE}")
         if cfg.MODEL.SUM_LR_ERROR_POS != "HR" or not cfg.MODEL.KBPN_KERNEL_SFT:
             raise NotImplementedError("only the KBPN variants with the HR error sum and the kernel SFT are built")
+        if cfg.MODEL.ZERO_PAD_KERNEL:       # kbpn.py:543-554,583-596: a learned per-sample choice between zero-padding and bicubic upsampling
+            raise NotImplementedError("MODEL.ZERO_PAD_KERNEL=True (the kernel predictor's pad discriminator) is not built")
+        if cfg.MODEL.NUM_CLASSES != 1:      # build_model.py:209: every kernel of this path assumes the 1-class crack map
+            raise NotImplementedError(f"MODEL.NUM_CLASSES={cfg.MODEL.NUM_CLASSES}: only the 1-class detectors are built")
+        if cfg.MODEL.SR_SEG_INV or not cfg.MODEL.JOINT_LEARNING:
+            raise NotImplementedError("only MODEL.JOINT_LEARNING=True with SR_SEG_INV=False (SR feeds the detector, one joint loss) is built")
         self.cfg = cfg
         self.pc = path_config(cfg, antialias)
         self.scale_factor = cfg.MODEL.SCALE_FACTOR
@@ -130,6 +136,7 @@ class _JointBase(nn.Module):
         # (26.5 GB per image at HR 1792^2), the others are recomputed there.  None = as many as the free HBM allows.
         self.micro_batch = 4
         self.max_resident = None
+        self.lean_saves = None        # None: lean KBPN saves (KBPN.forward) only when that keeps more micro-batches resident; True / False force it
         self.dropout_enabled = True
         self.dropout_masks = None     # tests may inject {name: [B,C] fp32} keep-masks
         # Precision plan of the detector's FORWARD pass (PSPNet / PSPNet_BlurSkip / HRNet-OCR):
@@ -294,7 +301,7 @@ class JointModelWithLoss(_JointBase):
         B, _, h, w = x.shape
         H, W = h * pc.scale, w * pc.scale
         mb = max(1, min(self.micro_batch, B))
-        n_res = self.max_resident if self.max_resident is not None else self._auto_resident(B, mb, H, W)
+        n_res, lean = (self.max_resident, bool(self.lean_saves)) if self.max_resident is not None else self._auto_resident(B, mb, H, W)
         self._n_res = n_res
         single = mb >= B
         sr32 = eng.f32(B, 3, H, W, zero=False)
@@ -304,7 +311,7 @@ class JointModelWithLoss(_JointBase):
         saves = []
         for i, b0 in enumerate(range(0, B, mb)):
             resident = keep and i < n_res and not self.blur_skip     # BlurSkip: KBPN is frozen, no backward through it
-            s_, k_ = kbpn.forward(x[b0:b0 + mb], iter, kgt[b0:b0 + mb], save=resident)
+            s_, k_ = kbpn.forward(x[b0:b0 + mb], iter, kgt[b0:b0 + mb], save=resident, lean=lean)
             saves.append(kbpn.saved if resident else None)
             kbpn.saved = None
             sr32[b0:b0 + mb] = s_
@@ -394,12 +401,15 @@ class JointModelWithLoss(_JointBase):
         L.call("csbsr_l1_fwd_bwd", _ptr(lr_pred), _ptr(x), _ptr(wmap_lr), B, 3, h * w, _ptr(s_lr), 0.0, None, None, 0, eng.stream)
         kpred = vec.reshape(B, 1, K, K)
         k_l = ((kpred - kgt) ** 2).mean((1, 2, 3))
-        sr_loss = pc.sr_w[0] * s_hr / (3 * hw) + pc.sr_w[1] * s_lr / (3 * h * w) + pc.sr_w[2] * k_l
+        # SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN (sr_loss_functions.py:50-51): during the kernel-module pretraining phase the SR loss IS the
+        # kernel MSE (the reference returns the unreduced [B,1,K,K] map there and calc_loss takes its mean: the per-sample mean has the same mean)
+        sr_w = (0.0, 0.0, 1.0) if (pc.only_kernel_loss and pc.kernel_pretrain[0] <= iter < pc.kernel_pretrain[1]) else pc.sr_w
+        sr_loss = sr_w[0] * s_hr / (3 * hw) + sr_w[1] * s_lr / (3 * h * w) + sr_w[2] * k_l
         del blurred
         if keep:
             st = dict(iter=iter, x=x, hr=hr, mask=mask, kgt=kgt, sr32=sr32, kvec=kvec, ksum=ksum, vec=vec, mean=mean, invstd=invstd,
                       seg32=seg32, aux32=aux32, sdf=sdf, sums_m=sums_m, sums_a=sums_a, alpha=alpha, lr_pred=lr_pred,
-                      wmap=wmap, wmap_lr=wmap_lr, saves=saves, mb=mb, B=B, h=h, w=w, psp_saved=psp_saved, n_res=self._n_res)
+                      wmap=wmap, wmap_lr=wmap_lr, saves=saves, mb=mb, B=B, h=h, w=w, psp_saved=psp_saved, n_res=self._n_res, sr_w=sr_w)
             params = [p for p in self.parameters()]
             seg_loss, sr_loss = _JointFn.apply(self, st, seg_loss, sr_loss, *params)
         return seg_loss, sr_loss, seg32, sr32, kpred
@@ -416,8 +426,15 @@ class JointModelWithLoss(_JointBase):
         det = (9.5e9 if self.seg_model_name == "HRNet_OCR" else 6.3e9) * r * B
         if self.detector_precision == "split":
             det += 4.9e9 * r * B
-        imgs = int((free - 18e9 - det) // (26.5e9 * r)) if r > 0 else B
-        return max(0, min((B + mb - 1) // mb, imgs // mb))
+        n_mb = (B + mb - 1) // mb
+
+        def fit(per_img):
+            imgs = int((free - 18e9 - det) // (per_img * r)) if r > 0 else B
+            return max(0, min(n_mb, imgs // mb))
+        full, lean = fit(26.5e9), fit(21.2e9)      # lean saves: the kernel predictors' fe_SR chains are rebuilt in the backward (KBPN.forward)
+        if self.lean_saves is not None:
+            return (lean, True) if self.lean_saves else (full, False)
+        return (lean, True) if lean > full else (full, False)
 
     # ------------------------------------------------------------------ backward
     def _hip_backward(self, st, dseg_loss, dsr_loss):
@@ -472,8 +489,9 @@ class JointModelWithLoss(_JointBase):
         if dsr_loss is not None:
             g = (dsr_loss.to(torch.float32) * gs)
             K = pc.ksize_out
-            g_hr = (g * pc.sr_w[0] / (3 * hw)).contiguous()
-            g_lr = (g * pc.sr_w[1] / (3 * h * w)).contiguous()
+            sr_w = st["sr_w"]
+            g_hr = (g * sr_w[0] / (3 * hw)).contiguous()
+            g_lr = (g * sr_w[1] / (3 * h * w)).contiguous()
             L.call("csbsr_l1_fwd_bwd", _ptr(st["sr32"]), _ptr(st["hr"]), _ptr(st["wmap"]), B, 3, hw, None, 1.0, _ptr(g_hr), _ptr(dsr32), 1,
                    eng.stream)
             dlr = eng.f32(B, 3, h, w, zero=False)
@@ -484,8 +502,8 @@ class JointModelWithLoss(_JointBase):
             L.call("csbsr_blur_bwd_input", _ptr(dbl), _ptr(st["vec"]), _ptr(dsr32), 1, B, 3, H, W, K, 1, eng.stream)
             dvec = eng.f32(B, K * K)
             L.call("csbsr_blur_bwd_kernel", _ptr(dbl), _ptr(st["sr32"]), _ptr(dvec), B, 3, H, W, K, 1, eng.stream)
-            if pc.sr_w[2] != 0:
-                dvec += (g * pc.sr_w[2] / (K * K)).reshape(B, 1) * 2 * (st["vec"] - st["kgt"].reshape(B, -1))
+            if sr_w[2] != 0:
+                dvec += (g * sr_w[2] / (K * K)).reshape(B, 1) * 2 * (st["vec"] - st["kgt"].reshape(B, -1))
             dkvec = (dvec - (dvec * st["vec"]).sum(1, keepdim=True)) / st["ksum"]
             del dbl, dlr
         # ---- KBPN backward (per micro-batch; recompute the forward when it was not kept)

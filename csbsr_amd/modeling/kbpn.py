@@ -126,9 +126,13 @@ class KBPN:
         return FM(t, g.shape[1], bcast=True, H=H, W=W)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x32, it, kernel_gt, save=True):
-        """x32: fp32 NCHW LR batch on device.  Returns (sr32 [B,3,H,W] fp32, kvec [B,kk] fp32 normalised)."""
+    def forward(self, x32, it, kernel_gt, save=True, lean=False):
+        """x32: fp32 NCHW LR batch on device.  Returns (sr32 [B,3,H,W] fp32, kvec [B,kk] fp32 normalised).
+        ``lean``: do not keep the fe_SR chain of the per-stage kernel predictors for the backward (208 of the ~1040 HR channel planes a
+        stage saves: 5.3 of 26.5 GB per image at HR 1792^2); the backward rebuilds it from the saved 3-channel SR estimate with five thin
+        convolutions per stage (~2 % of a step, bit-identical values: the path is order-fixed)."""
         e = self.eng
+        self.lean = bool(lean)
         self.set_phase(it)
         B, _, h, w = x32.shape
         H, W = h * self.scale, w * self.scale
@@ -210,7 +214,8 @@ class KBPN:
                 del q
         sr32 = e.f32(B, 3, H, W, zero=False)
         self.output_conv.fwd(concat_h, out32=sr32)
-        L.call("csbsr_bicubic_up_add", _ptr(x32), _ptr(sr32), B * 3, h, w, self.scale, e.stream)
+        if getattr(self.cfg, "residual_learning", True):      # MODEL.SR_RESIDUAL_LEARNING (kbpn.py:112-116): sr += bicubic_up(x)
+            L.call("csbsr_bicubic_up_add", _ptr(x32), _ptr(sr32), B * 3, h, w, self.scale, e.stream)
         sv["stages"] = stg
         self.saved = sv if save else None
         return sr32, kvec
@@ -230,7 +235,7 @@ class KBPN:
         gap = e.f32(B, pad8(self.kc))
         st.fe_cat[2].fwd(c2, stat=gap, stat_mode=L.STAT_SAMPLE_SUM, store=False)
         d49 = gap[:, :self.kc] / float(H * W)
-        q["kp"] = (a, kfm, b1, b2, c1, c2)
+        q["kp"] = (a[:1] if getattr(self, "lean", False) else a, kfm, b1, b2, c1, c2)
         return kvec + d49 @ self.U.t()
 
     # ------------------------------------------------------------------ backward
@@ -414,6 +419,10 @@ class KBPN:
         """backward of kvec2 = kvec_in + U @ GAP(fe_cat(...)); adds the fe_SR path into dsr_t (fp32 planar)."""
         e = self.eng
         a, kfm, b1, b2, c1, c2 = q["kp"]
+        if len(a) == 1:              # lean save: rebuild the fe_SR chain from the SR estimate (same kernels, same order: bit-identical)
+            a = list(a)
+            for c in st.fe_sr:
+                a.append(c.fwd(a[-1]))
         B = dk2.shape[0]
         d49 = (dk2 @ self.U) / float(H * W)
         g = self._bcast_grad(d49, H, W)

@@ -10,32 +10,51 @@ backward has passed that stage -- so every all-reduce but the last runs on a sid
 backward.  Buckets are preallocated flat fp32 buffers that the per-parameter gradient accumulators are views of
 (``launch_flat``): no flatten / scatter copies.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
+def _forced():
+    """CSBSR_FORCE_DIST=1: issue every collective even in a one-rank group, so the real backend (RCCL on the GPU box) executes the
+    N > 1 call sequence -- side-stream launches from inside the backward, in-place flat buckets -- on the one GPU a test box has."""
+    return os.environ.get("CSBSR_FORCE_DIST") == "1"
+
+
 class GradBucketReducer:
-    def __init__(self, process_group=None, side_stream=None):
+    def __init__(self, process_group=None, side_stream=None, force=None):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.side_stream = side_stream
+        self.force = (_forced() if force is None else bool(force)) and dist.is_initialized()
         self._pending = []
+        # what was exchanged so far: collectives issued, of which on the side stream, and payload bytes (tests / bench JSON)
+        self.stats = {"all_reduces": 0, "on_side_stream": 0, "bytes": 0, "steps": 0}
+
+    @property
+    def active(self):
+        return self.world > 1 or self.force
+
+    def _all_reduce(self, flat):
+        self.stats["all_reduces"] += 1
+        self.stats["bytes"] += flat.numel() * flat.element_size()
+        if self.side_stream is not None and flat.is_cuda:
+            self.stats["on_side_stream"] += 1
+            self.side_stream.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(self.side_stream):
+                return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def launch(self, grads):
         """Start the all-reduce of a list of fp32 gradient tensors (None entries are skipped).  Returns a handle."""
         live = [g for g in grads if g is not None]
-        if not live or self.world == 1:
+        if not live or not self.active:
             h = (grads, None, None, None)
             self._pending.append(h)
             return h
         flat = torch.cat([g.reshape(-1) for g in live])
-        work = None
-        if self.side_stream is not None and flat.is_cuda:
-            self.side_stream.wait_stream(torch.cuda.current_stream(flat.device))
-            with torch.cuda.stream(self.side_stream):
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        else:
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        work = self._all_reduce(flat)
         h = (grads, live, flat, work)
         self._pending.append(h)
         return h
@@ -43,14 +62,9 @@ class GradBucketReducer:
     def launch_flat(self, flat):
         """Start the in-place all-reduce of one preallocated flat fp32 bucket (the gradient accumulators of a parameter group are
         views into it: no flatten copy before, no scatter copy after).  The caller must not touch the bucket until finish()."""
-        if self.world == 1 or flat is None or flat.numel() == 0:
+        if not self.active or flat is None or flat.numel() == 0:
             return None
-        if self.side_stream is not None and flat.is_cuda:
-            self.side_stream.wait_stream(torch.cuda.current_stream(flat.device))
-            with torch.cuda.stream(self.side_stream):
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        else:
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        work = self._all_reduce(flat)
         h = (None, None, flat, work)
         self._pending.append(h)
         return h
@@ -63,7 +77,8 @@ class GradBucketReducer:
             work.wait()
             if self.side_stream is not None and flat.is_cuda:
                 torch.cuda.current_stream(flat.device).wait_stream(self.side_stream)
-            flat.mul_(1.0 / self.world)
+            if self.world > 1:          # (a one-rank group's sum is the value itself: forced runs stay bit-identical to undistributed ones)
+                flat.mul_(1.0 / self.world)
             if live is None:            # launch_flat: the accumulators are views of the bucket
                 continue
             off = 0
@@ -72,11 +87,17 @@ class GradBucketReducer:
                 g.copy_(flat[off:off + n].view_as(g))
                 off += n
         self._pending = []
+        self.stats["steps"] += 1
 
 
-def broadcast_parameters(module, src=0, process_group=None):
-    """Make every replica start from rank ``src``'s weights and buffers (once, not per step)."""
-    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
-        return
+def broadcast_parameters(module, src=0, process_group=None, force=None):
+    """Make every replica start from rank ``src``'s weights and buffers (once, not per step).  Returns the number of broadcasts issued."""
+    if not dist.is_initialized():
+        return 0
+    if dist.get_world_size(process_group) == 1 and not (_forced() if force is None else force):
+        return 0
+    n = 0
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=process_group)
+        n += 1
+    return n

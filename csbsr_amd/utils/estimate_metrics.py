@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
-from ..engine import _ptr
+from ..engine import _ptr, _reduction_scratch
 
 
 def _stream(t):
@@ -26,6 +26,7 @@ def psnr_ssim(img1, img2):
     a = _dev32(img1)
     b = _dev32(img2, a)
     B, Cc, H, W = a.shape
+    _reduction_scratch(a.device)         # the sums are an order-fixed fold of per-workgroup partial rows (csrc/common.h)
     sums = torch.zeros(B, 2, dtype=torch.float32, device=a.device)
     ps, ss = torch.empty(B, dtype=torch.float32, device=a.device), torch.empty(B, dtype=torch.float32, device=a.device)
     L.call("csbsr_psnr_ssim", _ptr(a), _ptr(b), B, Cc, H, W, _ptr(sums), _ptr(ps), _ptr(ss), _stream(a))

@@ -57,6 +57,8 @@ class PathCfg:
         self.sfo_sr_amp = 0.0                # SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP
         self.detector = "PSPNet"             # MODEL.DETECTOR_TYPE: "PSPNet" | "PSPNet_BlurSkip" | "HRNet_OCR"
         self.pixel_shuffle = False           # MODEL.SR_PIXEL_SHUFFLE
+        self.residual_learning = True        # MODEL.SR_RESIDUAL_LEARNING (kbpn.py:32,112-116)
+        self.only_kernel_loss = False        # SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN (sr_loss_functions.py:32,50-51)
         self.__dict__.update(kw)
 
     @property
@@ -242,7 +244,8 @@ def kbpn_forward(P, x, it, kernel_gt, cfg, taps=None):
             if taps is not None:
                 taps[f"s{s}.low"] = low
     sr = conv_block(P, "sr_model.output_conv", concat_h, act=None)
-    sr = sr + bicubic_up(x, scale=cfg.scale)                              # SR_RESIDUAL_LEARNING
+    if cfg.residual_learning:                                             # kbpn.py:112-116
+        sr = sr + bicubic_up(x, scale=cfg.scale)
     return sr, kvec
 
 
@@ -522,6 +525,10 @@ def kbpn_loss(sr, hr, x_lr, kvec, kernel_gt, cfg, seg=None, seg_t=None, it=0):
         w = torch.exp(cfg.sfo_sr_amp * (seg.detach() - seg_t).abs())
         hr_l = w * hr_l
         lr_l = F.interpolate(w, scale_factor=1 / cfg.scale, mode="bilinear") * lr_l
+    if cfg.only_kernel_loss and cfg.kernel_pretrain[0] <= it < cfg.kernel_pretrain[1]:
+        # sr_loss_functions.py:50-51 returns the UNREDUCED kernel MSE map there; trainer.calc_loss takes its mean, which equals the mean of
+        # the per-sample means returned here (one value per sample keeps the (B,) contract of every other phase)
+        return k_l.mean((1, 2, 3)), kpred
     loss = cfg.sr_w[0] * hr_l.mean((1, 2, 3)) + cfg.sr_w[1] * lr_l.mean((1, 2, 3)) + cfg.sr_w[2] * k_l.mean((1, 2, 3))
     return loss, kpred
 

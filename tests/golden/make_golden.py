@@ -120,7 +120,8 @@ def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha
                alpha=np.float64(model.ss_loss_fn.alpha), antialias=np.bool_(antialias), scale=np.int64(scale),
                detector=np.array(detector), sfo_sr_amp=np.float64(cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP),
                oriented_w_iter=np.int64(cfg.SOLVER.ORIENTED_WEIGHT_ITER), beta=np.float64(cfg.SOLVER.TASK_LOSS_WEIGHT),
-               pixel_shuffle=np.bool_(cfg.MODEL.SR_PIXEL_SHUFFLE), torch_version=np.array(torch.__version__))
+               pixel_shuffle=np.bool_(cfg.MODEL.SR_PIXEL_SHUFFLE), torch_version=np.array(torch.__version__),
+               residual_learning=np.bool_(cfg.MODEL.SR_RESIDUAL_LEARNING), only_kernel_loss=np.bool_(cfg.SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN))
     for kname, v in cap.masks.items():
         if v is not None:
             out["dropmask." + kname] = v.numpy()
@@ -134,7 +135,8 @@ def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha
     print(f"{name}: loss={loss.item():.6f} seg={seg_loss.tolist()} sr={sr_loss.tolist()} -> {os.path.getsize(path)/1e3:.0f} kB")
 
 
-def run_case_wc(name, it, B=2, lr=64, scale=4, alpha=0.7, overrides=(), seed=1121, detector="PSPNet", dropout=False, eps=1e-3):
+def run_case_wc(name, it, B=2, lr=64, scale=4, alpha=0.7, overrides=(), seed=1121, detector="PSPNet", dropout=False, eps=1e-3,
+                fill="random"):
     """Fixtures at a well-conditioned size (HR >= 192: BatchNorm over >= 1e3 values per channel even at 1/32 resolution) that let
     the two halves of the path be checked against the reference SEPARATELY, with fixed bounds:
       * sr_preds (full fp32) + segment_preds + BN buffers + detector gradients  -> the detector fed the reference's own SR image;
@@ -142,7 +144,9 @@ def run_case_wc(name, it, B=2, lr=64, scale=4, alpha=0.7, overrides=(), seed=112
         upstream gradient;
     and the reference's own CONDITIONING: the same step re-run with the SR image moved by eps * max|sr| of seeded uniform noise
     (eps = 1e-3 = north_star's tolerance on the SR image), recording how far segment_preds / losses / BN buffers / gradients move.
-    Inputs are regenerated from ``seed`` by csbsr_amd.data.synthetic.make_batch (checksums stored)."""
+    Inputs are regenerated from ``seed`` by csbsr_amd.data.synthetic.make_batch (checksums stored).
+    ``fill``: csbsr_amd.utils.detfill style.  "contractive" (the wc2_* fixtures) gives the detector smooth low-gain filters, so it damps
+    perturbations like a trained network instead of amplifying them ~100x: on those the COMPOSED path is held to tight fixed bounds."""
     ref_shims.ANTIALIAS = True
     cfg, JM, J, FR = ref_shims.build_reference(detector=detector, scale=scale, overrides=overrides)
     x, hr, mask, k = make_batch(B, lr, scale=scale, ksize=cfg.BLUR.KERNEL_SIZE_OUTPUT, seed=seed)
@@ -151,7 +155,7 @@ def run_case_wc(name, it, B=2, lr=64, scale=4, alpha=0.7, overrides=(), seed=112
 
     def one_pass(perturb_eps):
         model = JM(cfg, 1000, 0, FR(scale, "bicubic"))
-        deterministic_fill(model)
+        deterministic_fill(model, fill)
         model.train()
         model.ss_loss_fn.alpha = alpha
         cap_d = DropCapture(dropout, keys=("ocr_drop",) if detector == "HRNet_OCR" else None)
@@ -218,7 +222,7 @@ def run_case_wc(name, it, B=2, lr=64, scale=4, alpha=0.7, overrides=(), seed=112
                alpha=np.float64(a["alpha"]), antialias=np.bool_(True), scale=np.int64(scale),
                detector=np.array(detector), sfo_sr_amp=np.float64(cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP),
                oriented_w_iter=np.int64(cfg.SOLVER.ORIENTED_WEIGHT_ITER), beta=np.float64(cfg.SOLVER.TASK_LOSS_WEIGHT),
-               torch_version=np.array(torch.__version__),
+               torch_version=np.array(torch.__version__), fill=np.array(fill), pixel_shuffle=np.bool_(cfg.MODEL.SR_PIXEL_SHUFFLE),
                # the reference's own response to an SR image moved by eps * max|sr| (uniform noise)
                cond_eps=np.float64(eps), cond_seg_max=np.float64(mx(b["seg"], a["seg"])), cond_seg_l2=np.float64(rl2(b["seg"], a["seg"])),
                cond_segloss=np.float64(mx(b["seg_loss"], a["seg_loss"])),
@@ -239,6 +243,78 @@ def run_case_wc(name, it, B=2, lr=64, scale=4, alpha=0.7, overrides=(), seed=112
           f"{out['cond_segloss']:.2e} bn {out['cond_bn']:.2e} grads median {out['cond_grad_median']:.2e} p90 {out['cond_grad_p90']:.2e}"
           f" -> {os.path.getsize(path)/1e6:.2f} MB")
 
+
+
+def run_trajectory(name, steps=12, it0=40000, B=2, lr=64, scale=4, detector="PSPNet", overrides=(), seed0=2100, fill="contractive",
+                   lr_rate=None):
+    """``steps`` consecutive optimiser steps of the reference's training loop in the JOINT phase (trainer.py:57-72: zero_grad, forward,
+    calc_loss, backward, Adam step -- train.py:91 hyper-parameters -- and the alpha schedule of trainer.py:495-508), a fresh synthetic batch
+    per step (seed0 + step), Dropout2d masks seeded and recorded.  Stored per step: the two per-sample loss vectors, the scalar loss, alpha,
+    the gradient L2 norm per gradient bucket (segmentation net, KBPN stage 1..S, KBPN head) and the L2 distance the parameters have
+    moved from the start; plus a checksum of the final weights.  The HIP path must reproduce the CURVE (tests/test_trajectory_gpu.py)."""
+    ref_shims.ANTIALIAS = True
+    cfg, JM, J, FR = ref_shims.build_reference(detector=detector, scale=scale, overrides=overrides)
+    from model.engine.trainer import calc_loss
+    import argparse
+    model = JM(cfg, 1000, 0, FR(scale, "bicubic"))
+    deterministic_fill(model, fill)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=float(cfg.SOLVER.LR) if lr_rate is None else lr_rate, betas=(0.9, 0.999), eps=1e-8)
+    start = {n: p.detach().clone() for n, p in model.named_parameters()}
+    S = cfg.MODEL.NUM_STAGES
+
+    def bucket(n):
+        if n.startswith("segmentation_model"):
+            return 0
+        if n.startswith("sr_model.back_projection_stages."):
+            return int(n.split(".")[2]) + 1
+        if n.startswith("sr_model.output_conv"):
+            return S
+        return S + 1
+    rec = dict(seg_loss=[], sr_loss=[], loss=[], alpha=[], gnorm=[], moved=[])
+    masks_all = {}
+    orig = nn.Dropout2d.forward
+    for step in range(steps):
+        it = it0 + step
+        model.ss_loss_fn.fix_alpha = False            # trainer.py:501-508 (not the SR-pretrain phase)
+        model.ss_loss_fn.update_alpha()
+        x, hr, mask, k = make_batch(B, lr, scale=scale, ksize=cfg.BLUR.KERNEL_SIZE_OUTPUT, seed=seed0 + step)
+        cap = DropCapture(True, seed=7 + step, keys=("ocr_drop",) if detector == "HRNet_OCR" else None)
+        nn.Dropout2d.forward = lambda self, x_: cap(self, x_)
+        try:
+            opt.zero_grad()
+            seg_loss, sr_loss, seg, sr, kpred = model(it, x, sr_targets=hr, segment_targets=mask, kernel_targets=k)
+            loss, _, _ = calc_loss(seg_loss, 0.0, sr_loss, 0.0, it, cfg, argparse.Namespace())
+            loss.backward()
+        finally:
+            nn.Dropout2d.forward = orig
+        gn = np.zeros(S + 2)
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                gn[bucket(n)] += float(p.grad.double().pow(2).sum())
+        opt.step()
+        mv = np.sqrt(sum(float((p.detach() - start[n]).double().pow(2).sum()) for n, p in model.named_parameters()))
+        rec["seg_loss"].append(seg_loss.detach().numpy().copy()); rec["sr_loss"].append(sr_loss.detach().numpy().copy())
+        rec["loss"].append(float(loss)); rec["alpha"].append(float(model.ss_loss_fn.alpha)); rec["gnorm"].append(np.sqrt(gn)); rec["moved"].append(mv)
+        for kname, v in cap.masks.items():
+            if v is not None:
+                masks_all[f"dropmask.{step}.{kname}"] = v.numpy()
+        print(f"  {name} step {step}: loss {float(loss):.6f} seg {seg_loss.mean():.6f} sr {sr_loss.mean():.6f} alpha {model.ss_loss_fn.alpha:.3f} "
+              f"|g| {np.sqrt(gn).round(5).tolist()} moved {mv:.5f}", flush=True)
+    final = {n: p.detach() for n, p in model.named_parameters()}
+    names = list(final)
+    out = dict(steps=np.int64(steps), it0=np.int64(it0), B=np.int64(B), lr=np.int64(lr), scale=np.int64(scale), seed0=np.int64(seed0),
+               detector=np.array(detector), fill=np.array(fill), lr_rate=np.float64(opt.param_groups[0]["lr"]), beta=np.float64(cfg.SOLVER.TASK_LOSS_WEIGHT),
+               antialias=np.bool_(True), sfo_sr_amp=np.float64(cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP),
+               oriented_w_iter=np.int64(cfg.SOLVER.ORIENTED_WEIGHT_ITER),
+               seg_loss=np.stack(rec["seg_loss"]), sr_loss=np.stack(rec["sr_loss"]), loss=np.array(rec["loss"]), alpha=np.array(rec["alpha"]),
+               gnorm=np.stack(rec["gnorm"]), moved=np.array(rec["moved"]), torch_version=np.array(torch.__version__),
+               final_names=np.array(names), final_delta_norm=np.array([float((final[n] - start[n]).double().norm()) for n in names]),
+               final_delta_dot=np.array([float(((final[n] - start[n]).double() * torch.sign(final[n] - start[n]).double()).sum()) for n in names]))
+    out.update(masks_all)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {steps} steps -> {os.path.getsize(path)/1e3:.0f} kB")
 
 
 def aux_cases():
@@ -331,6 +407,22 @@ if __name__ == "__main__":
     if "--aux" in sys.argv:
         aux_cases()
         sys.exit(0)
+    if "--wc2" in sys.argv:         # well-conditioned size AND a contractive detector fill: the composed path under tight fixed bounds
+        only = [a for a in sys.argv[1:] if not a.startswith("--")]
+        todo = {
+            "wc2_pspnet_it40000": lambda n: run_case_wc(n, 40000, B=2, lr=64, fill="contractive"),
+            "wc2_blurskip_x8_it40000": lambda n: run_case_wc(n, 40000, B=2, lr=32, scale=8, alpha=0.8, detector="PSPNet_BlurSkip", seed=9, fill="contractive",
+                                                              overrides=("SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP", 1.0, "SOLVER.ORIENTED_WEIGHT_ITER", 0)),
+            "wc2_hrnet_ocr_it40000": lambda n: run_case_wc(n, 40000, B=4, lr=48, alpha=0.8, detector="HRNet_OCR", seed=13, dropout=True, fill="contractive",
+                                                            overrides=("SOLVER.TASK_LOSS_WEIGHT", 0.9)),
+            "wc2_pspnet_pixelshuffle_it40000": lambda n: run_case_wc(n, 40000, B=2, lr=64, seed=17, fill="contractive",
+                                                                      overrides=("MODEL.SR_PIXEL_SHUFFLE", True)),
+            "traj_pspnet_it40000": lambda n: run_trajectory(n, steps=12, lr=64, B=2),
+        }
+        for n, fn in todo.items():
+            if not only or n in only:
+                fn(n)
+        sys.exit(0)
     if "--wc" in sys.argv:          # the well-conditioned-size fixtures only (minutes of CPU each)
         run_case_wc("wc_pspnet_it40000", 40000, B=2, lr=64)
         run_case_wc("wc_blurskip_x8_it40000", 40000, B=2, lr=32, scale=8, alpha=0.8, detector="PSPNet_BlurSkip", seed=9,
@@ -356,3 +448,7 @@ if __name__ == "__main__":
     # config 2 with the w^F weight on (README row 'CSBSR w/ PSPNet + w^F')
     run_case("e2e_pspnet_wf_it40000", 40000, alpha=0.7, seed=11,
              overrides=("SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP", 1.0, "SOLVER.ORIENTED_WEIGHT_ITER", 0))
+    # cfg variants of the KBPN path: no bicubic residual (kbpn.py:112-116); kernel-MSE-only loss in the kernel pretraining phase
+    # (sr_loss_functions.py:50-51, with a non-zero kernel weight in the other phases)
+    run_case("e2e_pspnet_noresidual_it40000", 40000, alpha=0.7, seed=19, overrides=("MODEL.SR_RESIDUAL_LEARNING", False))
+    run_case("e2e_pspnet_konly_it10001", 10001, seed=23, overrides=("SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN", True))

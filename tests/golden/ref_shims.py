@@ -147,6 +147,8 @@ def install():
 
     class _Any(types.ModuleType):
         def __getattr__(self, k):
+            if k.startswith("__"):          # dunder probes (inspect.getmodule walks sys.modules reading __file__): behave like a module
+                raise AttributeError(k)
             return 0
     sys.modules["cv2"] = _Any("cv2")
     _mod("wandb")

@@ -30,12 +30,19 @@ def golden_cfg(g):
         kw.update(beta=float(g["beta"]))
     if "pixel_shuffle" in g:
         kw.update(pixel_shuffle=bool(g["pixel_shuffle"]))
+    if "residual_learning" in g:
+        kw.update(residual_learning=bool(g["residual_learning"]), only_kernel_loss=bool(g["only_kernel_loss"]))
     return O.PathCfg(**kw)
 
 
-def det_params(scale=4, num_stages=4, detector="PSPNet", requires_grad=True, pixel_shuffle=False):
+def fill_style(g):
+    """detfill style a fixture was generated with (fixtures older than the contractive fill carry no key)."""
+    return str(g["fill"]) if "fill" in g else "random"
+
+
+def det_params(scale=4, num_stages=4, detector="PSPNet", requires_grad=True, pixel_shuffle=False, style="random"):
     shapes = joint_state_shapes(scale=scale, num_stages=num_stages, detector=detector, pixel_shuffle=pixel_shuffle)
-    sd = det_state_dict(shapes)
+    sd = det_state_dict(shapes, style)
     if requires_grad:
         for k, v in sd.items():
             if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):

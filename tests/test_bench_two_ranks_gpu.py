@@ -27,9 +27,11 @@ def test_bench_two_ranks_one_device():
 
 
 def test_bench_rccl_backend_one_rank():
-    """The same N > 1 code path with the REAL backend: `nccl` (= RCCL on ROCm) with world size 1 on the one GPU of the test box
-    (CSBSR_FORCE_DIST=1): process-group init with device_id, parameter broadcast, flat-bucket all-reduces on the side stream launched
-    from inside the backward, barrier, MAX all-reduce of the step time.  What a one-GPU box cannot show is only the transfer itself."""
+    """The same N > 1 code path with the REAL backend: `nccl` (= RCCL on ROCm) with world size 1 on the one GPU of the test box.
+    CSBSR_FORCE_DIST=1 makes the reducer and the parameter broadcast ISSUE their collectives in a one-rank group (they return early
+    otherwise): process-group init with device_id, one broadcast per parameter / buffer, per step the six flat-bucket all-reduces
+    (segmentation net, KBPN stages 4..1, KBPN head) on the side stream launched from inside the backward, barrier, MAX all-reduce of
+    the step time.  What a one-GPU box cannot show is only the transfer between GPUs."""
     env = dict(os.environ, CSBSR_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("CSBSR_DIST_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
@@ -41,3 +43,48 @@ def test_bench_rccl_backend_one_rank():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["loss"] == d["loss"]
+    r = d["reducer"]
+    assert r["backend"] == "nccl" and r["steps"] == 3                       # 1 warmup + 2 timed steps
+    assert r["all_reduces"] == 6 * r["steps"] and r["on_side_stream"] == r["all_reduces"], r
+    assert r["bytes"] == r["steps"] * 4 * 89_249_704, r      # every trainable parameter of KBPN x4 + PSPNet, fp32, once per step
+    assert r["broadcasts"] == 410                           # 290 parameters + 120 BatchNorm buffers
+
+
+def test_forced_rccl_all_reduce_leaves_gradients_bit_identical():
+    """One-rank `nccl` group in this process: a step with the forced reducer (six in-place all-reduces of the flat gradient buckets on the
+    side stream, launched from inside the backward) must give exactly the gradients of the undistributed step -- the path is
+    bit-reproducible (tests/test_determinism_gpu.py), so ANY corruption by the exchange (a bucket reduced before its last writer, a
+    missing stream wait, a wrong view) shows as a bit difference."""
+    import torch
+    import torch.distributed as dist
+    from golden_utils import load_golden
+    from test_joint_gpu import build_model
+    from csbsr_amd.parallel import GradBucketReducer
+    g = load_golden("e2e_pspnet_it40000")
+    t = lambda k: torch.from_numpy(g[k])
+
+    def step(m):
+        for p in m.parameters():
+            p.grad = None
+        seg_l, sr_l, _, _, _ = m(40000, t("x"), sr_targets=t("hr"), segment_targets=t("mask"), kernel_targets=t("kernel"))
+        (0.7 * sr_l.mean() + 0.3 * seg_l.mean()).backward()
+        torch.cuda.synchronize()
+        return {k: v.grad.detach().clone() for k, v in m._named_full() if isinstance(v, torch.nn.Parameter) and v.grad is not None}
+    m, _ = build_model(g, micro_batch=1)        # two micro-batches: the stage buckets are launched under the LAST one's backward
+    m.max_resident = 8
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    base = step(m)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        m.load_state_dict(sd0)
+        m.reducer = GradBucketReducer(side_stream=torch.cuda.Stream(torch.device("cuda:0")), force=True)
+        got = step(m)
+        st = dict(m.reducer.stats)
+    finally:
+        m.reducer = None
+        dist.destroy_process_group()
+    assert st["all_reduces"] == 6 and st["on_side_stream"] == 6 and st["steps"] == 1, st
+    assert set(got) == set(base) and len(base) == 290
+    bad = [k for k in base if not torch.equal(base[k], got[k])]
+    assert not bad, bad[:5]

@@ -146,6 +146,33 @@ def test_unsupported_variants_fail_loudly():
     c.SOLVER.SEG_LOSS_FUNC = "Dice"
     with pytest.raises(NotImplementedError):
         JointModelWithLoss(c, 1000, 0, None)
+    # every cfg key the path consumes is either honoured or refused -- never silently ignored
+    for key, val in (("MODEL.ZERO_PAD_KERNEL", True), ("MODEL.NUM_CLASSES", 2), ("MODEL.SUM_LR_ERROR_POS", "LR"), ("MODEL.KBPN_KERNEL_SFT", False),
+                     ("MODEL.SR_SEG_INV", True), ("MODEL.JOINT_LEARNING", False), ("SOLVER.INTERM_SSLOSSWEGHT4SR", True),
+                     ("SOLVER.CRACK_ORIENTED_WEIGHT4SR_AMP", 1.0), ("SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SS_AMP", 1.0), ("MODEL.SR", "DBPN")):
+        c = cfg.clone()
+        c.merge_from_list([key, val])
+        with pytest.raises(NotImplementedError):
+            JointModelWithLoss(c, 1000, 0, None)
+    # ... and the honoured ones reach the flat path configuration the kernels read
+    c = cfg.clone()
+    c.merge_from_list(["MODEL.SR_RESIDUAL_LEARNING", False, "SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN", True, "MODEL.SR_PIXEL_SHUFFLE", True])
+    m = JointModelWithLoss(c, 1000, 0, None)
+    assert m.pc.residual_learning is False and m.pc.only_kernel_loss is True and m.pc.pixel_shuffle is True
+
+
+def test_up_down_scheduler_matches_the_reference_rule():
+    """lr_scheduler.py:31-42 as used by train.py:95-96 (LambdaLR multiplier)."""
+    from csbsr_amd.utils.lr_scheduler import UpDownScheduler
+    s = UpDownScheduler(30001, 0, True)
+    assert [s(i) for i in (0, 30000, 100000, 100001, 124999, 125000, 200000)] == [1, 1, 1, 10, 10, 1, 1]
+    assert UpDownScheduler(30001, 0, False)(110000) == 1
+    r = UpDownScheduler(30001, 100000, True)          # resumed at iteration 100000: LambdaLR restarts its counter
+    assert [r(i) for i in (0, 1, 24999, 25000)] == [1, 10, 10, 1]
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=2e-5)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=UpDownScheduler(2, 70001, True))
+    opt.step(); sch.step()
+    assert abs(opt.param_groups[0]["lr"] - 2e-4) < 1e-12
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")

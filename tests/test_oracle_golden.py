@@ -4,12 +4,13 @@ import numpy as np
 import pytest
 import torch
 
-from golden_utils import load_golden, det_params, rel_err, sample_idx, golden_cfg
+from golden_utils import load_golden, det_params, rel_err, sample_idx, golden_cfg, fill_style
 from oracle import csbsr_oracle as O
 
 CASES = ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "e2e_pspnet_it10001",
          "e2e_pspnet_it20001", "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24",
-         "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000", "e2e_pspnet_pixelshuffle_it20001"]
+         "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000", "e2e_pspnet_pixelshuffle_it20001",
+         "e2e_pspnet_noresidual_it40000", "e2e_pspnet_konly_it10001"]
 
 # fp32 CPU vs fp32 CPU, same torch build: differences come only from op ordering (grouped conv vs the
 # reference's per-sample loop, vector kernel vs expanded map)
@@ -80,6 +81,36 @@ def test_oracle_matches_reference_outputs_and_grads(case):
         n_checked += 1
     blurskip = "detector" in g and str(g["detector"]) == "PSPNet_BlurSkip"
     assert n_checked >= (26 if blurskip else 1000 if hrnet else 150 if int(g["it"]) >= 30001 else 20)
+
+
+def test_oracle_matches_reference_with_the_contractive_fill():
+    """wc2_pspnet_it40000 (HR 256, B 2, detfill style "contractive"): pins the second fill rule -- the oracle regenerates the weights from
+    names + shapes, the fixture was produced by the reference's own modules filled through the same rule -- and the oracle at a size where
+    every BatchNorm sees >= 1e3 values per channel."""
+    import zlib
+    from csbsr_amd.data.synthetic import make_batch
+    g = load_golden("wc2_pspnet_it40000")
+    assert fill_style(g) == "contractive"
+    cfg = golden_cfg(g)
+    x, hr, mask, k = make_batch(int(g["B"]), int(g["lr"]), scale=cfg.scale, ksize=21, seed=int(g["seed"]))
+    assert np.allclose(x.numpy(), g["x"], atol=1e-5)
+    P = det_params(scale=cfg.scale, detector=cfg.detector, style="contractive")
+    out = O.joint_forward(P, cfg, int(g["it"]), torch.from_numpy(g["x"]), hr, mask, torch.from_numpy(g["kernel"]), alpha=float(g["alpha"]))
+    loss = O.calc_loss(out["segment_loss"], out["sr_loss"], int(g["it"]), cfg)
+    loss.backward()
+    for kk in ("segment_loss", "sr_loss", "segment_preds", "sr_preds", "kernel_preds"):
+        assert rel_err(out[kk].detach(), g[kk]) < TOL_OUT, kk
+    errs = []
+    for n, ref_norm, smp in zip((str(v) for v in g["grad_names"]), g["grad_norms"], g["grad_samples32"]):
+        gr = P[n].grad
+        if ref_norm < 1e-7 or gr is None or gr.numel() == 1:
+            continue
+        flat = gr.reshape(-1)
+        idx = [(zlib.crc32((n + str(j)).encode()) % flat.numel()) for j in range(32)]
+        errs.append(max(abs(float(flat.double().norm()) - ref_norm) / ref_norm,
+                        float(np.sqrt(np.mean((flat[idx].double().numpy() - smp.astype(np.float64)) ** 2)) / (ref_norm / np.sqrt(flat.numel())))))
+    errs = np.array(errs)
+    assert len(errs) > 200 and np.median(errs) < 2e-3 and errs.max() < TOL_GRAD, (np.median(errs), errs.max())
 
 
 def _frozen_in_phase(name, it, detector="PSPNet"):
