@@ -32,7 +32,7 @@ class ConvDesc(C.Structure):
                 ("res2", vp), ("r2_sn", i64), ("r2_sy", i64), ("r2_sx", i64),
                 ("accumulate", i32), ("stat_mode", i32), ("stat", vp), ("out_scale", f32),
                 ("o_lo", i64), ("r_lo", i64), ("r2_lo", i64),
-                ("mask", vp), ("m_sn", i64), ("m_sy", i64), ("m_sx", i64), ("mask_slope", f32), ("_pad_mask", i32),
+                ("mask", vp), ("m_sn", i64), ("m_sy", i64), ("m_sx", i64), ("mask_slope", f32), ("cbias_mode", i32),
                 ("mask_prelu", vp), ("dact_bias", vp), ("dact_prelu", vp),
                 ("dres", vp), ("dr_sn", i64), ("dr_sy", i64), ("dr_sx", i64)]
 
@@ -113,6 +113,7 @@ SIGNATURES = {
     "csbsr_border_class_fill": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
     "csbsr_border_class_fill_masked": (i32, [vp, vp, i64, vp, i64, C.c_float, i32, i32, i32, i32, vp]),
     "csbsr_border_class_sums": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
+    "csbsr_ring_class_sums": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
     "csbsr_bn_finalize": (i32, [vp, i64, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
     "csbsr_bn_apply": (i32, [C.POINTER(BnDesc), vp]),
     "csbsr_bn_backward": (i32, [C.POINTER(BnDesc), vp]),

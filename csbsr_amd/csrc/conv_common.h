@@ -16,7 +16,8 @@ struct ConvK {
   half_t* out16; long o_sn, o_sy, o_sx;
   float* out32; long o32_sn, o32_sy, o32_sx, o32_sc;
   const float* bias;
-  const float* cbias;        // optional [N][16][coutp]: bias per (sample, border class of the output pixel) -- folded constant segment
+  const float* cbias;        // optional [N][16 | 25][coutp]: bias per (sample, position class of the output pixel) -- folded constant segment
+  int cb_mode;               // 0: 16 border classes, 1: 25 two-ring classes (csbsr_conv_desc_t::cbias_mode)
   int act; float act_slope; const float* prelu;
   int res_mode; const half_t* res; long r_sn, r_sy, r_sx;
   const half_t* res2; long r2_sn, r2_sy, r2_sx;
@@ -77,8 +78,13 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
                                                   int ox, float (&ssum)[8], float (&ssq)[8], const EpiPre* pre = nullptr) {
   const float* cb = nullptr;
   if (p.cbias) {
-    const int cls = (oy == 0) * 8 + (oy == p.OH - 1) * 4 + (ox == 0) * 2 + (ox == p.OW - 1);
-    cb = p.cbias + ((size_t)n * 16 + cls) * p.coutp + co;
+    if (p.cb_mode == 0) {
+      const int cls = (oy == 0) * 8 + (oy == p.OH - 1) * 4 + (ox == 0) * 2 + (ox == p.OW - 1);
+      cb = p.cbias + ((size_t)n * 16 + cls) * p.coutp + co;
+    } else {
+      const int ty = oy < 2 ? oy : (oy >= p.OH - 2 ? oy - p.OH + 5 : 2), tx = ox < 2 ? ox : (ox >= p.OW - 2 ? ox - p.OW + 5 : 2);
+      cb = p.cbias + ((size_t)n * 25 + ty * 5 + tx) * p.coutp + co;
+    }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {

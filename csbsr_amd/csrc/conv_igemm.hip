@@ -408,7 +408,8 @@ int conv_desc_to_k(const csbsr_conv_desc_t* d, ConvK& k) {
   CSBSR_CHECK(d->out16 || d->out32 || d->stat_mode != CSBSR_STAT_NONE, "conv: no output requested");
   CSBSR_CHECK(d->stride >= 1 && d->KH >= 1 && d->KW >= 1, "conv: bad geometry");
   CSBSR_CHECK(!d->transposed || d->dil == 1, "conv: transposed conv supports dilation 1 only");
-  CSBSR_CHECK(!d->cbias || (!d->transposed && d->stride == 1), "conv: border-class bias needs a stride-1 convolution");
+  CSBSR_CHECK(!d->cbias || (!d->transposed && d->stride == 1), "conv: a position-class bias needs a stride-1 convolution");
+  CSBSR_CHECK(!d->cbias || d->cbias_mode == 0 || (d->cbias_mode == 1 && d->OH >= 5 && d->OW >= 5), "conv: cbias_mode 1 needs OH, OW >= 5");
   CSBSR_CHECK(d->act != CSBSR_ACT_PRELU || d->prelu, "conv: PReLU needs a slope pointer");
   CSBSR_CHECK(d->res_mode == CSBSR_RES_NONE || d->res, "conv: res_mode set without res");
   k.in[0] = d->in[0]; k.in[1] = d->in[1];
@@ -425,7 +426,7 @@ int conv_desc_to_k(const csbsr_conv_desc_t* d, ConvK& k) {
   k.cout = d->cout; k.coutp = d->coutp;
   k.out16 = reinterpret_cast<half_t*>(d->out16); k.o_sn = d->o_sn; k.o_sy = d->o_sy; k.o_sx = d->o_sx;
   k.out32 = d->out32; k.o32_sn = d->o32_sn; k.o32_sy = d->o32_sy; k.o32_sx = d->o32_sx; k.o32_sc = d->o32_sc;
-  k.bias = d->bias; k.cbias = d->cbias; k.act = d->act; k.act_slope = d->act_slope; k.prelu = d->prelu;
+  k.bias = d->bias; k.cbias = d->cbias; k.cb_mode = d->cbias_mode; k.act = d->act; k.act_slope = d->act_slope; k.prelu = d->prelu;
   k.res_mode = d->res_mode; k.res = reinterpret_cast<const half_t*>(d->res);
   k.r_sn = d->r_sn; k.r_sy = d->r_sy; k.r_sx = d->r_sx;
   k.res2 = reinterpret_cast<const half_t*>(d->res2); k.r2_sn = d->r2_sn; k.r2_sy = d->r2_sy; k.r2_sx = d->r2_sx;

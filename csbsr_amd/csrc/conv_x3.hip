@@ -50,7 +50,9 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_make_rs(const half_t
 }
 #endif
 
-template <int KS>
+// ABL (builds with -DCSBSR_X3_ABLATE only; timing experiments, results are garbage): 1 halo DMA pieces fetch nothing (out-of-range
+// offsets), 2 every K step loads the weights of step 0, 4 no LDS fragment reads in the K loop, 8 no weight loads in the K loop
+template <int KS, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Extra q, const half_t* __restrict__ zero_page) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int X3_HW = X3_TW + KS - 1, X3_HH = X3_TH + KS - 1;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
     return in0 + n * p.in[0].sn + (long)by * p.in[0].sy + (long)bx * p.in[0].sx + coff;
   };
   auto issue_one = [&](__amdgpu_buffer_rsrc_t rs, int by, int bx, int i, int buf) __attribute__((always_inline)) {
-    const bool ok = (unsigned)(iy0[i] + by) < (unsigned)p.H && (unsigned)(ix0[i] + bx) < (unsigned)p.W;
+    const bool ok = !(ABL & 1) && (unsigned)(iy0[i] + by) < (unsigned)p.H && (unsigned)(ix0[i] + bx) < (unsigned)p.W;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + buf * X3_BUF + (wid + 4 * i) * 1024), 16,
                                              ok ? voff[i] : -1, 0, 0, 0);
   };
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
   const int mh = wid & 1, rq = wid >> 1;
   const unsigned wlane = (unsigned)(mh * 8192 + lane * 16);
   auto load_w = [&](int ct, int step, h8 (&w)[2][4]) __attribute__((always_inline)) {
+    if (ABL & 2) step = 0;
     const char* b = reinterpret_cast<const char*>(p.wt) + ((size_t)ct * q.nch * NT + step) * X3_WSTEP;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -188,7 +191,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
         // weights DIST K steps ahead (past the tile's last step: the next tile's first ones)
         {
           const int g = c * NT + tap + DIST;
-          if (g < nsteps) load_w(ct, g, wreg[(tap + DIST) % RING]);
+          if (ABL & 8) {}
+          else if (g < nsteps) load_w(ct, g, wreg[(tap + DIST) % RING]);
           else load_w(ctn, g - nsteps, wreg[(tap + DIST) % RING]);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -200,7 +204,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
             acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap % RING][0][kk], bfr[i], acc[0][i], 0, 0, 0);
             acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap % RING][1][kk], bfr[i], acc[1][i], 0, 0, 0);
             // the same row's fragment of the next k-slice / next tap (the next chunk starts over after its barrier)
-            if (kk < 3) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + ky) * X3_HW + kx) * X3_PITCH + (kk + 1) * 32);
+            if (ABL & 4) {}
+            else if (kk < 3) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + ky) * X3_HW + kx) * X3_PITCH + (kk + 1) * 32);
             else if (tap < NT - 1) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + (tap + 1) / KS) * X3_HW + (tap + 1) % KS) * X3_PITCH);
             if (i == 1 && tap * 4 + kk < NFI) issue_one(nrs, nby, nbx, tap * 4 + kk, bnext);       // one DMA piece per k-slice
             __builtin_amdgcn_sched_barrier(0);
@@ -317,7 +322,8 @@ extern "C" int csbsr_pack_weights_x3_strided(const float* w, void* dst, int32_t 
 }
 
 static int g_conv_x3_mode = 1;      // 0 off, 1 launches that fill the chip, 2 every eligible launch (tests)
-extern "C" void csbsr_debug_set_conv_x3(int mode) { g_conv_x3_mode = mode; }
+static int g_conv_x3_abl = 0;       // bits 4.. of the debug mode: ablation variant of the 3x3 kernel (CSBSR_X3_ABLATE builds)
+extern "C" void csbsr_debug_set_conv_x3(int mode) { g_conv_x3_mode = mode & 15; g_conv_x3_abl = mode >> 4; }
 
 // Which launches take this kernel.  3x3, stride 1, pad 1, dilation 1: ONE plain-fp16 input segment whose padded channels are a multiple of
 // 64, >= 384 by default (measured at N = 4, 448^2, with the halo DMA issued inside the K loop: 825 -> 384 1041 TF/s against 899 for the
@@ -350,12 +356,12 @@ extern "C" int32_t csbsr_conv_x3_eligible(const csbsr_conv_desc_t* d) {
 
 static half_t* g_x3_zero_page[CSBSR_MAX_DEVICES] = {};
 
-template <int KS>
+template <int KS, int ABL = 0>
 static int launch_x3(const ConvK& k, const X3Extra& q, unsigned g, const half_t* zp, hipStream_t st) {
   constexpr int SM_BYTES = 2 * x3_buf(KS);
   static LdsAttrOnce attr;
-  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_x3_kernel<KS>), SM_BYTES, "conv_x3")) return e;
-  hipLaunchKernelGGL(conv_x3_kernel<KS>, dim3(g), dim3(256), SM_BYTES, st, k, q, zp);
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_x3_kernel<KS, ABL>), SM_BYTES, "conv_x3")) return e;
+  hipLaunchKernelGGL((conv_x3_kernel<KS, ABL>), dim3(g), dim3(256), SM_BYTES, st, k, q, zp);
   CSBSR_LAUNCH_CHECK("csbsr_conv_x3_forward");
   return 0;
 }
@@ -379,6 +385,22 @@ extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   const unsigned items = q.tiles_x * q.tiles_y * (unsigned)d->N * q.nct;
   const unsigned g = items < (unsigned)ncu ? items : (unsigned)ncu;
   g_last_conv_kernel = strided ? CONVK_X3S : CONVK_X3;
+#ifdef CSBSR_X3_ABLATE
+  if (!strided) {
+    hipStream_t st_ = reinterpret_cast<hipStream_t>(s);
+    switch (g_conv_x3_abl) {
+      case 1: return launch_x3<3, 1>(k, q, g, g_x3_zero_page[dev], st_);
+      case 2: return launch_x3<3, 2>(k, q, g, g_x3_zero_page[dev], st_);
+      case 4: return launch_x3<3, 4>(k, q, g, g_x3_zero_page[dev], st_);
+      case 8: return launch_x3<3, 8>(k, q, g, g_x3_zero_page[dev], st_);
+      case 5: return launch_x3<3, 5>(k, q, g, g_x3_zero_page[dev], st_);
+      case 9: return launch_x3<3, 9>(k, q, g, g_x3_zero_page[dev], st_);
+      case 12: return launch_x3<3, 12>(k, q, g, g_x3_zero_page[dev], st_);
+      case 13: return launch_x3<3, 13>(k, q, g, g_x3_zero_page[dev], st_);
+      default: break;
+    }
+  }
+#endif
   return strided ? launch_x3<2>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s))
                  : launch_x3<3>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s));
 }

@@ -1398,3 +1398,93 @@ extern "C" int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, i
   CSBSR_LAUNCH_CHECK("csbsr_border_class_sums");
   return 0;
 }
+
+// ---- two-ring classes (csbsr_ring_class_sums): class = ty * 5 + tx, t = 0, 1, 2, 3, 4 for coordinate 0, 1, interior, size-2, size-1.
+// Lines: the four special rows (full width, binned by column type) and the four special columns restricted to the interior rows
+// (one class each).  grid = N * 8 lines * channel groups * BCS_SEG segments; partial rows part[((n * 8 + line) * SEG + seg)][5][c].
+__global__ __launch_bounds__(256) void rcs_lines_kernel(const half_t* x, long ld, float* part, int H, int W, int c8) {
+  __shared__ float sbin[8][5][32][8];
+  const int groups = (c8 + 31) / 32;
+  int b = blockIdx.x;
+  const int seg = b % BCS_SEG; b /= BCS_SEG;
+  const int g = b % groups; b /= groups;
+  const int line = b % 8; const int n = b / 8;
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int cc = g * 32 + cl;
+  const bool is_row = line < 4;
+  const int coord = (line & 3) < 2 ? (line & 3) : ((is_row ? H : W) - 4 + (line & 3));      // 0, 1, size-2, size-1
+  const int lo = is_row ? 0 : 2, hi = is_row ? W : H - 2;                                    // columns: interior rows only
+  float a[5][8];
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[k][e] = 0.f;
+  const int len = hi - lo;
+  const int i0 = lo + (int)((long)len * seg / BCS_SEG), i1 = lo + (int)((long)len * (seg + 1) / BCS_SEG);
+  if (cc < c8)
+    for (int i = i0 + pl; i < i1; i += 8) {
+      const int y = is_row ? coord : i, xx = is_row ? i : coord;
+      const h8 v = *reinterpret_cast<const h8*>(x + (((long)n * H + y) * W + xx) * ld + cc * 8);
+      const int k = is_row ? (xx < 2 ? xx : (xx >= W - 2 ? xx - W + 5 : 2)) : 2;
+#pragma unroll
+      for (int kk = 0; kk < 5; ++kk)
+        if (kk == k) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[kk][e] += (float)v[e];
+        }
+    }
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sbin[pl][k][cl][e] = a[k][e];
+  __syncthreads();
+  if (pl == 0 && cc < c8) {
+    float* row = part + (((long)n * 8 + line) * BCS_SEG + seg) * 5 * c8 * 8;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += sbin[q][k][cl][e];
+        row[(long)k * c8 * 8 + cc * 8 + e] = t;
+      }
+  }
+}
+// sums[n][ty*5+tx][ch] += ...: special rows from their lines, special columns (interior rows) from theirs, the interior class =
+// total (already in class 12 from the fold of bcs_total_kernel's rows) minus the 24 others -- every sum in a fixed order
+__global__ void rcs_finish_kernel(const float* part, float* sums, int N, int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * c) return;
+  const int n = i / c, ch = i % c;
+  float* S = sums + (long)n * 25 * c + ch;
+  float others = 0.f;
+  for (int line = 0; line < 8; ++line) {
+    const int t = (line & 3) < 2 ? (line & 3) : (line & 3) + 1;      // 0, 1, 3, 4
+    for (int k = 0; k < 5; ++k) {
+      if (line >= 4 && k != 2) continue;
+      float v = 0.f;
+      for (int seg = 0; seg < BCS_SEG; ++seg) v += part[((((long)n * 8 + line) * BCS_SEG + seg) * 5 + k) * c + ch];
+      const int cls = line < 4 ? t * 5 + k : 2 * 5 + t;
+      S[(long)cls * c] += v;
+      others += v;
+    }
+  }
+  S[12l * c] -= others;
+}
+extern "C" int csbsr_ring_class_sums(const void* x, int64_t ld, float* sums, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
+  CSBSR_CHECK(x && sums && c % 8 == 0 && H >= 5 && W >= 5, "ring_class_sums: bad args (H, W >= 5, c % 8 == 0)");
+  const long hw = (long)H * W;
+  int chunks = (int)((hw + 511) / 512);
+  if (chunks > 2048) chunks = 2048;
+  const long n_tot = (long)N * chunks * c, n_line = (long)N * 8 * BCS_SEG * 5 * c;
+  float* part = csbsr_red_scratch(n_tot + n_line);
+  CSBSR_NEED_SCRATCH(part, "ring_class_sums");
+  hipLaunchKernelGGL(bcs_total_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks, part);
+  if (csbsr_sum_partials_batched(part, chunks, c, c, sums + 12l * c, N, 25l * c, ST(s))) return 1;      // the total lands in the interior class
+  float* lpart = part + n_tot;
+  hipLaunchKernelGGL(rcs_lines_kernel, dim3(N * 8 * ((c / 8 + 31) / 32) * BCS_SEG), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, lpart, H, W, c / 8);
+  hipLaunchKernelGGL(rcs_finish_kernel, dim3((N * c + 255) / 256), dim3(256), 0, ST(s), (const float*)lpart, sums, N, c);
+  CSBSR_LAUNCH_CHECK("csbsr_ring_class_sums");
+  return 0;
+}

@@ -256,7 +256,8 @@ class Conv:
         return (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
 
     def _launch(self, xs, wt, transposed, k, stride, pad, dil, H, W, OH, OW, cout, out, out32, bias, act, slope, prelu, res, res2,
-                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None, hr=None, tp=None, dact=None, x3=None, dres=None):
+                res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None, hr=None, tp=None, dact=None, x3=None, dres=None,
+                cb_mode=0):
         d = L.ConvDesc()
         x0 = xs[0]
         if x0.lo:                       # split-fp16 input: [hi | lo] + hi again, weights from _pack_split
@@ -278,6 +279,7 @@ class Conv:
             assert out32.is_contiguous() and tuple(out32.shape) == (x0.N, cout, OH, OW)
             d.out32, d.o32_sn, d.o32_sy, d.o32_sx, d.o32_sc = _ptr(out32), cout * OH * OW, OW, 1, OH * OW
         d.bias, d.cbias, d.act, d.act_slope, d.prelu = _ptr(bias), _ptr(cbias), act, slope, _ptr(prelu)
+        d.cbias_mode = cb_mode
         d.res_mode = res_mode
         if res is not None:
             sn, sy, sx = res.strides()
@@ -466,6 +468,19 @@ class Conv:
                      None, None, L.RES_NONE, False, None, L.STAT_NONE, 1.0 / self.WSCALE if sp else 1.0, cbias=cb,
                      x3=None if sp else (0, cf, self.cout, 0, 0))
         return out, (w16c, k16)
+
+    def fwd_classbias(self, x, cb, cb_mode, out=None):
+        """conv over input segment 0 only; segment 1 -- a map that is constant within each position class (``cb_mode`` 0: the 16 border
+        classes, 1: the 25 two-ring classes, include/csbsr_hip.h) -- enters through ``cb`` [B, classes, pad8(cout)] fp32, its exact
+        contribution per (sample, class) computed by the caller.  Plain fp16 inputs."""
+        assert not self.transposed and self.stride == 1 and self.split[1] > 0 and not x.lo
+        cf = self.split[0]
+        wt = self._pack("fwd_feat", 0, cf, 0, 0, self.cout, 1, self.pad, 0)
+        if out is None:
+            out = self.eng.new(x.N, x.H, x.W, self.cout)
+        self._launch((x,), wt, False, self.k, 1, self.pad, self.dil, x.H, x.W, x.H, x.W, self.cout, out, None, self.b, self.act, self.slope,
+                     self.prelu, None, None, L.RES_NONE, False, None, L.STAT_NONE, 1.0, cbias=cb, cb_mode=cb_mode)
+        return out
 
     def fwd_const_1x1(self, cvec, x, out=None, stat=None, stat_mode=L.STAT_NONE):
         """1x1 conv over cat(spatially constant vector [B, c0], x): the constant segment is a per-sample bias W[:, :c0] . cvec (exact; a

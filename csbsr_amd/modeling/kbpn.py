@@ -23,6 +23,45 @@ class _Stage:
     pass
 
 
+def border_tap_mask():
+    """Mtap[a, k] = 1 when tap k of a zero-padded 3-tap window lands inside the image for an output coordinate of border class a
+    (a = first * 2 + last: 0 interior, 1 last, 2 first, 3 first and last)."""
+    m = torch.ones(4, 3)
+    m[2, 0] = m[3, 0] = 0.0          # first row/col: tap 0 reads outside
+    m[1, 2] = m[3, 2] = 0.0          # last row/col: tap 2 reads outside
+    return m
+
+
+def ring_tap_classes():
+    """Rtap[t, k, a] = 1 when tap k of an output coordinate of two-ring type t (0, 1, 2, 3, 4 = coordinate 0, 1, interior, size-2,
+    size-1; size >= 5) reads an input coordinate of border class a (0 interior, 1 last, 2 first); out-of-image taps have no entry."""
+    r = torch.zeros(5, 3, 4)
+    r[0, 1, 2] = r[0, 2, 0] = 1.0                       # coordinate 0: tap 0 is outside, tap 1 reads the first row, tap 2 an interior row
+    r[1, 0, 2] = r[1, 1, 0] = r[1, 2, 0] = 1.0
+    r[2, :, 0] = 1.0
+    r[3, 0, 0] = r[3, 1, 0] = r[3, 2, 1] = 1.0
+    r[4, 0, 0] = r[4, 1, 1] = 1.0                       # last coordinate: tap 2 is outside
+    return r
+
+
+def _act_fn(conv):
+    if conv.act == A_LRELU:
+        return lambda t: F.leaky_relu(t, conv.slope)
+    return F.relu if conv.act == A_RELU else (lambda t: t)
+
+
+def kernel_branch_table(kv, w0, w1, w_tail, mtap, rtap, act0, act1):
+    """[B, 5, 5, cout] table of  W_tail . act1(conv3x3(act0(conv3x3(kv expanded over the image, w0)), w1))  per two-ring class of the pixel
+    (both convs zero-padded, stride 1): plain differentiable torch ops on a handful of small tensors.
+    kv [B, cin] the spatially constant input, w0 [c0, cin, 3, 3], w1 [c1, c0, 3, 3], w_tail [cout, c1]."""
+    T = torch.einsum("ocyx,nc->noyx", w0, kv)                               # per-tap response to the constant code
+    V1 = act0(torch.einsum("noyx,ay,bx->nabo", T, mtap, mtap))               # [B, 4, 4, c0] border-class values of the first conv
+    A1 = torch.einsum("tya,nabc->ntybc", rtap, V1)
+    A2 = torch.einsum("uxb,ntybc->ntuyxc", rtap, A1)                         # [B, 5, 5, 3, 3, c0]: what each tap of the second conv reads
+    V2 = act1(torch.einsum("ocyx,ntuyxc->ntuo", w1, A2))                     # [B, 5, 5, c1] two-ring-class values of the second conv
+    return torch.einsum("oc,ntuc->ntuo", w_tail, V2)
+
+
 class KBPN:
     def __init__(self, eng, params, cfg, prefix="sr_model"):
         self.eng, self.P, self.cfg, self.prefix = eng, params, cfg, prefix
@@ -87,11 +126,8 @@ class KBPN:
         self.U = up.reshape(kc, self.kk).t().contiguous().to(eng.device)       # [kk, kc]
         self.kc = kc
         self.saved = None
-        # border-class tap masks for the folded constant-operand conv: index = first*2 + last, entry [ky]
-        m = torch.ones(4, 3)
-        m[2, 0] = m[3, 0] = 0.0          # first row/col: tap 0 reads outside
-        m[1, 2] = m[3, 2] = 0.0          # last row/col: tap 2 reads outside
-        self.Mtap = m.to(eng.device)
+        self.Mtap = border_tap_mask().to(eng.device)       # folded constant-operand convs: see _kernel_branch_fwd / Conv.fwd_folded
+        self.Rtap = ring_tap_classes().to(eng.device)
 
     # ------------------------------------------------------------------ phase logic (kbpn.py:118-142, 414-447)
     def set_phase(self, it):
@@ -228,14 +264,13 @@ class KBPN:
         for c in st.fe_sr:
             x = c.fwd(x)
             a.append(x)
-        b1, kfm = self._fold_const_conv_fwd(st.fe_k[0], kvec, H, W)
-        b2 = st.fe_k[1].fwd(b1)
-        c1 = st.fe_cat[0].fwd((a[-1], b2))
+        cb, kctx = self._kernel_branch_fwd(st, kvec, H, W)
+        c1 = st.fe_cat[0].fwd_classbias(a[-1], cb, 1)
         c2 = st.fe_cat[1].fwd(c1)
         gap = e.f32(B, pad8(self.kc))
         st.fe_cat[2].fwd(c2, stat=gap, stat_mode=L.STAT_SAMPLE_SUM, store=False)
         d49 = gap[:, :self.kc] / float(H * W)
-        q["kp"] = (a[:1] if getattr(self, "lean", False) else a, kfm, b1, b2, c1, c2)
+        q["kp"] = (a[:1] if getattr(self, "lean", False) else a, kctx, c1, c2)
         return kvec + d49 @ self.U.t()
 
     # ------------------------------------------------------------------ backward
@@ -418,7 +453,7 @@ class KBPN:
     def _kernel_predictor_bwd(self, st, q, dk2, dsr_t, H, W):
         """backward of kvec2 = kvec_in + U @ GAP(fe_cat(...)); adds the fe_SR path into dsr_t (fp32 planar)."""
         e = self.eng
-        a, kfm, b1, b2, c1, c2 = q["kp"]
+        a, kctx, c1, c2 = q["kp"]
         if len(a) == 1:              # lean save: rebuild the fe_SR chain from the SR estimate (same kernels, same order: bit-identical)
             a = list(a)
             for c in st.fe_sr:
@@ -436,16 +471,11 @@ class KBPN:
         self._wg(cat1, dc2, c1)
         dc1 = cat1.bwd_input(dc2, mask=msk(cat0, c1))
         del dc2
-        self._wg(cat0, dc1, (a[-1], b2))
+        if not cat0.frozen:
+            cat0.bwd_weights(dc1, a[-1], split_override=(cat0.split[0], 0))
         da = cat0.bwd_input(dc1, seg=0, mask=msk(st.fe_sr[4], a[5]))
-        db2 = cat0.bwd_input(dc1, seg=1, mask=msk(st.fe_k[1], b2))
+        dkin = self._kernel_branch_bwd(st, dc1, kctx, H, W)      # the fe_kernel branch: 25 class sums of dPre + a tiny autograd graph
         del dc1
-        # fe_kernel chain
-        self._wg(st.fe_k[1], db2, b1)
-        db1 = st.fe_k[1].bwd_input(db2, mask=msk(st.fe_k[0], b1))
-        del db2
-        dkin = self._fold_const_conv_bwd(st.fe_k[0], db1, kfm, H, W)
-        del db1
         # fe_SR chain
         for i in (4, 3, 2, 1, 0):
             c = st.fe_sr[i]
@@ -457,23 +487,40 @@ class KBPN:
         return dk2 + dkin
 
     # ------------------------------------------------------------------ constant-operand folding (exact)
-    def _fold_const_conv_fwd(self, conv, kvec, H, W):
-        """3x3 zero-padded conv of the spatially constant kernel-code map (fe_kernel.0, kbpn.py:565-567): the output takes
-        one value per border class, so it is T = W . k (a [cout, 9] mat-vec per sample), 16 masked tap sums, the activation,
-        and a class fill of the map -- instead of 2*H*W*441*49*9 FLOP on the MFMA."""
+    def _kernel_branch_fwd(self, st, kvec, H, W):
+        """The fe_kernel branch of KernelPredictorLikeIKC (kbpn.py:565-569: GAP'ed kernel code expanded over the image -> conv3x3 + LReLU
+        -> conv3x3 + LReLU -> second half of fe_cat.0's input) never exists as a map.  A zero-padded 3x3 conv of a spatially constant
+        map takes one value per BORDER class (16, by which image edges the pixel touches); a second one on top takes one value per
+        TWO-RING class (25 = 5 row types x 5 column types: coordinate 0, 1, interior, size-2, size-1), and fe_cat.0 is 1x1, so the whole
+        branch enters fe_cat.0 as a bias table [B, 25, 32] (conv desc cbias_mode 1) -- exact, instead of a 441 -> 49 and a 49 -> 49 3x3
+        convolution and a 49-channel concat half at HR resolution.  The table is a few small fp32 contractions; they are recorded as a
+        torch autograd graph (leaves: the kernel vector and the three weight tensors), which IS the backward of the branch."""
         e = self.eng
-        B = kvec.shape[0]
-        w16 = conv.w.to(torch.float16).float()                      # same operand rounding as the MFMA path
-        k16 = kvec.to(torch.float16).float()
-        T = torch.einsum("ocyx,nc->noyx", w16, k16)                  # [B, cout, 3, 3]
-        V = torch.einsum("noyx,ay,bx->nabo", T, self.Mtap, self.Mtap)   # [B, 4, 4, cout]
-        V = torch.where(V > 0, V, V * conv.slope) if conv.act == A_LRELU else V
-        cp = pad8(conv.cout)
-        Vp = e.f32(B, 16, cp)
-        Vp[:, :, :conv.cout] = V.reshape(B, 16, conv.cout)
-        out = e.new(B, H, W, conv.cout)
-        L.call("csbsr_border_class_fill", _ptr(Vp), _ptr(out.t), out.ld, B, H, W, cp, e.stream)
-        return out, (w16, k16)
+        assert H >= 5 and W >= 5, "two-ring classes need a map of at least 5 x 5"
+        k0, k1, cat0 = st.fe_k[0], st.fe_k[1], st.fe_cat[0]
+        with torch.enable_grad():
+            kv = kvec.detach().to(torch.float32).requires_grad_(True)
+            w0, w1, wc = (c.w.detach().requires_grad_(not c.frozen) for c in (k0, k1, cat0))
+            cbv = kernel_branch_table(kv, w0, w1, wc[:, cat0.split[0]:, 0, 0], self.Mtap, self.Rtap, _act_fn(k0), _act_fn(k1))
+        cb = e.f32(kvec.shape[0], 25, pad8(cat0.cout))
+        cb[:, :, :cat0.cout] = cbv.detach().reshape(-1, 25, cat0.cout)
+        return cb, (cbv, kv, (w0, w1, wc))
+
+    def _kernel_branch_bwd(self, st, dc1, kctx, H, W):
+        """adjoint of the above: 25 two-ring class sums of fe_cat.0's dPre, then the recorded graph; returns dL/d(kernel vector)."""
+        e = self.eng
+        cbv, kv, ws = kctx
+        cat0 = st.fe_cat[0]
+        B = dc1.N
+        sums = e.f32(B, 25, dc1.cp)
+        L.call("csbsr_ring_class_sums", _ptr(dc1.t), dc1.ld, _ptr(sums), B, H, W, dc1.cp, e.stream)
+        leaves = [kv] + [w for w in ws if w.requires_grad]
+        grads = torch.autograd.grad(cbv, leaves, sums[:, :, :cat0.cout].reshape(B, 5, 5, cat0.cout))
+        gi = iter(grads[1:])
+        for conv, w in zip((st.fe_k[0], st.fe_k[1], cat0), ws):
+            if w.requires_grad:
+                grad_acc(conv.w).add_(next(gi))
+        return grads[0]
 
     def _fold_const_dgrad(self, conv, gvec, mask, H, W):
         """dgrad of a zero-padded 3x3 conv whose dOut is spatially constant per sample (``gvec`` [B, cout]: the backward of the global
@@ -495,16 +542,3 @@ class KBPN:
         assert mfm.cp == cp and (mfm.H, mfm.W) == (H, W) and not mfm.bcast
         L.call("csbsr_border_class_fill_masked", _ptr(Vp), _ptr(out.t), out.ld, _ptr(mfm.t), mfm.ld, float(mslope), B, H, W, cp, e.stream)
         return out
-
-    def _fold_const_conv_bwd(self, conv, dpre, saved, H, W):
-        """adjoint of the above: 16 class sums of dPre -> per-tap sums S, dW += S (x) k, dk = W^T S."""
-        e = self.eng
-        w16, k16 = saved
-        B = dpre.N
-        sums = e.f32(B, 16, dpre.cp)
-        L.call("csbsr_border_class_sums", _ptr(dpre.t), dpre.ld, _ptr(sums), B, H, W, dpre.cp, e.stream)
-        C_ = sums[:, :, :conv.cout].reshape(B, 4, 4, conv.cout)
-        S = torch.einsum("nabo,ay,bx->noyx", C_, self.Mtap, self.Mtap)     # [B, cout, 3, 3]
-        if not conv.frozen:
-            grad_acc(conv.w).add_(torch.einsum("noyx,nc->ocyx", S, k16))
-        return torch.einsum("ocyx,noyx->nc", w16, S)

@@ -67,6 +67,14 @@ def det_value(name: str, shape, sd_keys, style: str = "random") -> torch.Tensor:
             mix = _wave(name + "#mix", shape[0] * shape[1]).reshape(shape[0], shape[1], 1, 1) * (math.sqrt(2.0 / shape[1]) / 0.53)
             prof = torch.outer(_smooth_profile(shape[2]), _smooth_profile(shape[3])).reshape(1, 1, shape[2], shape[3])
             v = (mix * prof).reshape(-1) + 0.15 * v
+        if (style == "contractive" and name.startswith("sr_model.") and shape[2] == 3 and shape[0] > shape[1] and shape[0] % shape[1] == 0
+                and shape[0] // shape[1] in (4, 16, 64)):
+            # ConvAndPixelShuffleBlock (MODEL.SR_PIXEL_SHUFFLE): every output pixel of conv3x3 + PixelShuffle(s) sums 9 C kaiming-scaled
+            # terms where the ConvTranspose2d(k = 2 s) it replaces sums 4 C terms of weights scaled for a fan of C k^2 -- 4x the output
+            # std per up-projection, which compounds to activations of several hundred and an "SR image" of magnitude ~170 by stage 4.
+            # An eighth of the kaiming scale keeps the stack's SR residual below the magnitude of the image itself (max |sr| 3.7 instead of
+            # 168), as it is in a trained network -- and in the deconvolution variant with plain kaiming weights.
+            v = v * 0.125
         if "kernel_predictor.fe_cat.2" in name:
             v = v * 0.02       # kernel refinement delta << kernel, as in a trained net: keeps k/sum(k) well conditioned
     elif is_bn and name.endswith(".weight"):

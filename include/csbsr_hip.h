@@ -64,8 +64,9 @@ typedef struct {
   float* out32;            /* optional fp32 output with arbitrary strides (planar NCHW: sc = H*W) or NULL */
   int64_t o32_sn, o32_sy, o32_sx, o32_sc;
   const float* bias;       /* fp32[cout] or NULL */
-  const float* cbias;      /* fp32 [N][16][coutp] or NULL: extra bias per (sample, border class of the output pixel) = the exact
-                              contribution of a folded spatially-constant input segment (see csbsr_border_class_fill) */
+  const float* cbias;      /* fp32 [N][16 | 25][coutp] or NULL: extra bias per (sample, position class of the output pixel) = the exact
+                              contribution of a folded input segment that is constant within each class (cbias_mode below;
+                              see csbsr_border_class_fill / csbsr_ring_class_sums) */
   int32_t act;             /* CSBSR_ACT_* */
   float act_slope;         /* LRELU slope */
   const float* prelu;      /* device scalar for CSBSR_ACT_PRELU */
@@ -86,7 +87,10 @@ typedef struct {
    * (mask > 0 ? 1 : mask_slope) where mask = the saved forward OUTPUT of the layer whose input gradient this launch produces
    * (ReLU: slope 0; LeakyReLU / PReLU: the slope): autograd of F.relu / F.leaky_relu (kbpn.py:236-247) without a pass of its own.
    * Only valid on the launch that completes the gradient (the last accumulating contribution).  NULL = off. */
-  const void* mask; int64_t m_sn, m_sy, m_sx; float mask_slope; int32_t _pad_mask;
+  const void* mask; int64_t m_sn, m_sy, m_sx; float mask_slope;
+  int32_t cbias_mode;      /* classes of cbias: 0 = the 16 border classes (y==0)*8 + (y==OH-1)*4 + (x==0)*2 + (x==OW-1);
+                              1 = the 25 two-ring classes ty*5 + tx, t = 0,1,2,3,4 for coordinate 0, 1, interior, size-2, size-1
+                              (needs OH, OW >= 5): what a map takes after TWO zero-padded 3x3 convs of a constant */
   /* csbsr_conv_tp_forward only (NULL elsewhere): the masking layer's PReLU slope on the device (overrides mask_slope), and where its
    * bias / PReLU-slope gradients go -- dact_bias[c] += sum over pixels of the masked result, dact_prelu[0] += sum over the pixels
    * with mask <= 0 of (unmasked result) x mask / slope, i.e. exactly what csbsr_epilogue_backward adds for that layer
@@ -295,6 +299,11 @@ int csbsr_border_class_fill_masked(const float* V, void* out, int64_t ld, const 
                                    int32_t H, int32_t W, int32_t c, csbsr_stream_t s);
 int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, int32_t N, int32_t H, int32_t W, int32_t c,
                             csbsr_stream_t s);
+/* Two 3x3 convs deep (fe_kernel.0 -> fe_kernel.1 on the expanded kernel code, kbpn.py:565-569) the map takes one value per
+ * two-ring class ty*5 + tx (conv desc cbias_mode 1): the whole branch is a [N][25][c] table and never exists as a map.  Adjoint of
+ * adding such a table: sums[n][class][:] += sum over the pixels of that class of x[n,y,x,:]  (fp32 [N][25][c], H, W >= 5). */
+int csbsr_ring_class_sums(const void* x, int64_t ld, float* sums, int32_t N, int32_t H, int32_t W, int32_t c,
+                          csbsr_stream_t s);
 
 /* ------------------------------------------------------------------------------------------- batch norm */
 /* Train-mode BatchNorm2d (extractors.py:47-66, pspnet.py:48-49,83); sum / sumsq come from the conv epilogue. */

@@ -114,7 +114,9 @@ def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha
                      "segmentation_model.ocr_distri_head.object_context_block.f_up.1.0.running_var",
                      "segmentation_model.aux_head.1.0.running_mean")}
     out = dict(x=x.numpy(), hr=hr.numpy(), mask=mask.numpy(), kernel=k.numpy(), it=np.int64(it),
-               segment_loss=seg_loss.detach().numpy(), sr_loss=sr_loss.detach().numpy(), loss=np.float64(loss.item()),
+               # (ONLY_KERNEL_LOSS_FOR_PRETRAIN returns the unreduced [B,1,K,K] kernel MSE map as "sr_loss" in the kernel pretraining phase,
+               # sr_loss_functions.py:50-51; calc_loss takes its mean: stored as the per-sample means, whose mean is the same)
+               segment_loss=seg_loss.detach().numpy(), sr_loss=sr_loss.detach().reshape(sr_loss.shape[0], -1).mean(1).numpy(), loss=np.float64(loss.item()),
                segment_preds=seg.detach().numpy(), sr_preds=sr.detach().numpy(), kernel_preds=kpred.detach().numpy(),
                grad_names=np.array(names), grad_norms=norms, grad_samples=samples,
                alpha=np.float64(model.ss_loss_fn.alpha), antialias=np.bool_(antialias), scale=np.int64(scale),
@@ -132,7 +134,15 @@ def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha
         out["tap." + kname] = v if v.size <= 70000 else v[:, :8]          # first 8 channels of big maps
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
-    print(f"{name}: loss={loss.item():.6f} seg={seg_loss.tolist()} sr={sr_loss.tolist()} -> {os.path.getsize(path)/1e3:.0f} kB")
+    print(f"{name}: loss={loss.item():.6f} seg={seg_loss.tolist()} sr={out['sr_loss'].tolist()} -> {os.path.getsize(path)/1e3:.0f} kB")
+
+
+def _iou_min(a, b, th=0.5, smooth=1e-5):
+    """estimate_metrics.IoU (thr 0.5, smooth 1e-5) between two probability maps, minimum over the batch"""
+    pa, pb = (a > th).float(), (b > th).float()
+    inter = (pa * pb).sum((1, 2, 3))
+    union = pa.sum((1, 2, 3)) + pb.sum((1, 2, 3)) - inter
+    return float(((inter + smooth) / (union + smooth)).min())
 
 
 def run_case_wc(name, it, B=2, lr=64, scale=4, alpha=0.7, overrides=(), seed=1121, detector="PSPNet", dropout=False, eps=1e-3,
@@ -225,7 +235,7 @@ def run_case_wc(name, it, B=2, lr=64, scale=4, alpha=0.7, overrides=(), seed=112
                torch_version=np.array(torch.__version__), fill=np.array(fill), pixel_shuffle=np.bool_(cfg.MODEL.SR_PIXEL_SHUFFLE),
                # the reference's own response to an SR image moved by eps * max|sr| (uniform noise)
                cond_eps=np.float64(eps), cond_seg_max=np.float64(mx(b["seg"], a["seg"])), cond_seg_l2=np.float64(rl2(b["seg"], a["seg"])),
-               cond_segloss=np.float64(mx(b["seg_loss"], a["seg_loss"])),
+               cond_segloss=np.float64(mx(b["seg_loss"], a["seg_loss"])), cond_iou=np.float64(_iou_min(b["seg"], a["seg"])),
                cond_bn=np.float64(max([mx(b["bufs"][n], a["bufs"][n]) for n in a["bufs"]] or [0.0])),
                cond_grad_median=np.float64(np.median(cond_g)), cond_grad_p90=np.float64(np.percentile(cond_g, 90)))
     if a["dsr"] is not None:      # upstream gradient of the KBPN backward, stored as fp16 of (grad * 2^20): the backward is linear in it
@@ -239,7 +249,7 @@ def run_case_wc(name, it, B=2, lr=64, scale=4, alpha=0.7, overrides=(), seed=112
         out["buf." + kname] = v.numpy()
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
-    print(f"{name}: loss={a['loss']:.6f} cond(eps={eps:g}): seg max {out['cond_seg_max']:.2e} l2 {out['cond_seg_l2']:.2e} segloss "
+    print(f"{name}: loss={a['loss']:.6f} cond(eps={eps:g}): IoU {out['cond_iou']:.4f} seg max {out['cond_seg_max']:.2e} l2 {out['cond_seg_l2']:.2e} segloss "
           f"{out['cond_segloss']:.2e} bn {out['cond_bn']:.2e} grads median {out['cond_grad_median']:.2e} p90 {out['cond_grad_p90']:.2e}"
           f" -> {os.path.getsize(path)/1e6:.2f} MB")
 

@@ -563,6 +563,35 @@ def test_wide_3x3_kernel_with_folded_constant_segment():
     assert relmax(outs[0], outs[1]) < 1e-3
 
 
+@pytest.mark.parametrize("H,W", [(5, 5), (12, 40), (33, 70)])
+def test_conv_with_two_ring_class_bias(H, W):
+    """fe_cat.0 as the model runs it (Conv.fwd_classbias, conv desc cbias_mode 1): a 1x1 conv over cat(features, a map that is the
+    output of TWO zero-padded 3x3 convs of a spatially constant code) with the second segment folded into a [B, 25, cout] table by
+    csbsr_amd.modeling.kbpn.kernel_branch_table, against F.conv2d on the literally computed concatenated input."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv, pad8
+    from csbsr_amd.modeling.kbpn import kernel_branch_table, border_tap_mask, ring_tap_classes
+    torch.manual_seed(H * W)
+    eng = _eng()
+    N, cf, ccode, c0, c1, cout = 2, 49, 21, 49, 49, 32
+    x = torch.randn(N, cf, H, W).half().float()
+    kv = torch.rand(N, ccode) / ccode
+    w0, w1 = torch.randn(c0, ccode, 3, 3) / (ccode * 9) ** 0.5, torch.randn(c1, c0, 3, 3) / (c0 * 9) ** 0.5
+    w = (torch.randn(cout, cf + c1, 1, 1) / (cf + c1) ** 0.5)
+    act = lambda t: F.leaky_relu(t, 0.01)
+    b2 = act(F.conv2d(act(F.conv2d(kv[:, :, None, None].expand(N, ccode, H, W), w0, None, 1, 1)), w1, None, 1, 1))
+    w16 = w.clone()
+    w16[:, :cf] = w[:, :cf].half().float()          # the feature half goes through the MFMA in fp16, the folded half stays fp32
+    ref = F.leaky_relu(F.conv2d(torch.cat([x, b2], 1), w16), 0.01)
+    tab = kernel_branch_table(kv, w0, w1, w[:, cf:, 0, 0], border_tap_mask(), ring_tap_classes(), act, act)       # [N, 5, 5, cout]
+    cb = torch.zeros(N, 25, pad8(cout), device="cuda")
+    cb[:, :, :cout] = tab.reshape(N, 25, cout).cuda()
+    conv = Conv(eng, "l", {"l.weight": w.cuda()}, 1, 1, 0, 1, bias=False, act=L.ACT_LRELU, slope=0.01, split=(cf, c1))
+    y = conv.fwd_classbias(to_fm(eng, x), cb, 1)
+    torch.cuda.synchronize()
+    assert relmax(from_fm(y), ref) < 2e-3
+
+
 @pytest.mark.parametrize("cin,cout,k,s,p,OH,OW,mode", [
     (128, 128, 8, 4, 2, 19, 45, "prelu_sub"),      # up_conv2 / down_conv shapes, ragged tiles on both axes
     (128, 128, 8, 4, 2, 16, 64, "prelu_add"),      # whole tiles

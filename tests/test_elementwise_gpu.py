@@ -374,6 +374,31 @@ def test_border_class_fill_and_sums(shape):
     assert relmax(sums.cpu(), ref_s) < 2e-4
 
 
+@pytest.mark.parametrize("shape", [(2, 5, 5, 8), (2, 9, 11, 24), (1, 70, 66, 32), (3, 64, 64, 136)])
+def test_ring_class_sums(shape):
+    """the 25 two-ring class sums (adjoint of a per-class bias table with conv desc cbias_mode 1) vs a one-hot einsum, and twice: the
+    reduction is order-fixed, so the two results must be bit-identical."""
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    N, H, W, Cc = shape
+    torch.manual_seed(11)
+    x = r16(torch.randn(N, Cc, H, W))
+    fx = to_fm(x)
+    res = []
+    for _ in range(2):
+        sums = torch.zeros(N, 25, Cc, device="cuda")
+        L.call("csbsr_ring_class_sums", P(fx.t), fx.ld, P(sums), N, H, W, Cc, eng.stream)
+        torch.cuda.synchronize()
+        res.append(sums.cpu())
+    typ = lambda v, n: torch.where(v < 2, v, torch.where(v >= n - 2, v - n + 5, torch.full_like(v, 2)))
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    cls = typ(yy, H) * 5 + typ(xx, W)
+    onehot = torch.nn.functional.one_hot(cls.reshape(-1), 25).float().reshape(H, W, 25)
+    ref = torch.einsum("nchw,hwk->nkc", x, onehot)
+    assert torch.equal(res[0], res[1])
+    assert relmax(res[0], ref) < 2e-4
+
+
 @pytest.mark.parametrize("n,relu", [(1, True), (3, True), (4, False)])
 def test_sum_act(n, relu):
     """n-ary fuse sum of an HRNet module (csbsr_sum_act) vs torch."""

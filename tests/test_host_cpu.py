@@ -209,3 +209,26 @@ def test_deterministic_fill_is_reproducible():
     a, b = det_state_dict(shapes), det_state_dict(shapes)
     assert all(torch.equal(a[k], b[k]) for k in a)
     assert float(a["sr_model.feat.0.weight"].std()) > 0
+
+
+def test_kernel_branch_table_is_the_two_conv_branch():
+    """csbsr_amd.modeling.kbpn.kernel_branch_table -- the fe_kernel branch of KernelPredictorLikeIKC (kbpn.py:565-569) as a [B, 25, c]
+    two-ring class table -- against the branch computed literally with F.conv2d on the expanded map, forward and backward (fp64)."""
+    import torch.nn.functional as F
+    from csbsr_amd.modeling.kbpn import kernel_branch_table, border_tap_mask, ring_tap_classes
+    gen = torch.Generator().manual_seed(5)
+    B, cin, c0, c1, co, H, W = 2, 11, 7, 6, 5, 7, 9
+    rnd = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).requires_grad_(True)
+    kv, w0, w1, wt = rnd(B, cin), rnd(c0, cin, 3, 3), rnd(c1, c0, 3, 3), rnd(co, c1)
+    act = lambda t: F.leaky_relu(t, 0.01)
+    tab = kernel_branch_table(kv, w0, w1, wt, border_tap_mask().double(), ring_tap_classes().double(), act, act)
+    y = F.conv2d(act(F.conv2d(act(F.conv2d(kv[:, :, None, None].expand(B, cin, H, W), w0, padding=1)), w1, padding=1)), wt[:, :, None, None])
+    typ = lambda v, n: v if v < 2 else (v - n + 5 if v >= n - 2 else 2)
+    g = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+    sums = torch.zeros(B, 5, 5, co, dtype=torch.float64)
+    for i in range(H):
+        for j in range(W):
+            assert float((tab[:, typ(i, H), typ(j, W)] - y[:, :, i, j]).abs().max()) < 1e-12
+            sums[:, typ(i, H), typ(j, W)] += g[:, :, i, j]
+    for a, b in zip(torch.autograd.grad(y, [kv, w0, w1, wt], g, retain_graph=True), torch.autograd.grad(tab, [kv, w0, w1, wt], sums)):
+        assert float((a - b).abs().max()) < 1e-10

@@ -23,6 +23,17 @@ pytestmark = pytest.mark.gpu
 SEG_BOUND = {"PSPNet": (0.12, 2e-2, 5e-2, 0.95), "PSPNet_BlurSkip": (0.12, 2e-2, 5e-2, 0.95), "HRNet_OCR": (0.45, 0.1, 0.3, 0.70)}
 
 
+def gate_flip_prone(name):
+    """fe_kernel.0 of a stage's kernel predictor is a conv3x3 + LeakyReLU of a SPATIALLY CONSTANT map (kbpn.py:565-567): each of its 49
+    pre-activations is one number per (sample, border class), so when one of them changes sign the activation derivative of the whole
+    channel -- every pixel at once -- jumps, and with it 1/49 of that weight's gradient.  The e2e_pspnet_* fixtures (seed 1121) hold such a
+    value: stage index 1, sample 0, channel 24 is 3.6e-6 against an rms of 1.1e-2, i.e. 3e-4 of the typical magnitude, while the kernel
+    vector the HIP path feeds it is only good to ~1e-3 (north_star's tolerance).  Its sign differs from the reference's and that ONE
+    tensor sits 4.7e-2 away (every other kernel-predictor tensor: <= 4e-3; measured with scripts/debug_grads.py).  A discontinuity of
+    the function, not an error of the gradient: these tensors get a bound of 0.1."""
+    return name.endswith("kernel_predictor.fe_kernel.0.layer.weight")
+
+
 def build_model(g, micro_batch=8):
     from csbsr_amd.config import cfg as base_cfg
     from csbsr_amd.modeling.build_model import JointModelWithLoss
@@ -37,6 +48,8 @@ def build_model(g, micro_batch=8):
         cfg.SOLVER.ORIENTED_WEIGHT_ITER = int(g["oriented_w_iter"])
     if "pixel_shuffle" in g:
         cfg.MODEL.SR_PIXEL_SHUFFLE = bool(g["pixel_shuffle"])
+    if "residual_learning" in g:
+        cfg.MODEL.SR_RESIDUAL_LEARNING, cfg.SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN = bool(g["residual_learning"]), bool(g["only_kernel_loss"])
     m = JointModelWithLoss(cfg, 1000, 0, None, antialias=bool(g["antialias"]))
     deterministic_fill(m.state_dict())
     m.ss_loss_fn.alpha = float(g["alpha"])
@@ -79,7 +92,8 @@ def run_oracle(g):
 
 @pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "e2e_pspnet_it10001",
                                   "e2e_pspnet_it20001", "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24", "e2e_blurskip_x8_it40000",
-                                  "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000", "e2e_pspnet_pixelshuffle_it20001"])
+                                  "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000", "e2e_pspnet_pixelshuffle_it20001",
+                                  "e2e_pspnet_noresidual_it40000", "e2e_pspnet_konly_it10001"])
 def test_forward_matches_golden(case):
     g = load_golden(case)
     det = str(g["detector"]) if "detector" in g else "PSPNet"
@@ -106,7 +120,7 @@ def test_forward_matches_golden(case):
 
 @pytest.mark.parametrize("case", ["e2e_pspnet_it1", "e2e_pspnet_it10001", "e2e_pspnet_it20001", "e2e_pspnet_it40000",
                                   "e2e_pspnet_it40000_dropout", "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000",
-                                  "e2e_pspnet_pixelshuffle_it20001"])
+                                  "e2e_pspnet_pixelshuffle_it20001", "e2e_pspnet_noresidual_it40000", "e2e_pspnet_konly_it10001"])
 def test_gradients_match_oracle(case):
     """Per-parameter relative L2 error of the HIP gradients vs the fp32 oracle.
 
@@ -148,7 +162,7 @@ def test_gradients_match_oracle(case):
         # (PixelShuffle variant: run to run the HIP gradients of the stage-1 kernel predictor themselves move by 1-3e-2, see
         # test_forward_matches_golden; observed against the oracle: typical maximum 1.3-4e-2, once 0.22 in ~15 runs -- so per tensor only a
         # sanity bound, the distribution carries the check)
-        if not joint and e > (0.3 if bool(g.get("pixel_shuffle", False)) else 3e-2):
+        if not joint and e > (0.3 if bool(g.get("pixel_shuffle", False)) else 0.1 if gate_flip_prone(n) else 3e-2):
             bad.append((n, e))
     errs = np.array(errs)
     print(case, "grad rel-L2 vs fp32 oracle: median %.2e  p90 %.2e  max %.2e  (n=%d)" % (np.median(errs), np.percentile(errs, 90), errs.max(), len(errs)))
@@ -188,7 +202,10 @@ def test_sr_loss_gradients_match_oracle(case):
         if og is None or og.numel() == 1 or float(og.norm()) < 1e-9:
             continue
         assert grads[n] is not None, n
-        errs.append(rel_err(grads[n].cpu(), og))
+        e = rel_err(grads[n].cpu(), og)
+        assert e < 0.1, (n, e)
+        if not gate_flip_prone(n):
+            errs.append(e)
     errs = np.array(errs)
     print(case, "SR-loss grads: median %.2e max %.2e (n=%d)" % (np.median(errs), errs.max(), len(errs)))
     assert len(errs) > 100 and np.median(errs) < 5e-3 and errs.max() < 3e-2

@@ -43,6 +43,7 @@ def test_joint_phase_trajectory_follows_the_reference(precision):
     m.train()
     params = [p for p in m.parameters() if p.requires_grad]
     opt = torch.optim.Adam(params, lr=float(g["lr_rate"]), betas=(0.9, 0.999), eps=1e-8)
+    m._runtime()                                         # parameters move to the device here
     named = [(k, v) for k, v in m._named_full() if isinstance(v, torch.nn.Parameter)]
     start = {k: v.detach().clone() for k, v in named}
     S = m.pc.num_stages
