@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsbsr_hip.so")
+LIB_PATH = os.environ.get("CSBSR_LIB") or os.path.join(_HERE, "libcsbsr_hip.so")       # CSBSR_LIB: a variant build (kernel A/B experiments)
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3, 4
 RES_NONE, RES_ADD, RES_SUB, RES_MUL, RES_FMA = 0, 1, 2, 3, 4

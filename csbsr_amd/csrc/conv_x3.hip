@@ -26,6 +26,10 @@
 // stride-1 convolution of the phase's sub-sampled grid, so a chunk is (phase, 64 channels), its halo the (8+1) x (32+1) sub-grid
 // pixels of the tile (every input pixel crosses the fabric ONCE per tile instead of once per tap it belongs to), and the accumulators
 // simply run over all s^2 x cin/64 chunks: K = 64 s^2 cin/64 x 4 taps = 8192 for 128 channels.
+#ifndef X3_RING3
+#define X3_RING3 3
+#endif
+#define X3_RING_OVERRIDE(NT) ((NT) % 3 == 0 ? X3_RING3 : 4)
 #define X3_TH 8
 #define X3_TW 32
 #define X3_SLOTS 9                        // 64 channels = 8 sixteen-byte slots + 1 pad slot: odd pitch, conflict-free rows of pixels
@@ -38,6 +42,7 @@ constexpr int x3_buf(int KS) { return x3_ninst(KS) * 1024; }
 struct X3Extra {
   unsigned tiles_x, tiles_y, nct, nch;   // pixel tiles, 128-cout tiles, chunks (64 channels [x input phase])
   unsigned ncc;                          // 64-channel chunks per input phase (KS = 2)
+  unsigned ct_major;                     // 1: cout tile as the slowest index of the item order (A/B timing; default 0, see decode())
 };
 
 // (the buffer-descriptor type and builtins exist in the device pass only: the host pass sees an empty kernel body and emits the stub)
@@ -51,14 +56,15 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_make_rs(const half_t
 #endif
 
 // ABL (builds with -DCSBSR_X3_ABLATE only; timing experiments, results are garbage): 1 halo DMA pieces fetch nothing (out-of-range
-// offsets), 2 every K step loads the weights of step 0, 4 no LDS fragment reads in the K loop, 8 no weight loads in the K loop
+// offsets), 2 every K step loads the weights of step 0, 4 no LDS fragment reads in the K loop, 8 no weight loads in the K loop,
+// 16 every halo comes from the same few (L2-resident) rows of the input
 template <int KS, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Extra q, const half_t* __restrict__ zero_page) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int X3_HW = X3_TW + KS - 1, X3_HH = X3_TH + KS - 1;
   constexpr int X3_NINST = x3_ninst(KS), X3_BUF = x3_buf(KS);
   constexpr int NT = KS * KS;                           // K steps (taps) per chunk
-  constexpr int RING = NT % 3 == 0 ? 3 : 4, DIST = RING - 1;      // weight register ring; loads run DIST K steps ahead (NT % RING == 0)
+  constexpr int RING = X3_RING_OVERRIDE(NT), DIST = RING - 1;      // weight register ring; loads run DIST K steps ahead (NT % RING == 0)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,6 +111,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
   // (uniform) source of chunk `chunk` of tile (n, Y0, X0): the input coordinates of halo pixel (0, 0) and its address
   auto chunk_src = [&](int n, int Y0, int X0, int chunk, int& by, int& bx) -> const half_t* {
     int coff;
+    if (ABL & 16) { n = 0; Y0 = 8 * (int)(blockIdx.x & 31); X0 = 0; chunk = 0; }      // every halo from one small (L2-resident) region
     if (KS == 3) { by = Y0 - 1; bx = X0 - 1; coff = chunk * 64; }
     else {
       const int ph = chunk / (int)q.ncc, py = ph / p.stride;
@@ -124,8 +131,20 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
     for (int i = 0; i < NFI; ++i) issue_one(rs, by, bx, i, buf);
   };
   auto decode = [&](unsigned item, int& ct, int& n, int& Y0, int& X0) {
-    ct = item / ntiles;                                  // cout-tile-major: everybody streams the same weight slice
-    const unsigned tile = item - ct * ntiles;
+    // The cout tiles of ONE pixel tile are consecutive items, and an XCD owns a contiguous run of the item order (xcd_remap: the
+    // launcher keeps the grid a multiple of 8, so item % 8 == blockIdx % 8 == the XCD): the nct workgroups that need the same input
+    // halo run side by side on one XCD at the same time, the halo comes from HBM once and the other nct - 1 requests meet it in that
+    // XCD's L2 (merged misses or hits).  With the cout tile as the SLOWEST index every pass over the image re-fetched the whole input
+    // from HBM (nct x the input bytes: FETCH_SIZE 4.8 GB per launch for 1.6 GB algorithmic at 825 -> 384).  The nct weight slices an
+    // XCD now streams at once (nct x 128 couts x 64 ch x 9 taps x 2 B = 0.44 MB per chunk) stay L2-resident because its 32 workgroups
+    // walk the chunks in loose lock step.
+    unsigned tile;
+    if (q.ct_major) { ct = item / ntiles; tile = item - ct * ntiles; }
+    else {
+      item = xcd_remap(item, items);
+      tile = item / q.nct;
+      ct = item - tile * q.nct;
+    }
     n = tile / per_img;
     const unsigned r_ = tile - n * per_img;
     Y0 = (r_ / q.tiles_x) * X3_TH; X0 = (r_ % q.tiles_x) * X3_TW;
@@ -323,7 +342,8 @@ extern "C" int csbsr_pack_weights_x3_strided(const float* w, void* dst, int32_t 
 
 static int g_conv_x3_mode = 1;      // 0 off, 1 launches that fill the chip, 2 every eligible launch (tests)
 static int g_conv_x3_abl = 0;       // bits 4.. of the debug mode: ablation variant of the 3x3 kernel (CSBSR_X3_ABLATE builds)
-extern "C" void csbsr_debug_set_conv_x3(int mode) { g_conv_x3_mode = mode & 15; g_conv_x3_abl = mode >> 4; }
+static int g_conv_x3_ct_major = 0;  // bit 3 of the debug mode: the old cout-tile-major item order (A/B timing)
+extern "C" void csbsr_debug_set_conv_x3(int mode) { g_conv_x3_mode = mode & 7; g_conv_x3_ct_major = (mode >> 3) & 1; g_conv_x3_abl = mode >> 4; }
 
 // Which launches take this kernel.  3x3, stride 1, pad 1, dilation 1: ONE plain-fp16 input segment whose padded channels are a multiple of
 // 64, >= 384 by default (measured at N = 4, 448^2, with the halo DMA issued inside the K loop: 825 -> 384 1041 TF/s against 899 for the
@@ -375,6 +395,7 @@ extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   q.tiles_x = (unsigned)((d->OW + X3_TW - 1) / X3_TW); q.tiles_y = (unsigned)((d->OH + X3_TH - 1) / X3_TH);
   q.nct = (unsigned)((d->coutp + 127) / 128); q.ncc = (unsigned)(d->in[0].c / 64);
   q.nch = strided ? q.ncc * (unsigned)(d->stride * d->stride) : q.ncc;
+  q.ct_major = (unsigned)g_conv_x3_ct_major;
   int dev = 0, ncu = 256;
   CSBSR_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CSBSR_MAX_DEVICES, "conv_x3: no current device");
   (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -397,6 +418,8 @@ extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
       case 9: return launch_x3<3, 9>(k, q, g, g_x3_zero_page[dev], st_);
       case 12: return launch_x3<3, 12>(k, q, g, g_x3_zero_page[dev], st_);
       case 13: return launch_x3<3, 13>(k, q, g, g_x3_zero_page[dev], st_);
+      case 16: return launch_x3<3, 16>(k, q, g, g_x3_zero_page[dev], st_);
+      case 24: return launch_x3<3, 24>(k, q, g, g_x3_zero_page[dev], st_);
       default: break;
     }
   }

@@ -6,6 +6,7 @@ epilogue, Dropout2d channel masks are fused into the following resize / BN-apply
 written in place by its producers.  Explicit backward.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -95,6 +96,10 @@ class PSPNet:
         # three MFMA passes (x_hi w_hi + x_lo w_hi + x_hi w_lo) in one fp32 accumulator; the backward reads the hi planes (BatchNorm /
         # max-pool backward also the lo planes, so their masks are the forward's).  Set by the model (detector_precision).
         self.split = False
+        # split mode: how many of the three upsample stages, counted from the output, run plain fp16 again (their input is the hi plane of
+        # the stage before).  Rounding introduced there only passes the remaining 1-2 conv + BatchNorm layers and the 1x1 head, so it is
+        # not amplified like the trunk's, while those stages hold the largest maps of the detector (64 channels at HR / HR/2).
+        self.split_tail_plain = int(os.environ.get("CSBSR_SPLIT_TAIL_PLAIN", "0"))
 
     def all_convs(self):
         cs = [self.stem.conv] + [b[k].conv for b in self.blocks for k in ("c1", "c2", "down") if b[k] is not None]
@@ -171,6 +176,8 @@ class PSPNet:
         usv = []
         names = ("drop_2a", "drop_2b", "drop_2c")
         for j, up in enumerate(self.ups):
+            if cur.lo and j >= len(self.ups) - self.split_tail_plain:
+                cur = FM(cur.t, cur.c, H=cur.H, W=cur.W)          # the hi plane alone: this stage and everything after it is plain fp16
             u = e.bilinear(cur, cur.H * 2, cur.W * 2, False, drop=cur_drop)
             raw, m, iv = up.fwd(u, training)
             last = j == 2

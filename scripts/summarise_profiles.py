@@ -18,9 +18,9 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r02")
+SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r03")
 DST = os.path.join(ROOT, "profiles")
-TAG = sys.argv[2] if len(sys.argv) > 2 else "r02"
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r03"
 
 
 def canon(name):
@@ -76,8 +76,14 @@ json.dump(json.loads(line), open(os.path.join(DST, f"{TAG}_bench.json"), "w"), i
 fetch = pmc(os.path.join(SRC, "pmc_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE")
 write = pmc(os.path.join(SRC, "pmc_write", "write_counter_collection.csv"), "WRITE_SIZE")
 out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --batch 4 --steps 1 --warmup 1 --no-cpu-baseline "
-                  "--no-kernel-timing (two separate passes)",
-       "units": "bytes per launch; FETCH_SIZE(KiB) x 1024 x 2 (gfx950 correction), WRITE_SIZE(KiB) x 1024", "kernels": {}}
+                  "--no-kernel-timing --no-h2d-leg --no-other-precision-leg (two separate passes; a third with TCC_HIT_sum TCC_MISS_sum)",
+       "units": "bytes per launch; FETCH_SIZE(KiB) x 1024 x 2 (gfx950 correction), WRITE_SIZE(KiB) x 1024.  CAVEAT (MI355X_MICROARCH.md, HBM "
+                "section): FETCH_SIZE derives from the L2's fabric-side read requests, so reads served by the 256 MB Infinity Cache are "
+                "counted too -- it is an upper bound on HBM reads; l2_hit_rate = TCC_HIT / (TCC_HIT + TCC_MISS) of the same launches says how "
+                "much of a kernel's traffic never left its XCD", "kernels": {}}
+l2p = os.path.join(SRC, "pmc_l2", "l2_counter_collection.csv")
+l2hit = pmc(l2p, "TCC_HIT_sum") if os.path.exists(l2p) else {}
+l2miss = pmc(l2p, "TCC_MISS_sum") if os.path.exists(l2p) else {}
 for k in sorted(fetch, key=lambda k: -fetch[k][0]):
     f, n = fetch[k]
     w, nw = write.get(k, (0.0, 0))
@@ -86,6 +92,8 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0]):
     fb, wb = f / n * 1024 * 2, (w / nw * 1024 if nw else 0.0)
     out["kernels"][k] = {"launches": n, "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                          "hbm_bytes_per_launch": round(fb + wb)}
+    if k in l2hit and (l2hit[k][0] + l2miss.get(k, (0.0, 0))[0]) > 0:
+        out["kernels"][k]["l2_hit_rate"] = round(l2hit[k][0] / (l2hit[k][0] + l2miss[k][0]), 4)
 json.dump(out, open(os.path.join(DST, f"{TAG}_pmc_traffic.json"), "w"), indent=1)
 # ---- MFMA utilisation: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs (= 32 x the 32x32x16 MFMA instructions, checked
 # against SQ_INSTS_MFMA); utilisation = busy / (1024 SIMDs x the kernel's cycles), the kernel's cycles taken from GRBM_GUI_ACTIVE

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from csbsr_amd import _lib as L
 import bench_conv as BC
 names = {0: "baseline", 1: "no halo DMA traffic", 2: "weights of step 0 every step", 4: "no LDS fragment reads", 8: "no weight loads",
-         5: "no DMA traffic + no LDS reads", 9: "no DMA traffic + no weight loads", 12: "no LDS reads + no weight loads", 13: "MFMA + issue only"}
+         16: "halo DMA from an L2-resident region", 24: "L2-resident halo + no weight loads", 13: "MFMA + issue only"}
 for abl, nm in names.items():
     L.load().csbsr_debug_set_conv_x3(1 | (abl << 4))
     print(f"--- ABL {abl}: {nm}")

@@ -3,8 +3,9 @@ buffer-descriptor windows of the LDS-DMA kernels (csrc/conv_x3.hip, conv_hr.hip,
 computation only exist at this size, and bench.py -- the only other full-size execution -- asserts nothing about its outputs.
 
   * one joint-phase step at B = 2: every output and every gradient finite; whether KBPN runs as one micro-batch of 2 or two of 1 (no
-    batch-coupled op) only moves fp32 summation orders -- which tiles a persistent workgroup folds into its partial sums of the global
-    average pools, how the wgrad slabs are split -- so outputs agree to 1e-4 and gradients to 2e-3;
+    batch-coupled op) moves fp32 summation orders (which tiles a persistent workgroup folds into its partial sums of the global average
+    pools, how the wgrad slabs are split) and, through the launch-size thresholds, which kernel takes a layer -- so the images agree to
+    fp16 storage noise (<= 2e-3 of their maximum), the losses to 1e-4, the gradients to 2e-3;
   * translation property: the LR 448 input built by tiling an LR 112 image 4 x 4 must reproduce, in the bottom-right corner of the LAST
     sample -- the highest addresses of every buffer -- the bottom-right corner of the LR 112 run (same zero padding below / right, far
     enough from the tile seams: KBPN in the SR-pretraining phase is purely convolutional, receptive field ~50 LR pixels).  Not bit for bit:
@@ -55,7 +56,9 @@ def test_full_size_step_is_finite_and_micro_batch_invariant():
         assert bool(torch.isfinite(v).all()), kk
         d = float((v - o1[kk]).abs().max() / v.abs().max())
         print(f"   {kk}: micro-batch 2 vs 1 max |diff| / max = {d:.2e}")
-        assert d <= 1e-4, kk
+        # images: which kernel takes a layer depends on the launch size (N = 1 or 2 here), and another accumulation order flips fp16 storage
+        # roundings -- the two schedules agree like two fp16 implementations (measured 2.6e-4 / 5.1e-4); the losses average that out
+        assert d <= (2e-3 if kk in ("seg", "sr", "kp") else 1e-4), kk
     assert len(g2) == 290 and set(g1) == set(g2)
     worst = 0.0
     for n, a in g2.items():

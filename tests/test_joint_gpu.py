@@ -109,6 +109,11 @@ def test_forward_matches_golden(case):
     # random-weight kernel predictor amplify the summation-order noise of the global-average-pool atomics: the HIP path's own run-to-run
     # spread is 1.3-1.5e-3 on this SR image (2e-4 on the default variant; scripts/determinism_test.py).  Its own bound: 4e-3
     tol_sr = 4e-3 if bool(g.get("pixel_shuffle", False)) else 1e-3
+    if not bool(g.get("residual_learning", True)):
+        # MODEL.SR_RESIDUAL_LEARNING = False: the SR image is the stack's output alone, max |sr| 0.48 instead of 1.19 with the (exactly
+        # computed) bicubic term, so the same absolute error -- 6.8e-4 of the image range here, 8e-4 for the default variant -- is 2.5x larger
+        # relative to this map's own maximum
+        tol_sr = 2.5e-3
     for k in ("sr_preds", "kernel_preds", "sr_loss"):
         # (with the w^F weight on, the SR loss is weighted by exp(|seg - mask|): it inherits the segmentation map's conditioning)
         assert worst[k] < (5e-3 if k == "sr_loss" and float(g.get("sfo_sr_amp", 0.0)) != 0 else tol_sr), (k, worst[k])
