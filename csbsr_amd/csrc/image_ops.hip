@@ -290,8 +290,9 @@ extern "C" int csbsr_blur_fwd(const float* x, const float* kvec, int32_t N, int3
   dim3 grid((OW + 15) / 16, (OH + 15) / 16, N * C);
   if (smem > 48 * 1024) {      // stride-8 windows (141^2 floats) need the opt-in above the default dynamic LDS limit
     CSBSR_CHECK(smem <= 160 * 1024, "blur_fwd: window does not fit LDS");
-    BLUR_DISPATCH(K, hipFuncSetAttribute(reinterpret_cast<const void*>(blur_fwd_kernel<KK>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)smem));
+    BLUR_DISPATCH(K, CSBSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(blur_fwd_kernel<KK>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess,
+                                 "blur_fwd: cannot reserve %d bytes of LDS", (int)smem));
   }
   BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_fwd_kernel<KK>), grid, dim3(256), smem, ST(s), x, kvec, C, H, W, OH, OW, stride, sub, y32,
                                       (half_t*)y16, y16_ld));
@@ -871,7 +872,7 @@ extern "C" int csbsr_sdf(const float* mask, float* sdf, float* scratch /*3*N*H*W
   const long npx = (long)N * H * W;
   float* g = scratch; float* posdis = scratch + npx; float* negdis = scratch + 2 * npx; float* mm = scratch + 3 * npx;
   hipStream_t st = ST(s);
-  hipMemsetAsync(mm, 0, 2 * N * sizeof(float), st);
+  CSBSR_CHECK(hipMemsetAsync(mm, 0, 2 * N * sizeof(float), st) == hipSuccess, "sdf: memset failed");
   hipLaunchKernelGGL(edt_cols_kernel, dim3(grid_for((long)N * W, 64)), dim3(64), 0, st, mask, g, N, H, W, 0);
   hipLaunchKernelGGL(edt_rows_kernel, dim3(N * H), dim3(256), W * sizeof(float), st, g, posdis, H, W, mm);
   hipLaunchKernelGGL(edt_cols_kernel, dim3(grid_for((long)N * W, 64)), dim3(64), 0, st, mask, g, N, H, W, 1);

@@ -731,3 +731,4 @@ def test_phase_decomposed_dgrad_with_the_residual_layers_epilogue_backward(H, W)
     assert relmax(from_fm(dxd), -dy) < 2e-3
     assert relmax(grad_acc(pb["b.bias"]).cpu(), ref_db) < 2e-3
     assert abs(float(grad_acc(pb["a"]).cpu()) - float(ref_da)) < 2e-3 * float((dy * (y / a0))[neg].abs().sum()) ** 0.5 + 2e-3 * abs(float(ref_da))
+
