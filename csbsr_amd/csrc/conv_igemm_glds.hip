@@ -22,10 +22,12 @@ extern "C" int csbsr_debug_read_ts(void* dst, long n) { return (int)hipMemcpyFro
 #else
 #define TS(i)
 #endif
-template <int BM, int NWM, int NSTAGE, int CT = 1>     // CT: 128-cout tiles per workgroup (2: a 256-cout tile, every wave 64 px x 128 couts)
+template <int BM, int NWM, int NSTAGE, int CT = 1>     // CT: 128-cout tiles per workgroup (2: a 256-cout tile, every wave 64 px x 128 couts;
+                                                       // 0: a 64-cout tile for the 33..64-cout layers, every wave 64 px x 32 couts)
 __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK p, const half_t* __restrict__ zero_page) {
-  constexpr int BN = 128 * CT, BKG = 64;
-  constexpr int TA = 2 * CT;                         // 32-cout MFMA tiles per wave
+  constexpr int BN = CT ? 128 * CT : 64, BKG = 64;
+  constexpr int TA = CT ? 2 * CT : 1;                // 32-cout MFMA tiles per wave
+  constexpr int SOW = BN > 128 ? 128 : BN;           // couts of the fp32 tile the epilogue stages at a time
   constexpr int NW = NWM * 2, NT = NW * 64;
   constexpr int XI = BM / 8, WI = BN / 8;            // wave-instructions per stage for the X / W tile
   constexpr int NI = (XI + WI) / NW;                 // per wave
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int RING_BYTES = NSTAGE * STAGE_BYTES;
   constexpr int OUT_LD = 64 + 4;
-  constexpr int EPI_BYTES = 128 * OUT_LD * 4;
+  constexpr int EPI_BYTES = BM * SOW * 4;
   constexpr int SM_BYTES = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
   static_assert(XI % NW == 0 && WI % NW == 0, "tile rows must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -300,9 +302,8 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   // stage at once, one LDS-only barrier, then every thread owns one 8-channel chunk of BM/RSTEP rows.  (Two 64-cout passes with
   // three full barriers, each also draining the previous pass's stores, made the epilogue longer than the 8-slice K loop of the
   // transposed conv.)
-  static_assert(BM * 128 * 4 <= RING_BYTES, "the staged tile must fit the ring");
   float* sO = reinterpret_cast<float*>(smem);
-  constexpr int CPR = 16;                     // 8-channel chunks per staged row (128 couts)
+  constexpr int CPR = SOW / 8;                // 8-channel chunks per staged row (128 couts; 64 for the narrow tile)
   const int cc8 = tid % CPR;
   constexpr int RSTEP = NT / CPR;
   const EpiFast fe = conv_epilogue_fast_setup(p, slope);      // conv_common.h
@@ -314,27 +315,27 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   constexpr int hh = decltype(HH)::value;
   if (hh > 0) lds_barrier();                 // the previous half's rows are read out
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < (TA < 2 ? TA : 2); ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int pix = wm * 64 + b * 32 + (lane & 31);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int slot = (wn * 64 + a * 32 + 8 * q + 4 * (lane >> 5)) >> 2;
+        const int slot = (wn * (SOW / 2) + a * 32 + 8 * q + 4 * (lane >> 5)) >> 2;
         const f16v& t = acc[2 * hh + a][b];
         f4 v = {t[4 * q + 0], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
-        *reinterpret_cast<f4*>(sO + pix * 128 + ((slot ^ (pix & 15)) << 2)) = v;
+        *reinterpret_cast<f4*>(sO + pix * SOW + ((slot ^ (pix & 15)) << 2)) = v;
       }
     }
   lds_barrier();
   if (hh == 0) TS(5);
-  const int lcol = CT == 1 ? cc8 * 8 : (cc8 >> 3) * 128 + hh * 64 + (cc8 & 7) * 8;      // this thread's 8 couts within the workgroup's BN
+  const int lcol = CT != 2 ? cc8 * 8 : (cc8 >> 3) * 128 + hh * 64 + (cc8 & 7) * 8;      // this thread's 8 couts within the workgroup's BN
   const int co = cout0 + lcol;
   float bias[8], ssum[8], ssq[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bias[e] = sBias[lcol + e]; ssum[e] = ssq[e] = 0.f; }
   if (fe.ok) {
-    constexpr int RPT = BM / RSTEP, EG = CT == 2 ? 2 : 8;
+    constexpr int RPT = BM / RSTEP, EG = CT == 2 ? 2 : (RPT < 8 ? RPT : 8);
     static_assert(RPT % EG == 0, "rows per thread must split into groups");
     auto rows = [&](auto EXTRA, auto BNSTAT) {       // EXTRA: a residual and / or the old output is combined in
 #pragma unroll 1
@@ -364,8 +365,8 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
         for (int i = 0; i < EG; ++i) {
           if (!live[i]) continue;
           const int row = tid / CPR + (g * EG + i) * RSTEP;
-          const f4 v0 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8) ^ (row & 15)) << 2));
-          const f4 v1 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8 + 1) ^ (row & 15)) << 2));
+          const f4 v0 = *reinterpret_cast<const f4*>(sO + row * SOW + (((2 * cc8) ^ (row & 15)) << 2));
+          const f4 v1 = *reinterpret_cast<const f4*>(sO + row * SOW + (((2 * cc8 + 1) ^ (row & 15)) << 2));
           const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
           conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, bias, co, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq, mm[i]);
         }
@@ -396,8 +397,8 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
         if (rn[i] < 0) continue;
         const int row = tid / CPR + (g * EG + i) * RSTEP;
         float v[8];
-        const f4 v0 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8) ^ (row & 15)) << 2));
-        const f4 v1 = *reinterpret_cast<const f4*>(sO + row * 128 + (((2 * cc8 + 1) ^ (row & 15)) << 2));
+        const f4 v0 = *reinterpret_cast<const f4*>(sO + row * SOW + (((2 * cc8) ^ (row & 15)) << 2));
+        const f4 v1 = *reinterpret_cast<const f4*>(sO + row * SOW + (((2 * cc8 + 1) ^ (row & 15)) << 2));
         v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3]; v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
         conv_epilogue_row(p, v, bias, slope, co, rn[i], roy[i], rox[i], ssum, ssq, &pre[i]);
       }
@@ -416,18 +417,19 @@ static int g_glds_phase_flat = 1;
 static int g_glds_tile2d = 1;
 static int g_glds_tap_group = 1;
 static int g_glds_wide = 1;
+static int g_glds_narrow = 1;
 
 template <int BM, int NWM, int NSTAGE, int CT = 1>
 static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   ConvK p = k;
-  constexpr int BN = 128 * CT;
+  constexpr int BN = CT ? 128 * CT : 64, SOW = BN > 128 ? 128 : BN;
   p.tiles_m = (unsigned)((maxM + BM - 1) / BM);
   p.tile2d = (g_glds_tile2d && !k.transposed && k.KHt * k.KWt > 1 && k.OW % 16 == 0 && k.OH % (BM / 16) == 0) ? 1 : 0;      // same tile count
   p.tap_group = (g_glds_tap_group && !k.transposed && k.stride > 1 && k.dil == 1 && k.KHt > k.stride && k.KHt % k.stride == 0 &&
                  k.KWt > k.stride && k.KWt % k.stride == 0) ? 1 : 0;
   p.tiles_n = (unsigned)((k.coutp + BN - 1) / BN);
   constexpr int RING = NSTAGE * (BM + BN) * 128;
-  constexpr int EPI = BM * 128 * 4;
+  constexpr int EPI = BM * SOW * 4;
   constexpr int SM_BYTES = (RING > EPI ? RING : EPI) + BM * (4 * 8 + 3 * 4) + 3 * BN * 4;      // ring / staged tile + row tables + statistics + bias
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
   static LdsAttrOnce attr;
@@ -453,6 +455,7 @@ extern "C" void csbsr_debug_set_conv_glds(int mode) {
   g_glds_tap_group = (mode & 128) ? 0 : 1;       // bit 7: raster tap order on the strided layers (A/B timing)
   g_glds_tile2d = (mode & 64) ? 0 : 1;           // bit 6: linear pixel tiles everywhere (A/B timing)     // bit 5: phases back on grid.z (A/B timing)
   g_glds_wide = (mode & 256) ? 0 : 1;            // bit 8: no 256-cout tile (A/B timing)
+  g_glds_narrow = (mode & 1024) ? 0 : 1;         // bit 10: no 64-cout tile, 33..64-cout layers back on the register-staged kernel (A/B timing)
   conv_thin_enable((mode & 16) ? 0 : 1);      // bit 4: route the 3-channel heads through the generic kernel (A/B timing)
   conv_thin_cin2_enable((mode & 512) ? 0 : 1);  // bit 9: no streaming variant of the 3-channel-input kernel (A/B timing, tests)
 }
@@ -460,7 +463,7 @@ extern "C" void csbsr_debug_set_conv_glds(int mode) {
 // eligibility: MFMA-bound shapes only
 bool conv_glds_eligible(const ConvK& k) {
   if (g_glds_mode == 0) return false;
-  if (k.coutp <= 64) return false;
+  if (k.coutp <= 32 || (k.coutp <= 64 && !g_glds_narrow)) return false;      // 33..64 couts: the 64-cout tile
   if (k.ctot % 64 != 0) return false;
   if (k.c0 != k.ctot && k.c0 % 64 != 0) return false;
   if (k.rows_p % 128 != 0) return false;      // packed weights padded to the 128-row tile (csbsr_pack_weights does)
@@ -476,6 +479,7 @@ int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   // 256 px x 256 couts (128 flop per staged byte instead of 85) where the couts fill 256-wide tiles about as well as 128-wide ones
   const int pad128 = (k.coutp + 127) / 128 * 128, pad256 = (k.coutp + 255) / 256 * 256;
   const bool wide = big && g_glds_wide && k.coutp >= 256 && pad256 * 8 <= pad128 * 9 + 64;
+  if (k.coutp <= 64) { g_last_conv_kernel = CONVK_GLDS64; return launch_glds<128, 2, 2, 0>(k, nphase, maxM, st); }
   g_last_conv_kernel = big ? (wide ? CONVK_GLDS256W : CONVK_GLDS256) : CONVK_GLDS128;
   if (!big) return launch_glds<128, 2, 2>(k, nphase, maxM, st);
   if (wide) return launch_glds<256, 4, 2, 2>(k, nphase, maxM, st);

@@ -61,6 +61,10 @@ if __name__ == "__main__":
         "c128": (1, 448, 448, 128, 128, 3, 1, 1),
         "res256": (8, 224, 224, 256, 256, 3, 1, 1),
         "up1024": (1, 448, 448, 1024, 256, 3, 1, 1),
+        "up3_64": (1, 1792, 1792, 64, 64, 3, 1, 1),            # detector decoder, 64-cout layers (the 64-cout LDS-DMA tile)
+        "up3_128_64": (1, 1792, 1792, 128, 64, 3, 1, 1),
+        "up2_256_64": (1, 896, 896, 256, 64, 3, 1, 1),
+        "l1_64": (1, 448, 448, 64, 64, 3, 1, 1),
     }
     for n, sh in shapes.items():
         if sel in ("all", n):

@@ -68,6 +68,11 @@ CASES = [
     (768, 128, 3, 1, 1, 1, False, 24, 24),         # 6912 wgrad columns: the 128 x 256 eight-wave wgrad tile
     (256, 256, 3, 1, 1, 1, False, 192, 192),       # 256 px x 256 cout LDS-DMA tile (two staged epilogue passes), 2-D pixel tiles
     (264, 505, 3, 1, 1, 1, False, 190, 194),       # the same with a partly empty second cout tile, ragged pixel tiles, K padding
+    (64, 64, 3, 1, 1, 1, False, 40, 70),           # 64-cout LDS-DMA tile (33..64 couts, input channels a multiple of 64), ragged pixel tiles
+    (128, 49, 3, 1, 2, 2, False, 14, 18),          # the same, dilated, couts padded 49 -> 56 (dgrad: 128 couts from 64 padded channels -> general kernel)
+    (256, 64, 1, 1, 0, 1, False, 32, 48),          # 1x1, 2-D pixel tiles off
+    (128, 64, 8, 4, 2, 1, True, 12, 8),            # transposed into 64 couts: 16 phases on the 64-cout tile
+    (64, 64, 3, 2, 1, 1, False, 48, 64),           # strided; its dgrad is a gather-form transposed conv on the 64-cout tile
 ]
 
 
