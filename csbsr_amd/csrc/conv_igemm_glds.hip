@@ -466,7 +466,7 @@ bool conv_glds_eligible(const ConvK& k) {
   if (k.coutp <= 32 || (k.coutp <= 64 && !g_glds_narrow)) return false;      // 33..64 couts: the 64-cout tile
   if (k.ctot % 64 != 0) return false;
   if (k.c0 != k.ctot && k.c0 % 64 != 0) return false;
-  if (k.rows_p % 128 != 0) return false;      // packed weights padded to the 128-row tile (csbsr_pack_weights does)
+  if (k.rows_p % (k.coutp <= 64 ? 64 : 128) != 0) return false;      // packed weights padded to the tile's rows (csbsr_pack_weights does)
   if (k.KHt * k.KWt > 64) return false;       // one validity bit per tap in a 64-bit mask
   return true;
 }

@@ -368,13 +368,18 @@ class Conv:
             L.call("csbsr_conv_forward", C.byref(d), self.eng.stream)
         if tm is not None:
             ev1.record()
-            ctot = sum(f.c for f in xs)
+            # algorithmic work of the layer: ONE product per (pixel, cout, cin, tap).  The split-precision launches execute more --
+            # three K blocks for a hi+lo input against hi+lo weights, two for a gradient against hi+lo weights (the same tensor passed
+            # twice) -- which goes into the last field, not into the FLOPs
+            twice = len(xs) == 2 and xs[0] is xs[1]
+            ctot = xs[0].c if twice else sum(f.c for f in xs)
+            executed = 3 if x0.lo else (2 if twice else 1)
             npx = x0.N * OH * OW
             taps = k * k if not transposed else ((k + stride - 1) // stride) ** 2
             flops = 2.0 * npx * cout * ctot * taps
-            nbytes = 2.0 * (sum(0 if f.bcast else f.N * f.H * f.W * f.c for f in xs) + (npx * cout if out is not None else 0))
+            nbytes = 2.0 * (sum(0 if f.bcast else f.N * f.H * f.W * f.c for f in (xs[:1] if twice else xs)) + (npx * cout if out is not None else 0))
             tm.append(("conv", flops, nbytes, ev0, ev1, self.name, (x0.N, H, W, ctot, cout, k, stride, int(transposed)),
-                       int(L.load().csbsr_debug_last_conv_kernel())))
+                       int(L.load().csbsr_debug_last_conv_kernel()), executed))
 
     def fwd(self, x, out=None, out32=None, res=None, res2=None, res_mode=L.RES_NONE, stat=None, stat_mode=L.STAT_NONE, store=True):
         xs = x if isinstance(x, (tuple, list)) else (x,)

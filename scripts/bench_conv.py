@@ -65,6 +65,7 @@ if __name__ == "__main__":
         "up3_128_64": (1, 1792, 1792, 128, 64, 3, 1, 1),
         "up2_256_64": (1, 896, 896, 256, 64, 3, 1, 1),
         "l1_64": (1, 448, 448, 64, 64, 3, 1, 1),
+        "bs_scale1": (1, 1792, 1792, 505, 64, 3, 1, 1),        # PSPNet_BlurSkip conv_scale.1 (config 5)
     }
     for n, sh in shapes.items():
         if sel in ("all", n):
