@@ -4,7 +4,7 @@
 // to LDS exactly as loaded ([pixel][channel], 16-byte channel chunks) and the MFMA fragments -- which want 8
 // consecutive *pixels* per lane -- are fetched with the gfx950 hardware transpose read ds_read_b64_tr_b16
 // (two per fragment), so no shuffle / scalar-LDS transposition is needed.  fp32 accumulate; the pixel range is
-// split across grid.z and combined with fp32 atomics.
+// split across grid.z, every split writes its own fp32 slab and csbsr_unpack_wgrad sums the slabs in a fixed order.
 //
 // Autograd wgrad of F.conv2d / F.conv_transpose2d at the call sites listed in conv_igemm.hip.
 #include "common.h"

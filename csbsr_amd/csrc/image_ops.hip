@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void blur_bwd_input_s4_kernel(const float* dy,
 // dk[n][ky*K+kx] = sum_{c,oy,ox} dy[n,c,oy,ox] * x[n,c,oy*s-P+ky, ox*s-P+kx]
 // Tiled: a workgroup stages a TOxTO tile of dy and the matching x window in LDS, every thread owns up to two taps and sweeps the
 // tile (dy is a wave-wide broadcast read, the x reads of neighbouring taps are neighbouring words), and accumulates over
-// ``tiles_per_wg`` tiles before one atomic per tap.  (The first version walked the whole plane once per tap with two 64-bit
+// ``tiles_per_wg`` tiles before writing one partial row (folded in fixed order afterwards).  (The first version walked the whole plane once per tap with two 64-bit
 // divisions per element: 2.1 ms per launch at HR.)
 template <int K>
 __global__ __launch_bounds__(256) void blur_bwd_kernel_kernel(const float* dy, const float* x, float* dk, int C, int H, int W, int OH,
@@ -335,7 +335,7 @@ extern "C" int csbsr_blur_bwd_kernel(const float* dy, const float* x, float* dk,
   CSBSR_CHECK(smem <= 64 * 1024, "blur_bwd_kernel: window does not fit LDS");
   const int tiles_x = (OW + TO - 1) / TO, tiles_y = (OH + TO - 1) / TO;
   const int total = C * tiles_x * tiles_y;
-  int tpw = (total + 1023) / 1024;          // ~1024 workgroups per sample at most: bounds the atomics per tap
+  int tpw = (total + 1023) / 1024;          // ~1024 workgroups per sample at most: bounds the partial rows per tap
   if (tpw < 1) tpw = 1;
   dim3 grid((total + tpw - 1) / tpw, N);
   float* part = csbsr_red_scratch((long)N * grid.x * 512);

@@ -102,5 +102,5 @@ def test_patch_tiled_evaluation_step():
         for iy in range(2):
             for ix in range(2):
                 tile = out["sr_preds"][b, :, iy * 64:(iy + 1) * 64, ix * 64:(ix + 1) * 64]
-                # (two runs differ at the fp16-rounding level: fp32 atomics order in the kernel predictor's average-pool sums)
+                # (the patch batch of 8 and the whole-image run pick different kernels / summation orders for some layers: fp16-rounding level)
                 assert float((tile - sr_p[b * 4 + iy * 2 + ix].clamp(0, 1)).abs().max()) < 2e-3

@@ -5,9 +5,9 @@ reducer, the bucket layout, the side-stream launches and their ordering are the 
   * iter 40000 (joint phase, BatchNorm per replica as in the reference's multi-GPU behaviour): every bucket -- the segmentation
     bucket launched under the KBPN backward, the per-stage KBPN buckets launched under the last micro-batch's backward -- ends up
     holding exactly the mean over ranks of what it held when it was launched (nothing launched early, twice or not at all), in the
-    order the backward completes them.  (Comparing with separately computed single-process gradients is not a test there: two runs
-    of the SAME shard differ by ~20 % in relative L2 at this size -- fp32-atomics order in the kernel predictor's pooling sums
-    flips fp16 roundings of the SR image and the random-weight detector amplifies that, see tests/test_wc_parity_gpu.py.)
+    order the backward completes them.  (Comparing with separately computed single-process gradients is not a test there: BatchNorm
+    statistics are per replica, so 2 x B=2 and 1 x B=4 are different functions in the joint phase.  Two runs of the SAME shard are
+    bit-identical since round 3 -- tests/test_determinism_gpu.py.)
 """
 import os
 import socket

@@ -352,7 +352,7 @@ def test_instance_norm_fwd_bwd():
 
 @pytest.mark.parametrize("shape", [(2, 9, 11, 24), (1, 70, 66, 56), (2, 64, 64, 136)])
 def test_border_class_fill_and_sums(shape):
-    """constant-operand folding helpers: class fill and its adjoint (small-image atomics path and the large-image path)."""
+    """constant-operand folding helpers: class fill and its adjoint (small-image path and the large-image path)."""
     from csbsr_amd import _lib as L
     eng = _eng()
     N, H, W, Cc = shape

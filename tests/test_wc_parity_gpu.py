@@ -154,12 +154,12 @@ def test_detector_on_reference_sr(case, precision):
             # ~940 tensors judged on 32 sampled elements each (the fixture cannot hold 75 M gradient values): the estimate of a
             # tensor's relative L2 error carries ~12 % sampling noise, so the bounds are median 2.5e-2, 90th percentile 4e-2 and 8e-2 on the
             # worst tensor; the same network's FULL gradient tensors are held to 3e-2 each against the oracle in tests/test_hrnet_gpu.py
-            # (measured over runs: median 1.5-1.6e-2, p90 2.9-3.0e-2 -- the atomics' summation order moves them in the third digit)
+            # (measured: median 1.5-1.6e-2, p90 2.9-3.0e-2)
             _assert_grads(errs, None, f"{case} detector gradients [split]", dist_only=(2.5e-2, 4e-2, 8e-2))
         else:
             _assert_grads(errs, 3e-2, f"{case} detector gradients [split]")
         # dLoss/dSR: 3e-2 for PSPNet (measured 1.3e-2); the HRNet-OCR gradient comes back through ~300 BatchNorm'd layers and sits AT
-        # 3.0e-2 run to run (atomic summation order), so its fixed bound is 5e-2
+        # 3.0e-2, so its fixed bound is 5e-2
         assert e_dsr < (5e-2 if str(g["detector"]) == "HRNet_OCR" else 3e-2), e_dsr
     else:
         # plain fp16 storage: every layer's 2^-11 rounding goes through the same ~100x amplification as an input perturbation (module
