@@ -39,6 +39,8 @@
 constexpr int x3_ninst(int KS) { return (((X3_TH + KS - 1) * (X3_TW + KS - 1) * X3_SLOTS + 63) / 64 + 3) / 4 * 4; }
 constexpr int x3_buf(int KS) { return x3_ninst(KS) * 1024; }
 
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
 struct X3Extra {
   unsigned tiles_x, tiles_y, nct, nch;   // pixel tiles, 128-cout tiles, chunks (64 channels [x input phase])
   unsigned ncc;                          // 64-channel chunks per input phase (KS = 2)
@@ -57,7 +59,7 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_make_rs(const half_t
 
 // ABL (builds with -DCSBSR_X3_ABLATE only; timing experiments, results are garbage): 1 halo DMA pieces fetch nothing (out-of-range
 // offsets), 2 every K step loads the weights of step 0, 4 no LDS fragment reads in the K loop, 8 no weight loads in the K loop,
-// 16 every halo comes from the same few (L2-resident) rows of the input
+// 16 every halo comes from the same few (L2-resident) rows of the input, 32 halo pieces through registers + ds_write instead of LDS-DMA
 template <int KS, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Extra q, const half_t* __restrict__ zero_page) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -124,11 +126,30 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + buf * X3_BUF + (wid + 4 * i) * 1024), 16,
                                              ok ? voff[i] : -1, 0, 0, 0);
   };
+  // ABL & 32: the same pieces through registers (buffer load -> VGPRs, ds_write_b128 LAG k-slices later) instead of LDS-DMA
+  constexpr bool STG = (ABL & 32) != 0;
+  constexpr int LAG = KS == 3 ? 8 : 4;
+  static_assert(!STG || NFI + LAG <= NT * 4, "staged pieces must be written inside the chunk that loads them");
+  auto load_piece = [&](__amdgpu_buffer_rsrc_t rs, int by, int bx, int i) __attribute__((always_inline)) -> u4v {
+    const bool ok = (unsigned)(iy0[i] + by) < (unsigned)p.H && (unsigned)(ix0[i] + bx) < (unsigned)p.W;
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? voff[i] : -1, 0, 0);
+  };
+  auto store_piece = [&](const u4v& v, int i, int buf) __attribute__((always_inline)) {
+    *reinterpret_cast<u4v*>(smem + buf * X3_BUF + (wid + 4 * i) * 1024 + lane * 16) = v;
+  };
   auto issue_x = [&](int n, int Y0, int X0, int chunk, int buf) {
     int by, bx;
     const __amdgpu_buffer_rsrc_t rs = x3_make_rs(chunk_src(n, Y0, X0, chunk, by, bx));
+    if constexpr (STG) {
+      u4v t[NFI];
 #pragma unroll
-    for (int i = 0; i < NFI; ++i) issue_one(rs, by, bx, i, buf);
+      for (int i = 0; i < NFI; ++i) t[i] = load_piece(rs, by, bx, i);
+#pragma unroll
+      for (int i = 0; i < NFI; ++i) store_piece(t[i], i, buf);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NFI; ++i) issue_one(rs, by, bx, i, buf);
+    }
   };
   auto decode = [&](unsigned item, int& ct, int& n, int& Y0, int& X0) {
     // The cout tiles of ONE pixel tile are consecutive items, and an XCD owns a contiguous run of the item order (xcd_remap: the
@@ -189,7 +210,8 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
       // chunk c's halo has landed everywhere, and every wave is done with the other buffer (chunk c - 1): refill that one.  The only
       // vector-memory instructions issued after this chunk's last DMA piece (k-slice NFI - 1 of the previous chunk) are the weight
       // loads of the taps that followed it (8 each) -- except right after an epilogue, where the count is simply drained.
-      if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (STG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's staged pieces are in LDS
+      else if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NT - 1 - (NFI - 1) / 4)) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -203,6 +225,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
       asm volatile("" ::: "memory");
       const char* xb = xl + ((par + c) & 1) * X3_BUF;
       h8 bfr[4];
+      u4v stg[LAG];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) bfr[nt] = *reinterpret_cast<const h8*>(xb + (nt * X3_HW) * X3_PITCH);      // tap (0,0), k-slice 0
 #pragma unroll
@@ -226,7 +249,13 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
             if (ABL & 4) {}
             else if (kk < 3) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + ky) * X3_HW + kx) * X3_PITCH + (kk + 1) * 32);
             else if (tap < NT - 1) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + (tap + 1) / KS) * X3_HW + (tap + 1) % KS) * X3_PITCH);
-            if (i == 1 && tap * 4 + kk < NFI) issue_one(nrs, nby, nbx, tap * 4 + kk, bnext);       // one DMA piece per k-slice
+            if constexpr (STG) {
+              if (i == 1) {
+                const int sl = tap * 4 + kk;
+                if (sl >= LAG && sl - LAG < NFI) store_piece(stg[(sl - LAG) % LAG], sl - LAG, bnext);
+                if (sl < NFI) stg[sl % LAG] = load_piece(nrs, nby, nbx, sl);
+              }
+            } else if (i == 1 && tap * 4 + kk < NFI) issue_one(nrs, nby, nbx, tap * 4 + kk, bnext);       // one DMA piece per k-slice
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -423,6 +452,12 @@ extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
       default: break;
     }
   }
+  // 32: register-staged halo pieces (results are correct with this one).  Measured against the LDS-DMA pieces in one process
+  // (scripts/x3_stage_ab.py, N = 4): 825 -> 384 1104 vs 1105 TF/s, its dgrad 842 vs 820, 384 -> 825 893 vs 868, the 8x8 stride-4 conv 945 vs
+  // 970 -- so the LDS-DMA instruction itself is not what the halo stream costs
+  if (g_conv_x3_abl == 32)
+    return strided ? launch_x3<2, 32>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s))
+                   : launch_x3<3, 32>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s));
 #endif
   return strided ? launch_x3<2>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s))
                  : launch_x3<3>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s));
