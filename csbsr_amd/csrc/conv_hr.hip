@@ -352,7 +352,7 @@ static bool hr_geometry(int ksize, int c_real, int rows_real, int& ch8, int& nks
   else return false;
   nks = (ksize * ksize * ch8 + 1) / 2;
   ntile_c = (round_up(rows_real, 8) + 31) / 32;
-  return rows_real >= 1 && ntile_c <= 2;
+  return rows_real >= 1 && (ntile_c <= 2 || ntile_c == 4);      // 4: two groups of workgroups, two 32-cout tiles each (128 couts)
 }
 
 extern "C" int64_t csbsr_packed_weight_elems_hr(int32_t ksize, int32_t c_real, int32_t rows_real) {
@@ -365,7 +365,7 @@ extern "C" int csbsr_pack_weights_hr(const float* w, void* dst, int32_t kind, in
                                      int32_t row_off, int32_t k_off, csbsr_stream_t s) {
   CSBSR_CHECK(w && dst && (kind == 0 || kind == 1), "pack_hr: bad args");
   PackHrK p;
-  CSBSR_CHECK(hr_geometry(ksize, c_real, rows_real, p.ch8, p.nks, p.ntile_c), "pack_hr: 1x1 or 3x3, channels must pad to 32 or 56, rows to <= 64");
+  CSBSR_CHECK(hr_geometry(ksize, c_real, rows_real, p.ch8, p.nks, p.ntile_c), "pack_hr: 1x1 or 3x3, channels must pad to 32 or 56, rows to <= 64 or to 128");
   p.ks = ksize;
   const int kdim = kind == 0 ? D1 : D0, rdim = kind == 0 ? D0 : D1;
   CSBSR_CHECK(k_off >= 0 && k_off + c_real <= kdim && row_off >= 0 && row_off + rows_real <= rdim, "pack_hr: range out of bounds");
@@ -378,13 +378,14 @@ extern "C" int csbsr_pack_weights_hr(const float* w, void* dst, int32_t kind, in
 }
 
 // Which launches take this kernel: 3x3 / pad 1 or 1x1 / pad 0, stride 1, dilation 1, one plain-fp16 input segment of 32 or 56 (padded) channels,
-// <= 64 output channels, ReLU / LeakyReLU / no activation, no bias / residual / accumulate / fp32 side output / BatchNorm sums; large
+// <= 64 (or exactly 128: two workgroup groups, each re-reading the halo) output channels, ReLU / LeakyReLU / no activation, no bias / residual / accumulate / fp32 side output / BatchNorm sums; large
 // maps only (the tile grid must fill the chip).
 extern "C" int32_t csbsr_conv_hr_eligible(const csbsr_conv_desc_t* d) {
   if (!d || d->transposed || d->KH != d->KW || d->stride != 1 || d->dil != 1) return 0;
   if (!((d->KH == 3 && d->pad == 1) || (d->KH == 1 && d->pad == 0))) return 0;
   if (d->in[1].c != 0 || d->in[0].sx == 0 || (d->in[0].c != 32 && d->in[0].c != 56)) return 0;
-  if (d->coutp > 64 || d->OH != d->H || d->OW != d->W) return 0;
+  if ((d->coutp > 64 && d->coutp != 128) || d->OH != d->H || d->OW != d->W) return 0;
+  if (d->coutp == 128 && (d->stat_mode != CSBSR_STAT_NONE || d->mask)) return 0;      // 128 couts: the plain variant only
   if (d->bias || d->cbias || d->res_mode != CSBSR_RES_NONE || d->accumulate || d->out32 || d->o_lo) return 0;
   if (d->act != CSBSR_ACT_NONE && d->act != CSBSR_ACT_RELU && d->act != CSBSR_ACT_LRELU) return 0;
   if (d->stat_mode == CSBSR_STAT_BN || d->out_scale != 1.0f) return 0;
@@ -438,7 +439,7 @@ extern "C" int csbsr_conv_hr_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   CSBSR_CHECK(d->in[0].sy < (1l << 31) / 64, "conv_hr: row stride too large for 32-bit piece offsets");
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   g_last_conv_kernel = CONVK_HR;
-  const bool two = k.ntile_c == 2;
+  const bool two = k.ntile_c >= 2;
   if (d->KH == 3) {
     if (d->in[0].c == 32) return two ? launch_hr<4, 9, 2>(k, st) : launch_hr<4, 9, 1>(k, st);
     return two ? launch_hr<7, 9, 2>(k, st) : launch_hr<7, 9, 1>(k, st);

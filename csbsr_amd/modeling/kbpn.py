@@ -9,6 +9,8 @@ backward pass is hand-scheduled (gradient fan-in by accumulate flags, no autogra
 """
 import ctypes as C
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -126,6 +128,8 @@ class KBPN:
         self.U = up.reshape(kc, self.kk).t().contiguous().to(eng.device)       # [kk, kc]
         self.kc = kc
         self.saved = None
+        self._gather = {}
+        self.gather = os.environ.get("CSBSR_GATHER_DCH", "1") != "0"      # backward: gather each stage's slice of d(concat_h) (see _gather_conv)
         self.Mtap = border_tap_mask().to(eng.device)       # folded constant-operand convs: see _kernel_branch_fwd / Conv.fwd_folded
         self.Rtap = ring_tap_classes().to(eng.device)
 
@@ -148,6 +152,34 @@ class KBPN:
     def invalidate(self):
         for l in self.layers:
             l.invalidate()
+        self._gather = {}
+
+    def _gather_conv(self, kind, s):
+        """The gradient of stage ``s``'s 128-channel slice of the concatenated HR features (``concat_h``, kbpn.py:355-372) is a sum of
+        convolutions of small maps: the 3-channel dPre of ``output_conv`` and of every later stage's ``sr_reconst`` through their 3x3
+        weights ("img"), and the 128-channel dPre of this and every later stage's ``down.conv`` through their 1x1 weights ("down").
+        Autograd adds them one producer at a time -- each a read-modify-write of a multi-GB slice of the gradient buffer.  Here the
+        producers' dPre maps are kept side by side as channel slots of one buffer each, the matching weight slices are stacked into
+        ONE gradient-free conv per kind and stage (rebuilt when the master weights change), and the slice is produced when its stage
+        needs it: one write and one read-modify-write instead of up to seven."""
+        c = self._gather.get((kind, s))
+        if c is None:
+            sl = slice(128 * (s - 1), 128 * s)
+            if kind == "img":        # slot 0: output_conv, slot t: sr_reconst of stage S - t + 1 (t = 1 .. S - s)
+                ws = [self.output_conv.w[:, sl]] + [self.stages[sp - 1].sr_reconst.w[:, sl] for sp in range(self.S, s, -1)]
+                if len(ws) == 1:
+                    w = ws[0].detach().contiguous()
+                else:                # 3 real + 5 zero rows per slot: the slots are 8-channel aligned (FM channel granularity); always the
+                    # whole (zero-filled) slot buffer, so every stage's launch has the 32-channel shape the direct HR kernel takes
+                    w = torch.zeros(8 * self.S, 128, 3, 3, dtype=torch.float32, device=self.eng.device)
+                    for t, wt in enumerate(ws):
+                        w[8 * t:8 * t + 3] = wt.detach()
+                c = Conv(self.eng, "gather", {"gather.weight": w}, 3, 1, 1, bias=False)
+            else:                    # slot u: down.conv of stage S - 1 - u (u = 0 .. S - 1 - s)
+                w = torch.cat([self.stages[sp - 1].down_conv.w[:, sl].detach() for sp in range(self.S - 1, s - 1, -1)], 0).contiguous()
+                c = Conv(self.eng, "gather", {"gather.weight": w}, 1, 1, 0, bias=False)
+            self._gather[(kind, s)] = c
+        return c
 
     # ------------------------------------------------------------------ helpers
     def _kfm(self, vec, H, W):
@@ -298,13 +330,27 @@ class KBPN:
         B, h, w = sv["B"], sv["h"], sv["w"]
         H, W = h * self.scale, w * self.scale
         concat_h, concat_l = sv["concat_h"], sv["concat_l"]
-        dch = e.new(B, H, W, 128 * self.S, zero=False)      # first written (every channel, every pixel) by output_conv's dgrad below
+        S = self.S
+        # The gradient of the concatenated HR features is never held as a whole (13 GB at micro-batch 4, read-modify-written by six
+        # dgrads): its producers' small dPre maps wait in the slots of these two buffers and each stage's 128-channel slice is
+        # gathered when the stage's backward starts (_gather_conv).
+        # (self.gather = False, CSBSR_GATHER_DCH=0: autograd's order -- the whole gradient buffer, every producer accumulating into it
+        # as it runs; kept for same-run A/B timing and as a cross-check of the gathered path in tests/test_kbpn_gather_gpu.py)
+        gather = self.gather
+        dimg = e.new(B, H, W, 8 * S, zero=True) if gather else None                # slot 0: output_conv, slot S - s + 1: sr_reconst(s)
+        dxdc = e.new(B, H, W, 128 * (S - 1), zero=False) if (gather and S > 1) else None      # slot S - 1 - s: down.conv(s)
+        dch = None if gather else e.new(B, H, W, 128 * S, zero=False)
+        img_slot = lambda t: dimg.slice(8 * t, 8 * t + 8, creal=3)
         dcl = e.new(B, h, w, 128 * (self.S - 1), zero=True) if self.S > 1 else None
         # output conv
-        dpre = e.nchw32_to_fm(dsr32)
-        self._wg(self.output_conv, dpre, concat_h)
-        self.output_conv.bwd_input(dpre, out=dch, accumulate=False)     # no 13 GB zero fill + read-back at micro-batch 4
-        del dpre
+        # (a slot's pixels are 16 S bytes apart: the weight gradients and the single-producer launches read a compact copy instead --
+        # through the slots the thin wgrads ran 40 % slower)
+        dpre_out = e.nchw32_to_fm(dsr32)
+        if gather and S > 1:
+            e.nchw32_to_fm(dsr32, out=img_slot(0))
+        self._wg(self.output_conv, dpre_out, concat_h)
+        if not gather:
+            self.output_conv.bwd_input(dpre_out, out=dch, accumulate=False)
         dvec_next = dkvec_final.clone()     # gradient wrt the normalised kernel vector leaving stage s
         dlowp = None
         for s in range(self.S, 0, -1):
@@ -334,7 +380,7 @@ class KBPN:
                 self._wg(st.down3, dlow_s, q["dd"])
                 # (down_conv2's epilogue-backward pass -- PReLU derivative from dd + xd, bias / slope sums, d(xd) = -dOut -- rides on
                 # down_conv3's dgrad where the phase-decomposed kernel takes the launch)
-                dxd = e.new(B, H, W, 128)
+                dxd = dxdc.slice(128 * (S - 1 - s), 128 * (S - s)) if gather else e.new(B, H, W, 128)
                 ddd = st.down3.bwd_input(dlow_s, in_hw=(H, W), dact=(st.down2, q["dd"]), dres=(q["xd"], dxd, L.RES_SUB))
                 if not st.down3.last_fused:
                     self._act_bwd(st.down2, ddd, q["dd"], res=q["xd"], res_mode=L.RES_SUB, dres=dxd)
@@ -349,13 +395,23 @@ class KBPN:
                     self._act_bwd(st.down_conv, dxd, q["xd"])
                 chp = concat_h.slice(0, 128 * s)
                 self._wg(st.down_conv, dxd, chp)
-                st.down_conv.bwd_input(dxd, out=dch.slice(0, 128 * s), accumulate=True)
+                if not gather:
+                    st.down_conv.bwd_input(dxd, out=dch.slice(0, 128 * s), accumulate=True)
                 del dxd
             # ---- KBlock backward
             hs = concat_h.slice(128 * (s - 1), 128 * s)
-            dhs = dch.slice(128 * (s - 1), 128 * s)
-            # out = act(pre) + h: the gradient wrt h IS dOut, so dPre goes to a fresh buffer and dOut's own storage (this stage's slice of
-            # dch, dead after this block) carries on as dh -- one HR write stream less than copying it out (same below for up3 / h0)
+            # this stage's slice of the concatenated gradient: every 3-channel producer so far in one write-only launch, then every
+            # down.conv producer in one accumulating launch
+            if gather:
+                dhs = e.new(B, H, W, 128)
+                nimg = S - s + 1
+                self._gather_conv("img", s).bwd_input(dpre_out if nimg == 1 else dimg, out=dhs, accumulate=False)
+                if s < S:
+                    self._gather_conv("down", s).bwd_input(dxdc.slice(0, 128 * (S - s)), out=dhs, accumulate=True)
+            else:
+                dhs = dch.slice(128 * (s - 1), 128 * s)
+            # out = act(pre) + h: the gradient wrt h IS dOut, so dPre goes to a fresh buffer and dOut's own storage (dead after this
+            # block) carries on as dh -- one HR write stream less than copying it out (same below for up3 / h0)
             dpk = e.new(B, H, W, 128)
             self._act_bwd(st.kb_up, dhs, hs, res=q["h"], res_mode=L.RES_ADD, dpre=dpk)
             dh = dhs
@@ -378,13 +434,14 @@ class KBPN:
             dvec_next = dkin
             # sr_t = sr_reconst(cat(concat_h[:128(s-1)], h))
             dpre = e.nchw32_to_fm(dsr_t)
+            if s > 1 and gather:
+                e.nchw32_to_fm(dsr_t, out=img_slot(S - s + 1))
+            if s > 1 and not gather:
+                st.sr_reconst.bwd_input(dpre, seg=0, out=dch.slice(0, 128 * (s - 1)), accumulate=True)
             segs = (concat_h.slice(0, 128 * (s - 1)), q["h"]) if s > 1 else (q["h"],)
             self._wg(st.sr_reconst, dpre, segs)
-            if s > 1:
-                st.sr_reconst.bwd_input(dpre, seg=0, out=dch.slice(0, 128 * (s - 1)), accumulate=True)
-                st.sr_reconst.bwd_input(dpre, seg=1, out=dh, accumulate=True)
-            else:
-                st.sr_reconst.bwd_input(dpre, seg=0, out=dh, accumulate=True)
+            # (its gradient wrt the earlier stages' slices waits in the slot; the part wrt this stage's own h is added now)
+            st.sr_reconst.bwd_input(dpre, seg=1 if s > 1 else 0, out=dh, accumulate=True)
             del dpre, dsr_t, derr
             # ---- UpBlock backward
             dpu = e.new(B, H, W, 128)

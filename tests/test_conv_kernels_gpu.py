@@ -339,6 +339,34 @@ def test_hr_direct_conv_kernel(cin, cout, act, ks):
     assert relmax(from_fm(dx), refd) < 2e-3
 
 
+def test_hr_direct_conv_kernel_128_couts():
+    """32 -> 128 channels on the direct kernel (two groups of workgroups, two 32-cout tiles each): the launch that gathers a stage's slice
+    of the concatenated feature gradient from the 3-channel dPre slots (KBPN._gather_conv) -- forward form, and the dgrad form the
+    backward actually uses (a conv with 32 'output' channels whose dgrad has 128), plain epilogue, ragged tiles."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    torch.manual_seed(5)
+    eng = _eng()
+    N, H, W = 2, 363, 371
+    x = torch.randn(N, 32, H, W).half().float()
+    x[:, 3:8] = 0
+    w = (torch.randn(128, 32, 3, 3) / 17.0).half().float()
+    conv = Conv(eng, "l", {"l.weight": w.cuda()}, 3, 1, 1, 1, bias=False)
+    y = conv.fwd(to_fm(eng, x))
+    torch.cuda.synchronize()
+    assert L.load().csbsr_debug_last_conv_kernel() == 8
+    assert relmax(from_fm(y), F.conv2d(x, w, None, 1, 1)) < 2e-3
+    wt = (torch.randn(32, 128, 3, 3) / 17.0).half().float()          # a conv 128 -> 32: its dgrad maps 32 channels to 128
+    conv2 = Conv(eng, "m", {"m.weight": wt.cuda()}, 3, 1, 1, 1, bias=False)
+    xr = torch.zeros(N, 128, H, W, requires_grad=True)
+    F.conv2d(xr, wt, None, 1, 1).backward(x)
+    out = eng.new(N, H, W, 128)
+    conv2.bwd_input(to_fm(eng, x), out=out, accumulate=False)
+    torch.cuda.synchronize()
+    assert L.load().csbsr_debug_last_conv_kernel() == 8
+    assert relmax(from_fm(out), xr.grad) < 2e-3
+
+
 @pytest.mark.parametrize("k,s,p,cin,cout,H,W,mode", [
     (8, 4, 2, 128, 128, 24, 40, "prelu_add"),      # up_conv3: PReLU + residual add, ragged tiles on both axes
     (8, 4, 2, 128, 128, 16, 64, "prelu"),          # up_conv1
