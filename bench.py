@@ -281,7 +281,7 @@ def main():
                                 "FETCH_SIZE doubled per MI355X_MICROARCH.md), same command at --batch 4 (one KBPN micro-batch of 4, as in the default run)" if traffic else None,
                 "mfma_pmc": mfma_pmc, "launches": nl, "avg_launch_ms": round(tt * 1e3 / max(nl, 1), 4),
                 "alg_flop_per_launch": round(fl / max(nl, 1) / 1e9, 2), "alg_flop_unit": "GFLOP",
-                "executed": round(flx / tt / 1e12, 1),
+                "executed": round(flx / tt / 1e12, 1), "executed_frac": round(flx / tt / 1e12 / MFMA_PEAK_TFLOPS, 4),
                 "executed_note": "MFMA work the kernel actually ran / its time: the split-precision detector launches multiply hi+lo operand pairs "
                                  "(3 K blocks per algorithmic product forward, 2 in the dgrads); 'achieved' and 'frac' count the algorithmic product once",
                 "alg_bytes_per_launch": round(by / max(nl, 1)), "share_of_step_time": round(tt / dt, 3),
