@@ -186,13 +186,20 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
       const half_t* src = (tapmask[i] & bit) ? xb + offc[i] : zp;
+#ifdef CSBSR_GLDS_ABLATE      // timing experiments only (results are garbage): bit 0 = every DMA source folded into one L2-resident 512 KB window
+      if ((CSBSR_GLDS_ABLATE & 1) && (tapmask[i] & bit)) src = xb0_0 + ((size_t)(src - xb0_0) & 0x3ffff);
+#endif
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sbase + (wid + NW * i) * 1024), 16, 0, 0);
     }
     const int wk = tap * p.ctot + cs;                                                        // column of this slice in the packed weights
 #pragma unroll
     for (int i = 0; i < NI - NXI; ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[i] + wk),
+      const half_t* wsrc = wrow[i] + wk;
+#ifdef CSBSR_GLDS_ABLATE
+      if (CSBSR_GLDS_ABLATE & 1) wsrc = wt + ((size_t)(wsrc - wt) & 0x3ffff);
+#endif
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
                                        (__attribute__((address_space(3))) void*)(sbase + BM * 128 + (wid + NW * (NXI + i) - XI) * 1024), 16, 0, 0);
     }
     if (++tcount == ntaps) {                  // next channel slice (wave-uniform branch)
@@ -247,11 +254,16 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt == 0) TS(3);
+    // (measured and dropped, r03: the second wave of each SIMD issuing its pieces half a stage later -- so that one wave's ~100 address /
+    // issue instructions run under the other's MFMAs -- changed nothing: 920 vs 926 TF/s on the ResNet 512 -> 512 layer)
     if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1);      // refills the buffer read in iteration kt-1
     const char* xs = smem + (kt % NSTAGE) * STAGE_BYTES;
     const char* ws = xs + BM * 128;
     // fragment double-buffering: the reads of sub-step ks+1 are in flight while the 4 MFMAs of sub-step ks issue
     auto load_frags = [&](int ks, h8 (&af)[TA], h8 (&bf)[2]) {
+#ifdef CSBSR_GLDS_ABLATE      // bit 1 = no LDS fragment reads after a tile's first K step (stale fragments)
+      if ((CSBSR_GLDS_ABLATE & 2) && (kt | ks)) return;
+#endif
       const int c = ks * 2 + (lane >> 5);
 #pragma unroll
       for (int a = 0; a < TA; ++a) {

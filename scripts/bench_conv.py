@@ -36,6 +36,8 @@ if __name__ == "__main__":
     it = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     if len(sys.argv) > 3:
         L.load().csbsr_debug_set_conv_glds(int(sys.argv[3]))
+    if os.environ.get("BENCH_NOX3"):          # the wide 3x3 layers on the LDS-ring kernel (as the detector's BatchNorm'd layers run)
+        L.load().csbsr_debug_set_conv_x3(0)
     what = tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else ("fwd",)
     nb = int(sys.argv[5]) if len(sys.argv) > 5 else None
     shapes = {

@@ -1,4 +1,4 @@
-"""Per-workgroup phase timestamps of the glds conv kernel (needs a -DCSBSR_TS build copied over libcsbsr_hip.so)."""
+"""Per-workgroup phase timestamps of the glds conv kernel (needs a -DCSBSR_TS build: CSBSR_LIB=<that library>)."""
 import sys, os, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,9 +8,10 @@ from csbsr_amd.engine import Engine, Conv, FM, pad8
 shape = sys.argv[1]; nb = int(sys.argv[2]); what = sys.argv[3]
 shapes = {"deconv8s4": (448, 448, 128, 128, 8, 4, 2, True), "conv8s4": (1792, 1792, 128, 128, 8, 4, 2, False), "c128": (448, 448, 128, 128, 3, 1, 1, False),
           "gemm1x1": (1792, 1792, 128, 128, 1, 1, 0, False), "hr32": (1792, 1792, 32, 32, 3, 1, 1, False), "hr49": (1792, 1792, 49, 49, 3, 1, 1, False),
-          "hr64": (1792, 1792, 64, 64, 3, 1, 1, False)}
+          "hr64": (1792, 1792, 64, 64, 3, 1, 1, False), "res512": (224, 224, 512, 512, 3, 1, 1, False), "up1024": (448, 448, 1024, 256, 3, 1, 1, False)}
 H, W, cin, cout, k, s, p, tr = shapes[shape]
 eng = Engine()
+L.load().csbsr_debug_set_conv_x3(0)
 wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
 params = {"l.weight": torch.randn(wshape, device="cuda") * 0.01, "l.bias": torch.zeros(cout, device="cuda")}
 conv = Conv(eng, "l", params, k, s, p, 1, transposed=tr, bias=True, act=L.ACT_LRELU, slope=0.1)
