@@ -102,8 +102,8 @@ class _JointBase(nn.Module):
         if cfg.MODEL.SR != "KBPN" or cfg.MODEL.DETECTOR_TYPE not in ("PSPNet", "PSPNet_BlurSkip", "HRNet_OCR"):
             raise NotImplementedError(f"csbsr_amd builds KBPN + PSPNet / PSPNet_BlurSkip / HRNet_OCR; got SR={cfg.MODEL.SR} "
                                       f"DETECTOR_TYPE={cfg.MODEL.DETECTOR_TYPE}")
-        if cfg.MODEL.SUM_LR_ERROR_POS != "HR" or not cfg.MODEL.KBPN_KERNEL_SFT:
-            raise NotImplementedError("only the KBPN variants with the HR error sum and the kernel SFT are built")
+        if cfg.MODEL.SUM_LR_ERROR_POS not in ("HR", "LR"):      # kbpn.py:174-187: the reference's forward handles exactly these two
+            raise NotImplementedError(f"MODEL.SUM_LR_ERROR_POS={cfg.MODEL.SUM_LR_ERROR_POS!r}: 'HR' or 'LR'")
         if cfg.MODEL.ZERO_PAD_KERNEL:       # kbpn.py:543-554,583-596: a learned per-sample choice between zero-padding and bicubic upsampling
             raise NotImplementedError("MODEL.ZERO_PAD_KERNEL=True (the kernel predictor's pad discriminator) is not built")
         if cfg.MODEL.NUM_CLASSES != 1:      # build_model.py:209: every kernel of this path assumes the 1-class crack map
@@ -118,7 +118,7 @@ class _JointBase(nn.Module):
         self.blur_skip = self.seg_model_name == "PSPNet_BlurSkip"
         self._device = torch.device(device)
         shapes = joint_state_shapes(self.pc.scale, self.pc.num_stages, self.pc.ksize, self.pc.ksize_out, self.seg_model_name,
-                                    pixel_shuffle=self.pc.pixel_shuffle)
+                                    pixel_shuffle=self.pc.pixel_shuffle, kernel_sft=self.pc.kernel_sft, lr_error=self.pc.lr_error)
         # registration order = reference state_dict order: segmentation_model.* then sr_model.*
         self.segmentation_model = _ParamGroup(shapes, "segmentation_model")
         self.sr_model = _ParamGroup(shapes, "sr_model")

@@ -72,6 +72,10 @@ class KBPN:
         self.K = cfg.ksize_out
         self.kk = self.K * self.K
         k, s, p = CONV_SETTING[self.scale]
+        self.sft = bool(getattr(cfg, "kernel_sft", True))
+        self.lr_err = bool(getattr(cfg, "lr_error", False))
+        if self.lr_err and getattr(cfg, "pixel_shuffle", False):
+            raise NotImplementedError("MODEL.SUM_LR_ERROR_POS='LR' together with MODEL.SR_PIXEL_SHUFFLE is not built")
         md = 128
         kc = cfg.ksize * cfg.ksize
         e, P = eng, params
@@ -109,13 +113,19 @@ class KBPN:
             o.fe_k = [block(kp + ".fe_kernel.0", 3, 1, 1, A_LRELU), block(kp + ".fe_kernel.1", 3, 1, 1, A_LRELU)]
             o.fe_cat = [block(kp + ".fe_cat.0", 1, 1, 0, A_LRELU, split=(kc, kc)), block(kp + ".fe_cat.1", 3, 1, 1, A_LRELU),
                         block(kp + ".fe_cat.2", 3, 1, 1, A_NONE)]
-            o.kb_up = block(sp + ".kb.up_conv1", k, s, p, A_PRELU, transposed=True)
+            if self.lr_err:      # MODEL.SUM_LR_ERROR_POS = 'LR' (kbpn.py:369-374): a 3x3 conv of the LR error, added to the next stage's LR features
+                o.kb_up, o.kb_conv = None, block(sp + ".kb.conv", 3, 1, 1, A_NONE)
+            else:
+                o.kb_up, o.kb_conv = block(sp + ".kb.up_conv1", k, s, p, A_PRELU, transposed=True), None
             if st < self.S:
                 o.down_conv = block(sp + ".down.conv", 1, 1, 0, A_PRELU, bias=True)
                 o.down1 = block(sp + ".down.down_conv1", k, s, p, A_PRELU)
                 o.down2 = block(sp + ".down.down_conv2", k, s, p, A_PRELU, transposed=True)
                 o.down3 = block(sp + ".down.down_conv3", k, s, p, A_PRELU)
                 sf = sp + ".sft"
+                if not self.sft:     # MODEL.KBPN_KERNEL_SFT = False (kbpn.py:169-171,190): the concatenated LR features go to the next stage as they are
+                    self.stages.append(o)
+                    continue
                 o.sc0 = mk(sf + ".SFT_scale_conv0", 3, 1, 1, act=A_LRELU, slope=0.1, split=(md * st, self.kk))
                 o.sc1 = mk(sf + ".SFT_scale_conv1", 3, 1, 1, act=A_SIG)
                 o.sh0 = mk(sf + ".SFT_shift_conv0", 3, 1, 1, act=A_LRELU, slope=0.1, split=(md * st, self.kk))
@@ -241,7 +251,9 @@ class KBPN:
             xu = st.up_conv.fwd(low)
             h0 = st.up1.fwd(xu)
             d = st.up2.fwd(h0, res=xu, res_mode=L.RES_SUB)
-            hh = st.up3.fwd(d, res=h0, res_mode=L.RES_ADD)
+            hs = concat_h.slice(128 * (s - 1), 128 * s)
+            # (LR-error variant: h leaves the KBlock unchanged, kbpn.py:407-409 -- the UpBlock writes the stage's slice itself)
+            hh = st.up3.fwd(d, out=hs if self.lr_err else None, res=h0, res_mode=L.RES_ADD)
             q.update(xu=xu, h0=h0, d=d, h=hh)
             segs = (concat_h.slice(0, 128 * (s - 1)), hh) if s > 1 else (hh,)
             sr_t32 = e.f32(B, 3, H, W, zero=False)
@@ -259,8 +271,8 @@ class KBPN:
             L.call("csbsr_blur_fwd", _ptr(sr_t32), _ptr(vec.contiguous()), B, 3, H, W, self.K, self.scale, _ptr(x32), None,
                    _ptr(err16.t), err16.ld, e.stream)
             q["err16"] = err16
-            hs = concat_h.slice(128 * (s - 1), 128 * s)
-            st.kb_up.fwd(err16, out=hs, res=hh, res_mode=L.RES_ADD)
+            if not self.lr_err:
+                st.kb_up.fwd(err16, out=hs, res=hh, res_mode=L.RES_ADD)
             kvec = vec
             if s < self.S:
                 chp = concat_h.slice(0, 128 * s)
@@ -268,8 +280,17 @@ class KBPN:
                 l0 = st.down1.fwd(xd)
                 dd = st.down2.fwd(l0, res=xd, res_mode=L.RES_SUB)
                 lows = concat_l.slice(128 * (s - 1), 128 * s)
-                st.down3.fwd(dd, out=lows, res=l0, res_mode=L.RES_ADD)
+                if self.lr_err:          # low = down(concat_h) + conv(error)   (kbpn.py:183-185)
+                    q["lowd"] = st.down3.fwd(dd, res=l0, res_mode=L.RES_ADD)
+                    st.kb_conv.fwd(err16, out=lows, res=q["lowd"], res_mode=L.RES_ADD)
+                else:
+                    st.down3.fwd(dd, out=lows, res=l0, res_mode=L.RES_ADD)
                 fpre = concat_l.slice(0, 128 * s)
+                if not self.sft:
+                    q.update(xd=xd, l0=l0, dd=dd)
+                    low = fpre
+                    stg.append(q if save else None)
+                    continue
                 # the 441 kernel-code channels of the SFT input are spatially constant: folded exactly into a class bias
                 t1, fold1 = st.sc0.fwd_folded(fpre, vec, self.Mtap)
                 sc = st.sc1.fwd(t1)
@@ -355,7 +376,7 @@ class KBPN:
         dlowp = None
         for s in range(self.S, 0, -1):
             st, q = self.stages[s - 1], sv["stages"][s - 1]
-            if s < self.S:
+            if s < self.S and self.sft:
                 # ---- SFT backward
                 fpre = concat_l.slice(0, 128 * s)
                 dfpre = dcl.slice(0, 128 * s)
@@ -372,9 +393,16 @@ class KBPN:
                     c0.bwd_input(dt, seg=0, out=dfpre, accumulate=True)
                     del dt
                 del dsc, dlowp
+            derr = None
+            if s < self.S:
                 # ---- DownBlock backward
                 dlow_s = dcl.slice(128 * (s - 1), 128 * s)
                 lows = concat_l.slice(128 * (s - 1), 128 * s)
+                if self.lr_err:      # low = down(...) + kb.conv(error): the error branch takes dlow_s before the in-place pass below turns it into dPre
+                    self._wg(st.kb_conv, dlow_s, q["err16"])
+                    derr = e.f32(B, 3, h, w, zero=False)
+                    st.kb_conv.bwd_input(dlow_s, out32=derr, in_hw=(h, w))
+                    lows = q["lowd"]
                 dl0 = e.new(B, h, w, 128)
                 self._act_bwd(st.down3, dlow_s, lows, res=q["l0"], res_mode=L.RES_ADD, dres=dl0)
                 self._wg(st.down3, dlow_s, q["dd"])
@@ -412,18 +440,22 @@ class KBPN:
                 dhs = dch.slice(128 * (s - 1), 128 * s)
             # out = act(pre) + h: the gradient wrt h IS dOut, so dPre goes to a fresh buffer and dOut's own storage (dead after this
             # block) carries on as dh -- one HR write stream less than copying it out (same below for up3 / h0)
-            dpk = e.new(B, H, W, 128)
-            self._act_bwd(st.kb_up, dhs, hs, res=q["h"], res_mode=L.RES_ADD, dpre=dpk)
             dh = dhs
-            self._wg(st.kb_up, dpk, q["err16"])
-            derr = e.f32(B, 3, h, w, zero=False)
-            st.kb_up.bwd_input(dpk, out32=derr, in_hw=(h, w))
-            del dpk
-            dsr_t = e.f32(B, 3, H, W, zero=False)
+            if not self.lr_err:
+                dpk = e.new(B, H, W, 128)
+                self._act_bwd(st.kb_up, dhs, hs, res=q["h"], res_mode=L.RES_ADD, dpre=dpk)
+                self._wg(st.kb_up, dpk, q["err16"])
+                derr = e.f32(B, 3, h, w, zero=False)
+                st.kb_up.bwd_input(dpk, out32=derr, in_hw=(h, w))
+                del dpk
             vec = q["vec"].contiguous()
-            L.call("csbsr_blur_bwd_input", _ptr(derr), _ptr(vec), _ptr(dsr_t), 0, B, 3, H, W, self.K, self.scale, e.stream)
             dvec = e.f32(B, self.kk)
-            L.call("csbsr_blur_bwd_kernel", _ptr(derr), _ptr(q["sr_t32"]), _ptr(dvec), B, 3, H, W, self.K, self.scale, e.stream)
+            if derr is not None:
+                dsr_t = e.f32(B, 3, H, W, zero=False)
+                L.call("csbsr_blur_bwd_input", _ptr(derr), _ptr(vec), _ptr(dsr_t), 0, B, 3, H, W, self.K, self.scale, e.stream)
+                L.call("csbsr_blur_bwd_kernel", _ptr(derr), _ptr(q["sr_t32"]), _ptr(dvec), B, 3, H, W, self.K, self.scale, e.stream)
+            else:                    # LR-error variant, last stage: its error map feeds nothing (kbpn.py:179-181); only the predictor reads sr_t
+                dsr_t = e.f32(B, 3, H, W, zero=True)
             dvec = dvec + dvec_next
             # vec = kvec2 / sum(kvec2)
             dk2 = (dvec - (dvec * q["vec"]).sum(1, keepdim=True)) / q["ksum"]
@@ -464,7 +496,11 @@ class KBPN:
             del dh0
             self._act_bwd(st.up_conv, dxu, q["xu"])
             self._wg(st.up_conv, dxu, q["low_in"])
-            dlowp = st.up_conv.bwd_input(dxu)        # gradient wrt this stage's `low` input
+            if self.sft or s == 1:
+                dlowp = st.up_conv.bwd_input(dxu)        # gradient wrt this stage's `low` input
+            else:                    # no SFT layer: `low` IS the first 128 (s - 1) channels of the concatenated LR features
+                st.up_conv.bwd_input(dxu, out=dcl.slice(0, 128 * (s - 1)), accumulate=True)
+                dlowp = None
             del dxu
             sv["stages"][s - 1] = None
             if stage_done is not None:

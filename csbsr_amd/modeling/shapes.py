@@ -31,9 +31,11 @@ def _cb(d, pre, cin, cout, k, bias=False, prelu=False, deconv=False, shuffle=0):
         d[pre + ".act.weight"] = (1,)
 
 
-def kbpn_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, md=128, prefix="sr_model", pixel_shuffle=False):
+def kbpn_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, md=128, prefix="sr_model", pixel_shuffle=False, kernel_sft=True, lr_error=False):
     """pixel_shuffle: MODEL.SR_PIXEL_SHUFFLE -- the four up-sampling layers of a stage are conv3x3 + PixelShuffle(scale)
-    (kbpn.py:372-373,457-459,479-480) instead of transposed convolutions; same key names, different weight shapes."""
+    (kbpn.py:372-373,457-459,479-480) instead of transposed convolutions; same key names, different weight shapes.
+    kernel_sft: MODEL.KBPN_KERNEL_SFT -- False: the stages have no ``sft`` module (kbpn.py:169-171).
+    lr_error: MODEL.SUM_LR_ERROR_POS == 'LR' -- ``kb.conv`` (3x3, 3 -> md at LR, no activation) in place of ``kb.up_conv1`` (kbpn.py:369-374)."""
     d = OrderedDict()
     k, s, p = CONV_SETTING[scale]
     ps = scale if pixel_shuffle else 0
@@ -63,14 +65,17 @@ def kbpn_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, md=128, prefix="sr
         _cb(d, kp + ".fe_cat.0", 2 * kc, 32, 1)
         _cb(d, kp + ".fe_cat.1", 32, 32, 3)
         _cb(d, kp + ".fe_cat.2", 32, kc, 3)
-        _cb(d, sp + ".kb.up_conv1", 3, md, k, prelu=True, deconv=True, shuffle=ps)
+        if lr_error:
+            _cb(d, sp + ".kb.conv", 3, md, 3)
+        else:
+            _cb(d, sp + ".kb.up_conv1", 3, md, k, prelu=True, deconv=True, shuffle=ps)
         if st < num_stages:
             _cb(d, sp + ".down.conv", md * st, md, 1, bias=True, prelu=True)
             _cb(d, sp + ".down.down_conv1", md, md, k, prelu=True)
             _cb(d, sp + ".down.down_conv3", md, md, k, prelu=True)
             _cb(d, sp + ".down.down_conv2", md, md, k, prelu=True, deconv=True, shuffle=ps)
             cc = md * st + cond
-            for nm, co in (("SFT_scale_conv0", cc), ("SFT_scale_conv1", md * st), ("SFT_shift_conv0", cc), ("SFT_shift_conv1", md * st)):
+            for nm, co in () if not kernel_sft else (("SFT_scale_conv0", cc), ("SFT_scale_conv1", md * st), ("SFT_shift_conv0", cc), ("SFT_shift_conv1", md * st)):
                 d[f"{sp}.sft.{nm}.weight"] = (co, cc, 3, 3)
                 d[f"{sp}.sft.{nm}.bias"] = (co,)
     _cb(d, f"{prefix}.output_conv", md * num_stages, 3, 3)
@@ -190,7 +195,7 @@ def hrnet_ocr_shapes(prefix="segmentation_model", n_classes=1):
     return d
 
 
-def joint_state_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, detector="PSPNet", pixel_shuffle=False):
+def joint_state_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, detector="PSPNet", pixel_shuffle=False, kernel_sft=True, lr_error=False):
     """state_dict order of JointModelWithLoss: segmentation_model.* first, then sr_model.*
     (MetaSSModel.__init__ runs before MetaSRModel's body, build_model.py:52-60,191-197)."""
     d = OrderedDict()
@@ -202,5 +207,5 @@ def joint_state_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, detector="P
         d.update(hrnet_ocr_shapes())
     else:
         raise NotImplementedError(detector)
-    d.update(kbpn_shapes(scale, num_stages, ksize, ksize_out, pixel_shuffle=pixel_shuffle))
+    d.update(kbpn_shapes(scale, num_stages, ksize, ksize_out, pixel_shuffle=pixel_shuffle, kernel_sft=kernel_sft, lr_error=lr_error))
     return d

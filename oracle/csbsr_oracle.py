@@ -59,6 +59,8 @@ class PathCfg:
         self.pixel_shuffle = False           # MODEL.SR_PIXEL_SHUFFLE
         self.residual_learning = True        # MODEL.SR_RESIDUAL_LEARNING (kbpn.py:32,112-116)
         self.only_kernel_loss = False        # SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN (sr_loss_functions.py:32,50-51)
+        self.kernel_sft = True               # MODEL.KBPN_KERNEL_SFT (kbpn.py:165,169-171,190)
+        self.lr_error = False                # MODEL.SUM_LR_ERROR_POS == 'LR' (kbpn.py:166,174-187,369-374,404-409)
         self.__dict__.update(kw)
 
     @property
@@ -214,8 +216,10 @@ def k_block(P, pre, concat_h, h, x_lr, kvec, it, cfg):
     vec = kvec / kvec.sum(dim=1, keepdim=True)
     pseudo_lr = blur_down(sr_t, vec, cfg.ksize_out, cfg.scale)
     err = pseudo_lr - x_lr
+    if cfg.lr_error:             # kbpn.py:407-409: h leaves unchanged, the error enters the next stage's LR features
+        return h, vec, sr_t, conv_block(P, pre + ".conv", err, act=None)
     e_h = deconv_block(P, pre + ".up_conv1", err, s, p, act="prelu", pixel_shuffle=cfg.pixel_shuffle)
-    return h + e_h, vec, sr_t
+    return h + e_h, vec, sr_t, None
 
 
 def kbpn_forward(P, x, it, kernel_gt, cfg, taps=None):
@@ -233,14 +237,16 @@ def kbpn_forward(P, x, it, kernel_gt, cfg, taps=None):
         pre = f"sr_model.back_projection_stages.{s - 1}"
         h = up_block(P, pre + ".up", low, cfg)
         pre_cat = h if concat_h is None else torch.cat((concat_h, h), 1)
-        h, kvec, sr_t = k_block(P, pre + ".kb", pre_cat, h, x, kvec, it, cfg)
+        h, kvec, sr_t, err_feat = k_block(P, pre + ".kb", pre_cat, h, x, kvec, it, cfg)
         concat_h = h if concat_h is None else torch.cat((concat_h, h), 1)
         if taps is not None:
             taps[f"s{s}.h"], taps[f"s{s}.kvec"], taps[f"s{s}.sr_t"] = h, kvec, sr_t
         if s < S:
             low = down_block(P, pre + ".down", concat_h, cfg)
+            if cfg.lr_error:
+                low = low + err_feat                                       # kbpn.py:184-185
             concat_l = low if concat_l is None else torch.cat((concat_l, low), 1)
-            low = sft_layer(P, pre + ".sft", concat_l, kvec)
+            low = sft_layer(P, pre + ".sft", concat_l, kvec) if cfg.kernel_sft else concat_l      # kbpn.py:190
             if taps is not None:
                 taps[f"s{s}.low"] = low
     sr = conv_block(P, "sr_model.output_conv", concat_h, act=None)

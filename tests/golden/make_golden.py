@@ -123,7 +123,8 @@ def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha
                detector=np.array(detector), sfo_sr_amp=np.float64(cfg.SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP),
                oriented_w_iter=np.int64(cfg.SOLVER.ORIENTED_WEIGHT_ITER), beta=np.float64(cfg.SOLVER.TASK_LOSS_WEIGHT),
                pixel_shuffle=np.bool_(cfg.MODEL.SR_PIXEL_SHUFFLE), torch_version=np.array(torch.__version__),
-               residual_learning=np.bool_(cfg.MODEL.SR_RESIDUAL_LEARNING), only_kernel_loss=np.bool_(cfg.SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN))
+               residual_learning=np.bool_(cfg.MODEL.SR_RESIDUAL_LEARNING), only_kernel_loss=np.bool_(cfg.SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN),
+               kernel_sft=np.bool_(cfg.MODEL.KBPN_KERNEL_SFT), lr_error=np.bool_(cfg.MODEL.SUM_LR_ERROR_POS == "LR"))
     for kname, v in cap.masks.items():
         if v is not None:
             out["dropmask." + kname] = v.numpy()
@@ -439,6 +440,12 @@ if __name__ == "__main__":
                     overrides=("SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SR_AMP", 1.0, "SOLVER.ORIENTED_WEIGHT_ITER", 0))
         run_case_wc("wc_hrnet_ocr_it40000", 40000, B=4, lr=48, alpha=0.8, detector="HRNet_OCR", seed=13, dropout=True,
                     overrides=("SOLVER.TASK_LOSS_WEIGHT", 0.9))
+        sys.exit(0)
+    if "--variants" in sys.argv:      # (only) the KBPN structure variants: no SFT layer between the stages (kbpn.py:169-171,190); the
+        # back-projection error added to the next stage's LR features instead of this stage's HR features (kbpn.py:174-187,369-374,404-409)
+        run_case("e2e_pspnet_nosft_it40000", 40000, alpha=0.7, seed=29, overrides=("MODEL.KBPN_KERNEL_SFT", False))
+        run_case("e2e_pspnet_lrerr_it40000", 40000, alpha=0.7, seed=31, overrides=("MODEL.SUM_LR_ERROR_POS", "LR"))
+        run_case("e2e_pspnet_lrerr_it1", 1, seed=37, overrides=("MODEL.SUM_LR_ERROR_POS", "LR"))
         sys.exit(0)
     run_case("e2e_pspnet_it40000", 40000, taps=True, alpha=0.7)
     run_case("e2e_pspnet_it40000_dropout", 40000, dropout=True, alpha=0.7)

@@ -147,7 +147,7 @@ def test_unsupported_variants_fail_loudly():
     with pytest.raises(NotImplementedError):
         JointModelWithLoss(c, 1000, 0, None)
     # every cfg key the path consumes is either honoured or refused -- never silently ignored
-    for key, val in (("MODEL.ZERO_PAD_KERNEL", True), ("MODEL.NUM_CLASSES", 2), ("MODEL.SUM_LR_ERROR_POS", "LR"), ("MODEL.KBPN_KERNEL_SFT", False),
+    for key, val in (("MODEL.ZERO_PAD_KERNEL", True), ("MODEL.NUM_CLASSES", 2), ("MODEL.SUM_LR_ERROR_POS", "mid"),
                      ("MODEL.SR_SEG_INV", True), ("MODEL.JOINT_LEARNING", False), ("SOLVER.INTERM_SSLOSSWEGHT4SR", True),
                      ("SOLVER.CRACK_ORIENTED_WEIGHT4SR_AMP", 1.0), ("SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SS_AMP", 1.0), ("MODEL.SR", "DBPN")):
         c = cfg.clone()
@@ -159,6 +159,21 @@ def test_unsupported_variants_fail_loudly():
     c.merge_from_list(["MODEL.SR_RESIDUAL_LEARNING", False, "SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN", True, "MODEL.SR_PIXEL_SHUFFLE", True])
     m = JointModelWithLoss(c, 1000, 0, None)
     assert m.pc.residual_learning is False and m.pc.only_kernel_loss is True and m.pc.pixel_shuffle is True
+    # the two KBPN structure variants change the state_dict as the reference's constructor does (kbpn.py:169-171, 369-374)
+    c = cfg.clone()
+    c.merge_from_list(["MODEL.KBPN_KERNEL_SFT", False, "MODEL.SUM_LR_ERROR_POS", "LR"])
+    m = JointModelWithLoss(c, 1000, 0, None)
+    keys = list(m.state_dict().keys())
+    assert m.pc.kernel_sft is False and m.pc.lr_error is True
+    assert not any(".sft." in k for k in keys) and not any(".kb.up_conv1." in k for k in keys)
+    assert sum(1 for k in keys if k.endswith(".kb.conv.layer.weight")) == 4 and len(keys) == 410 - 3 * 8 - 4
+    # ... in the reference's own parameter order (the fixtures carry its named_parameters() list)
+    from golden_utils import load_golden
+    for case, ov in (("e2e_pspnet_nosft_it40000", ["MODEL.KBPN_KERNEL_SFT", False]), ("e2e_pspnet_lrerr_it40000", ["MODEL.SUM_LR_ERROR_POS", "LR"])):
+        c = cfg.clone()
+        c.merge_from_list(ov)
+        mine = [k for k in JointModelWithLoss(c, 1000, 0, None).state_dict().keys() if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+        assert mine == [str(n) for n in load_golden(case)["grad_names"]], case
 
 
 def test_up_down_scheduler_matches_the_reference_rule():

@@ -50,6 +50,8 @@ def build_model(g, micro_batch=8):
         cfg.MODEL.SR_PIXEL_SHUFFLE = bool(g["pixel_shuffle"])
     if "residual_learning" in g:
         cfg.MODEL.SR_RESIDUAL_LEARNING, cfg.SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN = bool(g["residual_learning"]), bool(g["only_kernel_loss"])
+    if "kernel_sft" in g:
+        cfg.MODEL.KBPN_KERNEL_SFT, cfg.MODEL.SUM_LR_ERROR_POS = bool(g["kernel_sft"]), ("LR" if bool(g["lr_error"]) else "HR")
     m = JointModelWithLoss(cfg, 1000, 0, None, antialias=bool(g["antialias"]))
     deterministic_fill(m.state_dict())
     m.ss_loss_fn.alpha = float(g["alpha"])
@@ -81,7 +83,7 @@ def run_hip(g, micro_batch=8):
 
 def run_oracle(g):
     cfg = golden_cfg(g)
-    P = det_params(scale=cfg.scale, detector=cfg.detector, pixel_shuffle=cfg.pixel_shuffle)
+    P = det_params(scale=cfg.scale, detector=cfg.detector, pixel_shuffle=cfg.pixel_shuffle, kernel_sft=cfg.kernel_sft, lr_error=cfg.lr_error)
     t = lambda k: torch.from_numpy(g[k])
     drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
     out = O.joint_forward(P, cfg, int(g["it"]), t("x"), t("hr"), t("mask"), t("kernel"), alpha=float(g["alpha"]), drop=drop or None)
@@ -93,7 +95,8 @@ def run_oracle(g):
 @pytest.mark.parametrize("case", ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "e2e_pspnet_it10001",
                                   "e2e_pspnet_it20001", "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24", "e2e_blurskip_x8_it40000",
                                   "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000", "e2e_pspnet_pixelshuffle_it20001",
-                                  "e2e_pspnet_noresidual_it40000", "e2e_pspnet_konly_it10001"])
+                                  "e2e_pspnet_noresidual_it40000", "e2e_pspnet_konly_it10001", "e2e_pspnet_nosft_it40000",
+                                  "e2e_pspnet_lrerr_it40000", "e2e_pspnet_lrerr_it1"])
 def test_forward_matches_golden(case):
     g = load_golden(case)
     det = str(g["detector"]) if "detector" in g else "PSPNet"
@@ -114,6 +117,12 @@ def test_forward_matches_golden(case):
         # computed) bicubic term, so the same absolute error -- 6.8e-4 of the image range here, 8e-4 for the default variant -- is 2.5x larger
         # relative to this map's own maximum
         tol_sr = 2.5e-3
+    if bool(g.get("lr_error", False)):
+        # MODEL.SUM_LR_ERROR_POS = 'LR': the back-projection error reaches the next stage through a 27-term 3x3 conv of the fp16 LR error
+        # image instead of a 192-term 8x8 deconv (less averaging of its storage rounding) and the stage's LR features are rounded once more
+        # (down(...) and down(...) + conv(error) are both stored): 1.06e-3 / 1.09e-3 of the SR image's maximum on the two fixtures, where the
+        # default variant has 6.2e-4 with the same weights; gradients agree with the oracle like the default variant's (2.7e-3 median at iter 1)
+        tol_sr = 1.5e-3
     for k in ("sr_preds", "kernel_preds", "sr_loss"):
         # (with the w^F weight on, the SR loss is weighted by exp(|seg - mask|): it inherits the segmentation map's conditioning)
         assert worst[k] < (5e-3 if k == "sr_loss" and float(g.get("sfo_sr_amp", 0.0)) != 0 else tol_sr), (k, worst[k])
@@ -125,7 +134,8 @@ def test_forward_matches_golden(case):
 
 @pytest.mark.parametrize("case", ["e2e_pspnet_it1", "e2e_pspnet_it10001", "e2e_pspnet_it20001", "e2e_pspnet_it40000",
                                   "e2e_pspnet_it40000_dropout", "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000",
-                                  "e2e_pspnet_pixelshuffle_it20001", "e2e_pspnet_noresidual_it40000", "e2e_pspnet_konly_it10001"])
+                                  "e2e_pspnet_pixelshuffle_it20001", "e2e_pspnet_noresidual_it40000", "e2e_pspnet_konly_it10001",
+                                  "e2e_pspnet_nosft_it40000", "e2e_pspnet_lrerr_it40000", "e2e_pspnet_lrerr_it1"])
 def test_gradients_match_oracle(case):
     """Per-parameter relative L2 error of the HIP gradients vs the fp32 oracle.
 
