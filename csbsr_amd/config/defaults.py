@@ -113,5 +113,6 @@ def path_config(c, antialias=True):
     p.residual_learning = bool(c.MODEL.SR_RESIDUAL_LEARNING)             # kbpn.py:32,69-70,112-116
     p.only_kernel_loss = bool(c.SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN)    # sr_loss_functions.py:32,50-51
     p.kernel_sft = bool(c.MODEL.KBPN_KERNEL_SFT)                         # kbpn.py:165,169-171,190: False = no SFT layer between the stages
+    p.zero_pad_kernel = bool(c.MODEL.ZERO_PAD_KERNEL)                    # kbpn.py:543-554,583-596: per-sample choice zero-pad / bicubic for the 7x7 -> 21x21 kernel update
     p.lr_error = str(c.MODEL.SUM_LR_ERROR_POS) == "LR"                   # kbpn.py:166,174-187,369-374,404-409: back-projection error added at LR
     return p

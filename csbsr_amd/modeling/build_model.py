@@ -104,8 +104,6 @@ class _JointBase(nn.Module):
                                       f"DETECTOR_TYPE={cfg.MODEL.DETECTOR_TYPE}")
         if cfg.MODEL.SUM_LR_ERROR_POS not in ("HR", "LR"):      # kbpn.py:174-187: the reference's forward handles exactly these two
             raise NotImplementedError(f"MODEL.SUM_LR_ERROR_POS={cfg.MODEL.SUM_LR_ERROR_POS!r}: 'HR' or 'LR'")
-        if cfg.MODEL.ZERO_PAD_KERNEL:       # kbpn.py:543-554,583-596: a learned per-sample choice between zero-padding and bicubic upsampling
-            raise NotImplementedError("MODEL.ZERO_PAD_KERNEL=True (the kernel predictor's pad discriminator) is not built")
         if cfg.MODEL.NUM_CLASSES != 1:      # build_model.py:209: every kernel of this path assumes the 1-class crack map
             raise NotImplementedError(f"MODEL.NUM_CLASSES={cfg.MODEL.NUM_CLASSES}: only the 1-class detectors are built")
         if cfg.MODEL.SR_SEG_INV or not cfg.MODEL.JOINT_LEARNING:
@@ -118,7 +116,8 @@ class _JointBase(nn.Module):
         self.blur_skip = self.seg_model_name == "PSPNet_BlurSkip"
         self._device = torch.device(device)
         shapes = joint_state_shapes(self.pc.scale, self.pc.num_stages, self.pc.ksize, self.pc.ksize_out, self.seg_model_name,
-                                    pixel_shuffle=self.pc.pixel_shuffle, kernel_sft=self.pc.kernel_sft, lr_error=self.pc.lr_error)
+                                    pixel_shuffle=self.pc.pixel_shuffle, kernel_sft=self.pc.kernel_sft, lr_error=self.pc.lr_error,
+                                    zero_pad_kernel=self.pc.zero_pad_kernel)
         # registration order = reference state_dict order: segmentation_model.* then sr_model.*
         self.segmentation_model = _ParamGroup(shapes, "segmentation_model")
         self.sr_model = _ParamGroup(shapes, "sr_model")
@@ -297,6 +296,7 @@ class JointModelWithLoss(_JointBase):
         device -- csbsr_amd.data.degrade.DeviceDegradation computes it with the batch -- so the loss does not recompute it."""
         rt = self._runtime()
         eng, kbpn, psp, pc = rt["eng"], rt["kbpn"], rt["psp"], self.pc
+        kbpn.training_mode, kbpn.pad_dropout = self.training, self.dropout_enabled and self.dropout_masks is None
         self._invalidate()              # master weights may have been stepped by the optimiser
         x, hr, mask, kgt = self._mount(x), self._mount(sr_targets), self._mount(segment_targets), self._mount(kernel_targets)
         B, _, h, w = x.shape
@@ -337,6 +337,7 @@ class JointModelWithLoss(_JointBase):
         dLoss/d kernel vector [B,kk], true scale) -- e.g. the reference's own, from a golden fixture.  Returns {state_dict name: grad}."""
         rt = self._runtime()
         eng, kbpn, pc = rt["eng"], rt["kbpn"], self.pc
+        kbpn.training_mode, kbpn.pad_dropout = self.training, self.dropout_enabled and self.dropout_masks is None
         self._invalidate()
         x, kgt, dsr, dkvec = self._mount(x), self._mount(kernel_targets), self._mount(dsr), self._mount(dkvec)
         B, _, h, w = x.shape
@@ -576,6 +577,7 @@ class JointModel(_JointBase):
     def forward(self, x, damy_kernel, sr_targets=None):
         rt = self._runtime()
         eng, kbpn, psp = rt["eng"], rt["kbpn"], rt["psp"]
+        kbpn.training_mode = self.training
         self._invalidate()
         x, kgt = self._mount(x), self._mount(damy_kernel)
         B = x.shape[0]

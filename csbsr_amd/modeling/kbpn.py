@@ -136,8 +136,19 @@ class KBPN:
         eye = torch.eye(kc).reshape(kc, 1, cfg.ksize, cfg.ksize)
         up = F.interpolate(eye, size=(self.K, self.K), mode="bicubic", align_corners=False) if cfg.ksize != self.K else eye
         self.U = up.reshape(kc, self.kk).t().contiguous().to(eng.device)       # [kk, kc]
+        # MODEL.ZERO_PAD_KERNEL (kbpn.py:543-554,583-596): per sample, a three-layer MLP on the stage predictor's 7x7 update picks centred zero
+        # padding instead of the bicubic map (hard threshold on .item(): no gradient reaches the MLP); Z is that padding as a [kk, kc] matrix
+        self.zero_pad = bool(getattr(cfg, "zero_pad_kernel", False))
+        self.pad_dropout = True        # the MLP's two nn.Dropout(0.2) in training (the owner turns it off with its own dropout switch)
+        pz = (self.K - cfg.ksize) // 2
+        self.Z = F.pad(eye, (pz, pz, pz, pz)).reshape(kc, self.kk).t().contiguous().to(eng.device)
+        if self.zero_pad:
+            for st_i, o in enumerate(self.stages):
+                pd = f"{prefix}.back_projection_stages.{st_i}.kb.kernel_predictor.pad_descriminator"
+                o.pad_disc = [(P[f"{pd}.{i}.weight"], P[f"{pd}.{i}.bias"]) for i in (0, 3, 6)]
         self.kc = kc
         self.saved = None
+        self.training_mode = True      # set by the owner (nn.Module.training of the model)
         self._gather = {}
         self.gather = os.environ.get("CSBSR_GATHER_DCH", "1") != "0"      # backward: gather each stage's slice of d(concat_h) (see _gather_conv)
         self.Mtap = border_tap_mask().to(eng.device)       # folded constant-operand convs: see _kernel_branch_fwd / Conv.fwd_folded
@@ -324,7 +335,24 @@ class KBPN:
         st.fe_cat[2].fwd(c2, stat=gap, stat_mode=L.STAT_SAMPLE_SUM, store=False)
         d49 = gap[:, :self.kc] / float(H * W)
         q["kp"] = (a[:1] if getattr(self, "lean", False) else a, kctx, c1, c2)
-        return kvec + d49 @ self.U.t()
+        q["kp_map"] = self._update_map(st, d49)
+        return kvec + torch.einsum("bc,bkc->bk", d49, q["kp_map"])
+
+    def _update_map(self, st, d49):
+        """[B, kk, kc] linear map from the predictor's 7x7 update to the 21x21 kernel update: bicubic (kbpn.py:558,598-599), or per sample
+        the zero padding the pad discriminator picks (kbpn.py:583-596)."""
+        B = d49.shape[0]
+        if not self.zero_pad:
+            return self.U.unsqueeze(0).expand(B, -1, -1)
+        with torch.no_grad():
+            drop = self.pad_dropout and self.training_mode
+            hdn = d49
+            for i, (w, b) in enumerate(st.pad_disc):
+                hdn = F.linear(hdn, w.detach().to(torch.float32), b.detach().to(torch.float32))
+                if i < 2:
+                    hdn = F.dropout(F.relu(hdn), 0.2, training=drop)
+            take_up = torch.sigmoid(hdn).reshape(B) >= 0.5
+        return torch.where(take_up.reshape(B, 1, 1), self.U.unsqueeze(0), self.Z.unsqueeze(0))
 
     # ------------------------------------------------------------------ backward
     def _act_bwd(self, conv, dout, out, res=None, res2=None, res_mode=L.RES_NONE, dres=None, dres_acc=False, dres2=None,
@@ -552,7 +580,7 @@ class KBPN:
             for c in st.fe_sr:
                 a.append(c.fwd(a[-1]))
         B = dk2.shape[0]
-        d49 = (dk2 @ self.U) / float(H * W)
+        d49 = torch.einsum("bk,bkc->bc", dk2, q["kp_map"]) / float(H * W)
         g = self._bcast_grad(d49, H, W)
         cat2, cat1, cat0 = st.fe_cat[2], st.fe_cat[1], st.fe_cat[0]
         # Every layer of this branch is a bias-free conv + ReLU / LeakyReLU with a single consumer, so each dgrad applies the activation

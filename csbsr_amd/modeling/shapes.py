@@ -31,10 +31,13 @@ def _cb(d, pre, cin, cout, k, bias=False, prelu=False, deconv=False, shuffle=0):
         d[pre + ".act.weight"] = (1,)
 
 
-def kbpn_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, md=128, prefix="sr_model", pixel_shuffle=False, kernel_sft=True, lr_error=False):
+def kbpn_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, md=128, prefix="sr_model", pixel_shuffle=False, kernel_sft=True, lr_error=False,
+                zero_pad_kernel=False):
     """pixel_shuffle: MODEL.SR_PIXEL_SHUFFLE -- the four up-sampling layers of a stage are conv3x3 + PixelShuffle(scale)
     (kbpn.py:372-373,457-459,479-480) instead of transposed convolutions; same key names, different weight shapes.
     kernel_sft: MODEL.KBPN_KERNEL_SFT -- False: the stages have no ``sft`` module (kbpn.py:169-171).
+    zero_pad_kernel: MODEL.ZERO_PAD_KERNEL -- every stage's kernel predictor carries the three Linear layers of its ``pad_descriminator``
+    (kbpn.py:543-554).
     lr_error: MODEL.SUM_LR_ERROR_POS == 'LR' -- ``kb.conv`` (3x3, 3 -> md at LR, no activation) in place of ``kb.up_conv1`` (kbpn.py:369-374)."""
     d = OrderedDict()
     k, s, p = CONV_SETTING[scale]
@@ -65,6 +68,10 @@ def kbpn_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, md=128, prefix="sr
         _cb(d, kp + ".fe_cat.0", 2 * kc, 32, 1)
         _cb(d, kp + ".fe_cat.1", 32, 32, 3)
         _cb(d, kp + ".fe_cat.2", 32, kc, 3)
+        if zero_pad_kernel:
+            for i, (ci, co) in zip((0, 3, 6), ((kc, 8), (8, 8), (8, 1))):
+                d[f"{kp}.pad_descriminator.{i}.weight"] = (co, ci)
+                d[f"{kp}.pad_descriminator.{i}.bias"] = (co,)
         if lr_error:
             _cb(d, sp + ".kb.conv", 3, md, 3)
         else:
@@ -195,7 +202,8 @@ def hrnet_ocr_shapes(prefix="segmentation_model", n_classes=1):
     return d
 
 
-def joint_state_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, detector="PSPNet", pixel_shuffle=False, kernel_sft=True, lr_error=False):
+def joint_state_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, detector="PSPNet", pixel_shuffle=False, kernel_sft=True, lr_error=False,
+                       zero_pad_kernel=False):
     """state_dict order of JointModelWithLoss: segmentation_model.* first, then sr_model.*
     (MetaSSModel.__init__ runs before MetaSRModel's body, build_model.py:52-60,191-197)."""
     d = OrderedDict()
@@ -207,5 +215,6 @@ def joint_state_shapes(scale=4, num_stages=4, ksize=7, ksize_out=21, detector="P
         d.update(hrnet_ocr_shapes())
     else:
         raise NotImplementedError(detector)
-    d.update(kbpn_shapes(scale, num_stages, ksize, ksize_out, pixel_shuffle=pixel_shuffle, kernel_sft=kernel_sft, lr_error=lr_error))
+    d.update(kbpn_shapes(scale, num_stages, ksize, ksize_out, pixel_shuffle=pixel_shuffle, kernel_sft=kernel_sft, lr_error=lr_error,
+                         zero_pad_kernel=zero_pad_kernel))
     return d

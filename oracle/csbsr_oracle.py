@@ -61,6 +61,7 @@ class PathCfg:
         self.only_kernel_loss = False        # SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN (sr_loss_functions.py:32,50-51)
         self.kernel_sft = True               # MODEL.KBPN_KERNEL_SFT (kbpn.py:165,169-171,190)
         self.lr_error = False                # MODEL.SUM_LR_ERROR_POS == 'LR' (kbpn.py:166,174-187,369-374,404-409)
+        self.zero_pad_kernel = False         # MODEL.ZERO_PAD_KERNEL (kbpn.py:543-554,583-596)
         self.__dict__.update(kw)
 
     @property
@@ -203,7 +204,20 @@ def kernel_predictor_ikc(P, pre, sr_t, kvec, cfg):
     delta = y.mean(dim=(2, 3), keepdim=True)
     ks = int(round(math.sqrt(delta.shape[1])))
     if ks != cfg.ksize_out:
-        delta = kernel_up_normalise(delta, cfg.ksize_out)
+        up = kernel_up_normalise(delta, cfg.ksize_out)
+        if cfg.zero_pad_kernel:
+            # kbpn.py:583-596: a small MLP on the 7x7 update decides per sample (hard threshold on .item(): no gradient reaches it) between
+            # bicubic upsampling and centred zero padding.  Its nn.Dropout(0.2) layers are taken as identity here (their expectation; the
+            # fixtures are generated with them disabled) -- in the reference's train mode they make the decision itself random.
+            v = delta.reshape(B, -1)
+            pd = pre + ".pad_descriminator"
+            h = F.relu(F.linear(v, P[pd + ".0.weight"], P[pd + ".0.bias"]))
+            h = F.relu(F.linear(h, P[pd + ".3.weight"], P[pd + ".3.bias"]))
+            pr = torch.sigmoid(F.linear(h, P[pd + ".6.weight"], P[pd + ".6.bias"])).detach().reshape(B)
+            padn = (cfg.ksize_out - ks) // 2
+            zp = F.pad(delta.reshape(B, 1, ks, ks), (padn, padn, padn, padn))
+            up = torch.where((pr >= 0.5).reshape(B, 1, 1, 1), up, zp)
+        delta = up
     return kvec + delta.reshape(B, -1)
 
 

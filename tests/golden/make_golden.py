@@ -124,7 +124,8 @@ def run_case(name, it, B=2, lr=16, scale=4, dropout=False, antialias=True, alpha
                oriented_w_iter=np.int64(cfg.SOLVER.ORIENTED_WEIGHT_ITER), beta=np.float64(cfg.SOLVER.TASK_LOSS_WEIGHT),
                pixel_shuffle=np.bool_(cfg.MODEL.SR_PIXEL_SHUFFLE), torch_version=np.array(torch.__version__),
                residual_learning=np.bool_(cfg.MODEL.SR_RESIDUAL_LEARNING), only_kernel_loss=np.bool_(cfg.SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN),
-               kernel_sft=np.bool_(cfg.MODEL.KBPN_KERNEL_SFT), lr_error=np.bool_(cfg.MODEL.SUM_LR_ERROR_POS == "LR"))
+               kernel_sft=np.bool_(cfg.MODEL.KBPN_KERNEL_SFT), lr_error=np.bool_(cfg.MODEL.SUM_LR_ERROR_POS == "LR"),
+               zero_pad_kernel=np.bool_(cfg.MODEL.ZERO_PAD_KERNEL))
     for kname, v in cap.masks.items():
         if v is not None:
             out["dropmask." + kname] = v.numpy()
@@ -446,6 +447,17 @@ if __name__ == "__main__":
         run_case("e2e_pspnet_nosft_it40000", 40000, alpha=0.7, seed=29, overrides=("MODEL.KBPN_KERNEL_SFT", False))
         run_case("e2e_pspnet_lrerr_it40000", 40000, alpha=0.7, seed=31, overrides=("MODEL.SUM_LR_ERROR_POS", "LR"))
         run_case("e2e_pspnet_lrerr_it1", 1, seed=37, overrides=("MODEL.SUM_LR_ERROR_POS", "LR"))
+        sys.exit(0)
+    if "--zeropad" in sys.argv:       # MODEL.ZERO_PAD_KERNEL (kbpn.py:543-554,583-596).  The pad discriminator's two nn.Dropout(0.2) layers are
+        # disabled while the fixture is made: in the reference's train mode they make the HARD per-sample decision (p.item() >= 0.5)
+        # itself random, so no implementation could reproduce a fixture made with them on
+        orig_do = nn.Dropout.forward
+        nn.Dropout.forward = lambda self, x: x
+        try:
+            # (with the deterministic fill the discriminators of stages 1-2 pick the bicubic map and those of stages 3-4 the zero padding)
+            run_case("e2e_pspnet_zeropad_it40000", 40000, alpha=0.7, seed=41, overrides=("MODEL.ZERO_PAD_KERNEL", True))
+        finally:
+            nn.Dropout.forward = orig_do
         sys.exit(0)
     run_case("e2e_pspnet_it40000", 40000, taps=True, alpha=0.7)
     run_case("e2e_pspnet_it40000_dropout", 40000, dropout=True, alpha=0.7)

@@ -34,6 +34,8 @@ def golden_cfg(g):
         kw.update(residual_learning=bool(g["residual_learning"]), only_kernel_loss=bool(g["only_kernel_loss"]))
     if "kernel_sft" in g:
         kw.update(kernel_sft=bool(g["kernel_sft"]), lr_error=bool(g["lr_error"]))
+    if "zero_pad_kernel" in g:
+        kw.update(zero_pad_kernel=bool(g["zero_pad_kernel"]))
     return O.PathCfg(**kw)
 
 
@@ -42,9 +44,10 @@ def fill_style(g):
     return str(g["fill"]) if "fill" in g else "random"
 
 
-def det_params(scale=4, num_stages=4, detector="PSPNet", requires_grad=True, pixel_shuffle=False, style="random", kernel_sft=True, lr_error=False):
+def det_params(scale=4, num_stages=4, detector="PSPNet", requires_grad=True, pixel_shuffle=False, style="random", kernel_sft=True, lr_error=False,
+               zero_pad_kernel=False):
     shapes = joint_state_shapes(scale=scale, num_stages=num_stages, detector=detector, pixel_shuffle=pixel_shuffle, kernel_sft=kernel_sft,
-                                lr_error=lr_error)
+                                lr_error=lr_error, zero_pad_kernel=zero_pad_kernel)
     sd = det_state_dict(shapes, style)
     if requires_grad:
         for k, v in sd.items():

@@ -147,7 +147,7 @@ def test_unsupported_variants_fail_loudly():
     with pytest.raises(NotImplementedError):
         JointModelWithLoss(c, 1000, 0, None)
     # every cfg key the path consumes is either honoured or refused -- never silently ignored
-    for key, val in (("MODEL.ZERO_PAD_KERNEL", True), ("MODEL.NUM_CLASSES", 2), ("MODEL.SUM_LR_ERROR_POS", "mid"),
+    for key, val in (("MODEL.NUM_CLASSES", 2), ("MODEL.SUM_LR_ERROR_POS", "mid"),
                      ("MODEL.SR_SEG_INV", True), ("MODEL.JOINT_LEARNING", False), ("SOLVER.INTERM_SSLOSSWEGHT4SR", True),
                      ("SOLVER.CRACK_ORIENTED_WEIGHT4SR_AMP", 1.0), ("SOLVER.SEG_FAIL_ORIENTED_WEIGHT4SS_AMP", 1.0), ("MODEL.SR", "DBPN")):
         c = cfg.clone()
@@ -169,7 +169,8 @@ def test_unsupported_variants_fail_loudly():
     assert sum(1 for k in keys if k.endswith(".kb.conv.layer.weight")) == 4 and len(keys) == 410 - 3 * 8 - 4
     # ... in the reference's own parameter order (the fixtures carry its named_parameters() list)
     from golden_utils import load_golden
-    for case, ov in (("e2e_pspnet_nosft_it40000", ["MODEL.KBPN_KERNEL_SFT", False]), ("e2e_pspnet_lrerr_it40000", ["MODEL.SUM_LR_ERROR_POS", "LR"])):
+    for case, ov in (("e2e_pspnet_nosft_it40000", ["MODEL.KBPN_KERNEL_SFT", False]), ("e2e_pspnet_lrerr_it40000", ["MODEL.SUM_LR_ERROR_POS", "LR"]),
+                     ("e2e_pspnet_zeropad_it40000", ["MODEL.ZERO_PAD_KERNEL", True])):
         c = cfg.clone()
         c.merge_from_list(ov)
         mine = [k for k in JointModelWithLoss(c, 1000, 0, None).state_dict().keys() if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]

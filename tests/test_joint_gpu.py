@@ -52,6 +52,8 @@ def build_model(g, micro_batch=8):
         cfg.MODEL.SR_RESIDUAL_LEARNING, cfg.SOLVER.ONLY_KERNEL_LOSS_FOR_PRETRAIN = bool(g["residual_learning"]), bool(g["only_kernel_loss"])
     if "kernel_sft" in g:
         cfg.MODEL.KBPN_KERNEL_SFT, cfg.MODEL.SUM_LR_ERROR_POS = bool(g["kernel_sft"]), ("LR" if bool(g["lr_error"]) else "HR")
+    if "zero_pad_kernel" in g:
+        cfg.MODEL.ZERO_PAD_KERNEL = bool(g["zero_pad_kernel"])
     m = JointModelWithLoss(cfg, 1000, 0, None, antialias=bool(g["antialias"]))
     deterministic_fill(m.state_dict())
     m.ss_loss_fn.alpha = float(g["alpha"])
@@ -83,7 +85,8 @@ def run_hip(g, micro_batch=8):
 
 def run_oracle(g):
     cfg = golden_cfg(g)
-    P = det_params(scale=cfg.scale, detector=cfg.detector, pixel_shuffle=cfg.pixel_shuffle, kernel_sft=cfg.kernel_sft, lr_error=cfg.lr_error)
+    P = det_params(scale=cfg.scale, detector=cfg.detector, pixel_shuffle=cfg.pixel_shuffle, kernel_sft=cfg.kernel_sft, lr_error=cfg.lr_error,
+                   zero_pad_kernel=cfg.zero_pad_kernel)
     t = lambda k: torch.from_numpy(g[k])
     drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
     out = O.joint_forward(P, cfg, int(g["it"]), t("x"), t("hr"), t("mask"), t("kernel"), alpha=float(g["alpha"]), drop=drop or None)
@@ -96,7 +99,7 @@ def run_oracle(g):
                                   "e2e_pspnet_it20001", "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24", "e2e_blurskip_x8_it40000",
                                   "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000", "e2e_pspnet_pixelshuffle_it20001",
                                   "e2e_pspnet_noresidual_it40000", "e2e_pspnet_konly_it10001", "e2e_pspnet_nosft_it40000",
-                                  "e2e_pspnet_lrerr_it40000", "e2e_pspnet_lrerr_it1"])
+                                  "e2e_pspnet_lrerr_it40000", "e2e_pspnet_lrerr_it1", "e2e_pspnet_zeropad_it40000"])
 def test_forward_matches_golden(case):
     g = load_golden(case)
     det = str(g["detector"]) if "detector" in g else "PSPNet"
@@ -135,7 +138,7 @@ def test_forward_matches_golden(case):
 @pytest.mark.parametrize("case", ["e2e_pspnet_it1", "e2e_pspnet_it10001", "e2e_pspnet_it20001", "e2e_pspnet_it40000",
                                   "e2e_pspnet_it40000_dropout", "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000",
                                   "e2e_pspnet_pixelshuffle_it20001", "e2e_pspnet_noresidual_it40000", "e2e_pspnet_konly_it10001",
-                                  "e2e_pspnet_nosft_it40000", "e2e_pspnet_lrerr_it40000", "e2e_pspnet_lrerr_it1"])
+                                  "e2e_pspnet_nosft_it40000", "e2e_pspnet_lrerr_it40000", "e2e_pspnet_lrerr_it1", "e2e_pspnet_zeropad_it40000"])
 def test_gradients_match_oracle(case):
     """Per-parameter relative L2 error of the HIP gradients vs the fp32 oracle.
 

@@ -10,7 +10,8 @@ from oracle import csbsr_oracle as O
 CASES = ["e2e_pspnet_it40000", "e2e_pspnet_it40000_dropout", "e2e_pspnet_it1", "e2e_pspnet_it10001",
          "e2e_pspnet_it20001", "e2e_pspnet_it40000_noaa", "e2e_pspnet_it40000_lr24",
          "e2e_blurskip_x8_it40000", "e2e_pspnet_wf_it40000", "e2e_hrnet_ocr_it40000", "e2e_pspnet_pixelshuffle_it20001",
-         "e2e_pspnet_noresidual_it40000", "e2e_pspnet_konly_it10001", "e2e_pspnet_nosft_it40000", "e2e_pspnet_lrerr_it40000", "e2e_pspnet_lrerr_it1"]
+         "e2e_pspnet_noresidual_it40000", "e2e_pspnet_konly_it10001", "e2e_pspnet_nosft_it40000", "e2e_pspnet_lrerr_it40000", "e2e_pspnet_lrerr_it1",
+         "e2e_pspnet_zeropad_it40000"]
 
 # fp32 CPU vs fp32 CPU, same torch build: differences come only from op ordering (grouped conv vs the
 # reference's per-sample loop, vector kernel vs expanded map)
@@ -21,7 +22,7 @@ TOL_GRAD = 3e-2   # fp32 evaluation-order noise: up to 1.1e-2 on kb.sr_reconst w
 def run_oracle(g, grads=True):
     cfg = golden_cfg(g)
     P = det_params(scale=cfg.scale, detector=cfg.detector, requires_grad=grads, pixel_shuffle=cfg.pixel_shuffle, kernel_sft=cfg.kernel_sft,
-                   lr_error=cfg.lr_error)
+                   lr_error=cfg.lr_error, zero_pad_kernel=cfg.zero_pad_kernel)
     t = lambda k: torch.from_numpy(g[k])
     drop = {k.split(".", 1)[1]: torch.from_numpy(v) for k, v in g.items() if k.startswith("dropmask.")}
     taps = {}
@@ -78,6 +79,10 @@ def test_oracle_matches_reference_outputs_and_grads(case):
             # stage 2's the reference's own fp32 value (0.09876) is 4.0 % from an fp64 run of the oracle (0.10288), the fp32 oracle (0.10201)
             # 0.9 % -- every other tensor of the fixture agrees to <= 0.2 %
             tol = 6e-2
+        if bool(g.get("zero_pad_kernel", False)) and ".kb.kernel_predictor.fe_SR.0." in n:
+            # MODEL.ZERO_PAD_KERNEL: in the stages whose update is zero-padded the predictor's gradient is tiny (norm 3e-4) and noise-limited:
+            # stage 2's fe_SR.0 weight is 2.4 % from an fp64 run of the oracle in the reference's own fp32 result, 0.9 % in the fp32 oracle's
+            tol = 5e-2
         assert abs(mine_norm - ref_norm) <= tol * ref_norm + atol, (n, mine_norm, ref_norm)
         if gr.numel() == 1:
             n_checked += 1
