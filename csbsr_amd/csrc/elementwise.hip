@@ -819,49 +819,79 @@ __global__ void maxpool_fwd_kernel(const half_t* x, half_t* y, int N, int H, int
     st_split(y + (i / c8) * y_ld + cc * 8, y_lo, m);
   }
 }
-// gather form: dx[iy,ix] = sum over windows containing it whose argmax (first max in scan order) is (iy,ix)
-__global__ void maxpool_bwd_kernel(const half_t* x, const half_t* y, const half_t* dy, half_t* dx, int N, int H, int W, int c8,
-                                   int OH, int OW, long x_ld, long x_lo, long y_ld, long y_lo) {
-  const long total = (long)N * H * W * c8;
+// Backward, block-stationary gather: a thread owns a 2 x 2 block of input pixels (rows 2a, 2a+1; columns 2b, 2b+1) of one channel octet.
+// Only the four windows (oy, ox) in {a, a+1} x {b, b+1} can touch the block; each is rescanned from x -- first maximum in scan order,
+// torch's argmax rule (strict >) -- with nine 16-byte loads (L1 / L2 hits: a pixel is read by nine windows), its gradient goes to the
+// block pixel that holds the argmax.  No saved output needed, no scalar loads, every dx pixel written once.  (The per-pixel version
+// tested "am I the first maximum" with up to 8 scalar loads per element and window: 6.1 ms for the 64-channel 896^2 map at B = 8.)
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const half_t* x, const half_t* dy, half_t* dx, int N, int H, int W, int c8, int OH,
+                                                          int OW, long x_ld, long x_lo) {
+  const int HB = (H + 1) / 2, WB = (W + 1) / 2;
+  const long total = (long)N * HB * WB * c8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cc = (int)(i % c8); long t = i / c8;
-    const int ix = (int)(t % W); t /= W;
-    const int iy = (int)(t % H); const int n = (int)(t / H);
-    float xv[8];
-    ld_split(x + (i / c8) * x_ld + cc * 8, x_lo, xv);
-    float acc[8];
+    const int b = (int)(t % WB); t /= WB;
+    const int a = (int)(t % HB); const int n = (int)(t / HB);
+    float acc[2][2][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int oy = iy / 2 > 0 ? iy / 2 - 1 : 0; oy <= (iy + 1) / 2 && oy < OH; ++oy) {
-      if (oy * 2 - 1 > iy || oy * 2 + 1 < iy) continue;
-      for (int ox = ix / 2 > 0 ? ix / 2 - 1 : 0; ox <= (ix + 1) / 2 && ox < OW; ++ox) {
-        if (ox * 2 - 1 > ix || ox * 2 + 1 < ix) continue;
-        const long oi = (((long)n * OH + oy) * OW + ox) * c8 + cc;
-        float yv[8];
-        ld_split(y + (oi / c8) * y_ld + cc * 8, y_lo, yv);
-        const h8 gv = *reinterpret_cast<const h8*>(dy + oi * 8);
-        // is (iy,ix) the FIRST position in the window attaining the max?
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (xv[e] != yv[e]) continue;
-          bool first = true;
-          for (int ky = 0; ky < 3 && first; ++ky) {
-            const int jy = oy * 2 - 1 + ky; if ((unsigned)jy >= (unsigned)H) continue;
-            for (int kx = 0; kx < 3; ++kx) {
-              const int jx = ox * 2 - 1 + kx; if ((unsigned)jx >= (unsigned)W) continue;
-              if (jy == iy && jx == ix) { ky = 3; break; }
-              const half_t* q = x + (((long)n * H + jy) * W + jx) * x_ld + cc * 8 + e;
-              if ((float)q[0] + (x_lo ? (float)q[x_lo] : 0.f) == yv[e]) { first = false; break; }
-            }
+      for (int e = 0; e < 8; ++e) acc[q >> 1][q & 1][e] = 0.f;
+#pragma unroll
+    for (int wy = 0; wy < 2; ++wy) {
+      const int oy = a + wy;
+      if (oy >= OH) continue;
+#pragma unroll
+      for (int wx = 0; wx < 2; ++wx) {
+        const int ox = b + wx;
+        if (ox >= OW) continue;
+        float m[8];
+        int idx[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; idx[e] = -1; }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int jy = 2 * oy - 1 + ky;
+          if ((unsigned)jy >= (unsigned)H) continue;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int jx = 2 * ox - 1 + kx;
+            if ((unsigned)jx >= (unsigned)W) continue;
+            float v[8];
+            ld_split(x + (((long)n * H + jy) * W + jx) * x_ld + cc * 8, x_lo, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (v[e] > m[e]) { m[e] = v[e]; idx[e] = ky * 3 + kx; }
           }
-          if (first) acc[e] += (float)gv[e];
+        }
+        const h8 g = *reinterpret_cast<const h8*>(dy + ((((long)n * OH + oy) * OW + ox) * c8 + cc) * 8);
+        // block pixel (py, px) sits at window position (py + 1 - 2 wy, px + 1 - 2 wx)
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+          const int ky = py + 1 - 2 * wy;
+          if (ky < 0) continue;
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const int kx = px + 1 - 2 * wx;
+            if (kx < 0) continue;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (idx[e] == ky * 3 + kx) acc[py][px][e] += (float)g[e];
+          }
         }
       }
     }
-    h8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
-    *reinterpret_cast<h8*>(dx + i * 8) = o;
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int iy = 2 * a + py, ix = 2 * b + px;
+        if (iy >= H || ix >= W) continue;
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[py][px][e];
+        *reinterpret_cast<h8*>(dx + ((((long)n * H + iy) * W + ix) * c8 + cc) * 8) = o;
+      }
   }
 }
 extern "C" int csbsr_maxpool3x3s2_fwd_split(const void* x, int64_t x_ld, int64_t x_lo, void* y, int64_t y_ld, int64_t y_lo, int32_t N,
@@ -880,8 +910,9 @@ extern "C" int csbsr_maxpool3x3s2_bwd_split(const void* x, int64_t x_ld, int64_t
                                             const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
   CSBSR_CHECK(x && y && dy && dx && c % 8 == 0, "maxpool_bwd: bad args");
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x,
-                     (const half_t*)y, (const half_t*)dy, (half_t*)dx, N, H, W, c / 8, OH, OW, x_ld, x_lo, y_ld, y_lo);
+  (void)y; (void)y_ld; (void)y_lo;        // (the saved output is not needed: the windows are rescanned)
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)N * ((H + 1) / 2) * ((W + 1) / 2) * (c / 8))), dim3(256), 0, ST(s), (const half_t*)x,
+                     (const half_t*)dy, (half_t*)dx, N, H, W, c / 8, OH, OW, x_ld, x_lo);
   CSBSR_LAUNCH_CHECK("csbsr_maxpool3x3s2_bwd");
   return 0;
 }

@@ -161,6 +161,19 @@ def test_maxpool_and_adaptive_pool():
     torch.cuda.synchronize()
     assert relmax(from_fm(fy), y.detach()) == 0.0
     assert relmax(from_fm(fdx), x.grad) < 2e-3
+    for (n_, c_, h_, w_) in ((1, 8, 7, 9), (2, 24, 16, 12), (1, 8, 1, 5)):          # odd / even / degenerate sizes, many ties (values on a coarse grid)
+        xq = r16((torch.randn(n_, c_, h_, w_) * 2).round() / 2).requires_grad_(True)
+        yq = F.max_pool2d(xq, 3, 2, 1)
+        dq = r16(torch.randn_like(yq))
+        yq.backward(dq)
+        fq = to_fm(xq.detach())
+        fo = eng.new(n_, yq.shape[2], yq.shape[3], c_)
+        L.call("csbsr_maxpool3x3s2_fwd", P(fq.t), P(fo.t), n_, h_, w_, c_, eng.stream)
+        fd = eng.new(n_, h_, w_, c_)
+        L.call("csbsr_maxpool3x3s2_bwd", P(fq.t), P(fo.t), P(to_fm(dq).t), P(fd.t), n_, h_, w_, c_, eng.stream)
+        torch.cuda.synchronize()
+        assert relmax(from_fm(fo), yq.detach()) == 0.0
+        assert relmax(from_fm(fd), xq.grad) < 2e-3, (n_, c_, h_, w_)
     for size in (1, 2, 3, 6):
         x2 = r16(torch.randn(2, 24, 8, 8)).requires_grad_(True)
         y2 = F.adaptive_avg_pool2d(x2, size)
