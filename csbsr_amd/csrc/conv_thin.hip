@@ -455,13 +455,18 @@ __global__ __launch_bounds__(256) void conv_thin_tp_kernel(const ConvK p, int gr
   const int by = (py + p.pad) / s, bx = (px + p.pad) / s;
   const int ph = py * s + px;
   const int co = oct * 8;
-  float w[4][CI][8];
+  // weights as fp16 channel pairs for v_dot2_f32_f16 (exact products, fp32 accumulate): (c0, c1) and (c2, 0) per tap -- the input's
+  // channel 3 is zero padding
+  static_assert(CI == 3, "channel pairs (c0, c1), (c2, pad)");
+  h2 w2[4][2][8];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int c = 0; c < CI; ++c)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) w[t][c][e] = (float)p.wt[((size_t)ph * p.rows_p + co + e) * p.Kp + t * p.ctot + c];
+    for (int e = 0; e < 8; ++e) {
+      const half_t* wp = p.wt + ((size_t)ph * p.rows_p + co + e) * p.Kp + t * p.ctot;
+      w2[t][0][e] = h2{wp[0], wp[1]};
+      w2[t][1][e] = h2{wp[2], (half_t)0};
+    }
   float bias[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f;
@@ -473,49 +478,60 @@ __global__ __launch_bounds__(256) void conv_thin_tp_kernel(const ConvK p, int gr
     const int qy = rg * rows_per_group + r;
     const int oy = qy * s + py;
     if (oy >= p.OH) break;
-    // four pixels per pass: their 16 input loads and 4 residual loads are in flight together (the loop is latency-bound otherwise:
-    // stores to out16 may alias every load as far as the compiler knows, so it would not hoist the next pixel's loads itself)
-    for (int qx0 = sub; qx0 * s + px < p.OW; qx0 += 4 * nsub) {
-      h8 xv[4][4], rr[4];
+    // EIGHT pixels per pass: their residual loads -- the HBM stream of this kernel -- are all requested up front (with four, 2 workgroups
+    // x 256 threads x 64 B kept 32 KB per CU in flight: 2.45 TB/s by Little's law, which is what the kernel ran at); the input loads
+    // (a 3-channel LR image: L1 / L2 hits) follow four pixels at a time.  Stores to out16 may alias every load as far as the compiler
+    // knows, so it would not hoist the next pixels' loads itself.
+    for (int qx0 = sub; qx0 * s + px < p.OW; qx0 += 8 * nsub) {
+      h8 rr[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int qx = qx0 + u * nsub, ox = qx * s + px;
-        const bool live = ox < p.OW;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int iy = qy + by - (t >> 1), ix = qx + bx - (t & 1);
-          xv[u][t] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-          if (live && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-            xv[u][t] = *reinterpret_cast<const h8*>(in0 + (long)iy * p.in[0].sy + (long)ix * p.in[0].sx);
-        }
+      for (int u = 0; u < 8; ++u) {
+        const int ox = (qx0 + u * nsub) * s + px;
         rr[u] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (live && rsign != 0.f) rr[u] = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + (long)oy * p.r_sy + (long)ox * p.r_sx + co);
+        if (ox < p.OW && rsign != 0.f) rr[u] = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + (long)oy * p.r_sy + (long)ox * p.r_sx + co);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int qx = qx0 + u * nsub, ox = qx * s + px;
-        if (ox >= p.OW) break;
-        float acc[8];
+      for (int half = 0; half < 2; ++half) {
+        h8 xv[4][4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int u = 0; u < 4; ++u) {
+          const int qx = qx0 + (4 * half + u) * nsub, ox = qx * s + px;
+          const bool live = ox < p.OW;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int c = 0; c < CI; ++c) {
-            const float xf = (float)xv[u][t][c];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += xf * w[t][c][e];
+          for (int t = 0; t < 4; ++t) {
+            const int iy = qy + by - (t >> 1), ix = qx + bx - (t & 1);
+            xv[u][t] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (live && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+              xv[u][t] = *reinterpret_cast<const h8*>(in0 + (long)iy * p.in[0].sy + (long)ix * p.in[0].sx);
           }
-        h8 hv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float t_ = acc[e] * p.out_scale + bias[e];
-          t_ = t_ > 0.f ? t_ : t_ * slope;
-          if (co + e >= p.cout) t_ = 0.f;
-          t_ += rsign * (float)rr[u][e];
-          hv[e] = (half_t)t_;
         }
-        *reinterpret_cast<h8*>(p.out16 + n * p.o_sn + (long)oy * p.o_sy + (long)ox * p.o_sx + co) = hv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int qx = qx0 + (4 * half + u) * nsub, ox = qx * s + px;
+          if (ox >= p.OW) break;
+          float acc[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const h2 x01 = h2{xv[u][t][0], xv[u][t][1]}, x23 = h2{xv[u][t][2], xv[u][t][3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              acc[e] = __builtin_amdgcn_fdot2(x01, w2[t][0][e], acc[e], false);
+              acc[e] = __builtin_amdgcn_fdot2(x23, w2[t][1][e], acc[e], false);
+            }
+          }
+          h8 hv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t_ = acc[e] * p.out_scale + bias[e];
+            t_ = t_ > 0.f ? t_ : t_ * slope;
+            if (co + e >= p.cout) t_ = 0.f;
+            t_ += rsign * (float)rr[4 * half + u][e];
+            hv[e] = (half_t)t_;
+          }
+          *reinterpret_cast<h8*>(p.out16 + n * p.o_sn + (long)oy * p.o_sy + (long)ox * p.o_sx + co) = hv;
+        }
       }
     }
   }
