@@ -43,6 +43,7 @@ struct ConvHrK {
   float* stat;                      // optional [N][coutp] per-sample channel sums of act(conv) (global average pool)
   float* stat_part;                 // ... as order-fixed partial rows [N][workgroups][waves][coutp] (launcher: zeroed before, folded after)
   unsigned tiles_x, tiles_y;
+  const float* cbias;               // optional [N][25][coutp] two-ring position-class bias (csbsr_conv_desc_t.cbias, cbias_mode 1), added before the activation
 };
 
 // Ring depth: as many halo tiles as fit the 160 KB of LDS, at most 3 (the tiles NBUF - 1 ahead are in flight while one is multiplied)
@@ -68,7 +69,7 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t hr_make_rs(const half_t
 }
 #endif
 
-template <int CH8, bool STAT, int TAPS, int NCT, bool MASK>
+template <int CH8, bool STAT, int TAPS, int NCT, bool MASK, bool CB = false>
 __global__ __launch_bounds__(64 * hr_nw(CH8, TAPS)) void conv_hr_kernel(const ConvHrK p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int HR_NW = hr_nw(CH8, TAPS);
@@ -291,6 +292,14 @@ __global__ __launch_bounds__(64 * hr_nw(CH8, TAPS)) void conv_hr_kernel(const Co
           // 2/3 of the tile time once a single wave per SIMD had to run it.)
           const int co = ct * 32 + 16 * pair + 8 * hi;
           const bool st_ok = live && co < p.coutp;
+          if constexpr (CB) {      // the folded constant segment: one of 25 values per (sample, cout), by the pixel's two-ring class
+            if (st_ok) {
+              const int ty = oy < 2 ? oy : (oy >= p.H - 2 ? oy - p.H + 5 : 2), tx = ox < 2 ? ox : (ox >= p.W - 2 ? ox - p.W + 5 : 2);
+              const float* cbp = p.cbias + ((size_t)n * 25 + ty * 5 + tx) * p.coutp + co;
+              const f4 c0 = *reinterpret_cast<const f4*>(cbp), c1 = *reinterpret_cast<const f4*>(cbp + 4);
+              v[0] += c0[0]; v[1] += c0[1]; v[2] += c0[2]; v[3] += c0[3]; v[4] += c1[0]; v[5] += c1[1]; v[6] += c1[2]; v[7] += c1[3];
+            }
+          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], v[e] * aslope);
           if constexpr (STAT) {
@@ -386,7 +395,9 @@ extern "C" int32_t csbsr_conv_hr_eligible(const csbsr_conv_desc_t* d) {
   if (d->in[1].c != 0 || d->in[0].sx == 0 || (d->in[0].c != 32 && d->in[0].c != 56)) return 0;
   if ((d->coutp > 64 && d->coutp != 128) || d->OH != d->H || d->OW != d->W) return 0;
   if (d->coutp == 128 && (d->stat_mode != CSBSR_STAT_NONE || d->mask)) return 0;      // 128 couts: the plain variant only
-  if (d->bias || d->cbias || d->res_mode != CSBSR_RES_NONE || d->accumulate || d->out32 || d->o_lo) return 0;
+  if (d->bias || d->res_mode != CSBSR_RES_NONE || d->accumulate || d->out32 || d->o_lo) return 0;
+  // a position-class bias: the two-ring table on the plain 1x1 variant with one cout tile (fe_cat.0 with its folded kernel branch)
+  if (d->cbias && !(d->cbias_mode == 1 && d->KH == 1 && d->coutp <= 32 && d->stat_mode == CSBSR_STAT_NONE && !d->mask && d->H >= 5 && d->W >= 5)) return 0;
   if (d->act != CSBSR_ACT_NONE && d->act != CSBSR_ACT_RELU && d->act != CSBSR_ACT_LRELU) return 0;
   if (d->stat_mode == CSBSR_STAT_BN || d->out_scale != 1.0f) return 0;
   if (d->mask && d->stat_mode != CSBSR_STAT_NONE) return 0;
@@ -417,6 +428,15 @@ static int launch_hr(const ConvHrK& k, hipStream_t st) {
     if (hipMemsetAsync(ks.stat_part, 0, (size_t)elems * 4, st) != hipSuccess) { csbsr_set_error("conv_hr: memset of the partial rows failed"); return 2; }
     hipLaunchKernelGGL((conv_hr_kernel<CH8, true, TAPS, NCT, false>), grid, dim3(64 * hr_nw(CH8, TAPS)), SM_BYTES, st, ks);
     if (int e = csbsr_sum_partials_batched(ks.stat_part, (int)rows_n, k.coutp, k.coutp, k.stat, k.N, k.coutp, st)) return e;
+  } else if (k.cbias) {
+    if constexpr (TAPS == 1 && NCT == 1) {
+      static LdsAttrOnce a3;
+      if (int e = csbsr_lds_attr(a3, reinterpret_cast<const void*>(conv_hr_kernel<CH8, false, TAPS, NCT, false, true>), SM_BYTES, "conv_hr")) return e;
+      hipLaunchKernelGGL((conv_hr_kernel<CH8, false, TAPS, NCT, false, true>), grid, dim3(64 * hr_nw(CH8, TAPS)), SM_BYTES, st, k);
+    } else {
+      csbsr_set_error("conv_hr: class bias on a variant that is not built");
+      return 1;
+    }
   } else if (k.mask) hipLaunchKernelGGL((conv_hr_kernel<CH8, false, TAPS, NCT, true>), grid, dim3(64 * hr_nw(CH8, TAPS)), SM_BYTES, st, k);
   else hipLaunchKernelGGL((conv_hr_kernel<CH8, false, TAPS, NCT, false>), grid, dim3(64 * hr_nw(CH8, TAPS)), SM_BYTES, st, k);
   CSBSR_LAUNCH_CHECK("csbsr_conv_hr_forward");
@@ -435,6 +455,7 @@ extern "C" int csbsr_conv_hr_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   k.act = d->act; k.slope = d->act_slope;
   k.mask = reinterpret_cast<const half_t*>(d->mask); k.m_sn = d->m_sn; k.m_sy = d->m_sy; k.m_sx = d->m_sx; k.mask_slope = d->mask_slope;
   k.stat = d->stat_mode == CSBSR_STAT_SAMPLE_SUM ? d->stat : nullptr; k.stat_part = nullptr;
+  k.cbias = d->cbias;
   k.tiles_x = (unsigned)((d->W + HR_TW - 1) / HR_TW); k.tiles_y = (unsigned)((d->H + HR_TH - 1) / HR_TH);
   CSBSR_CHECK(d->in[0].sy < (1l << 31) / 64, "conv_hr: row stride too large for 32-bit piece offsets");
   hipStream_t st = reinterpret_cast<hipStream_t>(s);

@@ -484,7 +484,8 @@ class Conv:
         if out is None:
             out = self.eng.new(x.N, x.H, x.W, self.cout)
         self._launch((x,), wt, False, self.k, 1, self.pad, self.dil, x.H, x.W, x.H, x.W, self.cout, out, None, self.b, self.act, self.slope,
-                     self.prelu, None, None, L.RES_NONE, False, None, L.STAT_NONE, 1.0, cbias=cb, cb_mode=cb_mode)
+                     self.prelu, None, None, L.RES_NONE, False, None, L.STAT_NONE, 1.0, cbias=cb, cb_mode=cb_mode,
+                     hr=(0, cf, self.cout, 0) if (self.k == 1 and cb_mode == 1 and self.prelu is None) else None)
         return out
 
     def fwd_const_1x1(self, cvec, x, out=None, stat=None, stat_mode=L.STAT_NONE):

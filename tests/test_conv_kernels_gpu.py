@@ -596,7 +596,7 @@ def test_wide_3x3_kernel_with_folded_constant_segment():
     assert relmax(outs[0], outs[1]) < 1e-3
 
 
-@pytest.mark.parametrize("H,W", [(5, 5), (12, 40), (33, 70)])
+@pytest.mark.parametrize("H,W", [(5, 5), (12, 40), (33, 70), (363, 371)])
 def test_conv_with_two_ring_class_bias(H, W):
     """fe_cat.0 as the model runs it (Conv.fwd_classbias, conv desc cbias_mode 1): a 1x1 conv over cat(features, a map that is the
     output of TWO zero-padded 3x3 convs of a spatially constant code) with the second segment folded into a [B, 25, cout] table by
@@ -622,6 +622,8 @@ def test_conv_with_two_ring_class_bias(H, W):
     conv = Conv(eng, "l", {"l.weight": w.cuda()}, 1, 1, 0, 1, bias=False, act=L.ACT_LRELU, slope=0.01, split=(cf, c1))
     y = conv.fwd_classbias(to_fm(eng, x), cb, 1)
     torch.cuda.synchronize()
+    # (full-resolution maps take the direct kernel's class-bias variant, csrc/conv_hr.hip; small ones the general kernel)
+    assert (L.load().csbsr_debug_last_conv_kernel() == 8) == (N * H * W >= 256 * 1024)
     assert relmax(from_fm(y), ref) < 2e-3
 
 
