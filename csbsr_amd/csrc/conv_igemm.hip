@@ -468,6 +468,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
     return conv_thin_cin_launch(k, d->in[0].creal, st);
   }
   if (!split_io && conv_thin_tp_eligible(k, d->in[0].creal, d->in[1].c != 0)) { g_last_conv_kernel = CONVK_THIN_TP; return conv_thin_tp_launch(k, st); }
+  if (!d->r_lo && !d->r2_lo && conv_thin_sc_eligible(k)) { g_last_conv_kernel = CONVK_THIN_SC; return conv_thin_sc_launch(k, st); }
   if (conv_glds_eligible(k)) return conv_glds_launch(k, nphase, maxM, st);
   CSBSR_CHECK(k.KHt * k.KWt <= NTAP_MAX, "conv: more taps per phase than the tap tables hold");
   g_last_conv_kernel = k.coutp > 64 ? CONVK_IGEMM128 : (k.coutp > 32 ? CONVK_IGEMM64 : CONVK_IGEMM32);

@@ -469,6 +469,7 @@ extern "C" void csbsr_debug_set_conv_glds(int mode) {
   g_glds_wide = (mode & 256) ? 0 : 1;            // bit 8: no 256-cout tile (A/B timing)
   g_glds_narrow = (mode & 1024) ? 0 : 1;         // bit 10: no 64-cout tile, 33..64-cout layers back on the register-staged kernel (A/B timing)
   conv_thin_enable((mode & 16) ? 0 : 1);      // bit 4: route the 3-channel heads through the generic kernel (A/B timing)
+  conv_thin_sc_enable((mode & 4096) ? 0 : 1);    // bit 12: the 128 -> 3 strided layers back on the general kernel (A/B timing)
   conv_thin_cin2_enable((mode & 512) ? 0 : 1);  // bit 9: no streaming variant of the 3-channel-input kernel (A/B timing, tests)
 }
 

@@ -558,3 +558,120 @@ int conv_thin_tp_launch(const ConvK& k, hipStream_t st) {
   CSBSR_LAUNCH_CHECK("csbsr_conv_forward(thin transposed)");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Strided convolution INTO <= 3 channels from 128 (8x8 stride 4 / 12x12 stride 8): the dgrad of kb.up_conv1 (ConvTranspose2d 3 -> 128, 8x8
+// stride 4; kbpn.py:372-374) -- the gradient of the 3-channel LR error image, an 8192-term dot product per output value over a 3.3 GB
+// map (N = 4).  On the 32-cout implicit-GEMM tile it ran at 1.8 TB/s with 29 of 32 MFMA columns multiplying zeros.  Here a wave owns four
+// consecutive output pixels of a row x all 16 channel octets (lane = 16 * pixel + octet): every tap is one fully coalesced 1 KB load
+// (4 x 256 contiguous bytes), multiplied with v_dot2_f32_f16 against the tap's weights for the lane's octet -- the whole packed weight
+// matrix sits in LDS ([tap][octet][cout][8], 49 KB for 8x8), read as three 16-byte broadcasts per tap -- and the 16 octet partial sums of
+// a pixel meet in a 4-step xor-shuffle.  A workgroup = 4 waves = a 4-row x 16-column tile of outputs: consecutive rows share half of
+// their input rows (L1), neighbouring tiles a fifth (L2).  Plain epilogue (out_scale only): fp32 planar and / or fp16 NHWC output.
+template <int KS>
+__global__ __launch_bounds__(256) void conv_thin_sc_kernel(const ConvK p, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = KS * KS;
+  h8* sW = reinterpret_cast<h8*>(smem);                       // [NT][16][3]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int oct = lane & 15, sub = lane >> 4;
+  for (int id = tid; id < NT * 16 * 3; id += 256) {
+    const int co = id % 3, o = (id / 3) & 15, tap = id / 48;
+    h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (co < p.cout) v = *reinterpret_cast<const h8*>(p.wt + (size_t)co * p.Kp + tap * p.ctot + o * 8);
+    sW[id] = v;
+  }
+  __syncthreads();
+  const half_t* in0 = reinterpret_cast<const half_t*>(p.in[0].ptr);
+  const int s = p.stride;
+  const unsigned per_img = (unsigned)(tiles_x * tiles_y), total = per_img * (unsigned)p.N;
+  for (unsigned t = blockIdx.x; t < total; t += gridDim.x) {
+    const int n = t / per_img;
+    const unsigned r_ = t - n * per_img;
+    const int oy = (int)(r_ / tiles_x) * 4 + wid, ox0 = (int)(r_ % tiles_x) * 16;
+    if (oy >= p.OH) continue;
+    const half_t* inn = in0 + (long)n * p.in[0].sn + oct * 8;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      const int ox = ox0 + 4 * q + sub;
+      const bool live = ox < p.OW;
+      const int iy0 = oy * s - p.pad, ix0 = ox * s - p.pad;
+      float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int ky = 0; ky < KS; ++ky) {
+        const int iy = iy0 + ky;
+        const bool rowok = live && (unsigned)iy < (unsigned)p.H;
+        const half_t* rowp = inn + (long)iy * p.in[0].sy;
+        h8 xv[KS];
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int ix = ix0 + kx;
+          xv[kx] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+          if (rowok && (unsigned)ix < (unsigned)p.W) xv[kx] = *reinterpret_cast<const h8*>(rowp + (long)ix * p.in[0].sx);
+        }
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const h8* wp = sW + ((ky * KS + kx) * 16 + oct) * 3;
+#pragma unroll
+          for (int co = 0; co < 3; ++co) {
+            const h8 w = wp[co];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[co] = __builtin_amdgcn_fdot2(h2{xv[kx][2 * j], xv[kx][2 * j + 1]}, h2{w[2 * j], w[2 * j + 1]}, acc[co], false);
+          }
+        }
+      }
+#pragma unroll
+      for (int co = 0; co < 3; ++co) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc[co] += __shfl_xor(acc[co], o, 64);
+        acc[co] *= p.out_scale;
+      }
+      if (live && oct == 0) {
+        if (p.out32) {
+          float* o32 = p.out32 + (long)n * p.o32_sn + (long)oy * p.o32_sy + (long)ox * p.o32_sx;
+          for (int co = 0; co < p.cout; ++co) o32[co * p.o32_sc] = acc[co];
+        }
+        if (p.out16) {
+          h8 hv = {0, 0, 0, 0, 0, 0, 0, 0};
+          hv[0] = (half_t)acc[0]; hv[1] = (half_t)acc[1]; hv[2] = (half_t)acc[2];
+          if (p.cout < 3) hv[2] = (half_t)0;
+          if (p.cout < 2) hv[1] = (half_t)0;
+          *reinterpret_cast<h8*>(p.out16 + n * p.o_sn + (long)oy * p.o_sy + (long)ox * p.o_sx) = hv;
+        }
+      }
+    }
+  }
+}
+
+static int g_conv_thin_sc = 1;
+void conv_thin_sc_enable(int on) { g_conv_thin_sc = on; }
+
+bool conv_thin_sc_eligible(const ConvK& k) {
+  if (!g_conv_thin_sc || k.transposed || k.dil != 1) return false;
+  if (k.KHt != k.KWt || (k.KHt != 8 && k.KHt != 12) || k.stride < 2 || k.pad < 0 || k.pad >= k.stride) return false;      // 8x8 s4, 12x12 s8 (kbpn.py:22-25)
+  if (k.c0 != k.ctot || k.ctot != 128 || k.in[0].sx == 0) return false;
+  if (k.cout > 3 || k.coutp != 8) return false;
+  if (k.bias || k.cbias || k.act != CSBSR_ACT_NONE || k.res_mode != CSBSR_RES_NONE || k.accumulate || k.mask || k.o_lo) return false;
+  if (k.stat_mode != CSBSR_STAT_NONE) return false;
+  if (k.OH != (k.H + 2 * k.pad - k.KHt) / k.stride + 1 || k.OW != (k.W + 2 * k.pad - k.KWt) / k.stride + 1) return false;
+  if ((long)k.N * k.OH * k.OW < 64L * 1024) return false;          // small maps: the general kernel
+  return true;
+}
+
+int conv_thin_sc_launch(const ConvK& k, hipStream_t st) {
+  const int tiles_x = (k.OW + 15) / 16, tiles_y = (k.OH + 3) / 4;
+  const long total = (long)k.N * tiles_x * tiles_y;
+  const size_t smem = (size_t)k.KHt * k.KWt * 16 * 3 * 16;
+  static LdsAttrOnce a8, a12;
+  const unsigned g = (unsigned)(total < 2048 ? total : 2048);
+  if (k.KHt == 8) {
+    if (int e = csbsr_lds_attr(a8, reinterpret_cast<const void*>(conv_thin_sc_kernel<8>), (int)smem, "conv(thin strided)")) return e;
+    hipLaunchKernelGGL((conv_thin_sc_kernel<8>), dim3(g), dim3(256), smem, st, k, tiles_x, tiles_y);
+  } else {
+    if (int e = csbsr_lds_attr(a12, reinterpret_cast<const void*>(conv_thin_sc_kernel<12>), (int)smem, "conv(thin strided)")) return e;
+    hipLaunchKernelGGL((conv_thin_sc_kernel<12>), dim3(g), dim3(256), smem, st, k, tiles_x, tiles_y);
+  }
+  CSBSR_LAUNCH_CHECK("csbsr_conv_forward(thin strided)");
+  return 0;
+}

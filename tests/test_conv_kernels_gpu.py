@@ -339,6 +339,32 @@ def test_hr_direct_conv_kernel(cin, cout, act, ks):
     assert relmax(from_fm(dx), refd) < 2e-3
 
 
+@pytest.mark.parametrize("k,s,N,h,w", [(8, 4, 4, 130, 141), (12, 8, 8, 96, 101)])
+def test_thin_strided_dgrad_kernel(k, s, N, h, w):
+    """The dgrad of kb.up_conv1 (ConvTranspose2d 3 -> 128, k = 2 x stride; kbpn.py:372-374) -- a strided conv from 128 channels into 3 --
+    on its own streaming kernel (csrc/conv_thin.hip, conv_thin_sc_kernel): fp32 planar output as the backward requests it, and the fp16
+    output; ragged tiles on both axes; against autograd on the same fp16-rounded operands."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    torch.manual_seed(k)
+    eng = _eng()
+    wt = (torch.randn(3, 128, k, k) / (3 * k * k / s / s) ** 0.5).half().float()
+    conv = Conv(eng, "l", {"l.weight": wt.cuda()}, k, s, 2, 1, transposed=True, bias=False)
+    dpre = torch.randn(N, 128, h * s, w * s).half().float()
+    xr = torch.zeros(N, 3, h, w, requires_grad=True)
+    F.conv_transpose2d(xr, wt, None, s, 2).backward(dpre)
+    dfm = to_fm(eng, dpre)
+    d32 = torch.empty(N, 3, h, w, device="cuda")
+    conv.bwd_input(dfm, out32=d32, in_hw=(h, w))
+    torch.cuda.synchronize()
+    assert L.load().csbsr_debug_last_conv_kernel() == 15
+    assert relmax(d32.cpu(), xr.grad) < 2e-3
+    d16 = conv.bwd_input(dfm, in_hw=(h, w))
+    torch.cuda.synchronize()
+    assert L.load().csbsr_debug_last_conv_kernel() == 15
+    assert relmax(from_fm(d16), xr.grad) < 2e-3
+
+
 def test_hr_direct_conv_kernel_128_couts():
     """32 -> 128 channels on the direct kernel (two groups of workgroups, two 32-cout tiles each): the launch that gathers a stage's slice
     of the concatenated feature gradient from the 3-channel dPre slots (KBPN._gather_conv) -- forward form, and the dgrad form the
