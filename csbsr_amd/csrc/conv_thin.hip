@@ -591,24 +591,29 @@ __global__ __launch_bounds__(256) void conv_thin_sc_kernel(const ConvK p, int ti
     const int oy = (int)(r_ / tiles_x) * 4 + wid, ox0 = (int)(r_ % tiles_x) * 16;
     if (oy >= p.OH) continue;
     const half_t* inn = in0 + (long)n * p.in[0].sn + oct * 8;
+    // two pixel quads per pass: a tap's weights (three 16-byte LDS broadcasts per lane -- the LDS port is this kernel's busiest unit) serve both
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-      const int ox = ox0 + 4 * q + sub;
-      const bool live = ox < p.OW;
-      const int iy0 = oy * s - p.pad, ix0 = ox * s - p.pad;
-      float acc[3] = {0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; q += 2) {
+      int oxs[2], ix0s[2];
+      bool lives[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { oxs[u] = ox0 + 4 * (q + u) + sub; lives[u] = oxs[u] < p.OW; ix0s[u] = oxs[u] * s - p.pad; }
+      const int iy0 = oy * s - p.pad;
+      float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 #pragma unroll 1
       for (int ky = 0; ky < KS; ++ky) {
         const int iy = iy0 + ky;
-        const bool rowok = live && (unsigned)iy < (unsigned)p.H;
+        const bool rowin = (unsigned)iy < (unsigned)p.H;
         const half_t* rowp = inn + (long)iy * p.in[0].sy;
-        h8 xv[KS];
+        h8 xv[2][KS];
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-          const int ix = ix0 + kx;
-          xv[kx] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-          if (rowok && (unsigned)ix < (unsigned)p.W) xv[kx] = *reinterpret_cast<const h8*>(rowp + (long)ix * p.in[0].sx);
-        }
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const int ix = ix0s[u] + kx;
+            xv[u][kx] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (rowin && lives[u] && (unsigned)ix < (unsigned)p.W) xv[u][kx] = *reinterpret_cast<const h8*>(rowp + (long)ix * p.in[0].sx);
+          }
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) {
           const h8* wp = sW + ((ky * KS + kx) * 16 + oct) * 3;
@@ -616,28 +621,35 @@ __global__ __launch_bounds__(256) void conv_thin_sc_kernel(const ConvK p, int ti
           for (int co = 0; co < 3; ++co) {
             const h8 w = wp[co];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[co] = __builtin_amdgcn_fdot2(h2{xv[kx][2 * j], xv[kx][2 * j + 1]}, h2{w[2 * j], w[2 * j + 1]}, acc[co], false);
+            for (int j = 0; j < 4; ++j) {
+              const h2 wj = h2{w[2 * j], w[2 * j + 1]};
+              acc[0][co] = __builtin_amdgcn_fdot2(h2{xv[0][kx][2 * j], xv[0][kx][2 * j + 1]}, wj, acc[0][co], false);
+              acc[1][co] = __builtin_amdgcn_fdot2(h2{xv[1][kx][2 * j], xv[1][kx][2 * j + 1]}, wj, acc[1][co], false);
+            }
           }
         }
       }
 #pragma unroll
-      for (int co = 0; co < 3; ++co) {
+      for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc[co] += __shfl_xor(acc[co], o, 64);
-        acc[co] *= p.out_scale;
-      }
-      if (live && oct == 0) {
-        if (p.out32) {
-          float* o32 = p.out32 + (long)n * p.o32_sn + (long)oy * p.o32_sy + (long)ox * p.o32_sx;
-          for (int co = 0; co < p.cout; ++co) o32[co * p.o32_sc] = acc[co];
+        for (int co = 0; co < 3; ++co) {
+#pragma unroll
+          for (int o = 8; o > 0; o >>= 1) acc[u][co] += __shfl_xor(acc[u][co], o, 64);
+          acc[u][co] *= p.out_scale;
         }
-        if (p.out16) {
-          h8 hv = {0, 0, 0, 0, 0, 0, 0, 0};
-          hv[0] = (half_t)acc[0]; hv[1] = (half_t)acc[1]; hv[2] = (half_t)acc[2];
-          if (p.cout < 3) hv[2] = (half_t)0;
-          if (p.cout < 2) hv[1] = (half_t)0;
-          *reinterpret_cast<h8*>(p.out16 + n * p.o_sn + (long)oy * p.o_sy + (long)ox * p.o_sx) = hv;
+        const int ox = oxs[u];
+        if (lives[u] && oct == 0) {
+          if (p.out32) {
+            float* o32 = p.out32 + (long)n * p.o32_sn + (long)oy * p.o32_sy + (long)ox * p.o32_sx;
+            for (int co = 0; co < p.cout; ++co) o32[co * p.o32_sc] = acc[u][co];
+          }
+          if (p.out16) {
+            h8 hv = {0, 0, 0, 0, 0, 0, 0, 0};
+            hv[0] = (half_t)acc[u][0]; hv[1] = (half_t)acc[u][1]; hv[2] = (half_t)acc[u][2];
+            if (p.cout < 3) hv[2] = (half_t)0;
+            if (p.cout < 2) hv[1] = (half_t)0;
+            *reinterpret_cast<h8*>(p.out16 + n * p.o_sn + (long)oy * p.o_sy + (long)ox * p.o_sx) = hv;
+          }
         }
       }
     }
