@@ -25,47 +25,60 @@ import torch  # noqa: E402
 # the 441 kernel-code input channels of the six SFT conv0's: 6.66 TFLOP forward; x3 for fwd + dgrad + wgrad = 35.0 TFLOP), so
 # the reduced figures are the denominator (never divide folded run time into unfolded work).  Bytes: the folded
 # fe_kernel.0 conv I/O (37.8 GB) is replaced by the class-filled map (2.5 GB); the SFT code channels were never read from HBM.
-ALG_TFLOP_PER_IMG_448 = 108.3 - 35.0
-ALG_GB_PER_IMG_448 = 249.0 - 37.8 + 2.5
+# Round 3 folded one layer deeper (the whole fe_kernel branch of a kernel predictor is a [B, 25, 32] bias table):
+# fe_kernel.1 (49 -> 49 3x3 at HR, 4 x 0.1388 TFLOP forward) and the second half of fe_cat.0's input (49 -> 32 1x1, 4 x 0.0101) no
+# longer run: -0.595 TFLOP forward, x3 = -1.79 TFLOP; bytes: the class-filled fe_kernel.0 map (2.5 GB) is gone again, with it
+# fe_kernel.1's conv I/O (98 channel planes at HR x 4 stages x 3 passes = 7.55 GB) and the 49 constant-branch input planes of fe_cat.0
+# (3.78 GB).
+ALG_TFLOP_PER_IMG_448 = 108.3 - 35.0 - 1.79
+ALG_GB_PER_IMG_448 = 249.0 - 37.8 - 7.55 - 3.78
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(lr=112, seconds_budget=20.0):
+def cpu_baseline(lr=112, seconds_budget=20.0, threads=0):
     """The oracle (CPU restatement of the reference path, fp32 torch ops) timed on this host's cores on a bounded sample of the
-    bench workload: B=1, LR 112 -> HR 448 (BASELINE.md section 2's CPU-runnable size), forward + backward, repeated until ~the
-    budget; imgs/s scaled to LR 448 by the pixel ratio (x16; every term of the path is linear in pixels).  ``--cpu-baseline-lr 32``
-    gives round 1's smaller sample (B=2), which over-states CPU throughput ~5x: its maps are cache-resident."""
+    bench workload: B=2, LR 112 -> HR 448 (BASELINE.md section 2's CPU-runnable size; LR 448 needs ~300 GB of
+    host RAM for the autograd tape), forward + backward, after one tiny untimed step that pays the allocator's and the thread pool's
+    warm-up; steps are repeated until ~the budget (one B=2 step is ~25 s, so usually ONE timed step); imgs/s scaled to LR 448 by the
+    pixel ratio (x16; every term of the path is linear in pixels)."""
     from oracle import csbsr_oracle as O
     from csbsr_amd.utils.detfill import det_state_dict
     from csbsr_amd.modeling.shapes import joint_state_shapes
     from csbsr_amd.data.synthetic import make_batch
-    # intra-op threads: the oracle's convolutions stop scaling past ~16 threads (a 256-thread pool on the GPU box's host took 315 s
-    # for one LR-32 step against ~1.3 s with 16), so the pool is capped and the count actually used is reported
-    cores = min(os.cpu_count() or 1, 16)
+    # intra-op threads: measured on the GPU box's host (256 hardware threads) the oracle's convolutions do not scale past ~16 threads --
+    # one LR-32 step took 315 s on the default 256-thread pool against 1.3 s with 16 (oversubscribed OpenMP barriers in the many small
+    # grouped / thin convolutions) -- so the pool is capped at 16 unless --cpu-baseline-threads says otherwise; the count used is reported
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, threads if threads > 0 else 16)
     torch.set_num_threads(cores)
     P = det_state_dict(joint_state_shapes())
     for k, v in P.items():
         if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
             v.requires_grad_(True)
     cfg = O.PathCfg()
-    B = 2 if lr <= 32 else 1
-    x, hr, mask, k = make_batch(B, lr, seed=1)
-    n, t0, per = 0, time.time(), []
-    while True:          # at least two steps (the first one also pays the allocator's and the thread pool's warm-up), then until the budget
-        t1 = time.time()
-        out = O.joint_forward(P, cfg, 40000, x, hr, mask, k, alpha=0.9)
+    B = 2
+
+    def one(xb):
+        out = O.joint_forward(P, cfg, 40000, *xb, alpha=0.9)
         O.calc_loss(out["segment_loss"], out["sr_loss"], 40000, cfg).backward()
+    one(make_batch(B, 16, seed=2))          # untimed warm-up (HR 64)
+    batch = make_batch(B, lr, seed=1)
+    n, t0, per = 0, time.time(), []
+    while True:
+        t1 = time.time()
+        one(batch)
         per.append(time.time() - t1)
         n += 1
-        if (n >= 2 and time.time() - t0 > seconds_budget) or n >= 40:
+        if time.time() - t0 > seconds_budget or n >= 40:
             break
     dt = time.time() - t0
     per_s = ", ".join("%.1f" % t for t in per[:8])
     ips = B * n / dt
     scale = (448.0 / lr) ** 2
     return {"value": ips / scale, "unit": "imgs/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fwd+bwd, B={B}, LR {lr}->HR {lr * 4}, {n} steps in {dt:.1f}s (per step: {per_s} s) = {ips:.4f} img/s at LR {lr}; "
+            "cores_note": f"{cores} intra-op threads of the host's {ncpu}: the fp32 torch oracle stops scaling there (a 256-thread pool ran the same step 240x slower); --cpu-baseline-threads overrides",
+            "sample": f"oracle fwd+bwd, B={B}, LR {lr}->HR {lr * 4}, {n} step(s) in {dt:.1f}s after a tiny warm-up step (per step: {per_s} s) = {ips:.4f} img/s at LR {lr}; "
                       f"divided by (448/{lr})^2 = {scale:.2f} (conv work linear in pixels) to quote it at LR 448"}
 
 
@@ -90,6 +103,7 @@ def main():
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the extra (untimed-for-value) leg that re-times the step with the PCIe copy of the batch inside")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-lr", type=int, default=112, help="LR size of the bounded CPU sample (112 = BASELINE.md section 2's size; 32 = round 1's)")
+    ap.add_argument("--cpu-baseline-threads", type=int, default=0, help="intra-op threads of the CPU sample (0 = min(host threads, 16), see cpu_baseline)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dump-layers", default=None, help="write the per-launch conv / wgrad log of the timed region (layer, shape, kernel, ms) as JSON")
     args = ap.parse_args()
@@ -190,6 +204,20 @@ def main():
     imgs = B * world * args.steps / dt
     timing_log, eng.timing = eng.timing, None
     peak_main = torch.cuda.max_memory_allocated(dev)          # of the warm-up + timed steps only: the extra legs below have their own peaks
+    # the KBPN residency schedule the step ran with (agreed over the ranks: JointModelWithLoss._auto_resident) and every rank's peak
+    n_mb = (B + max(1, min(args.micro_batch, B)) - 1) // max(1, min(args.micro_batch, B))
+    schedule = {"micro_batches": n_mb, "n_resident": int(getattr(model, "_n_res", 0)), "lean_saves": bool(getattr(model, "_lean", False)),
+                "peak_mem_gb_per_rank": [round(peak_main / 2 ** 30, 1)]}
+    exposed = model.reducer.exposed_ms()[-args.steps:] if dist_on else []          # of the timed steps (the device is synchronised)
+    if dist_on:
+        pk = torch.tensor([peak_main / 2 ** 30], device=dev, dtype=torch.float64)
+        allpk = [torch.zeros_like(pk) for _ in range(world)]
+        dist.all_gather(allpk, pk)
+        schedule["peak_mem_gb_per_rank"] = [round(float(t), 1) for t in allpk]
+        sc = torch.tensor([schedule["n_resident"], int(schedule["lean_saves"])], device=dev, dtype=torch.int64)
+        lo, hi = sc.clone(), sc.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        schedule["same_on_every_rank"] = bool((lo == hi).all())
     # ---- extra leg (never `value`): the same step with the host -> device copy of the batch inside it (SURVEY 8d counts it; the
     # bench contract wants inputs resident).  Pinned host buffers, a few steps.
     h2d = None
@@ -301,16 +329,20 @@ def main():
                "loss": round(last, 5),
                "step_roofline": {"hbm_frac": round(ALG_GB_PER_IMG_448 * pix / per_img_s / HBM_PEAK_GBS, 4),
                                  "mfma_frac": round(ALG_TFLOP_PER_IMG_448 * pix / per_img_s / MFMA_PEAK_TFLOPS, 4),
-                                 "note": "algorithmic work per image at LR 448 after exact constant-operand folding (fe_kernel.0 + SFT code channels): 73.3 TFLOP / 213.7 GB (SURVEY.md 8(d) as-executed: 108.3 TFLOP / 249 GB)"},
+                                 "note": f"algorithmic work per image at LR 448 after exact constant-operand folding (the fe_kernel branch of every kernel predictor + the SFT code channels): {ALG_TFLOP_PER_IMG_448:.1f} TFLOP / {ALG_GB_PER_IMG_448:.1f} GB (SURVEY.md 8(d) as-executed: 108.3 TFLOP / 249 GB; rounds 1-3 divided by 73.3 TFLOP / 213.7 GB)"},
                "roofline": roof,
                "peak_mem_gb": round(peak_main / 2 ** 30, 1),
                "with_h2d_inside_step": h2d}
-        if dist_on:      # what the gradient exchange did (per rank): collectives, how many rode the side stream, payload
-            out["reducer"] = dict(model.reducer.stats, broadcasts=n_bcast, backend=backend, world=world)
+        out["schedule"] = schedule
+        if dist_on:      # what the gradient exchange did (per rank): collectives, how many rode the side stream, payload, and how long the
+            # compute stream waited for the exchange at the end of each backward (the part NOT hidden under it), rank 0's view
+            out["reducer"] = dict(model.reducer.stats, broadcasts=n_bcast, backend=backend, world=world,
+                                  exposed_all_reduce_ms_per_step=round(sum(exposed) / max(len(exposed), 1), 3),
+                                  exposed_all_reduce_ms_max=max(exposed, default=0.0))
         if other:
             out["step_roofline"] = None          # the folded-work figures above are config 2's
         if not args.no_cpu_baseline and world == 1 and not other:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_lr)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_lr, threads=args.cpu_baseline_threads)
         print(json.dumps(out))
     if dist_on:
         dist.destroy_process_group()

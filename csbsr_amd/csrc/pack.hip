@@ -9,7 +9,7 @@ struct PackK {
   int D0, D1, KH, KW, stride, pad;
   int seg0_real, seg0_p, segtot_p, chan_real;
   int row_off, nrows, rows_p, Kp, KHt, KWt, nphase, k_off;
-  int split;           // 1: K channels are [hi | hi | lo] blocks of seg0_p each, 2: [hi | lo] (csbsr_pack_weights_split)
+  int split;           // 1: K channels are [hi | hi | lo] blocks of seg0_p each, 2: [hi | lo], 3: [hi | hi] (csbsr_pack_weights_split)
   float wscale;        // weights are multiplied by this power of two before the fp16 split (keeps the lo halves out of subnormals)
 };
 
@@ -46,7 +46,7 @@ __global__ void pack_weights_kernel(const PackK p) {
     if (p.split) {
       v *= p.wscale;
       const half_t hi = (half_t)v;
-      p.dst[i] = blk < (p.split == 1 ? 2 : 1) ? hi : (half_t)(v - (float)hi);
+      p.dst[i] = blk < (p.split == 2 ? 1 : 2) ? hi : (half_t)(v - (float)hi);
     } else {
       p.dst[i] = (half_t)v;
     }
@@ -73,11 +73,13 @@ static void pack_geometry(int kind, int D0, int D1, int KH, int KW, int stride, 
 // layout 1 (dgrad of the split-precision detector): the activation gradient is plain fp16, passed as in[0] = in[1] = dY, against
 // [w_hi | w_lo]:  dY w_hi + dY w_lo -- the weight's fp16 rounding error is the same for every pixel, so unlike the (incoherent)
 // rounding of the gradients it does not average out in the BatchNorm backward sums
+// layout 2 (per-layer precision plan): in[0] = [x_hi | x_lo] alone against [w_hi | w_hi]: the activation keeps its ~22 bits, the
+// weight its fp16 rounding (two K blocks instead of three)
 static void pack_geometry_split(int kind, int D0, int D1, int KH, int KW, int stride, int creal, int nrows, int layout, PackK& p) {
   pack_geometry(kind, D0, D1, KH, KW, stride, creal, 0, nrows, p);
-  p.segtot_p = (layout == 1 ? 2 : 3) * p.seg0_p;
+  p.segtot_p = (layout == 0 ? 3 : 2) * p.seg0_p;
   p.Kp = round_up(p.KHt * p.KWt * p.segtot_p, 64);
-  p.split = layout == 1 ? 2 : 1;
+  p.split = layout == 1 ? 2 : (layout == 2 ? 3 : 1);
 }
 
 extern "C" int64_t csbsr_packed_weight_elems(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,

@@ -218,6 +218,10 @@ class Conv:
         self.prelu = params[prelu] if prelu else None
         self._packed = {}
         self.hp_dgrad = False        # detector precision mode: dgrad against [w_hi | w_lo] (two MFMA passes), see bwd_input
+        # detector precision mode, per layer (the model's precision plan): K blocks a forward conv of a split (hi + lo) input runs --
+        # 3: x_hi w_hi + x_lo w_hi + x_hi w_lo;  2: [x_hi | x_lo] w_hi (the weight's rounding error stays);  1: x_hi w_hi, plain fp16
+        # operands.  The output is stored as a hi + lo pair in every case, so the layers around it need not know.
+        self.fwd_blocks = 3
 
     # -- packed operand cache (invalidated by the model at every optimiser step)
     def invalidate(self):
@@ -249,6 +253,14 @@ class Conv:
         self._packed[key] = dst
         return dst
 
+    def _split_operand(self, x, key, kind, creal, nrows, stride, pad, k_off=0):
+        """(input FMs, packed weights, out_scale, K blocks) of a forward conv whose input is a split map, per this layer's plan."""
+        nb = self.fwd_blocks
+        if nb == 1:      # the hi plane alone against plain fp16 weights
+            return (FM(x.t, x.c, H=x.H, W=x.W),), self._pack((key, 1), kind, creal, 0, 0, nrows, stride, pad, k_off), 1.0, 1
+        wt = self._pack_split((key, nb), kind, creal, nrows, stride, pad, k_off=k_off, layout=0 if nb == 3 else 2)
+        return (x,), wt, 1.0 / self.WSCALE, nb
+
     def out_size(self, H, W):
         k, s, p, d = self.k, self.stride, self.pad, self.dil
         if self.transposed:
@@ -257,12 +269,15 @@ class Conv:
 
     def _launch(self, xs, wt, transposed, k, stride, pad, dil, H, W, OH, OW, cout, out, out32, bias, act, slope, prelu, res, res2,
                 res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None, hr=None, tp=None, dact=None, x3=None, dres=None,
-                cb_mode=0):
+                cb_mode=0, split_blocks=3):
         d = L.ConvDesc()
         x0 = xs[0]
-        if x0.lo:                       # split-fp16 input: [hi | lo] + hi again, weights from _pack_split
-            assert len(xs) == 1 and not transposed
-            d.inp[0], d.inp[1] = x0.split_segs()
+        if x0.lo:                       # split-fp16 input: [hi | lo] (+ hi again for the x_hi w_lo block), weights from _pack_split
+            assert len(xs) == 1 and not transposed and split_blocks in (2, 3)
+            s0, s1 = x0.split_segs()
+            d.inp[0] = s0
+            if split_blocks == 3:
+                d.inp[1] = s1
         else:
             d.inp[0] = x0.seg()
             if len(xs) > 1:
@@ -373,7 +388,7 @@ class Conv:
             # twice) -- which goes into the last field, not into the FLOPs
             twice = len(xs) == 2 and xs[0] is xs[1]
             ctot = xs[0].c if twice else sum(f.c for f in xs)
-            executed = 3 if x0.lo else (2 if twice else 1)
+            executed = split_blocks if x0.lo else (2 if twice else 1)
             npx = x0.N * OH * OW
             taps = k * k if not transposed else ((k + stride - 1) // stride) ** 2
             flops = 2.0 * npx * cout * ctot * taps
@@ -389,19 +404,21 @@ class Conv:
         sp = bool(xs[0].lo)
         if out is None and store and out32 is None:
             out = self.eng.new(xs[0].N, OH, OW, self.cout, split=sp)
+        osc, nb = 1.0, 3
         if sp:
             assert not self.transposed and self.split[1] == 0
-            wt = self._pack_split("fwd_split", 0, self.cin, self.cout, self.stride, self.pad)
+            xs, wt, osc, nb = self._split_operand(xs[0], "fwd_split", 0, self.cin, self.cout, self.stride, self.pad)
         elif self.transposed:
             wt = self._pack("fwd", 2, self.split[0], self.split[1], 0, self.cout, self.stride, self.pad)
         else:
             wt = self._pack("fwd", 0, self.split[0], self.split[1], 0, self.cout, self.stride, self.pad)
         hr = (0, self.cin, self.cout, 0) if (not sp and not self.transposed and self.k in (1, 3) and len(xs) == 1 and self.prelu is None) else None
         self._launch(xs, wt, self.transposed, self.k, self.stride, self.pad, self.dil, H, W, OH, OW, self.cout, out, out32, self.b,
-                     self.act, self.slope, self.prelu, res, res2, res_mode, False, stat, stat_mode, 1.0 / self.WSCALE if sp else 1.0, hr=hr,
+                     self.act, self.slope, self.prelu, res, res2, res_mode, False, stat, stat_mode, osc, hr=hr,
                      tp=(self.cin, self.cout, 0, 0) if (self.transposed and len(xs) == 1 and not sp) else None,
                      x3=((0 if self.k == 3 else 2, self.cin, self.cout, 0, 0)
-                         if (not sp and not self.transposed and len(xs) == 1 and (self.k == 3 or self.k == 2 * self.stride)) else None))
+                         if (not sp and not self.transposed and len(xs) == 1 and (self.k == 3 or self.k == 2 * self.stride)) else None),
+                     split_blocks=nb)
         return out
 
     def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None, mask=None, dact=None, dres=None):
@@ -458,7 +475,11 @@ class Conv:
         cf = self.split[0]
         B = x.N
         sp = bool(x.lo)
-        wt = self._pack_split("fwd_feat_split", 0, cf, self.cout, 1, self.pad) if sp else self._pack("fwd_feat", 0, cf, 0, 0, self.cout, 1, self.pad, 0)
+        xs, osc, nb = (x,), 1.0, 3
+        if sp:
+            xs, wt, osc, nb = self._split_operand(x, "fwd_feat_split", 0, cf, self.cout, 1, self.pad)
+        else:
+            wt = self._pack("fwd_feat", 0, cf, 0, 0, self.cout, 1, self.pad, 0)
         # the constant part is a tiny fp32 mat-vec: operands rounded to fp16 only in the plain mode (there they mirror the MFMA path)
         w16c = self.w[:, cf:] if sp else self.w[:, cf:].to(torch.float16).float()
         k16 = kvec.to(torch.float32) if sp else kvec.to(torch.float16).float()
@@ -469,9 +490,9 @@ class Conv:
         H, W = x.H, x.W
         if out is None:
             out = self.eng.new(B, H, W, self.cout, split=sp)
-        self._launch((x,), wt, False, 3, 1, self.pad, self.dil, H, W, H, W, self.cout, out, None, self.b, self.act, self.slope, self.prelu,
-                     None, None, L.RES_NONE, False, None, L.STAT_NONE, 1.0 / self.WSCALE if sp else 1.0, cbias=cb,
-                     x3=None if sp else (0, cf, self.cout, 0, 0))
+        self._launch(xs, wt, False, 3, 1, self.pad, self.dil, H, W, H, W, self.cout, out, None, self.b, self.act, self.slope, self.prelu,
+                     None, None, L.RES_NONE, False, None, L.STAT_NONE, osc, cbias=cb,
+                     x3=None if sp else (0, cf, self.cout, 0, 0), split_blocks=nb)
         return out, (w16c, k16)
 
     def fwd_classbias(self, x, cb, cb_mode, out=None):
@@ -495,14 +516,18 @@ class Conv:
         c0 = self.split[0]
         B = x.N
         sp = bool(x.lo)
-        wt = self._pack_split("fwd_x_split", 0, self.split[1], self.cout, 1, 0, k_off=c0) if sp else self._pack("fwd_x", 0, self.split[1], 0, 0, self.cout, 1, 0, c0)
+        xs, osc, nb = (x,), 1.0, 3
+        if sp:
+            xs, wt, osc, nb = self._split_operand(x, "fwd_x_split", 0, self.split[1], self.cout, 1, 0, k_off=c0)
+        else:
+            wt = self._pack("fwd_x", 0, self.split[1], 0, 0, self.cout, 1, 0, c0)
         T = cvec.to(torch.float32) @ self.w[:, :c0, 0, 0].t()              # [B, cout]
         cb = self.eng.f32(B, 16, pad8(self.cout))
         cb[:, :, :self.cout] = T[:, None, :]
         if out is None:
             out = self.eng.new(B, x.H, x.W, self.cout, split=sp)
-        self._launch((x,), wt, False, 1, 1, 0, 1, x.H, x.W, x.H, x.W, self.cout, out, None, self.b, self.act, self.slope, self.prelu,
-                     None, None, L.RES_NONE, False, stat, stat_mode, 1.0 / self.WSCALE if sp else 1.0, cbias=cb)
+        self._launch(xs, wt, False, 1, 1, 0, 1, x.H, x.W, x.H, x.W, self.cout, out, None, self.b, self.act, self.slope, self.prelu,
+                     None, None, L.RES_NONE, False, stat, stat_mode, osc, cbias=cb, split_blocks=nb)
         return out
 
     def bwd_weights_folded(self, dpre, x, saved, mtap, frozen=False):

@@ -146,6 +146,17 @@ class _JointBase(nn.Module):
         #            time (~11 % of a config-2 step) and 2x its activation memory; the backward is unchanged (fp16 hi planes).
         #   "fp16"   fp16 activation storage, one MFMA pass: the throughput configuration, reported beside the headline by bench.py.
         self.detector_precision = "split"
+        # Per-layer refinement of the split mode (the precision PLAN): an ordered list of (regex on the conv's parameter name, K blocks)
+        # -- 3 = full hi + lo product, 2 = hi + lo activation against the fp16 weight, 1 = plain fp16 operands (Conv.fwd_blocks); the
+        # first match wins, unmatched layers run 3 blocks.  Swept in round 4 on the reference's own SR images (scripts/study_split_plan.py,
+        # profiles/r04_split_plan_study.json): every group of the trunk needs all three blocks (layer 3 alone at two blocks: 2.2e-3 on the
+        # map); only the tail (up_1 .. final) and the PSP module stay under 1e-3 with two, each eating a third to a half of the margin for
+        # < 2 % of the step, so the default plan is None.
+        # ``detector_hp_dgrad``: dgrads against [w_hi | w_lo] (two K blocks).  The same sweep shows it buys nothing -- every detector
+        # gradient tensor and dLoss/dSR agree with the reference equally well without it (PSPNet median 1.15e-2 vs 1.12e-2, HRNet-OCR
+        # 1.65e-2 both, BlurSkip 9.4e-4 vs 9.1e-4: the error is the ReLU-gate flips of the forward, not the weights' rounding) -- so it is off.
+        self.detector_plan = None
+        self.detector_hp_dgrad = False
 
     # ---- naming: state_dict keys are the reference's dotted names
     def _named_full(self):
@@ -186,8 +197,11 @@ class _JointBase(nn.Module):
             raise ValueError(f"detector_precision must be 'fp16' or 'split', got {self.detector_precision!r}")
         split = self.detector_precision == "split"
         self._rt["psp"].split = split
+        import re
+        plan = [(re.compile(pat), int(nb)) for pat, nb in (self.detector_plan or ())]
         for c in self._rt["psp"].all_convs():      # the split mode's dgrads run against fp16 hi + lo weight pairs (Conv.bwd_input)
-            c.hp_dgrad = split
+            c.hp_dgrad = split and bool(self.detector_hp_dgrad)
+            c.fwd_blocks = next((nb for pat, nb in plan if pat.search(c.name)), 3)
         return self._rt
 
     def _bucket_of(self, name):
@@ -303,17 +317,18 @@ class JointModelWithLoss(_JointBase):
         H, W = h * pc.scale, w * pc.scale
         mb = max(1, min(self.micro_batch, B))
         n_res, lean = (self.max_resident, bool(self.lean_saves)) if self.max_resident is not None else self._auto_resident(B, mb, H, W)
-        self._n_res = n_res
+        self._n_res, self._lean = n_res, lean
         single = mb >= B
         sr32 = eng.f32(B, 3, H, W, zero=False)
         kvec = eng.f32(B, pc.ksize_out ** 2, zero=False)
         training = self.training
         keep = training and torch.is_grad_enabled()
-        saves = []
+        saves, self._pad_takes = [], []
         for i, b0 in enumerate(range(0, B, mb)):
             resident = keep and i < n_res and not self.blur_skip     # BlurSkip: KBPN is frozen, no backward through it
             s_, k_ = kbpn.forward(x[b0:b0 + mb], iter, kgt[b0:b0 + mb], save=resident, lean=lean)
             saves.append(kbpn.saved if resident else None)
+            self._pad_takes.append(kbpn.pad_taken)        # ZERO_PAD_KERNEL: a recomputed forward replays these (KBPN.forward)
             kbpn.saved = None
             sr32[b0:b0 + mb] = s_
             kvec[b0:b0 + mb] = k_
@@ -411,7 +426,8 @@ class JointModelWithLoss(_JointBase):
         if keep:
             st = dict(iter=iter, x=x, hr=hr, mask=mask, kgt=kgt, sr32=sr32, kvec=kvec, ksum=ksum, vec=vec, mean=mean, invstd=invstd,
                       seg32=seg32, aux32=aux32, sdf=sdf, sums_m=sums_m, sums_a=sums_a, alpha=alpha, lr_pred=lr_pred,
-                      wmap=wmap, wmap_lr=wmap_lr, saves=saves, mb=mb, B=B, h=h, w=w, psp_saved=psp_saved, n_res=self._n_res, sr_w=sr_w)
+                      wmap=wmap, wmap_lr=wmap_lr, saves=saves, mb=mb, B=B, h=h, w=w, psp_saved=psp_saved, n_res=self._n_res, sr_w=sr_w,
+                      pad_takes=getattr(self, "_pad_takes", None) if saves is not None else None)
             params = [p for p in self.parameters()]
             seg_loss, sr_loss = _JointFn.apply(self, st, seg_loss, sr_loss, *params)
         return seg_loss, sr_loss, seg32, sr32, kpred
@@ -434,6 +450,15 @@ class JointModelWithLoss(_JointBase):
             imgs = int((free - 18e9 - det) // (per_img * r)) if r > 0 else B
             return max(0, min(n_mb, imgs // mb))
         full, lean = fit(26.5e9), fit(21.2e9)      # lean saves: the kernel predictors' fe_SR chains are rebuilt in the backward (KBPN.forward)
+        if self.reducer is not None and self.reducer.active:
+            # data-parallel: the ranks must take the SAME schedule (at ~240 of 288 GB the collective library's buffers can tip one rank into
+            # recomputing a KBPN forward, and every other rank would wait for it at the all-reduce): the minimum over the ranks, agreed
+            # once per problem shape in one tiny collective and kept for the life of the model
+            key = (B, mb, H, W, self.detector_precision)
+            agreed = self.__dict__.setdefault("_sched_agreed", {})
+            if key not in agreed:
+                agreed[key] = self.reducer.agree_min([full, lean])
+            full, lean = agreed[key]
         if self.lean_saves is not None:
             return (lean, True) if self.lean_saves else (full, False)
         return (lean, True) if lean > full else (full, False)
@@ -526,7 +551,8 @@ class JointModelWithLoss(_JointBase):
                 launched.add(f"kbpn.{s}")
         for j, (i, b0, recompute) in enumerate(sched):
             if recompute:
-                kbpn.forward(st["x"][b0:b0 + mb], st["iter"], st["kgt"][b0:b0 + mb], save=True)
+                kbpn.forward(st["x"][b0:b0 + mb], st["iter"], st["kgt"][b0:b0 + mb], save=True,
+                             pad_replay=st["pad_takes"][i] if kbpn.zero_pad else None)
             else:
                 kbpn.saved, saves[i] = saves[i], None
             kbpn.backward(dsr32[b0:b0 + mb].contiguous(), dkvec[b0:b0 + mb].contiguous(),

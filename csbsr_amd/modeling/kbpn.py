@@ -140,6 +140,7 @@ class KBPN:
         # padding instead of the bicubic map (hard threshold on .item(): no gradient reaches the MLP); Z is that padding as a [kk, kc] matrix
         self.zero_pad = bool(getattr(cfg, "zero_pad_kernel", False))
         self.pad_dropout = True        # the MLP's two nn.Dropout(0.2) in training (the owner turns it off with its own dropout switch)
+        self._pad_replay, self.pad_taken = None, []
         pz = (self.K - cfg.ksize) // 2
         self.Z = F.pad(eye, (pz, pz, pz, pz)).reshape(kc, self.kk).t().contiguous().to(eng.device)
         if self.zero_pad:
@@ -215,13 +216,17 @@ class KBPN:
         return FM(t, g.shape[1], bcast=True, H=H, W=W)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x32, it, kernel_gt, save=True, lean=False):
+    def forward(self, x32, it, kernel_gt, save=True, lean=False, pad_replay=None):
         """x32: fp32 NCHW LR batch on device.  Returns (sr32 [B,3,H,W] fp32, kvec [B,kk] fp32 normalised).
+        ``pad_replay``: MODEL.ZERO_PAD_KERNEL only -- the per-stage pad decisions (``self.pad_taken`` of an earlier forward of the same
+        micro-batch) to replay instead of evaluating the pad discriminator again: its nn.Dropout layers make the hard choice random in
+        training, and a forward recomputed inside the backward must be the SAME function as the one that produced the losses.
         ``lean``: do not keep the fe_SR chain of the per-stage kernel predictors for the backward (208 of the ~1040 HR channel planes a
         stage saves: 5.3 of 26.5 GB per image at HR 1792^2); the backward rebuilds it from the saved 3-channel SR estimate with five thin
         convolutions per stage (~2 % of a step, bit-identical values: the path is order-fixed)."""
         e = self.eng
         self.lean = bool(lean)
+        self._pad_replay, self.pad_taken = pad_replay, []
         self.set_phase(it)
         B, _, h, w = x32.shape
         H, W = h * self.scale, w * self.scale
@@ -344,6 +349,10 @@ class KBPN:
         B = d49.shape[0]
         if not self.zero_pad:
             return self.U.unsqueeze(0).expand(B, -1, -1)
+        if self._pad_replay is not None:      # recomputed forward: the decision of the forward that produced the losses
+            take_up = self._pad_replay[len(self.pad_taken)]
+            self.pad_taken.append(take_up)
+            return torch.where(take_up.reshape(B, 1, 1), self.U.unsqueeze(0), self.Z.unsqueeze(0))
         with torch.no_grad():
             drop = self.pad_dropout and self.training_mode
             hdn = d49
@@ -352,6 +361,7 @@ class KBPN:
                 if i < 2:
                     hdn = F.dropout(F.relu(hdn), 0.2, training=drop)
             take_up = torch.sigmoid(hdn).reshape(B) >= 0.5
+        self.pad_taken.append(take_up)
         return torch.where(take_up.reshape(B, 1, 1), self.U.unsqueeze(0), self.Z.unsqueeze(0))
 
     # ------------------------------------------------------------------ backward

@@ -30,7 +30,24 @@ class GradBucketReducer:
         self.force = (_forced() if force is None else bool(force)) and dist.is_initialized()
         self._pending = []
         # what was exchanged so far: collectives issued, of which on the side stream, and payload bytes (tests / bench JSON)
-        self.stats = {"all_reduces": 0, "on_side_stream": 0, "bytes": 0, "steps": 0}
+        self.stats = {"all_reduces": 0, "on_side_stream": 0, "bytes": 0, "steps": 0, "agreements": 0}
+        self._exposed = []          # per step: (event at the main stream's arrival in finish(), event after its last wait)
+
+    def agree_min(self, values):
+        """Element-wise minimum of a short list of ints over the ranks (one tiny collective): every rank must take the same
+        memory-dependent scheduling decision -- a rank that alone recomputes a forward makes all the others wait at the all-reduce."""
+        if not self.active:
+            return [int(v) for v in values]
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.pg)
+        self.stats["agreements"] += 1
+        return [int(v) for v in t.tolist()]
+
+    def exposed_ms(self):
+        """per finished step: how long the compute stream stood still in finish() until the last bucket had arrived, i.e. the part of
+        the gradient exchange that was NOT hidden under the backward (call after a device synchronize)."""
+        return [round(a.elapsed_time(b), 3) for a, b in self._exposed]
 
     @property
     def active(self):
@@ -71,12 +88,22 @@ class GradBucketReducer:
 
     def finish(self):
         """Wait for every launched bucket and write the averaged values back in place."""
-        for grads, live, flat, work in self._pending:
+        timed = [h for h in self._pending if h[3] is not None and h[2].is_cuda]
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        for grads, live, flat, work in self._pending:       # first every wait (that is what can be exposed), then the arithmetic
             if work is None:
                 continue
             work.wait()
             if self.side_stream is not None and flat.is_cuda:
                 torch.cuda.current_stream(flat.device).wait_stream(self.side_stream)
+        if timed:
+            ev1.record()
+            self._exposed = (self._exposed + [(ev0, ev1)])[-64:]
+        for grads, live, flat, work in self._pending:
+            if work is None:
+                continue
             if self.world > 1:          # (a one-rank group's sum is the value itself: forced runs stay bit-identical to undistributed ones)
                 flat.mul_(1.0 / self.world)
             if live is None:            # launch_flat: the accumulators are views of the bucket

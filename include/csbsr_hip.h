@@ -192,7 +192,8 @@ int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32_t D0, int3
  * MFMA passes; the dropped x_lo w_lo term is ~2^-22 relative).  wscale (a power of two, undone by the conv's out_scale) keeps w_lo
  * out of fp16's subnormal range.  Single-segment layers only. */
 /* layout 0: the three-block forward operand above.  layout 1: two blocks [w_hi | w_lo] for the dgrads of that mode, whose input (a
- * plain fp16 activation gradient) is passed twice, in[0] = in[1] = dY. */
+ * plain fp16 activation gradient) is passed twice, in[0] = in[1] = dY.  layout 2: two blocks [w_hi | w_hi] against in[0] = [x_hi | x_lo]
+ * alone (a layer whose precision plan keeps the activation's ~22 bits but not the weight's). */
 int64_t csbsr_packed_weight_elems_split(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t stride,
                                         int32_t creal, int32_t nrows, int32_t layout);
 int csbsr_pack_weights_split(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,

@@ -191,6 +191,25 @@ def test_up_down_scheduler_matches_the_reference_rule():
     assert abs(opt.param_groups[0]["lr"] - 2e-4) < 1e-12
 
 
+def test_warmup_multistep_lr_matches_the_reference_rule():
+    """lr_scheduler.py:14-29: linear ramp from warmup_factor * SOLVER.LR to SOLVER.LR over warmup_iters steps, then constant (the
+    milestones are never consulted); every parameter group gets that rate (the reference returns a one-element list, which current torch
+    rejects for more than one group)."""
+    from csbsr_amd.config import cfg
+    from csbsr_amd.utils.lr_scheduler import WarmupMultiStepLR
+    c = cfg.clone()
+    c.SOLVER.LR = 2e-5
+    opt = torch.optim.Adam([{"params": [torch.nn.Parameter(torch.zeros(1))]}, {"params": [torch.nn.Parameter(torch.zeros(1))], "lr": 7e-3}], lr=1.0)
+    sch = WarmupMultiStepLR(c, opt, milestones=[3, 6], gamma=0.1, warmup_factor=1.0 / 3, warmup_iters=4)
+    seen = []
+    for _ in range(8):
+        seen.append(opt.param_groups[0]["lr"])
+        opt.step(); sch.step()
+    want = [2e-5 * f for f in (1 / 3, 1 / 3 + 2 / 3 * 0.25, 1 / 3 + 2 / 3 * 0.5, 1 / 3 + 2 / 3 * 0.75, 1, 1, 1, 1)]
+    assert all(abs(a - b) < 1e-12 for a, b in zip(seen, want)), (seen, want)
+    assert opt.param_groups[1]["lr"] == 2e-5
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
 def test_no_cpu_fallback():
     from csbsr_amd import _lib as L
