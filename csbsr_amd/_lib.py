@@ -34,7 +34,8 @@ class ConvDesc(C.Structure):
                 ("o_lo", i64), ("r_lo", i64), ("r2_lo", i64),
                 ("mask", vp), ("m_sn", i64), ("m_sy", i64), ("m_sx", i64), ("mask_slope", f32), ("cbias_mode", i32),
                 ("mask_prelu", vp), ("dact_bias", vp), ("dact_prelu", vp),
-                ("dres", vp), ("dr_sn", i64), ("dr_sy", i64), ("dr_sx", i64)]
+                ("dres", vp), ("dr_sn", i64), ("dr_sy", i64), ("dr_sx", i64),
+                ("split_fused", i32), ("_pad_sf", i32)]
 
 
 class WgradDesc(C.Structure):

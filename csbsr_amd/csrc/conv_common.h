@@ -40,6 +40,7 @@ struct ConvK {
   // csbsr_sum_partials* (no atomics: two runs are bit-identical).  hw_pad > 0: the linear pixel index is laid out per sample,
   // each sample padded to hw_pad (a multiple of the pixel tile) positions, so a tile never straddles two samples.
   float* stat_part; long stat_ld; int hw_pad;
+  int fs;                    // 1: fused split-fp16 input (csbsr_conv_desc_t::split_fused): in[0] = [hi | lo], c0 = ctot = 2 x plane channels
 };
 
 // value -> (hi, lo) fp16 pair with hi + lo == value to ~2^-22 relative (lo is exact down to fp16's subnormal spacing, 6e-8)

@@ -441,6 +441,8 @@ int conv_desc_to_k(const csbsr_conv_desc_t* d, ConvK& k) {
   CSBSR_CHECK(!d->o_lo || d->out16, "conv: o_lo without out16");
   k.tile2d = 0; k.nphase_flat = 0; k.tap_group = 0;
   k.stat_part = nullptr; k.stat_ld = 0; k.hw_pad = 0;
+  k.fs = d->split_fused ? 1 : 0;
+  CSBSR_CHECK(!k.fs || (d->in[1].c == 0 && d->in[0].c % 64 == 0 && !d->transposed), "conv: split_fused needs one [hi | lo] segment of 2 x (a multiple of 32) channels");
   CSBSR_CHECK(d->stat_mode == CSBSR_STAT_NONE || d->stat, "conv: stat_mode set without stat buffer");
   return 0;
 }
@@ -470,6 +472,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   if (!split_io && conv_thin_tp_eligible(k, d->in[0].creal, d->in[1].c != 0)) { g_last_conv_kernel = CONVK_THIN_TP; return conv_thin_tp_launch(k, st); }
   if (!d->r_lo && !d->r2_lo && conv_thin_sc_eligible(k)) { g_last_conv_kernel = CONVK_THIN_SC; return conv_thin_sc_launch(k, st); }
   if (conv_glds_eligible(k)) return conv_glds_launch(k, nphase, maxM, st);
+  CSBSR_CHECK(!k.fs, "conv: split_fused launch not eligible for the LDS-DMA kernels (needs > 32 padded output channels)");
   CSBSR_CHECK(k.KHt * k.KWt <= NTAP_MAX, "conv: more taps per phase than the tap tables hold");
   g_last_conv_kernel = k.coutp > 64 ? CONVK_IGEMM128 : (k.coutp > 32 ? CONVK_IGEMM64 : CONVK_IGEMM32);
   if (k.coutp > 64) return launch_conv<128, 2, 2>(k, nphase, maxM, st);

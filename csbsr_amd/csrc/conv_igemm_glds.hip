@@ -22,8 +22,14 @@ extern "C" int csbsr_debug_read_ts(void* dst, long n) { return (int)hipMemcpyFro
 #else
 #define TS(i)
 #endif
-template <int BM, int NWM, int NSTAGE, int CT = 1>     // CT: 128-cout tiles per workgroup (2: a 256-cout tile, every wave 64 px x 128 couts;
-                                                       // 0: a 64-cout tile for the 33..64-cout layers, every wave 64 px x 32 couts)
+// FS (fused split-fp16 input, csbsr_conv_desc_t::split_fused): the input segment is a [hi | lo] plane pair and a K slice holds 32
+// channels of x_hi and the same 32 of x_lo (pixel tile) next to 32 of w_hi and of w_lo (weight tile, csbsr_pack_weights_split layout 3).
+// The three products of the split arithmetic -- x_hi w_hi + x_lo w_hi + x_hi w_lo -- are all fed from that ONE staged slice: six
+// k-slice MFMA groups per stage instead of four, i.e. the 3x MFMA work of the precision mode for 2x the staged bytes (the
+// three-block form stages x_hi twice and w_hi twice: 3x).  The kernel is bound by its stage refills, so the
+// launch time follows the staged bytes.
+template <int BM, int NWM, int NSTAGE, int CT = 1, bool FS = false>     // CT: 128-cout tiles per workgroup (2: a 256-cout tile, every wave
+                                                       // 64 px x 128 couts; 0: a 64-cout tile for the 33..64-cout layers, every wave 64 px x 32 couts)
 __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK p, const half_t* __restrict__ zero_page) {
   constexpr int BN = CT ? 128 * CT : 64, BKG = 64;
   constexpr int TA = CT ? 2 * CT : 1;                // 32-cout MFMA tiles per wave
@@ -136,7 +142,10 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 
   // ---- per-lane DMA roles.  Instruction j = wid + NW*i of a stage covers tile rows 8j .. 8j+7, lane -> row 8j + lane/8,
   // LDS chunk position c' = lane%8, channel chunk c = c' ^ ((row>>1)&7) = c' ^ ((4*(wid&1) + lane/16) & 7) for every i.
-  const int cch = ((lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7)) * 8;          // halves
+  const int cchunk = (lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7);
+  const int cch = cchunk * 8;          // halves (weight rows; pixel rows of a plain input)
+  // FS: chunks 0..3 of a pixel row are 32 channels of the hi plane, chunks 4..7 the same 32 channels of the lo plane (c0 / 2 elements on)
+  const int cchx = FS ? (cchunk & 3) * 8 + (cchunk >> 2) * (p.c0 >> 1) : cch;
   // Per row: the 64-bit element offset of tap (0,0) in each input segment and a bit per tap saying whether that tap lands inside
   // the image (from the tables above).  Per slice only a wave-uniform base pointer changes.
   long off0[NXI], off1[NXI];
@@ -144,8 +153,8 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 #pragma unroll
   for (int i = 0; i < NXI; ++i) {
     const int r = 8 * (wid + NW * i) + (lane >> 3);
-    off0[i] = sOff0[r] + cch;
-    off1[i] = sOff1[r] + cch;
+    off0[i] = sOff0[r] + cchx;
+    off1[i] = sOff1[r] + cchx;
     tapmask[i] = sMask[r];
   }
   const half_t* wrow[NI - NXI];
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 
   auto issue = [&](int kt) {
     char* sbase = smem + (kt % NSTAGE) * STAGE_BYTES;
-    const half_t* xb = (seg0 ? xb0 : xb1) + cs;                                              // wave-uniform
+    const half_t* xb = (seg0 ? xb0 : xb1) + (FS ? (cs >> 1) : cs);                           // wave-uniform (FS: K slice s = channels 32 s .. of both planes)
     const unsigned long long bit = 1ull << tap;                                             // ntaps <= 64 (eligibility)
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
@@ -276,6 +285,42 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
         bf[b] = *reinterpret_cast<const h8*>(xs + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
       }
     };
+    if constexpr (FS) {
+      // chunk pairs ks = 0, 1: channels 0..15 / 16..31 of the hi halves, ks = 2, 3: of the lo halves (pixel AND weight tile)
+      auto load_w = [&](int ks, h8 (&af)[TA]) {
+        const int c = ks * 2 + (lane >> 5);
+#pragma unroll
+        for (int a = 0; a < TA; ++a) {
+          const int R = wr0 + a * 32;
+          af[a] = *reinterpret_cast<const h8*>(ws + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+        }
+      };
+      auto load_x = [&](int ks, h8 (&bf)[2]) {
+        const int c = ks * 2 + (lane >> 5);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int R = xr0 + b * 32;
+          bf[b] = *reinterpret_cast<const h8*>(xs + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+        }
+      };
+      auto mm = [&](const h8 (&af)[TA], const h8 (&bf)[2]) {
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+      };
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        h8 af[TA], bh[2], bl[2];
+        load_w(j, af); load_x(j, bh);
+        mm(af, bh);                      // x_hi w_hi
+        load_x(j + 2, bl);
+        mm(af, bl);                      // x_lo w_hi
+        load_w(j + 2, af);
+        mm(af, bh);                      // x_hi w_lo
+      }
+      continue;
+    }
     if constexpr (CT == 2) {      // 8 MFMAs per sub-step cover the next fragment reads; one fragment set keeps the wave inside 256 registers
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -431,7 +476,7 @@ static int g_glds_tap_group = 1;
 static int g_glds_wide = 1;
 static int g_glds_narrow = 1;
 
-template <int BM, int NWM, int NSTAGE, int CT = 1>
+template <int BM, int NWM, int NSTAGE, int CT = 1, bool FS = false>
 static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   ConvK p = k;
   constexpr int BN = CT ? 128 * CT : 64, SOW = BN > 128 ? 128 : BN;
@@ -445,7 +490,7 @@ static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   constexpr int SM_BYTES = (RING > EPI ? RING : EPI) + BM * (4 * 8 + 3 * 4) + 3 * BN * 4;      // ring / staged tile + row tables + statistics + bias
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
   static LdsAttrOnce attr;
-  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT>), SM_BYTES, "conv(glds)")) return e;
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT, FS>), SM_BYTES, "conv(glds)")) return e;
   if (!g_zero_page) {
     if (hipMalloc(reinterpret_cast<void**>(&g_zero_page), 256) != hipSuccess) { csbsr_set_error("conv(glds): zero page alloc failed"); return 2; }
     (void)hipMemset(g_zero_page, 0, 256);
@@ -454,7 +499,7 @@ static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   ConvStatPlan sp;
   if (int e = conv_stat_prepare(p, BM, nphase, sp, st)) return e;
   dim3 grid(p.tiles_m * p.tiles_n * (p.nphase_flat ? nphase : 1), 1, p.nphase_flat ? 1 : nphase);
-  hipLaunchKernelGGL((conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT>), grid, dim3(NWM * 128), SM_BYTES, st, p, g_zero_page);
+  hipLaunchKernelGGL((conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT, FS>), grid, dim3(NWM * 128), SM_BYTES, st, p, g_zero_page);
   if (int e = conv_stat_finish(p, sp, st)) return e;
   CSBSR_LAUNCH_CHECK("csbsr_conv_forward(glds)");
   return 0;
@@ -492,8 +537,13 @@ int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   // 256 px x 256 couts (128 flop per staged byte instead of 85) where the couts fill 256-wide tiles about as well as 128-wide ones
   const int pad128 = (k.coutp + 127) / 128 * 128, pad256 = (k.coutp + 255) / 256 * 256;
   const bool wide = big && g_glds_wide && k.coutp >= 256 && pad256 * 8 <= pad128 * 9 + 64;
-  if (k.coutp <= 64) { g_last_conv_kernel = CONVK_GLDS64; return launch_glds<128, 2, 2, 0>(k, nphase, maxM, st); }
+  if (k.coutp <= 64) { g_last_conv_kernel = CONVK_GLDS64; return k.fs ? launch_glds<128, 2, 2, 0, true>(k, nphase, maxM, st) : launch_glds<128, 2, 2, 0>(k, nphase, maxM, st); }
   g_last_conv_kernel = big ? (wide ? CONVK_GLDS256W : CONVK_GLDS256) : CONVK_GLDS128;
+  if (k.fs) {
+    if (!big) return launch_glds<128, 2, 2, 1, true>(k, nphase, maxM, st);
+    if (wide) return launch_glds<256, 4, 2, 2, true>(k, nphase, maxM, st);
+    return launch_glds<256, 4, 3, 1, true>(k, nphase, maxM, st);
+  }
   if (!big) return launch_glds<128, 2, 2>(k, nphase, maxM, st);
   if (wide) return launch_glds<256, 4, 2, 2>(k, nphase, maxM, st);
   return launch_glds<256, 4, 3>(k, nphase, maxM, st);

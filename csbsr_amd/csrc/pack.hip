@@ -9,7 +9,7 @@ struct PackK {
   int D0, D1, KH, KW, stride, pad;
   int seg0_real, seg0_p, segtot_p, chan_real;
   int row_off, nrows, rows_p, Kp, KHt, KWt, nphase, k_off;
-  int split;           // 1: K channels are [hi | hi | lo] blocks of seg0_p each, 2: [hi | lo], 3: [hi | hi] (csbsr_pack_weights_split)
+  int split;           // 1: K channels are [hi | hi | lo] blocks of seg0_p each, 2: [hi | lo], 3: [hi | hi], 4: per 32-channel slice [hi 32 | lo 32] (csbsr_pack_weights_split)
   float wscale;        // weights are multiplied by this power of two before the fp16 split (keeps the lo halves out of subnormals)
 };
 
@@ -25,7 +25,8 @@ __global__ void pack_weights_kernel(const PackK p) {
     const int cp = k - tap * p.segtot_p;
     // padded channel -> real channel of the K side
     int c = -1, blk = 0;
-    if (p.split) { blk = cp / p.seg0_p; const int c1 = cp - blk * p.seg0_p; if (c1 < p.seg0_real) c = c1; }
+    if (p.split == 4) { blk = (cp >> 5) & 1; const int c1 = (cp >> 6) * 32 + (cp & 31); if (c1 < p.seg0_real) c = c1; }
+    else if (p.split) { blk = cp / p.seg0_p; const int c1 = cp - blk * p.seg0_p; if (c1 < p.seg0_real) c = c1; }
     else if (cp < p.seg0_p) { if (cp < p.seg0_real) c = cp; }
     else { const int c1 = cp - p.seg0_p; if (p.seg0_real + c1 < p.chan_real) c = p.seg0_real + c1; }
     if (c >= 0) c += p.k_off;
@@ -46,7 +47,7 @@ __global__ void pack_weights_kernel(const PackK p) {
     if (p.split) {
       v *= p.wscale;
       const half_t hi = (half_t)v;
-      p.dst[i] = blk < (p.split == 2 ? 1 : 2) ? hi : (half_t)(v - (float)hi);
+      p.dst[i] = blk < ((p.split == 2 || p.split == 4) ? 1 : 2) ? hi : (half_t)(v - (float)hi);
     } else {
       p.dst[i] = (half_t)v;
     }
@@ -75,11 +76,14 @@ static void pack_geometry(int kind, int D0, int D1, int KH, int KW, int stride, 
 // rounding of the gradients it does not average out in the BatchNorm backward sums
 // layout 2 (per-layer precision plan): in[0] = [x_hi | x_lo] alone against [w_hi | w_hi]: the activation keeps its ~22 bits, the
 // weight its fp16 rounding (two K blocks instead of three)
+// layout 3 (fused form of layout 0, csbsr_conv_desc_t::split_fused): per tap and 32-channel slice [w_hi (32) | w_lo (32)] -- one 64-wide
+// K slice of the LDS-DMA kernels, staged next to [x_hi (32) | x_lo (32)] and used for all three products
 static void pack_geometry_split(int kind, int D0, int D1, int KH, int KW, int stride, int creal, int nrows, int layout, PackK& p) {
   pack_geometry(kind, D0, D1, KH, KW, stride, creal, 0, nrows, p);
+  if (layout == 3) p.seg0_p = round_up(creal, 32);      // whole 32-channel slices
   p.segtot_p = (layout == 0 ? 3 : 2) * p.seg0_p;
   p.Kp = round_up(p.KHt * p.KWt * p.segtot_p, 64);
-  p.split = layout == 1 ? 2 : (layout == 2 ? 3 : 1);
+  p.split = layout == 1 ? 2 : (layout == 2 ? 3 : (layout == 3 ? 4 : 1));
 }
 
 extern "C" int64_t csbsr_packed_weight_elems(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,

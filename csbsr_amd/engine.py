@@ -118,6 +118,7 @@ class Engine:
         self.use_hr = os.environ.get("CSBSR_CONV_HR", "1") != "0"       # A/B hook: 0 routes the HR small-channel layers through the implicit-GEMM kernels
         self.use_x3 = os.environ.get("CSBSR_CONV_X3", "1") != "0"       # A/B hook: 0 routes the wide 3x3 layers through the implicit-GEMM kernels
         self.use_tp = os.environ.get("CSBSR_CONV_TP", "1") != "0"       # A/B hook: 0 routes the 2x2-tap transposed layers through the implicit-GEMM kernels
+        self.split_fused = os.environ.get("CSBSR_SPLIT_FUSED", "1") != "0"   # A/B hook: 0 = the three-block split forward (x_hi staged twice)
         self.timing = None              # list of (kind, flops, bytes, start_event, end_event) when profiling is on
 
     @property
@@ -258,6 +259,10 @@ class Conv:
         nb = self.fwd_blocks
         if nb == 1:      # the hi plane alone against plain fp16 weights
             return (FM(x.t, x.c, H=x.H, W=x.W),), self._pack((key, 1), kind, creal, 0, 0, nrows, stride, pad, k_off), 1.0, 1
+        if nb == 3 and self.eng.split_fused and x.cp % 32 == 0 and pad8(nrows) > 32 and kind == 0:
+            # fused form (csbsr_conv_desc_t::split_fused): one staged K slice = 32 channels of [x_hi | x_lo] against [w_hi | w_lo], all three
+            # products from it -- the LDS-DMA kernels' launch time follows the staged bytes, 2/3 of the three-block form's
+            return (x,), self._pack_split((key, "fs"), kind, creal, nrows, stride, pad, k_off=k_off, layout=3), 1.0 / self.WSCALE, 4
         wt = self._pack_split((key, nb), kind, creal, nrows, stride, pad, k_off=k_off, layout=0 if nb == 3 else 2)
         return (x,), wt, 1.0 / self.WSCALE, nb
 
@@ -273,11 +278,12 @@ class Conv:
         d = L.ConvDesc()
         x0 = xs[0]
         if x0.lo:                       # split-fp16 input: [hi | lo] (+ hi again for the x_hi w_lo block), weights from _pack_split
-            assert len(xs) == 1 and not transposed and split_blocks in (2, 3)
+            assert len(xs) == 1 and not transposed and split_blocks in (2, 3, 4)      # 4: the fused three-product form
             s0, s1 = x0.split_segs()
             d.inp[0] = s0
             if split_blocks == 3:
                 d.inp[1] = s1
+            d.split_fused = int(split_blocks == 4)
         else:
             d.inp[0] = x0.seg()
             if len(xs) > 1:
@@ -388,7 +394,7 @@ class Conv:
             # twice) -- which goes into the last field, not into the FLOPs
             twice = len(xs) == 2 and xs[0] is xs[1]
             ctot = xs[0].c if twice else sum(f.c for f in xs)
-            executed = split_blocks if x0.lo else (2 if twice else 1)
+            executed = min(split_blocks, 3) if x0.lo else (2 if twice else 1)
             npx = x0.N * OH * OW
             taps = k * k if not transposed else ((k + stride - 1) // stride) ** 2
             flops = 2.0 * npx * cout * ctot * taps

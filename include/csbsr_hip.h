@@ -100,6 +100,12 @@ typedef struct {
    * its activation is rebuilt as mask -+ res, and dres (fp16 NHWC, same geometry as out16) receives d(res) = +- the unmasked result
    * (kbpn.py:254-256, DownBlock: l1 = down_conv3(h0 - x)) */
   void* dres; int64_t dr_sn, dr_sy, dr_sx;
+  /* csbsr_conv_forward only.  1: FUSED split-fp16 input -- in[0] = the [hi | lo] channel pair (2c channels, c a multiple of 32), in[1]
+   * unused, weights from csbsr_pack_weights_split layout 3 ([w_hi | w_lo] per 32-channel slice).  One staged K slice then holds 32
+   * channels of x_hi and x_lo against the same 32 of w_hi and w_lo and feeds all three products (x_hi w_hi + x_lo w_hi + x_hi w_lo)
+   * from it: 2/3 of the operand traffic of the three-block form above for the same arithmetic.  LDS-DMA kernels only (> 32 padded
+   * output channels); the call fails otherwise. */
+  int32_t split_fused; int32_t _pad_sf;
 } csbsr_conv_desc_t;
 
 int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
@@ -193,7 +199,8 @@ int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32_t D0, int3
  * out of fp16's subnormal range.  Single-segment layers only. */
 /* layout 0: the three-block forward operand above.  layout 1: two blocks [w_hi | w_lo] for the dgrads of that mode, whose input (a
  * plain fp16 activation gradient) is passed twice, in[0] = in[1] = dY.  layout 2: two blocks [w_hi | w_hi] against in[0] = [x_hi | x_lo]
- * alone (a layer whose precision plan keeps the activation's ~22 bits but not the weight's). */
+ * alone (a layer whose precision plan keeps the activation's ~22 bits but not the weight's).  layout 3: the fused form of layout 0
+ * (csbsr_conv_desc_t::split_fused): per tap and 32-channel slice [w_hi (32) | w_lo (32)]; creal padded to a multiple of 32. */
 int64_t csbsr_packed_weight_elems_split(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t stride,
                                         int32_t creal, int32_t nrows, int32_t layout);
 int csbsr_pack_weights_split(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,

@@ -793,3 +793,67 @@ def test_phase_decomposed_dgrad_with_the_residual_layers_epilogue_backward(H, W)
     assert relmax(grad_acc(pb["b.bias"]).cpu(), ref_db) < 2e-3
     assert abs(float(grad_acc(pb["a"]).cpu()) - float(ref_da)) < 2e-3 * float((dy * (y / a0))[neg].abs().sum()) ** 0.5 + 2e-3 * abs(float(ref_da))
 
+
+
+# ---------------------------------------------------------------------------------------------- split-fp16 (hi + lo) forward convs
+def to_fm_split(eng, x):      # NCHW fp32 cpu -> split FM (value = hi + lo)
+    from csbsr_amd.engine import pad8
+    N, C, H, W = x.shape
+    fm = eng.new(N, H, W, C, zero=True, split=True)
+    v = x.permute(0, 2, 3, 1).contiguous()
+    hi = v.half()
+    fm.t[..., :C] = hi.cuda()
+    fm.t.as_strided(fm.t.shape, fm.t.stride(), fm.t.storage_offset() + fm.lo)[..., :C] = (v - hi.float()).half().cuda()
+    return fm
+
+
+def from_fm_split(fm):
+    lo = fm.t.as_strided(fm.t.shape, fm.t.stride(), fm.t.storage_offset() + fm.lo)
+    return (fm.t[..., :fm.c].float() + lo[..., :fm.c].float()).cpu().permute(0, 3, 1, 2)
+
+
+SPLIT_CASES = [
+    # cin, cout, k, stride, pad, dil, H, W, N          (input channels a multiple of 32: the fused form; else the three-block form)
+    (64, 64, 3, 1, 1, 1, 40, 70, 2),          # 64-cout tile, ragged pixel tiles
+    (128, 128, 3, 1, 1, 1, 24, 24, 2),        # 128 x 128 tile
+    (64, 128, 3, 2, 1, 1, 48, 64, 2),         # strided
+    (512, 512, 3, 1, 2, 2, 64, 64, 4),        # dilated, 256 px x 256 cout tile (K >= 2304, >= 65536 px at N >= 16: forced below by the size)
+    (256, 256, 3, 1, 1, 1, 192, 192, 2),      # 256 x 256 tile, 2-D pixel tiles
+    (1024, 256, 3, 1, 1, 1, 96, 96, 8),       # up_1
+    (2560, 1024, 1, 1, 0, 1, 24, 24, 2),      # PSP bottleneck (1x1)
+    (96, 192, 3, 2, 1, 1, 40, 40, 2),         # HRNet transition (32-multiple that is not a 64-multiple)
+    (48, 48, 3, 1, 1, 1, 40, 40, 2),          # HRNet branch width 48: not a multiple of 32 -> the three-block form on the register-staged kernel
+    (64, 505, 3, 1, 1, 1, 20, 24, 2),         # blur_skip conv0 feature part
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+@pytest.mark.parametrize("fused", [1, 0])
+def test_split_precision_forward_conv(case, fused):
+    """The detector precision mode's forward conv (x_hi w_hi + x_lo w_hi + x_hi w_lo in one fp32 accumulator) in its fused form (one
+    staged K slice of [x_hi | x_lo] x [w_hi | w_lo] feeds all three products) and its three-block form, against fp64 torch on the SAME
+    hi + lo input: ~22 mantissa bits -> 2e-5 of the output's maximum (fp32 accumulation over up to 2.3e4 terms included), BatchNorm sums
+    to 1e-5 relative; the two forms agree with each other to accumulation-order noise."""
+    from csbsr_amd.engine import Conv
+    from csbsr_amd import _lib as L
+    cin, cout, k, stride, pad, dil, H, W, N = case
+    eng = _eng()
+    eng.split_fused = bool(fused)
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    xs = to_fm_split(eng, x)
+    xv = from_fm_split(xs).double()                 # what the kernel actually sees
+    conv = Conv(eng, "l", {"l.weight": w.cuda()}, k, stride, pad, dil, bias=False)
+    from csbsr_amd.engine import pad8
+    stat = eng.f32(2, pad8(cout))
+    out = conv.fwd(xs, stat=stat, stat_mode=L.STAT_BN)
+    torch.cuda.synchronize()
+    assert out.lo, "the output of a split conv is a hi + lo pair"
+    ref = F.conv2d(xv, w.double(), None, stride, pad, dil)
+    got = from_fm_split(out).double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    s_ref = torch.stack([ref.sum((0, 2, 3)), (ref * ref).sum((0, 2, 3))])
+    e_stat = float((stat[:, :cout].double().cpu() - s_ref).abs().max() / s_ref.abs().max())
+    print(f"split conv {case} fused={fused}: max err {err:.2e} of max, BN sums {e_stat:.2e}")
+    assert err < 2e-5 and e_stat < 1e-5
