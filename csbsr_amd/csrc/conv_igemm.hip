@@ -442,7 +442,7 @@ int conv_desc_to_k(const csbsr_conv_desc_t* d, ConvK& k) {
   k.tile2d = 0; k.nphase_flat = 0; k.tap_group = 0;
   k.stat_part = nullptr; k.stat_ld = 0; k.hw_pad = 0;
   k.fs = d->split_fused ? 1 : 0;
-  CSBSR_CHECK(!k.fs || (d->in[1].c == 0 && d->in[0].c % 64 == 0 && !d->transposed), "conv: split_fused needs one [hi | lo] segment of 2 x (a multiple of 32) channels");
+  CSBSR_CHECK(!k.fs || (d->in[1].c == 0 && d->in[0].c % 16 == 0 && d->in[0].c >= 64 && !d->transposed), "conv: split_fused needs one [hi | lo] segment of 2 x (>= 32, a multiple of 8) channels");
   CSBSR_CHECK(d->stat_mode == CSBSR_STAT_NONE || d->stat, "conv: stat_mode set without stat buffer");
   return 0;
 }

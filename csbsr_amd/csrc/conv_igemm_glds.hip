@@ -28,7 +28,17 @@ extern "C" int csbsr_debug_read_ts(void* dst, long n) { return (int)hipMemcpyFro
 // k-slice MFMA groups per stage instead of four, i.e. the 3x MFMA work of the precision mode for 2x the staged bytes (the
 // three-block form stages x_hi twice and w_hi twice: 3x).  The kernel is bound by its stage refills, so the
 // launch time follows the staged bytes.
-template <int BM, int NWM, int NSTAGE, int CT = 1, bool FS = false>     // CT: 128-cout tiles per workgroup (2: a 256-cout tile, every wave
+// GK (general K walk): channel counts that are not whole 64-channel slices (HRNet-W48's 48 / 96-channel branches and its 720-channel
+// concat, /root/reference/model/modeling/hrnet_ocr/backbones/hrnet/hrnet_backbone.py:108-286).  K is the flat (tap, channel) index
+// of the packed weights in 8-channel units; a staged slice is 8 consecutive units (FS: 4, for both planes) and may straddle taps, so
+// every lane tracks the (tap, channel) of ITS unit, looks the tap's displacement up in a small LDS table and tests that tap's bit
+// of the row's validity mask.  One input segment, tap-major order (these layers' tiles re-touch a small window: no L2 issue).
+// (Measured and rejected, round 4: the two waves of a SIMD run half a stage apart -- wave groups 0-3 / 4-7 alternating between a LOAD
+// section and an MFMA section with two barriers per stage and s_setprio, each group refilling its own half of the pixel tile and half
+// of the weight rows where no reader is left, bit-exact and race-free in the kernel tests -- 838 vs 935 TF/s on the ResNet 512 -> 512
+// layer, 974 vs 1090 on up_1: the second barrier per stage costs more than the role split buys.  Like round 3's half-stage offset
+// of the DMA issue, it says the stage is not waiting for instruction issue of the other wave.)
+template <int BM, int NWM, int NSTAGE, int CT = 1, bool FS = false, bool GK = false>     // CT: 128-cout tiles per workgroup (2: a 256-cout tile, every wave
                                                        // 64 px x 128 couts; 0: a 64-cout tile for the 33..64-cout layers, every wave 64 px x 32 couts)
 __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK p, const half_t* __restrict__ zero_page) {
   constexpr int BN = CT ? 128 * CT : 64, BKG = 64;
@@ -55,6 +65,7 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   int* sRow = reinterpret_cast<int*>(sOOff + BM);                            // [BM][3] (n, oy, ox) of the phase grid; n = -1: no pixel
   float* sStat = reinterpret_cast<float*>(sRow + BM * 3);                    // [2][BN]
   float* sBias = sStat + 2 * BN;                                             // [BN]: this tile's bias
+  long* sDisp = reinterpret_cast<long*>(sBias + BN);                         // GK: [64] element displacement of tap t from tap (0, 0)
 
   TS(0);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -137,6 +148,10 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     sOOff[tid] = n * p.o_sn + (long)(py + oy * o_step) * p.o_sy + (long)(px + ox * o_step) * p.o_sx;
   }
   if (tid < 2 * BN) sStat[tid] = 0.f;
+  if (GK && tid < 64) {
+    const int ty = tid / p.KWt, tx = tid - ty * p.KWt;
+    sDisp[tid] = tid < p.KHt * p.KWt ? (long)tap_step * (ty * p.in[0].sy + tx * p.in[0].sx) : 0;
+  }
   __syncthreads();
   TS(1);
 
@@ -145,7 +160,11 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   const int cchunk = (lane & 7) ^ ((4 * (wid & 1) + (lane >> 4)) & 7);
   const int cch = cchunk * 8;          // halves (weight rows; pixel rows of a plain input)
   // FS: chunks 0..3 of a pixel row are 32 channels of the hi plane, chunks 4..7 the same 32 channels of the lo plane (c0 / 2 elements on)
-  const int cchx = FS ? (cchunk & 3) * 8 + (cchunk >> 2) * (p.c0 >> 1) : cch;
+  const int cchx = GK ? (FS ? (cchunk >> 2) * (p.c0 >> 1) : 0) : (FS ? (cchunk & 3) * 8 + (cchunk >> 2) * (p.c0 >> 1) : cch);
+  // GK: this lane's 8-channel unit of the slice being issued, as (tap, unit within the tap); U units per tap
+  const int gk_U = (FS ? (p.c0 >> 1) : p.c0) >> 3;
+  int gk_tap = 0, gk_ch8 = FS ? (cchunk & 3) : cchunk;
+  if (GK) { while (gk_ch8 >= gk_U) { gk_ch8 -= gk_U; ++gk_tap; } }
   // Per row: the 64-bit element offset of tap (0,0) in each input segment and a bit per tap saying whether that tap lands inside
   // the image (from the tables above).  Per slice only a wave-uniform base pointer changes.
   long off0[NXI], off1[NXI];
@@ -188,28 +207,48 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 #pragma unroll
   for (int i = 0; i < NXI; ++i) offc[i] = off0[i];
 
-  auto issue = [&](int kt) {
+  // PART / NPARTS: the stage's DMA pieces in NPARTS instalments (GLDS_SPREAD: between the MFMA groups of the stage being multiplied
+  // instead of as one burst behind the barrier); the scalar K-walk state advances with the last instalment
+  // issue_sel: X pieces [XLO, XHI), W pieces [WLO, WHI) of stage kt; ADV: the scalar K-walk state moves on to the next stage afterwards
+  auto issue_sel = [&](int kt, auto XLO, auto XHI, auto WLO, auto WHI, auto ADV) __attribute__((always_inline)) {
+    constexpr int xlo = decltype(XLO)::value, xhi = decltype(XHI)::value, wlo = decltype(WLO)::value, whi = decltype(WHI)::value;
     char* sbase = smem + (kt % NSTAGE) * STAGE_BYTES;
     const half_t* xb = (seg0 ? xb0 : xb1) + (FS ? (cs >> 1) : cs);                           // wave-uniform (FS: K slice s = channels 32 s .. of both planes)
     const unsigned long long bit = 1ull << tap;                                             // ntaps <= 64 (eligibility)
+    long gk_off = 0;
+    bool gk_ok = true;
+    if constexpr (GK) {
+      gk_ok = gk_tap < ntaps;
+      gk_off = sDisp[gk_ok ? gk_tap : 0] + gk_ch8 * 8;
+    }
 #pragma unroll
     for (int i = 0; i < NXI; ++i) {
-      const half_t* src = (tapmask[i] & bit) ? xb + offc[i] : zp;
+      if (i < xlo || i >= xhi) continue;
+      const half_t* src = GK ? ((gk_ok && ((tapmask[i] >> (gk_tap & 63)) & 1)) ? xb0_0 + offc[i] + gk_off : zp)
+                             : ((tapmask[i] & bit) ? xb + offc[i] : zp);
 #ifdef CSBSR_GLDS_ABLATE      // timing experiments only (results are garbage): bit 0 = every DMA source folded into one L2-resident 512 KB window
       if ((CSBSR_GLDS_ABLATE & 1) && (tapmask[i] & bit)) src = xb0_0 + ((size_t)(src - xb0_0) & 0x3ffff);
 #endif
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sbase + (wid + NW * i) * 1024), 16, 0, 0);
     }
-    const int wk = tap * p.ctot + cs;                                                        // column of this slice in the packed weights
+    const int wk = GK ? kt * BKG : tap * p.ctot + cs;                                        // column of this slice in the packed weights
 #pragma unroll
     for (int i = 0; i < NI - NXI; ++i) {
+      if (i < wlo || i >= whi) continue;
       const half_t* wsrc = wrow[i] + wk;
 #ifdef CSBSR_GLDS_ABLATE
       if (CSBSR_GLDS_ABLATE & 1) wsrc = wt + ((size_t)(wsrc - wt) & 0x3ffff);
 #endif
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
                                        (__attribute__((address_space(3))) void*)(sbase + BM * 128 + (wid + NW * (NXI + i) - XI) * 1024), 16, 0, 0);
+    }
+    if (!decltype(ADV)::value) return;
+    if constexpr (GK) {                       // this lane's unit moves on by one slice (8 units; FS: 4), wrapping into the next tap(s)
+      gk_ch8 += FS ? 4 : 8;
+      if (gk_ch8 >= gk_U) { gk_ch8 -= gk_U; ++gk_tap; }
+      if (gk_ch8 >= gk_U) { gk_ch8 -= gk_U; ++gk_tap; }
+      return;
     }
     if (++tcount == ntaps) {                  // next channel slice (wave-uniform branch)
       tcount = 0; tap = 0; kx = 0; xb0 = xb0_0; xb1 = xb1_0;
@@ -237,6 +276,19 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     }
   };
 
+  auto issue_part = [&](int kt, auto PART, auto NPARTS) __attribute__((always_inline)) {
+    constexpr int part = decltype(PART)::value, nparts = decltype(NPARTS)::value;
+    issue_sel(kt, std::integral_constant<int, NXI * part / nparts>{}, std::integral_constant<int, NXI * (part + 1) / nparts>{},
+              std::integral_constant<int, (NI - NXI) * part / nparts>{}, std::integral_constant<int, (NI - NXI) * (part + 1) / nparts>{},
+              std::integral_constant<bool, part == nparts - 1>{});
+  };
+  auto issue = [&](int kt) { issue_part(kt, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); };
+#ifndef GLDS_SPREAD
+#define GLDS_SPREAD 2      // measured (scripts/glds_spread_ab.py, same process): 2 instalments behind the stage's first two MFMA groups +4..7 %, 4 instalments +-0
+#endif
+  constexpr int SPREAD_ = GLDS_SPREAD > 0 ? GLDS_SPREAD : 1;
+  constexpr int SPREAD = (GLDS_SPREAD > 0 && NXI % SPREAD_ == 0 && (NI - NXI) % SPREAD_ == 0) ? GLDS_SPREAD : 0;
+
   f16v acc[TA][2];
 #pragma unroll
   for (int a = 0; a < TA; ++a)
@@ -255,6 +307,88 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
   // fragment addressing: tile row R, channel chunk c -> byte R*128 + ((c ^ ((R>>1)&7)) << 4)
   const int xr0 = wm * 64 + (lane & 31), wr0 = wn * (32 * TA) + (lane & 31);
   TS(2);
+  // ---- the MFMAs of stage kt; hook(PART), PART = 0..3, runs behind the stage's first four MFMA groups (DMA pieces of the refill)
+  auto compute = [&](int kt, auto&& hook) __attribute__((always_inline)) {
+    const char* xs = smem + (kt % NSTAGE) * STAGE_BYTES;
+    const char* ws = xs + BM * 128;
+    auto load_w = [&](int ks, h8 (&af)[TA]) __attribute__((always_inline)) {
+      const int c = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int a = 0; a < TA; ++a) {
+        const int R = wr0 + a * 32;
+        af[a] = *reinterpret_cast<const h8*>(ws + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+      }
+    };
+    auto load_x = [&](int ks, h8 (&bf)[2]) __attribute__((always_inline)) {
+      const int c = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int R = xr0 + b * 32;
+        bf[b] = *reinterpret_cast<const h8*>(xs + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
+      }
+    };
+    // fragment double-buffering: the reads of sub-step ks+1 are in flight while the 4 MFMAs of sub-step ks issue
+    auto load_frags = [&](int ks, h8 (&af)[TA], h8 (&bf)[2]) __attribute__((always_inline)) {
+#ifdef CSBSR_GLDS_ABLATE      // bit 1 = no LDS fragment reads after a tile's first K step (stale fragments)
+      if ((CSBSR_GLDS_ABLATE & 2) && (kt | ks)) return;
+#endif
+      load_w(ks, af); load_x(ks, bf);
+    };
+    auto mm = [&](const h8 (&af)[TA], const h8 (&bf)[2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    };
+    if constexpr (FS) {
+      // chunk pairs ks = 0, 1: channels 0..15 / 16..31 of the hi halves, ks = 2, 3: of the lo halves (pixel AND weight tile)
+      h8 af[TA], bh[2], bl[2];
+      load_w(0, af); load_x(0, bh);
+      mm(af, bh);                      // x_hi w_hi
+      hook(std::integral_constant<int, 0>{});
+      load_x(2, bl);
+      mm(af, bl);                      // x_lo w_hi
+      hook(std::integral_constant<int, 1>{});
+      load_w(2, af);
+      mm(af, bh);                      // x_hi w_lo
+      hook(std::integral_constant<int, 2>{});
+      load_w(1, af); load_x(1, bh);
+      mm(af, bh);
+      hook(std::integral_constant<int, 3>{});
+      load_x(3, bl);
+      mm(af, bl);
+      load_w(3, af);
+      mm(af, bh);
+    } else if constexpr (CT == 2) {      // 8 MFMAs per sub-step cover the next fragment reads; one fragment set keeps the wave inside 256 registers
+      auto kslice = [&](auto KS) __attribute__((always_inline)) {
+        h8 af[TA], bf[2];
+        load_frags(decltype(KS)::value, af, bf);
+        mm(af, bf);
+        hook(KS);
+      };
+      kslice(std::integral_constant<int, 0>{}); kslice(std::integral_constant<int, 1>{});
+      kslice(std::integral_constant<int, 2>{}); kslice(std::integral_constant<int, 3>{});
+    } else {
+      h8 af0[TA], bf0[2], af1[TA], bf1[2];
+      load_frags(0, af0, bf0);
+      load_frags(1, af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(af0, bf0);
+      hook(std::integral_constant<int, 0>{});
+      load_frags(2, af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(af1, bf1);
+      hook(std::integral_constant<int, 1>{});
+      load_frags(3, af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(af0, bf0);
+      hook(std::integral_constant<int, 2>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mm(af1, bf1);
+      hook(std::integral_constant<int, 3>{});
+    }
+  };
+
   for (int kt = 0; kt < nkt; ++kt) {
     // stage kt landed (this wave's DMAs), then everyone's
     const int ahead = (nkt - 1 - kt) < (NSTAGE - 2) ? (nkt - 1 - kt) : (NSTAGE - 2);   // stages still allowed in flight
@@ -265,91 +399,11 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     if (kt == 0) TS(3);
     // (measured and dropped, r03: the second wave of each SIMD issuing its pieces half a stage later -- so that one wave's ~100 address /
     // issue instructions run under the other's MFMAs -- changed nothing: 920 vs 926 TF/s on the ResNet 512 -> 512 layer)
-    if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1);      // refills the buffer read in iteration kt-1
-    const char* xs = smem + (kt % NSTAGE) * STAGE_BYTES;
-    const char* ws = xs + BM * 128;
-    // fragment double-buffering: the reads of sub-step ks+1 are in flight while the 4 MFMAs of sub-step ks issue
-    auto load_frags = [&](int ks, h8 (&af)[TA], h8 (&bf)[2]) {
-#ifdef CSBSR_GLDS_ABLATE      // bit 1 = no LDS fragment reads after a tile's first K step (stale fragments)
-      if ((CSBSR_GLDS_ABLATE & 2) && (kt | ks)) return;
-#endif
-      const int c = ks * 2 + (lane >> 5);
-#pragma unroll
-      for (int a = 0; a < TA; ++a) {
-        const int R = wr0 + a * 32;
-        af[a] = *reinterpret_cast<const h8*>(ws + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
-      }
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int R = xr0 + b * 32;
-        bf[b] = *reinterpret_cast<const h8*>(xs + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
-      }
-    };
-    if constexpr (FS) {
-      // chunk pairs ks = 0, 1: channels 0..15 / 16..31 of the hi halves, ks = 2, 3: of the lo halves (pixel AND weight tile)
-      auto load_w = [&](int ks, h8 (&af)[TA]) {
-        const int c = ks * 2 + (lane >> 5);
-#pragma unroll
-        for (int a = 0; a < TA; ++a) {
-          const int R = wr0 + a * 32;
-          af[a] = *reinterpret_cast<const h8*>(ws + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
-        }
-      };
-      auto load_x = [&](int ks, h8 (&bf)[2]) {
-        const int c = ks * 2 + (lane >> 5);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int R = xr0 + b * 32;
-          bf[b] = *reinterpret_cast<const h8*>(xs + R * 128 + ((c ^ ((R >> 1) & 7)) << 4));
-        }
-      };
-      auto mm = [&](const h8 (&af)[TA], const h8 (&bf)[2]) {
-#pragma unroll
-        for (int a = 0; a < TA; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-      };
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        h8 af[TA], bh[2], bl[2];
-        load_w(j, af); load_x(j, bh);
-        mm(af, bh);                      // x_hi w_hi
-        load_x(j + 2, bl);
-        mm(af, bl);                      // x_lo w_hi
-        load_w(j + 2, af);
-        mm(af, bh);                      // x_hi w_lo
-      }
-      continue;
-    }
-    if constexpr (CT == 2) {      // 8 MFMAs per sub-step cover the next fragment reads; one fragment set keeps the wave inside 256 registers
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        h8 af[TA], bf[2];
-        load_frags(ks, af, bf);
-#pragma unroll
-        for (int a = 0; a < TA; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-      }
-      continue;
-    }
-    h8 af0[TA], bf0[2], af1[TA], bf1[2];
-    load_frags(0, af0, bf0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ks += 2) {
-      load_frags(ks + 1, af1, bf1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int a = 0; a < TA; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0[a], bf0[b], acc[a][b], 0, 0, 0);
-      if (ks + 2 < 4) load_frags(ks + 2, af0, bf0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int a = 0; a < TA; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1[a], bf1[b], acc[a][b], 0, 0, 0);
-    }
+    const bool refill = kt + NSTAGE - 1 < nkt;
+    if (SPREAD == 0 && refill) issue(kt + NSTAGE - 1);      // refills the buffer read in iteration kt-1
+    compute(kt, [&](auto PART) __attribute__((always_inline)) {      // instalment PART of SPREAD, after an MFMA group
+      if constexpr (SPREAD > 0 && decltype(PART)::value < SPREAD) { if (refill) issue_part(kt + NSTAGE - 1, PART, std::integral_constant<int, SPREAD>{}); }
+    });
   }
   TS(4);
   __syncthreads();
@@ -475,22 +529,23 @@ static int g_glds_tile2d = 1;
 static int g_glds_tap_group = 1;
 static int g_glds_wide = 1;
 static int g_glds_narrow = 1;
+static int g_glds_gk = 1;
 
-template <int BM, int NWM, int NSTAGE, int CT = 1, bool FS = false>
+template <int BM, int NWM, int NSTAGE, int CT = 1, bool FS = false, bool GK = false>
 static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   ConvK p = k;
   constexpr int BN = CT ? 128 * CT : 64, SOW = BN > 128 ? 128 : BN;
   p.tiles_m = (unsigned)((maxM + BM - 1) / BM);
   p.tile2d = (g_glds_tile2d && !k.transposed && k.KHt * k.KWt > 1 && k.OW % 16 == 0 && k.OH % (BM / 16) == 0) ? 1 : 0;      // same tile count
-  p.tap_group = (g_glds_tap_group && !k.transposed && k.stride > 1 && k.dil == 1 && k.KHt > k.stride && k.KHt % k.stride == 0 &&
+  p.tap_group = (!GK && g_glds_tap_group && !k.transposed && k.stride > 1 && k.dil == 1 && k.KHt > k.stride && k.KHt % k.stride == 0 &&
                  k.KWt > k.stride && k.KWt % k.stride == 0) ? 1 : 0;
   p.tiles_n = (unsigned)((k.coutp + BN - 1) / BN);
   constexpr int RING = NSTAGE * (BM + BN) * 128;
   constexpr int EPI = BM * SOW * 4;
-  constexpr int SM_BYTES = (RING > EPI ? RING : EPI) + BM * (4 * 8 + 3 * 4) + 3 * BN * 4;      // ring / staged tile + row tables + statistics + bias
+  constexpr int SM_BYTES = (RING > EPI ? RING : EPI) + BM * (4 * 8 + 3 * 4) + 3 * BN * 4 + (GK ? 64 * 8 : 0);      // ring / staged tile + row tables + statistics + bias (+ GK tap table)
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
   static LdsAttrOnce attr;
-  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT, FS>), SM_BYTES, "conv(glds)")) return e;
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT, FS, GK>), SM_BYTES, "conv(glds)")) return e;
   if (!g_zero_page) {
     if (hipMalloc(reinterpret_cast<void**>(&g_zero_page), 256) != hipSuccess) { csbsr_set_error("conv(glds): zero page alloc failed"); return 2; }
     (void)hipMemset(g_zero_page, 0, 256);
@@ -499,7 +554,7 @@ static int launch_glds(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   ConvStatPlan sp;
   if (int e = conv_stat_prepare(p, BM, nphase, sp, st)) return e;
   dim3 grid(p.tiles_m * p.tiles_n * (p.nphase_flat ? nphase : 1), 1, p.nphase_flat ? 1 : nphase);
-  hipLaunchKernelGGL((conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT, FS>), grid, dim3(NWM * 128), SM_BYTES, st, p, g_zero_page);
+  hipLaunchKernelGGL((conv_igemm_glds_kernel<BM, NWM, NSTAGE, CT, FS, GK>), grid, dim3(NWM * 128), SM_BYTES, st, p, g_zero_page);
   if (int e = conv_stat_finish(p, sp, st)) return e;
   CSBSR_LAUNCH_CHECK("csbsr_conv_forward(glds)");
   return 0;
@@ -513,17 +568,21 @@ extern "C" void csbsr_debug_set_conv_glds(int mode) {
   g_glds_tile2d = (mode & 64) ? 0 : 1;           // bit 6: linear pixel tiles everywhere (A/B timing)     // bit 5: phases back on grid.z (A/B timing)
   g_glds_wide = (mode & 256) ? 0 : 1;            // bit 8: no 256-cout tile (A/B timing)
   g_glds_narrow = (mode & 1024) ? 0 : 1;         // bit 10: no 64-cout tile, 33..64-cout layers back on the register-staged kernel (A/B timing)
+  g_glds_gk = (mode & 2048) ? 0 : 1;             // bit 11: no general K walk, channel counts off the 64-channel grid back on the register-staged kernel (A/B timing)
   conv_thin_enable((mode & 16) ? 0 : 1);      // bit 4: route the 3-channel heads through the generic kernel (A/B timing)
   conv_thin_sc_enable((mode & 4096) ? 0 : 1);    // bit 12: the 128 -> 3 strided layers back on the general kernel (A/B timing)
   conv_thin_cin2_enable((mode & 512) ? 0 : 1);  // bit 9: no streaming variant of the 3-channel-input kernel (A/B timing, tests)
 }
 
+static bool conv_glds_general_k(const ConvK& k) { return k.fs ? (k.ctot / 2) % 32 != 0 : k.ctot % 64 != 0; }
+
 // eligibility: MFMA-bound shapes only
 bool conv_glds_eligible(const ConvK& k) {
   if (g_glds_mode == 0) return false;
   if (k.coutp <= 32 || (k.coutp <= 64 && !g_glds_narrow)) return false;      // 33..64 couts: the 64-cout tile
-  if (k.ctot % 64 != 0) return false;
-  if (k.c0 != k.ctot && k.c0 % 64 != 0) return false;
+  if (conv_glds_general_k(k)) {          // channel counts that are not whole 64-channel slices: the general K walk (one segment, >= 32 channels)
+    if (!g_glds_gk || k.c0 != k.ctot || (k.fs ? k.ctot / 2 : k.ctot) < 32) return false;
+  } else if (k.c0 != k.ctot && k.c0 % 64 != 0) return false;
   if (k.rows_p % (k.coutp <= 64 ? 64 : 128) != 0) return false;      // packed weights padded to the tile's rows (csbsr_pack_weights does)
   if (k.KHt * k.KWt > 64) return false;       // one validity bit per tap in a 64-bit mask
   return true;
@@ -537,14 +596,18 @@ int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   // 256 px x 256 couts (128 flop per staged byte instead of 85) where the couts fill 256-wide tiles about as well as 128-wide ones
   const int pad128 = (k.coutp + 127) / 128 * 128, pad256 = (k.coutp + 255) / 256 * 256;
   const bool wide = big && g_glds_wide && k.coutp >= 256 && pad256 * 8 <= pad128 * 9 + 64;
-  if (k.coutp <= 64) { g_last_conv_kernel = CONVK_GLDS64; return k.fs ? launch_glds<128, 2, 2, 0, true>(k, nphase, maxM, st) : launch_glds<128, 2, 2, 0>(k, nphase, maxM, st); }
-  g_last_conv_kernel = big ? (wide ? CONVK_GLDS256W : CONVK_GLDS256) : CONVK_GLDS128;
-  if (k.fs) {
-    if (!big) return launch_glds<128, 2, 2, 1, true>(k, nphase, maxM, st);
-    if (wide) return launch_glds<256, 4, 2, 2, true>(k, nphase, maxM, st);
-    return launch_glds<256, 4, 3, 1, true>(k, nphase, maxM, st);
+  const bool gk = conv_glds_general_k(k);
+  const int tile = k.coutp <= 64 ? 0 : (!big ? 1 : (wide ? 3 : 2));
+  g_last_conv_kernel = tile == 0 ? CONVK_GLDS64 : (tile == 1 ? CONVK_GLDS128 : (tile == 3 ? CONVK_GLDS256W : CONVK_GLDS256));
+#define GLDS_DISPATCH(FS_, GK_)                                                                      \
+  switch (tile) {                                                                                    \
+    case 0: return launch_glds<128, 2, 2, 0, FS_, GK_>(k, nphase, maxM, st);                        \
+    case 1: return launch_glds<128, 2, 2, 1, FS_, GK_>(k, nphase, maxM, st);                        \
+    case 3: return launch_glds<256, 4, 2, 2, FS_, GK_>(k, nphase, maxM, st);                        \
+    default: return launch_glds<256, 4, 3, 1, FS_, GK_>(k, nphase, maxM, st);                       \
   }
-  if (!big) return launch_glds<128, 2, 2>(k, nphase, maxM, st);
-  if (wide) return launch_glds<256, 4, 2, 2>(k, nphase, maxM, st);
-  return launch_glds<256, 4, 3>(k, nphase, maxM, st);
+  if (k.fs) { if (gk) { GLDS_DISPATCH(true, true) } else { GLDS_DISPATCH(true, false) } }
+  if (gk) { GLDS_DISPATCH(false, true) }
+  GLDS_DISPATCH(false, false)
+#undef GLDS_DISPATCH
 }

@@ -21,11 +21,17 @@ __global__ void pack_weights_kernel(const PackK p) {
     const int r = (int)(t % p.rows_p);
     const int ph = (int)(t / p.rows_p);
     float v = 0.f;
-    const int tap = k / p.segtot_p;
+    int tap = k / p.segtot_p;
     const int cp = k - tap * p.segtot_p;
     // padded channel -> real channel of the K side
     int c = -1, blk = 0;
-    if (p.split == 4) { blk = (cp >> 5) & 1; const int c1 = (cp >> 6) * 32 + (cp & 31); if (c1 < p.seg0_real) c = c1; }
+    if (p.split == 4) {      // K slice j = k / 64 holds units [32 j, 32 j + 32) of the flat (tap, channel) index, hi then lo
+      blk = (k >> 5) & 1;
+      const int u = (k >> 6) * 32 + (k & 31);
+      tap = u / p.seg0_p;
+      const int c1 = u - tap * p.seg0_p;
+      if (c1 < p.seg0_real) c = c1;
+    }
     else if (p.split) { blk = cp / p.seg0_p; const int c1 = cp - blk * p.seg0_p; if (c1 < p.seg0_real) c = c1; }
     else if (cp < p.seg0_p) { if (cp < p.seg0_real) c = cp; }
     else { const int c1 = cp - p.seg0_p; if (p.seg0_real + c1 < p.chan_real) c = p.seg0_real + c1; }
@@ -80,7 +86,6 @@ static void pack_geometry(int kind, int D0, int D1, int KH, int KW, int stride, 
 // K slice of the LDS-DMA kernels, staged next to [x_hi (32) | x_lo (32)] and used for all three products
 static void pack_geometry_split(int kind, int D0, int D1, int KH, int KW, int stride, int creal, int nrows, int layout, PackK& p) {
   pack_geometry(kind, D0, D1, KH, KW, stride, creal, 0, nrows, p);
-  if (layout == 3) p.seg0_p = round_up(creal, 32);      // whole 32-channel slices
   p.segtot_p = (layout == 0 ? 3 : 2) * p.seg0_p;
   p.Kp = round_up(p.KHt * p.KWt * p.segtot_p, 64);
   p.split = layout == 1 ? 2 : (layout == 2 ? 3 : (layout == 3 ? 4 : 1));

@@ -259,7 +259,7 @@ class Conv:
         nb = self.fwd_blocks
         if nb == 1:      # the hi plane alone against plain fp16 weights
             return (FM(x.t, x.c, H=x.H, W=x.W),), self._pack((key, 1), kind, creal, 0, 0, nrows, stride, pad, k_off), 1.0, 1
-        if nb == 3 and self.eng.split_fused and x.cp % 32 == 0 and pad8(nrows) > 32 and kind == 0:
+        if nb == 3 and self.eng.split_fused and x.cp >= 32 and pad8(nrows) > 32 and kind == 0:
             # fused form (csbsr_conv_desc_t::split_fused): one staged K slice = 32 channels of [x_hi | x_lo] against [w_hi | w_lo], all three
             # products from it -- the LDS-DMA kernels' launch time follows the staged bytes, 2/3 of the three-block form's
             return (x,), self._pack_split((key, "fs"), kind, creal, nrows, stride, pad, k_off=k_off, layout=3), 1.0 / self.WSCALE, 4

@@ -100,7 +100,7 @@ typedef struct {
    * its activation is rebuilt as mask -+ res, and dres (fp16 NHWC, same geometry as out16) receives d(res) = +- the unmasked result
    * (kbpn.py:254-256, DownBlock: l1 = down_conv3(h0 - x)) */
   void* dres; int64_t dr_sn, dr_sy, dr_sx;
-  /* csbsr_conv_forward only.  1: FUSED split-fp16 input -- in[0] = the [hi | lo] channel pair (2c channels, c a multiple of 32), in[1]
+  /* csbsr_conv_forward only.  1: FUSED split-fp16 input -- in[0] = the [hi | lo] channel pair (2c channels, c >= 32), in[1]
    * unused, weights from csbsr_pack_weights_split layout 3 ([w_hi | w_lo] per 32-channel slice).  One staged K slice then holds 32
    * channels of x_hi and x_lo against the same 32 of w_hi and w_lo and feeds all three products (x_hi w_hi + x_lo w_hi + x_hi w_lo)
    * from it: 2/3 of the operand traffic of the three-block form above for the same arithmetic.  LDS-DMA kernels only (> 32 padded
@@ -200,7 +200,7 @@ int csbsr_pack_weights(const float* w, void* dst, int32_t kind, int32_t D0, int3
 /* layout 0: the three-block forward operand above.  layout 1: two blocks [w_hi | w_lo] for the dgrads of that mode, whose input (a
  * plain fp16 activation gradient) is passed twice, in[0] = in[1] = dY.  layout 2: two blocks [w_hi | w_hi] against in[0] = [x_hi | x_lo]
  * alone (a layer whose precision plan keeps the activation's ~22 bits but not the weight's).  layout 3: the fused form of layout 0
- * (csbsr_conv_desc_t::split_fused): per tap and 32-channel slice [w_hi (32) | w_lo (32)]; creal padded to a multiple of 32. */
+ * (csbsr_conv_desc_t::split_fused): the flat (tap, channel) K index cut into 32-wide slices, each stored as [w_hi (32) | w_lo (32)]. */
 int64_t csbsr_packed_weight_elems_split(int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t stride,
                                         int32_t creal, int32_t nrows, int32_t layout);
 int csbsr_pack_weights_split(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t KH, int32_t KW,

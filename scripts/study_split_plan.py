@@ -56,7 +56,9 @@ def run(case, plan, hp):
 
 
 def main():
-    cases = sys.argv[1:] or ["wc_pspnet_it40000", "wc_blurskip_x8_it40000", "wc_hrnet_ocr_it40000"]
+    combos = "--combos" in sys.argv
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    cases = args or ["wc_pspnet_it40000", "wc_blurskip_x8_it40000", "wc_hrnet_ocr_it40000"]
     res = {}
     for case in cases:
         det = str(load_golden(case)["detector"])
@@ -65,6 +67,17 @@ def main():
         for name, pat in groups:
             variants.append((f"{name}=1", [(pat, 1)], True))
             variants.append((f"{name}=2", [(pat, 2)], True))
+        if combos:      # candidate PLANS (several groups at once), hp dgrads off as in the default
+            gp = dict(groups)
+            variants = [("base", None, False)]
+            if det == "PSPNet_BlurSkip":
+                variants += [("bs_conv0+1=2", [(gp["bs_conv0"], 2), (gp["bs_conv1"], 2)], False),
+                             ("bs_conv0+1+cb=2", [(gp["bs_conv0"], 2), (gp["bs_conv1"], 2), (gp["bs_cb"], 2)], False),
+                             ("bs_all=2 final=2", [(gp["bs_conv0"], 2), (gp["bs_conv1"], 2), (gp["bs_cb"], 2), (gp["final"], 2)], False)]
+            elif det == "PSPNet":
+                variants += [("up_1+2+3=2", [(gp["up_1"], 2), (gp["up_2"], 2), (gp["up_3"], 2)], False),
+                             ("up_1=2", [(gp["up_1"], 2)], False), ("aux=1", [(gp["aux"], 1)], False),
+                             ("up_1=2 aux=1", [(gp["up_1"], 2), (gp["aux"], 1)], False)]
         res[case] = {}
         for vname, plan, hp in variants:
             try:
@@ -74,7 +87,7 @@ def main():
             res[case][vname] = r
             print(case, vname, {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in r.items()}, flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/split_plan_study.json", "w") as f:
+    with open("gpurun_out/split_plan_%s.json" % ("combos" if combos else "study"), "w") as f:
         json.dump(res, f, indent=1)
 
 

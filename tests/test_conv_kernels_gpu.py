@@ -73,6 +73,13 @@ CASES = [
     (256, 64, 1, 1, 0, 1, False, 32, 48),          # 1x1, 2-D pixel tiles off
     (128, 64, 8, 4, 2, 1, True, 12, 8),            # transposed into 64 couts: 16 phases on the 64-cout tile
     (64, 64, 3, 2, 1, 1, False, 48, 64),           # strided; its dgrad is a gather-form transposed conv on the 64-cout tile
+    (48, 48, 3, 1, 1, 1, False, 40, 44),           # HRNet-W48 branch widths: the LDS-DMA kernels' general K walk (a 64-wide K slice straddles taps)
+    (96, 96, 3, 1, 1, 1, False, 24, 40),
+    (48, 96, 3, 2, 1, 1, False, 40, 40),           # transition / fuse layers between the branches (strided; dgrad = gather-form transposed conv)
+    (96, 48, 1, 1, 0, 1, False, 24, 24),
+    (720, 512, 3, 1, 1, 1, False, 20, 24),         # the 720-channel concat of the four branches into the OCR head's 3x3 conv
+    (720, 720, 1, 1, 0, 1, False, 24, 24),
+    (40, 72, 3, 1, 1, 1, False, 24, 24),           # 40 channels: five 8-channel units per tap
 ]
 
 
@@ -822,7 +829,9 @@ SPLIT_CASES = [
     (1024, 256, 3, 1, 1, 1, 96, 96, 8),       # up_1
     (2560, 1024, 1, 1, 0, 1, 24, 24, 2),      # PSP bottleneck (1x1)
     (96, 192, 3, 2, 1, 1, 40, 40, 2),         # HRNet transition (32-multiple that is not a 64-multiple)
-    (48, 48, 3, 1, 1, 1, 40, 40, 2),          # HRNet branch width 48: not a multiple of 32 -> the three-block form on the register-staged kernel
+    (48, 48, 3, 1, 1, 1, 40, 40, 2),          # HRNet branch width 48: a 32-channel K slice straddles taps (fused form + general K walk)
+    (48, 192, 3, 2, 1, 1, 40, 40, 2),
+    (720, 512, 3, 1, 1, 1, 20, 24, 2),
     (64, 505, 3, 1, 1, 1, 20, 24, 2),         # blur_skip conv0 feature part
 ]
 
