@@ -22,6 +22,7 @@
 #include "common.h"
 #include "csbsr_debug.h"
 #include "conv_wgrad.h"
+#include <type_traits>
 
 int g_wgrad_glds = 203;    // bit 0 kernel enabled, bit 1 256 x 256 tile, bit 2 no 128 x 256 tile, bit 3 every eligible problem, bit 6 128 x 256 tap-pair
                            // tiles for the 8x8 stride-4 layers, bit 7 2-D stage rectangles (csbsr_debug_set_wgrad_tr)
@@ -192,22 +193,35 @@ __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const W
   const long db_x = (long)tw_ * p.stride * p.b[0].sx, db_y = (long)th_ * p.stride * p.b[0].sy - (long)p.gx * db_x,
              db_n = p.b[0].sn - (long)p.gy * th_ * p.stride * p.b[0].sy;
   const int dXs = tw_ * p.stride, dYs = th_ * p.stride;
-  auto issue2d = [&](int kt) {
+  // PART of NPARTS: the stage's pieces in instalments (behind the first MFMA groups of the stage being multiplied instead of as one
+  // burst behind the barrier: WG_SPREAD); the uniform stage position steps on with the last instalment
+  auto issue2d_part = [&](int kt, auto PART, auto NPARTS) __attribute__((always_inline)) {
+    constexpr int part = decltype(PART)::value, nparts = decltype(NPARTS)::value;
     const unsigned sbase = lds0 + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
     const wg_v4i rsa = wg_make_rs(base_a), rsb = wg_make_rs(base_b);
 #pragma unroll
-    for (int i = 0; i < NIA; ++i) wg_dma16_buf(rsa, voffA[i], sbase + (unsigned)(NW * i * 1024));
+    for (int i = 0; i < NIA; ++i) {
+      if (i < NIA * part / nparts || i >= NIA * (part + 1) / nparts) continue;
+      wg_dma16_buf(rsa, voffA[i], sbase + (unsigned)(NW * i * 1024));
+    }
 #pragma unroll
     for (int i = 0; i < NIB; ++i) {
+      if (i < NIB * part / nparts || i >= NIB * (part + 1) / nparts) continue;
       const bool ok = (unsigned)(cy[i] + Ys) < (unsigned)p.BH && (unsigned)(cx[i] + Xs) < (unsigned)p.BW;
       wg_dma16_buf(rsb, ok ? voffB[i] : -1, sbase + (unsigned)(A_BYTES + NW * i * 1024));
     }
+    if (part != nparts - 1) return;
     base_a += da_x; base_b += db_x; Xs += dXs;
     if (++t_x == p.gx) {
       t_x = 0; Xs = 0; base_a += da_y; base_b += db_y; Ys += dYs;
       if (++t_y == p.gy) { t_y = 0; Ys = 0; base_a += da_n; base_b += db_n; }
     }
   };
+  auto issue2d = [&](int kt) { issue2d_part(kt, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); };
+#ifndef WG_SPREAD
+#define WG_SPREAD 2
+#endif
+  constexpr int SPREAD = (T2D && WG_SPREAD > 0 && NIA % (WG_SPREAD > 0 ? WG_SPREAD : 1) == 0 && NIB % (WG_SPREAD > 0 ? WG_SPREAD : 1) == 0) ? WG_SPREAD : 0;
   auto issue = [&](int kt) {
     if (T2D) { issue2d(kt); return; }
     const unsigned sbase = lds0 + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
@@ -273,10 +287,11 @@ __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const W
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + NSTAGE - 1 < nkt) issue(kt + NSTAGE - 1);      // refills the buffer read in iteration kt-1
+    const bool refill = kt + NSTAGE - 1 < nkt;
+    if (SPREAD == 0 && refill) issue(kt + NSTAGE - 1);      // refills the buffer read in iteration kt-1
     const char* st = smem + (kt % NSTAGE) * STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BP / 16; ++ks) {
+    auto sub = [&](auto KS) __attribute__((always_inline)) {
+      constexpr int ks = decltype(KS)::value;
       h8 af[TA], bf[TB];
 #pragma unroll
       for (int a = 0; a < TA; ++a) af[a] = tr8(st + ks * 16 * (BA * 2) + offA[a], BA * 2);
@@ -286,7 +301,11 @@ __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const W
       for (int a = 0; a < TA; ++a)
 #pragma unroll
         for (int b = 0; b < TB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-    }
+      if constexpr (SPREAD > 0 && ks < SPREAD) { if (refill) issue2d_part(kt + NSTAGE - 1, KS, std::integral_constant<int, SPREAD>{}); }
+    };
+    static_assert(BP / 16 == 4, "four sub-steps per stage");
+    sub(std::integral_constant<int, 0>{}); sub(std::integral_constant<int, 1>{});
+    sub(std::integral_constant<int, 2>{}); sub(std::integral_constant<int, 3>{});
   }
 
   // ---- epilogue: D[a][col], lane: col = lane%32, rows (r&3)+8*(r>>2)+4*(lane>>5); every (row < ca, col < ktot) element of this

@@ -486,9 +486,10 @@ class Conv:
             xs, wt, osc, nb = self._split_operand(x, "fwd_feat_split", 0, cf, self.cout, 1, self.pad)
         else:
             wt = self._pack("fwd_feat", 0, cf, 0, 0, self.cout, 1, self.pad, 0)
-        # the constant part is a tiny fp32 mat-vec: operands rounded to fp16 only in the plain mode (there they mirror the MFMA path)
-        w16c = self.w[:, cf:] if sp else self.w[:, cf:].to(torch.float16).float()
-        k16 = kvec.to(torch.float32) if sp else kvec.to(torch.float16).float()
+        # the constant part is a tiny fp32 mat-vec on the fp32 master weights and the fp32 kernel code (rounds 1-3 rounded both to fp16 in the
+        # plain mode "to mirror the MFMA path": a precision loss the reference does not have and the fold does not need)
+        w16c = self.w[:, cf:]
+        k16 = kvec.to(torch.float32)
         T = torch.einsum("ocyx,nc->noyx", w16c, k16)
         V = torch.einsum("noyx,ay,bx->nabo", T, mtap, mtap).reshape(B, 16, self.cout)
         cb = self.eng.f32(B, 16, pad8(self.cout))

@@ -24,6 +24,10 @@ def test_bench_two_ranks_one_device():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["steps"] == 2 and "roofline" in d
     assert d["loss"] == d["loss"]                       # not NaN
+    # the KBPN residency schedule is agreed over the ranks (one MIN all-reduce at the first forward) and reported with every rank's peak
+    sch, red = d["schedule"], d["reducer"]
+    assert sch["same_on_every_rank"] is True and len(sch["peak_mem_gb_per_rank"]) == 2 and sch["n_resident"] >= 1
+    assert red["agreements"] == 1 and red["exposed_all_reduce_ms_per_step"] >= 0.0
 
 
 def test_bench_rccl_backend_one_rank():

@@ -41,7 +41,10 @@ def _worker(rank, world, port, out):
     red.launch(seg)                          # first bucket in flight while "the rest of the backward" runs
     red.launch(srg)
     red.finish()
-    out[rank] = (w0, lin.weight.grad.clone(), lin.bias.grad.clone())
+    # memory-dependent schedule decisions are agreed as the minimum over the ranks (JointModelWithLoss._auto_resident): rank 0 "fits"
+    # (2, 2) micro-batches, rank 1 only (1, 2)
+    agreed = red.agree_min([2 - rank, 2])
+    out[rank] = (w0, lin.weight.grad.clone(), lin.bias.grad.clone(), agreed, dict(red.stats))
     dist.destroy_process_group()
 
 
@@ -50,8 +53,9 @@ def test_two_rank_bucket_allreduce_matches_global_batch_mean():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    w0a, gwa, gba = out[0]
-    w0b, gwb, gbb = out[1]
+    w0a, gwa, gba, ag_a, st_a = out[0]
+    w0b, gwb, gbb, ag_b, st_b = out[1]
+    assert ag_a == ag_b == [1, 2] and st_a["agreements"] == st_b["agreements"] == 1      # every rank takes the SAME schedule
     assert torch.equal(w0a, w0b)                                      # broadcast from rank 0
     assert torch.allclose(gwa, gwb) and torch.allclose(gba, gbb)      # every replica holds the same averaged gradient
     lin = torch.nn.Linear(4, 3)

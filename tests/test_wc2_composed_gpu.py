@@ -61,6 +61,8 @@ def test_composed_step_matches_the_reference(case, precision):
          (("sr_preds", sr), ("kernel_preds", kp), ("sr_loss", sr_l), ("segment_preds", seg), ("segment_loss", seg_l))}
     seg_ref = torch.from_numpy(g["segment_preds"])
     iou = float(O.iou(seg.cpu(), seg_ref).min())
+    l2 = {kk: float((v.detach().cpu().double() - torch.from_numpy(g[kk]).double()).norm() / torch.from_numpy(g[kk]).double().norm())
+          for kk, v in (("sr_preds", sr), ("segment_preds", seg))}
     sd = m.state_dict()
     e_bn = max(max_rel_to_scale(sd[kk[4:]].cpu(), v) for kk, v in g.items() if kk.startswith("buf."))
     e_loss = abs(float(loss.detach()) - float(g["loss"])) / abs(float(g["loss"]))
@@ -74,6 +76,9 @@ def test_composed_step_matches_the_reference(case, precision):
           f"grads median {float(g['cond_grad_median']):.1e} p90 {float(g['cond_grad_p90']):.1e}")
     for name, val, bound in rows:
         print(f"   {name:14s} {val:.2e}  bound {bound:.0e}  margin {bound / max(val, 1e-30):.1f}x")
+    # (the rows above are max |a - b| / max |b|; in relative L2 the same maps sit at:)
+    print(f"   relative L2: sr_preds {l2['sr_preds']:.2e}  segment_preds {l2['segment_preds']:.2e}")
+    assert l2["sr_preds"] < 1e-3
     grads = {kk: v.grad for kk, v in m._named_full() if isinstance(v, torch.nn.Parameter)}
     errs = [er for er in _grad_errors(g, grads, "") if not _zero_by_construction(er[0])]
     v = np.array([max(en, es) for n, numel, en, es in errs if numel > 1])
