@@ -221,7 +221,10 @@ __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const W
 #ifndef WG_SPREAD
 #define WG_SPREAD 2
 #endif
-  constexpr int SPREAD = (T2D && WG_SPREAD > 0 && NIA % (WG_SPREAD > 0 ? WG_SPREAD : 1) == 0 && NIB % (WG_SPREAD > 0 ? WG_SPREAD : 1) == 0) ? WG_SPREAD : 0;
+  // (8-wave tiles only: measured per launch at N = 4, same process, 256 x 256 SFT 958 -> 992 TF/s, ResNet 512 867 -> 945, up_1 1044 -> 1126,
+  // 128 x 256 8x8 stride-4 750 -> 768; in the training step 1.85 -> 1.72 ms and 1.93 -> 1.84 ms per launch.  The 128 x 128 tile -- two
+  // workgroups per CU, which already overlap each other's bursts -- went 0.60 -> 0.66 ms in the step: burst kept)
+  constexpr int SPREAD = (T2D && NW == 8 && WG_SPREAD > 0 && NIA % (WG_SPREAD > 0 ? WG_SPREAD : 1) == 0 && NIB % (WG_SPREAD > 0 ? WG_SPREAD : 1) == 0) ? WG_SPREAD : 0;
   auto issue = [&](int kt) {
     if (T2D) { issue2d(kt); return; }
     const unsigned sbase = lds0 + (unsigned)((kt % NSTAGE) * STAGE_BYTES);
