@@ -277,7 +277,12 @@ def main():
         fl, by, tt, nl, flx = per[dom]
         ach = fl / tt / 1e12
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        # the newest committed PMC summaries (scripts/collect_profiles.sh + summarise_profiles.py; round tag in the file name)
+        def newest(kind):
+            import glob
+            c = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0[0-9]_pmc_{kind}.json")))
+            return c[-1] if c else ""
+        tpath = newest("traffic")
         if os.path.exists(tpath) and args.workload == "pspnet_x4":
             try:
                 tj = json.load(open(tpath))
@@ -291,7 +296,7 @@ def main():
                 traffic = None
         # MFMA-pipe utilisation in cycles and the clock the kernel ran at, from the committed SQ_VALU_MFMA_BUSY_CYCLES pass
         mfma_pmc = None
-        mpath = os.path.join(ROOT, "profiles", "r03_pmc_mfma.json")
+        mpath = newest("mfma")
         if os.path.exists(mpath) and args.workload == "pspnet_x4":
             try:
                 mk = json.load(open(mpath)).get("kernels", {})
@@ -300,12 +305,12 @@ def main():
                     wsum = sum(v["launches"] * v["avg_launch_us"] for v in var)
                     mfma_pmc = {"mfma_pipe_busy": round(sum(v["mfma_util"] * v["launches"] * v["avg_launch_us"] for v in var) / wsum, 4),
                                 "clock_ghz": round(sum(v["clock_ghz"] * v["launches"] * v["avg_launch_us"] for v in var) / wsum, 3),
-                                "source": "profiles/r03_pmc_mfma.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, same command at --batch 4)"}
+                                "source": "profiles/" + os.path.basename(mpath) + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, same command at --batch 4)"}
             except Exception:
                 mfma_pmc = None
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r03_pmc_traffic.json; "
+                "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/" + os.path.basename(tpath) + "; "
                                 "FETCH_SIZE doubled per MI355X_MICROARCH.md), same command at --batch 4 (one KBPN micro-batch of 4, as in the default run)" if traffic else None,
                 "mfma_pmc": mfma_pmc, "launches": nl, "avg_launch_ms": round(tt * 1e3 / max(nl, 1), 4),
                 "alg_flop_per_launch": round(fl / max(nl, 1) / 1e9, 2), "alg_flop_unit": "GFLOP",

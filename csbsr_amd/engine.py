@@ -119,6 +119,18 @@ class Engine:
         self.use_x3 = os.environ.get("CSBSR_CONV_X3", "1") != "0"       # A/B hook: 0 routes the wide 3x3 layers through the implicit-GEMM kernels
         self.use_tp = os.environ.get("CSBSR_CONV_TP", "1") != "0"       # A/B hook: 0 routes the 2x2-tap transposed layers through the implicit-GEMM kernels
         self.split_fused = os.environ.get("CSBSR_SPLIT_FUSED", "1") != "0"   # A/B hook: 0 = the three-block split forward (x_hi staged twice)
+        # Weight gradients on a second HIP stream (opt-in, CSBSR_WGRAD_STREAM=1).  In the backward a layer's wgrad is a side branch (it
+        # only feeds the parameter's gradient accumulator) while the dgrad chain is the critical path; the wgrads are MFMA-bound on
+        # L2-resident tiles, much of what the chain runs between two of its convolutions is HBM-bound, so two streams could let the
+        # dispatcher fill CUs an HBM-bound kernel leaves idle.  Same kernels, same per-parameter accumulation order (all wgrads stay
+        # in program order on the side stream): bit-identical results (the GPU suite passes with it on).  Measured, round 4: config 4
+        # (HRNet-OCR, hundreds of small launches) 5.52 -> 5.71 img/s; config 2 at B = 4 6.92 -> 6.88 (the big kernels each fill the
+        # chip: nothing to overlap); config 2 at B = 8 collapses to 2.4 img/s -- at 239 of 288 GB the operands the lagging side
+        # stream still holds (record_stream) leave the caching allocator without free blocks and it falls back to synchronising
+        # hipFree / hipMalloc cycles.  Hence off by default.
+        self.wg_stream = None
+        self._wg_on = os.environ.get("CSBSR_WGRAD_STREAM", "0") == "1"
+        self._ws_by_stream = {}
         self.timing = None              # list of (kind, flops, bytes, start_event, end_event) when profiling is on
 
     @property
@@ -137,9 +149,26 @@ class Engine:
         return f(shape, dtype=torch.float32, device=self.device)
 
     def workspace(self, nfloat):
-        if self._ws is None or self._ws.numel() < nfloat:
-            self._ws = torch.empty(int(nfloat * 1.25) + 1024, dtype=torch.float32, device=self.device)
-        return self._ws
+        """wgrad slab workspace of the CURRENT stream (allocated under it, so the caching allocator orders its reuse on that stream)"""
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws_by_stream.get(key)
+        if ws is None or ws.numel() < nfloat:
+            ws = torch.empty(int(nfloat * 1.25) + 1024, dtype=torch.float32, device=self.device)
+            self._ws_by_stream[key] = ws
+        return ws
+
+    def wgrad_stream(self):
+        """the side stream weight gradients run on (None: the caller's stream)"""
+        if not self._wg_on:
+            return None
+        if self.wg_stream is None:
+            self.wg_stream = torch.cuda.Stream(self.device)
+        return self.wg_stream
+
+    def join_wgrad(self):
+        """the caller's stream waits for every weight gradient issued so far (before anything reads or exchanges the accumulators)"""
+        if self.wg_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.wg_stream)
 
     # ------------------------------------------------------------------ elementwise wrappers
     def epilogue_bwd(self, dout, out=None, act=L.ACT_NONE, slope=0.0, prelu=None, res=None, res2=None, res_mode=L.RES_NONE,
@@ -552,7 +581,19 @@ class Conv:
         return torch.einsum("ocyx,noyx->nc", w16c, S)
 
     def bwd_weights(self, dpre, x, split_override=None):
-        """wgrad; accumulates (scaled) into self.w.gacc [same shape as w] fp32."""
+        """wgrad; accumulates (scaled) into self.w.gacc [same shape as w] fp32.  Runs on the engine's wgrad stream when there is one:
+        the operands are final when this is called (every call site), so the side stream only has to start after the caller's
+        stream got here, and the operands' memory must not be handed out again before the side stream is done with it."""
+        side = self.eng.wgrad_stream()
+        if side is None:
+            return self._bwd_weights_impl(dpre, x, split_override)
+        side.wait_stream(torch.cuda.current_stream(self.eng.device))
+        for f in ((dpre,) + (tuple(x) if isinstance(x, (tuple, list)) else (x,))):
+            f.t.record_stream(side)
+        with torch.cuda.stream(side):
+            self._bwd_weights_impl(dpre, x, split_override)
+
+    def _bwd_weights_impl(self, dpre, x, split_override=None):
         xs = x if isinstance(x, (tuple, list)) else (x,)
         d = L.WgradDesc()
         if self.transposed:                      # A = input (LR), B = dOut (HR)
@@ -625,8 +666,8 @@ class ShuffleConv(Conv):
         super().invalidate()
         self.w.copy_(self._remap(self.master))       # the optimiser steps the master; same tensor object keeps its accumulator
 
-    def bwd_weights(self, dpre, x, split_override=None):
-        super().bwd_weights(dpre, x, split_override)
+    def _bwd_weights_impl(self, dpre, x, split_override=None):      # (whole body on the wgrad stream: the remap reads what the kernel wrote)
+        super()._bwd_weights_impl(dpre, x, split_override)
         grad_acc(self.master).add_(self._unmap(self.w.gacc))
         self.w.gacc.zero_()
 

@@ -368,6 +368,7 @@ class JointModelWithLoss(_JointBase):
         for b0 in range(0, B, mb):
             kbpn.forward(x[b0:b0 + mb], iter, kgt[b0:b0 + mb], save=True)
             kbpn.backward((dsr[b0:b0 + mb] * gs).contiguous(), (dkvec[b0:b0 + mb] * gs).contiguous())
+        eng.join_wgrad()
         return {k: (rt["P"][k].gacc / gs if getattr(rt["P"][k], "gacc_touched", False) else None) for k in names}
 
     def _detector_and_losses(self, iter, x, hr, mask, kgt, sr32, kvec, saves, mb, sdf=None):
@@ -493,6 +494,7 @@ class JointModelWithLoss(_JointBase):
                 L.call("csbsr_segloss_finish", _ptr(p_), _ptr(st["mask"]), _ptr(st["sdf"]), B, hw, _ptr(sums), st["alpha"], pw[0], pw[1],
                        lw[0], lw[1], wgt, _ptr(gsc), None, _ptr(dp), 0, eng.stream)
             dxin = psp.backward(dseg32, daux32)
+            eng.join_wgrad()                    # the detector's weight gradients (side stream) are complete
             if self.blur_skip:                  # only blur_skip.* trains: no gradient leaves the segmentation net
                 return self._finish_backward(pnames, gs, ("segmentation_model",), st)
             if self.reducer is not None:        # segmentation gradients are final: exchange them under the KBPN backward
@@ -562,6 +564,7 @@ class JointModelWithLoss(_JointBase):
 
     def _finish_backward(self, pnames, gs, reduce_groups, st):
         rt = self._rt
+        rt["eng"].join_wgrad()
         if self.reducer is not None:
             # whatever this phase's backward wrote and has not been launched yet (every rank takes the same branch: the set of
             # buckets depends on the training phase only)

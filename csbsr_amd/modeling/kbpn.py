@@ -542,6 +542,7 @@ class KBPN:
             del dxu
             sv["stages"][s - 1] = None
             if stage_done is not None:
+                e.join_wgrad()           # the stage's weight gradients are complete before its bucket is exchanged
                 stage_done(s)
         # ---- initial kernel predictor + VGG head
         dinit = dlowp
@@ -578,6 +579,7 @@ class KBPN:
             if i > 0:
                 d = c.bwd_input(d)
         self.saved = None
+        e.join_wgrad()
         if stage_done is not None:
             stage_done(0)
 
@@ -650,7 +652,12 @@ class KBPN:
         gi = iter(grads[1:])
         for conv, w in zip((st.fe_k[0], st.fe_k[1], cat0), ws):
             if w.requires_grad:
-                grad_acc(conv.w).add_(next(gi))
+                g = next(gi)
+                if conv is cat0:      # only the folded half of fe_cat.0's input channels: the other half's wgrad kernel (possibly on the
+                    c0 = cat0.split[0]          # wgrad stream) owns those elements of the accumulator
+                    grad_acc(conv.w)[:, c0:].add_(g[:, c0:])
+                else:
+                    grad_acc(conv.w).add_(g)
         return grads[0]
 
     def _fold_const_dgrad(self, conv, gvec, mask, H, W):

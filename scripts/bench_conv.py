@@ -8,6 +8,7 @@ from csbsr_amd.engine import Engine, Conv, FM, pad8
 
 def run(name, N, H, W, cin, cout, k, s, p, d=1, tr=False, iters=10, what=("fwd", "fwd_noepi")):
     eng = Engine()
+    eng._wg_on = False          # (the timing events below sit on the caller's stream)
     wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
     params = {"l.weight": (torch.randn(wshape, device="cuda") / (cin * k * k) ** 0.5) * (0.0 if os.environ.get("BENCH_ZERO") else 1.0), "l.bias": torch.zeros(cout, device="cuda")}
     conv = Conv(eng, "l", params, k, s, p, d, transposed=tr, bias=os.environ.get("BENCH_NOBIAS") is None, act=L.ACT_LRELU, slope=0.1)
