@@ -4,7 +4,7 @@
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-VARIANTS = [("default (staggered 256x256 tile)", "libcsbsr_hip.so", None), ("lock step", "libcsbsr_hip.so", "8194")]      # (name, library, CSBSR_CONV_GLDS mode)
+VARIANTS = [("default", "libcsbsr_hip.so", None), ("variant", "libcsbsr_hip_variant.so", None)]      # (name, library under csbsr_amd/ -- build the variant with e.g. -DGLDS_SPREAD=0 --, CSBSR_CONV_GLDS mode)
 SHAPES = [  # name, N, H, W, cin, cout, k, stride, pad, dil
     ("res512 d2", 8, 224, 224, 512, 512, 3, 1, 2, 2), ("res256 d1", 8, 224, 224, 256, 256, 3, 1, 1, 1), ("up_1 1024>256", 8, 448, 448, 1024, 256, 3, 1, 1, 1),
     ("sft825>384", 4, 448, 448, 832, 384, 3, 1, 1, 1), ("bott 2560>1024 1x1", 8, 224, 224, 2560, 1024, 1, 1, 0, 1)]
