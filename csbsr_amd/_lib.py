@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
                 ("mask", vp), ("m_sn", i64), ("m_sy", i64), ("m_sx", i64), ("mask_slope", f32), ("cbias_mode", i32),
                 ("mask_prelu", vp), ("dact_bias", vp), ("dact_prelu", vp),
                 ("dres", vp), ("dr_sn", i64), ("dr_sy", i64), ("dr_sx", i64),
-                ("split_fused", i32), ("_pad_sf", i32)]
+                ("split_fused", i32), ("_pad_sf", i32), ("bias_sn", i64)]
 
 
 class WgradDesc(C.Structure):
@@ -110,6 +110,9 @@ SIGNATURES = {
     "csbsr_nchw32_to_nhwc16": (i32, [vp, vp, i32, i32, i32, i32, i32, i64, vp, vp, vp]),
     "csbsr_nhwc16_to_nchw32": (i32, [vp, i64, vp, i32, i32, i32, i32, f32, f32, vp]),
     "csbsr_plane_reduce": (i32, [vp, vp, i32, i64, vp, vp]),
+    "csbsr_channel_mean_sub": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp]),
+    "csbsr_dc_table": (i32, [vp, vp, i32, i32, i32, vp]),
+    "csbsr_dc_bias": (i32, [vp, i32, i32, vp, i64, i32, vp, i64, i32, vp, i32, vp, vp]),
     "csbsr_instnorm_bwd": (i32, [vp, i64, vp, vp, vp, vp, i32, i32, i32, i64, vp, vp]),
     "csbsr_border_class_fill": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
     "csbsr_border_class_fill_masked": (i32, [vp, vp, i64, vp, i64, C.c_float, i32, i32, i32, i32, vp]),

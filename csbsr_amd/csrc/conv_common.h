@@ -40,6 +40,7 @@ struct ConvK {
   // csbsr_sum_partials* (no atomics: two runs are bit-identical).  hw_pad > 0: the linear pixel index is laid out per sample,
   // each sample padded to hw_pad (a multiple of the pixel tile) positions, so a tile never straddles two samples.
   float* stat_part; long stat_ld; int hw_pad;
+  long bias_sn;              // per-sample bias: element stride between the samples' bias rows (0: one row), csbsr_conv_desc_t::bias_sn
   int fs;                    // 1: fused split-fp16 input (csbsr_conv_desc_t::split_fused): in[0] = [hi | lo], c0 = ctot = 2 x plane channels
 };
 

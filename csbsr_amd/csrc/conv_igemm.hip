@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
     sTapYX[tid] = live ? (ty | (tx << 16)) : -1;
   }
   if (tid < 2 * BN) sStat[tid] = 0.f;
-  if (tid < BN) sBias[tid] = (p.bias && cout0 + tid < p.cout) ? p.bias[cout0 + tid] : 0.f;
+  // (a per-sample bias: the tile lies within one sample -- OH * OW is a multiple of the tile, checked by the launcher)
+  if (tid < BN) sBias[tid] = (p.bias && cout0 + tid < p.cout) ? p.bias[(p.bias_sn ? (m0 / ((long)OHp * OWp)) * p.bias_sn : 0) + cout0 + tid] : 0.f;
   const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
   __syncthreads();
   ITS(1);
@@ -441,6 +442,9 @@ int conv_desc_to_k(const csbsr_conv_desc_t* d, ConvK& k) {
   CSBSR_CHECK(!d->o_lo || d->out16, "conv: o_lo without out16");
   k.tile2d = 0; k.nphase_flat = 0; k.tap_group = 0;
   k.stat_part = nullptr; k.stat_ld = 0; k.hw_pad = 0;
+  k.bias_sn = d->bias_sn;
+  CSBSR_CHECK(!d->bias_sn || (d->bias && !d->transposed && ((long)d->OH * d->OW) % 256 == 0),
+              "conv: a per-sample bias needs a non-transposed layer whose samples are whole pixel tiles (OH * OW a multiple of 256)");
   k.fs = d->split_fused ? 1 : 0;
   CSBSR_CHECK(!k.fs || (d->in[1].c == 0 && d->in[0].c % 16 == 0 && d->in[0].c >= 64 && !d->transposed), "conv: split_fused needs one [hi | lo] segment of 2 x (>= 32, a multiple of 8) channels");
   CSBSR_CHECK(d->stat_mode == CSBSR_STAT_NONE || d->stat, "conv: stat_mode set without stat buffer");
@@ -465,11 +469,11 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
     g_last_conv_kernel = CONVK_THIN_CIN2;
     return conv_thin_cin2_launch(k, d->in[0].creal, st);
   }
-  if (!split_io && d->in[1].c == 0 && conv_thin_cin_eligible(k, d->in[0].creal)) {
+  if (!split_io && !d->bias_sn && d->in[1].c == 0 && conv_thin_cin_eligible(k, d->in[0].creal)) {
     g_last_conv_kernel = CONVK_THIN_CIN;
     return conv_thin_cin_launch(k, d->in[0].creal, st);
   }
-  if (!split_io && conv_thin_tp_eligible(k, d->in[0].creal, d->in[1].c != 0)) { g_last_conv_kernel = CONVK_THIN_TP; return conv_thin_tp_launch(k, st); }
+  if (!split_io && !d->bias_sn && conv_thin_tp_eligible(k, d->in[0].creal, d->in[1].c != 0)) { g_last_conv_kernel = CONVK_THIN_TP; return conv_thin_tp_launch(k, st); }
   if (!d->r_lo && !d->r2_lo && conv_thin_sc_eligible(k)) { g_last_conv_kernel = CONVK_THIN_SC; return conv_thin_sc_launch(k, st); }
   if (conv_glds_eligible(k)) return conv_glds_launch(k, nphase, maxM, st);
   CSBSR_CHECK(!k.fs, "conv: split_fused launch not eligible for the LDS-DMA kernels (needs > 32 padded output channels)");

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
 
   // the bias is fetched now and parked in LDS after the first DMA issue: its HBM round trip used to sit in front of the prologue barrier
   float bias_reg = 0.f;
-  if (tid < BN && p.bias && cout0 + tid < p.cout) bias_reg = p.bias[cout0 + tid];
+  if (tid < BN && p.bias && cout0 + tid < p.cout)      // (a per-sample bias: the tile lies within one sample, checked by the launcher)
+    bias_reg = p.bias[(p.bias_sn ? (p.tile2d ? (long)t2_n : m0 / ((long)OHp * OWp)) * p.bias_sn : 0) + cout0 + tid];
   TS(7);
   if (tid < BM) {
     long m = m0 + tid;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void conv_thin_cout_kernel(const ConvK p, int 
   const float slope = p.act == CSBSR_ACT_PRELU ? p.prelu[0] : p.act_slope;
   float bias[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (p.bias)
-    for (int co = 0; co < CR; ++co) bias[co] = p.bias[co];
+    for (int co = 0; co < CR; ++co) bias[co] = p.bias[n * p.bias_sn + co];
   bool first = true;
 #pragma unroll 1
   for (int ty = ty0; ty < ty0 + TN_TPW && ty < tiles_y; ++ty) {

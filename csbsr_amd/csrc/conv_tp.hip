@@ -477,6 +477,7 @@ extern "C" int32_t csbsr_conv_tp_eligible(const csbsr_conv_desc_t* d) {
   if (d->dres && !(d->mask && d->res_mode != CSBSR_RES_NONE && !d->accumulate && d->H % TP_TH == 0 && d->W % TP_TW == 0 &&
                    (long)d->OH * d->dr_sy < (1l << 31))) return 0;
   if ((d->accumulate || d->mask) && (d->bias || d->act != CSBSR_ACT_NONE)) return 0;
+  if (d->bias_sn) return 0;                 // (per-sample bias: the general kernels and conv_x3 only)
   // the fused bias / PReLU-slope sums: accumulate + mask launches over whole tiles (a dead lane would add its garbage to the sums)
   if ((d->dact_bias || d->dact_prelu) && !((d->accumulate || d->dres) && d->mask && d->H % TP_TH == 0 && d->W % TP_TW == 0)) return 0;
   if (d->mask_prelu && !d->mask) return 0;

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           v[e] = acc[mt][nt][8 * pair + e];
-          bias[e] = (p.bias && co + e < p.cout) ? p.bias[co + e] : 0.f;
+          bias[e] = (p.bias && co + e < p.cout) ? p.bias[n * p.bias_sn + co + e] : 0.f;
         }
         conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, s0, s1);
       }

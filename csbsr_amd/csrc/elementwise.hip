@@ -491,6 +491,92 @@ extern "C" int csbsr_plane_reduce(const float* a, const float* b, int32_t planes
   return 0;
 }
 
+// Per-sample, per-channel mean of an fp16 NHWC map over a regular SUBSAMPLE of its pixels (every step-th row and column): the input
+// statistic of the weight-rounding compensation (csbsr_amd/engine.py Conv._dc_bias) -- a correction term of relative size 2^-12, for
+// which a 1 / step^2 sample of the pixels is plenty (>= 1e4 pixels per channel at the sizes that matter) and costs 1 / step^2 of a pass
+// over the map.  grid = (channel octets, 1, N): ONE workgroup sums a sample's sampled pixels of its channel octet in a fixed order
+// (thread-strided, then a fixed LDS tree) and writes the means -- <= 200 sixteen-byte loads per thread at HR 1792^2, one launch, no
+// partial rows; bit-reproducible like every reduction here, and a function of the sample alone (KBPN stays free of batch-coupled
+// operations).
+#define CM_SLICES 1
+__global__ __launch_bounds__(256) void channel_mean_sub_kernel(const half_t* x, long sn, long sy, long sx, int H, int W, int step,
+                                                                float inv_count, float* part, int cp) {
+  __shared__ float sm[256][8];
+  const int oct = blockIdx.x, slice = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
+  const int hs = (H + step - 1) / step, ws = (W + step - 1) / step;
+  const int total = hs * ws;
+  float a[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = 0.f;
+#pragma unroll 4      // (independent loads: several in flight per thread -- the kernel is latency-bound)
+  for (int i = slice + CM_SLICES * tid; i < total; i += CM_SLICES * 256) {
+    const int y = (i / ws) * step, xx = (i % ws) * step;
+    const h8 v = *reinterpret_cast<const h8*>(x + n * sn + y * sy + xx * sx + oct * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sm[tid][e] = a[e];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sm[tid][e] += sm[tid + o][e];
+    }
+    __syncthreads();
+  }
+  if (tid < 8) part[((long)n * CM_SLICES + slice) * cp + oct * 8 + tid] = sm[0][tid] * inv_count;
+}
+extern "C" int csbsr_channel_mean_sub(const void* x, int64_t sn, int64_t sy, int64_t sx, int32_t N, int32_t H, int32_t W, int32_t cp,
+                                      int32_t step, float* out /*[N][cp], overwritten*/, csbsr_stream_t s) {
+  CSBSR_CHECK(x && out && cp > 0 && cp % 8 == 0 && step >= 1 && N > 0 && H > 0 && W > 0, "channel_mean_sub: bad args");
+  const long count = (long)((H + step - 1) / step) * ((W + step - 1) / step);
+  hipLaunchKernelGGL(channel_mean_sub_kernel, dim3(cp / 8, CM_SLICES, N), dim3(256), 0, ST(s), (const half_t*)x, (long)sn, (long)sy, (long)sx, H, W,
+                     step, 1.f / (float)count, out, cp);
+  CSBSR_LAUNCH_CHECK("csbsr_channel_mean_sub");
+  return 0;
+}
+
+// The two small contractions of the weight-rounding compensation (engine.Conv._dc_bias), one launch each:
+//   dc_table:  S[o][c] = sum over taps of (w - fp16(w))[o][c][tap]            (once per layer and optimiser step)
+//   dc_bias:   out[n][o] = (bias ? bias[o] : 0) + sum_c S[o][c] * mean[n][c]    (once per layer and forward; the means of up to two
+//              input segments, c0 / c1 real channels each).  One wave per (sample, output channel): lanes stride the channels, fixed
+//              xor-shuffle tree -- order-fixed.
+__global__ void dc_table_kernel(const float* w, float* S, long rows, int taps) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
+    const float* q = w + i * taps;
+    float a = 0.f;
+    for (int t = 0; t < taps; ++t) a += q[t] - (float)(half_t)q[t];
+    S[i] = a;
+  }
+}
+extern "C" int csbsr_dc_table(const float* w, float* S, int32_t D0, int32_t D1, int32_t taps, csbsr_stream_t s) {
+  CSBSR_CHECK(w && S && D0 > 0 && D1 > 0 && taps > 0, "dc_table: bad args");
+  const long rows = (long)D0 * D1;
+  const int blocks = (int)((rows + 255) / 256 > 2048 ? 2048 : (rows + 255) / 256);
+  hipLaunchKernelGGL(dc_table_kernel, dim3(blocks), dim3(256), 0, ST(s), w, S, rows, taps);
+  CSBSR_LAUNCH_CHECK("csbsr_dc_table");
+  return 0;
+}
+__global__ __launch_bounds__(256) void dc_bias_kernel(const float* S, int cin, const float* m0, long m0_ld, int c0, const float* m1, long m1_ld, int c1,
+                                                       const float* bias, float* out, int cout) {
+  const int n = blockIdx.y, o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= cout) return;
+  const float* row = S + (long)o * cin;
+  float a = 0.f;
+  for (int c = lane; c < c0; c += 64) a += row[c] * m0[n * m0_ld + c];
+  for (int c = lane; c < c1; c += 64) a += row[c0 + c] * m1[n * m1_ld + c];
+  a = wave_sum(a);
+  if (lane == 0) out[(long)n * cout + o] = a + (bias ? bias[o] : 0.f);
+}
+extern "C" int csbsr_dc_bias(const float* S, int32_t cout, int32_t cin, const float* m0, int64_t m0_ld, int32_t c0, const float* m1, int64_t m1_ld,
+                             int32_t c1, const float* bias, int32_t N, float* out, csbsr_stream_t s) {
+  CSBSR_CHECK(S && m0 && out && cout > 0 && c0 > 0 && c1 >= 0 && c0 + c1 <= cin && N > 0 && (c1 == 0 || m1), "dc_bias: bad args");
+  hipLaunchKernelGGL(dc_bias_kernel, dim3((cout + 3) / 4, N), dim3(256), 0, ST(s), S, cin, m0, (long)m0_ld, c0, m1, (long)m1_ld, c1, bias, out, cout);
+  CSBSR_LAUNCH_CHECK("csbsr_dc_bias");
+  return 0;
+}
+
 // InstanceNorm2d backward on planes: dx (+)= invstd*(dy - mean(dy) - xhat*mean(dy*xhat)), dy given as fp16 NHWC8
 __global__ void instnorm_bwd_reduce_kernel(const half_t* dy, long dy_ld, const float* x, const float* mean, const float* invstd,
                                            int C, long hw, float* red /*[N*C][2]*/, int chunks) {

@@ -202,6 +202,7 @@ class _JointBase(nn.Module):
         for c in self._rt["psp"].all_convs():      # the split mode's dgrads run against fp16 hi + lo weight pairs (Conv.bwd_input)
             c.hp_dgrad = split and bool(self.detector_hp_dgrad)
             c.fwd_blocks = next((nb for pat, nb in plan if pat.search(c.name)), 3)
+            c.dc_comp = c.fwd_blocks < 3          # a layer that keeps its weights' fp16 rounding gets the mean compensation (Conv._dc_bias)
         return self._rt
 
     def _bucket_of(self, name):

@@ -132,7 +132,13 @@ class KBPN:
                 o.sh1 = mk(sf + ".SFT_shift_conv1", 3, 1, 1, act=A_NONE)
             self.stages.append(o)
         self.output_conv = block(f"{prefix}.output_conv", 3, 1, 1, A_NONE)
-        # bicubic 7x7 -> 21x21 as a fixed linear map U [kk, kc] (nn.Upsample(size, 'bicubic'), kbpn.py:317,558)
+        # compensation of the forward weights' fp16 rounding (Conv._dc_bias) on the (non-transposed) layers whose kernels take a
+        # per-channel bias at no cost: the VGG head, the initial predictor, the strided and 1x1 convolutions of the Up / Down blocks, SFT
+        # layers and the 3-channel image heads.  Not the per-stage kernel
+        # predictors (full-resolution 32 / 49-channel layers on the bias-free direct kernels): exempting their weights from rounding
+        # altogether moves nothing.
+        for c in self.layers:
+            c.dc_comp = ".kernel_predictor." not in c.name        # bicubic 7x7 -> 21x21 as a fixed linear map U [kk, kc] (nn.Upsample(size, 'bicubic'), kbpn.py:317,558)
         eye = torch.eye(kc).reshape(kc, 1, cfg.ksize, cfg.ksize)
         up = F.interpolate(eye, size=(self.K, self.K), mode="bicubic", align_corners=False) if cfg.ksize != self.K else eye
         self.U = up.reshape(kc, self.kk).t().contiguous().to(eng.device)       # [kk, kc]

@@ -106,6 +106,11 @@ typedef struct {
    * from it: 2/3 of the operand traffic of the three-block form above for the same arithmetic.  LDS-DMA kernels only (> 32 padded
    * output channels); the call fails otherwise. */
   int32_t split_fused; int32_t _pad_sf;
+  /* csbsr_conv_forward / csbsr_conv_x3_forward: element stride between the samples' rows of ``bias`` (0 = one fp32[cout] row for the whole
+   * batch, the reference's bias).  Non-zero = a per-sample bias [N][bias_sn]: the host's compensation of the forward weights' fp16
+   * rounding (csbsr_amd/engine.py Conv._dc_bias).  Needs a non-transposed layer whose samples are whole pixel tiles (OH * OW a multiple
+   * of 256); the call fails otherwise. */
+  int64_t bias_sn;
 } csbsr_conv_desc_t;
 
 int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
@@ -291,6 +296,17 @@ int csbsr_nhwc16_to_nchw32(const void* src, int64_t src_ld, float* dst, int32_t 
                            float alpha, float beta, csbsr_stream_t s);
 /* out[plane] = {sum a, sum a*a (b NULL) | sum a*b} over fp32 planes (instance-norm statistics) */
 int csbsr_plane_reduce(const float* a, const float* b, int32_t planes, int64_t hw, float* out, csbsr_stream_t s);
+/* out[n][c] = mean over the pixels (step i, step j) of x[n, y, x, c]  (fp16 NHWC view with element strides sn / sy / sx, cp channels, a
+ * multiple of 8; out [N][cp] fp32): the per-sample input statistic of the host's compensation of the forward weights' fp16 rounding
+ * (csbsr_amd/engine.py Conv._dc_bias; nothing in the reference corresponds to it -- the reference multiplies fp32 weights).  Order-fixed. */
+int csbsr_channel_mean_sub(const void* x, int64_t sn, int64_t sy, int64_t sx, int32_t N, int32_t H, int32_t W, int32_t cp,
+                           int32_t step, float* out, csbsr_stream_t s);
+/* the same compensation's two small contractions: S[o][c] = sum over taps of (w - fp16(w))[o][c][tap] for a conv weight [D0][D1][taps], and
+ * out[n][o] = (bias ? bias[o] : 0) + sum_c S[o][c] * mean[n][c] with the means of up to two input segments (c0 / c1 real channels, row
+ * strides m0_ld / m1_ld) -- the per-sample bias rows handed to csbsr_conv_forward with bias_sn = cout */
+int csbsr_dc_table(const float* w, float* S, int32_t D0, int32_t D1, int32_t taps, csbsr_stream_t s);
+int csbsr_dc_bias(const float* S, int32_t cout, int32_t cin, const float* m0, int64_t m0_ld, int32_t c0, const float* m1, int64_t m1_ld,
+                  int32_t c1, const float* bias, int32_t N, float* out, csbsr_stream_t s);
 int csbsr_instnorm_bwd(const void* dy, int64_t dy_ld, const float* x, const float* mean, const float* invstd,
                        float* dx, int32_t accumulate, int32_t N, int32_t C, int64_t hw, float* red,
                        csbsr_stream_t s);

@@ -68,3 +68,52 @@ def test_lean_saves_rebuild_the_same_bits():
     b = _step(m, g)
     bad = [k for k in a if not torch.equal(a[k], b[k])]
     assert set(a) == set(b) and not bad, bad[:6]
+
+
+@pytest.mark.parametrize("case,micro_batch", [("e2e_pspnet_it40000", 1), ("e2e_hrnet_ocr_it40000", 8)])
+def test_wgrad_side_stream_gives_the_same_bits(case, micro_batch):
+    """``CSBSR_WGRAD_STREAM=1`` (Engine.wgrad_stream, opt-in) runs every weight-gradient kernel on a second HIP stream: same kernels, same
+    per-parameter accumulation order, operands kept alive for the side stream -- every gradient must equal the one-stream run bit for
+    bit (a missing event wait or a buffer handed out too early shows as a difference)."""
+    g = load_golden(case)
+    m, _ = build_model(g, micro_batch)
+    m.max_resident = 8
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    eng = m._runtime()["eng"]
+    assert eng.wgrad_stream() is None, "the side stream is opt-in"
+    a = _step(m, g)
+    m.load_state_dict(sd0)
+    eng._wg_on = True
+    try:
+        b = _step(m, g)
+        assert eng.wg_stream is not None
+    finally:
+        eng._wg_on = False
+    bad = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not bad, f"{len(bad)} tensors differ with the wgrad stream on, e.g. {bad[:6]}"
+
+
+def test_precision_plan_hooks():
+    """``model.detector_plan`` / ``Conv.fwd_blocks`` (the per-layer refinement of the split mode): the default plan runs all
+    three hi/lo products everywhere in the fused form; a two-product plan for the decoder changes the segmentation map by less than
+    1e-3 of its maximum and nothing else of the forward; the unfused three-block form agrees with the fused one to accumulation noise."""
+    g = load_golden("wc2_pspnet_it40000")
+    from test_wc_parity_gpu import _inputs, _model
+    x, hr, mask, k = _inputs(g)
+    outs = {}
+    for name, plan, fused in (("fused", None, True), ("blocks", None, False), ("decoder2", [(r"\.up_[123]\.|\.final\.", 2)], True)):
+        m = _model(g, "split")
+        m.detector_plan = plan
+        m._runtime()["eng"].split_fused = fused
+        with torch.no_grad():
+            seg_l, sr_l, seg, sr, kp = m(int(g["it"]), x, sr_targets=hr, segment_targets=mask, kernel_targets=k)
+        torch.cuda.synchronize()
+        convs = m._runtime()["psp"].all_convs()
+        assert {c.fwd_blocks for c in convs} == ({3} if plan is None else {2, 3})
+        outs[name] = (seg.clone(), sr.clone())
+        del m
+    d = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert torch.equal(outs["fused"][1], outs["blocks"][1]) and torch.equal(outs["fused"][1], outs["decoder2"][1])      # KBPN is untouched
+    e_form, e_plan = d(outs["blocks"][0], outs["fused"][0]), d(outs["decoder2"][0], outs["fused"][0])
+    print(f"split forward: three-block vs fused form {e_form:.2e}; two products in the decoder vs three {e_plan:.2e}")
+    assert e_form < 5e-4 and 0.0 < e_plan < 2e-3, (e_form, e_plan)

@@ -453,3 +453,24 @@ def test_weighted_pool_fwd_bwd():
     L.call("csbsr_weighted_pool_bwd", P(fx.t), fx.ld, P(wd), P(gd), P(dx.t), dx.ld, P(dw), N, H * W, Cc, eng.stream)
     assert relmax(dw.cpu(), w.grad) < 1e-4
     assert relmax(from_fm(dx), base + x.grad) < 2e-3
+
+
+@pytest.mark.parametrize("N,H,W,c,step", [(2, 64, 48, 128, 8), (3, 17, 23, 40, 4), (1, 9, 9, 8, 1), (4, 96, 96, 512, 8)])
+def test_subsampled_channel_mean(N, H, W, c, step):
+    """csbsr_channel_mean_sub: per-sample, per-channel mean over every step-th row / column (the input statistic of the weight-rounding
+    compensation, engine.Conv._dc_bias), on a channel SLICE of a wider buffer; two calls give the same bits."""
+    import ctypes as C
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    g = torch.Generator().manual_seed(N * 100 + c)
+    full = (torch.randn(N, H, W, c + 16, generator=g) + 0.5).half().cuda()
+    x = full[..., 8:8 + c]
+    outs = []
+    for _ in range(2):
+        m = torch.zeros(N, c, dtype=torch.float32, device="cuda")
+        L.call("csbsr_channel_mean_sub", C.c_void_p(x.data_ptr()), x.stride(0), x.stride(1), x.stride(2), N, H, W, c, step, C.c_void_p(m.data_ptr()), eng.stream)
+        torch.cuda.synchronize()
+        outs.append(m.clone())
+    ref = x[:, ::step, ::step].float().mean((1, 2))
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0] - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))

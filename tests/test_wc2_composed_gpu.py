@@ -25,7 +25,9 @@ pytestmark = pytest.mark.gpu
 
 # Fixed bounds per (fixture, detector precision mode): segmentation map (max |a-b| / max|b|), segmentation loss, BatchNorm running
 # buffers, 1 - IoU of the thresholded maps, and (median, 90th percentile, max) of the per-tensor gradient relative-L2 errors.  Measured on
-# MI355X (r03, printed by the test; the path is bit-reproducible so the values do not move run to run) with >= 2x margin each.  What the
+# MI355X (printed by the test; the path is bit-reproducible so the values do not move run to run) with >= 2x margin each; the split-mode
+# bounds on the map were tightened in r04 (5e-3 / 5e-3 / 1e-2 -> 4e-3 / 3e-3 / 5e-3) with the compensation of KBPN's weight rounding
+# (engine.Conv._dc_bias: measured 2.18e-3 -> 1.66e-3, 1.44e-3 -> 1.19e-3, 3.08e-3 -> 1.98e-3).  What the
 # numbers say: in split mode (the default, and the mode bench.py's headline is quoted in) the step sits INSIDE the reference's own response
 # to a 1e-3 perturbation of its SR image (cond_* in the fixtures: seg 4.8e-3 / 9.8e-3 / 3.7e-3 / 9.2e-3, IoU 0.995 / 0.997 / 0.965 / 0.988,
 # gradient median 1.3e-2 / 5.8e-3 / 5.9e-2 / 2.0e-2 for PSPNet / BlurSkip / HRNet-OCR / PixelShuffle); plain fp16 detector storage costs
@@ -33,11 +35,11 @@ pytestmark = pytest.mark.gpu
 # not the parity mode.  HRNet-OCR's IoU: its thresholded map has 5.6 % positives, so the ~75 pixels within 3e-3 of the threshold are 3.7 %.
 B = {
     "wc2_pspnet_it40000": {"fp16": dict(seg=1e-2, segl=5e-4, bn=1e-3, iou1=1e-2, grad=(2.5e-2, 7e-2, 0.15)),
-                           "split": dict(seg=5e-3, segl=2e-4, bn=5e-4, iou1=5e-3, grad=(2e-2, 5e-2, 0.1))},
+                           "split": dict(seg=4e-3, segl=2e-4, bn=5e-4, iou1=5e-3, grad=(2e-2, 5e-2, 0.1))},
     "wc2_blurskip_x8_it40000": {"fp16": dict(seg=1.5e-2, segl=5e-4, bn=1e-3, iou1=1e-2, grad=(1.5e-2, 2e-2, 3e-2)),
-                                "split": dict(seg=5e-3, segl=2e-4, bn=5e-4, iou1=5e-3, grad=(5e-3, 1e-2, 1.5e-2))},
+                                "split": dict(seg=3e-3, segl=2e-4, bn=5e-4, iou1=5e-3, grad=(5e-3, 1e-2, 1.5e-2))},
     "wc2_hrnet_ocr_it40000": {"fp16": dict(seg=1.5e-2, segl=2e-3, bn=5e-3, iou1=0.15, grad=(0.5, 0.7, 2.0)),
-                              "split": dict(seg=1e-2, segl=1.5e-3, bn=3e-3, iou1=0.1, grad=(8e-2, 0.12, 0.3))},
+                              "split": dict(seg=5e-3, segl=1.5e-3, bn=3e-3, iou1=0.1, grad=(8e-2, 0.12, 0.3))},
     "wc2_pspnet_pixelshuffle_it40000": {"fp16": dict(seg=2e-2, segl=1e-3, bn=2e-3, iou1=3e-2, grad=(5e-2, 0.12, 0.3)),
                                         "split": dict(seg=1.5e-2, segl=5e-4, bn=1e-3, iou1=2e-2, grad=(4e-2, 0.1, 0.2))},
 }
