@@ -304,14 +304,16 @@ class Conv:
         perturbation: its response to the (large, positive after ReLU / PReLU) channel means is a per-output-channel offset of relative
         size 2^-12 sqrt(C) that no later layer averages out, and a low-pass detector passes it in full -- on the contractive reference
         fixtures it is the larger half of the segmentation map's deviation.  Measured on the composed HIP step
-        (tests/test_wc2_composed_gpu.py, split mode, with / without): segmentation map 2.18e-3 -> 1.24e-3 of its maximum (relative L2
-        8.1e-4 -> 5.5e-4) with PSPNet, 3.08e-3 -> 1.96e-3 with HRNet-OCR, 1.44e-3 -> 1.26e-3 with BlurSkip; SR image 6.95e-4 -> 5.9e-4;
-        kernel vector at HR 64 6.6e-4 -> 4.5e-4; 0.3 % of a step.  The means are PER SAMPLE (a per-sample bias row, csbsr_conv_desc_t::bias_sn:
-        KBPN keeps no batch-coupled operation, micro-batching and data-parallel sharding stay exact), from every 8th row and column
-        (csbsr_channel_mean_sub: 1/64 of a pass over the input, order-fixed).  Stride-1 / strided convolutions only: a transposed layer's
-        residual response differs per output phase, and its average over the phases -- all a per-channel bias can carry -- measured
-        no gain (PSPNet 1.42e-3 with it, 1.24e-3 without; the PixelShuffle variant 4.5e-3 / 4.3e-3).  A constant of the backward (its
-        gradient would be 2^-12 of the layer's)."""
+        (tests/test_wc2_composed_gpu.py, split mode, without / with): segmentation map 2.18e-3 -> 1.66e-3 of its maximum (relative L2
+        8.1e-4 -> 6.1e-4) with PSPNet, 3.08e-3 -> 1.98e-3 (2.26e-3 -> 1.54e-3) with HRNet-OCR, 1.44e-3 -> 1.19e-3 (3.6e-4 -> 3.1e-4) with
+        BlurSkip; SR image 6.95e-4 -> 6.2e-4; kernel vector at HR 64 6.6e-4 -> 4.5e-4; 0.35 % of a step (one mean kernel per input
+        segment and one small contraction per layer and forward, one tap-sum kernel per layer and optimiser step).  The means are PER
+        SAMPLE (a per-sample bias row, csbsr_conv_desc_t::bias_sn: KBPN keeps no batch-coupled operation, micro-batching and
+        data-parallel sharding stay exact -- a batch mean measured 1.24-1.42e-3 on the PSPNet fixture but broke both), from every 8th
+        row and column (csbsr_channel_mean_sub: 1/64 of a pass over the input, order-fixed).  Stride-1 / strided convolutions only: a
+        transposed layer's residual response differs per output phase, and its average over the phases -- all a per-channel bias can
+        carry -- measured no gain (the oracle simulation agrees: nothing for the average, 7 % for the exact per-phase form).  A constant
+        of the backward (its gradient would be 2^-12 of the layer's)."""
         assert not self.transposed and 1 <= len(xs) <= 2
         S = self._packed.get("dc_table")
         if S is None:
