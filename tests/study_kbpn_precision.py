@@ -20,22 +20,37 @@ from oracle import csbsr_oracle as O
 
 
 class storage_sim:
-    def __init__(self, names, round_w, round_x):
-        self.names, self.rw, self.rx = names, round_w, round_x
+    """comp: None | "bias" (per-sample channel means x tap sums of the rounding residual, non-transposed layers: what engine.Conv._dc_bias
+    does) | "exact" (the residual filter's full response to the per-sample constant map, every layer: the upper bound of the idea)"""
+
+    def __init__(self, names, round_w, round_x, comp=None):
+        self.names, self.rw, self.rx, self.comp = names, round_w, round_x, comp
 
     def __enter__(self):
         self.saved = (F.conv2d, F.conv_transpose2d)
         oc, ot = self.saved
         r16 = lambda t: t.half().float()
 
-        def wrap(fn):
+        def wrap(fn, transposed):
             def f(x, w, b=None, *a, **k):
                 n = self.names.get(id(w))
                 if n is None or not n.startswith("sr_model"):
                     return fn(x, w, b, *a, **k)
-                return fn(r16(x) if self.rx(n) else x, r16(w) if self.rw(n) else w, b, *a, **k)
+                xi = r16(x) if self.rx(n) else x
+                if not self.rw(n):
+                    return fn(xi, w, b, *a, **k)
+                w16 = r16(w)
+                y = fn(xi, w16, b, *a, **k)
+                if self.comp is None or ".kernel_predictor." in n:
+                    return y
+                m = (xi[:, :, ::8, ::8] if xi.shape[-1] >= 64 else xi).mean(dim=(2, 3))          # per sample, subsampled like the build
+                if self.comp == "exact":
+                    return y + fn(m[:, :, None, None].expand(-1, -1, xi.shape[2], xi.shape[3]), w - w16, None, *a, **k)
+                if transposed:
+                    return y
+                return y + torch.einsum("nc,oc->no", m, (w - w16).sum((2, 3)))[:, :, None, None]
             return f
-        F.conv2d, F.conv_transpose2d = wrap(oc), wrap(ot)
+        F.conv2d, F.conv_transpose2d = wrap(oc, False), wrap(ot, True)
         return self
 
     def __exit__(self, *exc):
@@ -62,8 +77,8 @@ def main():
     drop = {kk.split(".", 1)[1]: torch.from_numpy(v) for kk, v in g.items() if kk.startswith("dropmask.")}
     it = int(g["it"])
 
-    def run(rw, rx):
-        with torch.no_grad(), storage_sim(names, rw, rx):
+    def run(rw, rx, comp=None):
+        with torch.no_grad(), storage_sim(names, rw, rx, comp):
             sr, kvec = O.kbpn_forward(P, x, it, k, cfg)
             bn = O.BNState(P, True)
             seg, aux = O.pspnet_forward(P, O.norm_sr(sr, cfg), bn, drop, kvec if cfg.detector == "PSPNet_BlurSkip" else None)
@@ -79,6 +94,11 @@ def main():
     print(f"{case}: error against the reference fixture, max|a-b|/max|b| (rel-L2)")
     for name, rw, rx in rows:
         e = run(rw, rx)
+        print(f"{name:44s} sr {e[0]:.2e} ({e[1]:.2e})   seg {e[2]:.2e} ({e[3]:.2e})", flush=True)
+    print("-- the weight term's structure: its response to the input's per-sample channel means, given back (engine.Conv._dc_bias)")
+    for name, rw, rx, comp in (("W only + bias compensation (the build)", yes, no, "bias"), ("W only + exact mean response (bound)", yes, no, "exact"),
+                               ("W + X + bias compensation (the build)", yes, yes, "bias"), ("W + X + exact mean response (bound)", yes, yes, "exact")):
+        e = run(rw, rx, comp)
         print(f"{name:44s} sr {e[0]:.2e} ({e[1]:.2e})   seg {e[2]:.2e} ({e[3]:.2e})", flush=True)
 
 

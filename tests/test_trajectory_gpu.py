@@ -6,7 +6,7 @@ parameters -- and must stay ON the reference's curve, in both detector precision
 
     scalar loss, steps 0-3 / every step                                 <= 2e-3 / LOSS_BAND relative (measured 7.7e-4 / 1.5e-3 .. 2.7e-3)
     per-sample segmentation / SR loss at every step                     <= SEG_BAND / SR_BAND        (1.7e-3 .. 6.0e-3, 1.1e-2 .. 2.6e-2)
-    gradient L2 norm of each gradient bucket at every step             <= GNORM_BAND relative       (0.08 .. 0.13)
+    gradient L2 norm of each gradient bucket at every step             <= GNORM_BAND relative       (r03: 0.08 .. 0.13; r04: 0.030 split, 0.073 fp16)
     L2 distance the parameters have moved from the start, per step     <= MOVED_BAND relative       (3e-4 .. 2.6e-3)
     alpha schedule                                                      exact
 (measured on MI355X, r03, over both precision modes and four builds of the library that differ only in fp32 summation order / which
@@ -16,6 +16,11 @@ parameter whose gradient is noise by the full learning rate in a noise-determine
 (including between two correct builds of this library: 1.7e-3 .. 6.0e-3 on the per-sample segmentation loss) grows the same way; the
 first four steps, before that growth, are held to 2e-3, and the scalar loss stays within 0.3 % of the reference's throughout while it
 falls by 35 % -- the statement that matters for training.
+
+Round 4 (the weight-rounding compensation of KBPN's forward, engine.Conv._dc_bias, and the fp32 folded constants): the per-bucket
+gradient norms start 9e-4 from the reference's at step 0 (r03: 2e-2) and reach 3.0e-2 (split) / 7.3e-2 (fp16 detector) by step 11 -- the same
+Adam-driven separation as the losses', not a per-bucket bias: which bucket is worst changes from step to step (kbpn.1 at step 4, kbpn.4 at
+step 8, kbpn.0 at step 9).  The band went from 0.3 to 0.15.
 
 This is the evidence that gradient errors of the size the single-step tests report (median 1e-2 .. 3e-2 per tensor in relative L2) do
 not bend training: Adam's normalised step turns a gradient with the right sign pattern into the right update, and the loss curve of
@@ -32,7 +37,7 @@ LOSS_EARLY = 2e-3
 LOSS_BAND = {"fp16": 8e-3, "split": 8e-3}
 SEG_BAND = {"fp16": 1.5e-2, "split": 1.5e-2}
 SR_BAND = {"fp16": 6e-2, "split": 6e-2}
-GNORM_BAND = {"fp16": 0.3, "split": 0.3}
+GNORM_BAND = {"fp16": 0.15, "split": 0.15}
 MOVED_BAND = {"fp16": 1e-2, "split": 1e-2}
 
 
