@@ -494,22 +494,24 @@ extern "C" int csbsr_plane_reduce(const float* a, const float* b, int32_t planes
 // Per-sample, per-channel mean of an fp16 NHWC map over a regular SUBSAMPLE of its pixels (every step-th row and column): the input
 // statistic of the weight-rounding compensation (csbsr_amd/engine.py Conv._dc_bias) -- a correction term of relative size 2^-12, for
 // which a 1 / step^2 sample of the pixels is plenty (>= 1e4 pixels per channel at the sizes that matter) and costs 1 / step^2 of a pass
-// over the map.  grid = (channel octets, 1, N): ONE workgroup sums a sample's sampled pixels of its channel octet in a fixed order
-// (thread-strided, then a fixed LDS tree) and writes the means -- <= 200 sixteen-byte loads per thread at HR 1792^2, one launch, no
-// partial rows; bit-reproducible like every reduction here, and a function of the sample alone (KBPN stays free of batch-coupled
-// operations).
-#define CM_SLICES 1
+// over the map.  grid = (channel octets, slices, N): a workgroup sums its share of a sample's sampled pixels of its channel octet in a
+// fixed order (thread-strided, then a fixed LDS tree).  Small maps: one slice, the means are written directly (one launch).  Large
+// maps (>= 16384 sampled pixels per sample, HR 1792^2): 8 slices write partial rows and csbsr_sum_partials_batched folds them in a fixed
+// tree -- one workgroup per octet and sample was latency-bound there (~200 us per call for 3 MB of reads).  Bit-reproducible like every
+// reduction here, and a function of the sample alone (KBPN stays free of batch-coupled operations).
+#define CM_SLICES 8
 __global__ __launch_bounds__(256) void channel_mean_sub_kernel(const half_t* x, long sn, long sy, long sx, int H, int W, int step,
                                                                 float inv_count, float* part, int cp) {
   __shared__ float sm[256][8];
   const int oct = blockIdx.x, slice = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
+  const int nsl = gridDim.y;
   const int hs = (H + step - 1) / step, ws = (W + step - 1) / step;
   const int total = hs * ws;
   float a[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) a[e] = 0.f;
 #pragma unroll 4      // (independent loads: several in flight per thread -- the kernel is latency-bound)
-  for (int i = slice + CM_SLICES * tid; i < total; i += CM_SLICES * 256) {
+  for (int i = slice + nsl * tid; i < total; i += nsl * 256) {
     const int y = (i / ws) * step, xx = (i % ws) * step;
     const h8 v = *reinterpret_cast<const h8*>(x + n * sn + y * sy + xx * sx + oct * 8);
 #pragma unroll
@@ -525,14 +527,23 @@ __global__ __launch_bounds__(256) void channel_mean_sub_kernel(const half_t* x, 
     }
     __syncthreads();
   }
-  if (tid < 8) part[((long)n * CM_SLICES + slice) * cp + oct * 8 + tid] = sm[0][tid] * inv_count;
+  if (tid < 8) part[((long)n * nsl + slice) * cp + oct * 8 + tid] = sm[0][tid] * inv_count;
 }
 extern "C" int csbsr_channel_mean_sub(const void* x, int64_t sn, int64_t sy, int64_t sx, int32_t N, int32_t H, int32_t W, int32_t cp,
                                       int32_t step, float* out /*[N][cp], overwritten*/, csbsr_stream_t s) {
   CSBSR_CHECK(x && out && cp > 0 && cp % 8 == 0 && step >= 1 && N > 0 && H > 0 && W > 0, "channel_mean_sub: bad args");
   const long count = (long)((H + step - 1) / step) * ((W + step - 1) / step);
-  hipLaunchKernelGGL(channel_mean_sub_kernel, dim3(cp / 8, CM_SLICES, N), dim3(256), 0, ST(s), (const half_t*)x, (long)sn, (long)sy, (long)sx, H, W,
-                     step, 1.f / (float)count, out, cp);
+  if (count < 16384) {
+    hipLaunchKernelGGL(channel_mean_sub_kernel, dim3(cp / 8, 1, N), dim3(256), 0, ST(s), (const half_t*)x, (long)sn, (long)sy, (long)sx, H, W,
+                       step, 1.f / (float)count, out, cp);
+  } else {
+    float* part = csbsr_red_scratch((long)N * CM_SLICES * cp);
+    CSBSR_NEED_SCRATCH(part, "channel_mean_sub");
+    CSBSR_CHECK(hipMemsetAsync(out, 0, (size_t)N * cp * sizeof(float), ST(s)) == hipSuccess, "channel_mean_sub: memset failed");
+    hipLaunchKernelGGL(channel_mean_sub_kernel, dim3(cp / 8, CM_SLICES, N), dim3(256), 0, ST(s), (const half_t*)x, (long)sn, (long)sy, (long)sx, H, W,
+                       step, 1.f / (float)count, part, cp);
+    if (csbsr_sum_partials_batched(part, CM_SLICES, cp, cp, out, N, cp, ST(s))) return 1;
+  }
   CSBSR_LAUNCH_CHECK("csbsr_channel_mean_sub");
   return 0;
 }

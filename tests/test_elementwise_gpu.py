@@ -455,7 +455,7 @@ def test_weighted_pool_fwd_bwd():
     assert relmax(from_fm(dx), base + x.grad) < 2e-3
 
 
-@pytest.mark.parametrize("N,H,W,c,step", [(2, 64, 48, 128, 8), (3, 17, 23, 40, 4), (1, 9, 9, 8, 1), (4, 96, 96, 512, 8)])
+@pytest.mark.parametrize("N,H,W,c,step", [(2, 64, 48, 128, 8), (3, 17, 23, 40, 4), (1, 9, 9, 8, 1), (4, 96, 96, 512, 8), (2, 520, 260, 64, 2)])
 def test_subsampled_channel_mean(N, H, W, c, step):
     """csbsr_channel_mean_sub: per-sample, per-channel mean over every step-th row / column (the input statistic of the weight-rounding
     compensation, engine.Conv._dc_bias), on a channel SLICE of a wider buffer; two calls give the same bits."""
