@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256) void conv_thin_tp_kernel(const ConvK p, int gr
           for (int e = 0; e < 8; ++e) acc[e] = 0.f;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const h2 x01 = h2{xv[u][t][0], xv[u][t][1]}, x23 = h2{xv[u][t][2], xv[u][t][3]};
+            const h2 x01 = h2{xv[u][t][0], xv[u][t][1]}, x23 = h2{xv[u][t][2], (half_t)0};      // (the input's padding lane is never read: 0 * NaN would poison every output)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               acc[e] = __builtin_amdgcn_fdot2(x01, w2[t][0][e], acc[e], false);

@@ -44,8 +44,12 @@ extern "C" int csbsr_set_reduction_scratch(float* buf, int64_t elems) {
 }
 float* csbsr_red_scratch(long need_elems) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CSBSR_MAX_DEVICES) return nullptr;
-  return (g_red_buf[dev] && need_elems + CSBSR_RED_TAIL <= g_red_elems[dev]) ? g_red_buf[dev] : nullptr;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CSBSR_MAX_DEVICES) { csbsr_set_error("reduction scratch: no current device"); return nullptr; }
+  if (g_red_buf[dev] && need_elems + CSBSR_RED_TAIL <= g_red_elems[dev]) return g_red_buf[dev];
+  // (every caller turns the nullptr into an error return; the text says which scratch was wanted)
+  csbsr_set_error("reduction scratch missing or too small on device %d: %ld floats (+ %ld tail) needed, %ld registered (csbsr_set_reduction_scratch)",
+                  dev, need_elems, (long)CSBSR_RED_TAIL, g_red_buf[dev] ? g_red_elems[dev] : 0l);
+  return nullptr;
 }
 static float* red_tail() {
   int dev = 0;
