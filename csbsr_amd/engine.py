@@ -124,8 +124,8 @@ class Engine:
         # only feeds the parameter's gradient accumulator) while the dgrad chain is the critical path; the wgrads are MFMA-bound on
         # L2-resident tiles, much of what the chain runs between two of its convolutions is HBM-bound, so two streams could let the
         # dispatcher fill CUs an HBM-bound kernel leaves idle.  Same kernels, same per-parameter accumulation order (all wgrads stay
-        # in program order on the side stream): bit-identical results (the GPU suite passes with it on).  Measured, round 4: config 4
-        # (HRNet-OCR, hundreds of small launches) 5.52 -> 5.71 img/s; config 2 at B = 4 6.92 -> 6.88 (the big kernels each fill the
+        # in program order on the side stream): bit-identical results (the GPU suite passes with it on).  Measured, round 4, same-run A/B: config 4
+        # (HRNet-OCR, hundreds of small launches) 5.57 vs 5.57 img/s; config 2 at B = 4 6.92 -> 6.88 (the big kernels each fill the
         # chip: nothing to overlap); config 2 at B = 8 collapses to 2.4 img/s -- at 239 of 288 GB the operands the lagging side
         # stream still holds (record_stream) leave the caching allocator without free blocks and it falls back to synchronising
         # hipFree / hipMalloc cycles.  Hence off by default.
