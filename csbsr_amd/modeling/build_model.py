@@ -156,7 +156,7 @@ class _JointBase(nn.Module):
         # gradient tensor and dLoss/dSR agree with the reference equally well without it (PSPNet median 1.15e-2 vs 1.12e-2, HRNet-OCR
         # 1.65e-2 both, BlurSkip 9.4e-4 vs 9.1e-4: the error is the ReLU-gate flips of the forward, not the weights' rounding) -- so it is off.
         self.detector_plan = None
-        self.detector_hp_dgrad = False
+        self.detector_hp_dgrad = __import__("os").environ.get("CSBSR_HP_DGRAD") == "1"      # (A/B hook; default off)
 
     # ---- naming: state_dict keys are the reference's dotted names
     def _named_full(self):
