@@ -145,7 +145,8 @@ extern "C" int csbsr_pack_weights_split(const float* w, void* dst, int32_t kind,
 }
 
 // G[a][tap][bpad]  ->  grad[a_off + a][b][kh][kw] += ...   (grad is [D0][D1][KH][KW]; a indexes D0 unless
-// transpose_ab, in which case a indexes D1 and b indexes D0)
+// transpose_ab & 1, in which case a indexes D1 and b indexes D0; transpose_ab & 2: the taps are mirrored, (kh, kw) -> (KH-1-kh, KW-1-kw) --
+// together the two bits turn the slab of the MIRRORED problem  sum_pix X[pix][ci] dPre[pix - off(tap)][co]  into an OIHW gradient)
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* g, float* grad, int A, int Breal, int KH, int KW, int seg0_real,
                                                            int seg0_p, int segtot_p, int D0, int D1, int transpose_ab, int b_off, float scale,
                                                            int splits, long slab) {
@@ -183,13 +184,14 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* g, float
       f4 v = red[ql];
 #pragma unroll
       for (int j = 1; j < 8; ++j) v += red[32 * j + ql];
-      const int kh = tap / KW, kw = tap - kh * KW;
+      int kh = tap / KW, kw = tap - kh * KW;
+      if (transpose_ab & 2) { kh = KH - 1 - kh; kw = KW - 1 - kw; }
       const int lim = bp < seg0_p ? seg0_real : Breal;      // real channels end inside this group of four?
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (b + e >= lim) break;
         const int bb = b + e + b_off;
-        const long di = transpose_ab ? ((((long)bb * D1 + a) * KH + kh) * KW + kw) : ((((long)a * D1 + bb) * KH + kh) * KW + kw);
+        const long di = (transpose_ab & 1) ? ((((long)bb * D1 + a) * KH + kh) * KW + kw) : ((((long)a * D1 + bb) * KH + kh) * KW + kw);
         grad[di] += v[e] * scale;
       }
     }

@@ -129,6 +129,7 @@ class Engine:
         # chip: nothing to overlap); config 2 at B = 8 collapses to 2.4 img/s -- at 239 of 288 GB the operands the lagging side
         # stream still holds (record_stream) leave the caching allocator without free blocks and it falls back to synchronising
         # hipFree / hipMalloc cycles.  Hence off by default.
+        self.wgrad_mirror = os.environ.get("CSBSR_WGRAD_MIRROR", "1") == "1"      # see Conv._bwd_weights_impl
         self.wg_stream = None
         self._wg_on = os.environ.get("CSBSR_WGRAD_STREAM", "0") == "1"
         self._ws_by_stream = {}
@@ -644,14 +645,31 @@ class Conv:
 
     def _bwd_weights_impl(self, dpre, x, split_override=None):
         xs = x if isinstance(x, (tuple, list)) else (x,)
-        d = L.WgradDesc()
-        if self.transposed:                      # A = input (LR), B = dOut (HR)
+        # A layer with <= 64 output channels fills half (or a tenth) of the kernels' 128-row tiles.  For a stride-1 "same" conv the MIRRORED
+        # problem  G'[ci][tap'][co] = sum_pix X[pix][ci] dPre[pix - off(tap')][co]  is the same sum with the roles swapped -- rows = input
+        # channels (one launch per input segment), columns = taps x output channels, taps mirrored -- and csbsr_unpack_wgrad writes it
+        # back transposed and flipped.  Same-process A/B (scripts/wgrad_mirror_ab.py): config 5's 505 -> 64 HR layers 18.7 -> 10.9 ms per
+        # launch, the decoder's 256 -> 64 4.35 -> 2.49, and the 3-channel image heads 512 -> 3 3.86 -> 2.37 / 128 -> 3 1.07 -> 0.68
+        # (against the taps-in-rows kernel written for them, csrc/conv_wgrad.hip).
+        mirror = (self.eng.wgrad_mirror and not self.transposed and self.stride == 1 and self.cout <= 64
+                  and 2 * self.pad == self.dil * (self.k - 1) and all(f.cp >= 128 and not f.bcast for f in xs))
+        if mirror:
+            off = 0
+            for i, f in enumerate(xs):
+                creal = f.c if split_override is None else split_override[i]
+                self._wgrad_launch(f, (dpre,), self.cout, 0, creal, 3, off)
+                off += creal
+        elif self.transposed:                    # A = input (LR), B = dOut (HR)
             assert len(xs) == 1
-            a, bs = xs[0], (dpre,)
-            seg0, seg1 = self.cout, 0
+            self._wgrad_launch(xs[0], (dpre,), self.cout, 0, self.w.shape[0], 0, 0)
         else:
-            a, bs = dpre, xs
             seg0, seg1 = split_override if split_override is not None else self.split
+            self._wgrad_launch(dpre, xs, seg0, seg1, self.w.shape[0], 0, 0)
+
+    def _wgrad_launch(self, a, bs, seg0, seg1, A_real, unpack_mode, a_off):
+        """G[a][tap][b] = sum_pix A[pix][a] B[pix @ tap][b] into fp32 slabs, then the slabs into the master parameter's accumulator
+        (unpack_mode 3 = the mirrored problem: rows index the weight's dim 1 from ``a_off``, taps flipped)."""
+        d = L.WgradDesc()
         sn, sy, sx = a.strides()
         d.a, d.a_sn, d.a_sy, d.a_sx, d.ca, d.ca_real = _ptr(a.t), sn, sy, sx, a.cp, a.c
         d.b[0] = bs[0].seg()
@@ -676,9 +694,8 @@ class Conv:
             tm.append(("wgrad", flops, nbytes, ev0, ev1, self.name, (a.N, a.H, a.W, a.c, sum(f.c for f in bs), self.k, self.stride, int(self.transposed)),
                        int(L.load().csbsr_debug_last_wgrad_kernel())))
         gacc = grad_acc(self.w)
-        A_real = self.w.shape[0]
-        L.call("csbsr_unpack_wgrad", _ptr(g), _ptr(gacc), A_real, self.k, self.k, seg0, seg1, self.w.shape[0], self.w.shape[1], 0, 0,
-               1.0, splits, a.cp, self.eng.stream)
+        L.call("csbsr_unpack_wgrad", _ptr(g), C.c_void_p(gacc.data_ptr() + 4 * a_off * self.k * self.k), A_real, self.k, self.k, seg0, seg1,
+               self.w.shape[0], self.w.shape[1], unpack_mode, 0, 1.0, splits, a.cp, self.eng.stream)
 
 
 class ShuffleConv(Conv):

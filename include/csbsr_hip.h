@@ -212,7 +212,8 @@ int csbsr_pack_weights_split(const float* w, void* dst, int32_t kind, int32_t D0
                              int32_t stride, int32_t pad, int32_t creal, int32_t row_off, int32_t nrows, int32_t k_off,
                              float wscale, int32_t layout, csbsr_stream_t s);
 /* packed fp32 wgrad slabs G[split][ca_padded][tap][b(padded segments)] -> grad[a][b_off + b][kh][kw] += scale * sum_split G
- * (grad is [D0][D1][KH][KW]; transpose_ab: a indexes D1 and b indexes D0) */
+ * (grad is [D0][D1][KH][KW]; transpose_ab bit 0: a indexes D1 and b indexes D0; bit 1: taps mirrored, (kh, kw) -> (KH-1-kh, KW-1-kw) --
+ * the two together unpack the slab of a stride-1 conv's mirrored wgrad problem, A = input, B = dOut) */
 int csbsr_unpack_wgrad(const float* g, float* grad, int32_t A, int32_t KH, int32_t KW, int32_t seg0_real,
                        int32_t seg1_real, int32_t D0, int32_t D1, int32_t transpose_ab, int32_t b_off, float scale,
                        int32_t splits, int32_t ca_padded, csbsr_stream_t s);

@@ -125,6 +125,42 @@ def test_conv_fwd_dgrad_wgrad(case, use_tr):
     L.load().csbsr_debug_set_wgrad_tr(1)
 
 
+@pytest.mark.parametrize("case", [
+    # cin (segments), cout, k, pad, dil, H, W
+    ((505,), 64, 3, 1, 1, 20, 24),          # blur_skip conv_scale.1
+    ((256,), 64, 3, 2, 2, 14, 18),          # dilated
+    ((128, 128), 3, 3, 1, 1, 20, 24),       # kb.sr_reconst: two input segments -> two mirrored launches at a column offset
+    ((264, 136), 17, 3, 1, 1, 9, 30),       # ragged everything
+    ((256,), 32, 1, 0, 1, 12, 16),          # 1x1
+])
+def test_mirrored_wgrad_of_few_output_channels(case):
+    """engine.Conv._bwd_weights_impl: layers with <= 64 output channels run the mirrored problem (rows = input channels); against torch
+    autograd, and against the plain form of the same launch"""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv, grad_acc
+    segs, cout, k, p, d, H, W = case
+    cin = sum(segs)
+    torch.manual_seed(11)
+    eng = _eng()
+    x = torch.randn(2, cin, H, W).half().float()
+    w = (torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5)
+    dpre = torch.randn(2, cout, H, W).half().float()
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, None, 1, p, d).backward(dpre)
+    fx = tuple(to_fm(eng, t) for t in torch.split(x, list(segs), 1))
+    got = {}
+    for mirror in (True, False):
+        params = {"l.weight": w.clone().cuda()}
+        conv = Conv(eng, "l", params, k, 1, p, d, bias=False, split=segs if len(segs) > 1 else None)
+        eng.wgrad_mirror = mirror
+        conv.bwd_weights(to_fm(eng, dpre), fx if len(fx) > 1 else fx[0])
+        conv.bwd_weights(to_fm(eng, dpre), fx if len(fx) > 1 else fx[0])          # accumulates
+        torch.cuda.synchronize()
+        got[mirror] = params["l.weight"].gacc.cpu() / 2
+        assert relmax(got[mirror], wr.grad) < 2e-3, mirror
+    assert relmax(got[True], got[False]) < 1e-5
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(32, 32, 19, 45), (32, 32, 16, 64), (49, 32, 24, 33), (32, 49, 9, 40), (49, 49, 17, 70), (64, 64, 8, 32)])
 def test_full_resolution_thin_wgrad(cin, cout, H, W):
     """csrc/conv_wgrad_hr.hip (dPre tile + input halo tile in LDS once per 8 x 32 pixels, nine taps from the one halo, one slab per
