@@ -143,6 +143,7 @@ def main():
         cfg.MODEL.DETECTOR_TYPE, cfg.SOLVER.TASK_LOSS_WEIGHT = "HRNet_OCR", 0.9
     other = args.workload != "pspnet_x4"
     scale = cfg.MODEL.SCALE_FACTOR
+    torch.manual_seed(cfg.SEED + rank)      # Dropout2d masks come from torch's CUDA generator, whose initial seed is per process on this build: two runs print the same loss
     model = JointModelWithLoss(cfg, 9000, 40000, None, device=str(dev))
     model.micro_batch = args.micro_batch
     model.detector_precision = args.detector_precision
