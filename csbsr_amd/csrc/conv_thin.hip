@@ -439,6 +439,7 @@ int conv_thin_cin2_launch(const ConvK& k, int creal, hipStream_t st) {
 // one output phase column (ox % s) and one channel octet, keeps that phase's 4 taps x 3 channels x 8 couts of weights in registers
 // (fp16-rounded, straight from the standard phase-major pack) and walks the pixels of its phase along a group of rows with equal
 // oy % s; the 16 octet-threads of a pixel share its four 16-byte input loads and write one contiguous 256-byte pixel.
+#define TP_ROW_MAX 1024      // input width the row staging holds (conv_thin_tp_eligible)
 template <int CI>
 __global__ __launch_bounds__(256) void conv_thin_tp_kernel(const ConvK p, int groups_per_phase) {
   const int tid = threadIdx.x;
@@ -474,10 +475,22 @@ __global__ __launch_bounds__(256) void conv_thin_tp_kernel(const ConvK p, int gr
   const float rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
   const half_t* in0 = reinterpret_cast<const half_t*>(p.in[0].ptr) + (long)n * p.in[0].sn;
   const int rows_per_group = (p.OH / s + groups_per_phase - 1) / groups_per_phase;
+  // the two input rows an output row reads (3 channels in one 16-byte pixel), staged in LDS once per row with a zero pixel at either end:
+  // as per-pixel global loads (L2 hits, but two rounds of L2 latency per pass on the critical path of a kernel with two waves per SIMD)
+  // they held the HBM stream of the residual at 2.9 TB/s
+  __shared__ h8 srow[2][TP_ROW_MAX + 2];
   for (int r = 0; r < rows_per_group; ++r) {
     const int qy = rg * rows_per_group + r;
     const int oy = qy * s + py;
     if (oy >= p.OH) break;
+    __syncthreads();
+    for (int i = tid; i < 2 * (p.W + 2); i += 256) {
+      const int tr = i / (p.W + 2), ix = i - tr * (p.W + 2) - 1, iy = qy + by - tr;
+      h8 v = h8{0, 0, 0, 0, 0, 0, 0, 0};
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = *reinterpret_cast<const h8*>(in0 + (long)iy * p.in[0].sy + (long)ix * p.in[0].sx);
+      srow[tr][ix + 1] = v;
+    }
+    __syncthreads();
     // EIGHT pixels per pass: their residual loads -- the HBM stream of this kernel -- are all requested up front (with four, 2 workgroups
     // x 256 threads x 64 B kept 32 KB per CU in flight: 2.45 TB/s by Little's law, which is what the kernel ran at); the input loads
     // (a 3-channel LR image: L1 / L2 hits) follow four pixels at a time.  Stores to out16 may alias every load as far as the compiler
@@ -499,10 +512,8 @@ __global__ __launch_bounds__(256) void conv_thin_tp_kernel(const ConvK p, int gr
           const bool live = ox < p.OW;
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const int iy = qy + by - (t >> 1), ix = qx + bx - (t & 1);
-            xv[u][t] = h8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (live && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-              xv[u][t] = *reinterpret_cast<const h8*>(in0 + (long)iy * p.in[0].sy + (long)ix * p.in[0].sx);
+            const int ix = qx + bx - (t & 1);
+            xv[u][t] = srow[t >> 1][live ? ix + 1 : 0];
           }
         }
 #pragma unroll
@@ -540,7 +551,7 @@ __global__ __launch_bounds__(256) void conv_thin_tp_kernel(const ConvK p, int gr
 bool conv_thin_tp_eligible(const ConvK& k, int creal, bool second_seg) {
   if (!g_conv_thin || !k.transposed || second_seg) return false;
   if (k.KHt != 2 || k.KWt != 2 || k.stride < 2 || k.dil != 1 || k.pad >= k.stride) return false;
-  if (k.ctot != 8 || creal != 3 || k.in[0].sx == 0) return false;
+  if (k.ctot != 8 || creal != 3 || k.in[0].sx == 0 || k.W > TP_ROW_MAX) return false;
   if (k.OH != k.H * k.stride || k.OW != k.W * k.stride) return false;
   if (k.coutp < 8 || k.coutp > 128 || (256 / (k.coutp / 8)) % k.stride != 0 || 256 % (k.coutp / 8) != 0) return false;
   if (!k.out16 || k.out32 || k.o_lo || k.r_lo || k.cbias || k.mask || k.accumulate || k.stat_mode != CSBSR_STAT_NONE) return false;
