@@ -28,6 +28,13 @@ __device__ __forceinline__ void st_split(half_t* p, long lo, const float (&v)[8]
   *reinterpret_cast<h8*>(p) = a;
   if (lo) *reinterpret_cast<h8*>(p + lo) = b;
 }
+// eight consecutive fp32 values of a per-(sample, channel) row (dropout scales): two 16-byte loads.  Written as eight indexed reads of a
+// pointer of unknown alignment the compiler issued eight 4-byte loads per channel octet: the x2 up-samplings of the detector's decoder
+// ran at 1.7-2.2 TB/s with the scale row and 2.7-2.9 without (scripts/bench_bilinear.py).  (The row starts at a multiple of 8 floats.)
+__device__ __forceinline__ void ld8f(const float* p, float (&v)[8]) {
+  const f4 a = *reinterpret_cast<const f4*>(p), b = *reinterpret_cast<const f4*>(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
 
 // ------------------------------------------------------------------------------------------- two-stage reductions
 // One registration per DEVICE (keyed on the calling thread's current HIP device, which is also the device every launch below goes to):
@@ -720,12 +727,13 @@ __global__ void bn_apply_kernel(const BnK p) {
     float xv[8], rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o[8];
     ld_split(p.x + px * p.x_ld + c0, p.x_lo, xv);
     if (p.res) ld_split(p.res + px * p.res_ld + c0, p.res_lo, rv);
-    const float* dr = p.drop ? p.drop + (long)((unsigned)px / (unsigned)p.hw) * p.cp + c0 : nullptr;
+    float dr[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (p.drop) ld8f(p.drop + (long)((unsigned)px / (unsigned)p.hw) * p.cp + c0, dr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = (xv[e] - mean[e]) * sc[e] + be[e] + rv[e];
       v = apply_act(v, p.act, slope);
-      if (dr) v *= dr[e];
+      v *= dr[e];
       o[e] = v;
     }
     st_split(p.y + px * p.y_ld + c0, p.y_lo, o);
@@ -770,13 +778,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnK p) {
         float xv[8], rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         ld_split(p.x + px * p.x_ld + c0, p.x_lo, xv);
         if (p.res) ld_split(p.res + px * p.res_ld + c0, p.res_lo, rv);
-        const float* dr = p.drop ? p.drop + (long)((unsigned)px / (unsigned)p.hw) * p.cp + c0 : nullptr;
+        float dr[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (p.drop) ld8f(p.drop + (long)((unsigned)px / (unsigned)p.hw) * p.cp + c0, dr);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float xh = (xv[e] - mean[e]) * istd[e];
           const float z = xh * ga[e] + be[e] + rv[e];
           float gg = (float)g[e];
-          if (dr) gg *= dr[e];
+          gg *= dr[e];
           float dz = gg;
           if (p.act == CSBSR_ACT_RELU) dz = z > 0.f ? gg : 0.f;
           else if (p.act == CSBSR_ACT_PRELU && !(z > 0.f)) { dsl += gg * z; dz = gg * slope; }
@@ -827,7 +836,8 @@ __global__ void bn_bwd_apply_kernel(const BnK p) {
     float xv[8], rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     ld_split(p.x + px * p.x_ld + c0, p.x_lo, xv);
     if (p.res) ld_split(p.res + px * p.res_ld + c0, p.res_lo, rv);
-    const float* dr = p.drop ? p.drop + (long)((unsigned)px / (unsigned)p.hw) * p.cp + c0 : nullptr;
+    float dr[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (p.drop) ld8f(p.drop + (long)((unsigned)px / (unsigned)p.hw) * p.cp + c0, dr);
     h8 old = {0, 0, 0, 0, 0, 0, 0, 0};
     if (p.dres && p.dres_acc) old = *reinterpret_cast<const h8*>(p.dres + px * p.dres_ld + c0);
     h8 o, drs;
@@ -836,7 +846,7 @@ __global__ void bn_bwd_apply_kernel(const BnK p) {
       const float xh = (xv[e] - mean[e]) * istd[e];
       const float z = xh * ga[e] + be[e] + rv[e];
       float gg = (float)g[e];
-      if (dr) gg *= dr[e];
+      gg *= dr[e];
       float dz = gg;
       if (p.act == CSBSR_ACT_RELU) dz = z > 0.f ? gg : 0.f;
       else if (p.act == CSBSR_ACT_PRELU) dz = z > 0.f ? gg : gg * slope;
@@ -1172,7 +1182,8 @@ __global__ void bilinear_fwd_kernel(const half_t* x, long x_ld, half_t* y, long 
     const int ox = (int)(i / (unsigned)c8), cc = (int)(i - (unsigned)ox * (unsigned)c8);
     int x0, x1; float wx;
     bil_src(ox, W, OW, align, x0, x1, wx);
-    float v00[8], v01[8], v10[8], v11[8], o[8];
+    float v00[8], v01[8], v10[8], v11[8], o[8], dr[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (drop) ld8f(drop + n * cp + cc * 8, dr);
     ld_split(b0 + (long)x0 * x_ld + cc * 8, x_lo, v00);
     ld_split(b0 + (long)x1 * x_ld + cc * 8, x_lo, v01);
     ld_split(b1 + (long)x0 * x_ld + cc * 8, x_lo, v10);
@@ -1180,7 +1191,7 @@ __global__ void bilinear_fwd_kernel(const half_t* x, long x_ld, half_t* y, long 
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = (1.f - wy) * ((1.f - wx) * v00[e] + wx * v01[e]) + wy * ((1.f - wx) * v10[e] + wx * v11[e]);
-      if (drop) v *= drop[n * cp + cc * 8 + e];
+      if (drop) v *= dr[e];
       o[e] = v;
     }
     st_split(yr + (long)ox * y_ld + cc * 8, y_lo, o);
@@ -1226,8 +1237,10 @@ __global__ void bilinear_bwd_kernel(const half_t* dy, long dy_ld, half_t* dx, lo
       }
     }
     if (drop) {
+      float dr[8];
+      ld8f(drop + n * cp + cc * 8, dr);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] *= drop[n * cp + cc * 8 + e];
+      for (int e = 0; e < 8; ++e) a[e] *= dr[e];
     }
     half_t* q = dx + (((long)n * H + iy) * W + ix) * dx_ld + cc * 8;
     if (accumulate) { const h8 old = *reinterpret_cast<const h8*>(q);
@@ -1308,7 +1321,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_block_kernel(const half_t* d
     for (int e = 0; e < 8; ++e) {
       float s_ = 0.f;
       for (int k = 0; k < 32; ++k) s_ += sred[k][cl][e];
-      if (drop) s_ *= drop[n * cp + cc * 8 + e];
+      if (drop) s_ *= drop[n * cp + cc * 8 + e];      // (one thread per pixel and octet here: not a stream)
       o[e] = (half_t)(s_ + (float)old[e]);
     }
     *reinterpret_cast<h8*>(q) = o;

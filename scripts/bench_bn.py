@@ -23,6 +23,13 @@ for (N, H, W, c) in ((8, 896, 896, 64), (8, 448, 448, 256), (8, 224, 224, 1024))
     gb = x.t.numel() * 2 / 1e9
     ms = t(lambda: bn.apply(x, mean, invstd, act=L.ACT_RELU, out=y))
     print(f"bn_apply [{N},{H},{W},{c}] {ms:.3f} ms  {2 * gb / ms:.2f} TB/s (r+w)")
+    xs, ys = eng.new(N, H, W, c, split=True), eng.new(N, H, W, c, split=True)      # the detector precision mode: hi + lo planes in and out
+    xs.t.normal_()
+    ms = t(lambda: bn.apply(xs, mean, invstd, act=L.ACT_RELU, out=ys))
+    print(f"bn_apply split [{N},{H},{W},{c}] {ms:.3f} ms  {4 * gb / ms:.2f} TB/s (r+w, two planes each)")
+    ms = t(lambda: bn.apply(xs, mean, invstd, act=L.ACT_RELU, res=ys, out=ys))
+    print(f"bn_apply split + residual {ms:.3f} ms  {6 * gb / ms:.2f} TB/s")
+    del xs, ys
     dy = FM(torch.randn(N, H, W, c, device="cuda", dtype=torch.float16), c)
     ms = t(lambda: bn.backward(dy, x, mean, invstd, act=L.ACT_RELU))
     print(f"bn_backward (reduce + apply) {ms:.3f} ms  {5 * gb / ms:.2f} TB/s (2 x (dy, x) reads + 1 write)")
