@@ -475,6 +475,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   }
   if (!split_io && !d->bias_sn && conv_thin_tp_eligible(k, d->in[0].creal, d->in[1].c != 0)) { g_last_conv_kernel = CONVK_THIN_TP; return conv_thin_tp_launch(k, st); }
   if (!d->r_lo && !d->r2_lo && conv_thin_sc_eligible(k)) { g_last_conv_kernel = CONVK_THIN_SC; return conv_thin_sc_launch(k, st); }
+  if (!split_io && d->in[1].c == 0 && conv_thin_tpd_eligible(k, d->KH)) { g_last_conv_kernel = CONVK_THIN_TPD; return conv_thin_tpd_launch(k, d->KH, st); }
   if (conv_glds_eligible(k)) return conv_glds_launch(k, nphase, maxM, st);
   CSBSR_CHECK(!k.fs, "conv: split_fused launch not eligible for the LDS-DMA kernels (needs > 32 padded output channels)");
   CSBSR_CHECK(k.KHt * k.KWt <= NTAP_MAX, "conv: more taps per phase than the tap tables hold");

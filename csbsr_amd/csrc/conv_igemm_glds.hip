@@ -572,6 +572,7 @@ extern "C" void csbsr_debug_set_conv_glds(int mode) {
   g_glds_gk = (mode & 2048) ? 0 : 1;             // bit 11: no general K walk, channel counts off the 64-channel grid back on the register-staged kernel (A/B timing)
   conv_thin_enable((mode & 16) ? 0 : 1);      // bit 4: route the 3-channel heads through the generic kernel (A/B timing)
   conv_thin_sc_enable((mode & 4096) ? 0 : 1);    // bit 12: the 128 -> 3 strided layers back on the general kernel (A/B timing)
+  conv_thin_tpd_enable((mode & 8192) ? 0 : 1);   // bit 13: the stems' 64 -> 3 stride-2 dgrads back on the general kernel (A/B timing)
   conv_thin_cin2_enable((mode & 512) ? 0 : 1);  // bit 9: no streaming variant of the 3-channel-input kernel (A/B timing, tests)
 }
 

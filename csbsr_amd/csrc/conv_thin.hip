@@ -571,6 +571,112 @@ int conv_thin_tp_launch(const ConvK& k, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Stride-2 transposed convolution from 64 channels INTO <= 3: the dgrad of the detectors' stems (PSPNet: Conv2d 3 -> 64, 7x7 stride 2,
+// extractors.py:45; HRNet: 3x3 stride 2, hrnet_backbone.py:303) -- the gradient of the SR image under the segmentation loss.  It ran on the
+// 32-cout register-staged implicit GEMM (29 of 32 MFMA columns multiplying zeros, every tap re-gathered): 5.3 ms at B = 8, 30 TF/s, 190 GB/s.
+// Here a workgroup owns a 16 x 32 output tile; the (8 + taps) x (16 + taps) input pixels it reads are staged in LDS once (144-byte
+// pixel pitch: an odd number of 16-byte slots, conflict-free b128 reads); wave w multiplies the output phase (w / 2, w % 2) -- one tap
+// set per wave, so the tap's weights are wave-uniform and come as SCALAR loads (constant address space) straight into the v_dot2
+// operands -- two pixels per lane, fp32 accumulate, the common epilogue row.  Phase-packed weights of csbsr_pack_weights (kind 2).
+#define TPD_TH 16
+#define TPD_TW 32
+#define TPD_PITCH 72
+#define TPD_IH 12
+#define TPD_IW 20
+typedef __attribute__((address_space(4))) const unsigned tpd_cu32;
+
+__global__ __launch_bounds__(256) void conv_thin_tpd_kernel(const ConvK p, int tiles_x, int tiles_y, int KH) {
+  __shared__ __attribute__((aligned(16))) half_t sIn[TPD_IH * TPD_IW * TPD_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int py = wid >> 1, px = wid & 1, ph = wid;
+  const int by = (py + p.pad) >> 1, bx = (px + p.pad) >> 1, bmin = p.pad >> 1, bmax = (1 + p.pad) >> 1;
+  const int IH = TPD_TH / 2 + bmax - bmin + p.KHt - 1, IW = TPD_TW / 2 + bmax - bmin + p.KWt - 1;
+  const int qyl = lane >> 4, qxl = lane & 15;
+  tpd_cu32* wc = (tpd_cu32*)(unsigned long)(p.wt + (size_t)ph * p.rows_p * p.Kp);
+  const int kpd = p.Kp >> 1;                           // dwords per weight row
+  float bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = (p.bias && e < p.cout) ? p.bias[e] : 0.f;
+  const float slope = p.act == CSBSR_ACT_PRELU ? *p.prelu : p.act_slope;
+  const half_t* in0 = reinterpret_cast<const half_t*>(p.in[0].ptr);
+  const unsigned per_img = (unsigned)(tiles_x * tiles_y), total = per_img * (unsigned)p.N;
+  for (unsigned t = blockIdx.x; t < total; t += gridDim.x) {
+    const int n = t / per_img;
+    const unsigned r_ = t - n * per_img;
+    const int oy0 = (int)(r_ / tiles_x) * TPD_TH, ox0 = (int)(r_ % tiles_x) * TPD_TW;
+    const int iyo = oy0 / 2 + bmin - (p.KHt - 1), ixo = ox0 / 2 + bmin - (p.KWt - 1);
+    __syncthreads();
+    for (int id = tid; id < IH * IW * 8; id += 256) {
+      const int pix = id >> 3, oc = id & 7;
+      const int ly = pix / IW, lx = pix - ly * IW;
+      const int iy = iyo + ly, ix = ixo + lx;
+      h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        v = *reinterpret_cast<const h8*>(in0 + (long)n * p.in[0].sn + (long)iy * p.in[0].sy + (long)ix * p.in[0].sx + oc * 8);
+      *reinterpret_cast<h8*>(sIn + pix * TPD_PITCH + oc * 8) = v;
+    }
+    __syncthreads();
+    float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll 1
+    for (int ty = 0; ty < p.KHt; ++ty) {
+      if (((py + p.pad) & 1) + 2 * ty >= KH) break;            // (wave-uniform) the phase has no such kernel row: its packed weights are zeros
+      const int ly = qyl + (by - bmin) + (p.KHt - 1) - ty;
+#pragma unroll 1
+      for (int tx = 0; tx < p.KWt; ++tx) {
+        if (((px + p.pad) & 1) + 2 * tx >= KH) break;
+        const int lx = qxl + (bx - bmin) + (p.KWt - 1) - tx;
+        const half_t* s0 = sIn + (ly * IW + lx) * TPD_PITCH;
+        const half_t* s1 = s0 + 4 * IW * TPD_PITCH;
+        const int wbase = ((ty * p.KWt + tx) * 64) >> 1;
+#pragma unroll 2
+        for (int oc = 0; oc < 8; ++oc) {      // (two octets = 24 scalar weight registers at a time: all eight overflowed the SGPR file)
+          const h8 x0 = *reinterpret_cast<const h8*>(s0 + oc * 8), x1 = *reinterpret_cast<const h8*>(s1 + oc * 8);
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned wu = wc[r * kpd + wbase + oc * 4 + j];
+              const h2 w2 = __builtin_bit_cast(h2, wu);
+              acc[0][r] = __builtin_amdgcn_fdot2(h2{x0[2 * j], x0[2 * j + 1]}, w2, acc[0][r], false);
+              acc[1][r] = __builtin_amdgcn_fdot2(h2{x1[2 * j], x1[2 * j + 1]}, w2, acc[1][r], false);
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int oy = oy0 + 2 * (qyl + 4 * j) + py, ox = ox0 + 2 * qxl + px;
+      if (oy >= p.OH || ox >= p.OW) continue;
+      float v[8] = {acc[j][0], acc[j][1], acc[j][2], 0.f, 0.f, 0.f, 0.f, 0.f}, ssum[8], ssq[8];
+      conv_epilogue_row(p, v, bias, slope, 0, n, oy, ox, ssum, ssq);
+    }
+  }
+}
+
+static int g_conv_thin_tpd = 1;
+void conv_thin_tpd_enable(int on) { g_conv_thin_tpd = on; }
+
+bool conv_thin_tpd_eligible(const ConvK& k, int KH) {
+  if (!g_conv_thin_tpd || !k.transposed || k.stride != 2 || k.dil != 1 || k.KHt != k.KWt || k.KHt > 4 || k.pad < 0) return false;
+  if (KH > 2 * k.KHt || TPD_TH / 2 + ((1 + k.pad) >> 1) - (k.pad >> 1) + k.KHt - 1 > TPD_IH) return false;
+  if (k.c0 != k.ctot || k.ctot != 64 || k.in[0].sx == 0 || k.cout > 3 || k.coutp != 8 || k.rows_p < 3) return false;
+  if (k.cbias || k.mask || k.o_lo || k.r_lo || k.r2_lo || k.stat_mode != CSBSR_STAT_NONE || k.bias_sn || k.fs) return false;
+  if (k.OH != 2 * k.H || k.OW != 2 * k.W) return false;
+  if ((long)k.N * k.OH * k.OW < 64L * 1024) return false;          // small maps: the general kernel
+  return true;
+}
+
+int conv_thin_tpd_launch(const ConvK& k, int KH, hipStream_t st) {
+  const int tiles_x = (k.OW + TPD_TW - 1) / TPD_TW, tiles_y = (k.OH + TPD_TH - 1) / TPD_TH;
+  const long total = (long)k.N * tiles_x * tiles_y;
+  const unsigned g = (unsigned)(total < 1024 ? total : 1024);
+  hipLaunchKernelGGL(conv_thin_tpd_kernel, dim3(g), dim3(256), 0, st, k, tiles_x, tiles_y, KH);
+  CSBSR_LAUNCH_CHECK("csbsr_conv_forward(thin transposed dgrad)");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // Strided convolution INTO <= 3 channels from 128 (8x8 stride 4 / 12x12 stride 8): the dgrad of kb.up_conv1 (ConvTranspose2d 3 -> 128, 8x8
 // stride 4; kbpn.py:372-374) -- the gradient of the 3-channel LR error image, an 8192-term dot product per output value over a 3.3 GB
 // map (N = 4).  On the 32-cout implicit-GEMM tile it ran at 1.8 TB/s with 29 of 32 MFMA columns multiplying zeros.  Here a wave owns four

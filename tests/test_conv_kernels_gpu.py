@@ -80,6 +80,9 @@ CASES = [
     (720, 512, 3, 1, 1, 1, False, 20, 24),         # the 720-channel concat of the four branches into the OCR head's 3x3 conv
     (720, 720, 1, 1, 0, 1, False, 24, 24),
     (40, 72, 3, 1, 1, 1, False, 24, 24),           # 40 channels: five 8-channel units per tap
+    (3, 64, 7, 2, 3, 1, False, 192, 256),          # PSPNet stem at a size whose dgrad (64 -> 3, 4x4 taps per phase) takes conv_thin_tpd
+    (3, 64, 3, 2, 1, 1, False, 200, 168),          # HRNet stem (2x2 taps per phase), ragged 16 x 32 output tiles
+    (2, 64, 7, 2, 3, 1, False, 130, 258),          # two image channels, tiles ragged in both directions
 ]
 
 
