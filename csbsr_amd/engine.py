@@ -130,6 +130,7 @@ class Engine:
         # stream still holds (record_stream) leave the caching allocator without free blocks and it falls back to synchronising
         # hipFree / hipMalloc cycles.  Hence off by default.
         self.wgrad_mirror = os.environ.get("CSBSR_WGRAD_MIRROR", "1") == "1"      # see Conv._bwd_weights_impl
+        self.thin_tp_fused = os.environ.get("CSBSR_KBUP_FUSED", "1") == "1"       # see Conv.bwd_thin_tp_fused (A/B timing: 0)
         self.wg_stream = None
         self._wg_on = os.environ.get("CSBSR_WGRAD_STREAM", "0") == "1"
         self._ws_by_stream = {}
@@ -642,6 +643,29 @@ class Conv:
             f.t.record_stream(side)
         with torch.cuda.stream(side):
             self._bwd_weights_impl(dpre, x, split_override)
+
+    def thin_tp_fused_ok(self, x):
+        """kb.up_conv1's shape: ConvTranspose2d(3 -> C, 8x8, stride 4) + PReLU without bias -- csbsr_thin_tp_backward takes its backward"""
+        return (self.transposed and self.k == 8 and self.stride == 4 and self.cin == 3 and self.b is None and self.act == L.ACT_PRELU
+                and self.prelu is not None and self.cout % 8 == 0 and 8 <= self.cout <= 128 and 64 % (self.cout // 8) == 0 and x.W <= 1024
+                and self.eng.thin_tp_fused)
+
+    def bwd_thin_tp_fused(self, dout, x, dpre, frozen=False):
+        """dOut -> dPre, weight gradient and PReLU-slope gradient of the layer in ONE pass over dOut: the pre-activation is rebuilt from
+        the 3-channel input (csrc/conv_kbup.hip), so the epilogue-backward pass over (dOut, saved output, residual) and the separate
+        weight-gradient launch are gone.  ``dout`` is left untouched (it lives on as the residual's gradient)."""
+        wt = self._pack("fwd", 2, self.split[0], self.split[1], 0, self.cout, self.stride, self.pad)
+        N, h, w = x.N, x.H, x.W
+        ns = int(L.load().csbsr_thin_tp_backward_slabs(N, h))
+        slabs = None if frozen else self.eng.workspace(ns * 8 * 64 * self.cout)
+        part = None if frozen else self.eng.f32(4 * ns, zero=False)
+        L.call("csbsr_thin_tp_backward", _ptr(dout.t), *dout.strides(), _ptr(x.t), *x.strides(), _ptr(wt), 3, self.cout, self.stride, self.pad,
+               _ptr(self.prelu), N, h, w, _ptr(dpre.t), *dpre.strides(), _ptr(slabs), _ptr(part), self.eng.stream)
+        if not frozen:
+            L.call("csbsr_unpack_wgrad", _ptr(slabs), _ptr(grad_acc(self.w)), 3, 8, 8, self.cout, 0, self.w.shape[0], self.w.shape[1], 0, 0,
+                   1.0, ns, 8, self.eng.stream)
+            grad_acc(self.prelu).add_(part.sum())
+        return dpre
 
     def _bwd_weights_impl(self, dpre, x, split_override=None):
         xs = x if isinstance(x, (tuple, list)) else (x,)

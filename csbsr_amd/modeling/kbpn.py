@@ -487,8 +487,13 @@ class KBPN:
             dh = dhs
             if not self.lr_err:
                 dpk = e.new(B, H, W, 128)
-                self._act_bwd(st.kb_up, dhs, hs, res=q["h"], res_mode=L.RES_ADD, dpre=dpk)
-                self._wg(st.kb_up, dpk, q["err16"])
+                if st.kb_up.thin_tp_fused_ok(q["err16"]):
+                    # one pass over dOut: the pre-activation is rebuilt from the 3-channel error image (csrc/conv_kbup.hip) instead of
+                    # read back as hs - h; dPre, the weight gradient and the slope gradient leave together
+                    st.kb_up.bwd_thin_tp_fused(dhs, q["err16"], dpk, frozen=st.kb_up.frozen)
+                else:
+                    self._act_bwd(st.kb_up, dhs, hs, res=q["h"], res_mode=L.RES_ADD, dpre=dpk)
+                    self._wg(st.kb_up, dpk, q["err16"])
                 derr = e.f32(B, 3, h, w, zero=False)
                 st.kb_up.bwd_input(dpk, out32=derr, in_hw=(h, w))
                 del dpk

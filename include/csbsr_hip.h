@@ -429,6 +429,19 @@ int csbsr_iou_sweep(const float* pred, const float* mask, const float* threshold
 int csbsr_psnr_ssim(const float* a, const float* b, int32_t N, int32_t C, int32_t H, int32_t W, float* sums, float* psnr, float* ssim,
                     csbsr_stream_t s);
 
+/* Backward of kb.up_conv1 -- ConvTranspose2d(3 -> cout, 8x8, stride 4, pad 2, no bias) + PReLU (+ residual) -- in one streaming pass over the
+ * output gradient (replaces the autograd backward of /root/reference/model/modeling/kbpn.py:372-374,405-409 for that layer: PReLU backward,
+ * conv_transpose2d weight gradient, slope gradient).  The pre-activation is rebuilt from the 3-channel input x [N, h, w, 8] and the forward's
+ * phase-packed weights (csbsr_pack_weights kind 2, the operand of csbsr_conv_forward), so neither the saved output nor the residual is read:
+ *   dpre [N, 4h, 4w, cout] fp16 = dout * (pre > 0 ? 1 : *prelu);
+ *   slabs (optional, with dprelu_part): csbsr_thin_tp_backward_slabs(N, h) fp32 slabs [8][64 taps][cout] of the weight gradient in
+ *   csbsr_conv_wgrad's layout (fold with csbsr_unpack_wgrad(.., A = 3, KH = KW = 8, seg0 = cout, .., splits = that count, ca_padded = 8));
+ *   dprelu_part [4 * slabs] partial sums of dout * min(pre, 0) (one per workgroup: add them in index order).  Strides in elements. */
+int32_t csbsr_thin_tp_backward_slabs(int32_t N, int32_t h);
+int csbsr_thin_tp_backward(const void* dout, int64_t d_sn, int64_t d_sy, int64_t d_sx, const void* x, int64_t x_sn, int64_t x_sy,
+                           int64_t x_sx, const void* wt_packed, int32_t cin, int32_t cout, int32_t stride, int32_t pad,
+                           const float* prelu, int32_t N, int32_t h, int32_t w, void* dpre, int64_t p_sn, int64_t p_sy, int64_t p_sx,
+                           float* slabs, float* dprelu_part, csbsr_stream_t s);
 #ifdef __cplusplus
 }
 #endif
