@@ -88,10 +88,17 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
       cb = p.cbias + ((size_t)n * 25 + ty * 5 + tx) * p.coutp + co;
     }
   }
+  // (the class row as two 16-byte loads -- rows are coutp floats, co a multiple of 8: as eight indexed reads of a pointer of unknown
+  // alignment it was eight dependent 4-byte loads per row piece, 10 % of a launch of the SFT conv0 forwards)
+  float cbv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (cb) {
+    const f4 c0 = *reinterpret_cast<const f4*>(cb), c1 = *reinterpret_cast<const f4*>(cb + 4);
+    cbv[0] = c0[0]; cbv[1] = c0[1]; cbv[2] = c0[2]; cbv[3] = c0[3]; cbv[4] = c1[0]; cbv[5] = c1[1]; cbv[6] = c1[2]; cbv[7] = c1[3];
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     float t = v[e] * p.out_scale + bias[e];
-    if (cb) t += cb[e];
+    if (cb) t += cbv[e];
     t = apply_act(t, p.act, slope);
     v[e] = (co + e < p.cout) ? t : 0.f;
   }
