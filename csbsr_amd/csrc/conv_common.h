@@ -160,10 +160,11 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
 // max(t, t*sneg), sneg <= 1), residual add or subtract, optional accumulate, optional BatchNorm sums: the mode switches of
 // conv_epilogue_row become two multipliers picked once per kernel.  The general row re-tests every mode per element (~100 scalar
 // branches per row): its 8 rows took 7.7 us of an 18 us transposed-conv workgroup whose 8 K slices take 5.9 us (CSBSR_TS build).
-struct EpiFast { bool ok, has_res, has_old, has_mask, bn, masked; float sneg, rsign, osc, mslope; int cout; long o_lo; };
+struct EpiFast { bool ok, has_res, has_old, has_mask, bn, masked, has_cb; float sneg, rsign, osc, mslope; int cout; long o_lo; };
 __device__ __forceinline__ EpiFast conv_epilogue_fast_setup(const ConvK& p, float slope) {
   EpiFast f;
-  f.ok = (p.stat_mode == CSBSR_STAT_NONE || p.stat_mode == CSBSR_STAT_BN) && !p.cbias && !p.out32 && p.out16 &&
+  f.has_cb = p.cbias != nullptr;      // a position-class bias: the caller adds the pixel's class row to ``bias`` (conv_class_bias_row)
+  f.ok = (p.stat_mode == CSBSR_STAT_NONE || p.stat_mode == CSBSR_STAT_BN) && !p.out32 && p.out16 &&
          p.act != CSBSR_ACT_SIGMOID && !(p.act != CSBSR_ACT_NONE && p.act != CSBSR_ACT_RELU && slope > 1.f) &&
          (p.res_mode == CSBSR_RES_NONE || p.res_mode == CSBSR_RES_ADD || p.res_mode == CSBSR_RES_SUB) && !p.r_lo;
   f.o_lo = p.o_lo;
@@ -174,6 +175,19 @@ __device__ __forceinline__ EpiFast conv_epilogue_fast_setup(const ConvK& p, floa
   f.masked = (p.cout & 7) != 0;      // the last channel octet is partly padding: those lanes are forced to zero (one branch per row)
   f.osc = p.out_scale; f.cout = p.cout;
   return f;
+}
+// bias + the class row of output pixel (oy, ox) of sample n (ConvK::cbias: 16 border classes or 25 two-ring classes), 8 couts from co
+__device__ __forceinline__ void conv_class_bias_row(const ConvK& p, const float (&bias)[8], int co, int n, int oy, int ox, float (&out)[8]) {
+  int cls, ncls;
+  if (p.cb_mode == 0) { cls = (oy == 0) * 8 + (oy == p.OH - 1) * 4 + (ox == 0) * 2 + (ox == p.OW - 1); ncls = 16; }
+  else {
+    const int ty = oy < 2 ? oy : (oy >= p.OH - 2 ? oy - p.OH + 5 : 2), tx = ox < 2 ? ox : (ox >= p.OW - 2 ? ox - p.OW + 5 : 2);
+    cls = ty * 5 + tx; ncls = 25;
+  }
+  const float* cb = p.cbias + ((size_t)n * ncls + cls) * p.coutp + co;
+  const f4 c0 = *reinterpret_cast<const f4*>(cb), c1 = *reinterpret_cast<const f4*>(cb + 4);
+  out[0] = bias[0] + c0[0]; out[1] = bias[1] + c0[1]; out[2] = bias[2] + c0[2]; out[3] = bias[3] + c0[3];
+  out[4] = bias[4] + c1[0]; out[5] = bias[5] + c1[1]; out[6] = bias[6] + c1[2]; out[7] = bias[7] + c1[3];
 }
 // one pixel x 8 channels co..co+7; o = &out16[pixel][co]; rr / oo / mm = residual / old output / activation mask (zeros when absent;
 // only read when EXTRA)
@@ -303,8 +317,14 @@ __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const 
       h8 rr = {0, 0, 0, 0, 0, 0, 0, 0}, oo = {0, 0, 0, 0, 0, 0, 0, 0};
       if (fe->has_res) rr = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
       if (fe->has_old) oo = *reinterpret_cast<const h8*>(o);
-      if (fe->has_res || fe->has_old) conv_epilogue_fast_row<true, false>(*fe, v, bias, co, o, rr, oo, s0, s1);
-      else conv_epilogue_fast_row<false, false>(*fe, v, bias, co, o, rr, oo, s0, s1);
+      float brow[8];
+      if (fe->has_cb) conv_class_bias_row(p, bias, co, n, oy, ox, brow);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) brow[e] = bias[e];
+      }
+      if (fe->has_res || fe->has_old) conv_epilogue_fast_row<true, false>(*fe, v, brow, co, o, rr, oo, s0, s1);
+      else conv_epilogue_fast_row<false, false>(*fe, v, brow, co, o, rr, oo, s0, s1);
       continue;
     }
     conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, s0, s1);

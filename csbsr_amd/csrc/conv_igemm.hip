@@ -337,6 +337,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 128 ?
             const f4 v0 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8);
             const f4 v1 = *reinterpret_cast<const f4*>(sO + row * OUT_LD + cc8 * 8 + 4);
             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (fe.has_cb) {      // (workgroup-uniform) the pixel's class row joins the bias
+              float brow[8];
+              conv_class_bias_row(p, bias, co, sRow[row * 3], py + sRow[row * 3 + 1] * o_step, px + sRow[row * 3 + 2] * o_step, brow);
+              conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, brow, co, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq, mm[i]);
+              continue;
+            }
             conv_epilogue_fast_row<decltype(EXTRA)::value, decltype(BNSTAT)::value>(fe, v, bias, co, p.out16 + ooff[i], rr[i], oo[i], ssum, ssq, mm[i]);
           }
         }
