@@ -161,12 +161,16 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
 // conv_epilogue_row become two multipliers picked once per kernel.  The general row re-tests every mode per element (~100 scalar
 // branches per row): its 8 rows took 7.7 us of an 18 us transposed-conv workgroup whose 8 K slices take 5.9 us (CSBSR_TS build).
 struct EpiFast { bool ok, has_res, has_old, has_mask, bn, masked, has_cb; float sneg, rsign, osc, mslope; int cout; long o_lo; };
+// which launches the straight-line rows cover (host and device: conv_x3 picks its kernel instance by it).  The activation is
+// max(t, 0) + sneg * min(t, 0): exact for any slope (a learned PReLU slope may exceed 1), bit-identical to t > 0 ? t : t * sneg.
+__host__ __device__ __forceinline__ bool conv_epilogue_fast_ok(const ConvK& p) {
+  return (p.stat_mode == CSBSR_STAT_NONE || p.stat_mode == CSBSR_STAT_BN) && !p.out32 && p.out16 && p.act != CSBSR_ACT_SIGMOID &&
+         (p.res_mode == CSBSR_RES_NONE || p.res_mode == CSBSR_RES_ADD || p.res_mode == CSBSR_RES_SUB) && !p.r_lo;
+}
 __device__ __forceinline__ EpiFast conv_epilogue_fast_setup(const ConvK& p, float slope) {
   EpiFast f;
   f.has_cb = p.cbias != nullptr;      // a position-class bias: the caller adds the pixel's class row to ``bias`` (conv_class_bias_row)
-  f.ok = (p.stat_mode == CSBSR_STAT_NONE || p.stat_mode == CSBSR_STAT_BN) && !p.out32 && p.out16 &&
-         p.act != CSBSR_ACT_SIGMOID && !(p.act != CSBSR_ACT_NONE && p.act != CSBSR_ACT_RELU && slope > 1.f) &&
-         (p.res_mode == CSBSR_RES_NONE || p.res_mode == CSBSR_RES_ADD || p.res_mode == CSBSR_RES_SUB) && !p.r_lo;
+  f.ok = conv_epilogue_fast_ok(p);
   f.o_lo = p.o_lo;
   f.sneg = p.act == CSBSR_ACT_NONE ? 1.f : (p.act == CSBSR_ACT_RELU ? 0.f : slope);
   f.rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
@@ -199,7 +203,7 @@ __device__ __forceinline__ void conv_epilogue_fast_row(const EpiFast& f, const f
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     t[e] = v[e] * f.osc + bias[e];
-    t[e] = fmaxf(t[e], t[e] * f.sneg);
+    t[e] = fmaxf(t[e], 0.f) + f.sneg * fminf(t[e], 0.f);
   }
   if (f.masked) {
 #pragma unroll

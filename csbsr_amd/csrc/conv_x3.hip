@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
   unsigned it = blockIdx.x;
   if (it >= items) return;
   const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
+  const EpiFast fe = conv_epilogue_fast_setup(p, slope);
   const half_t* in0 = reinterpret_cast<const half_t*>(p.in[0].ptr);
   const int isy = (int)p.in[0].sy, isx = (int)p.in[0].sx;
 
@@ -278,7 +279,23 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
           v[e] = acc[mt][nt][8 * pair + e];
           bias[e] = (p.bias && co + e < p.cout) ? p.bias[n * p.bias_sn + co + e] : 0.f;
         }
-        conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, s0, s1);
+        if constexpr ((ABL & 1024) != 0) {      // straight-line row (conv_common.h; the host picks the instance by conv_epilogue_fast_ok): with one wave per SIMD nothing runs beside the 16 row pieces of a tile
+          half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
+          h8 rr = {0, 0, 0, 0, 0, 0, 0, 0}, oo = {0, 0, 0, 0, 0, 0, 0, 0}, mm = {1, 1, 1, 1, 1, 1, 1, 1};
+          if (fe.has_res) rr = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
+          if (fe.has_old) oo = *reinterpret_cast<const h8*>(o);
+          if (fe.has_mask) mm = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oy * p.m_sy + ox * p.m_sx + co);
+          float brow[8];
+          if (fe.has_cb) conv_class_bias_row(p, bias, co, n, oy, ox, brow);
+          else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) brow[e] = bias[e];
+          }
+          if (fe.has_res || fe.has_old || fe.has_mask) conv_epilogue_fast_row<true, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
+          else conv_epilogue_fast_row<false, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
+        } else {
+          conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, s0, s1);
+        }
       }
     }
     ct = ctn; n = nn; Y0 = Y0n; X0 = X0n;
@@ -414,6 +431,11 @@ static int launch_x3(const ConvK& k, const X3Extra& q, unsigned g, const half_t*
   CSBSR_LAUNCH_CHECK("csbsr_conv_x3_forward");
   return 0;
 }
+// the instance with the straight-line epilogue rows where they cover the launch (template bit 1024), the general rows elsewhere
+template <int KS>
+static int launch_x3_epi(const ConvK& k, const X3Extra& q, unsigned g, const half_t* zp, hipStream_t st) {
+  return conv_epilogue_fast_ok(k) ? launch_x3<KS, 1024>(k, q, g, zp, st) : launch_x3<KS, 0>(k, q, g, zp, st);
+}
 
 extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) {
   CSBSR_CHECK(csbsr_conv_x3_eligible(d), "conv_x3: launch not eligible (see csbsr_conv_x3_eligible)");
@@ -459,6 +481,6 @@ extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
     return strided ? launch_x3<2, 32>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s))
                    : launch_x3<3, 32>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s));
 #endif
-  return strided ? launch_x3<2>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s))
-                 : launch_x3<3>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s));
+  return strided ? launch_x3_epi<2>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s))
+                 : launch_x3_epi<3>(k, q, g, g_x3_zero_page[dev], reinterpret_cast<hipStream_t>(s));
 }
