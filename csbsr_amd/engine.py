@@ -617,8 +617,11 @@ class Conv:
                      None, None, L.RES_NONE, False, stat, stat_mode, osc, cbias=cb, split_blocks=nb)
         return out
 
-    def bwd_weights_folded(self, dpre, x, saved, mtap, frozen=False):
-        """wgrad of the feature part on the MFMA, of the constant part from 16 border-class sums of dPre; returns dL/dk [B, c_const]."""
+    def bwd_weights_folded(self, dpre, x, saved, mtap, frozen=False, bias_grad=False):
+        """wgrad of the feature part on the MFMA, of the constant part from 16 border-class sums of dPre; returns dL/dk [B, c_const].
+        ``bias_grad``: the layer's bias gradient -- the sum of dPre over samples and pixels -- is the sum of the 16 class sums: callers
+        that fused this layer's activation derivative into the dgrad above it (``bwd_input(mask=)``) get it here instead of from an
+        epilogue-backward pass over the map."""
         w16c, k16 = saved
         cf = self.split[0]
         if not frozen:
@@ -626,6 +629,8 @@ class Conv:
         B = dpre.N
         sums = self.eng.f32(B, 16, dpre.cp)
         L.call("csbsr_border_class_sums", _ptr(dpre.t), dpre.ld, _ptr(sums), B, dpre.H, dpre.W, dpre.cp, self.eng.stream)
+        if bias_grad and self.b is not None and not frozen:
+            grad_acc(self.b).add_(sums.sum((0, 1))[:self.cout])
         S = torch.einsum("nabo,ay,bx->noyx", sums[:, :, :self.cout].reshape(B, 4, 4, self.cout), mtap, mtap)
         if not frozen:
             grad_acc(self.w)[:, cf:].add_(torch.einsum("noyx,nc->ocyx", S, k16))

@@ -431,9 +431,10 @@ class KBPN:
                     if dz is None:
                         dz = self._act_bwd(c1, dsc, q["sc"])
                     self._wg(c1, dz, t)
-                    dt = c1.bwd_input(dz)
-                    self._act_bwd(c0, dt, t)
-                    dvec_next = dvec_next + c0.bwd_weights_folded(dt, fpre, fold, self.Mtap, frozen=c0.frozen)
+                    # conv0's LeakyReLU derivative rides on conv1's dgrad (mask = conv0's saved output) and its bias gradient comes out of
+                    # the border-class sums the folded weight gradient takes anyway: no epilogue-backward pass over the C-channel map
+                    dt = c1.bwd_input(dz, mask=(t, c0.slope))
+                    dvec_next = dvec_next + c0.bwd_weights_folded(dt, fpre, fold, self.Mtap, frozen=c0.frozen, bias_grad=True)
                     c0.bwd_input(dt, seg=0, out=dfpre, accumulate=True)
                     del dt
                 del dsc, dlowp
