@@ -263,7 +263,8 @@ def main():
         # every launch with the kernel it dispatched to).  achieved = algorithmic FLOPs of those launches / their HIP-event time.
         names = {0: "conv_igemm_kernel<32,4,1>", 1: "conv_igemm_kernel<64,2,2>", 2: "conv_igemm_kernel<128,2,2>",
                  3: "conv_igemm_glds_kernel<128,2,2>", 4: "conv_igemm_glds_kernel<256,4,3>", 5: "conv_thin_cout_kernel",
-                 6: "conv_thin_cin_kernel", 7: "conv_igemm_glds_kernel<256,4,2,2>", 8: "conv_hr_kernel", 9: "conv_tp_kernel", 10: "conv_x3_kernel<3>", 11: "conv_thin_tp_kernel", 12: "conv_x3_kernel<2>", 13: "conv_thin_cin2_kernel", 14: "conv_igemm_glds_kernel<128,2,2,0>", 15: "conv_thin_sc_kernel"}
+                 6: "conv_thin_cin_kernel", 7: "conv_igemm_glds_kernel<256,4,2,2>", 8: "conv_hr_kernel", 9: "conv_tp_kernel", 10: "conv_x3_kernel<3>", 11: "conv_thin_tp_kernel", 12: "conv_x3_kernel<2>", 13: "conv_thin_cin2_kernel", 14: "conv_igemm_glds_kernel<128,2,2,0>", 15: "conv_thin_sc_kernel",
+                 16: "conv_thin_tpd_kernel", 17: "conv_x3_kernel<3,1024>", 18: "conv_x3_kernel<2,1024>"}
         wnames = {0: "conv_wgrad_kernel<128,128,2,2>", 1: "conv_wgrad_kernel<128,256,2,4>", 2: "conv_wgrad_kernel<64,128,2,2>",
                   3: "conv_wgrad_kernel<32,128,1,4>", 4: "conv_wgrad_thin_kernel", 5: "conv_wgrad_glds_kernel<128,128>",
                   6: "conv_wgrad_glds_kernel<128,256>", 7: "conv_wgrad_glds_kernel<256,256>", 8: "conv_wgrad_hr_kernel"}

@@ -456,7 +456,8 @@ extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   }
   const unsigned items = q.tiles_x * q.tiles_y * (unsigned)d->N * q.nct;
   const unsigned g = items < (unsigned)ncu ? items : (unsigned)ncu;
-  g_last_conv_kernel = strided ? CONVK_X3S : CONVK_X3;
+  const bool fast_rows = conv_epilogue_fast_ok(k);      // (launch_x3_epi picks the instance by the same test)
+  g_last_conv_kernel = strided ? (fast_rows ? CONVK_X3SF : CONVK_X3S) : (fast_rows ? CONVK_X3F : CONVK_X3);
 #ifdef CSBSR_X3_ABLATE
   if (!strided) {
     hipStream_t st_ = reinterpret_cast<hipStream_t>(s);

@@ -10,7 +10,8 @@ extern "C" {
 /* kernel the calling thread's last csbsr_conv_forward dispatched to -- 0/1/2 conv_igemm_kernel<32|64|128,..>, 3/4/7
  * conv_igemm_glds_kernel<128,2,2 | 256,4,3 | 256,4,2,2>, 5 conv_thin_cout_kernel, 6 conv_thin_cin_kernel,
  * 8 conv_hr_kernel, 9 conv_tp_kernel, 10 conv_x3_kernel<3>, 11 conv_thin_tp_kernel, 12 conv_x3_kernel<2>, 13 conv_thin_cin2_kernel,
- * 14 conv_igemm_glds_kernel<128,2,2,0>, 15 conv_thin_sc_kernel, 16 conv_thin_tpd_kernel (bench.py's roofline block) */
+ * 14 conv_igemm_glds_kernel<128,2,2,0>, 15 conv_thin_sc_kernel, 16 conv_thin_tpd_kernel,
+ * 17 / 18 conv_x3_kernel<3,1024> / <2,1024> (the instances with the straight-line epilogue rows) (bench.py's roofline block) */
 int32_t csbsr_debug_last_conv_kernel(void);
 /* same for csbsr_conv_wgrad: 0 conv_wgrad_kernel<128,128,2,2>, 1 <128,256,2,4>, 2 <64,128,2,2>, 3 <32,128,1,4>, 4 conv_wgrad_thin_kernel,
  * 5 / 6 / 7 conv_wgrad_glds_kernel<128,128,..> / <128,256,..> / <256,256,..> */

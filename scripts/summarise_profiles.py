@@ -47,7 +47,10 @@ def canon(name):
     m = re.search(r"conv_tp_kernelILi\d+ELb(\d)ELb(\d)ELb(\d)E", name)
     if m:
         return "conv_tp_kernel<res=%s,acc=%s,mask=%s>" % m.groups()
-    m = re.search(r"conv_x3_kernelILi(\d)E", name) or re.search(r"conv_x3_kernel<(\d)>", name)
+    m = re.search(r"conv_x3_kernelILi(\d)ELi1024E", name) or re.search(r"conv_x3_kernel<(\d), 1024>", name)
+    if m:      # the instance with the straight-line epilogue rows (csrc/conv_x3.hip)
+        return "conv_x3_kernel<%s,1024>" % m.group(1)
+    m = re.search(r"conv_x3_kernelILi(\d)E", name) or re.search(r"conv_x3_kernel<(\d)", name)
     if m:
         return "conv_x3_kernel<%s>" % m.group(1)
     for k in ("conv_wgrad_hr_kernel", "conv_wgrad_thin_kernel", "conv_wgrad_kernel", "conv_thin_cout_kernel", "conv_thin_cin2_kernel", "conv_thin_cin_kernel", "epilogue_bwd_kernel",

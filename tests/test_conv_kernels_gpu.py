@@ -669,12 +669,12 @@ def test_wide_3x3_kernel(cin, cout, H, W, mode):
             conv.invalidate()
             y = conv.fwd(to_fm(eng, x), **{k_: (to_fm(eng, v) if isinstance(v, torch.Tensor) else v) for k_, v in kw.items()})
             torch.cuda.synchronize()
-            assert (lib.csbsr_debug_last_conv_kernel() == 10) == (x3_mode == 2 and cin % 64 == 0 or x3_mode == 2 and cin == 825)
+            assert (lib.csbsr_debug_last_conv_kernel() in (10, 17)) == (x3_mode == 2 and cin % 64 == 0 or x3_mode == 2 and cin == 825)
             dx = to_fm(eng, old)
             conv.bwd_input(to_fm(eng, dpre), out=dx, accumulate=True)
             torch.cuda.synchronize()
             from csbsr_amd.engine import pad8
-            assert (lib.csbsr_debug_last_conv_kernel() == 10) == (x3_mode == 2 and pad8(cout) % 64 == 0 and pad8(cout) >= 128)
+            assert (lib.csbsr_debug_last_conv_kernel() in (10, 17)) == (x3_mode == 2 and pad8(cout) % 64 == 0 and pad8(cout) >= 128)
         finally:
             lib.csbsr_debug_set_conv_x3(1)
         outs.append((from_fm(y), from_fm(dx)))
@@ -707,7 +707,7 @@ def test_wide_3x3_kernel_with_folded_constant_segment():
             conv = Conv(eng, "l", {"l.weight": w.cuda(), "l.bias": b.cuda()}, 3, 1, 1, 1, bias=True, act=L.ACT_LRELU, slope=0.1, split=(cf, cc))
             y, _ = conv.fwd_folded(to_fm(eng, x), kv.cuda(), m.cuda())
             torch.cuda.synchronize()
-            assert (lib.csbsr_debug_last_conv_kernel() == 10) == (x3_mode == 2)
+            assert (lib.csbsr_debug_last_conv_kernel() in (10, 17)) == (x3_mode == 2)
         finally:
             lib.csbsr_debug_set_conv_x3(1)
         outs.append(from_fm(y))
@@ -799,11 +799,11 @@ def test_phase_accumulated_strided_conv(cin, cout, k, s, p, OH, OW, mode):
             conv.invalidate(); tconv.invalidate()
             y = conv.fwd(to_fm(eng, x), **{k_: (to_fm(eng, v) if isinstance(v, torch.Tensor) else v) for k_, v in kw.items()})
             torch.cuda.synchronize()
-            assert (lib.csbsr_debug_last_conv_kernel() == 12) == (x3_mode == 2 and pad8(cout) >= 72)
+            assert (lib.csbsr_debug_last_conv_kernel() in (12, 18)) == (x3_mode == 2 and pad8(cout) >= 72)
             dz = to_fm(eng, old)
             tconv.bwd_input(to_fm(eng, dpre), out=dz, accumulate=True, in_hw=(OH, OW))
             torch.cuda.synchronize()
-            assert (lib.csbsr_debug_last_conv_kernel() == 12) == (x3_mode == 2 and pad8(cout) >= 72)
+            assert (lib.csbsr_debug_last_conv_kernel() in (12, 18)) == (x3_mode == 2 and pad8(cout) >= 72)
         finally:
             lib.csbsr_debug_set_conv_x3(1)
         outs.append((from_fm(y), from_fm(dz)))
