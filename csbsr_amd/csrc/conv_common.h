@@ -348,6 +348,8 @@ int conv_thin_cin_launch(const ConvK& k, int creal, hipStream_t st);
 bool conv_thin_cin2_eligible(const ConvK& k, int creal);  // ... with a plain (optionally accumulating) epilogue: the streaming kernel
 int conv_thin_cin2_launch(const ConvK& k, int creal, hipStream_t st);
 void conv_thin_cin2_enable(int on);
+int conv_thin_cin2_dact_launch(const ConvK& k, const csbsr_conv_desc_t* d, hipStream_t st);   // + the epilogue-backward pass of the PReLU + residual layer below
+extern "C" int32_t csbsr_conv_thin_dact_eligible(const csbsr_conv_desc_t* d);
 bool conv_thin_tp_eligible(const ConvK& k, int creal, bool second_seg);   // 3-channel image into a 2x2-tap transposed conv
 int conv_thin_tp_launch(const ConvK& k, hipStream_t st);
 bool conv_thin_sc_eligible(const ConvK& k);        // 8x8 s4 / 12x12 s8 strided conv from 128 into <= 3 channels (dgrad of kb.up_conv1)

@@ -285,8 +285,15 @@ int conv_thin_cin_launch(const ConvK& k, int creal, hipStream_t st) {
 // tiles always requested (a rolling register ring refilled right after each piece is consumed), activation as max(t, t * a),
 // persistent workgroups with the tiny 3-channel halo tile double-buffered in LDS one tile ahead.
 #define TC2_D 4                              // cout tiles of old output in flight per wave
-__global__ __launch_bounds__(512, 2) void conv_thin_cin2_kernel(const ConvK p, int tiles_x, int tiles_y, int CI, int has_old) {
+// DACT: this (accumulating) dgrad completes the output gradient of a layer  out = prelu(pre) +- res  (p.mask = its saved output, p.res /
+// p.res_mode ITS residual): the unmasked total goes to x.dres as the residual's gradient, what is stored to out16 is dPre = total x
+// prelu'(mask -+ res), and the layer's PReLU-slope gradient leaves as one partial sum per workgroup -- that layer's whole
+// epilogue-backward pass (csbsr_conv_desc_t::dact_prelu / dres, as csrc/conv_tp.hip does for the 2x2-tap transposed dgrads).
+struct Cin2Dact { half_t* dres; long d_sn, d_sy, d_sx; const float* slope; float* part; };
+template <bool DACT>
+__global__ __launch_bounds__(512, DACT ? 1 : 2) void conv_thin_cin2_kernel(const ConvK p, int tiles_x, int tiles_y, int CI, int has_old, const Cin2Dact x) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RD = DACT ? 2 : TC2_D;      // cout tiles of epilogue operands in flight per wave (DACT: three operands per piece)
   const int nct = (p.cout + 31) / 32;
   half_t* sWt = reinterpret_cast<half_t*>(smem);                     // [nct*32][TK_WLD], k = tap*CI + c
   half_t* sIn = sWt + (size_t)nct * 32 * TK_WLD;                      // [2][TN_HP][8]
@@ -302,6 +309,8 @@ __global__ __launch_bounds__(512, 2) void conv_thin_cin2_kernel(const ConvK p, i
     for (int c = 0; c < CI; ++c) sWt[co * TK_WLD + tap * CI + c] = v[c];
   }
   const float aslope = p.act == CSBSR_ACT_RELU ? 0.f : (p.act == CSBSR_ACT_LRELU ? p.act_slope : 1.f);
+  const float mslope = DACT ? *x.slope : 1.f, rsign = p.res_mode == CSBSR_RES_SUB ? -1.f : 1.f;
+  float dpr = 0.f;
   const half_t* in0 = reinterpret_cast<const half_t*>(p.in[0].ptr);
   const unsigned per_img = (unsigned)(tiles_x * tiles_y), total = per_img * (unsigned)p.N;
   // halo pixel of this thread (threads < TN_HP) for a tile: one 16-byte load, out-of-image pixels zero
@@ -345,18 +354,25 @@ __global__ __launch_bounds__(512, 2) void conv_thin_cin2_kernel(const ConvK p, i
       }
     // output pointer of this lane: couts 8 hi .. of its pixel; piece (ct, pair) at + 32 ct + 16 pair (dead lanes re-read pixel 0)
     half_t* o = p.out16 + (live ? n * p.o_sn + oy * p.o_sy + ox * p.o_sx : 0) + 8 * hi;
-    h8 ring[TC2_D][2];
+    h8 ring[RD][2];
+    h8 ringm[DACT ? RD : 1][2], ringr[DACT ? RD : 1][2];
+    const half_t* mo = DACT ? p.mask + (live ? n * p.m_sn + oy * p.m_sy + ox * p.m_sx : 0) + 8 * hi : nullptr;
+    const half_t* ro = DACT ? p.res + (live ? n * p.r_sn + oy * p.r_sy + ox * p.r_sx : 0) + 8 * hi : nullptr;
+    half_t* dro = DACT ? x.dres + (live ? n * x.d_sn + oy * x.d_sy + ox * x.d_sx : 0) + 8 * hi : nullptr;
     auto piece_ok = [&](int ct, int pair) { return 32 * ct + 16 * pair + 8 * hi < p.coutp; };
     if (has_old) {
 #pragma unroll
-      for (int j = 0; j < TC2_D; ++j)
+      for (int j = 0; j < RD; ++j)
 #pragma unroll
-        for (int pair = 0; pair < 2; ++pair)
-          ring[j][pair] = *reinterpret_cast<const h8*>(o + (piece_ok(j, pair) ? 32 * j + 16 * pair : 0));
+        for (int pair = 0; pair < 2; ++pair) {
+          const int off = piece_ok(j, pair) ? 32 * j + 16 * pair : 0;
+          ring[j][pair] = *reinterpret_cast<const h8*>(o + off);
+          if constexpr (DACT) { ringm[j][pair] = *reinterpret_cast<const h8*>(mo + off); ringr[j][pair] = *reinterpret_cast<const h8*>(ro + off); }
+        }
     }
-    for (int c4 = 0; c4 < nct; c4 += TC2_D) {
+    for (int c4 = 0; c4 < nct; c4 += RD) {
 #pragma unroll
-      for (int j = 0; j < TC2_D; ++j) {
+      for (int j = 0; j < RD; ++j) {
         const int ct = c4 + j;
         const int ctc = ct < nct ? ct : nct - 1;
         const half_t* wrow = sWt + (size_t)(ctc * 32 + pix) * TK_WLD + 8 * hi;
@@ -378,20 +394,35 @@ __global__ __launch_bounds__(512, 2) void conv_thin_cin2_kernel(const ConvK p, i
             v[4 + q] = __uint_as_float(r[1]);
           }
           const h8 old = ring[j][pair];
-          // refill this ring slot with the piece TC2_D cout tiles on (clamped: harmless re-read past the last tile)
+          h8 mk = {0, 0, 0, 0, 0, 0, 0, 0}, rs = {0, 0, 0, 0, 0, 0, 0, 0};
+          if constexpr (DACT) { mk = ringm[j][pair]; rs = ringr[j][pair]; }
+          // refill this ring slot with the piece RD cout tiles on (clamped: harmless re-read past the last tile)
           if (has_old) {
-            const int ctn = ct + TC2_D;
-            ring[j][pair] = *reinterpret_cast<const h8*>(o + ((ctn < nct && piece_ok(ctn, pair)) ? 32 * ctn + 16 * pair : 0));
+            const int ctn = ct + RD;
+            const int off = (ctn < nct && piece_ok(ctn, pair)) ? 32 * ctn + 16 * pair : 0;
+            ring[j][pair] = *reinterpret_cast<const h8*>(o + off);
+            if constexpr (DACT) { ringm[j][pair] = *reinterpret_cast<const h8*>(mo + off); ringr[j][pair] = *reinterpret_cast<const h8*>(ro + off); }
           }
-          h8 hv;
+          h8 hv, hd;
+          const bool st_ok = live && ct < nct && piece_ok(ct, pair);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float tv = v[e] * p.out_scale;
             tv = fmaxf(tv, tv * aslope);
             if (has_old) tv += (float)old[e];
+            if constexpr (DACT) {
+              const float y = (float)mk[e] - rsign * (float)rs[e];      // the masking layer's activation, rebuilt from its output and residual
+              const bool pos = y > 0.f;
+              hd[e] = (half_t)(rsign * tv);                               // d(res)
+              if (st_ok && !pos) dpr += tv * y;
+              tv = pos ? tv : tv * mslope;
+            }
             hv[e] = (half_t)tv;
           }
-          if (live && ct < nct && piece_ok(ct, pair)) *reinterpret_cast<h8*>(o + 32 * ct + 16 * pair) = hv;
+          if (st_ok) {
+            *reinterpret_cast<h8*>(o + 32 * ct + 16 * pair) = hv;
+            if constexpr (DACT) *reinterpret_cast<h8*>(dro + 32 * ct + 16 * pair) = hd;
+          }
         }
       }
     }
@@ -399,6 +430,17 @@ __global__ __launch_bounds__(512, 2) void conv_thin_cin2_kernel(const ConvK p, i
     if (tid < TN_HP) *reinterpret_cast<h8*>(sIn + (buf ^ 1) * (TN_HP * 8) + tid * 8) = hnext;
     __syncthreads();
     buf ^= 1;
+  }
+  if constexpr (DACT) {      // the slope gradient: lanes, then the eight waves one after the other (fixed order), one partial per workgroup
+    __shared__ float sdp[8];
+    for (int o_ = 1; o_ < 64; o_ <<= 1) dpr += __shfl_xor(dpr, o_, 64);
+    if (lane == 0) sdp[wid] = dpr;
+    __syncthreads();
+    if (tid == 0) {
+      float a = 0.f;
+      for (int w_ = 0; w_ < 8; ++w_) a += sdp[w_];
+      x.part[blockIdx.x] = a / mslope;
+    }
   }
 }
 
@@ -413,13 +455,24 @@ bool conv_thin_cin2_eligible(const ConvK& k, int creal) {
   return true;
 }
 
+// the accumulating launch that also takes over the epilogue-backward pass of the PReLU + residual layer below (DACT above)
+extern "C" int32_t csbsr_conv_thin_dact_eligible(const csbsr_conv_desc_t* d) {
+  if (!d || !g_conv_thin2 || d->transposed || !d->mask || !d->mask_prelu || !d->dres || !d->res || d->dact_bias) return 0;
+  if (d->res_mode != CSBSR_RES_ADD && d->res_mode != CSBSR_RES_SUB) return 0;
+  if (!d->accumulate || d->act != CSBSR_ACT_NONE || d->bias || d->cbias || d->out32 || !d->out16 || d->o_lo || d->r_lo || d->stat_mode != CSBSR_STAT_NONE) return 0;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dil != 1 || d->pad != 1 || d->OH != d->H || d->OW != d->W) return 0;
+  if (d->in[1].c != 0 || d->in[0].c != 8 || d->in[0].creal < 1 || d->in[0].creal > 3 || d->in[0].sx == 0) return 0;
+  if (d->cout < 32 || d->cout > 1024 || d->coutp % 8 != 0 || d->o_sx < d->coutp || d->dr_sx < d->coutp) return 0;
+  return 1;
+}
+
 int conv_thin_cin2_launch(const ConvK& k, int creal, hipStream_t st) {
   const int tiles_x = (k.OW + TN_TW - 1) / TN_TW, tiles_y = (k.OH + TN_TH - 1) / TN_TH;
   const int nct = (k.cout + 31) / 32;
   const size_t smem = ((size_t)nct * 32 * TK_WLD + (size_t)2 * TN_HP * 8) * sizeof(half_t);
   static size_t configured = 0;
   if (smem > configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_cin2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_cin2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
       csbsr_set_error("conv(thin-in, streaming): cannot reserve %zu bytes of LDS", smem);
       return 1;
     }
@@ -427,8 +480,33 @@ int conv_thin_cin2_launch(const ConvK& k, int creal, hipStream_t st) {
   }
   const long total = (long)k.N * tiles_x * tiles_y;
   const unsigned g = (unsigned)(total < 512 ? total : 512);
-  hipLaunchKernelGGL(conv_thin_cin2_kernel, dim3(g), dim3(512), smem, st, k, tiles_x, tiles_y, creal, k.accumulate ? 1 : 0);
+  hipLaunchKernelGGL(conv_thin_cin2_kernel<false>, dim3(g), dim3(512), smem, st, k, tiles_x, tiles_y, creal, k.accumulate ? 1 : 0, Cin2Dact{});
   CSBSR_LAUNCH_CHECK("csbsr_conv_forward(thin-in, streaming)");
+  return 0;
+}
+
+int conv_thin_cin2_dact_launch(const ConvK& k, const csbsr_conv_desc_t* d, hipStream_t st) {
+  const int tiles_x = (k.OW + TN_TW - 1) / TN_TW, tiles_y = (k.OH + TN_TH - 1) / TN_TH;
+  const int nct = (k.cout + 31) / 32;
+  const size_t smem = ((size_t)nct * 32 * TK_WLD + (size_t)2 * TN_HP * 8) * sizeof(half_t);
+  static size_t configured = 0;
+  if (smem > configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_cin2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+      csbsr_set_error("conv(thin-in, streaming, dact): cannot reserve %zu bytes of LDS", smem);
+      return 1;
+    }
+    configured = smem;
+  }
+  const long total = (long)k.N * tiles_x * tiles_y;
+  const unsigned g = (unsigned)(total < 256 ? total : 256);      // one 512-thread workgroup per CU (the rings of three operands: 215 registers)
+  Cin2Dact x;
+  x.dres = reinterpret_cast<half_t*>(d->dres); x.d_sn = d->dr_sn; x.d_sy = d->dr_sy; x.d_sx = d->dr_sx;
+  x.slope = d->mask_prelu;
+  x.part = csbsr_red_scratch((long)g);
+  CSBSR_NEED_SCRATCH(x.part, "conv(thin-in, dact)");
+  hipLaunchKernelGGL(conv_thin_cin2_kernel<true>, dim3(g), dim3(512), smem, st, k, tiles_x, tiles_y, d->in[0].creal, 1, x);
+  if (d->dact_prelu) { if (int e = csbsr_sum_partials(x.part, (int)g, 1, 1, d->dact_prelu, st)) return e; }
+  CSBSR_LAUNCH_CHECK("csbsr_conv_forward(thin-in, streaming, dact)");
   return 0;
 }
 

@@ -131,6 +131,9 @@ class Engine:
         # hipFree / hipMalloc cycles.  Hence off by default.
         self.wgrad_mirror = os.environ.get("CSBSR_WGRAD_MIRROR", "1") == "1"      # see Conv._bwd_weights_impl
         self.thin_tp_fused = os.environ.get("CSBSR_KBUP_FUSED", "1") == "1"       # see Conv.bwd_thin_tp_fused (A/B timing: 0)
+        # up_conv3's epilogue-backward pass on kb.sr_reconst's dgrad (csrc/conv_thin.hip, DACT): 26 GB per step less fabric traffic, but the
+        # fused launch is no faster than the two it replaces (1065 vs 1067 ms per step, same run) -- opt-in
+        self.thin_dact = os.environ.get("CSBSR_THIN_DACT", "0") == "1"
         self.wg_stream = None
         self._wg_on = os.environ.get("CSBSR_WGRAD_STREAM", "0") == "1"
         self._ws_by_stream = {}
@@ -409,6 +412,9 @@ class Conv:
                 d.dres, d.dr_sn, d.dr_sy, d.dr_sx = _ptr(dfm.t), sn, sy, sx
             if use_tp and L.load().csbsr_conv_tp_eligible(C.byref(d)):
                 self.last_fused = True
+            elif dres is not None and self.eng.thin_dact and L.load().csbsr_conv_thin_dact_eligible(C.byref(d)):
+                self.last_fused = True      # the thin-input accumulating dgrad (csrc/conv_thin.hip, DACT): csbsr_conv_forward dispatches it
+                use_tp = False
             else:
                 d.mask, d.mask_prelu, d.dact_bias, d.dact_prelu = None, None, None, None
                 if dres is not None:

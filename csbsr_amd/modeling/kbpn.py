@@ -523,12 +523,21 @@ class KBPN:
             segs = (concat_h.slice(0, 128 * (s - 1)), q["h"]) if s > 1 else (q["h"],)
             self._wg(st.sr_reconst, dpre, segs)
             # (its gradient wrt the earlier stages' slices waits in the slot; the part wrt this stage's own h is added now)
-            st.sr_reconst.bwd_input(dpre, seg=1 if s > 1 else 0, out=dh, accumulate=True)
+            # ... and, where the thin-input kernel takes the launch, up_conv3's whole epilogue-backward pass rides on it (h = prelu(pre) + h0:
+            # the launch that completes dh writes dPre = dh x prelu'(h - h0) in its place, the unmasked total to a second buffer as dh0
+            # and the slope-gradient partials): one pass over the HR map instead of two (csrc/conv_thin.hip, DACT)
+            spare = e.new(B, H, W, 128)
+            st.sr_reconst.bwd_input(dpre, seg=1 if s > 1 else 0, out=dh, accumulate=True, dact=(st.up3, q["h"]),
+                                    dres=(q["h0"], spare, L.RES_ADD))
             del dpre, dsr_t, derr
             # ---- UpBlock backward
-            dpu = e.new(B, H, W, 128)
-            self._act_bwd(st.up3, dh, q["h"], res=q["h0"], res_mode=L.RES_ADD, dpre=dpu)
-            dh0 = dh
+            if st.sr_reconst.last_fused:
+                dpu, dh0 = dh, spare
+            else:
+                dpu = spare
+                self._act_bwd(st.up3, dh, q["h"], res=q["h0"], res_mode=L.RES_ADD, dpre=dpu)
+                dh0 = dh
+            del spare
             self._wg(st.up3, dpu, q["d"])
             dd_ = st.up3.bwd_input(dpu, in_hw=(h, w))
             del dh, dpu

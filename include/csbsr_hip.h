@@ -100,6 +100,9 @@ typedef struct {
    * its activation is rebuilt as mask -+ res, and dres (fp16 NHWC, same geometry as out16) receives d(res) = +- the unmasked result
    * (kbpn.py:254-256, DownBlock: l1 = down_conv3(h0 - x)) */
   void* dres; int64_t dr_sn, dr_sy, dr_sx;
+  /* (mask_prelu / dact_prelu / dres are also taken by csbsr_conv_forward for ONE launch shape, csbsr_conv_thin_dact_eligible: the
+   * accumulating 3x3 dgrad from a <= 3-channel image gradient that completes the output gradient of a PReLU + residual layer --
+   * kb.sr_reconst's dgrad completing up_conv3's dOut, kbpn.py:385-392,460-468: out16 (accumulate) receives dPre, dres the unmasked total) */
   /* csbsr_conv_forward only.  1: FUSED split-fp16 input -- in[0] = the [hi | lo] channel pair (2c channels, c >= 32), in[1]
    * unused, weights from csbsr_pack_weights_split layout 3 ([w_hi | w_lo] per 32-channel slice).  One staged K slice then holds 32
    * channels of x_hi and x_lo against the same 32 of w_hi and w_lo and feeds all three products (x_hi w_hi + x_lo w_hi + x_hi w_lo)
@@ -442,6 +445,8 @@ int csbsr_thin_tp_backward(const void* dout, int64_t d_sn, int64_t d_sy, int64_t
                            int64_t x_sx, const void* wt_packed, int32_t cin, int32_t cout, int32_t stride, int32_t pad,
                            const float* prelu, int32_t N, int32_t h, int32_t w, void* dpre, int64_t p_sn, int64_t p_sy, int64_t p_sx,
                            float* slabs, float* dprelu_part, csbsr_stream_t s);
+/* 1 if csbsr_conv_forward takes this launch WITH its dact / dres fields (see csbsr_conv_desc_t::dres) */
+int32_t csbsr_conv_thin_dact_eligible(const csbsr_conv_desc_t* d);
 #ifdef __cplusplus
 }
 #endif

@@ -211,6 +211,43 @@ def test_fused_backward_of_the_thin_transposed_prelu_layer(cout, h, w):
     assert e_new <= e_old + 1e-4
 
 
+@pytest.mark.parametrize("cout,H,W", [(128, 24, 40), (128, 9, 70), (64, 16, 32)])
+def test_thin_input_dgrad_with_the_layer_belows_epilogue_backward(cout, H, W):
+    """csrc/conv_thin.hip, DACT: the accumulating 3x3 dgrad from a 3-channel image gradient that completes dOut of a layer
+    out = prelu(pre) + res also writes that layer's dPre, the residual's gradient and the slope-gradient sum -- against fp64"""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv, grad_acc
+    torch.manual_seed(5)
+    eng = _eng()
+    eng.thin_dact = True
+    N = 2
+    w = (torch.randn(3, cout, 3, 3) / 5.0).half().float()           # the head conv: cout features -> 3 image channels (OIHW [3, cout])
+    a = torch.tensor([0.2])
+    dimg = torch.randn(N, 3, H, W).half().float()                     # gradient wrt the 3-channel image
+    old = torch.randn(N, cout, H, W).half().float()                   # what dOut held before this contribution
+    h0 = torch.randn(N, cout, H, W).half().float()
+    pre = torch.randn(N, cout, H, W)
+    hh = (F.prelu(pre, a) + h0).half().float()                        # the layer below's saved output
+    head = Conv(eng, "l", {"l.weight": w.cuda()}, 3, 1, 1, 1, bias=False)
+    below = Conv(eng, "b", {"b.weight": torch.zeros(8, cout, 8, 8).cuda(), "b.a": a.clone().cuda()}, 8, 4, 2, 1, transposed=True, bias=False,
+                 act=L.ACT_PRELU, prelu="b.a")
+    below.frozen = False
+    f_old, f_h, f_h0, f_d = to_fm(eng, old), to_fm(eng, hh), to_fm(eng, h0), to_fm(eng, dimg)
+    spare = eng.new(N, H, W, cout)
+    head.bwd_input(f_d, out=f_old, accumulate=True, dact=(below, f_h), dres=(f_h0, spare, L.RES_ADD))
+    torch.cuda.synchronize()
+    assert head.last_fused
+    tot = old.double() + F.conv_transpose2d(dimg.double(), w.double(), None, 1, 1)      # dgrad of conv2d(x, w[3, cout]) wrt x
+    y = hh.double() - h0.double()
+    pos = y > 0
+    ref_dpre = torch.where(pos, tot, tot * 0.2)
+    ref_da = float((tot * y / 0.2)[~pos].sum())
+    assert relmax(from_fm(f_old), ref_dpre.float()) < 2e-3
+    assert relmax(from_fm(spare), tot.float()) < 2e-3
+    got_da = float(below.prelu.gacc.cpu())
+    assert abs(got_da - ref_da) < 1e-3 * float((tot * y / 0.2)[~pos].abs().sum()) ** 0.5 + 1e-3 * abs(ref_da), (got_da, ref_da)
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(32, 32, 19, 45), (32, 32, 16, 64), (49, 32, 24, 33), (32, 49, 9, 40), (49, 49, 17, 70), (64, 64, 8, 32)])
 def test_full_resolution_thin_wgrad(cin, cout, H, W):
     """csrc/conv_wgrad_hr.hip (dPre tile + input halo tile in LDS once per 8 x 32 pixels, nine taps from the one halo, one slab per

@@ -117,3 +117,28 @@ def test_precision_plan_hooks():
     e_form, e_plan = d(outs["blocks"][0], outs["fused"][0]), d(outs["decoder2"][0], outs["fused"][0])
     print(f"split forward: three-block vs fused form {e_form:.2e}; two products in the decoder vs three {e_plan:.2e}")
     assert e_form < 5e-4 and 0.0 < e_plan < 2e-3, (e_form, e_plan)
+
+
+def test_thin_dact_launch_matches_the_separate_pass():
+    """``CSBSR_THIN_DACT=1`` (Engine.thin_dact, opt-in): kb.sr_reconst's accumulating dgrad also runs up_conv3's epilogue-backward pass
+    (csrc/conv_thin.hip, DACT) -- dPre, the residual's gradient and the PReLU-slope gradient from one launch.  Same arithmetic except that
+    the completed gradient is not rounded to fp16 between the two steps: every gradient agrees to fp16 storage noise."""
+    g = load_golden("e2e_pspnet_it40000")
+    res = {}
+    for on in (False, True):
+        m, _ = build_model(g, 8)
+        m._runtime()["eng"].thin_dact = on
+        res[on] = _step(m, g)
+        if on:
+            st = m._runtime()["kbpn"].stages[0]
+            assert st.sr_reconst.last_fused
+        del m
+    bad = []
+    for k in res[False]:
+        a, b = res[False][k].float(), res[True][k].float()
+        if a.numel() == 1:       # PReLU slopes: sums of signed terms that nearly cancel (their own check: tests/test_conv_kernels_gpu.py)
+            continue
+        e = float((a - b).abs().max() / (a.abs().max() + 1e-30))
+        if e > 2e-3:
+            bad.append((k, e))
+    assert not bad, bad[:6]
