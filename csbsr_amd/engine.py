@@ -799,7 +799,7 @@ class BatchNorm:
 
     def finalize(self, stat, count, update_running=True):
         cp = pad8(self.c)
-        mean, invstd = self.eng.f32(cp), self.eng.f32(cp)
+        mean, invstd = self.eng.f32(cp, zero=False), self.eng.f32(cp, zero=False)      # (cp == c for BatchNorm layers: csbsr_bn_finalize writes every element)
         L.call("csbsr_bn_finalize", _ptr(stat), count, self.c, cp, 1e-5, 0.1, _ptr(mean), _ptr(invstd),
                _ptr(self.rmean) if update_running else None, _ptr(self.rvar) if update_running else None, self.eng.stream)
         if update_running:
