@@ -120,6 +120,7 @@ SIGNATURES = {
     "csbsr_border_class_fill": (i32, [vp, vp, i64, i32, i32, i32, i32, vp]),
     "csbsr_border_class_fill_masked": (i32, [vp, vp, i64, vp, i64, C.c_float, i32, i32, i32, i32, vp]),
     "csbsr_border_class_sums": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
+    "csbsr_border_class_sums_prelu": (i32, [vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp]),
     "csbsr_ring_class_sums": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
     "csbsr_bn_finalize": (i32, [vp, i64, i32, i32, f32, f32, vp, vp, vp, vp, vp]),
     "csbsr_bn_apply": (i32, [C.POINTER(BnDesc), vp]),

@@ -35,6 +35,7 @@ struct ConvK {
   // (mask > 0 ? 1 : mask_slope), mask = the saved forward output of the layer whose input gradient this launch produces --
   // i.e. dPre of that layer leaves this kernel directly and the stand-alone epilogue-backward pass is skipped
   const half_t* mask; long m_sn, m_sy, m_sx; float mask_slope;
+  const float* mask_prelu;   // the masking layer's PReLU slope on the device (overrides mask_slope): csbsr_conv_desc_t::mask_prelu
   // fused statistics, order-fixed: every workgroup writes ITS sums as one partial row stat_part[(phase * tiles_m + tile_m) * stat_ld + ...]
   // ([sum | sumsq] for CSBSR_STAT_BN, [sum] for CSBSR_STAT_SAMPLE_SUM); the launcher folds the rows into ``stat`` with
   // csbsr_sum_partials* (no atomics: two runs are bit-identical).  hw_pad > 0: the linear pixel index is laid out per sample,
@@ -139,8 +140,9 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
     }
     if (p.mask) {
       const h8 mk = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oy * p.m_sy + ox * p.m_sx + co);
+      const float ms_ = p.mask_prelu ? *p.mask_prelu : p.mask_slope;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= ((float)mk[e] > 0.f ? 1.f : p.mask_slope);
+      for (int e = 0; e < 8; ++e) v[e] *= ((float)mk[e] > 0.f ? 1.f : ms_);
     }
     split_store(o, p.o_lo, v);
   }
@@ -175,7 +177,7 @@ __device__ __forceinline__ EpiFast conv_epilogue_fast_setup(const ConvK& p, floa
   f.sneg = p.act == CSBSR_ACT_NONE ? 1.f : (p.act == CSBSR_ACT_RELU ? 0.f : slope);
   f.rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
   f.has_res = p.res_mode != CSBSR_RES_NONE; f.has_old = p.accumulate != 0; f.bn = p.stat_mode == CSBSR_STAT_BN;
-  f.has_mask = p.mask != nullptr; f.mslope = p.mask_slope;
+  f.has_mask = p.mask != nullptr; f.mslope = (p.mask && p.mask_prelu) ? *p.mask_prelu : p.mask_slope;
   f.masked = (p.cout & 7) != 0;      // the last channel octet is partly padding: those lanes are forced to zero (one branch per row)
   f.osc = p.out_scale; f.cout = p.cout;
   return f;

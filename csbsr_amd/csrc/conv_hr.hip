@@ -395,7 +395,7 @@ extern "C" int32_t csbsr_conv_hr_eligible(const csbsr_conv_desc_t* d) {
   if (d->in[1].c != 0 || d->in[0].sx == 0 || (d->in[0].c != 32 && d->in[0].c != 56)) return 0;
   if ((d->coutp > 64 && d->coutp != 128) || d->OH != d->H || d->OW != d->W) return 0;
   if (d->coutp == 128 && (d->stat_mode != CSBSR_STAT_NONE || d->mask)) return 0;      // 128 couts: the plain variant only
-  if (d->bias || d->res_mode != CSBSR_RES_NONE || d->accumulate || d->out32 || d->o_lo) return 0;
+  if (d->bias || d->res_mode != CSBSR_RES_NONE || d->accumulate || d->out32 || d->o_lo || d->mask_prelu) return 0;
   // a position-class bias: the two-ring table on the plain 1x1 variant with one cout tile (fe_cat.0 with its folded kernel branch)
   if (d->cbias && !(d->cbias_mode == 1 && d->KH == 1 && d->coutp <= 32 && d->stat_mode == CSBSR_STAT_NONE && !d->mask && d->H >= 5 && d->W >= 5)) return 0;
   if (d->act != CSBSR_ACT_NONE && d->act != CSBSR_ACT_RELU && d->act != CSBSR_ACT_LRELU) return 0;

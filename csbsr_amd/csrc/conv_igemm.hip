@@ -442,9 +442,11 @@ int conv_desc_to_k(const csbsr_conv_desc_t* d, ConvK& k) {
   k.out_scale = d->out_scale;
   k.o_lo = d->o_lo; k.r_lo = d->r_lo; k.r2_lo = d->r2_lo;
   k.mask = reinterpret_cast<const half_t*>(d->mask); k.m_sn = d->m_sn; k.m_sy = d->m_sy; k.m_sx = d->m_sx; k.mask_slope = d->mask_slope;
+  k.mask_prelu = d->mask_prelu;
+  CSBSR_CHECK(!d->mask_prelu || d->mask, "conv: mask_prelu without a mask");
   CSBSR_CHECK(!d->mask || (d->out16 && !d->o_lo), "conv: the activation mask applies to a plain fp16 output");
-  CSBSR_CHECK((!d->mask_prelu && !d->dact_bias && !d->dact_prelu && !d->dres) || csbsr_conv_thin_dact_eligible(d),
-              "conv: mask_prelu / dact_* / dres: csbsr_conv_tp_forward, or the thin-input accumulating dgrad (csbsr_conv_thin_dact_eligible)");
+  CSBSR_CHECK((!d->dact_bias && !d->dact_prelu && !d->dres) || csbsr_conv_thin_dact_eligible(d),
+              "conv: dact_* / dres: csbsr_conv_tp_forward, or the thin-input accumulating dgrad (csbsr_conv_thin_dact_eligible)");
   CSBSR_CHECK(!(d->o_lo && d->accumulate), "conv: a split (hi + lo) output cannot accumulate");
   CSBSR_CHECK(!d->o_lo || d->out16, "conv: o_lo without out16");
   k.tile2d = 0; k.nphase_flat = 0; k.tap_group = 0;
@@ -471,7 +473,7 @@ extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) 
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   const bool split_io = d->o_lo || d->r_lo || d->r2_lo || d->mask;     // the thin kernels have their own epilogues: plain fp16, no mask
-  if (d->dres || d->dact_prelu || d->dact_bias || d->mask_prelu) {      // a launch that takes over the layer below's epilogue-backward pass: only the kernels built for it
+  if (d->dres || d->dact_prelu || d->dact_bias) {      // a launch that takes over the layer below's epilogue-backward pass: only the kernels built for it
     CSBSR_CHECK(csbsr_conv_thin_dact_eligible(d), "conv: dact / dres launch not eligible here (csbsr_conv_tp_forward or the thin-input accumulating dgrad)");
     g_last_conv_kernel = CONVK_THIN_CIN2;
     return conv_thin_cin2_dact_launch(k, d, st);

@@ -414,7 +414,7 @@ extern "C" int32_t csbsr_conv_x3_eligible(const csbsr_conv_desc_t* d) {
   if (d->in[1].c != 0 || d->in[0].sx == 0) return 0;
   if (d->coutp < 72 || !d->out16 || d->out32 || d->o_lo || d->r_lo || d->r2_lo) return 0;
   if (d->stat_mode != CSBSR_STAT_NONE) return 0;
-  if (d->mask_prelu || d->dact_bias || d->dact_prelu || d->dres) return 0;
+  if (d->dact_bias || d->dact_prelu || d->dres) return 0;
   if (d->in[0].sy >= (1l << 31) / 2 / (strided ? 4 * (X3_TH + 1) : 1)) return 0;
   if (g_conv_x3_mode == 1 && (long)d->N * d->OH * d->OW * ((d->coutp + 127) / 128) < 512L * X3_TH * X3_TW) return 0;
   return 1;

@@ -1412,8 +1412,12 @@ extern "C" int csbsr_border_class_fill_masked(const float* V, void* out, int64_t
 }
 // fast path for real image sizes: (1) plain total over all pixels, (2) the O(perimeter) border pixels binned per class in LDS by one
 // workgroup per (sample, edge), (3) interior = total - sum of the border classes.  No contended global atomics.
-__global__ __launch_bounds__(256) void bcs_total_kernel(const half_t* x, long ld, float* sums, long hw, int c8, int chunks, float* part) {
-  __shared__ float sred[256][8];
+// T: also the per-channel sums of x * t over the pixels with t <= 0 (t = a second map of the same geometry) into part2 -- the PReLU-slope
+// gradient of a layer whose saved output is t and whose dPre is x (csbsr_border_class_sums_prelu)
+template <bool T>
+__global__ __launch_bounds__(256) void bcs_total_kernel(const half_t* x, long ld, float* sums, long hw, int c8, int chunks, float* part,
+                                                        const half_t* t = nullptr, long t_ld = 0, float* part2 = nullptr) {
+  __shared__ float sred[256][T ? 16 : 8];
   const int n = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
   const int cpb = c8 < 256 ? c8 : 256, ppb = 256 / cpb;
   const int ch = threadIdx.x % cpb, pl = threadIdx.x / cpb;
@@ -1421,24 +1425,36 @@ __global__ __launch_bounds__(256) void bcs_total_kernel(const half_t* x, long ld
   const long beg = chunk * per, end = beg + per < hw ? beg + per : hw;
   for (int cbase = 0; cbase < c8; cbase += cpb) {
     const int cc = cbase + ch;
-    float a[8];
+    float a[8], b[T ? 8 : 1];
 #pragma unroll
     for (int e = 0; e < 8; ++e) a[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < (T ? 8 : 1); ++e) b[e] = 0.f;
     if (cc < c8 && pl < ppb)
       for (long px = beg + pl; px < end; px += ppb) {
         const h8 v = *reinterpret_cast<const h8*>(x + ((long)n * hw + px) * ld + cc * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+        if constexpr (T) {
+          const h8 tv = *reinterpret_cast<const h8*>(t + ((long)n * hw + px) * t_ld + cc * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) b[e] += (float)tv[e] > 0.f ? 0.f : (float)v[e] * (float)tv[e];
+        }
       }
 #pragma unroll
     for (int e = 0; e < 8; ++e) sred[threadIdx.x][e] = a[e];
+    if constexpr (T) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sred[threadIdx.x][8 + e] = b[e];
+    }
     __syncthreads();
     if (threadIdx.x < cpb && cbase + threadIdx.x < c8) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
+      for (int e = 0; e < (T ? 16 : 8); ++e) {
         float s_ = 0.f;
         for (int q = 0; q < ppb; ++q) s_ += sred[q * cpb + threadIdx.x][e];
-        part[(long)blockIdx.x * c8 * 8 + (cbase + threadIdx.x) * 8 + e] = s_;      // row per (sample, chunk): folded by csbsr_sum_partials
+        if (e < 8) part[(long)blockIdx.x * c8 * 8 + (cbase + threadIdx.x) * 8 + e] = s_;      // row per (sample, chunk): folded by csbsr_sum_partials
+        else part2[(long)blockIdx.x * c8 * 8 + (cbase + threadIdx.x) * 8 + (e - 8)] = s_;
       }
     }
     __syncthreads();
@@ -1519,8 +1535,10 @@ __global__ void bcs_fixup_kernel(float* sums, int N, int c) {
   for (int k = 1; k < 16; ++k) border += s_[(long)k * c];
   s_[0] -= border;
 }
-extern "C" int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
+static int border_class_sums_impl(const void* x, int64_t ld, float* sums, int32_t N, int32_t H, int32_t W, int32_t c, const void* t, int64_t t_ld,
+                                  float* negdot, csbsr_stream_t s) {
   CSBSR_CHECK(x && sums && c % 8 == 0, "border_class_sums: bad args");
+  CSBSR_CHECK(!t || (negdot && H >= 3 && W >= 3 && (long)H * W >= 1024), "border_class_sums_prelu: maps of >= 1024 pixels, negdot required");
   if (H >= 3 && W >= 3 && (long)H * W >= 1024) {
     // (1) plain total over all pixels, (2) the O(perimeter) border pixels binned per class by one workgroup per (sample, edge, segment),
     // (3) interior = total - sum of the border classes.  Every stage is a fixed-order fold of partial rows.
@@ -1528,9 +1546,17 @@ extern "C" int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, i
     int chunks = (int)((hw + 511) / 512);     // >= 392 workgroups at LR 448^2: the 4096-pixel chunks left 4/5 of the CUs idle
     if (chunks > 2048) chunks = 2048;
     const long n_tot = (long)N * chunks * c, n_edge = (long)N * 4 * BCS_SEG * 3 * c;
-    float* part = csbsr_red_scratch(n_tot + n_edge);
+    float* part = csbsr_red_scratch(n_tot + n_edge + (t ? n_tot : 0));
     CSBSR_NEED_SCRATCH(part, "border_class_sums");
-    hipLaunchKernelGGL(bcs_total_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks, part);
+    if (t) {
+      float* part2 = part + n_tot + n_edge;
+      hipLaunchKernelGGL(bcs_total_kernel<true>, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks, part,
+                         (const half_t*)t, (long)t_ld, part2);
+      if (csbsr_sum_partials_batched(part2, chunks, c, c, negdot, N, (long)c, ST(s))) return 1;
+    } else {
+      hipLaunchKernelGGL(bcs_total_kernel<false>, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks, part,
+                         (const half_t*)nullptr, 0l, (float*)nullptr);
+    }
     if (csbsr_sum_partials_batched(part, chunks, c, c, sums, N, 16l * c, ST(s))) return 1;
     float* epart = part + n_tot;
     hipLaunchKernelGGL(bcs_edges_kernel, dim3(N * 4 * ((c / 8 + 31) / 32) * BCS_SEG), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, epart, H, W, c / 8);
@@ -1542,6 +1568,14 @@ extern "C" int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, i
   hipLaunchKernelGGL(border_class_sums_small_kernel, dim3(N), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, H, W, c / 8);
   CSBSR_LAUNCH_CHECK("csbsr_border_class_sums");
   return 0;
+}
+extern "C" int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, int32_t N, int32_t H, int32_t W, int32_t c, csbsr_stream_t s) {
+  return border_class_sums_impl(x, ld, sums, N, H, W, c, nullptr, 0, nullptr, s);
+}
+extern "C" int csbsr_border_class_sums_prelu(const void* x, int64_t ld, const void* t, int64_t t_ld, float* sums, float* negdot, int32_t N, int32_t H,
+                                             int32_t W, int32_t c, csbsr_stream_t s) {
+  CSBSR_CHECK(t && negdot, "border_class_sums_prelu: null pointer");
+  return border_class_sums_impl(x, ld, sums, N, H, W, c, t, t_ld, negdot, s);
 }
 
 // ---- two-ring classes (csbsr_ring_class_sums): class = ty * 5 + tx, t = 0, 1, 2, 3, 4 for coordinate 0, 1, interior, size-2, size-1.
@@ -1625,7 +1659,8 @@ extern "C" int csbsr_ring_class_sums(const void* x, int64_t ld, float* sums, int
   const long n_tot = (long)N * chunks * c, n_line = (long)N * 8 * BCS_SEG * 5 * c;
   float* part = csbsr_red_scratch(n_tot + n_line);
   CSBSR_NEED_SCRATCH(part, "ring_class_sums");
-  hipLaunchKernelGGL(bcs_total_kernel, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks, part);
+  hipLaunchKernelGGL(bcs_total_kernel<false>, dim3(N * chunks), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, sums, hw, c / 8, chunks, part,
+                     (const half_t*)nullptr, 0l, (float*)nullptr);
   if (csbsr_sum_partials_batched(part, chunks, c, c, sums + 12l * c, N, 25l * c, ST(s))) return 1;      // the total lands in the interior class
   float* lpart = part + n_tot;
   hipLaunchKernelGGL(rcs_lines_kernel, dim3(N * 8 * ((c / 8 + 31) / 32) * BCS_SEG), dim3(256), 0, ST(s), (const half_t*)x, (long)ld, lpart, H, W, c / 8);

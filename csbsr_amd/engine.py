@@ -134,6 +134,7 @@ class Engine:
         # up_conv3's epilogue-backward pass on kb.sr_reconst's dgrad (csrc/conv_thin.hip, DACT): 26 GB per step less fabric traffic, but the
         # fused launch is no faster than the two it replaces (1065 vs 1067 ms per step, same run) -- opt-in
         self.thin_dact = os.environ.get("CSBSR_THIN_DACT", "0") == "1"
+        self.fold_prelu = os.environ.get("CSBSR_FOLD_PRELU", "1") == "1"        # pspnet.py _blur_skip_bwd (A/B timing: 0)
         self.wg_stream = None
         self._wg_on = os.environ.get("CSBSR_WGRAD_STREAM", "0") == "1"
         self._ws_by_stream = {}
@@ -391,7 +392,10 @@ class Conv:
             mfm, mslope = mask
             assert out is not None and mfm.cp == d.coutp and (mfm.H, mfm.W) == (OH, OW) and not mfm.bcast
             sn, sy, sx = mfm.strides()
-            d.mask, d.m_sn, d.m_sy, d.m_sx, d.mask_slope = _ptr(mfm.t), sn, sy, sx, float(mslope)
+            if torch.is_tensor(mslope):      # a learned PReLU slope: read on the device (csbsr_conv_desc_t::mask_prelu)
+                d.mask, d.m_sn, d.m_sy, d.m_sx, d.mask_slope, d.mask_prelu = _ptr(mfm.t), sn, sy, sx, 0.0, _ptr(mslope)
+            else:
+                d.mask, d.m_sn, d.m_sy, d.m_sx, d.mask_slope = _ptr(mfm.t), sn, sy, sx, float(mslope)
         self.last_fused = False
         use_tp = tp is not None and self.eng.use_tp
         if dact is not None:
@@ -623,18 +627,25 @@ class Conv:
                      None, None, L.RES_NONE, False, stat, stat_mode, osc, cbias=cb, split_blocks=nb)
         return out
 
-    def bwd_weights_folded(self, dpre, x, saved, mtap, frozen=False, bias_grad=False):
+    def bwd_weights_folded(self, dpre, x, saved, mtap, frozen=False, bias_grad=False, prelu_out=None):
         """wgrad of the feature part on the MFMA, of the constant part from 16 border-class sums of dPre; returns dL/dk [B, c_const].
         ``bias_grad``: the layer's bias gradient -- the sum of dPre over samples and pixels -- is the sum of the 16 class sums: callers
         that fused this layer's activation derivative into the dgrad above it (``bwd_input(mask=)``) get it here instead of from an
-        epilogue-backward pass over the map."""
+        epilogue-backward pass over the map.  ``prelu_out``: this (PReLU) layer's saved output -- its slope gradient is taken in the same pass."""
         w16c, k16 = saved
         cf = self.split[0]
         if not frozen:
             self.bwd_weights(dpre, x, split_override=(cf, 0))
         B = dpre.N
         sums = self.eng.f32(B, 16, dpre.cp)
-        L.call("csbsr_border_class_sums", _ptr(dpre.t), dpre.ld, _ptr(sums), B, dpre.H, dpre.W, dpre.cp, self.eng.stream)
+        if prelu_out is not None and self.prelu is not None and not frozen:
+            # a PReLU layer: the slope gradient sum_{pre <= 0} dOut * pre = sum_{out <= 0} dPre * out / slope^2 comes out of the same pass
+            negdot = self.eng.f32(B, dpre.cp)
+            L.call("csbsr_border_class_sums_prelu", _ptr(dpre.t), dpre.ld, _ptr(prelu_out.t), prelu_out.ld, _ptr(sums), _ptr(negdot), B, dpre.H,
+                   dpre.W, dpre.cp, self.eng.stream)
+            grad_acc(self.prelu).add_((negdot[:, :self.cout].sum() / (self.prelu.detach() * self.prelu.detach())).reshape(self.prelu.shape))
+        else:
+            L.call("csbsr_border_class_sums", _ptr(dpre.t), dpre.ld, _ptr(sums), B, dpre.H, dpre.W, dpre.cp, self.eng.stream)
         if bias_grad and self.b is not None and not frozen:
             grad_acc(self.b).add_(sums.sum((0, 1))[:self.cout])
         S = torch.einsum("nabo,ay,bx->noyx", sums[:, :, :self.cout].reshape(B, 4, 4, self.cout), mtap, mtap)

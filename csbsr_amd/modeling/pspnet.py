@@ -249,9 +249,16 @@ class PSPNet:
                 if dz is None:
                     dz = act_bwd(c1, dsc, sc)
                 c1.bwd_weights(dz, t)
-                dt = c1.bwd_input(dz)
-                act_bwd(c0, dt, t)
-                c0.bwd_weights_folded(dt, q, fold, self.Mtap)
+                if t.H * t.W >= 1024 and e.fold_prelu:
+                    # conv0's PReLU derivative rides on conv1's dgrad (mask = conv0's saved output, slope read on the device); its bias
+                    # gradient is the sum of the border-class sums the folded weight gradient takes anyway, its slope gradient comes out
+                    # of the same pass over (dPre, t): no epilogue-backward pass over the 505-channel HR map (8.5 ms each at B = 4)
+                    dt = c1.bwd_input(dz, mask=(t, c0.prelu))
+                    c0.bwd_weights_folded(dt, q, fold, self.Mtap, bias_grad=True, prelu_out=t)
+                else:
+                    dt = c1.bwd_input(dz)
+                    act_bwd(c0, dt, t)
+                    c0.bwd_weights_folded(dt, q, fold, self.Mtap)
                 if need_dq:
                     c0.bwd_input(dt, seg=0, out=dq, accumulate=True)
                 del dt

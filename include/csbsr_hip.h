@@ -91,7 +91,8 @@ typedef struct {
   int32_t cbias_mode;      /* classes of cbias: 0 = the 16 border classes (y==0)*8 + (y==OH-1)*4 + (x==0)*2 + (x==OW-1);
                               1 = the 25 two-ring classes ty*5 + tx, t = 0,1,2,3,4 for coordinate 0, 1, interior, size-2, size-1
                               (needs OH, OW >= 5): what a map takes after TWO zero-padded 3x3 convs of a constant */
-  /* csbsr_conv_tp_forward only (NULL elsewhere): the masking layer's PReLU slope on the device (overrides mask_slope), and where its
+  /* mask_prelu: the masking layer's PReLU slope on the device (overrides mask_slope; every kernel that takes a mask except csbsr_conv_hr_forward).
+   * csbsr_conv_tp_forward only (NULL elsewhere): where the masking layer's
    * bias / PReLU-slope gradients go -- dact_bias[c] += sum over pixels of the masked result, dact_prelu[0] += sum over the pixels
    * with mask <= 0 of (unmasked result) x mask / slope, i.e. exactly what csbsr_epilogue_backward adds for that layer
    * (kbpn.py:230-262: the PReLU of a DeconvBlock / ConvBlock whose input gradient this launch completes) */
@@ -327,6 +328,11 @@ int csbsr_border_class_fill_masked(const float* V, void* out, int64_t ld, const 
                                    int32_t H, int32_t W, int32_t c, csbsr_stream_t s);
 int csbsr_border_class_sums(const void* x, int64_t ld, float* sums, int32_t N, int32_t H, int32_t W, int32_t c,
                             csbsr_stream_t s);
+/* the same plus negdot[n][ch] += sum over the pixels with t <= 0 of x * t (t: a second fp16 map of the same geometry): with x = dPre and
+ * t = the saved output of a PReLU layer, sum(negdot) / slope^2 is that layer's slope gradient (blocks.py:105-120, the SFTLikeBlock's
+ * conv_scale.0 / conv_shift.0 whose activation derivative rode on the dgrad above as csbsr_conv_desc_t::mask + mask_prelu).  Maps of >= 1024 pixels. */
+int csbsr_border_class_sums_prelu(const void* x, int64_t ld, const void* t, int64_t t_ld, float* sums, float* negdot, int32_t N, int32_t H,
+                                  int32_t W, int32_t c, csbsr_stream_t s);
 /* Two 3x3 convs deep (fe_kernel.0 -> fe_kernel.1 on the expanded kernel code, kbpn.py:565-569) the map takes one value per
  * two-ring class ty*5 + tx (conv desc cbias_mode 1): the whole branch is a [N][25][c] table and never exists as a map.  Adjoint of
  * adding such a table: sums[n][class][:] += sum over the pixels of that class of x[n,y,x,:]  (fp32 [N][25][c], H, W >= 5). */

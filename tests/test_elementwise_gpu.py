@@ -387,6 +387,27 @@ def test_border_class_fill_and_sums(shape):
     assert relmax(sums.cpu(), ref_s) < 2e-4
 
 
+@pytest.mark.parametrize("shape", [(1, 70, 66, 32), (3, 64, 64, 136), (2, 130, 40, 8)])
+def test_border_class_sums_with_the_prelu_slope_term(shape):
+    """csbsr_border_class_sums_prelu: the class sums of dPre plus, per channel, the sum of dPre * out over the pixels with out <= 0 --
+    sum / slope^2 is the PReLU-slope gradient of the layer whose activation derivative rode on the dgrad above as a mask"""
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    N, H, W, Cc = shape
+    torch.manual_seed(10)
+    x, t = r16(torch.randn(N, Cc, H, W)), r16(torch.randn(N, Cc, H, W))
+    fx, ft = to_fm(x), to_fm(t)
+    sums = torch.zeros(N, 16, fx.cp, device="cuda")
+    neg = torch.zeros(N, fx.cp, device="cuda")
+    L.call("csbsr_border_class_sums_prelu", P(fx.t), fx.ld, P(ft.t), ft.ld, P(sums), P(neg), N, H, W, fx.cp, eng.stream)
+    plain = torch.zeros(N, 16, fx.cp, device="cuda")
+    L.call("csbsr_border_class_sums", P(fx.t), fx.ld, P(plain), N, H, W, fx.cp, eng.stream)
+    torch.cuda.synchronize()
+    assert torch.equal(sums, plain)
+    ref = (x * t * (t <= 0)).double().sum((2, 3)).float()
+    assert relmax(neg[:, :Cc].cpu(), ref) < 2e-4
+
+
 @pytest.mark.parametrize("shape", [(2, 5, 5, 8), (2, 9, 11, 24), (1, 70, 66, 32), (3, 64, 64, 136)])
 def test_ring_class_sums(shape):
     """the 25 two-ring class sums (adjoint of a per-class bias table with conv desc cbias_mode 1) vs a one-hot einsum, and twice: the
