@@ -293,6 +293,21 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
           }
           if (fe.has_res || fe.has_old || fe.has_mask) conv_epilogue_fast_row<true, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
           else conv_epilogue_fast_row<false, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
+        } else if constexpr ((ABL & 2048) != 0) {
+          // the SFT conv1's (kbpn.py:505-516): bias + sigmoid (the scale branch) or bias + res x res2 (the shift branch, whose epilogue
+          // finishes the layer: f x scale + shift) -- plain fp16 output, nothing else (x3_sft_rows_ok on the host)
+          half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
+          h8 hv;
+          if (p.act == CSBSR_ACT_SIGMOID) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = (half_t)(co + e < p.cout ? 1.f / (1.f + __expf(-(v[e] * p.out_scale + bias[e]))) : 0.f);
+          } else {
+            const h8 r1 = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
+            const h8 r2 = *reinterpret_cast<const h8*>(p.res2 + n * p.r2_sn + oy * p.r2_sy + ox * p.r2_sx + co);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = (half_t)((co + e < p.cout ? v[e] * p.out_scale + bias[e] : 0.f) + (float)r1[e] * (float)r2[e]);
+          }
+          *reinterpret_cast<h8*>(o) = hv;
         } else {
           conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, s0, s1);
         }
@@ -432,9 +447,17 @@ static int launch_x3(const ConvK& k, const X3Extra& q, unsigned g, const half_t*
   return 0;
 }
 // the instance with the straight-line epilogue rows where they cover the launch (template bit 1024), the general rows elsewhere
+// the SFT conv1 epilogues: sigmoid, or no activation with the FMA residual; nothing else fused
+static bool x3_sft_rows_ok(const ConvK& k) {
+  const bool sig = k.act == CSBSR_ACT_SIGMOID && k.res_mode == CSBSR_RES_NONE;
+  const bool fma = k.act == CSBSR_ACT_NONE && k.res_mode == CSBSR_RES_FMA && k.res && k.res2 && !k.r_lo && !k.r2_lo;
+  return (sig || fma) && k.out16 && !k.out32 && !k.o_lo && !k.cbias && !k.mask && !k.accumulate && k.stat_mode == CSBSR_STAT_NONE;
+}
 template <int KS>
 static int launch_x3_epi(const ConvK& k, const X3Extra& q, unsigned g, const half_t* zp, hipStream_t st) {
-  return conv_epilogue_fast_ok(k) ? launch_x3<KS, 1024>(k, q, g, zp, st) : launch_x3<KS, 0>(k, q, g, zp, st);
+  if (conv_epilogue_fast_ok(k)) return launch_x3<KS, 1024>(k, q, g, zp, st);
+  if (KS == 3 && x3_sft_rows_ok(k)) return launch_x3<3, 2048>(k, q, g, zp, st);
+  return launch_x3<KS, 0>(k, q, g, zp, st);
 }
 
 extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) {

@@ -47,6 +47,9 @@ def canon(name):
     m = re.search(r"conv_tp_kernelILi\d+ELb(\d)ELb(\d)ELb(\d)E", name)
     if m:
         return "conv_tp_kernel<res=%s,acc=%s,mask=%s>" % m.groups()
+    m = re.search(r"conv_x3_kernelILi(\d)ELi2048E", name) or re.search(r"conv_x3_kernel<(\d), 2048>", name)
+    if m:      # the instance with the SFT conv1 rows (sigmoid / bias + res x res2): bench.py counts it with the general-row instance
+        return "conv_x3_kernel<%s>" % m.group(1)
     m = re.search(r"conv_x3_kernelILi(\d)ELi1024E", name) or re.search(r"conv_x3_kernel<(\d), 1024>", name)
     if m:      # the instance with the straight-line epilogue rows (csrc/conv_x3.hip)
         return "conv_x3_kernel<%s,1024>" % m.group(1)
