@@ -267,7 +267,8 @@ def main():
                  16: "conv_thin_tpd_kernel", 17: "conv_x3_kernel<3,1024>", 18: "conv_x3_kernel<2,1024>"}
         wnames = {0: "conv_wgrad_kernel<128,128,2,2>", 1: "conv_wgrad_kernel<128,256,2,4>", 2: "conv_wgrad_kernel<64,128,2,2>",
                   3: "conv_wgrad_kernel<32,128,1,4>", 4: "conv_wgrad_thin_kernel", 5: "conv_wgrad_glds_kernel<128,128>",
-                  6: "conv_wgrad_glds_kernel<128,256>", 7: "conv_wgrad_glds_kernel<256,256>", 8: "conv_wgrad_hr_kernel"}
+                  6: "conv_wgrad_glds_kernel<128,256>", 7: "conv_wgrad_glds_kernel<256,256>", 8: "conv_wgrad_hr_kernel",
+                  9: "conv_wgrad_glds_kernel<128,512>"}
         per = {}
         for t in timing_log:
             key = names.get(t[7], "conv?") if t[0] == "conv" else wnames.get(t[7] if len(t) > 7 else -1, "conv_wgrad?")

@@ -255,7 +255,7 @@ extern "C" void csbsr_debug_set_wgrad_tr(int v) {
   // hardware-transpose read; bits 8..9: LDS-DMA tile menu (256: no 256 x 256 tile, 512: no 128 x 256 tile); bit 10: LDS-DMA kernel only where the
   // 256-row tile applies (register-staged elsewhere: the default until the DMA pieces became inline assembly); bit 21: square tiles
   // for the tap-permuted 8x8 stride-4 layers; bit 22: linear 64-pixel stages (no 2-D stage rectangles)
-  g_wgrad_glds = ((v & 128) || !(v & 1)) ? 0 : (1 | ((v & 256) ? 0 : 2) | ((v & 512) ? 4 : 0) | ((v & 1024) ? 0 : 8) | ((v & (1 << 21)) ? 0 : 64) | ((v & (1 << 22)) ? 0 : 128));
+  g_wgrad_glds = ((v & 128) || !(v & 1)) ? 0 : (1 | ((v & 256) ? 0 : 2) | ((v & 512) ? 4 : 0) | ((v & 1024) ? 0 : 8) | ((v & (1 << 21)) ? 0 : 64) | ((v & (1 << 22)) ? 0 : 128) | ((v & (1 << 23)) ? 0 : 256));
   g_wgrad_extra_lds = ((v >> 12) & 0xff) * 1024;
 }
 
@@ -398,6 +398,7 @@ static int wgrad_tile_n(int ca, int ktot, bool perm8) { return (g_wgrad_wide && 
 static int32_t wgrad_splits_impl(int32_t ca, int32_t ktot, int64_t M, bool perm8) {
   int BA, BN;
   wgrad_tiles(ca, ktot, perm8, BA, BN);
+  if (perm8 && (g_wgrad_glds & 256) && ktot == 8192 && ca == 128) BN = 512;      // (the experimental four-tap tile: 16 tiles)
   const long ntile = (long)((ca + BA - 1) / BA) * ((ktot + BN - 1) / BN);
   long want = (1536 + ntile - 1) / ntile;
   long maxs = (M + WG_BP * 8 - 1) / (WG_BP * 8);
@@ -507,7 +508,7 @@ extern "C" int csbsr_conv_wgrad(const csbsr_wgrad_desc_t* d, csbsr_stream_t s) {
   const bool glds_all = wgrad_glds_eligible(k) && (g_wgrad_glds & 8);
   if (wgrad_glds_eligible(k) && (glds_all || wgrad_glds_tile_a(k) == 256)) {
     const int ta = wgrad_glds_tile_a(k), tn = wgrad_glds_tile_n(k);
-    g_last_wgrad_kernel = ta == 256 ? 7 : (tn == 256 ? 6 : 5);
+    g_last_wgrad_kernel = ta == 256 ? 7 : (tn == 512 ? 9 : (tn == 256 ? 6 : 5));
     k.ca_real = 0;
     if (ta != 256) {
       wgrad_locality(k, ta, tn, d->splits);

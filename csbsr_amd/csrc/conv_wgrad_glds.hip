@@ -24,8 +24,8 @@
 #include "conv_wgrad.h"
 #include <type_traits>
 
-int g_wgrad_glds = 203;    // bit 0 kernel enabled, bit 1 256 x 256 tile, bit 2 no 128 x 256 tile, bit 3 every eligible problem, bit 6 128 x 256 tap-pair
-                           // tiles for the 8x8 stride-4 layers, bit 7 2-D stage rectangles (csbsr_debug_set_wgrad_tr)
+int g_wgrad_glds = 459;    // bit 0 kernel enabled, bit 1 256 x 256 tile, bit 2 no 128 x 256 tile, bit 3 every eligible problem, bit 6 128 x 256 tap-pair
+                           // tiles for the 8x8 stride-4 layers, bit 7 2-D stage rectangles, bit 8 128 x 512 four-tap tiles for those layers (csbsr_debug_set_wgrad_tr)
 
 // One LDS-DMA piece (64 lanes x 16 bytes -> LDS bytes [lds_addr, lds_addr + 1024)) as inline assembly: behind the compiler's own
 // global_load_lds builtin hipcc puts an s_waitcnt vmcnt(0) in front of the next transposing LDS read (it cannot tell the ring stages
@@ -394,9 +394,18 @@ int wgrad_glds_tile_a(const WgradK& k) {
   return (g_wgrad_glds & 2) && k.ca >= 256 && k.ktot >= 1024 && pad_ok(k.ktot, 256) && !k.tap_perm ? 256 : 128;
 }
 int wgrad_glds_tile_n(const WgradK& k) {
+  // bit 8 (off: csbsr_debug_set_wgrad_tr bit 23): a 128 x 512 tile -- four taps of a kernel row of the 8x8 stride-4 layers, every wave 64 x 128:
+  // three LDS fragment reads per four MFMAs where the 128 x 256 tap-pair tile's 64 x 64 waves need four -- in two 80 KB stages, the whole
+  // LDS of a CU.  N = 4: 2.09 -> 1.92 ms per launch (805 -> 879 TF/s); in the step 1046 -> 1044 ms.
+  if ((g_wgrad_glds & 256) && k.tap_perm && k.ktot == 8192 && k.ca == 128) return 512;
   return (k.ktot >= 6144 && (!k.tap_perm || (g_wgrad_glds & 64)) && !(g_wgrad_glds & 4)) ? 256 : 128;
 }
 int wgrad_glds_launch(const WgradK& k, int ta, int tn, int splits, hipStream_t st) {
+  if (tn == 512) {
+    WgradK p = k;
+    p.tap_perm = 0;      // natural column order: tile t = taps 4t .. 4t + 3 = one kernel row half
+    return launch_wgrad_glds<128, 512, 2, 4, 2>(p, splits, st);
+  }
   if (ta == 256) return launch_wgrad_glds<256, 256, 2, 4, 2>(k, splits, st);
   if (tn == 256) return launch_wgrad_glds<128, 256, 2, 4, 3>(k, splits, st);
   return launch_wgrad_glds<128, 128, 2, 2, 2>(k, splits, st);

@@ -14,13 +14,14 @@ extern "C" {
  * 17 / 18 conv_x3_kernel<3,1024> / <2,1024> (the instances with the straight-line epilogue rows) (bench.py's roofline block) */
 int32_t csbsr_debug_last_conv_kernel(void);
 /* same for csbsr_conv_wgrad: 0 conv_wgrad_kernel<128,128,2,2>, 1 <128,256,2,4>, 2 <64,128,2,2>, 3 <32,128,1,4>, 4 conv_wgrad_thin_kernel,
- * 5 / 6 / 7 conv_wgrad_glds_kernel<128,128,..> / <128,256,..> / <256,256,..> */
+ * 5 / 6 / 7 / 9 conv_wgrad_glds_kernel<128,128,..> / <128,256,..> / <256,256,..> / <128,512,..>, 8 conv_wgrad_hr_kernel */
 int32_t csbsr_debug_last_wgrad_kernel(void);
 /* kernel selection only, results are identical:
  *   wgrad: bit0 hardware transpose reads (0 = scalar LDS transposition), 2 no thin kernel, 4 no XCD tap order, 8 no flat grid,
  *          16 flat grid everywhere, 32 no row shift, 64 no 128x256 tile (register-staged kernel), 128 register-staged kernel everywhere
  *          (implied by bit0 = 0), 256 no 256x256 LDS-DMA tile, 512 no 128x256 LDS-DMA tile, 1024 LDS-DMA kernel for every >= 65-row problem (default:
- *          only where it runs the 256x256 tile), bits 12..19 extra dynamic LDS in KiB
+ *          only where it runs the 256x256 tile), bits 12..19 extra dynamic LDS in KiB,
+ *          bit 23 no 128 x 512 four-tap tile for the 8x8 stride-4 layers (the 128 x 256 tap-pair tile instead)
  *   conv:  low 3 bits 0 = register-staged kernel only, 1 = 128x128 LDS-DMA tile only, 2 = default, 3 = 256x128 wherever it fits;
  *          16 no thin kernels, 32 phases on grid.z, 64 linear pixel tiles, 128 raster tap order, 256 no 256-cout tile */
 void csbsr_debug_set_wgrad_tr(int flags);

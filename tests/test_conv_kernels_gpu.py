@@ -89,7 +89,8 @@ CASES = [
 @pytest.mark.parametrize("case", CASES)
 # wgrad: default (LDS-DMA kernel for every eligible problem: 128x128 / 128x256 / 256x256 tiles) | register-staged, scalar LDS transposition |
 # register-staged, hardware transpose | LDS-DMA 256x256 tiles where eligible, register-staged elsewhere
-@pytest.mark.parametrize("use_tr", [1, 0, 129, 1025])
+# ... | the 128 x 256 tap-pair wgrad tile for the 8x8 stride-4 layers instead of the 128 x 512 four-tap one (bit 23)
+@pytest.mark.parametrize("use_tr", [1, 0, 129, 1025, 1 | (1 << 23)])
 def test_conv_fwd_dgrad_wgrad(case, use_tr):
     from csbsr_amd import _lib as L
     from csbsr_amd.engine import Conv
