@@ -83,7 +83,16 @@ __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const W
   const int wa = wid / NWB, wb = wid % NWB;
   const unsigned ntile = p.tiles_a * p.tiles_b;
   unsigned lt, zsplit;
-  if (p.flat) {
+  if (BN == 512 && p.flat == 2) {
+    // the four-tap tiles of the 8x8 stride-4 layers, 1-D grid of 16 tiles x (an even number of) splits.  An input pixel is read by the
+    // four taps (ky, ky + 4) x (kx, kx + 4) = four DIFFERENT tiles, so an XCD (blockIdx % 8) takes all four tiles of one ky pair, one
+    // after the other, for the splits of one parity: every input row then crosses the fabric into ONE L2 (with two tiles per XCD it
+    // entered two: 8.2-9.9 GB per launch against 5.2 for the tap-pair tile)
+    const unsigned e = blockIdx.x & 7u, i = blockIdx.x >> 3;
+    const unsigned t4 = i & 3u;
+    zsplit = 2u * (i >> 2) + (e >> 2);
+    lt = (((e & 3u) + 4u * (t4 >> 1)) << 1) | (t4 & 1u);      // tile index = 2 ky + column half
+  } else if (p.flat) {
     const unsigned w = xcd_remap(blockIdx.x, ntile * (unsigned)p.splits);
     zsplit = w / ntile; lt = w - zsplit * ntile;
   } else {
@@ -96,6 +105,7 @@ __global__ __launch_bounds__(64 * NWA * NWB) void conv_wgrad_glds_kernel(const W
       const int j = lt >> 3, r = lt & 7;
       const int ky = (j & 3) + 4 * (r >> 2), kx = 2 * (j >> 2) + (r & 1) + 4 * ((r >> 1) & 1);
       col0 = (ky * 8 + kx) * 128;
+    } else if constexpr (BN == 512) {      // (natural order: tile = 2 ky + column half; the XCD assignment is the grid mapping above)
     } else {
       const int j = lt >> 2, r = lt & 3;
       const int ky = (j & 3) + 4 * (r >> 1), kx0 = 2 * (j >> 2) + 4 * (r & 1);
@@ -354,6 +364,7 @@ static int launch_wgrad_glds_t(const WgradK& k, int splits, hipStream_t st) {
     if (hipMalloc(reinterpret_cast<void**>(&g_wg_zero_page[dev]), 256) != hipSuccess) { csbsr_set_error("wgrad(glds): zero page alloc failed"); return 2; }
     (void)hipMemset(g_wg_zero_page[dev], 0, 256);
   }
+  if (BN == 512 && ntile == 16 && splits % 2 == 0 && p.tap_perm) p.flat = 2;      // the XCD-by-(ky pair, split parity) grid of the four-tap tiles
   dim3 grid(p.flat ? ntile * splits : ntile, 1, p.flat ? 1 : splits);
   hipLaunchKernelGGL((conv_wgrad_glds_kernel<BA, BN, NWA, NWB, NSTAGE, T2D>), grid, dim3(64 * NWA * NWB), SM_BYTES, st, p, g_wg_zero_page[dev]);
   CSBSR_LAUNCH_CHECK("csbsr_conv_wgrad(glds)");
@@ -402,9 +413,7 @@ int wgrad_glds_tile_n(const WgradK& k) {
 }
 int wgrad_glds_launch(const WgradK& k, int ta, int tn, int splits, hipStream_t st) {
   if (tn == 512) {
-    WgradK p = k;
-    p.tap_perm = 0;      // natural column order: tile t = taps 4t .. 4t + 3 = one kernel row half
-    return launch_wgrad_glds<128, 512, 2, 4, 2>(p, splits, st);
+    return launch_wgrad_glds<128, 512, 2, 4, 2>(k, splits, st);
   }
   if (ta == 256) return launch_wgrad_glds<256, 256, 2, 4, 2>(k, splits, st);
   if (tn == 256) return launch_wgrad_glds<128, 256, 2, 4, 3>(k, splits, st);
