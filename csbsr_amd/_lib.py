@@ -158,6 +158,11 @@ DEBUG_SIGNATURES = {
     "csbsr_debug_set_wgrad_hr": (None, [i32]),
     "csbsr_debug_last_conv_kernel": (i32, []),
     "csbsr_debug_last_wgrad_kernel": (i32, []),
+    "csbsr_debug_cu_trace": (i32, [vp, i32, i32, vp]),
+    "csbsr_debug_stream_create_cu_mask": (i32, [C.POINTER(vp), C.POINTER(C.c_uint32), i32]),
+    "csbsr_debug_stream_destroy": (i32, [vp]),
+    "csbsr_debug_stream_set_cu_budget": (i32, [vp, i32]),
+    "csbsr_debug_stream_cu_budget": (i32, [vp]),
 }
 
 _lib = None

@@ -82,5 +82,8 @@ static inline int csbsr_lds_attr(LdsAttrOnce& o, const void* fn, int bytes, cons
   return 0;
 }
 
+// CUs a persistent-grid kernel launched on ``st`` may count on (csrc/streams.hip): the stream's CU-mask budget, else the device's CU count
+int csbsr_cu_budget(hipStream_t st);
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }

@@ -416,7 +416,7 @@ static int launch_hr(const ConvHrK& k, hipStream_t st) {
   // persistent: one workgroup per CU (the ring of halo tiles takes the LDS), a multiple of 8 x (cout-tile groups); never more than there is work
   const unsigned total = k.tiles_x * k.tiles_y * k.N;
   const unsigned groups = (unsigned)((k.ntile_c + NCT - 1) / NCT), unit = 8u * groups;
-  unsigned g = 256u;
+  unsigned g = (unsigned)csbsr_cu_budget(st);      // the stream's CU partition (csrc/streams.hip), else the whole device
   if (g > total * groups) g = total * groups;
   g = (g + unit - 1) / unit * unit;
   dim3 grid(g);

@@ -502,8 +502,7 @@ static int launch_tp(ConvTpK& k, hipStream_t st, half_t* zp, float* dbias, float
   static LdsAttrOnce attr;
   if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_tp_kernel<NKC, R, A, M, S>), SM_BYTES, "conv_tp")) return e;
   const unsigned items = k.tiles_x * k.tiles_y * k.N * k.pgroups;
-  int dev = 0, ncu = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int ncu = csbsr_cu_budget(st);      // the stream's CU partition (csrc/streams.hip), else the whole device
   const unsigned g = items < (unsigned)ncu ? items : (unsigned)ncu;
   if (S) {
     k.part_ld = k.coutp + 8;

@@ -472,7 +472,7 @@ extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   q.ct_major = (unsigned)g_conv_x3_ct_major;
   int dev = 0, ncu = 256;
   CSBSR_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < CSBSR_MAX_DEVICES, "conv_x3: no current device");
-  (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  ncu = csbsr_cu_budget(reinterpret_cast<hipStream_t>(s));      // the stream's CU partition (csrc/streams.hip), else the whole device
   if (!g_x3_zero_page[dev]) {
     CSBSR_CHECK(hipMalloc(reinterpret_cast<void**>(&g_x3_zero_page[dev]), 256) == hipSuccess, "conv_x3: zero page alloc failed");
     (void)hipMemset(g_x3_zero_page[dev], 0, 256);

@@ -32,6 +32,19 @@ void csbsr_debug_set_conv_tp(int mode);
 void csbsr_debug_set_conv_x3(int mode);
 /* full-resolution thin 3x3 weight-gradient kernel (csrc/conv_wgrad_hr.hip): 0 never, 1 launches of >= 1024 tiles (default), 2 every eligible launch */
 void csbsr_debug_set_wgrad_hr(int mode);
+/* CU-partitioned streams (csrc/streams.hip) -- a MEASUREMENT hook, not product: round 5 measured a weight gradient and an HBM-bound link of
+ * the dgrad chain on disjoint CU sets against the same launches back to back (scripts/overlap_pair.py, profiles/r05_overlap.json): no
+ * split is faster than serial by more than 5 %, most are slower, so the engine keeps ONE stream.  mask: bit i = one CU; bit i lands on
+ * XCD i % 8 on gfx950 (a prefix of the bit array spreads over all eight XCDs); nwords 32-bit words.  A stream created here remembers
+ * its CU count as its budget; the persistent-grid kernels (conv_x3, conv_tp, conv_hr) size their grids from the budget of the stream
+ * they are launched on (none: the device's CU count).  set_cu_budget attaches a budget to any stream, 0 removes it. */
+int csbsr_debug_stream_create_cu_mask(void** out, const uint32_t* mask, int32_t nwords);
+int csbsr_debug_stream_destroy(void* stream);
+int csbsr_debug_stream_set_cu_budget(void* stream, int32_t ncu);
+int32_t csbsr_debug_stream_cu_budget(void* stream);
+/* where a grid's workgroups ran: out[2 wg] = HW_REG_HW_ID, out[2 wg + 1] = HW_REG_XCC_ID of workgroup wg, each spinning spin_cycles
+ * so that the grid spreads over every CU its stream may use (scripts/overlap_pair.py: the CU-mask bit -> XCD map) */
+int csbsr_debug_cu_trace(uint32_t* out, int32_t nwg, int32_t spin_cycles, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,103 @@
+// CU-partitioned HIP streams -- measurement hooks (csbsr_debug.h), not product.  The round-4 review proposed running the backward's weight
+// gradients (side branches, MFMA-bound) and the HBM-bound links of its dgrad chain on DISJOINT sets of compute units.  Measured in round 5
+// (scripts/overlap_pair.py, profiles/r05_overlap.json): the pairs interfere through the memory system -- a weight gradient confined to 160
+// CUs takes 7.5 ms alone and 8.9 ms next to an epilogue-backward pass on the other 96 -- and no split beats the serial order by more
+// than 5 %.  The engine keeps one stream; what stays in the product is csbsr_cu_budget() for the persistent grids.
+//
+// Mask layout on this part (measured with csbsr_debug_cu_trace, scripts/overlap_pair.py): bit i of the mask handed to
+// hipExtStreamCreateWithCUMask selects a CU of XCD i % 8, so a prefix of the bit array spreads evenly over the eight XCDs (and their L2s).
+#include <mutex>
+#include <vector>
+#include "common.h"
+#include "csbsr_debug.h"
+
+namespace {
+struct Budget { hipStream_t st; int ncu; };
+std::mutex g_mu;
+std::vector<Budget> g_budgets;
+}  // namespace
+
+static int32_t csbsr_device_cu_count(void) {
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return ncu;
+}
+
+extern "C" int csbsr_debug_stream_create_cu_mask(void** out, const uint32_t* mask, int32_t nwords) {
+  CSBSR_CHECK(out != nullptr && mask != nullptr && nwords > 0, "csbsr_debug_stream_create_cu_mask: bad arguments");
+  int bits = 0;
+  for (int i = 0; i < nwords; ++i) bits += __builtin_popcount(mask[i]);
+  CSBSR_CHECK(bits > 0, "csbsr_debug_stream_create_cu_mask: empty mask");
+  hipStream_t st = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask);
+  if (e != hipSuccess) {
+    csbsr_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    return 2;
+  }
+  *out = (void*)st;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_budgets.push_back({st, bits});
+  return 0;
+}
+
+extern "C" int csbsr_debug_stream_destroy(void* s) {
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = 0; i < g_budgets.size(); ++i)
+      if (g_budgets[i].st == (hipStream_t)s) {
+        g_budgets.erase(g_budgets.begin() + i);
+        break;
+      }
+  }
+  hipError_t e = hipStreamDestroy((hipStream_t)s);
+  if (e != hipSuccess) {
+    csbsr_set_error("hipStreamDestroy: %s", hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+
+extern "C" int csbsr_debug_stream_set_cu_budget(void* s, int32_t ncu) {
+  CSBSR_CHECK(ncu >= 0, "csbsr_debug_stream_set_cu_budget: negative budget");
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& b : g_budgets)
+    if (b.st == (hipStream_t)s) {
+      if (ncu == 0) { b = g_budgets.back(); g_budgets.pop_back(); } else b.ncu = ncu;
+      return 0;
+    }
+  if (ncu > 0) g_budgets.push_back({(hipStream_t)s, ncu});
+  return 0;
+}
+
+// CUs a persistent-grid kernel launched on ``st`` may count on: the stream's budget if it has one, else the whole device
+int csbsr_cu_budget(hipStream_t st) {
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (const auto& b : g_budgets)
+      if (b.st == st) return b.ncu;
+  }
+  int n = csbsr_device_cu_count();
+  return n > 0 ? n : 256;
+}
+
+extern "C" int32_t csbsr_debug_stream_cu_budget(void* s) { return csbsr_cu_budget((hipStream_t)s); }
+
+// ---- where did my workgroups run?  out[2 * wg] = HW_ID, out[2 * wg + 1] = XCC_ID of workgroup wg (debug hook, csbsr_debug.h)
+__global__ void cu_trace_kernel(uint32_t* out, int spin) {
+  const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
+  const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+  long t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = hw;
+    out[2 * blockIdx.x + 1] = xcc;
+  }
+}
+
+extern "C" int csbsr_debug_cu_trace(uint32_t* out, int32_t nwg, int32_t spin_cycles, void* s) {
+  CSBSR_CHECK(out != nullptr && nwg > 0, "csbsr_debug_cu_trace: bad arguments");
+  hipLaunchKernelGGL(cu_trace_kernel, dim3(nwg), dim3(64), 0, (hipStream_t)s, out, spin_cycles);
+  CSBSR_LAUNCH_CHECK("cu_trace_kernel");
+  return 0;
+}
