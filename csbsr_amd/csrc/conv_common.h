@@ -159,12 +159,13 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
 
 // ---- straight-line rows for the common fused epilogues ---------------------------------------------------------------------------
 // No sample statistics / constant-segment bias / fp32 output, whole channel octets, identity / ReLU / leaky activation (as
-// max(t, t*sneg), sneg <= 1), residual add or subtract, optional accumulate, optional BatchNorm sums: the mode switches of
+// the select t > 0 ? t : t * sneg), residual add or subtract, optional accumulate, optional BatchNorm sums: the mode switches of
 // conv_epilogue_row become two multipliers picked once per kernel.  The general row re-tests every mode per element (~100 scalar
 // branches per row): its 8 rows took 7.7 us of an 18 us transposed-conv workgroup whose 8 K slices take 5.9 us (CSBSR_TS build).
 struct EpiFast { bool ok, has_res, has_old, has_mask, bn, masked, has_cb; float sneg, rsign, osc, mslope; int cout; long o_lo; };
 // which launches the straight-line rows cover (host and device: conv_x3 picks its kernel instance by it).  The activation is
-// max(t, 0) + sneg * min(t, 0): exact for any slope (a learned PReLU slope may exceed 1), bit-identical to t > 0 ? t : t * sneg.
+// the select t > 0 ? t : t * sneg with a kernel-uniform sneg: exact for any slope (a learned PReLU slope may exceed 1) and NaN-
+// preserving (round 4's max(t, 0) + sneg * min(t, 0) zeroed a NaN accumulator: maxnum / minnum return the non-NaN operand).
 __host__ __device__ __forceinline__ bool conv_epilogue_fast_ok(const ConvK& p) {
   return (p.stat_mode == CSBSR_STAT_NONE || p.stat_mode == CSBSR_STAT_BN) && !p.out32 && p.out16 && p.act != CSBSR_ACT_SIGMOID &&
          (p.res_mode == CSBSR_RES_NONE || p.res_mode == CSBSR_RES_ADD || p.res_mode == CSBSR_RES_SUB) && !p.r_lo;
@@ -205,7 +206,7 @@ __device__ __forceinline__ void conv_epilogue_fast_row(const EpiFast& f, const f
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     t[e] = v[e] * f.osc + bias[e];
-    t[e] = fmaxf(t[e], 0.f) + f.sneg * fminf(t[e], 0.f);
+    t[e] = t[e] > 0.f ? t[e] : t[e] * f.sneg;      // a select, not max / min: fmaxf / fminf return the non-NaN operand and would turn an overflowed (NaN) accumulator into 0, hiding it from the optimiser's overflow check
   }
   if (f.masked) {
 #pragma unroll

@@ -177,6 +177,26 @@ class Engine:
         if self.wg_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.wg_stream)
 
+    def prelu_fold_ok(self, p):
+        """May a learned PReLU slope's layer take the FOLDED backward (Conv.bwd_weights_folded(prelu_out=), the dgrad mask above it)?  That
+        form takes the gate from the sign of the saved output and divides the slope-gradient sum by slope^2: right for a slope safely above
+        zero (nn.PReLU starts at 0.25), inf / the wrong gate at slope <= 0.  The slope is read WITHOUT stalling the stream: each call starts
+        an asynchronous copy into pinned host memory and decides from the value the previous call fetched (one optimiser step old -- the
+        1e-2 threshold leaves two orders of magnitude more than a step can move it); the first call reads synchronously."""
+        st = getattr(p, "_slope_probe", None)
+        if st is None:
+            host = torch.empty(p.numel(), dtype=torch.float32, pin_memory=True)
+            host.copy_(p.detach().reshape(-1).to(torch.float32))
+        else:
+            host, ev = st
+            ev.synchronize()
+        ok = bool(float(host.min()) > 1e-2)
+        host.copy_(p.detach().reshape(-1).to(torch.float32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        p._slope_probe = (host, ev)
+        return ok
+
     # ------------------------------------------------------------------ elementwise wrappers
     def epilogue_bwd(self, dout, out=None, act=L.ACT_NONE, slope=0.0, prelu=None, res=None, res2=None, res_mode=L.RES_NONE,
                      dpre=None, dres=None, dres_acc=False, dres2=None, dres2_acc=False, dbias=None, dprelu=None, creal=None):
@@ -416,7 +436,8 @@ class Conv:
                 d.dres, d.dr_sn, d.dr_sy, d.dr_sx = _ptr(dfm.t), sn, sy, sx
             if use_tp and L.load().csbsr_conv_tp_eligible(C.byref(d)):
                 self.last_fused = True
-            elif dres is not None and self.eng.thin_dact and L.load().csbsr_conv_thin_dact_eligible(C.byref(d)):
+            elif (dres is not None and self.eng.thin_dact and L.load().csbsr_conv_thin_dact_eligible(C.byref(d))
+                  and (below.prelu is None or self.eng.prelu_fold_ok(below.prelu))):      # (the kernel divides its slope sum by the slope)
                 self.last_fused = True      # the thin-input accumulating dgrad (csrc/conv_thin.hip, DACT): csbsr_conv_forward dispatches it
                 use_tp = False
             else:

@@ -317,13 +317,15 @@ class JointModelWithLoss(_JointBase):
         B, _, h, w = x.shape
         H, W = h * pc.scale, w * pc.scale
         mb = max(1, min(self.micro_batch, B))
-        n_res, lean = (self.max_resident, bool(self.lean_saves)) if self.max_resident is not None else self._auto_resident(B, mb, H, W)
+        training = self.training
+        keep = training and torch.is_grad_enabled()
+        # (the rank agreement inside _auto_resident is a collective: only a forward that will be followed by a backward takes part in it, so
+        # a rank-0-only validation pass, an evaluator sharing the model or a no_grad call can never leave the other ranks waiting)
+        n_res, lean = (self.max_resident, bool(self.lean_saves)) if self.max_resident is not None else self._auto_resident(B, mb, H, W, agree=keep)
         self._n_res, self._lean = n_res, lean
         single = mb >= B
         sr32 = eng.f32(B, 3, H, W, zero=False)
         kvec = eng.f32(B, pc.ksize_out ** 2, zero=False)
-        training = self.training
-        keep = training and torch.is_grad_enabled()
         saves, self._pad_takes = [], []
         for i, b0 in enumerate(range(0, B, mb)):
             resident = keep and i < n_res and not self.blur_skip     # BlurSkip: KBPN is frozen, no backward through it
@@ -434,7 +436,7 @@ class JointModelWithLoss(_JointBase):
             seg_loss, sr_loss = _JointFn.apply(self, st, seg_loss, sr_loss, *params)
         return seg_loss, sr_loss, seg32, sr32, kpred
 
-    def _auto_resident(self, B, mb, H, W):
+    def _auto_resident(self, B, mb, H, W, agree=True):
         """micro-batches whose KBPN activations fit next to the detector's working set (measured at HR 1792^2: 26.5 GB per image
         of KBPN activations, 6.3 / 9.5 GB per image for PSPNet / HRNet-OCR incl. their backward workspaces -- the split-precision
         detector holds two planes per activation) with 18 GB to spare.  The budget is what is FREE now (driver-reported free memory
@@ -452,10 +454,13 @@ class JointModelWithLoss(_JointBase):
             imgs = int((free - 18e9 - det) // (per_img * r)) if r > 0 else B
             return max(0, min(n_mb, imgs // mb))
         full, lean = fit(26.5e9), fit(21.2e9)      # lean saves: the kernel predictors' fe_SR chains are rebuilt in the backward (KBPN.forward)
-        if self.reducer is not None and self.reducer.active:
+        if agree and self.reducer is not None and self.reducer.active:
             # data-parallel: the ranks must take the SAME schedule (at ~240 of 288 GB the collective library's buffers can tip one rank into
             # recomputing a KBPN forward, and every other rank would wait for it at the all-reduce): the minimum over the ranks, agreed
-            # once per problem shape in one tiny collective and kept for the life of the model
+            # in one tiny collective per problem shape.  EVERY rank must present each training shape (B, micro-batch, H, W) -- the
+            # data-parallel contract anyway: equal shards, train.py:105-112 of the reference -- and only training forwards with autograd
+            # on take part (``agree``); eval / no_grad forwards keep nothing resident and use the local figures.  The agreement is kept
+            # for the life of the model: renewing it when ONE rank's free memory drops later would be a collective only that rank enters
             key = (B, mb, H, W, self.detector_precision)
             agreed = self.__dict__.setdefault("_sched_agreed", {})
             if key not in agreed:

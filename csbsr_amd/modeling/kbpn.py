@@ -138,7 +138,8 @@ class KBPN:
         # predictors (full-resolution 32 / 49-channel layers on the bias-free direct kernels): exempting their weights from rounding
         # altogether moves nothing.
         for c in self.layers:
-            c.dc_comp = ".kernel_predictor." not in c.name        # bicubic 7x7 -> 21x21 as a fixed linear map U [kk, kc] (nn.Upsample(size, 'bicubic'), kbpn.py:317,558)
+            c.dc_comp = ".kernel_predictor." not in c.name
+        # bicubic 7x7 -> 21x21 as a fixed linear map U [kk, kc] (nn.Upsample(size, 'bicubic'), kbpn.py:317,558)
         eye = torch.eye(kc).reshape(kc, 1, cfg.ksize, cfg.ksize)
         up = F.interpolate(eye, size=(self.K, self.K), mode="bicubic", align_corners=False) if cfg.ksize != self.K else eye
         self.U = up.reshape(kc, self.kk).t().contiguous().to(eng.device)       # [kk, kc]

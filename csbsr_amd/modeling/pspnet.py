@@ -249,7 +249,7 @@ class PSPNet:
                 if dz is None:
                     dz = act_bwd(c1, dsc, sc)
                 c1.bwd_weights(dz, t)
-                if t.H * t.W >= 1024 and e.fold_prelu:
+                if t.H >= 3 and t.W >= 3 and t.H * t.W >= 1024 and e.fold_prelu and e.prelu_fold_ok(c0.prelu):      # (csbsr_border_class_sums_prelu's own precondition; a slope safely > 0)
                     # conv0's PReLU derivative rides on conv1's dgrad (mask = conv0's saved output, slope read on the device); its bias
                     # gradient is the sum of the border-class sums the folded weight gradient takes anyway, its slope gradient comes out
                     # of the same pass over (dPre, t): no epilogue-backward pass over the 505-channel HR map (8.5 ms each at B = 4)

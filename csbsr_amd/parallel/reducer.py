@@ -118,13 +118,27 @@ class GradBucketReducer:
 
 
 def broadcast_parameters(module, src=0, process_group=None, force=None):
-    """Make every replica start from rank ``src``'s weights and buffers (once, not per step).  Returns the number of broadcasts issued."""
+    """Make every replica start from rank ``src``'s weights and buffers (once, not per step): the tensors are packed into one flat
+    buffer per (parameter | buffer, dtype) group -- fp32 weights, fp32 BatchNorm running statistics, int64 batch counters: three
+    broadcasts where one per tensor would be 410 (290 parameters + 120 buffers with PSPNet) -- and copied back in place.  Returns the
+    number of broadcasts issued."""
     if not dist.is_initialized():
         return 0
     if dist.get_world_size(process_group) == 1 and not (_forced() if force is None else force):
         return 0
+    groups = {}
+    for kind, ts in (("param", module.parameters()), ("buffer", module.buffers())):
+        for t in ts:
+            groups.setdefault((kind, t.dtype, t.device), []).append(t.data)
     n = 0
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=process_group)
-        n += 1
+    with torch.no_grad():
+        for (_, dtype, device), ts in groups.items():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src, group=process_group)
+            n += 1
+            off = 0
+            for t in ts:
+                k = t.numel()
+                t.copy_(flat[off:off + k].view_as(t))
+                off += k
     return n

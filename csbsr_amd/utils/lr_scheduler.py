@@ -7,8 +7,8 @@ at 0 on resume, hence the ``resume_iter`` offset.
 
 ``WarmupMultiStepLR(cfg, optimizer, milestones, gamma, warmup_factor, warmup_iters, last_epoch)`` (same file, :14-29; not used by
 train.py, kept for callers that import it): despite its name and base class the reference's ``get_lr`` never consults the milestones --
-the rate ramps linearly from ``warmup_factor * cfg.SOLVER.LR`` to ``cfg.SOLVER.LR`` over ``warmup_iters`` steps and stays there --
-(the first quirk is reproduced).  It returns ONE value whatever the number of parameter groups; torch >= 2.6 zips strictly and
+the rate ramps linearly from ``warmup_factor * cfg.SOLVER.LR`` to ``cfg.SOLVER.LR`` over ``warmup_iters`` steps and stays there
+(this quirk is reproduced).  It also returns ONE value whatever the number of parameter groups; torch >= 2.6 zips strictly and
 raises on that with more than one group, so this class hands the same rate to every group -- identical for the single-group
 optimisers the reference builds."""
 from torch.optim.lr_scheduler import MultiStepLR

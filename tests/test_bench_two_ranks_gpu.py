@@ -33,7 +33,7 @@ def test_bench_two_ranks_one_device():
 def test_bench_rccl_backend_one_rank():
     """The same N > 1 code path with the REAL backend: `nccl` (= RCCL on ROCm) with world size 1 on the one GPU of the test box.
     CSBSR_FORCE_DIST=1 makes the reducer and the parameter broadcast ISSUE their collectives in a one-rank group (they return early
-    otherwise): process-group init with device_id, one broadcast per parameter / buffer, per step the six flat-bucket all-reduces
+    otherwise): process-group init with device_id, one broadcast per (parameters | buffers, dtype) group, per step the six flat-bucket all-reduces
     (segmentation net, KBPN stages 4..1, KBPN head) on the side stream launched from inside the backward, barrier, MAX all-reduce of
     the step time.  What a one-GPU box cannot show is only the transfer between GPUs."""
     env = dict(os.environ, CSBSR_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -51,7 +51,7 @@ def test_bench_rccl_backend_one_rank():
     assert r["backend"] == "nccl" and r["steps"] == 3                       # 1 warmup + 2 timed steps
     assert r["all_reduces"] == 6 * r["steps"] and r["on_side_stream"] == r["all_reduces"], r
     assert r["bytes"] == r["steps"] * 4 * 89_249_704, r      # every trainable parameter of KBPN x4 + PSPNet, fp32, once per step
-    assert r["broadcasts"] == 410                           # 290 parameters + 120 BatchNorm buffers
+    assert 1 <= r["broadcasts"] <= 8, r                     # flat groups (fp32 weights, fp32 running statistics, int64 counters), not 410 tensors
 
 
 def test_forced_rccl_all_reduce_leaves_gradients_bit_identical():

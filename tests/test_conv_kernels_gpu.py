@@ -129,6 +129,45 @@ def test_conv_fwd_dgrad_wgrad(case, use_tr):
     L.load().csbsr_debug_set_wgrad_tr(1)
 
 
+@pytest.mark.parametrize("shape", [
+    # cin, cout, k, stride, pad, transposed, H, W  -- one launch per kernel family whose epilogue is the straight-line row of conv_common.h
+    (128, 128, 3, 1, 1, False, 16, 16),            # LDS-DMA 128 x 128 tile
+    (256, 256, 3, 1, 1, False, 192, 192),          # 256 px x 256 cout tile
+    (832, 384, 3, 1, 1, False, 64, 64),            # conv_x3<3, 1024>
+    (128, 128, 8, 4, 2, False, 256, 256),          # conv_x3<2, 1024>
+    (16, 32, 3, 1, 1, False, 9, 11),               # register-staged kernel
+])
+@pytest.mark.parametrize("act", ["relu", "prelu", "none"])
+def test_non_finite_accumulators_reach_the_output(shape, act):
+    """an overflowed (inf / NaN) accumulator must leave the epilogue non-finite -- the optimiser's overflow check
+    (modeling/build_model.py: isfinite over the gradient accumulators) only sees what the dgrad chain hands on.  Round 4's
+    max(t, 0) + s * min(t, 0) activation turned NaN into 0 (maxnum / minnum return the non-NaN operand)."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    cin, cout, k, s, p, tr, H, W = shape
+    torch.manual_seed(5)
+    eng = _eng()
+    x = torch.randn(1, cin, H, W).half().float() * 0.1
+    w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    params = {"l.weight": w.cuda(), "l.slope": torch.tensor([0.25]).cuda()}
+    a = {"relu": L.ACT_RELU, "prelu": L.ACT_PRELU, "none": L.ACT_NONE}[act]
+    conv = Conv(eng, "l", params, k, s, p, 1, bias=False, act=a, prelu="l.slope" if act == "prelu" else False)
+    OH, OW = conv.out_size(H, W)
+    for bad in (float("nan"), float("inf"), float("-inf")):
+        xb = x.clone()
+        xb[0, 1, H // 2, W // 2] = bad                       # one poisoned input element: every output its taps reach must be non-finite
+        y = from_fm(conv.fwd(to_fm(eng, xb)))
+        torch.cuda.synchronize()
+        cy, cx = (H // 2) // s, (W // 2) // s
+        hit = y[0, :, cy, cx]                                # the output pixel straight under it
+        nf = ~torch.isfinite(hit)
+        if act == "relu" and bad != float("nan"):
+            # relu(-inf) = 0 and relu(+inf * w) is inf only where w > 0: at least the positive-weight channels must show it
+            assert nf.any(), (bad, act)
+        else:
+            assert nf.all(), (bad, act, int(nf.sum()), cout)
+
+
 @pytest.mark.parametrize("case", [
     # cin (segments), cout, k, pad, dil, H, W
     ((505,), 64, 3, 1, 1, 20, 24),          # blur_skip conv_scale.1
