@@ -10,6 +10,7 @@ Prints ONE JSON line (rank 0).  See DESIGN.md section "Measurement" for the algo
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -191,9 +192,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     last = 0.0
-    for _ in range(args.steps):
+    ovf0, bad_loss = model.overflow_steps, []
+    for i_ in range(args.steps):
         last = step()
+        if not math.isfinite(last):
+            bad_loss.append((i_, last))
     torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0          # this rank alone, before it waits for the others (schedule.step_ms_per_rank)
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -201,6 +206,11 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
+    if bad_loss or model.overflow_steps != ovf0:
+        # a timed step that produced a non-finite loss, or whose backward overflowed (the optimiser then skips the update: less work than a
+        # real step), is not a measurement -- fail loudly instead of printing a throughput
+        sys.stderr.write(f"bench.py: INVALID timed region on rank {rank}: non-finite losses {bad_loss}, overflowed steps {model.overflow_steps - ovf0}\n")
+        sys.exit(3)
     ms = dt / args.steps * 1e3
     imgs = B * world * args.steps / dt
     timing_log, eng.timing = eng.timing, None
@@ -215,6 +225,11 @@ def main():
         allpk = [torch.zeros_like(pk) for _ in range(world)]
         dist.all_gather(allpk, pk)
         schedule["peak_mem_gb_per_rank"] = [round(float(t), 1) for t in allpk]
+        # every rank's own wall time of the timed region (the reported time is the maximum): a straggler shows as a spread
+        mine = torch.tensor([dt_rank / args.steps * 1e3], device=dev, dtype=torch.float64)
+        allms = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allms, mine)
+        schedule["step_ms_per_rank"] = [round(float(t), 1) for t in allms]
         sc = torch.tensor([schedule["n_resident"], int(schedule["lean_saves"])], device=dev, dtype=torch.int64)
         lo, hi = sc.clone(), sc.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -259,22 +274,21 @@ def main():
         json.dump([{"kind": t[0], "flops": t[1], "bytes": t[2], "ms": t[3].elapsed_time(t[4]), "layer": t[5], "shape": list(t[6]),
                     "kernel": (t[7] if len(t) > 7 else -1)} for t in timing_log], open(args.dump_layers, "w"))
     if timing_log:
-        # one roofline block = ONE kernel: the conv kernel with the largest share of the timed region (csbsr_debug_last_conv_kernel tags
-        # every launch with the kernel it dispatched to).  achieved = algorithmic FLOPs of those launches / their HIP-event time.
-        names = {0: "conv_igemm_kernel<32,4,1>", 1: "conv_igemm_kernel<64,2,2>", 2: "conv_igemm_kernel<128,2,2>",
-                 3: "conv_igemm_glds_kernel<128,2,2>", 4: "conv_igemm_glds_kernel<256,4,3>", 5: "conv_thin_cout_kernel",
-                 6: "conv_thin_cin_kernel", 7: "conv_igemm_glds_kernel<256,4,2,2>", 8: "conv_hr_kernel", 9: "conv_tp_kernel", 10: "conv_x3_kernel<3>", 11: "conv_thin_tp_kernel", 12: "conv_x3_kernel<2>", 13: "conv_thin_cin2_kernel", 14: "conv_igemm_glds_kernel<128,2,2,0>", 15: "conv_thin_sc_kernel",
-                 16: "conv_thin_tpd_kernel", 17: "conv_x3_kernel<3,1024>", 18: "conv_x3_kernel<2,1024>"}
-        wnames = {0: "conv_wgrad_kernel<128,128,2,2>", 1: "conv_wgrad_kernel<128,256,2,4>", 2: "conv_wgrad_kernel<64,128,2,2>",
-                  3: "conv_wgrad_kernel<32,128,1,4>", 4: "conv_wgrad_thin_kernel", 5: "conv_wgrad_glds_kernel<128,128>",
-                  6: "conv_wgrad_glds_kernel<128,256>", 7: "conv_wgrad_glds_kernel<256,256>", 8: "conv_wgrad_hr_kernel",
-                  9: "conv_wgrad_glds_kernel<128,512>"}
+        # one roofline block = ONE kernel = one rocprofv3 ROW (template instance): the row with the largest share of the timed region.
+        # csbsr_debug_last_conv_kernel / _wgrad_kernel tag every launch with the instance it dispatched to; csbsr_amd/utils/kernel_names.py
+        # gives it the name scripts/summarise_profiles.py gives the same row of the rocprofv3 CSVs.  achieved = algorithmic FLOPs (or bytes)
+        # of those launches / their HIP-event time on the engine's stream.
+        from csbsr_amd.utils.kernel_names import conv_row, wgrad_row, family
         per = {}
         for t in timing_log:
-            key = names.get(t[7], "conv?") if t[0] == "conv" else wnames.get(t[7] if len(t) > 7 else -1, "conv_wgrad?")
+            key = conv_row(t[7]) if t[0] == "conv" else wgrad_row(t[7] if len(t) > 7 else -1)
             a = per.setdefault(key, [0.0, 0.0, 0.0, 0, 0.0])
             a[0] += t[1]; a[1] += t[2]; a[2] += t[3].elapsed_time(t[4]) * 1e-3; a[3] += 1
             a[4] += t[1] * (t[8] if len(t) > 8 else 1)          # executed MFMA work: the split-precision launches run 2 or 3 K blocks per product
+        fam = {}
+        for k_, v in per.items():
+            f_ = fam.setdefault(family(k_), [0.0, 0.0, 0])
+            f_[0] += v[2]; f_[1] += v[0]; f_[2] += v[3]
         # the dominant kernel is chosen over EVERY MFMA kernel of the step, each wgrad variant on its own
         dom = max(per, key=lambda k: per[k][2])
         fl, by, tt, nl, flx = per[dom]
@@ -291,10 +305,6 @@ def main():
                 tj = json.load(open(tpath))
                 ks = tj.get("kernels", {})
                 traffic = ks.get(dom, {}).get("hbm_bytes_per_launch")
-                if traffic is None:       # template variants of one kernel (conv_tp_kernel<res=..>, conv_hr_kernel<4|7>): launch-weighted mean
-                    var = [v for n_, v in ks.items() if n_.startswith(dom + "<")]
-                    if var:
-                        traffic = round(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in var) / sum(v["launches"] for v in var))
             except Exception:
                 traffic = None
         # MFMA-pipe utilisation in cycles and the clock the kernel ran at, from the committed SQ_VALU_MFMA_BUSY_CYCLES pass
@@ -303,7 +313,7 @@ def main():
         if os.path.exists(mpath) and args.workload == "pspnet_x4":
             try:
                 mk = json.load(open(mpath)).get("kernels", {})
-                var = [v for n_, v in mk.items() if n_ == dom or n_.startswith(dom + "<")]
+                var = [v for n_, v in mk.items() if n_ == dom]
                 if var:
                     wsum = sum(v["launches"] * v["avg_launch_us"] for v in var)
                     mfma_pmc = {"mfma_pipe_busy": round(sum(v["mfma_util"] * v["launches"] * v["avg_launch_us"] for v in var) / wsum, 4),
@@ -311,8 +321,22 @@ def main():
                                 "source": "profiles/" + os.path.basename(mpath) + " (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, same command at --batch 4)"}
             except Exception:
                 mfma_pmc = None
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        # which roof bounds the row: HBM when its algorithmic intensity (executed flop per algorithmic byte, fused epilogue operands
+        # included) is below the machine balance (peak flop/s / peak byte/s), or when the committed PMC pass shows the MFMA pipe under
+        # 35 % busy -- then `achieved` is bytes/s against the HBM peak
+        balance = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        hbm_bound = (flx / max(by, 1.0)) < balance or (mfma_pmc is not None and mfma_pmc["mfma_pipe_busy"] < 0.35)
+        if hbm_bound:
+            ach_b = by / tt / 1e9
+            head = {"bound": "hbm", "kernel": dom, "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_b / HBM_PEAK_GBS, 4),
+                    "mfma_tflops": round(ach, 1), "mfma_frac": round(ach / MFMA_PEAK_TFLOPS, 4)}
+        else:
+            head = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                    "hbm_gbs": round(by / tt / 1e9, 1)}
+        roof = {**head, "traffic": traffic,
+                "selection": "largest share of the timed region by rocprofv3 row (template instance); families = the same time summed per kernel source",
+                "families": {k_: {"share_of_step_time": round(v[0] / dt, 3), "achieved_tflops": round(v[1] / v[0] / 1e12, 1), "launches": v[2]}
+                             for k_, v in sorted(fam.items(), key=lambda kv: -kv[1][0])},
                 "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/" + os.path.basename(tpath) + "; "
                                 "FETCH_SIZE doubled per MI355X_MICROARCH.md), same command at --batch 4 (one KBPN micro-batch of 4, as in the default run)" if traffic else None,
                 "mfma_pmc": mfma_pmc, "launches": nl, "avg_launch_ms": round(tt * 1e3 / max(nl, 1), 4),

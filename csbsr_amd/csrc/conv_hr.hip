@@ -459,8 +459,8 @@ extern "C" int csbsr_conv_hr_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   k.tiles_x = (unsigned)((d->W + HR_TW - 1) / HR_TW); k.tiles_y = (unsigned)((d->H + HR_TH - 1) / HR_TH);
   CSBSR_CHECK(d->in[0].sy < (1l << 31) / 64, "conv_hr: row stride too large for 32-bit piece offsets");
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  g_last_conv_kernel = CONVK_HR;
   const bool two = k.ntile_c >= 2;
+  g_last_conv_kernel = CONVK_HR | ((d->in[0].c == 32 ? 0 : 1) | (d->KH == 3 ? 0 : 2) | (two ? 4 : 0) | (k.mask ? 8 : 0) | (k.stat ? 16 : 0) | (k.cbias ? 32 : 0)) << 8;      // bits 8..: <CH8 7, 1x1, two cout tiles, mask, stat, class bias>
   if (d->KH == 3) {
     if (d->in[0].c == 32) return two ? launch_hr<4, 9, 2>(k, st) : launch_hr<4, 9, 1>(k, st);
     return two ? launch_hr<7, 9, 2>(k, st) : launch_hr<7, 9, 1>(k, st);

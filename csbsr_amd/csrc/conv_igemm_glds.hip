@@ -606,7 +606,8 @@ int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   const bool wide = big && g_glds_wide && k.coutp >= 256 && pad256 * 8 <= pad128 * 9 + 64;
   const bool gk = conv_glds_general_k(k);
   const int tile = k.coutp <= 64 ? 0 : (!big ? 1 : (wide ? 3 : 2));
-  g_last_conv_kernel = tile == 0 ? CONVK_GLDS64 : (tile == 1 ? CONVK_GLDS128 : (tile == 3 ? CONVK_GLDS256W : CONVK_GLDS256));
+  g_last_conv_kernel = (tile == 0 ? CONVK_GLDS64 : (tile == 1 ? CONVK_GLDS128 : (tile == 3 ? CONVK_GLDS256W : CONVK_GLDS256))) |
+                       ((k.fs ? 1 : 0) | (gk ? 2 : 0)) << 8;      // bits 8..: the template instance (FS, GK), one rocprof row each
 #define GLDS_DISPATCH(FS_, GK_)                                                                      \
   switch (tile) {                                                                                    \
     case 0: return launch_glds<128, 2, 2, 0, FS_, GK_>(k, nphase, maxM, st);                        \

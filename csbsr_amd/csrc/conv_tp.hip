@@ -547,11 +547,11 @@ extern "C" int csbsr_conv_tp_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
     (void)hipMemset(g_tp_zero_page[dev], 0, 256 + 1024);
   }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  g_last_conv_kernel = CONVK_TP;
   half_t* zp = g_tp_zero_page[dev];
   const bool r = d->res_mode != CSBSR_RES_NONE, a = d->accumulate != 0, m = d->mask != nullptr;
   // the instantiated epilogues: forward (plain / residual), dgrad (plain / accumulate / mask / accumulate + mask)
   const bool st_ = d->dact_bias || d->dact_prelu;
+  g_last_conv_kernel = CONVK_TP | ((r ? 1 : 0) | (a ? 2 : 0) | (m ? 4 : 0) | ((m && (st_ || (r && d->dres))) ? 8 : 0)) << 8;      // bits 8..: <res, acc, mask, sums>
   if (!r && !a && !m) return launch_tp<2, false, false, false, false>(k, st, zp, nullptr, nullptr);
   if (r && !a && !m) return launch_tp<2, true, false, false, false>(k, st, zp, nullptr, nullptr);
   if (!r && a && !m) return launch_tp<2, false, true, false, false>(k, st, zp, nullptr, nullptr);

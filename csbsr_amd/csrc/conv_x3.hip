@@ -480,7 +480,8 @@ extern "C" int csbsr_conv_x3_forward(const csbsr_conv_desc_t* d, csbsr_stream_t 
   const unsigned items = q.tiles_x * q.tiles_y * (unsigned)d->N * q.nct;
   const unsigned g = items < (unsigned)ncu ? items : (unsigned)ncu;
   const bool fast_rows = conv_epilogue_fast_ok(k);      // (launch_x3_epi picks the instance by the same test)
-  g_last_conv_kernel = strided ? (fast_rows ? CONVK_X3SF : CONVK_X3S) : (fast_rows ? CONVK_X3F : CONVK_X3);
+  g_last_conv_kernel = (strided ? (fast_rows ? CONVK_X3SF : CONVK_X3S) : (fast_rows ? CONVK_X3F : CONVK_X3)) |
+                       ((!strided && !fast_rows && x3_sft_rows_ok(k)) ? 1 : 0) << 8;      // bit 8: the <3, 2048> instance (sigmoid / FMA rows)
 #ifdef CSBSR_X3_ABLATE
   if (!strided) {
     hipStream_t st_ = reinterpret_cast<hipStream_t>(s);

@@ -11,7 +11,10 @@ extern "C" {
  * conv_igemm_glds_kernel<128,2,2 | 256,4,3 | 256,4,2,2>, 5 conv_thin_cout_kernel, 6 conv_thin_cin_kernel,
  * 8 conv_hr_kernel, 9 conv_tp_kernel, 10 conv_x3_kernel<3>, 11 conv_thin_tp_kernel, 12 conv_x3_kernel<2>, 13 conv_thin_cin2_kernel,
  * 14 conv_igemm_glds_kernel<128,2,2,0>, 15 conv_thin_sc_kernel, 16 conv_thin_tpd_kernel,
- * 17 / 18 conv_x3_kernel<3,1024> / <2,1024> (the instances with the straight-line epilogue rows) (bench.py's roofline block) */
+ * 17 / 18 conv_x3_kernel<3,1024> / <2,1024> (the instances with the straight-line epilogue rows) (bench.py's roofline block).
+ * Bits 8.. = the template instance within the kernel (one rocprofv3 row each): conv_igemm_glds 1 FS (fused split stage) | 2 GK (general K
+ * walk); conv_tp 1 res | 2 acc | 4 mask | 8 sums; conv_hr 1 seven-octet input | 2 1x1 | 4 two cout tiles | 8 mask | 16 stat | 32 class bias; conv_x3<3> 1 = the
+ * <3,2048> instance */
 int32_t csbsr_debug_last_conv_kernel(void);
 /* same for csbsr_conv_wgrad: 0 conv_wgrad_kernel<128,128,2,2>, 1 <128,256,2,4>, 2 <64,128,2,2>, 3 <32,128,1,4>, 4 conv_wgrad_thin_kernel,
  * 5 / 6 / 7 / 9 conv_wgrad_glds_kernel<128,128,..> / <128,256,..> / <256,256,..> / <128,512,..>, 8 conv_wgrad_hr_kernel */

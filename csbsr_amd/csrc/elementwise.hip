@@ -505,79 +505,143 @@ extern "C" int csbsr_plane_reduce(const float* a, const float* b, int32_t planes
 // Per-sample, per-channel mean of an fp16 NHWC map over a regular SUBSAMPLE of its pixels (every step-th row and column): the input
 // statistic of the weight-rounding compensation (csbsr_amd/engine.py Conv._dc_bias) -- a correction term of relative size 2^-12, for
 // which a 1 / step^2 sample of the pixels is plenty (>= 1e4 pixels per channel at the sizes that matter) and costs 1 / step^2 of a pass
-// over the map.  grid = (channel octets, slices, N): a workgroup sums its share of a sample's sampled pixels of its channel octet in a
-// fixed order (thread-strided, then a fixed LDS tree).  Small maps: one slice, the means are written directly (one launch).  Large
-// maps (>= 16384 sampled pixels per sample, HR 1792^2): 8 slices write partial rows and csbsr_sum_partials_batched folds them in a fixed
-// tree -- one workgroup per octet and sample was latency-bound there (~200 us per call for 3 MB of reads).  Bit-reproducible like every
-// reduction here, and a function of the sample alone (KBPN stays free of batch-coupled operations).
-#define CM_SLICES 8
+// over the map.  grid = (slices, N); a workgroup walks its share of a sample's sampled pixels with ALL channel octets of a pixel on
+// neighbouring lanes (256 / octets pixels per pass), so every cache line of a sampled pixel is fetched once, by one workgroup.  (Round 4
+// gave every channel octet its own workgroup: the 16 octets of a 128-channel pixel -- two lines -- were fetched by 16 workgroups on 8
+// XCDs, 0.42 GB per HR launch for 51 MB of sampled pixels, 4.5 GB per image-step.)  Each lane keeps the sums of its (pixel lane, octet);
+// the pixel lanes of an octet are added in lane order through LDS; slices write partial rows that csbsr_sum_partials_batched folds in a
+// fixed tree.  Bit-reproducible like every reduction here, and a function of the sample alone (KBPN stays free of batch-coupled
+// operations).
+#define CM_MAX_SLICES 64
 __global__ __launch_bounds__(256) void channel_mean_sub_kernel(const half_t* x, long sn, long sy, long sx, int H, int W, int step,
                                                                 float inv_count, float* part, int cp) {
   __shared__ float sm[256][8];
-  const int oct = blockIdx.x, slice = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
-  const int nsl = gridDim.y;
+  const int slice = blockIdx.x, nsl = gridDim.x, n = blockIdx.y, tid = threadIdx.x;
   const int hs = (H + step - 1) / step, ws = (W + step - 1) / step;
-  const int total = hs * ws;
-  float a[8];
+  const int total = hs * ws, nocts = cp >> 3;
+  for (int oct0 = 0; oct0 < nocts; oct0 += 256) {           // (more than 256 octets: 2048+ channels, not on today's path)
+    const int no = nocts - oct0 < 256 ? nocts - oct0 : 256;
+    const int P = 256 / no;                                  // pixels per pass
+    const int pl = tid / no, oct = oct0 + tid % no;
+    float a[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    if (pl < P) {
 #pragma unroll 4      // (independent loads: several in flight per thread -- the kernel is latency-bound)
-  for (int i = slice + nsl * tid; i < total; i += nsl * 256) {
-    const int y = (i / ws) * step, xx = (i % ws) * step;
-    const h8 v = *reinterpret_cast<const h8*>(x + n * sn + y * sy + xx * sx + oct * 8);
+      for (int i = slice * P + pl; i < total; i += nsl * P) {
+        const int y = (i / ws) * step, xx = (i % ws) * step;
+        const h8 v = *reinterpret_cast<const h8*>(x + n * sn + y * sy + xx * sx + oct * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
-  }
+        for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+      }
+    }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) sm[tid][e] = a[e];
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) {
+    for (int e = 0; e < 8; ++e) sm[tid][e] = a[e];
+    __syncthreads();
+    if (tid < no) {                                          // pixel lanes of this octet, in lane order
+      float r[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) sm[tid][e] += sm[tid + o][e];
+      for (int e = 0; e < 8; ++e) r[e] = 0.f;
+      for (int q = 0; q < P; ++q) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] += sm[q * no + tid][e];
+      }
+      float* dst = part + ((long)n * nsl + slice) * cp + (oct0 + tid) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e] = r[e] * inv_count;
     }
     __syncthreads();
   }
-  if (tid < 8) part[((long)n * nsl + slice) * cp + oct * 8 + tid] = sm[0][tid] * inv_count;
 }
 extern "C" int csbsr_channel_mean_sub(const void* x, int64_t sn, int64_t sy, int64_t sx, int32_t N, int32_t H, int32_t W, int32_t cp,
                                       int32_t step, float* out /*[N][cp], overwritten*/, csbsr_stream_t s) {
   CSBSR_CHECK(x && out && cp > 0 && cp % 8 == 0 && step >= 1 && N > 0 && H > 0 && W > 0, "channel_mean_sub: bad args");
   const long count = (long)((H + step - 1) / step) * ((W + step - 1) / step);
-  if (count < 16384) {
-    hipLaunchKernelGGL(channel_mean_sub_kernel, dim3(cp / 8, 1, N), dim3(256), 0, ST(s), (const half_t*)x, (long)sn, (long)sy, (long)sx, H, W,
+  const int P = (cp >> 3) >= 256 ? 1 : 256 / (cp >> 3);
+  long nsl = (count + (long)P * 16 - 1) / ((long)P * 16);      // >= 16 passes per workgroup
+  if (nsl > CM_MAX_SLICES) nsl = CM_MAX_SLICES;
+  if (nsl <= 1) {
+    hipLaunchKernelGGL(channel_mean_sub_kernel, dim3(1, N), dim3(256), 0, ST(s), (const half_t*)x, (long)sn, (long)sy, (long)sx, H, W,
                        step, 1.f / (float)count, out, cp);
   } else {
-    float* part = csbsr_red_scratch((long)N * CM_SLICES * cp);
+    float* part = csbsr_red_scratch((long)N * nsl * cp);
     CSBSR_NEED_SCRATCH(part, "channel_mean_sub");
     CSBSR_CHECK(hipMemsetAsync(out, 0, (size_t)N * cp * sizeof(float), ST(s)) == hipSuccess, "channel_mean_sub: memset failed");
-    hipLaunchKernelGGL(channel_mean_sub_kernel, dim3(cp / 8, CM_SLICES, N), dim3(256), 0, ST(s), (const half_t*)x, (long)sn, (long)sy, (long)sx, H, W,
+    hipLaunchKernelGGL(channel_mean_sub_kernel, dim3((unsigned)nsl, N), dim3(256), 0, ST(s), (const half_t*)x, (long)sn, (long)sy, (long)sx, H, W,
                        step, 1.f / (float)count, part, cp);
-    if (csbsr_sum_partials_batched(part, CM_SLICES, cp, cp, out, N, cp, ST(s))) return 1;
+    if (csbsr_sum_partials_batched(part, (int)nsl, cp, cp, out, N, cp, ST(s))) return 1;
   }
   CSBSR_LAUNCH_CHECK("csbsr_channel_mean_sub");
   return 0;
 }
 
-// The two small contractions of the weight-rounding compensation (engine.Conv._dc_bias), one launch each:
-//   dc_table:  S[o][c] = sum over taps of (w - fp16(w))[o][c][tap]            (once per layer and optimiser step)
-//   dc_bias:   out[n][o] = (bias ? bias[o] : 0) + sum_c S[o][c] * mean[n][c]    (once per layer and forward; the means of up to two
-//              input segments, c0 / c1 real channels each).  One wave per (sample, output channel): lanes stride the channels, fixed
-//              xor-shuffle tree -- order-fixed.
-__global__ void dc_table_kernel(const float* w, float* S, long rows, int taps) {
+// Weight rounding for the plain-fp16 (KBPN) layers and the two small contractions of its compensation (engine.Conv._wq / _dc_bias):
+//   round_weights: wq = the fp16 value each weight is multiplied as (held as fp32), S[o][c] = sum over taps of (w - wq)[o][c][tap]
+//                  (once per layer and optimiser step).  mode 0: round to nearest.  mode >= 1: TAP-SUM-PRESERVING -- after rounding to nearest,
+//                  per (o, c) and tap group the taps that sat closest to a rounding midpoint move to their other fp16 neighbour until the
+//                  group's summed residual is below half an ulp, so the rounding error of a filter has (almost) no response to an input that
+//                  is constant over its footprint.  Group = all taps (mode 1: Conv2d, any stride) or the taps (ky % mode, kx % mode) one
+//                  output PHASE of a stride-``mode`` transposed convolution sees.  What is left of the response to the input's mean goes
+//                  back through the bias (S, dc_bias).  CPU study: tests/study_kbpn_precision.py (segmentation map of the contractive
+//                  fixture, W + X plan: 1.61e-3 nearest, 1.38e-3 nearest + bias, 1.15e-3 tap-sum + bias).
+//   dc_bias:       out[n][o] = (bias ? bias[o] : 0) + sum_c S[o][c] * mean[n][c]    (once per layer and forward; the means of up to two
+//                  input segments, c0 / c1 real channels each).  One wave per (sample, output channel): lanes stride the channels, fixed
+//                  xor-shuffle tree -- order-fixed.
+__device__ __forceinline__ float f16_spacing(float q, float dir) {      // distance from the fp16 value q to its neighbour in direction dir (+-1)
+  const float a = fabsf(q);
+  if (a <= 6.103515625e-05f) return 5.9604644775390625e-08f;     // subnormals and the smallest normal: 2^-24 either way
+  int e;
+  const float m = frexpf(a, &e);                                 // a = m 2^e, m in [0.5, 1)
+  const bool inward = q * dir < 0.f;                             // towards zero: below a power of two the grid is twice as fine
+  return ldexpf(1.f, e - ((inward && m == 0.5f) ? 12 : 11));
+}
+__global__ void round_weights_kernel(const float* w, float* wq, float* S, long rows, int KH, int KW, int mode) {
+  const int T = KH * KW;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
-    const float* q = w + i * taps;
-    float a = 0.f;
-    for (int t = 0; t < taps; ++t) a += q[t] - (float)(half_t)q[t];
-    S[i] = a;
+    const float* src = w + i * T;
+    float* q = wq + i * T;
+    for (int t = 0; t < T; ++t) q[t] = (float)(half_t)src[t];
+    if (mode >= 1 && T > 1) {
+      const int ng = mode * mode;
+      for (int g = 0; g < ng; ++g) {
+        const int gy = g / mode, gx = g % mode;
+        for (int it = 0; it < T; ++it) {
+          float r = 0.f;
+          for (int ky = gy; ky < KH; ky += mode)
+            for (int kx = gx; kx < KW; kx += mode) r += src[ky * KW + kx] - q[ky * KW + kx];
+          if (r == 0.f) break;
+          const float sg = r > 0.f ? 1.f : -1.f;
+          int best = -1;
+          float bs = 0.f, bu = 0.f;
+          for (int ky = gy; ky < KH; ky += mode)
+            for (int kx = gx; kx < KW; kx += mode) {
+              const int t = ky * KW + kx;
+              const float d = src[t] - q[t];
+              if (d * sg <= 0.f) continue;
+              const float u = f16_spacing(q[t], sg);
+              if (fabsf(r) - fabsf(r - sg * u) <= 0.f) continue;       // moving this tap would not shrink the group's residual
+              const float sc = fabsf(d) / u;                            // closest to its rounding midpoint first: least extra error
+              if (sc > bs) { bs = sc; best = t; bu = u; }
+            }
+          if (best < 0) break;
+          q[best] = (float)(half_t)(q[best] + sg * bu);
+        }
+      }
+    }
+    if (S) {
+      float a = 0.f;
+      for (int t = 0; t < T; ++t) a += src[t] - q[t];
+      S[i] = a;
+    }
   }
 }
-extern "C" int csbsr_dc_table(const float* w, float* S, int32_t D0, int32_t D1, int32_t taps, csbsr_stream_t s) {
-  CSBSR_CHECK(w && S && D0 > 0 && D1 > 0 && taps > 0, "dc_table: bad args");
+extern "C" int csbsr_round_weights(const float* w, float* wq, float* S, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t mode,
+                                   csbsr_stream_t s) {
+  CSBSR_CHECK(w && wq && D0 > 0 && D1 > 0 && KH > 0 && KW > 0 && mode >= 0 && mode <= KH && mode <= KW, "round_weights: bad args");
   const long rows = (long)D0 * D1;
-  const int blocks = (int)((rows + 255) / 256 > 2048 ? 2048 : (rows + 255) / 256);
-  hipLaunchKernelGGL(dc_table_kernel, dim3(blocks), dim3(256), 0, ST(s), w, S, rows, taps);
-  CSBSR_LAUNCH_CHECK("csbsr_dc_table");
+  const int blocks = (int)((rows + 63) / 64 > 4096 ? 4096 : (rows + 63) / 64);
+  hipLaunchKernelGGL(round_weights_kernel, dim3(blocks), dim3(64), 0, ST(s), w, wq, S, rows, KH, KW, mode);
+  CSBSR_LAUNCH_CHECK("csbsr_round_weights");
   return 0;
 }
 __global__ __launch_bounds__(256) void dc_bias_kernel(const float* S, int cin, const float* m0, long m0_ld, int c0, const float* m1, long m1_ld, int c1,

@@ -120,6 +120,7 @@ class Engine:
         self.use_tp = os.environ.get("CSBSR_CONV_TP", "1") != "0"       # A/B hook: 0 routes the 2x2-tap transposed layers through the implicit-GEMM kernels
         self.split_fused = os.environ.get("CSBSR_SPLIT_FUSED", "1") != "0"   # A/B hook: 0 = the three-block split forward (x_hi staged twice)
         self.dc_comp = os.environ.get("CSBSR_DC_COMP", "1") != "0"           # A/B hook: 0 = no compensation of the forward weights' fp16 rounding (Conv._dc_bias)
+        self.tapsum = os.environ.get("CSBSR_TAPSUM", "1") != "0"             # A/B hook: 0 = KBPN weights rounded to nearest instead of tap-sum-preserving (Conv._wq)
         # Weight gradients on a second HIP stream (opt-in, CSBSR_WGRAD_STREAM=1).  In the backward a layer's wgrad is a side branch (it
         # only feeds the parameter's gradient accumulator) while the dgrad chain is the critical path; the wgrads are MFMA-bound on
         # L2-resident tiles, much of what the chain runs between two of its convolutions is HBM-bound, so two streams could let the
@@ -292,10 +293,31 @@ class Conv:
         D0, D1 = self.w.shape[0], self.w.shape[1]
         n = L.load().csbsr_packed_weight_elems(kind, D0, D1, self.k, self.k, stride, seg0, seg1, nrows)
         dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
-        L.call("csbsr_pack_weights", _ptr(self.w), _ptr(dst), kind, D0, D1, self.k, self.k, stride, pad, seg0, seg1, row_off, nrows,
+        L.call("csbsr_pack_weights", _ptr(self._wq()), _ptr(dst), kind, D0, D1, self.k, self.k, stride, pad, seg0, seg1, row_off, nrows,
                k_off, self.eng.stream)
         self._packed[key] = dst
         return dst
+
+    def _wq(self):
+        """the fp32 tensor the plain-fp16 operand packs read: the master weights, or -- on the layers that carry the rounding compensation
+        (``dc_comp``: KBPN but its per-stage kernel predictors) -- their TAP-SUM-PRESERVING fp16 rounding (csbsr_round_weights, held as fp32
+        so every pack kernel converts it exactly; once per optimiser step).  Nearest rounding leaves each filter a residual whose tap sum
+        is a random walk of ~0.3 sqrt(taps) ulp: a spatially coherent per-(o, c) gain error that a low-pass detector passes in full.
+        Moving the one or two taps nearest to a rounding midpoint to their other neighbour brings the tap sum under half an ulp (3x3:
+        rms 3.6e-5 -> 6e-6 of kaiming-scaled weights, per-tap error +9 %) -- per output phase for transposed layers, which the bias form
+        of the compensation (_dc_bias) cannot reach.  tests/study_kbpn_precision.py, the build's W + X storage plan on the contractive PSPNet
+        fixture: segmentation map 1.61e-3 (nearest) / 1.38e-3 (nearest + bias, round 4) / 1.21e-3 (tap-sum) / 1.15e-3 (tap-sum + bias, this);
+        relative L2 7.8 / 5.6 / 5.4 / 4.5e-4.  Forward, dgrad and wgrad operands all come from the same rounded tensor."""
+        if not (self.dc_comp and self.eng.tapsum):
+            return self.w
+        q = self._packed.get("wq")
+        if q is None:
+            q = torch.empty_like(self.w)
+            S = torch.empty(self.w.shape[0], self.w.shape[1], dtype=torch.float32, device=self.eng.device)
+            mode = self.stride if (self.transposed and self.stride > 1) else 1
+            L.call("csbsr_round_weights", _ptr(self.w), _ptr(q), _ptr(S), self.w.shape[0], self.w.shape[1], self.k, self.k, mode, self.eng.stream)
+            self._packed["wq"], self._packed["dc_table"] = q, S
+        return q
 
     # split-fp16 forward operand (detector precision mode): [w_hi | w_hi | w_lo] per tap, weights pre-scaled by WSCALE (undone by
     # the epilogue's out_scale) so the lo halves of kaiming-sized weights stay in fp16's normal range
@@ -343,9 +365,14 @@ class Conv:
         assert not self.transposed and 1 <= len(xs) <= 2
         S = self._packed.get("dc_table")
         if S is None:
-            S = torch.empty(self.w.shape[0], self.w.shape[1], dtype=torch.float32, device=self.eng.device)
-            L.call("csbsr_dc_table", _ptr(self.w), _ptr(S), self.w.shape[0], self.w.shape[1], self.k * self.k, self.eng.stream)
-            self._packed["dc_table"] = S
+            if self.eng.tapsum:
+                self._wq()                      # tap sums of what the tap-sum-preserving rounding left
+                S = self._packed["dc_table"]
+            else:                               # (A/B: round to nearest)
+                S = torch.empty(self.w.shape[0], self.w.shape[1], dtype=torch.float32, device=self.eng.device)
+                scratch = torch.empty_like(self.w)
+                L.call("csbsr_round_weights", _ptr(self.w), _ptr(scratch), _ptr(S), self.w.shape[0], self.w.shape[1], self.k, self.k, 0, self.eng.stream)
+                self._packed["dc_table"] = S
         ms = []
         for f in xs:
             if f.bcast:
@@ -455,7 +482,7 @@ class Conv:
             if key not in self._packed:
                 n = L.load().csbsr_packed_weight_elems_hr(k, c_real, rows_real)
                 dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
-                L.call("csbsr_pack_weights_hr", _ptr(self.w), _ptr(dst), kind, k, self.w.shape[0], self.w.shape[1], c_real, rows_real, row_off, 0,
+                L.call("csbsr_pack_weights_hr", _ptr(self._wq()), _ptr(dst), kind, k, self.w.shape[0], self.w.shape[1], c_real, rows_real, row_off, 0,
                        self.eng.stream)
                 self._packed[key] = dst
             d.wt = _ptr(self._packed[key])
@@ -469,12 +496,12 @@ class Conv:
                 if kind == 2:
                     n = L.load().csbsr_packed_weight_elems_x3_strided(stride, c_real, rows_real)
                     dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
-                    L.call("csbsr_pack_weights_x3_strided", _ptr(self.w), _ptr(dst), self.w.shape[0], self.w.shape[1], k, stride, c_real,
+                    L.call("csbsr_pack_weights_x3_strided", _ptr(self._wq()), _ptr(dst), self.w.shape[0], self.w.shape[1], k, stride, c_real,
                            rows_real, row_off, k_off, self.eng.stream)
                 else:
                     n = L.load().csbsr_packed_weight_elems_x3(c_real, rows_real)
                     dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
-                    L.call("csbsr_pack_weights_x3", _ptr(self.w), _ptr(dst), kind, self.w.shape[0], self.w.shape[1], c_real, rows_real, row_off,
+                    L.call("csbsr_pack_weights_x3", _ptr(self._wq()), _ptr(dst), kind, self.w.shape[0], self.w.shape[1], c_real, rows_real, row_off,
                            k_off, self.eng.stream)
                 self._packed[key] = dst
             d.wt = _ptr(self._packed[key])
@@ -486,7 +513,7 @@ class Conv:
             if key not in self._packed:
                 n = L.load().csbsr_packed_weight_elems_tp(stride, c_real)
                 dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
-                L.call("csbsr_pack_weights_tp", _ptr(self.w), _ptr(dst), self.w.shape[0], self.w.shape[1], k, k, stride, pad, c_real, rows_real,
+                L.call("csbsr_pack_weights_tp", _ptr(self._wq()), _ptr(dst), self.w.shape[0], self.w.shape[1], k, k, stride, pad, c_real, rows_real,
                        row_off, k_off, self.eng.stream)
                 self._packed[key] = dst
             d.wt = _ptr(self._packed[key])
@@ -504,7 +531,11 @@ class Conv:
             npx = x0.N * OH * OW
             taps = k * k if not transposed else ((k + stride - 1) // stride) ** 2
             flops = 2.0 * npx * cout * ctot * taps
-            nbytes = 2.0 * (sum(0 if f.bcast else f.N * f.H * f.W * f.c for f in (xs[:1] if twice else xs)) + (npx * cout if out is not None else 0))
+            # algorithmic bytes: the input(s) once, the output once, and every map the fused epilogue reads (residuals, the accumulated-into
+            # output, the activation-derivative mask) or writes besides (d(res)): what a fused launch cannot avoid moving
+            nepi = sum(1 for f in (res, res2) if f is not None and not f.bcast) + int(bool(accumulate)) + int(mask is not None or dact is not None) + int(dres is not None)
+            nbytes = 2.0 * (sum(0 if f.bcast else f.N * f.H * f.W * f.c for f in (xs[:1] if twice else xs)) + (npx * cout if out is not None else 0)
+                            + nepi * npx * cout)
             tm.append(("conv", flops, nbytes, ev0, ev1, self.name, (x0.N, H, W, ctot, cout, k, stride, int(transposed)),
                        int(L.load().csbsr_debug_last_conv_kernel()), executed))
 

@@ -306,10 +306,15 @@ int csbsr_plane_reduce(const float* a, const float* b, int32_t planes, int64_t h
  * (csbsr_amd/engine.py Conv._dc_bias; nothing in the reference corresponds to it -- the reference multiplies fp32 weights).  Order-fixed. */
 int csbsr_channel_mean_sub(const void* x, int64_t sn, int64_t sy, int64_t sx, int32_t N, int32_t H, int32_t W, int32_t cp,
                            int32_t step, float* out, csbsr_stream_t s);
-/* the same compensation's two small contractions: S[o][c] = sum over taps of (w - fp16(w))[o][c][tap] for a conv weight [D0][D1][taps], and
- * out[n][o] = (bias ? bias[o] : 0) + sum_c S[o][c] * mean[n][c] with the means of up to two input segments (c0 / c1 real channels, row
- * strides m0_ld / m1_ld) -- the per-sample bias rows handed to csbsr_conv_forward with bias_sn = cout */
-int csbsr_dc_table(const float* w, float* S, int32_t D0, int32_t D1, int32_t taps, csbsr_stream_t s);
+/* How the plain-fp16 (KBPN) layers round their fp32 master weights [D0][D1][KH][KW] (F.conv2d / F.conv_transpose2d of the reference multiply
+ * fp32 weights, kbpn.py:196-289; this build multiplies fp16 ones): wq = the fp16 value of every weight, held as fp32 (the csbsr_pack_weights*
+ * calls then convert exactly), S (optional) [D0][D1] = sum over taps of (w - wq).  mode 0 = round to nearest; mode >= 1 = tap-sum-preserving:
+ * per (d0, d1) and tap group -- all taps (mode 1: Conv2d of any stride) or the taps (ky % mode, kx % mode) that one output phase of a
+ * stride-``mode`` ConvTranspose2d sees -- taps move to their other fp16 neighbour until the group's summed rounding residual is under half an
+ * ulp: the residual filter has no response to locally constant input.  csbsr_dc_bias: out[n][o] = (bias ? bias[o] : 0) + sum_c S[o][c] *
+ * mean[n][c] with the means of up to two input segments (c0 / c1 real channels, row strides m0_ld / m1_ld) -- the per-sample bias rows
+ * handed to csbsr_conv_forward with bias_sn = cout, giving back what is left of the residual's response to the input's mean */
+int csbsr_round_weights(const float* w, float* wq, float* S, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t mode, csbsr_stream_t s);
 int csbsr_dc_bias(const float* S, int32_t cout, int32_t cin, const float* m0, int64_t m0_ld, int32_t c0, const float* m1, int64_t m1_ld,
                   int32_t c1, const float* bias, int32_t N, float* out, csbsr_stream_t s);
 int csbsr_instnorm_bwd(const void* dy, int64_t dy_ld, const float* x, const float* mean, const float* invstd,

@@ -23,44 +23,8 @@ DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r03"
 
 
-def canon(name):
-    """kernel name as bench.py prints it"""
-    m = re.search(r"conv_igemm_glds_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name) or re.search(r"conv_igemm_glds_kernel<(\d+), (\d+), (\d+), (\d+)>", name)
-    if m:      # <BM, wave rows, stages, cout tiles>: the single-cout-tile variants keep their three-parameter name
-        g = m.groups()
-        return "conv_igemm_glds_kernel<%s,%s,%s>" % g[:3] if g[3] == "1" else "conv_igemm_glds_kernel<%s,%s,%s,%s>" % g
-    m = re.search(r"conv_igemm_glds_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name) or re.search(r"conv_igemm_glds_kernel<(\d+), (\d+), (\d+)>", name)
-    if m:
-        return "conv_igemm_glds_kernel<%s,%s,%s>" % m.groups()
-    m = re.search(r"conv_igemm_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name) or re.search(r"conv_igemm_kernel<(\d+), (\d+), (\d+)>", name)
-    if m:
-        return "conv_igemm_kernel<%s,%s,%s>" % m.groups()
-    m = re.search(r"conv_wgrad_glds_kernelILi(\d+)ELi(\d+)E", name) or re.search(r"conv_wgrad_glds_kernel<(\d+), (\d+)", name)
-    if m:
-        return "conv_wgrad_glds_kernel<%s,%s>" % m.groups()
-    m = re.search(r"conv_wgrad_kernel<(\d+), (\d+), (\d+), (\d+)", name) or re.search(r"conv_wgrad_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
-    if m:
-        return "conv_wgrad_kernel<%s,%s,%s,%s>" % m.groups()
-    m = re.search(r"conv_hr_kernelILi(\d+)ELb(\d)E", name) or re.search(r"conv_hr_kernel<(\d+), (\w+)>", name)
-    if m:
-        return "conv_hr_kernel<%s>" % m.group(1)
-    m = re.search(r"conv_tp_kernelILi\d+ELb(\d)ELb(\d)ELb(\d)E", name)
-    if m:
-        return "conv_tp_kernel<res=%s,acc=%s,mask=%s>" % m.groups()
-    m = re.search(r"conv_x3_kernelILi(\d)ELi2048E", name) or re.search(r"conv_x3_kernel<(\d), 2048>", name)
-    if m:      # the instance with the SFT conv1 rows (sigmoid / bias + res x res2): bench.py counts it with the general-row instance
-        return "conv_x3_kernel<%s>" % m.group(1)
-    m = re.search(r"conv_x3_kernelILi(\d)ELi1024E", name) or re.search(r"conv_x3_kernel<(\d), 1024>", name)
-    if m:      # the instance with the straight-line epilogue rows (csrc/conv_x3.hip)
-        return "conv_x3_kernel<%s,1024>" % m.group(1)
-    m = re.search(r"conv_x3_kernelILi(\d)E", name) or re.search(r"conv_x3_kernel<(\d)", name)
-    if m:
-        return "conv_x3_kernel<%s>" % m.group(1)
-    for k in ("conv_wgrad_hr_kernel", "conv_wgrad_thin_kernel", "conv_wgrad_kernel", "conv_thin_cout_kernel", "conv_thin_cin2_kernel", "conv_thin_cin_kernel", "epilogue_bwd_kernel",
-              "unpack_wgrad_kernel", "bn_bwd_apply_kernel", "bn_bwd_reduce_kernel", "bn_apply_kernel"):
-        if k in name:
-            return k
-    return name[:60]
+sys.path.insert(0, ROOT)
+from csbsr_amd.utils.kernel_names import canon      # one name per rocprofv3 row, the one bench.py prints  # noqa: E402
 
 
 def pmc(path, counter):

@@ -19,12 +19,53 @@ from golden_utils import load_golden, golden_cfg, det_params, max_rel_to_scale, 
 from oracle import csbsr_oracle as O
 
 
+def tapsum_round(w, transposed=False, stride=1):
+    """fp16 rounding of a filter bank that keeps the TAP SUM of every (output, input) channel pair: round to nearest, then move the taps
+    whose value sat closest to a rounding midpoint to their other fp16 neighbour until sum_taps (w - w16) is within half an ulp.  The
+    rounding residual then has no response to any input that is constant over the filter's footprint (not only to the mean, and at no
+    run-time cost).  Transposed layers: per output PHASE (the taps ky % stride, kx % stride an output pixel of that phase sees).
+    Returns fp32 values that are exactly representable in fp16."""
+    w16 = w.half().float()
+    K0, K1 = w.shape[2], w.shape[3]
+    if transposed and stride > 1:
+        ph = (torch.arange(K0)[:, None] % stride) * stride + (torch.arange(K1)[None, :] % stride)
+        groups = [(ph == g).reshape(-1) for g in range(stride * stride)]
+    else:
+        groups = [torch.ones(K0 * K1, dtype=torch.bool)]
+    W = w.reshape(w.shape[0], w.shape[1], -1).clone()
+    Q = w16.reshape(w.shape[0], w.shape[1], -1).clone()
+    for gm in groups:
+        wv, q = W[:, :, gm], Q[:, :, gm].clone()
+        def spacing(q, sgn):        # distance to the fp16 neighbour in direction sgn: below a power of two the grid is twice as fine
+            a = q.abs().clamp_min(2.0 ** -14)
+            e = torch.floor(torch.log2(a))
+            inward = (q * sgn < 0) & (a == torch.exp2(e)) & (a > 2.0 ** -14)
+            return torch.exp2(e - 10 - inward.float())
+        for _ in range(wv.shape[-1]):
+            d = wv - q
+            r = d.sum(-1, keepdim=True)
+            sgn = torch.sign(r)
+            ulp = spacing(q, sgn)
+            gain = r.abs() - (r - sgn * ulp).abs()                    # how much |r| shrinks if this tap moves one ulp towards r
+            cand = (torch.sign(d) == sgn) & (gain > 0)
+            score = torch.where(cand, d.abs() / ulp, torch.full_like(d, -1.0))     # closest to its midpoint first: least extra error
+            best = score.argmax(-1, keepdim=True)
+            ok = score.gather(-1, best) > 0
+            if not bool(ok.any()):
+                break
+            step = torch.zeros_like(q).scatter_(-1, best, (sgn * ulp.gather(-1, best)) * ok)
+            q = (q + step).half().float()
+        Q[:, :, gm] = q
+    return Q.reshape(w.shape)
+
+
 class storage_sim:
     """comp: None | "bias" (per-sample channel means x tap sums of the rounding residual, non-transposed layers: what engine.Conv._dc_bias
     does) | "exact" (the residual filter's full response to the per-sample constant map, every layer: the upper bound of the idea)"""
 
     def __init__(self, names, round_w, round_x, comp=None):
         self.names, self.rw, self.rx, self.comp = names, round_w, round_x, comp
+        self.cache = {}
 
     def __enter__(self):
         self.saved = (F.conv2d, F.conv_transpose2d)
@@ -39,9 +80,17 @@ class storage_sim:
                 xi = r16(x) if self.rx(n) else x
                 if not self.rw(n):
                     return fn(xi, w, b, *a, **k)
-                w16 = r16(w)
+                if self.comp in ("tapsum", "tapsum+bias") and ".kernel_predictor." not in n:
+                    key = (id(w), transposed)
+                    if key not in self.cache:
+                        st = (a[0] if a else k.get("stride", 1))
+                        st = st[0] if isinstance(st, (tuple, list)) else st
+                        self.cache[key] = tapsum_round(w, transposed, int(st))
+                    w16 = self.cache[key]
+                else:
+                    w16 = r16(w)
                 y = fn(xi, w16, b, *a, **k)
-                if self.comp is None or ".kernel_predictor." in n:
+                if self.comp in (None, "tapsum") or ".kernel_predictor." in n:
                     return y
                 m = (xi[:, :, ::8, ::8] if xi.shape[-1] >= 64 else xi).mean(dim=(2, 3))          # per sample, subsampled like the build
                 if self.comp == "exact":
@@ -92,12 +141,16 @@ def main():
         rows.append((f"W + X, {gname}: X exact", yes, (lambda n, p=pred: not p(n))))
         rows.append((f"W + X, {gname}: both exact", (lambda n, p=pred: not p(n)), (lambda n, p=pred: not p(n))))
     print(f"{case}: error against the reference fixture, max|a-b|/max|b| (rel-L2)")
+    if os.environ.get("STUDY_QUICK"):
+        rows = rows[:4]
     for name, rw, rx in rows:
         e = run(rw, rx)
         print(f"{name:44s} sr {e[0]:.2e} ({e[1]:.2e})   seg {e[2]:.2e} ({e[3]:.2e})", flush=True)
     print("-- the weight term's structure: its response to the input's per-sample channel means, given back (engine.Conv._dc_bias)")
     for name, rw, rx, comp in (("W only + bias compensation (the build)", yes, no, "bias"), ("W only + exact mean response (bound)", yes, no, "exact"),
-                               ("W + X + bias compensation (the build)", yes, yes, "bias"), ("W + X + exact mean response (bound)", yes, yes, "exact")):
+                               ("W + X + bias compensation (the build)", yes, yes, "bias"), ("W + X + exact mean response (bound)", yes, yes, "exact"),
+                               ("W only, tap-sum-preserving rounding", yes, no, "tapsum"), ("W only, tap-sum rounding + bias comp.", yes, no, "tapsum+bias"),
+                               ("W + X, tap-sum-preserving rounding", yes, yes, "tapsum"), ("W + X, tap-sum rounding + bias comp.", yes, yes, "tapsum+bias")):
         e = run(rw, rx, comp)
         print(f"{name:44s} sr {e[0]:.2e} ({e[1]:.2e})   seg {e[2]:.2e} ({e[3]:.2e})", flush=True)
 

@@ -27,6 +27,7 @@ def test_bench_two_ranks_one_device():
     # the KBPN residency schedule is agreed over the ranks (one MIN all-reduce at the first forward) and reported with every rank's peak
     sch, red = d["schedule"], d["reducer"]
     assert sch["same_on_every_rank"] is True and len(sch["peak_mem_gb_per_rank"]) == 2 and sch["n_resident"] >= 1
+    assert len(sch["step_ms_per_rank"]) == 2 and max(sch["step_ms_per_rank"]) <= d["ms_per_step"] * 1.001      # every rank's own time; the line reports the slowest
     assert red["agreements"] == 1 and red["exposed_all_reduce_ms_per_step"] >= 0.0
 
 

@@ -495,3 +495,52 @@ def test_subsampled_channel_mean(N, H, W, c, step):
     ref = x[:, ::step, ::step].float().mean((1, 2))
     assert torch.equal(outs[0], outs[1])
     assert float((outs[0] - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape,mode", [((64, 32, 3, 3), 1), ((16, 24, 8, 8), 4), ((16, 24, 8, 8), 1), ((8, 8, 12, 12), 8), ((40, 24, 1, 1), 1),
+                                        ((5, 7, 3, 3), 0), ((128, 128, 8, 8), 4)])
+def test_tap_sum_preserving_weight_rounding(shape, mode):
+    """csbsr_round_weights (engine.Conv._wq): every value is an fp16 number at most one fp16 step from the weight; per (d0, d1) and tap
+    group (all taps, or the taps of one output phase of a stride-``mode`` transposed layer) the summed rounding residual is under half an
+    ulp of the group; S = the tap sums of what is left; mode 0 = round to nearest.  Against the study's CPU form of the same greedy rule
+    (tests/study_kbpn_precision.py::tapsum_round: ties may resolve differently, so a small mismatch fraction is allowed)."""
+    import ctypes as C
+    from csbsr_amd import _lib as L
+    from study_kbpn_precision import tapsum_round
+    eng = _eng()
+    g = torch.Generator().manual_seed(sum(shape) + mode)
+    w = torch.randn(shape, generator=g) / (shape[1] * shape[2] * shape[3]) ** 0.5
+    w.view(-1)[::97] *= 30.0                      # a few large and a few tiny values: other binades, fp16 subnormals
+    w.view(-1)[5::89] *= 1e-4
+    wd = w.cuda()
+    q = torch.empty_like(wd)
+    S = torch.empty(shape[0], shape[1], device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    L.call("csbsr_round_weights", P(wd), P(q), P(S), shape[0], shape[1], shape[2], shape[3], mode, eng.stream)
+    torch.cuda.synchronize()
+    q, S = q.cpu(), S.cpu()
+    assert torch.equal(q, q.half().float())
+    d = w - q
+    ulp = torch.exp2(torch.floor(torch.log2(q.abs().clamp_min(2.0 ** -14))) - 10)
+    assert bool((d.abs() <= ulp * 1.0001 + 1e-12).all())          # (ulp of the value it landed on: moves are to the NEIGHBOUR, also across a binade)
+    assert float((S - d.sum((2, 3))).abs().max()) < 1e-7
+    if mode == 0:
+        assert torch.equal(q, w.half().float())
+        return
+    K0, K1 = shape[2], shape[3]
+    ph = (torch.arange(K0)[:, None] % mode) * mode + (torch.arange(K1)[None, :] % mode)
+    d0 = w - w.half().float()
+    for gidx in range(mode * mode):
+        m = (ph == gidx)
+        r = d[:, :, m].sum(-1)
+        assert bool((r.abs() <= 0.5 * ulp[:, :, m].amax(-1) * 1.0001 + 1e-12).all()), gidx
+        if m.sum() >= 9:        # nearest rounding leaves a random walk: the preserved sums are several times smaller (judged on the filters without
+            # one of the 30x enlarged taps: such a tap keeps its own residual, nothing smaller can cancel it)
+            big = torch.zeros(w.numel(), dtype=torch.bool)
+            big[::97] = True
+            sel = ~big.view(shape)[:, :, m].any(-1)
+            assert int(sel.sum()) >= 20
+            assert float(r[sel].pow(2).mean().sqrt()) < 0.6 * float(d0[:, :, m].sum(-1)[sel].pow(2).mean().sqrt())
+    assert float(d.pow(2).mean().sqrt()) < 1.35 * float(d0.pow(2).mean().sqrt())      # the price: a few taps one step further away
+    ref = tapsum_round(w, transposed=mode > 1, stride=mode)
+    assert float((ref == q).float().mean()) > 0.995

@@ -2,6 +2,8 @@
 buffer-descriptor windows of the LDS-DMA kernels (csrc/conv_x3.hip, conv_hr.hip, conv_wgrad_glds.hip) and every 32-bit offset
 computation only exist at this size, and bench.py -- the only other full-size execution -- asserts nothing about its outputs.
 
+  * bench.py's own shape, B = 8 in two micro-batches of 4 (test_bench_size_step_batch_8_micro_batch_4), and configs 4 / 5 at their stated
+    batch of 4: finite, no overflow, bit-reproducible, samples 0-1 equal to the B = 2 run;
   * one joint-phase step at B = 2: every output and every gradient finite; whether KBPN runs as one micro-batch of 2 or two of 1 (no
     batch-coupled op) moves fp32 summation orders (which tiles a persistent workgroup folds into its partial sums of the global average
     pools, how the wgrad slabs are split) and, through the launch-size thresholds, which kernel takes a layer -- so the images agree to
@@ -72,6 +74,91 @@ def test_full_size_step_is_finite_and_micro_batch_invariant():
     sr = o2["sr"]
     a, b = sr[:, :, 520:800, 520:800], sr[:, :, 968:1248, 968:1248]
     assert float((a - b).abs().max()) <= 1e-3 * float(sr.abs().max())
+
+
+def test_bench_size_step_batch_8_micro_batch_4():
+    """bench.py's exact shape -- config 2 at B = 8, LR 448 -> HR 1792, two KBPN micro-batches of 4, the residency schedule chosen from the
+    free HBM (lean saves, both micro-batches resident at ~240 GB) -- where a 64-channel detector map at 1792^2 is 3.3 GB (past the 2 GB
+    buffer-descriptor windows a B = 2 run never crosses) and bench.py itself only prints a loss.  Properties: every output and all 290
+    gradients finite, no overflow; KBPN has no batch-coupled operation, so samples 0-1 -- the B = 2 batch, the other six are its flips --
+    must give the B = 2 run's SR image (fp16 storage noise: another launch size may pick another kernel) and per-sample SR loss (1e-4);
+    a second forward + backward of the same model is bit-identical (outputs and every gradient)."""
+    from csbsr_amd.data.synthetic import make_batch
+    x, hr, mask, k = make_batch(2, 112, seed=77)
+    x, hr, mask = _tile(x, 4), _tile(hr, 4), _tile(mask, 4)
+    m = _model(2, 40000)
+    with torch.no_grad():
+        _, sr_l2, _, sr2, kp2 = m(40000, x, sr_targets=hr, segment_targets=mask, kernel_targets=k)
+        sr_l2, sr2, kp2 = sr_l2.clone(), sr2.clone(), kp2.clone()
+    del m
+    torch.cuda.empty_cache()
+    fl = lambda t: torch.cat([t, t.flip(-1), t.flip(-2), t.flip(-1, -2)]).contiguous()
+    x8, hr8, mask8, k8 = fl(x), fl(hr), fl(mask), fl(k)
+    assert x8.shape[0] == 8 and hr8.shape[-1] == 1792
+    m = _model(4, 40000)
+    m.max_resident = None                    # as bench.py: _auto_resident decides from the free memory
+    runs = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        seg_l, sr_l, seg, sr, kp = m(40000, x8, sr_targets=hr8, segment_targets=mask8, kernel_targets=k8)
+        (0.7 * sr_l.mean() + 0.3 * seg_l.mean()).backward()
+        torch.cuda.synchronize()
+        assert not m.last_step_overflowed
+        outs = dict(seg_l=seg_l.detach().clone(), sr_l=sr_l.detach().clone(), seg=seg.detach().clone(), sr=sr.detach().clone(), kp=kp.detach().clone())
+        grads = {n: v.grad.detach().clone() for n, v in m._named_full() if isinstance(v, torch.nn.Parameter) and v.grad is not None}
+        runs.append((outs, grads))
+    print(f"   B = 8, micro-batch 4: n_resident {m._n_res}, lean saves {m._lean}, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
+    (o, g), (o_b, g_b) = runs
+    assert len(g) == 290
+    for kk, v in o.items():
+        assert bool(torch.isfinite(v).all()), kk
+        assert torch.equal(v, o_b[kk]), kk
+    for n, v in g.items():
+        assert bool(torch.isfinite(v).all()), n
+        assert torch.equal(v, g_b[n]), n
+    e_sr = float((o["sr"][:2] - sr2).abs().max() / sr2.abs().max())
+    e_kp = float((o["kp"][:2] - kp2).abs().max() / kp2.abs().max())
+    e_l = float(((o["sr_l"][:2] - sr_l2).abs() / sr_l2.abs()).max())
+    print(f"   samples 0-1 of the B = 8 run vs the B = 2 run: sr {e_sr:.2e}  kernel {e_kp:.2e}  per-sample sr_loss {e_l:.2e}")
+    assert e_sr <= 2e-3 and e_kp <= 2e-3 and e_l <= 1e-4
+
+
+def test_residency_schedule_under_memory_pressure():
+    """The 8-GPU run's one unknown that one GPU can rehearse: at B = 8 the step peaks at ~239 of 268 GiB, and whatever a collective
+    library reserves on a rank comes out of the headroom _auto_resident decides from (every rank then takes the minimum schedule,
+    GradBucketReducer.agree_min).  Reserve 0 / 4 / 8 / 12 GB before the model exists and record the schedule and the step time: the
+    cost of losing a resident micro-batch is known before the driver's one shot.  Asserted: every case runs (finite loss, no overflow,
+    no out-of-memory), and 4 GB of foreign allocations -- more than RCCL's channel buffers -- do not change the schedule."""
+    import time
+    from csbsr_amd.data.synthetic import make_batch
+    x, hr, mask, k = make_batch(2, 112, seed=81)
+    fl = lambda t: torch.cat([t, t.flip(-1), t.flip(-2), t.flip(-1, -2)]).contiguous()
+    x8, hr8, mask8, k8 = (fl(t).cuda() for t in (_tile(x, 4), _tile(hr, 4), _tile(mask, 4), k))
+    seen = {}
+    for gb in (0, 4, 8, 12):
+        torch.cuda.empty_cache()
+        hold = torch.empty(gb << 30, dtype=torch.uint8, device="cuda") if gb else None
+        m = _model(4, 40000)
+        m.max_resident = None
+        ms = []
+        for i in range(2):
+            for p in m.parameters():
+                p.grad = None
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            seg_l, sr_l, _, _, _ = m(40000, x8, sr_targets=hr8, segment_targets=mask8, kernel_targets=k8)
+            loss = 0.7 * sr_l.mean() + 0.3 * seg_l.mean()
+            loss.backward()
+            torch.cuda.synchronize()
+            ms.append((time.perf_counter() - t0) * 1e3)
+            assert bool(torch.isfinite(loss.detach())) and not m.last_step_overflowed
+        seen[gb] = (m._n_res, m._lean)
+        print(f"   {gb:2d} GB reserved by another tenant: n_resident {m._n_res} of 2, lean saves {m._lean}, forward + backward {ms[1]:.0f} ms, "
+              f"peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
+        del m, hold, seg_l, sr_l, loss
+        torch.cuda.reset_peak_memory_stats()
+    assert seen[4] == seen[0], seen
 
 
 def test_full_size_corner_matches_the_small_run():
@@ -169,6 +256,11 @@ def test_full_size_hrnet_ocr_config4():
     print(f"config 4 full size: gradients of the two micro-batchings agree to median {med:.2e} p90 {p90:.2e} max {mx:.2e}")
     assert med < 5e-2 and p90 < 0.15
     del o_s1, g_s1
+    # the config's stated batch (4, one micro-batch of 4 -- bench.py --workload hrnet_x4 --batch 4): finite, no overflow
+    b4 = tuple(torch.cat([t, t.flip(-1)]).contiguous() for t in batch)
+    o4, g4 = _full_size_step("hrnet_x4", 4, "split", b4)
+    assert len(g4) == 1109
+    del o4, g4
     o_f2, g_f2 = _full_size_step("hrnet_x4", 2, "fp16", batch)
     _agree(o_s2, o_f2, "config 4 split vs fp16 detector", dict(sr=1e-6, kp=1e-6, seg=3e-2), 5e-3)      # (KBPN is the same code in both modes)
     med, p90, mx = _grad_dist(g_s2, g_f2)
@@ -188,5 +280,9 @@ def test_full_size_blurskip_x8_config5():
     med, p90, mx = _grad_dist(g_s, g_f)
     print(f"config 5 full size: gradients of the two detector precision modes agree to median {med:.2e} p90 {p90:.2e} max {mx:.2e}")
     assert med < 5e-2 and mx < 0.2
+    b4 = tuple(torch.cat([t, t.flip(-1)]).contiguous() for t in batch)          # the config's stated batch of 4
+    o4, g4 = _full_size_step("blurskip_x8", 4, "split", b4)
+    assert len(g4) == 26
+    del o4, g4
     o_1, g_1 = _full_size_step("blurskip_x8", 1, "split", batch)
     _agree(o_s, o_1, "config 5 split, micro-batch 2 vs 1", dict(sr=2e-3, kp=2e-3, seg=1e-2), 2e-3)

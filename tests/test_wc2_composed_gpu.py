@@ -25,23 +25,26 @@ pytestmark = pytest.mark.gpu
 
 # Fixed bounds per (fixture, detector precision mode): segmentation map (max |a-b| / max|b|), segmentation loss, BatchNorm running
 # buffers, 1 - IoU of the thresholded maps, and (median, 90th percentile, max) of the per-tensor gradient relative-L2 errors.  Measured on
-# MI355X (printed by the test; the path is bit-reproducible so the values do not move run to run) with >= 2x margin each; the split-mode
+# MI355X (printed by the test; the path is bit-reproducible so the values do not move run to run) with ~2x margin each; the split-mode
 # bounds on the map were tightened in r04 (5e-3 / 5e-3 / 1e-2 -> 4e-3 / 3e-3 / 5e-3) with the compensation of KBPN's weight rounding
-# (engine.Conv._dc_bias: measured 2.18e-3 -> 1.66e-3, 1.44e-3 -> 1.19e-3, 3.08e-3 -> 1.98e-3).  What the
+# (engine.Conv._dc_bias: measured 2.18e-3 -> 1.66e-3, 1.44e-3 -> 1.19e-3, 3.08e-3 -> 1.98e-3) and again in r05 with the tap-sum-preserving
+# rounding of KBPN's weights (engine.Conv._wq; same-run A/B, nearest -> tap-sum: PSPNet 1.76e-3 -> 1.08e-3, BlurSkip 1.20e-3 -> 1.02e-3,
+# PixelShuffle 3.67e-3 -> 3.07e-3, HRNet-OCR 1.84e-3 -> 1.92e-3 in max norm; in relative L2 -- asserted since r05 as ``segl2`` -- 6.3 -> 5.0e-4,
+# 3.0 -> 2.5e-4, 1.36 -> 1.10e-3, 1.38 -> 1.22e-3): 4e-3 / 3e-3 / 5e-3 / 1.5e-2 -> 2.2e-3 / 2e-3 / 4e-3 / 6e-3.  What the
 # numbers say: in split mode (the default, and the mode bench.py's headline is quoted in) the step sits INSIDE the reference's own response
 # to a 1e-3 perturbation of its SR image (cond_* in the fixtures: seg 4.8e-3 / 9.8e-3 / 3.7e-3 / 9.2e-3, IoU 0.995 / 0.997 / 0.965 / 0.988,
 # gradient median 1.3e-2 / 5.8e-3 / 5.9e-2 / 2.0e-2 for PSPNet / BlurSkip / HRNet-OCR / PixelShuffle); plain fp16 detector storage costs
 # 2-3x on the map and, through ~300 BatchNorm'd ReLU layers of HRNet-OCR, 6x on the gradients (0.22 median): it is the throughput mode,
 # not the parity mode.  HRNet-OCR's IoU: its thresholded map has 5.6 % positives, so the ~75 pixels within 3e-3 of the threshold are 3.7 %.
 B = {
-    "wc2_pspnet_it40000": {"fp16": dict(seg=1e-2, segl=5e-4, bn=1e-3, iou1=1e-2, grad=(2.5e-2, 7e-2, 0.15)),
-                           "split": dict(seg=4e-3, segl=2e-4, bn=5e-4, iou1=5e-3, grad=(2e-2, 5e-2, 0.1))},
-    "wc2_blurskip_x8_it40000": {"fp16": dict(seg=1.5e-2, segl=5e-4, bn=1e-3, iou1=1e-2, grad=(1.5e-2, 2e-2, 3e-2)),
-                                "split": dict(seg=3e-3, segl=2e-4, bn=5e-4, iou1=5e-3, grad=(5e-3, 1e-2, 1.5e-2))},
-    "wc2_hrnet_ocr_it40000": {"fp16": dict(seg=1.5e-2, segl=2e-3, bn=5e-3, iou1=0.15, grad=(0.5, 0.7, 2.0)),
-                              "split": dict(seg=5e-3, segl=1.5e-3, bn=3e-3, iou1=0.1, grad=(8e-2, 0.12, 0.3))},
-    "wc2_pspnet_pixelshuffle_it40000": {"fp16": dict(seg=2e-2, segl=1e-3, bn=2e-3, iou1=3e-2, grad=(5e-2, 0.12, 0.3)),
-                                        "split": dict(seg=1.5e-2, segl=5e-4, bn=1e-3, iou1=2e-2, grad=(4e-2, 0.1, 0.2))},
+    "wc2_pspnet_it40000": {"fp16": dict(seg=7e-3, segl2=3e-3, segl=5e-4, bn=1e-3, iou1=1e-2, grad=(2.5e-2, 7e-2, 0.15)),
+                           "split": dict(seg=2.2e-3, segl2=1e-3, segl=2e-4, bn=5e-4, iou1=5e-3, grad=(2e-2, 5e-2, 0.1))},
+    "wc2_blurskip_x8_it40000": {"fp16": dict(seg=1.3e-2, segl2=3.5e-3, segl=5e-4, bn=1e-3, iou1=1e-2, grad=(1.5e-2, 2e-2, 3e-2)),
+                                "split": dict(seg=2e-3, segl2=5e-4, segl=2e-4, bn=5e-4, iou1=5e-3, grad=(5e-3, 1e-2, 1.5e-2))},
+    "wc2_hrnet_ocr_it40000": {"fp16": dict(seg=1e-2, segl2=8e-3, segl=2e-3, bn=5e-3, iou1=0.15, grad=(0.5, 0.7, 2.0)),
+                              "split": dict(seg=4e-3, segl2=2.5e-3, segl=1.5e-3, bn=3e-3, iou1=0.1, grad=(8e-2, 0.12, 0.3))},
+    "wc2_pspnet_pixelshuffle_it40000": {"fp16": dict(seg=1e-2, segl2=3.5e-3, segl=1e-3, bn=2e-3, iou1=3e-2, grad=(5e-2, 0.12, 0.3)),
+                                        "split": dict(seg=6e-3, segl2=2.2e-3, segl=5e-4, bn=1e-3, iou1=2e-2, grad=(4e-2, 0.1, 0.2))},
 }
 CASES = ["wc2_pspnet_it40000", "wc2_blurskip_x8_it40000", "wc2_hrnet_ocr_it40000", "wc2_pspnet_pixelshuffle_it40000"]
 
@@ -80,7 +83,8 @@ def test_composed_step_matches_the_reference(case, precision):
         print(f"   {name:14s} {val:.2e}  bound {bound:.0e}  margin {bound / max(val, 1e-30):.1f}x")
     # (the rows above are max |a - b| / max |b|; in relative L2 the same maps sit at:)
     print(f"   relative L2: sr_preds {l2['sr_preds']:.2e}  segment_preds {l2['segment_preds']:.2e}")
-    assert l2["sr_preds"] < 1e-3
+    print(f"   relative L2 bound on segment_preds {bb['segl2']:.1e}  margin {bb['segl2'] / l2['segment_preds']:.1f}x")
+    assert l2["sr_preds"] < 1e-3 and l2["segment_preds"] < bb["segl2"], (case, precision, l2)
     grads = {kk: v.grad for kk, v in m._named_full() if isinstance(v, torch.nn.Parameter)}
     errs = [er for er in _grad_errors(g, grads, "") if not _zero_by_construction(er[0])]
     v = np.array([max(en, es) for n, numel, en, es in errs if numel > 1])
