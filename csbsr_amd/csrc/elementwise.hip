@@ -595,6 +595,7 @@ __device__ __forceinline__ float f16_spacing(float q, float dir) {      // dista
   const bool inward = q * dir < 0.f;                             // towards zero: below a power of two the grid is twice as fine
   return ldexpf(1.f, e - ((inward && m == 0.5f) ? 12 : 11));
 }
+// one thread per (d0, d1) filter.  Generic form: taps re-read from memory in every scan (any KH x KW; latency-bound: 160 us per 8x8 layer)
 __global__ void round_weights_kernel(const float* w, float* wq, float* S, long rows, int KH, int KW, int mode) {
   const int T = KH * KW;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long)gridDim.x * blockDim.x) {
@@ -635,12 +636,73 @@ __global__ void round_weights_kernel(const float* w, float* wq, float* S, long r
     }
   }
 }
+// the same rule with the filter in registers (compile-time tap count and grouping, every loop unrolled, the moved tap written by a
+// predicated sweep instead of a dynamic index): the layers of the x4 network -- 3x3, 8x8 Conv2d (one group of 64 taps), 8x8 stride-4
+// ConvTranspose2d (16 phases of 4 taps).  Same summation order as the generic form: bit-identical results.
+template <int KH, int KW, int MODE>
+__global__ __launch_bounds__(64) void round_weights_reg_kernel(const float* w, float* wq, float* S, long rows) {
+  constexpr int T = KH * KW;
+  const long i = (long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= rows) return;
+  float src[T], q[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) { src[t] = w[i * T + t]; q[t] = (float)(half_t)src[t]; }
+  // hipcc (ROCm 7.2) MISCOMPILES this nest when the group loop is unrolled and the iteration loop is left through lane-divergent
+  // breaks: rows whose neighbours in the wave finished earlier lose moves (found by the test against the CPU form; a stand-alone
+  // reproduction behaves the same).  So the multi-group instances run a FIXED number of iterations per group with a ``done`` predicate
+  // -- a group of n taps settles within n moves, 2 n + 2 is generous -- and only the single-group instances keep their breaks.
+  constexpr int GT = (KH / MODE) * (KW / MODE);
+  constexpr int NIT = MODE > 1 ? 2 * GT + 2 : T;
+#pragma unroll
+  for (int g = 0; g < MODE * MODE; ++g) {
+    const int gy = g / MODE, gx = g % MODE;
+    for (int it = 0; it < NIT; ++it) {
+      float r = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx)
+          if (ky % MODE == gy && kx % MODE == gx) r += src[ky * KW + kx] - q[ky * KW + kx];
+      const bool done = r == 0.f;
+      if constexpr (MODE == 1) { if (done) break; }
+      const float sg = r > 0.f ? 1.f : -1.f;
+      int best = -1;
+      float bs = 0.f, bu = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx)
+          if (ky % MODE == gy && kx % MODE == gx) {
+            const int t = ky * KW + kx;
+            const float d = src[t] - q[t];
+            const float u = f16_spacing(q[t], sg);
+            const float sc = fabsf(d) / u;
+            const bool cand = !done && d * sg > 0.f && fabsf(r) - fabsf(r - sg * u) > 0.f && sc > bs;
+            if (cand) { bs = sc; best = t; bu = u; }
+          }
+      if constexpr (MODE == 1) { if (best < 0) break; }
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (t == best) q[t] = (float)(half_t)(q[t] + sg * bu);      // (best = -1: nothing moves)
+    }
+  }
+  float a = 0.f;
+#pragma unroll
+  for (int t = 0; t < T; ++t) { wq[i * T + t] = q[t]; a += src[t] - q[t]; }
+  if (S) S[i] = a;
+}
 extern "C" int csbsr_round_weights(const float* w, float* wq, float* S, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t mode,
                                    csbsr_stream_t s) {
   CSBSR_CHECK(w && wq && D0 > 0 && D1 > 0 && KH > 0 && KW > 0 && mode >= 0 && mode <= KH && mode <= KW, "round_weights: bad args");
   const long rows = (long)D0 * D1;
-  const int blocks = (int)((rows + 63) / 64 > 4096 ? 4096 : (rows + 63) / 64);
-  hipLaunchKernelGGL(round_weights_kernel, dim3(blocks), dim3(64), 0, ST(s), w, wq, S, rows, KH, KW, mode);
+  const unsigned nb = (unsigned)((rows + 63) / 64);
+  if (KH == 3 && KW == 3 && mode == 1) hipLaunchKernelGGL((round_weights_reg_kernel<3, 3, 1>), dim3(nb), dim3(64), 0, ST(s), w, wq, S, rows);
+  else if (KH == 8 && KW == 8 && mode == 1) hipLaunchKernelGGL((round_weights_reg_kernel<8, 8, 1>), dim3(nb), dim3(64), 0, ST(s), w, wq, S, rows);
+  else if (KH == 8 && KW == 8 && mode == 4) hipLaunchKernelGGL((round_weights_reg_kernel<8, 8, 4>), dim3(nb), dim3(64), 0, ST(s), w, wq, S, rows);
+  else {
+    const int blocks = (int)(nb > 4096 ? 4096 : nb);
+    hipLaunchKernelGGL(round_weights_kernel, dim3(blocks), dim3(64), 0, ST(s), w, wq, S, rows, KH, KW, mode);
+  }
   CSBSR_LAUNCH_CHECK("csbsr_round_weights");
   return 0;
 }

@@ -139,6 +139,7 @@ class Engine:
         self.wg_stream = None
         self._wg_on = os.environ.get("CSBSR_WGRAD_STREAM", "0") == "1"
         self._ws_by_stream = {}
+        self._zero_blk, self._zero_off = None, 0
         self.timing = None              # list of (kind, flops, bytes, start_event, end_event) when profiling is on
 
     @property
@@ -152,9 +153,27 @@ class Engine:
             return FM(f((N, H, W, 2 * cp), dtype=torch.float16, device=self.device)[..., :cp], c, lo=cp)
         return FM(f((N, H, W, cp), dtype=torch.float16, device=self.device), c)
 
+    ZERO_ARENA = 1 << 20          # floats per arena block (4 MB)
+
     def f32(self, *shape, zero=True):
-        f = torch.zeros if zero else torch.empty
-        return f(shape, dtype=torch.float32, device=self.device)
+        if not zero:
+            return torch.empty(shape, dtype=torch.float32, device=self.device)
+        # small zero-initialised buffers (BatchNorm statistic rows, reduction targets, class-bias tables: hundreds per pass, ~2000 per
+        # HRNet-OCR step) are cut from a pre-zeroed block instead of costing a fill launch each; a block is never re-zeroed or reused --
+        # when it is used up the next one is allocated (one fill launch per 2^20 floats handed out) and the old one dies with its views
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if n == 0 or n > 65536:
+            return torch.zeros(shape, dtype=torch.float32, device=self.device)
+        n_al = (n + 63) // 64 * 64
+        if self._zero_blk is None or self._zero_off + n_al > self.ZERO_ARENA:
+            self._zero_blk, self._zero_off = torch.zeros(self.ZERO_ARENA, dtype=torch.float32, device=self.device), 0
+        # (a fresh tensor on the block's storage, NOT a view of it: views share one autograd version counter, and an in-place update of any
+        # buffer cut from the block would invalidate every other one that autograd has saved -- the OCR region-vector chain does save one)
+        t = torch.empty(0, dtype=torch.float32, device=self.device).set_(self._zero_blk.untyped_storage(), self._zero_off, tuple(int(d) for d in shape))
+        self._zero_off += n_al
+        return t
 
     def workspace(self, nfloat):
         """wgrad slab workspace of the CURRENT stream (allocated under it, so the caching allocator orders its reuse on that stream)"""
