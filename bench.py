@@ -106,9 +106,15 @@ def main():
     ap.add_argument("--cpu-baseline-lr", type=int, default=112, help="LR size of the bounded CPU sample (112 = BASELINE.md section 2's size; 32 = round 1's)")
     ap.add_argument("--cpu-baseline-threads", type=int, default=0, help="intra-op threads of the CPU sample (0 = min(host threads, 16), see cpu_baseline)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--watchdog-s", type=int, default=int(os.environ.get("CSBSR_BENCH_WATCHDOG", "0")),
+                    help="dump every thread's Python stack to stderr and exit if the run is still going after this many seconds (0 = off): a hung "
+                         "collective in a multi-rank run then says where each rank stands instead of timing out silently")
     ap.add_argument("--dump-layers", default=None, help="write the per-launch conv / wgrad log of the timed region (layer, shape, kernel, ms) as JSON")
     args = ap.parse_args()
 
+    if args.watchdog_s > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog_s, exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

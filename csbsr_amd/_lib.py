@@ -113,6 +113,7 @@ SIGNATURES = {
     "csbsr_channel_mean_sub": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp]),
     "csbsr_thin_tp_backward_slabs": (i32, [i32, i32]),
     "csbsr_conv_thin_dact_eligible": (i32, [vp]),
+    "csbsr_conv_split_fused_eligible": (i32, [C.POINTER(ConvDesc)]),
     "csbsr_thin_tp_backward": (i32, [vp, i64, i64, i64, vp, i64, i64, i64, vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, i64, i64, i64, vp, vp, vp]),
     "csbsr_round_weights": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "csbsr_dc_bias": (i32, [vp, i32, i32, vp, i64, i32, vp, i64, i32, vp, i32, vp, vp]),

@@ -460,6 +460,15 @@ int conv_desc_to_k(const csbsr_conv_desc_t* d, ConvK& k) {
   return 0;
 }
 
+// 1 if csbsr_conv_forward would take this descriptor WITH split_fused set (the fused three-product stage exists only in the LDS-DMA
+// kernels): the host asks before it packs the [w_hi 32 | w_lo 32] operand and falls back to the three-block form otherwise
+extern "C" int32_t csbsr_conv_split_fused_eligible(const csbsr_conv_desc_t* d) {
+  if (!d || !d->split_fused) return 0;
+  ConvK k;
+  if (conv_desc_to_k(d, k)) return 0;
+  return conv_glds_eligible(k) ? 1 : 0;
+}
+
 extern "C" int csbsr_conv_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) {
   ConvK k;
   if (int rc = conv_desc_to_k(d, k)) return rc;

@@ -691,14 +691,102 @@ __global__ __launch_bounds__(64) void round_weights_reg_kernel(const float* w, f
   for (int t = 0; t < T; ++t) { wq[i * T + t] = q[t]; a += src[t] - q[t]; }
   if (S) S[i] = a;
 }
+// The large filters, LPF lanes per filter with TPL taps each (a filter's taps are one coalesced read of its lanes):
+//   MODE > 1 (ConvTranspose2d of that stride): LPF = MODE^2, lane = output phase (ky % MODE, kx % MODE), its <= TPL taps ARE the phase's
+//   group -- no communication but the final tap sum;   MODE 1 (Conv2d): lane = TPL consecutive taps of the one group -- residual and best
+//   candidate by fixed LPF-lane xor trees (ties -> the lower tap index, like the serial scan).
+// The thread-per-filter forms above took 170-240 us per 128 x 128 x 8 x 8 layer (one wave per CU, 64 strided loads each: 25 launches, 5.3 ms
+// per step of config 2) and milliseconds on the 12 x 12 filters of the x8 network.  Wave-uniform exit only (see the miscompile note above):
+// a filter that has settled idles under its ``done`` flag.
+template <int KH, int KW, int MODE, int LPF, int TPL>
+__global__ __launch_bounds__(256) void round_weights_lanes_kernel(const float* w, float* wq, float* S, long rows) {
+  constexpr int T = KH * KW;
+  constexpr int NB = (KW + MODE - 1) / MODE;
+  static_assert(MODE == 1 ? LPF * TPL >= T : (LPF == MODE * MODE && TPL == ((KH + MODE - 1) / MODE) * NB), "lane layout");
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long row = gid / LPF;
+  const int sub = (int)(gid % LPF);
+  const bool live = row < rows;
+  int tix[TPL];
+  bool ok[TPL];
+#pragma unroll
+  for (int j = 0; j < TPL; ++j) {
+    if (MODE == 1) { tix[j] = sub * TPL + j; ok[j] = tix[j] < T; }
+    else {
+      const int ky = sub / MODE + MODE * (j / NB), kx = sub % MODE + MODE * (j % NB);
+      tix[j] = ky * KW + kx; ok[j] = ky < KH && kx < KW;
+    }
+    ok[j] = ok[j] && live;
+  }
+  float src[TPL], q[TPL];
+#pragma unroll
+  for (int j = 0; j < TPL; ++j) { src[j] = ok[j] ? w[row * T + tix[j]] : 0.f; q[j] = (float)(half_t)src[j]; }
+  bool done = !live;
+  for (int it = 0; it < 2 * T + 2; ++it) {
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < TPL; ++j) r += src[j] - q[j];
+    if (MODE == 1) {
+#pragma unroll
+      for (int o = 1; o < LPF; o <<= 1) r += __shfl_xor(r, o, 64);
+    }
+    done = done || r == 0.f;
+    const float sg = r > 0.f ? 1.f : -1.f;
+    int best = -1;
+    float bs = 0.f, bu = 0.f;
+#pragma unroll
+    for (int j = 0; j < TPL; ++j) {
+      const float d = src[j] - q[j];
+      const float u = f16_spacing(q[j], sg);
+      const float sc = fabsf(d) / u;
+      const bool cand = !done && d * sg > 0.f && fabsf(r) - fabsf(r - sg * u) > 0.f && sc > bs;
+      if (cand) { bs = sc; best = j; bu = u; }
+    }
+    int bt = T;                          // tap index of this lane's candidate
+#pragma unroll
+    for (int j = 0; j < TPL; ++j)
+      if (j == best) bt = tix[j];
+    bool mine = best >= 0;
+    if (MODE == 1) {       // the lanes of a filter agree on ONE move: highest score, then lowest tap index
+      float ws = bs;
+      int wt = bt;
+#pragma unroll
+      for (int o = 1; o < LPF; o <<= 1) {
+        const float os = __shfl_xor(ws, o, 64);
+        const int ot = __shfl_xor(wt, o, 64);
+        if (os > ws || (os == ws && ot < wt)) { ws = os; wt = ot; }
+      }
+      mine = best >= 0 && wt == bt;
+      done = done || wt == T;
+    } else {
+      done = done || best < 0;
+    }
+#pragma unroll
+    for (int j = 0; j < TPL; ++j)
+      if (mine && j == best) q[j] = (float)(half_t)(q[j] + sg * bu);
+    if (__all(done)) break;        // wave-uniform
+  }
+  float a = 0.f;
+#pragma unroll
+  for (int j = 0; j < TPL; ++j) { if (ok[j]) wq[row * T + tix[j]] = q[j]; a += src[j] - q[j]; }
+#pragma unroll
+  for (int o = 1; o < LPF; o <<= 1) a += __shfl_xor(a, o, 64);
+  if (S && live && sub == 0) S[row] = a;
+}
+template <int KH, int KW, int MODE, int LPF, int TPL>
+static void launch_round_lanes(const float* w, float* wq, float* S, long rows, hipStream_t st) {
+  hipLaunchKernelGGL((round_weights_lanes_kernel<KH, KW, MODE, LPF, TPL>), dim3((unsigned)((rows * LPF + 255) / 256)), dim3(256), 0, st, w, wq, S, rows);
+}
 extern "C" int csbsr_round_weights(const float* w, float* wq, float* S, int32_t D0, int32_t D1, int32_t KH, int32_t KW, int32_t mode,
                                    csbsr_stream_t s) {
   CSBSR_CHECK(w && wq && D0 > 0 && D1 > 0 && KH > 0 && KW > 0 && mode >= 0 && mode <= KH && mode <= KW, "round_weights: bad args");
   const long rows = (long)D0 * D1;
   const unsigned nb = (unsigned)((rows + 63) / 64);
   if (KH == 3 && KW == 3 && mode == 1) hipLaunchKernelGGL((round_weights_reg_kernel<3, 3, 1>), dim3(nb), dim3(64), 0, ST(s), w, wq, S, rows);
-  else if (KH == 8 && KW == 8 && mode == 1) hipLaunchKernelGGL((round_weights_reg_kernel<8, 8, 1>), dim3(nb), dim3(64), 0, ST(s), w, wq, S, rows);
-  else if (KH == 8 && KW == 8 && mode == 4) hipLaunchKernelGGL((round_weights_reg_kernel<8, 8, 4>), dim3(nb), dim3(64), 0, ST(s), w, wq, S, rows);
+  else if (KH == 8 && KW == 8 && mode == 1) launch_round_lanes<8, 8, 1, 16, 4>(w, wq, S, rows, ST(s));
+  else if (KH == 8 && KW == 8 && mode == 4) launch_round_lanes<8, 8, 4, 16, 4>(w, wq, S, rows, ST(s));
+  else if (KH == 12 && KW == 12 && mode == 1) launch_round_lanes<12, 12, 1, 16, 9>(w, wq, S, rows, ST(s));
+  else if (KH == 12 && KW == 12 && mode == 8) launch_round_lanes<12, 12, 8, 64, 4>(w, wq, S, rows, ST(s));
   else {
     const int blocks = (int)(nb > 4096 ? 4096 : nb);
     hipLaunchKernelGGL(round_weights_kernel, dim3(blocks), dim3(64), 0, ST(s), w, wq, S, rows, KH, KW, mode);

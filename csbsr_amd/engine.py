@@ -348,7 +348,9 @@ class Conv:
         D0, D1 = self.w.shape[0], self.w.shape[1]
         n = L.load().csbsr_packed_weight_elems_split(kind, D0, D1, self.k, self.k, stride, creal, nrows, layout)
         dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
-        L.call("csbsr_pack_weights_split", _ptr(self.w), _ptr(dst), kind, D0, D1, self.k, self.k, stride, pad, creal, row_off, nrows, k_off,
+        # (layout 2 = [w_hi | w_hi], a layer whose plan drops the x_hi w_lo product: its one rounding of the weights is the tap-sum-preserving one)
+        src = self._wq() if layout == 2 else self.w
+        L.call("csbsr_pack_weights_split", _ptr(src), _ptr(dst), kind, D0, D1, self.k, self.k, stride, pad, creal, row_off, nrows, k_off,
                self.WSCALE, layout, self.eng.stream)
         self._packed[key] = dst
         return dst
@@ -361,6 +363,9 @@ class Conv:
         if nb == 3 and self.eng.split_fused and x.cp >= 32 and pad8(nrows) > 32 and kind == 0:
             # fused form (csbsr_conv_desc_t::split_fused): one staged K slice = 32 channels of [x_hi | x_lo] against [w_hi | w_lo], all three
             # products from it -- the LDS-DMA kernels' launch time follows the staged bytes, 2/3 of the three-block form's
+            # (should the library refuse the fused form for this launch -- csbsr_conv_split_fused_eligible: the LDS-DMA kernels switched off by a
+            # debug mode, a tile they do not take -- _launch falls back to the three-block operand)
+            self._fs_fallback = lambda: self._pack_split((key, 3), kind, creal, nrows, stride, pad, k_off=k_off, layout=0)
             return (x,), self._pack_split((key, "fs"), kind, creal, nrows, stride, pad, k_off=k_off, layout=3), 1.0 / self.WSCALE, 4
         wt = self._pack_split((key, nb), kind, creal, nrows, stride, pad, k_off=k_off, layout=0 if nb == 3 else 2)
         return (x,), wt, 1.0 / self.WSCALE, nb
@@ -462,6 +467,8 @@ class Conv:
                 d.mask, d.m_sn, d.m_sy, d.m_sx, d.mask_slope, d.mask_prelu = _ptr(mfm.t), sn, sy, sx, 0.0, _ptr(mslope)
             else:
                 d.mask, d.m_sn, d.m_sy, d.m_sx, d.mask_slope = _ptr(mfm.t), sn, sy, sx, float(mslope)
+        if x0.lo and split_blocks == 4 and not L.load().csbsr_conv_split_fused_eligible(C.byref(d)):
+            d.split_fused, d.inp[1], d.wt, split_blocks = 0, x0.split_segs()[1], _ptr(self._fs_fallback()), 3
         self.last_fused = False
         use_tp = tp is not None and self.eng.use_tp
         if dact is not None:

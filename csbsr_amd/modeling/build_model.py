@@ -151,11 +151,18 @@ class _JointBase(nn.Module):
         # first match wins, unmatched layers run 3 blocks.  Swept in round 4 on the reference's own SR images (scripts/study_split_plan.py,
         # profiles/r04_split_plan_study.json): every group of the trunk needs all three blocks (layer 3 alone at two blocks: 2.2e-3 on the
         # map); only the tail (up_1 .. final) and the PSP module stay under 1e-3 with two, each eating a third to a half of the margin for
-        # < 2 % of the step, so the default plan is None.
+        # < 2 % of the step, so the default plan is None -- EXCEPT, since round 5, the four blur_skip conv0 / conv1 pairs of PSPNet_BlurSkip
+        # (64 -> 505 -> 64 at full HR resolution, 48 % of a config-5 step): with their fp16 weights rounded tap-sum-preservingly and the mean
+        # compensation on (engine.Conv._wq / _dc_bias: what a layer with fewer than three blocks gets) the two-block plan measures 2.36e-4 on
+        # the map against 2.10e-4 with three (nearest rounding: 4.99e-4; gradients median 1.4e-3 vs 9e-4, bound 3e-2) on the reference's own
+        # SR image -- inside 1e-3 with 4x margin -- for a third of those layers' forward MFMA time.  The same rounding does NOT rescue the
+        # BatchNorm'd trunk / decoder layers (up_1 at two blocks: 3.6e-4 vs 7.9e-5, r04: 4.1e-4), which stay at three.
         # ``detector_hp_dgrad``: dgrads against [w_hi | w_lo] (two K blocks).  The same sweep shows it buys nothing -- every detector
         # gradient tensor and dLoss/dSR agree with the reference equally well without it (PSPNet median 1.15e-2 vs 1.12e-2, HRNet-OCR
         # 1.65e-2 both, BlurSkip 9.4e-4 vs 9.1e-4: the error is the ReLU-gate flips of the forward, not the weights' rounding) -- so it is off.
-        self.detector_plan = None
+        self.detector_plan = [(r"blur_skip\.[02]\.conv_(scale|shift)\.[01]\.", 2)] if self.blur_skip else None
+        if __import__("os").environ.get("CSBSR_BS_PLAN") == "0":        # (A/B hook: three blocks everywhere)
+            self.detector_plan = None
         self.detector_hp_dgrad = __import__("os").environ.get("CSBSR_HP_DGRAD") == "1"      # (A/B hook; default off)
 
     # ---- naming: state_dict keys are the reference's dotted names

@@ -456,6 +456,9 @@ int csbsr_thin_tp_backward(const void* dout, int64_t d_sn, int64_t d_sy, int64_t
                            int64_t x_sx, const void* wt_packed, int32_t cin, int32_t cout, int32_t stride, int32_t pad,
                            const float* prelu, int32_t N, int32_t h, int32_t w, void* dpre, int64_t p_sn, int64_t p_sy, int64_t p_sx,
                            float* slabs, float* dprelu_part, csbsr_stream_t s);
+/* 1 if csbsr_conv_forward takes this descriptor with split_fused = 1 (the fused three-product stage of a split-fp16 input exists only in the
+ * LDS-DMA kernels); 0: pack the three-block operand (csbsr_pack_weights_split layout 0) and clear split_fused */
+int32_t csbsr_conv_split_fused_eligible(const csbsr_conv_desc_t* d);
 /* 1 if csbsr_conv_forward takes this launch WITH its dact / dres fields (see csbsr_conv_desc_t::dres) */
 int32_t csbsr_conv_thin_dact_eligible(const csbsr_conv_desc_t* d);
 #ifdef __cplusplus

@@ -11,10 +11,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """a port nobody listens on right now (a fixed rendezvous port that a previous run left in TIME_WAIT hangs the store's bind)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 def test_bench_two_ranks_one_device():
-    env = dict(os.environ, CSBSR_DIST_BACKEND="gloo", CSBSR_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, CSBSR_DIST_BACKEND="gloo", CSBSR_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", CSBSR_BENCH_WATCHDOG="300")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--lr-size", "64", "--steps", "2",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--lr-size", "64", "--steps", "2",
            "--warmup", "1", "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -37,10 +45,10 @@ def test_bench_rccl_backend_one_rank():
     otherwise): process-group init with device_id, one broadcast per (parameters | buffers, dtype) group, per step the six flat-bucket all-reduces
     (segmentation net, KBPN stages 4..1, KBPN head) on the side stream launched from inside the backward, barrier, MAX all-reduce of
     the step time.  What a one-GPU box cannot show is only the transfer between GPUs."""
-    env = dict(os.environ, CSBSR_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, CSBSR_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CSBSR_BENCH_WATCHDOG="300")
     env.pop("CSBSR_DIST_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "2", "--lr-size", "64", "--steps", "2",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "2", "--lr-size", "64", "--steps", "2",
            "--warmup", "1", "--no-cpu-baseline", "--no-h2d-leg", "--no-other-precision-leg"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -79,7 +87,7 @@ def test_forced_rccl_all_reduce_leaves_gradients_bit_identical():
     m.max_resident = 8
     sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
     base = step(m)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
         m.load_state_dict(sd0)

@@ -1029,3 +1029,33 @@ def test_split_precision_forward_conv(case, fused):
     e_stat = float((stat[:, :cout].double().cpu() - s_ref).abs().max() / s_ref.abs().max())
     print(f"split conv {case} fused={fused}: max err {err:.2e} of max, BN sums {e_stat:.2e}")
     assert err < 2e-5 and e_stat < 1e-5
+
+
+def test_fused_split_launch_falls_back_when_the_lds_dma_kernels_are_off():
+    """engine.Conv._launch asks csbsr_conv_split_fused_eligible before it hands over the fused [w_hi | w_lo] operand: with the LDS-DMA
+    kernels switched off (csbsr_debug_set_conv_glds(0), the debug mode the tests use to reach the register-staged kernels) the launch
+    used to fail with 'split_fused launch not eligible'; now it runs the three-block form of the same operand, same result to
+    accumulation-order noise."""
+    from csbsr_amd.engine import Conv
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    cin, cout, H, W, N = 64, 128, 24, 40, 2
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    xs = to_fm_split(eng, x)
+    ref = F.conv2d(from_fm_split(xs).double(), w.double(), None, 1, 1)
+    outs = []
+    try:
+        for mode in (2, 0):
+            L.load().csbsr_debug_set_conv_glds(mode)
+            conv = Conv(eng, "l", {"l.weight": w.cuda()}, 3, 1, 1, 1, bias=False)
+            out = conv.fwd(xs)
+            torch.cuda.synchronize()
+            kid = L.load().csbsr_debug_last_conv_kernel()
+            assert ((kid & 255) in (3, 4, 7, 14)) == (mode == 2) and (mode == 0 or (kid >> 8) & 1), (mode, kid)      # LDS-DMA + FS | register-staged
+            outs.append(from_fm_split(out).double())
+            assert float((outs[-1] - ref).abs().max() / ref.abs().max()) < 2e-5, mode
+    finally:
+        L.load().csbsr_debug_set_conv_glds(2)
+    assert float((outs[0] - outs[1]).abs().max() / ref.abs().max()) < 1e-5

