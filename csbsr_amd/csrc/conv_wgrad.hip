@@ -255,7 +255,7 @@ extern "C" void csbsr_debug_set_wgrad_tr(int v) {
   // hardware-transpose read; bits 8..9: LDS-DMA tile menu (256: no 256 x 256 tile, 512: no 128 x 256 tile); bit 10: LDS-DMA kernel only where the
   // 256-row tile applies (register-staged elsewhere: the default until the DMA pieces became inline assembly); bit 21: square tiles
   // for the tap-permuted 8x8 stride-4 layers; bit 22: linear 64-pixel stages (no 2-D stage rectangles)
-  g_wgrad_glds = ((v & 128) || !(v & 1)) ? 0 : (1 | ((v & 256) ? 0 : 2) | ((v & 512) ? 4 : 0) | ((v & 1024) ? 0 : 8) | ((v & (1 << 21)) ? 0 : 64) | ((v & (1 << 22)) ? 0 : 128) | ((v & (1 << 23)) ? 0 : 256));
+  g_wgrad_glds = ((v & 128) || !(v & 1)) ? 0 : (1 | ((v & 256) ? 0 : 2) | ((v & 512) ? 4 : 0) | ((v & 1024) ? 0 : 8) | ((v & (1 << 21)) ? 0 : 64) | ((v & (1 << 22)) ? 0 : 128) | ((v & (1 << 23)) ? 0 : 256) | ((v & (1 << 24)) ? 0 : 512));      // bit 24: no 256 x 256 tile for 512 .. 1023 columns (A/B timing)
   g_wgrad_extra_lds = ((v >> 12) & 0xff) * 1024;
 }
 

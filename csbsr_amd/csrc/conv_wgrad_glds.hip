@@ -19,12 +19,13 @@
 //  * tile order, tap permutation, row shift and the flat (split, tile) grid are those of conv_wgrad.hip.
 //
 // Autograd wgrad of F.conv2d / F.conv_transpose2d at the call sites listed in conv_igemm.hip.
+#include <cstdlib>
 #include "common.h"
 #include "csbsr_debug.h"
 #include "conv_wgrad.h"
 #include <type_traits>
 
-int g_wgrad_glds = 459;    // bit 0 kernel enabled, bit 1 256 x 256 tile, bit 2 no 128 x 256 tile, bit 3 every eligible problem, bit 6 128 x 256 tap-pair
+int g_wgrad_glds = 459 + 512;    // bit 0 kernel enabled, bit 1 256 x 256 tile, bit 2 no 128 x 256 tile, bit 3 every eligible problem, bit 6 128 x 256 tap-pair
                            // tiles for the 8x8 stride-4 layers, bit 7 2-D stage rectangles, bit 8 128 x 512 four-tap tiles for those layers (csbsr_debug_set_wgrad_tr)
 
 // One LDS-DMA piece (64 lanes x 16 bytes -> LDS bytes [lds_addr, lds_addr + 1024)) as inline assembly: behind the compiler's own
@@ -402,6 +403,12 @@ bool wgrad_glds_eligible(const WgradK& k) { return g_wgrad_glds != 0 && k.ca > 6
 // four-stage ring with one workgroup per CU measured 548 instead of 697).
 static bool pad_ok(int c, int t) { const int p128 = (c + 127) / 128 * 128, pt = (c + t - 1) / t * t; return pt * 8 <= p128 * 9; }
 int wgrad_glds_tile_a(const WgradK& k) {
+  // (round 5) 512 .. 1023 columns too, whatever the padding: the mirrored problems of the 64-cout 3x3 layers (9 taps x 64 = 576 columns, rows =
+  // 256 / 512 input channels) run three 256-wide column tiles instead of five 128-wide ones -- a quarter of the MFMA work is padding, but every
+  // input pixel is staged 3 x instead of 5 x: config 5's 505 -> 64 at HR 11.6 -> 8.6 ms per launch (646 -> 871 TF/s), the decoder's 256 -> 64
+  // 2.53 -> 2.25 ms (same-process A/B, scripts/wgrad_mirror_ab.py); in the step config 5 591 -> 570 ms, config 2 +-0.  Whole 256-row tiles only:
+  // with a remainder launch (HRNet's 720-channel 1x1 layers at 448^2) config 4 lost 10 ms per step
+  if ((g_wgrad_glds & 2) && (g_wgrad_glds & 512) && k.ca >= 256 && k.ca % 256 == 0 && k.ktot >= 512 && k.ktot < 1024 && !k.tap_perm) return 256;
   return (g_wgrad_glds & 2) && k.ca >= 256 && k.ktot >= 1024 && pad_ok(k.ktot, 256) && !k.tap_perm ? 256 : 128;
 }
 int wgrad_glds_tile_n(const WgradK& k) {

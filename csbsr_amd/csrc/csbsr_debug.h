@@ -24,7 +24,8 @@ int32_t csbsr_debug_last_wgrad_kernel(void);
  *          16 flat grid everywhere, 32 no row shift, 64 no 128x256 tile (register-staged kernel), 128 register-staged kernel everywhere
  *          (implied by bit0 = 0), 256 no 256x256 LDS-DMA tile, 512 no 128x256 LDS-DMA tile, 1024 LDS-DMA kernel for every >= 65-row problem (default:
  *          only where it runs the 256x256 tile), bits 12..19 extra dynamic LDS in KiB,
- *          bit 23 no 128 x 512 four-tap tile for the 8x8 stride-4 layers (the 128 x 256 tap-pair tile instead)
+ *          bit 23 no 128 x 512 four-tap tile for the 8x8 stride-4 layers (the 128 x 256 tap-pair tile instead),
+ *          bit 24 no 256 x 256 tile for problems of 512 .. 1023 columns (128 x 128 tiles, as through round 4)
  *   conv:  low 3 bits 0 = register-staged kernel only, 1 = 128x128 LDS-DMA tile only, 2 = default, 3 = 256x128 wherever it fits;
  *          16 no thin kernels, 32 phases on grid.z, 64 linear pixel tiles, 128 raster tap order, 256 no 256-cout tile */
 void csbsr_debug_set_wgrad_tr(int flags);

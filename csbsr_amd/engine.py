@@ -200,9 +200,10 @@ class Engine:
     def prelu_fold_ok(self, p):
         """May a learned PReLU slope's layer take the FOLDED backward (Conv.bwd_weights_folded(prelu_out=), the dgrad mask above it)?  That
         form takes the gate from the sign of the saved output and divides the slope-gradient sum by slope^2: right for a slope safely above
-        zero (nn.PReLU starts at 0.25), inf / the wrong gate at slope <= 0.  The slope is read WITHOUT stalling the stream: each call starts
-        an asynchronous copy into pinned host memory and decides from the value the previous call fetched (one optimiser step old -- the
-        1e-2 threshold leaves two orders of magnitude more than a step can move it); the first call reads synchronously."""
+        zero, inf / the wrong gate at slope <= 0.  The slope is read WITHOUT stalling the stream: each call starts
+        an asynchronous copy into pinned host memory and decides from the value the previous call fetched (one optimiser step old: the
+        threshold, 1e-3 -- the reference's SFTLikeBlock starts these slopes at 0.01 --, is ten Adam steps of lr 1e-4 above zero); the
+        first call reads synchronously."""
         st = getattr(p, "_slope_probe", None)
         if st is None:
             host = torch.empty(p.numel(), dtype=torch.float32, pin_memory=True)
@@ -210,7 +211,7 @@ class Engine:
         else:
             host, ev = st
             ev.synchronize()
-        ok = bool(float(host.min()) > 1e-2)
+        ok = bool(float(host.min()) > 1e-3)
         host.copy_(p.detach().reshape(-1).to(torch.float32), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))

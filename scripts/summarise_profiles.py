@@ -19,7 +19,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r03")
-DST = os.path.join(ROOT, "profiles")
+DST = os.environ.get("CSBSR_PROFILES_DST") or os.path.join(ROOT, "profiles")      # (on the GPU box: a directory under gpurun_out/, the only one that travels back)
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r03"
 
 
@@ -99,3 +99,37 @@ tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out["kernels"].valu
 print("total HBM bytes over the profiled run: %.1f GB" % (tot / 1e9))
 for k, v in list(out["kernels"].items())[:12]:
     print(f"{k:40s} n={v['launches']:5d} fetch/launch {v['fetch_bytes_per_launch']/1e6:9.1f} MB  write/launch {v['write_bytes_per_launch']/1e6:9.1f} MB")
+
+# ---- one table of current numbers (DESIGN.md section 5 quotes it verbatim): profiles/<tag>_summary.md
+bj = json.loads(line)
+rows = list(csv.DictReader(open(os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"))))
+nsteps = bj["steps"] + bj["warmup"]
+tot_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+roof = bj.get("roofline") or {}
+alg = dict(roof.get("other_kernels", {}))
+if roof:
+    alg[roof["kernel"]] = {"achieved": roof.get("mfma_tflops", roof.get("achieved")), "executed": roof.get("executed")}
+mfma = json.load(open(os.path.join(DST, f"{TAG}_pmc_mfma.json")))["kernels"] if os.path.exists(os.path.join(DST, f"{TAG}_pmc_mfma.json")) else {}
+md = [f"<!-- generated by scripts/summarise_profiles.py {os.path.basename(SRC)} {TAG} -->",
+      f"**{bj['config']['workload']}** — `{bj['value']}` img/s, {bj['ms_per_step']} ms/step ({bj['detector_precision']}); "
+      f"other mode: {(bj.get('other_precision') or {}).get('value')} img/s; peak {bj.get('peak_mem_gb')} GiB; "
+      f"kernel time {tot_ns / nsteps / 1e6:.0f} ms/step in {sum(int(r['Calls']) for r in rows) / nsteps:.0f} launches",
+      ""]
+if bj.get("step_roofline"):
+    md.append(f"step roofline: HBM {bj['step_roofline']['hbm_frac']}, MFMA {bj['step_roofline']['mfma_frac']} of peak; "
+              f"fabric traffic {tot / 1e9 / 8:.0f} GB per image-step (PMC passes at B = 4: warm-up + one step = 8 image-steps)")
+    md.append("")
+md += ["| rocprofv3 row | share | launches/step | avg µs | alg. TF/s (executed) | GB fetched+written / launch | L2 hit | MFMA busy @ GHz |", "|---|---|---|---|---|---|---|---|"]
+for r in rows[:16]:
+    k = canon(r["Name"])
+    a = alg.get(k, {})
+    t = out["kernels"].get(k, {})
+    m = mfma.get(k, {})
+    tf = f"{a.get('achieved', '')}" + (f" ({a['executed']})" if a.get("executed") not in (None, a.get("achieved")) else "") if a else ""
+    md.append(f"| `{k}` | {float(r['Percentage']):.1f} % | {int(r['Calls']) / nsteps:.0f} | {float(r['AverageNs']) / 1e3:.0f} | {tf} | "
+              f"{t.get('hbm_bytes_per_launch', 0) / 1e9:.2f} | {t.get('l2_hit_rate', '')} | "
+              + (f"{100 * m['mfma_util']:.0f} % @ {m['clock_ghz']:.2f}" if m else "") + " |")
+if roof.get("families"):
+    md += ["", "families (same time, summed per kernel source): " + ", ".join(f"`{k}` {100 * v['share_of_step_time']:.1f} %" for k, v in list(roof["families"].items())[:8])]
+open(os.path.join(DST, f"{TAG}_summary.md"), "w").write("\n".join(md) + "\n")
+print("\n".join(md))

@@ -18,7 +18,7 @@ SHAPES = {      # N, H, W, cin, cout, k, pad, dil
 }
 eng = Engine()
 eng._wg_on = False
-for name, (N, H, W, cin, cout, k, p, d) in SHAPES.items():
+for name, (N, H, W, cin, cout, k, p, d) in list(SHAPES.items())[:int(os.environ.get("AB_SHAPES", "99"))]:
     segs = cin if isinstance(cin, tuple) else (cin,)
     cin = sum(segs)
     params = {"l.weight": torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5}
