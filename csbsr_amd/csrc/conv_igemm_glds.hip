@@ -599,7 +599,11 @@ bool conv_glds_eligible(const ConvK& k) {
 int conv_glds_launch(const ConvK& k, int nphase, long maxM, hipStream_t st) {
   // measured (scripts/bench_conv.py): the 8-wave 256x128 tile only pays for long-K layers (SFT 3x3, ResNet 3x3, the 8x8 stride-4
   // gathers); transposed / short-K layers run faster with two 128x128 workgroups per CU
+  // (round 5) ... and for short-K layers into >= 384 output channels over >= 4 M pixels (config 5's 64 -> 505 blur_skip layers at HR 1792^2,
+  // B = 4: the 256 px x 256 cout tile halves the tile count of an epilogue-bound launch -- dgrad 12.3 -> 10.7 ms, the step 569 -> 551 ms;
+  // the same tile on config 2's / config 4's short-K layers, 0.8 M pixels each, measured +-0 / -0.6 %: they keep two 128 x 128 workgroups per CU)
   const bool big = (g_glds_mode == 2 && !k.transposed && k.Kp >= 2304 && maxM >= 256 * 256) ||
+                   (g_glds_mode == 2 && !k.transposed && k.Kp >= 512 && k.coutp >= 384 && maxM >= (1l << 22)) ||
                    (g_glds_mode == 3 && maxM >= 256 * 256);     // mode 3 (A/B timing): the 256-row tile wherever it fits
   // 256 px x 256 couts (128 flop per staged byte instead of 85) where the couts fill 256-wide tiles about as well as 128-wide ones
   const int pad128 = (k.coutp + 127) / 128 * 128, pad256 = (k.coutp + 255) / 256 * 256;
