@@ -267,3 +267,30 @@ def test_kernel_branch_table_is_the_two_conv_branch():
             sums[:, typ(i, H), typ(j, W)] += g[:, :, i, j]
     for a, b in zip(torch.autograd.grad(y, [kv, w0, w1, wt], g, retain_graph=True), torch.autograd.grad(tab, [kv, w0, w1, wt], sums)):
         assert float((a - b).abs().max()) < 1e-10
+
+
+def test_kernel_row_names_agree_between_bench_and_profiles():
+    """bench.py names a launch by the id the library reports (csbsr_debug_last_conv_kernel: kernel in the low byte, template instance above),
+    scripts/summarise_profiles.py names the same launch by its rocprofv3 row: csbsr_amd/utils/kernel_names.py must give both the SAME string, or
+    the roofline block's PMC lookups silently miss (review r04, item 8)."""
+    from csbsr_amd.utils.kernel_names import conv_row, wgrad_row, canon, family
+    pairs = [
+        (7 | (1 << 8), "_Z22conv_igemm_glds_kernelILi256ELi4ELi2ELi2ELb1ELb0EEv5ConvKPKDF16_"),
+        (3 | (2 << 8), "void conv_igemm_glds_kernel<128, 2, 2, 1, false, true>(ConvK, _Float16 const*)"),
+        (14, "_Z22conv_igemm_glds_kernelILi128ELi2ELi2ELi0ELb0ELb0EEv5ConvKPKDF16_"),
+        (9 | ((2 | 4 | 8) << 8), "_Z14conv_tp_kernelILi2ELb0ELb1ELb1ELb1EEv7ConvTpKPKDF16_PDF16_"),
+        (9 | (1 << 8), "_Z14conv_tp_kernelILi2ELb1ELb0ELb0ELb0EEv7ConvTpKPKDF16_PDF16_"),
+        (8 | ((4 | 8) << 8), "void conv_hr_kernel<4, false, 9, 2, true, false>(ConvHrK)"),
+        (8 | ((1 | 2 | 32) << 8), "void conv_hr_kernel<7, false, 1, 1, false, true>(ConvHrK)"),
+        (17, "_Z14conv_x3_kernelILi3ELi1024EEv5ConvK7X3ExtraPKDF16_"),
+        (10 | (1 << 8), "_Z14conv_x3_kernelILi3ELi2048EEv5ConvK7X3ExtraPKDF16_"),
+        (18, "_Z14conv_x3_kernelILi2ELi1024EEv5ConvK7X3ExtraPKDF16_"),
+        (13, "void conv_thin_cin2_kernel<false>(ConvK, int, int, int, int, Cin2Dact)"),
+    ]
+    for kid, raw in pairs:
+        assert conv_row(kid) == canon(raw), (kid, conv_row(kid), canon(raw))
+    for kid, raw in [(7, "_Z22conv_wgrad_glds_kernelILi256ELi256ELi2ELi4ELi2ELb1EEv6WgradKPKDF16_"),
+                     (9, "_Z22conv_wgrad_glds_kernelILi128ELi512ELi2ELi4ELi2ELb1EEv6WgradKPKDF16_"),
+                     (3, "void conv_wgrad_kernel<32, 128, 1, 4, true>(WgradK)"), (8, "void conv_wgrad_hr_kernel<7, 4, 4, 4>(WgradHrK)")]:
+        assert wgrad_row(kid) == canon(raw), (kid, wgrad_row(kid), canon(raw))
+    assert family("conv_tp_kernel<res=1,acc=0,mask=0,sums=0>") == "conv_tp_kernel" and family("epilogue_bwd_kernel") == "epilogue_bwd_kernel"
