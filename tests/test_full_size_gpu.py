@@ -76,16 +76,16 @@ def test_full_size_step_is_finite_and_micro_batch_invariant():
     assert float((a - b).abs().max()) <= 1e-3 * float(sr.abs().max())
 
 
-@pytest.mark.parametrize("mb", [8, 4])
-def test_bench_size_step_batch_8(mb):
+def test_bench_size_step_batch_8():
     """bench.py's exact shape -- config 2 at B = 8, LR 448 -> HR 1792, KBPN as ONE micro-batch of 8 (the bench default since round 5: 243 GiB
-    peak, 2 % faster than two of 4 -- the persistent tile kernels' last round is fuller) or two of 4 (through round 4), the residency
-    schedule chosen from the free HBM (lean saves, everything resident) -- where a 64-channel detector map at 1792^2 is 3.3 GB and a
-    128-channel KBPN map of the 8-image micro-batch 6.6 GB (past the 2 GB
-    buffer-descriptor windows a B = 2 run never crosses) and bench.py itself only prints a loss.  Properties: every output and all 290
-    gradients finite, no overflow; KBPN has no batch-coupled operation, so samples 0-1 -- the B = 2 batch, the other six are its flips --
-    must give the B = 2 run's SR image (fp16 storage noise: another launch size may pick another kernel) and per-sample SR loss (1e-4);
-    a second forward + backward of the same model is bit-identical (outputs and every gradient)."""
+    peak, 2 % faster than two of 4 -- the persistent tile kernels' last round is fuller), the residency schedule chosen from the free HBM
+    (lean saves, everything resident) -- where a 64-channel detector map at 1792^2 is 3.3 GB and a 128-channel KBPN map of the 8-image
+    micro-batch is 3.3e9 ELEMENTS (past 2^31: every 32-bit element offset that survived the N = 4 maps of rounds 1-4 would wrap here), and
+    bench.py itself only prints a loss.  Properties: every output and all 290 gradients finite, no overflow; a second forward + backward
+    of the same model is bit-identical; KBPN has no batch-coupled operation, so (i) samples 0-1 -- the B = 2 batch, the other six are its
+    flips -- give the B = 2 run's SR image (fp16 storage noise: another launch size may pick another kernel) and per-sample SR loss
+    (1e-4), and (ii) ALL eight samples and every gradient agree with the same step run as two micro-batches of 4 (the schedule of rounds
+    1-4, whose largest map has 1.6e9 elements): an addressing error in the upper half of any buffer is O(1) there."""
     from csbsr_amd.data.synthetic import make_batch
     x, hr, mask, k = make_batch(2, 112, seed=77)
     x, hr, mask = _tile(x, 4), _tile(hr, 4), _tile(mask, 4)
@@ -98,21 +98,26 @@ def test_bench_size_step_batch_8(mb):
     fl = lambda t: torch.cat([t, t.flip(-1), t.flip(-2), t.flip(-1, -2)]).contiguous()
     x8, hr8, mask8, k8 = fl(x), fl(hr), fl(mask), fl(k)
     assert x8.shape[0] == 8 and hr8.shape[-1] == 1792
-    m = _model(mb, 40000)
-    m.max_resident = None                    # as bench.py: _auto_resident decides from the free memory
-    runs = []
-    for _ in range(2):
-        for p in m.parameters():
-            p.grad = None
-        seg_l, sr_l, seg, sr, kp = m(40000, x8, sr_targets=hr8, segment_targets=mask8, kernel_targets=k8)
-        (0.7 * sr_l.mean() + 0.3 * seg_l.mean()).backward()
-        torch.cuda.synchronize()
-        assert not m.last_step_overflowed
-        outs = dict(seg_l=seg_l.detach().clone(), sr_l=sr_l.detach().clone(), seg=seg.detach().clone(), sr=sr.detach().clone(), kp=kp.detach().clone())
-        grads = {n: v.grad.detach().clone() for n, v in m._named_full() if isinstance(v, torch.nn.Parameter) and v.grad is not None}
-        runs.append((outs, grads))
-    print(f"   B = 8, micro-batch {mb}: n_resident {m._n_res}, lean saves {m._lean}, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
-    (o, g), (o_b, g_b) = runs
+
+    def run(mb, times):
+        m = _model(mb, 40000)
+        m.max_resident = None                    # as bench.py: _auto_resident decides from the free memory
+        res = []
+        for _ in range(times):
+            for p in m.parameters():
+                p.grad = None
+            seg_l, sr_l, seg, sr, kp = m(40000, x8, sr_targets=hr8, segment_targets=mask8, kernel_targets=k8)
+            (0.7 * sr_l.mean() + 0.3 * seg_l.mean()).backward()
+            torch.cuda.synchronize()
+            assert not m.last_step_overflowed
+            outs = dict(seg_l=seg_l.detach().cpu(), sr_l=sr_l.detach().cpu(), seg=seg.detach().cpu(), sr=sr.detach().cpu(), kp=kp.detach().cpu())
+            grads = {n: v.grad.detach().cpu() for n, v in m._named_full() if isinstance(v, torch.nn.Parameter) and v.grad is not None}
+            res.append((outs, grads))
+        print(f"   B = 8, micro-batch {mb}: n_resident {m._n_res}, lean saves {m._lean}, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
+        del m
+        torch.cuda.empty_cache()
+        return res
+    (o, g), (o_b, g_b) = run(8, 2)
     assert len(g) == 290
     for kk, v in o.items():
         assert bool(torch.isfinite(v).all()), kk
@@ -120,11 +125,21 @@ def test_bench_size_step_batch_8(mb):
     for n, v in g.items():
         assert bool(torch.isfinite(v).all()), n
         assert torch.equal(v, g_b[n]), n
-    e_sr = float((o["sr"][:2] - sr2).abs().max() / sr2.abs().max())
-    e_kp = float((o["kp"][:2] - kp2).abs().max() / kp2.abs().max())
-    e_l = float(((o["sr_l"][:2] - sr_l2).abs() / sr_l2.abs()).max())
+    e_sr = float((o["sr"][:2] - sr2.cpu()).abs().max() / sr2.abs().max())
+    e_kp = float((o["kp"][:2] - kp2.cpu()).abs().max() / kp2.abs().max())
+    e_l = float(((o["sr_l"][:2] - sr_l2.cpu()).abs() / sr_l2.cpu().abs()).max())
     print(f"   samples 0-1 of the B = 8 run vs the B = 2 run: sr {e_sr:.2e}  kernel {e_kp:.2e}  per-sample sr_loss {e_l:.2e}")
     assert e_sr <= 2e-3 and e_kp <= 2e-3 and e_l <= 1e-4
+    del o_b, g_b
+    ((o4, g4),) = run(4, 1)
+    for kk in ("sr", "kp", "seg", "sr_l", "seg_l"):
+        d = float((o[kk] - o4[kk]).abs().max() / o4[kk].abs().max())
+        per = [float((o[kk][i] - o4[kk][i]).abs().max() / o4[kk].abs().max()) for i in range(8)] if o[kk].dim() > 1 else []
+        print(f"   micro-batch 8 vs 4, all eight samples: {kk} {d:.2e}" + (f"  (per sample max {max(per):.2e} at {per.index(max(per))})" if per else ""))
+        assert d <= (2e-3 if kk in ("sr", "kp", "seg") else 1e-4), kk
+    worst = max(float((a.double() - g4[n].double()).norm() / a.double().norm()) for n, a in g.items() if a.numel() > 1 and float(a.norm()) > 0)
+    print(f"   micro-batch 8 vs 4: gradients agree to {worst:.2e} (relative L2, worst tensor)")
+    assert worst < 3e-2
 
 
 def test_residency_schedule_under_memory_pressure():
