@@ -59,12 +59,28 @@ def tapsum_round(w, transposed=False, stride=1):
     return Q.reshape(w.shape)
 
 
+def r16_diffuse(x, block):
+    """fp16 rounding of a stored map with the rounding error carried DOWN the rows of a ``block``-row group (noise shaping: the group's
+    column sums are rounded once, not ``block`` times -- the error moves to vertical frequencies a low-pass consumer damps); block 0 = the
+    whole column"""
+    N, C, H, W = x.shape
+    q = torch.empty_like(x)
+    carry = torch.zeros(N, C, W, dtype=x.dtype)
+    for r in range(H):
+        if block and r % block == 0:
+            carry.zero_()
+        t = x[:, :, r, :] + carry
+        q[:, :, r, :] = t.half().float()
+        carry = t - q[:, :, r, :]
+    return q
+
+
 class storage_sim:
     """comp: None | "bias" (per-sample channel means x tap sums of the rounding residual, non-transposed layers: what engine.Conv._dc_bias
     does) | "exact" (the residual filter's full response to the per-sample constant map, every layer: the upper bound of the idea)"""
 
-    def __init__(self, names, round_w, round_x, comp=None):
-        self.names, self.rw, self.rx, self.comp = names, round_w, round_x, comp
+    def __init__(self, names, round_w, round_x, comp=None, diffuse=None):
+        self.names, self.rw, self.rx, self.comp, self.diffuse = names, round_w, round_x, comp, diffuse
         self.cache = {}
 
     def __enter__(self):
@@ -77,7 +93,16 @@ class storage_sim:
                 n = self.names.get(id(w))
                 if n is None or not n.startswith("sr_model"):
                     return fn(x, w, b, *a, **k)
-                xi = r16(x) if self.rx(n) else x
+                if self.rx(n):
+                    if self.diffuse is None or x.shape[2] < 8:
+                        xi = r16(x)
+                    else:
+                        key = ("x", id(x))
+                        if key not in self.cache:
+                            self.cache[key] = (x, r16_diffuse(x, self.diffuse))      # (the tensor is kept alive with its rounded copy: ids stay unique)
+                        xi = self.cache[key][1]
+                else:
+                    xi = x
                 if not self.rw(n):
                     return fn(xi, w, b, *a, **k)
                 if self.comp in ("tapsum", "tapsum+bias") and ".kernel_predictor." not in n:
@@ -126,8 +151,8 @@ def main():
     drop = {kk.split(".", 1)[1]: torch.from_numpy(v) for kk, v in g.items() if kk.startswith("dropmask.")}
     it = int(g["it"])
 
-    def run(rw, rx, comp=None):
-        with torch.no_grad(), storage_sim(names, rw, rx, comp):
+    def run(rw, rx, comp=None, diffuse=None):
+        with torch.no_grad(), storage_sim(names, rw, rx, comp, diffuse):
             sr, kvec = O.kbpn_forward(P, x, it, k, cfg)
             bn = O.BNState(P, True)
             seg, aux = O.pspnet_forward(P, O.norm_sr(sr, cfg), bn, drop, kvec if cfg.detector == "PSPNet_BlurSkip" else None)
@@ -153,6 +178,16 @@ def main():
                                ("W + X, tap-sum-preserving rounding", yes, yes, "tapsum"), ("W + X, tap-sum rounding + bias comp.", yes, yes, "tapsum+bias")):
         e = run(rw, rx, comp)
         print(f"{name:44s} sr {e[0]:.2e} ({e[1]:.2e})   seg {e[2]:.2e} ({e[3]:.2e})", flush=True)
+
+
+    if os.environ.get("STUDY_DIFFUSE"):
+        print("-- activation storage with error diffusion down groups of rows (r16_diffuse)")
+        for blk in (4, 8, 0):
+            e = run(no, yes, None, blk)
+            print(f"{'X only, rows diffused in groups of ' + (str(blk) if blk else 'H'):44s} sr {e[0]:.2e} ({e[1]:.2e})   seg {e[2]:.2e} ({e[3]:.2e})", flush=True)
+        for blk in (4, 0):
+            e = run(yes, yes, "tapsum+bias", blk)
+            print(f"{'W (tap-sum + bias) + X diffused, groups of ' + (str(blk) if blk else 'H'):44s} sr {e[0]:.2e} ({e[1]:.2e})   seg {e[2]:.2e} ({e[3]:.2e})", flush=True)
 
 
 if __name__ == "__main__":
