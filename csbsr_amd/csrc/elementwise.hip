@@ -1,6 +1,7 @@
 // HBM-bound kernels on fp16 channels-last activations: epilogue backward, batch-norm, pooling, bilinear resize,
 // layout converters.  Every thread moves 16 bytes (8 channels) per access; reductions go wave-shuffle ->
 // LDS -> one partial row per workgroup -> csbsr_sum_partials (fixed order, no atomics: common.h).  Reference call sites are cited per entry point in include/csbsr_hip.h.
+#include <cstdlib>
 #include "common.h"
 
 static inline int grid_for(long work, int block = 256, int cap = 8192) {
@@ -1412,6 +1413,53 @@ __global__ void bilinear_fwd_kernel(const half_t* x, long x_ld, half_t* y, long 
   }
   }
 }
+// (round 5) the same arithmetic with the loops swapped: a thread OWNS one (output column, channel octet) and walks a strip of BIL_RS output
+// rows, so the column's source positions, weight and addresses -- one 32-bit division and one float division per octet in the kernel above,
+// ~250 VALU instructions per octet next to ~100 of conversions and lerps: the pass was VALU-bound at 1.65 ms per 3.3 GB of output whatever the
+// input size (2.0 TB/s written; torch's fill writes 6.9 on the same buffer) -- are computed once per thread; the strip's row sources come from LDS.
+#define BIL_RS 16
+__global__ __launch_bounds__(256) void bilinear_fwd_cols_kernel(const half_t* x, long x_ld, half_t* y, long y_ld, int N, int H, int W, int c8, int OH,
+                                                                 int OW, int align, const float* drop, int cp, long x_lo, long y_lo) {
+  __shared__ int sy0[BIL_RS], sy1[BIL_RS];
+  __shared__ float swy[BIL_RS];
+  const unsigned strips = (unsigned)(OH + BIL_RS - 1) / BIL_RS;
+  const int n = (int)(blockIdx.y / strips), r0 = (int)(blockIdx.y % strips) * BIL_RS;
+  if (threadIdx.x < BIL_RS) {
+    int a0 = 0, a1 = 0; float wq = 0.f;
+    if (r0 + (int)threadIdx.x < OH) bil_src(r0 + (int)threadIdx.x, H, OH, align, a0, a1, wq);
+    sy0[threadIdx.x] = a0; sy1[threadIdx.x] = a1; swy[threadIdx.x] = wq;
+  }
+  __syncthreads();
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned)OW * (unsigned)c8) return;
+  const int ox = (int)(i / (unsigned)c8), cc = (int)(i - (unsigned)ox * (unsigned)c8);
+  int x0, x1; float wx;
+  bil_src(ox, W, OW, align, x0, x1, wx);
+  float dr[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  if (drop) ld8f(drop + n * cp + cc * 8, dr);
+  const half_t* c0 = x + (long)n * H * W * x_ld + (long)x0 * x_ld + cc * 8;
+  const half_t* c1 = x + (long)n * H * W * x_ld + (long)x1 * x_ld + cc * 8;
+  half_t* yc = y + ((long)n * OH * OW + ox) * y_ld + cc * 8;
+  const long rs_in = (long)W * x_ld, rs_out = (long)OW * y_ld;
+  const int rows = OH - r0 < BIL_RS ? OH - r0 : BIL_RS;
+#pragma unroll 4
+  for (int r = 0; r < rows; ++r) {
+    const long o0 = sy0[r] * rs_in, o1 = sy1[r] * rs_in;
+    const float wy = swy[r];
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    ld_split(c0 + o0, x_lo, v00);
+    ld_split(c1 + o0, x_lo, v01);
+    ld_split(c0 + o1, x_lo, v10);
+    ld_split(c1 + o1, x_lo, v11);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = (1.f - wy) * ((1.f - wx) * v00[e] + wx * v01[e]) + wy * ((1.f - wx) * v10[e] + wx * v11[e]);
+      if (drop) v *= dr[e];
+      o[e] = v;
+    }
+    st_split(yc + (long)(r0 + r) * rs_out, y_lo, o);
+  }
+}
 // gather-form adjoint: each input pixel sums the output pixels that reference it (scan of a bounded output window)
 __global__ void bilinear_bwd_kernel(const half_t* dy, long dy_ld, half_t* dx, long dx_ld, int accumulate, int N, int H, int W, int c8,
                                     int OH, int OW, int align, const float* drop, int cp) {
@@ -1472,6 +1520,15 @@ extern "C" int csbsr_bilinear_fwd_split(const void* x, int64_t x_ld, int64_t x_l
   CSBSR_CHECK(x && y && c % 8 == 0, "bilinear_fwd: bad args");
   CSBSR_CHECK((long)N * OH < (1l << 31) && (long)OW * (c / 8) < (1l << 31), "bilinear_fwd: size");
   const long per_row = (long)OW * (c / 8), rows = (long)N * OH;
+  static int cols = -1;
+  if (cols < 0) { const char* e = getenv("CSBSR_BIL_COLS"); cols = e ? atoi(e) : 1; }      // (A/B hook: 0 = the row-major kernel)
+  const long strips = (long)N * ((OH + BIL_RS - 1) / BIL_RS);
+  if (cols && OH >= BIL_RS && strips <= 65535 && (per_row + 255) / 256 * strips >= 1024) {
+    hipLaunchKernelGGL(bilinear_fwd_cols_kernel, dim3((unsigned)((per_row + 255) / 256), (unsigned)strips), dim3(256), 0, ST(s), (const half_t*)x, x_ld,
+                       (half_t*)y, y_ld, N, H, W, c / 8, OH, OW, align_corners, drop, c, x_lo, y_lo);
+    CSBSR_LAUNCH_CHECK("csbsr_bilinear_fwd");
+    return 0;
+  }
   const int bx = (int)((per_row + 255) / 256 > 64 ? 64 : (per_row + 255) / 256);
   hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(bx, (unsigned)(rows > 65535 ? 65535 : rows)), dim3(256), 0, ST(s), (const half_t*)x, x_ld,
                      (half_t*)y, y_ld, N, H, W, c / 8, OH, OW, align_corners, drop, c, x_lo, y_lo);
