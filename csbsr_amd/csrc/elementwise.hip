@@ -1523,7 +1523,7 @@ extern "C" int csbsr_bilinear_fwd_split(const void* x, int64_t x_ld, int64_t x_l
   static int cols = -1;
   if (cols < 0) { const char* e = getenv("CSBSR_BIL_COLS"); cols = e ? atoi(e) : 1; }      // (A/B hook: 0 = the row-major kernel)
   const long strips = (long)N * ((OH + BIL_RS - 1) / BIL_RS);
-  if (cols && OH >= BIL_RS && strips <= 65535 && (per_row + 255) / 256 * strips >= 1024) {
+  if (cols && OH >= BIL_RS && strips <= 65535 && (per_row + 255) / 256 * strips >= 64) {
     hipLaunchKernelGGL(bilinear_fwd_cols_kernel, dim3((unsigned)((per_row + 255) / 256), (unsigned)strips), dim3(256), 0, ST(s), (const half_t*)x, x_ld,
                        (half_t*)y, y_ld, N, H, W, c / 8, OH, OW, align_corners, drop, c, x_lo, y_lo);
     CSBSR_LAUNCH_CHECK("csbsr_bilinear_fwd");
@@ -1598,6 +1598,95 @@ __global__ __launch_bounds__(256) void bilinear_bwd_block_kernel(const half_t* d
     *reinterpret_cast<h8*>(q) = o;
   }
 }
+// (round 5) small ratios with the adjoint's window TABULATED: per input coordinate i the outputs o that reference it are a short run
+// [lo, lo + cnt) with weights w[k] (the scan of the kernel above, done once per axis by bil_tab_kernel -- on the device, with bil_src's own
+// float arithmetic, so the tables are the forward's index map exactly), and a thread owns one (input column, channel octet) and walks a
+// strip of input rows: no bil_src, no division, no window scan per octet (the scan was ~1000 VALU instructions per octet: 2.07 ms for the
+// decoder's 256-channel x2 gradient at B = 8).  Same sums in the same order (rows outer, columns inner, (cy cx) g), so the results are the
+// old kernel's bit for bit except where it skipped an exactly-zero weight in the middle of a run (now adds +0).
+#define BIL_KMAX 6
+struct BilTab { int lo, cnt; float w[BIL_KMAX]; };
+__global__ void bil_tab_kernel(BilTab* tab, int in, int out, int align) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= in) return;
+  const float r = (align && in > 1) ? (float)(out - 1) / (in - 1) : (float)out / in;
+  int lo = (int)floorf((i - 1.5f) * r) - 2, hi = (int)ceilf((i + 1.5f) * r) + 2;
+  if (i == 0) lo = 0;
+  if (i == in - 1) hi = out - 1;
+  lo = lo < 0 ? 0 : lo; hi = hi > out - 1 ? out - 1 : hi;
+  BilTab t; t.lo = 0; t.cnt = 0;
+  for (int k = 0; k < BIL_KMAX; ++k) t.w[k] = 0.f;
+  int first = -1, last = -2;
+  for (int o = lo; o <= hi; ++o) {
+    int i0, i1; float w1; bil_src(o, in, out, align, i0, i1, w1);
+    float c = 0.f;
+    if (i0 == i) c += 1.f - w1;
+    if (i1 == i) c += w1;
+    if (c != 0.f) { if (first < 0) first = o; last = o; }
+  }
+  if (first >= 0) {
+    t.lo = first; t.cnt = last - first + 1;
+    for (int o = first; o <= last && o - first < BIL_KMAX; ++o) {
+      int i0, i1; float w1; bil_src(o, in, out, align, i0, i1, w1);
+      float c = 0.f;
+      if (i0 == i) c += 1.f - w1;
+      if (i1 == i) c += w1;
+      t.w[o - first] = c;
+    }
+  }
+  tab[i] = t;          // (cnt > BIL_KMAX cannot happen for the ratios this path takes: out / in < 2.5)
+}
+#define BILB_RS 8
+__global__ __launch_bounds__(256) void bilinear_bwd_cols_kernel(const half_t* dy, long dy_ld, half_t* dx, long dx_ld, int accumulate, int N, int H,
+                                                                 int W, int c8, int OH, int OW, const float* drop, int cp, const BilTab* tabx,
+                                                                 const BilTab* taby) {
+  __shared__ BilTab sy[BILB_RS];
+  const unsigned strips = (unsigned)(H + BILB_RS - 1) / BILB_RS;
+  const int n = (int)(blockIdx.y / strips), r0 = (int)(blockIdx.y % strips) * BILB_RS;
+  if (threadIdx.x < BILB_RS && r0 + (int)threadIdx.x < H) sy[threadIdx.x] = taby[r0 + threadIdx.x];
+  __syncthreads();
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned)W * (unsigned)c8) return;
+  const int ix = (int)(i / (unsigned)c8), cc = (int)(i - (unsigned)ix * (unsigned)c8);
+  const BilTab tx = tabx[ix];
+  float dr[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  if (drop) ld8f(drop + n * cp + cc * 8, dr);
+  const half_t* g0 = dy + ((long)n * OH * OW + tx.lo) * dy_ld + cc * 8;
+  half_t* q0 = dx + ((long)n * H * W + ix) * dx_ld + cc * 8;
+  const int rows = H - r0 < BILB_RS ? H - r0 : BILB_RS;
+  for (int r = 0; r < rows; ++r) {
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    const BilTab ty = sy[r];
+    for (int ky = 0; ky < ty.cnt; ++ky) {
+      const float cy = ty.w[ky];
+      if (cy == 0.f) continue;
+      const half_t* gr = g0 + (long)(ty.lo + ky) * OW * dy_ld;
+#pragma unroll
+      for (int kx = 0; kx < BIL_KMAX; ++kx) {
+        if (kx < tx.cnt && tx.w[kx] != 0.f) {
+          const h8 g = *reinterpret_cast<const h8*>(gr + (long)kx * dy_ld);
+          const float wv = cy * tx.w[kx];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += wv * (float)g[e];
+        }
+      }
+    }
+    if (drop) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] *= dr[e];
+    }
+    half_t* q = q0 + (long)(r0 + r) * W * dx_ld;
+    if (accumulate) { const h8 old = *reinterpret_cast<const h8*>(q);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += (float)old[e]; }
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)a[e];
+    *reinterpret_cast<h8*>(q) = o;
+  }
+}
 extern "C" int csbsr_bilinear_bwd(const void* dy, int64_t dy_ld, void* dx, int64_t dx_ld, int32_t accumulate, int32_t N, int32_t H,
                                   int32_t W, int32_t c, int32_t OH, int32_t OW, int32_t align_corners, const float* drop,
                                   csbsr_stream_t s) {
@@ -1607,8 +1696,20 @@ extern "C" int csbsr_bilinear_bwd(const void* dy, int64_t dy_ld, void* dx, int64
     hipLaunchKernelGGL(bilinear_bwd_block_kernel, dim3(N * H * W * groups), dim3(256), 0, ST(s), (const half_t*)dy, dy_ld, (half_t*)dx, dx_ld,
                        accumulate, N, H, W, c / 8, OH, OW, align_corners, drop, c);
   } else {
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), (const half_t*)dy, dy_ld,
-                       (half_t*)dx, dx_ld, accumulate, N, H, W, c / 8, OH, OW, align_corners, drop, c);
+    static int cols = -1;
+    if (cols < 0) { const char* e = getenv("CSBSR_BIL_COLS"); cols = e ? atoi(e) : 1; }      // (A/B hook: 0 = the scanning kernel)
+    const long per_row = (long)W * (c / 8), strips = (long)N * ((H + BILB_RS - 1) / BILB_RS);
+    BilTab* tab = (cols && OH >= H && OW >= W && 2 * OH <= 5 * H && 2 * OW <= 5 * W && strips <= 65535 && (per_row + 255) / 256 * strips >= 64)
+                      ? reinterpret_cast<BilTab*>(csbsr_red_scratch(((long)W + H) * (long)(sizeof(BilTab) / 4))) : nullptr;
+    if (tab) {
+      hipLaunchKernelGGL(bil_tab_kernel, dim3((W + 255) / 256), dim3(256), 0, ST(s), tab, W, OW, align_corners);
+      hipLaunchKernelGGL(bil_tab_kernel, dim3((H + 255) / 256), dim3(256), 0, ST(s), tab + W, H, OH, align_corners);
+      hipLaunchKernelGGL(bilinear_bwd_cols_kernel, dim3((unsigned)((per_row + 255) / 256), (unsigned)strips), dim3(256), 0, ST(s), (const half_t*)dy, dy_ld,
+                         (half_t*)dx, dx_ld, accumulate, N, H, W, c / 8, OH, OW, drop, c, tab, tab + W);
+    } else {
+      hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(grid_for((long)N * H * W * (c / 8))), dim3(256), 0, ST(s), (const half_t*)dy, dy_ld,
+                         (half_t*)dx, dx_ld, accumulate, N, H, W, c / 8, OH, OW, align_corners, drop, c);
+    }
   }
   CSBSR_LAUNCH_CHECK("csbsr_bilinear_bwd");
   return 0;

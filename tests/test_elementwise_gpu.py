@@ -190,6 +190,32 @@ def test_maxpool_and_adaptive_pool():
 
 
 @pytest.mark.parametrize("align", [False, True])
+@pytest.mark.parametrize("shape,c", [((96, 128, 192, 256), 64), ((100, 75, 230, 160), 40), ((64, 64, 64, 64), 24), ((50, 120, 51, 300), 16)])
+def test_bilinear_column_kernels(align, shape, c):
+    """the column-owning forward (bilinear_fwd_cols_kernel) and the tabulated backward (bil_tab_kernel + bilinear_bwd_cols_kernel) at sizes
+    that reach them (>= 64 workgroups; ratios <= 2.5 for the backward): against torch, with the dropout scale row and in accumulate mode"""
+    eng = _eng()
+    H, W, OH, OW = shape
+    torch.manual_seed(H + c)
+    N = 2
+    x = r16(torch.randn(N, c, H, W)).requires_grad_(True)
+    drop = (torch.rand(N, c) > 0.3).float() * 1.25
+    y = F.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=align) * drop[:, :, None, None]
+    dy = r16(torch.randn_like(y))
+    y.backward(dy)
+    from csbsr_amd.engine import pad8
+    dd = torch.zeros(N, pad8(c)); dd[:, :c] = drop
+    dd = dd.cuda()
+    fy = eng.bilinear(to_fm(x.detach()), OH, OW, align, drop=dd)
+    base = r16(torch.randn(N, c, H, W))
+    dx = to_fm(base)
+    eng.bilinear_bwd(to_fm(dy), dx, True, align, drop=dd)
+    torch.cuda.synchronize()
+    assert relmax(from_fm(fy), y.detach()) < 2e-3
+    assert relmax(from_fm(dx), base + x.grad) < 2e-3
+
+
+@pytest.mark.parametrize("align", [False, True])
 @pytest.mark.parametrize("shape", [(8, 8, 16, 16), (1, 1, 8, 8), (3, 3, 8, 8), (6, 6, 8, 8), (8, 8, 64, 64), (5, 7, 20, 21)])
 def test_bilinear_fwd_bwd(align, shape):
     from csbsr_amd import _lib as L
