@@ -59,6 +59,8 @@ if __name__ == "__main__":
         "hr1x1_32_49": (1, 1792, 1792, 32, 49, 1, 1, 0),
         "thin3_128": (1, 1792, 1792, 3, 128, 3, 1, 1),
         "thin3_512": (1, 1792, 1792, 3, 512, 3, 1, 1),
+        "thin512_3": (1, 1792, 1792, 512, 3, 3, 1, 1),         # output_conv / kb.sr_reconst of the last stage: the 3-channel image heads (conv_thin_cout)
+        "thin128_3": (1, 1792, 1792, 128, 3, 3, 1, 1),
         "conv8s4_small": (1, 448, 448, 128, 128, 8, 4, 2),
         "c128_small": (1, 112, 112, 128, 128, 3, 1, 1),
         "c128": (1, 448, 448, 128, 128, 3, 1, 1),
