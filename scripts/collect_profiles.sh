@@ -11,13 +11,13 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py $EXTRA > $O/bench.json 2> $O/bench.err
 # the stats pass runs EXACTLY the steps the JSON reports (no H2D leg, no other-precision leg): per-step launch counts = calls / (steps + warmup)
-rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $R/bench.py $EXTRA --no-cpu-baseline --no-h2d-leg --no-other-precision-leg > $O/bench_under_rocprof.json 2> $O/stats.err
+timeout -s KILL 900 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $R/bench.py $EXTRA --no-cpu-baseline --no-h2d-leg --no-other-precision-leg > $O/bench_under_rocprof.json 2> $O/stats.err
 PM="$EXTRA --batch 4 --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-h2d-leg --no-other-precision-leg"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch --output-format csv -- python3 $R/bench.py $PM > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write --output-format csv -- python3 $R/bench.py $PM > $O/pmc_write.json 2> $O/pmc_write.err
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_MFMA -d $O/pmc_mfma -o mfma --output-format csv -- python3 $R/bench.py $PM > $O/pmc_mfma.json 2> $O/pmc_mfma.err
+timeout -s KILL 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch --output-format csv -- python3 $R/bench.py $PM > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+timeout -s KILL 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o write --output-format csv -- python3 $R/bench.py $PM > $O/pmc_write.json 2> $O/pmc_write.err
+timeout -s KILL 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_MFMA -d $O/pmc_mfma -o mfma --output-format csv -- python3 $R/bench.py $PM > $O/pmc_mfma.json 2> $O/pmc_mfma.err
 # L2 hit rate next to FETCH_SIZE (which also counts Infinity-Cache hits: MI355X_MICROARCH.md, HBM section)
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $O/pmc_l2 -o l2 --output-format csv -- python3 $R/bench.py $PM > $O/pmc_l2.json 2> $O/pmc_l2.err
+timeout -s KILL 900 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d $O/pmc_l2 -o l2 --output-format csv -- python3 $R/bench.py $PM > $O/pmc_l2.json 2> $O/pmc_l2.err
 rm -f $O/*/*kernel_trace.csv $O/*/*agent_info.csv 2>/dev/null     # large; the stats / counter files are what is summarised
 ls -la $O $O/* | head -40
 tail -c 600 $O/bench.json
