@@ -601,10 +601,13 @@ class JointModelWithLoss(_JointBase):
             # parameter entirely (no moment decay, no step count, no weight move); zeros would still move Adam's weights by its momentum.
             return [None] * len(pnames)
         self.last_step_overflowed = False
-        out = []
-        for k in pnames:                    # parameters no kernel touched (frozen phase / unused) keep grad None
-            t = rt["P"][k]
-            out.append(t.gacc * inv if getattr(t, "gacc_touched", False) else None)
+        # parameters no kernel touched (frozen phase / unused) keep grad None; the others leave as accumulator x 1 / scale -- one multi-tensor
+        # launch set instead of one launch per parameter (290 with PSPNet, 1109 with HRNet-OCR; same fp32 products)
+        out = [None] * len(pnames)
+        idx = [i for i, k in enumerate(pnames) if getattr(rt["P"][k], "gacc_touched", False)]
+        if idx:
+            for i, g in zip(idx, torch._foreach_mul([rt["P"][pnames[i]].gacc for i in idx], inv)):
+                out[i] = g
         return out
 
 
