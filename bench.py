@@ -1,7 +1,11 @@
 """bench.py -- training imgs/s of the CSBSR joint SR+segmentation hot path on N MI355X GPUs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8] [--lr-size 448] [--micro-batch 1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 8] [--lr-size 448] [--micro-batch 8]
     python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...          (driver, N > 1)
+
+`python bench.py --gpus N` with N > 1 and no launcher on the command line starts the N ranks itself (a `torch.distributed.run` CHILD
+process, before this process touches the GPU -- one command drives all GPUs like the reference's train.py:105-112) and relays rank 0's
+JSON line and the exit code; a WORLD_SIZE that disagrees with --gpus, or fewer visible devices than ranks, is an error, not a silent 1-GPU run.
 
 One step = one pass of the hot path over one synthetic minibatch already resident in HBM: KBPN (x4) + PSPNet
 forward, fused losses, explicit HIP backward, gradient all-reduce over RCCL (N > 1), Adam -- BASELINE.json config 2
@@ -37,12 +41,13 @@ MFMA_PEAK_TFLOPS = 2500.0     # dense fp16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(lr=112, seconds_budget=20.0, threads=0):
+def cpu_baseline(lr=64, seconds_budget=24.0, threads=0, min_steps=3):
     """The oracle (CPU restatement of the reference path, fp32 torch ops) timed on this host's cores on a bounded sample of the
-    bench workload: B=2, LR 112 -> HR 448 (BASELINE.md section 2's CPU-runnable size; LR 448 needs ~300 GB of
-    host RAM for the autograd tape), forward + backward, after one tiny untimed step that pays the allocator's and the thread pool's
-    warm-up; steps are repeated until ~the budget (one B=2 step is ~25 s, so usually ONE timed step); imgs/s scaled to LR 448 by the
-    pixel ratio (x16; every term of the path is linear in pixels)."""
+    bench workload: B=2 (SURVEY.md 8(d)(ii)), LR 64 -> HR 256 by default (LR 448 needs ~300 GB of host RAM for the autograd tape;
+    --cpu-baseline-lr 112 is BASELINE.md section 2's CPU-runnable size, ~24 s per step), forward + backward, after one tiny untimed step
+    that pays the allocator's and the thread pool's warm-up; at least ``min_steps`` timed steps, more until ~the budget; the value is
+    quoted from the MEDIAN step (min / median / max reported) and scaled to LR 448 by the pixel ratio (every term of the path is linear
+    in pixels)."""
     from oracle import csbsr_oracle as O
     from csbsr_amd.utils.detfill import det_state_dict
     from csbsr_amd.modeling.shapes import joint_state_shapes
@@ -65,21 +70,23 @@ def cpu_baseline(lr=112, seconds_budget=20.0, threads=0):
         O.calc_loss(out["segment_loss"], out["sr_loss"], 40000, cfg).backward()
     one(make_batch(B, 16, seed=2))          # untimed warm-up (HR 64)
     batch = make_batch(B, lr, seed=1)
-    n, t0, per = 0, time.time(), []
+    t0, per = time.time(), []
     while True:
         t1 = time.time()
         one(batch)
         per.append(time.time() - t1)
-        n += 1
-        if time.time() - t0 > seconds_budget or n >= 40:
+        if (len(per) >= min_steps and time.time() - t0 > seconds_budget) or len(per) >= 40:
             break
     dt = time.time() - t0
-    per_s = ", ".join("%.1f" % t for t in per[:8])
-    ips = B * n / dt
+    srt = sorted(per)
+    med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    ips = B / med
     scale = (448.0 / lr) ** 2
     return {"value": ips / scale, "unit": "imgs/s", "cores": cores, "kind": "port",
+            "steps": len(per), "step_s": {"min": round(srt[0], 2), "median": round(med, 2), "max": round(srt[-1], 2)},
             "cores_note": f"{cores} intra-op threads of the host's {ncpu}: the fp32 torch oracle stops scaling there (a 256-thread pool ran the same step 240x slower); --cpu-baseline-threads overrides",
-            "sample": f"oracle fwd+bwd, B={B}, LR {lr}->HR {lr * 4}, {n} step(s) in {dt:.1f}s after a tiny warm-up step (per step: {per_s} s) = {ips:.4f} img/s at LR {lr}; "
+            "sample": f"oracle fwd+bwd, B={B}, LR {lr}->HR {lr * 4}, {len(per)} timed steps in {dt:.1f}s after a tiny warm-up step (min / median / max "
+                      f"{srt[0]:.1f} / {med:.1f} / {srt[-1]:.1f} s per step) = {ips:.4f} img/s at LR {lr} from the median step; "
                       f"divided by (448/{lr})^2 = {scale:.2f} (conv work linear in pixels) to quote it at LR 448"}
 
 
@@ -106,7 +113,7 @@ def main():
     ap.add_argument("--no-other-precision-leg", action="store_true", help="skip the extra (never `value`) leg that re-times the step in the other detector precision mode")
     ap.add_argument("--no-h2d-leg", action="store_true", help="skip the extra (untimed-for-value) leg that re-times the step with the PCIe copy of the batch inside")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-lr", type=int, default=112, help="LR size of the bounded CPU sample (112 = BASELINE.md section 2's size; 32 = round 1's)")
+    ap.add_argument("--cpu-baseline-lr", type=int, default=64, help="LR size of the bounded CPU sample (64: three timed B=2 steps fit ~25 s; 112 = BASELINE.md section 2's size, ~24 s per step)")
     ap.add_argument("--cpu-baseline-threads", type=int, default=0, help="intra-op threads of the CPU sample (0 = min(host threads, 16), see cpu_baseline)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--watchdog-s", type=int, default=int(os.environ.get("CSBSR_BENCH_WATCHDOG", "0")),
@@ -115,6 +122,26 @@ def main():
     ap.add_argument("--dump-layers", default=None, help="write the per-launch conv / wgrad log of the timed region (layer, shape, kernel, ms) as JSON")
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if launched and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    # one rank per GPU (the test hook CSBSR_FORCE_DEVICE puts every rank on one device over gloo).  device_count() does not initialise the GPU
+    if "CSBSR_FORCE_DEVICE" not in os.environ and torch.cuda.device_count() < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
+    if args.gpus > 1 and not launched:
+        # self-launch: this process has not touched the GPU and never will -- the ranks are CHILDREN (never exec a process that has
+        # initialised HIP), their stdout / stderr are inherited so rank 0's JSON line is this command's JSON line
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = str(s_.getsockname()[1])
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     if args.watchdog_s > 0:
         import faulthandler
         faulthandler.dump_traceback_later(args.watchdog_s, exit=True)
@@ -140,7 +167,6 @@ def main():
 
     from csbsr_amd.config import cfg as base_cfg
     from csbsr_amd.modeling.build_model import JointModelWithLoss
-    from csbsr_amd.data.synthetic import make_batch
     from csbsr_amd.parallel import GradBucketReducer
     from csbsr_amd.parallel.reducer import broadcast_parameters
 
@@ -167,13 +193,18 @@ def main():
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.SOLVER.LR, betas=(0.9, 0.999), eps=1e-8)    # train.py:91
 
     B, lr = args.batch, args.lr_size
-    # synthetic minibatch (seed differs per rank: each GPU gets its own shard of the global batch), resident in HBM
-    gen_lr = min(lr, 112)           # generate at <=112 and tile: the CPU-side generator is plumbing, not the bench
-    x, hr, mask, k = make_batch(B, gen_lr, scale=scale, seed=1121 + rank)
-    rep = lr // gen_lr
-    if rep > 1:
-        x, hr, mask = x.repeat(1, 1, rep, rep), hr.repeat(1, 1, rep, rep), mask.repeat(1, 1, rep, rep)
-    x, hr, mask, k = (t.to(dev).contiguous() for t in (x, hr, mask, k))
+    # synthetic minibatch (seed differs per rank: each GPU gets its own shard of the global batch), resident in HBM when the timed region
+    # starts.  Round 6: HR textures + crack masks are generated at FULL size on the host (no tiling of a small batch: periodic data), and
+    # the degradation -- per-sample anisotropic Gaussian blur + antialiased bicubic down-scaling, SURVEY 8 row f1 -- runs on the device
+    # (csbsr_amd.data.degrade.DeviceDegradation), untimed
+    from csbsr_amd.data.synthetic import make_hr_mask
+    from csbsr_amd.data.degrade import DeviceDegradation
+    gen = torch.Generator().manual_seed(1121 + rank)
+    hr, mask = make_hr_mask(B, lr * scale, gen)
+    deg = DeviceDegradation(scale, device=str(dev), seed=77 + rank)
+    x, hr, mask, k, _ = deg(hr, mask, with_sdf=False)
+    x = x.clamp_(0, 1)
+    torch.cuda.synchronize()
     it = 40000
     beta = cfg.SOLVER.TASK_LOSS_WEIGHT
 
@@ -194,8 +225,7 @@ def main():
     for _ in range(args.warmup):
         step()
     eng = rt["eng"]
-    if not args.no_kernel_timing:
-        eng.timing = []
+    eng.timing = None           # round 6: no per-launch HIP events inside the region `value` is timed over (they run in their own leg below)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -222,8 +252,24 @@ def main():
         sys.exit(3)
     ms = dt / args.steps * 1e3
     imgs = B * world * args.steps / dt
-    timing_log, eng.timing = eng.timing, None
     peak_main = torch.cuda.max_memory_allocated(dev)          # of the warm-up + timed steps only: the extra legs below have their own peaks
+    # ---- roofline leg: the SAME steps once more with a HIP-event pair around every conv / wgrad launch on the engine's stream (the
+    # per-kernel launch durations of the roofline block; rocprofv3's kernel statistics of this command must agree, profiles/).  Its wall
+    # time is reported as `with_launch_events` and is never `value`
+    timing_log, ev_leg = None, None
+    if not args.no_kernel_timing:
+        n1 = args.steps if args.steps <= 4 else max(4, args.steps // 4)
+        eng.timing = []
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            step()
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        timing_log, eng.timing = eng.timing, None
+        ev_leg = {"steps": n1, "ms_per_step": round(dt1 / n1 * 1e3, 1)}
     # the KBPN residency schedule the step ran with (agreed over the ranks: JointModelWithLoss._auto_resident) and every rank's peak
     n_mb = (B + max(1, min(args.micro_batch, B)) - 1) // max(1, min(args.micro_batch, B))
     schedule = {"micro_batches": n_mb, "n_resident": int(getattr(model, "_n_res", 0)), "lean_saves": bool(getattr(model, "_lean", False)),
@@ -299,6 +345,7 @@ def main():
             f_ = fam.setdefault(family(k_), [0.0, 0.0, 0])
             f_[0] += v[2]; f_[1] += v[0]; f_[2] += v[3]
         # the dominant kernel is chosen over EVERY MFMA kernel of the step, each wgrad variant on its own
+        dt_ev = ev_leg["ms_per_step"] * 1e-3 * ev_leg["steps"]          # the wall time the logged launches belong to
         dom = max(per, key=lambda k: per[k][2])
         fl, by, tt, nl, flx = per[dom]
         ach = fl / tt / 1e12
@@ -344,17 +391,17 @@ def main():
                     "hbm_gbs": round(by / tt / 1e9, 1)}
         roof = {**head, "traffic": traffic,
                 "selection": "largest share of the timed region by rocprofv3 row (template instance); families = the same time summed per kernel source",
-                "families": {k_: {"share_of_step_time": round(v[0] / dt, 3), "achieved_tflops": round(v[1] / v[0] / 1e12, 1), "launches": v[2]}
+                "families": {k_: {"share_of_step_time": round(v[0] / dt_ev, 3), "achieved_tflops": round(v[1] / v[0] / 1e12, 1), "launches": v[2]}
                              for k_, v in sorted(fam.items(), key=lambda kv: -kv[1][0])},
                 "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/" + os.path.basename(tpath) + "; "
-                                "FETCH_SIZE doubled per MI355X_MICROARCH.md), same command at --batch 4 (one KBPN micro-batch of 4, as in the default run)" if traffic else None,
+                                "FETCH_SIZE doubled per MI355X_MICROARCH.md), same command at --batch 4 (the default run is one KBPN micro-batch of 8: the same per-image work in half the launches)" if traffic else None,
                 "mfma_pmc": mfma_pmc, "launches": nl, "avg_launch_ms": round(tt * 1e3 / max(nl, 1), 4),
                 "alg_flop_per_launch": round(fl / max(nl, 1) / 1e9, 2), "alg_flop_unit": "GFLOP",
                 "executed": round(flx / tt / 1e12, 1), "executed_frac": round(flx / tt / 1e12 / MFMA_PEAK_TFLOPS, 4),
                 "executed_note": "MFMA work the kernel actually ran / its time: the split-precision detector launches multiply hi+lo operand pairs "
                                  "(3 K blocks per algorithmic product forward, 2 in the dgrads); 'achieved' and 'frac' count the algorithmic product once",
-                "alg_bytes_per_launch": round(by / max(nl, 1)), "share_of_step_time": round(tt / dt, 3),
-                "other_kernels": {k: {"achieved": round(v[0] / v[2] / 1e12, 1), "executed": round(v[4] / v[2] / 1e12, 1), "share_of_step_time": round(v[2] / dt, 3), "launches": v[3],
+                "alg_bytes_per_launch": round(by / max(nl, 1)), "share_of_step_time": round(tt / dt_ev, 3),
+                "other_kernels": {k: {"achieved": round(v[0] / v[2] / 1e12, 1), "executed": round(v[4] / v[2] / 1e12, 1), "share_of_step_time": round(v[2] / dt_ev, 3), "launches": v[3],
                                       "avg_launch_ms": round(v[2] * 1e3 / v[3], 4)} for k, v in per.items() if k != dom}}
     out = None
     if rank == 0:
@@ -365,7 +412,8 @@ def main():
                "vs_baseline": None, "dtype": "fp16 storage / fp32 accumulate" + (" (detector forward: split fp16 hi+lo)" if args.detector_precision == "split" else ""),
                "data": "synthetic", "detector_precision": args.detector_precision, "other_precision": other_prec,
                "config": {"workload": f"CSBSR KBPN x{scale} + {cfg.MODEL.DETECTOR_TYPE}, beta={beta}, joint phase (iter 40000), per-GPU batch {B}, "
-                                      f"LR {lr}x{lr} -> HR {lr * scale}x{lr * scale}, fwd+loss+bwd+Adam", "global_batch": B * world,
+                                      f"LR {lr}x{lr} -> HR {lr * scale}x{lr * scale}, fwd+loss+bwd+Adam; batch resident in HBM (H2D outside `value`, "
+                                      f"timed beside it as with_h2d_inside_step); full-size synthetic crack images degraded on the device", "global_batch": B * world,
                           "micro_batch": args.micro_batch, "parallelism": f"dp{world}"},
                "loss": round(last, 5),
                "step_roofline": {"hbm_frac": round(ALG_GB_PER_IMG_448 * pix / per_img_s / HBM_PEAK_GBS, 4),
@@ -373,7 +421,7 @@ def main():
                                  "note": f"algorithmic work per image at LR 448 after exact constant-operand folding (the fe_kernel branch of every kernel predictor + the SFT code channels): {ALG_TFLOP_PER_IMG_448:.1f} TFLOP / {ALG_GB_PER_IMG_448:.1f} GB (SURVEY.md 8(d) as-executed: 108.3 TFLOP / 249 GB; rounds 1-3 divided by 73.3 TFLOP / 213.7 GB)"},
                "roofline": roof,
                "peak_mem_gb": round(peak_main / 2 ** 30, 1),
-               "with_h2d_inside_step": h2d}
+               "with_h2d_inside_step": h2d, "with_launch_events": ev_leg}
         out["schedule"] = schedule
         if dist_on:      # what the gradient exchange did (per rank): collectives, how many rode the side stream, payload, and how long the
             # compute stream waited for the exchange at the end of each backward (the part NOT hidden under it), rank 0's view

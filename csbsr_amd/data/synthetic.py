@@ -51,10 +51,9 @@ def crack_masks(B, H, W, gen):
     return m
 
 
-def make_batch(B, lr_size, scale=4, ksize=21, seed=1121, device="cpu", antialias=True):
-    """Returns (x_lr [B,3,lr,lr], hr [B,3,H,H], mask [B,1,H,H], kernel [B,1,k,k]) fp32 NCHW."""
-    gen = torch.Generator().manual_seed(seed)
-    H = lr_size * scale
+def make_hr_mask(B, H, gen):
+    """HR texture [B,3,H,H] in [0,1] and its crack mask [B,1,H,H] (the part of make_batch that precedes the degradation: bench.py
+    generates these at full size and degrades them on the device, csbsr_amd.data.degrade.DeviceDegradation)."""
     g = max(4, H // 32)
     base = torch.rand(B, 3, g, g, generator=gen)
     hr = F.interpolate(base, size=(H, H), mode="bilinear", align_corners=False)
@@ -62,6 +61,14 @@ def make_batch(B, lr_size, scale=4, ksize=21, seed=1121, device="cpu", antialias
     hr = (hr + 0.02 * torch.randn(B, 3, H, H, generator=gen)).clamp(0, 1)
     mask = crack_masks(B, H, H, gen)
     hr = (hr * (1 - 0.5 * mask)).clamp(0, 1)
+    return hr, mask
+
+
+def make_batch(B, lr_size, scale=4, ksize=21, seed=1121, device="cpu", antialias=True):
+    """Returns (x_lr [B,3,lr,lr], hr [B,3,H,H], mask [B,1,H,H], kernel [B,1,k,k]) fp32 NCHW."""
+    gen = torch.Generator().manual_seed(seed)
+    H = lr_size * scale
+    hr, mask = make_hr_mask(B, H, gen)
     k = gaussian_kernels(B, ksize, gen)
     w = k.repeat_interleave(3, dim=0)
     blurred = F.conv2d(hr.reshape(1, B * 3, H, H), w, padding=(ksize - 1) // 2, groups=B * 3).reshape(B, 3, H, H)

@@ -116,6 +116,9 @@ class Engine:
         self._red = _reduction_scratch(self.device) if torch.cuda.is_available() else None
         self.training = True
         self.use_hr = os.environ.get("CSBSR_CONV_HR", "1") != "0"       # A/B hook: 0 routes the HR small-channel layers through the implicit-GEMM kernels
+        # Winograd F(2,3)-along-x kernel for the wide 3x3 layers (csrc/conv_x3w.hip): built, parity-tested and measured AT PARITY with the
+        # direct kernels in round 6 (bound by the CU's vector-memory path, see the kernel's header) -- opt-in: CSBSR_CONV_X3W=1
+        self.use_x3w = os.environ.get("CSBSR_CONV_X3W", "0") != "0"
         self.use_x3 = os.environ.get("CSBSR_CONV_X3", "1") != "0"       # A/B hook: 0 routes the wide 3x3 layers through the implicit-GEMM kernels
         self.use_tp = os.environ.get("CSBSR_CONV_TP", "1") != "0"       # A/B hook: 0 routes the 2x2-tap transposed layers through the implicit-GEMM kernels
         self.split_fused = os.environ.get("CSBSR_SPLIT_FUSED", "1") != "0"   # A/B hook: 0 = the three-block split forward (x_hi staged twice)
@@ -514,6 +517,19 @@ class Conv:
                 self._packed[key] = dst
             d.wt = _ptr(self._packed[key])
             L.call("csbsr_conv_hr_forward", C.byref(d), self.eng.stream)
+        elif x3 is not None and x3[0] in (0, 1) and self.eng.use_x3w and L.load().csbsr_conv_x3w_eligible(C.byref(d)):
+            # wide low-resolution 3x3 stride-1 layers (SFT convs and their dgrads) as Winograd F(2, 3) along x: 2/3 of the direct kernel's
+            # MFMA work, transformed fp16 weights packed once per optimiser step (csrc/conv_x3w.hip)
+            kind, c_real, rows_real, row_off, k_off = x3
+            key = ("x3w", kind, row_off, k_off, c_real)
+            if key not in self._packed:
+                n = L.load().csbsr_packed_weight_elems_x3w(c_real, rows_real)
+                dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
+                L.call("csbsr_pack_weights_x3w", _ptr(self._wq()), _ptr(dst), kind, self.w.shape[0], self.w.shape[1], c_real, rows_real, row_off,
+                       k_off, self.eng.stream)
+                self._packed[key] = dst
+            d.wt = _ptr(self._packed[key])
+            L.call("csbsr_conv_x3w_forward", C.byref(d), self.eng.stream)
         elif x3 is not None and self.eng.use_x3 and L.load().csbsr_conv_x3_eligible(C.byref(d)):
             # wide low-resolution 3x3 layers (SFT convs and their dgrads): per-chunk halo tile + fragment-ordered weights from L2 (csrc/conv_x3.hip)
             # ... and the k = 2 x stride strided layers (kind 2: 8x8 stride-4 convs, dgrads of the 8x8 stride-4 deconvs): chunk = input phase

@@ -329,7 +329,15 @@ class JointModelWithLoss(_JointBase):
         # (the rank agreement inside _auto_resident is a collective: only a forward that will be followed by a backward takes part in it, so
         # a rank-0-only validation pass, an evaluator sharing the model or a no_grad call can never leave the other ranks waiting)
         n_res, lean = (self.max_resident, bool(self.lean_saves)) if self.max_resident is not None else self._auto_resident(B, mb, H, W, agree=keep)
-        self._n_res, self._lean = n_res, lean
+        if self.max_resident is None and keep and n_res == 0 and mb >= B and B >= 2 and not self.blur_skip:
+            # the whole batch as ONE micro-batch is all-or-nothing: when it does not fit (RCCL buffers, another tenant, fragmentation)
+            # halve the micro-batch so that part of the batch stays resident instead of recomputing every KBPN forward in the backward.
+            # n_res is the agreed minimum over the ranks, so every rank takes this branch (and its second agreement) together
+            mb2 = (B + 1) // 2
+            n2, lean2 = self._auto_resident(B, mb2, H, W, agree=keep)
+            if n2 > 0:
+                mb, n_res, lean = mb2, n2, lean2
+        self._n_res, self._lean, self._mb_used = n_res, lean, mb
         single = mb >= B
         sr32 = eng.f32(B, 3, H, W, zero=False)
         kvec = eng.f32(B, pc.ksize_out ** 2, zero=False)

@@ -26,6 +26,8 @@ def conv_row(kid):
                 f"mask={(var >> 3) & 1},cb={(var >> 5) & 1}>")
     if base == 10 and var & 1:
         return "conv_x3_kernel<3,2048>"
+    if base == 19:
+        return f"conv_x3w_kernel<{var}>"
     return _CONV.get(base, f"conv?{base}")
 
 
@@ -66,6 +68,9 @@ def canon(name):
     m = re.search(r"conv_tp_kernelILi\d+ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name) or re.search(r"conv_tp_kernel<\d+, (\w+), (\w+), (\w+), (\w+)>", name)
     if m:
         return "conv_tp_kernel<res=%s,acc=%s,mask=%s,sums=%s>" % tuple(_b(x) for x in m.groups())
+    m = re.search(r"conv_x3w_kernelILi(\d)E", name) or re.search(r"conv_x3w_kernel<(\d)>", name)
+    if m:
+        return "conv_x3w_kernel<%s>" % m.group(1)
     m = re.search(r"conv_x3_kernelILi(\d)ELi(\d+)E", name) or re.search(r"conv_x3_kernel<(\d), (\d+)>", name)
     if m:
         return "conv_x3_kernel<%s>" % m.group(1) if m.group(2) == "0" else "conv_x3_kernel<%s,%s>" % m.groups()

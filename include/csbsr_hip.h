@@ -167,6 +167,21 @@ int64_t csbsr_packed_weight_elems_x3_strided(int32_t stride, int32_t c_real, int
 int csbsr_pack_weights_x3_strided(const float* w, void* dst, int32_t D0, int32_t D1, int32_t ksize, int32_t stride, int32_t c_real,
                                   int32_t rows_real, int32_t row_off, int32_t k_off, csbsr_stream_t s);
 
+/* Winograd F(2, 3) along x for the same wide 3x3 stride-1 layers (the SFT convolutions F.conv2d(cat(fea, k), w, b, 1, 1) of
+ * /root/reference/model/modeling/kbpn.py:505-520 and their dgrads): two neighbouring output pixels from four products per (channel, row tap)
+ * instead of six -- 2/3 of the MFMA work of csbsr_conv_x3_forward; input transform on the fly (registers -> LDS), weights transformed by the
+ * pack (U = G w, rounded to fp16 once), output transform on the accumulators, same descriptor and fused epilogue -- see csrc/conv_x3w.hip.
+ * The transformed operands are fp16: results differ from the direct product at the fp16 rounding level of the layer's inputs
+ * (tests/study_winograd.py; tests/test_conv_kernels_gpu.py holds both to the same bound).  Measured at parity with csbsr_conv_x3_forward
+ * (the CU's vector-memory path bounds it, csrc/conv_x3w.hip): off unless enabled (csbsr_conv_x3w_eligible then returns 0).  Eligible: one plain fp16 input segment of >= 128
+ * channels padded to a multiple of 32, >= 72 padded output channels, no statistics / fp32 output / split operands. */
+int32_t csbsr_conv_x3w_eligible(const csbsr_conv_desc_t* d);
+int csbsr_conv_x3w_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
+/* kind 0 forward (w = OIHW), 1 dgrad of the stride-1 conv (rows = its input channels, taps flipped) */
+int64_t csbsr_packed_weight_elems_x3w(int32_t c_real, int32_t rows_real);
+int csbsr_pack_weights_x3w(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
+                           int32_t row_off, int32_t k_off, csbsr_stream_t s);
+
 /* Weight-gradient GEMM: G[split][a][tap][b] = sum over the split's pixels of A[pix][a] * B[pix @ tap][b]  (fp32; the pixel
  * range is cut into csbsr_wgrad_splits() slabs, each written once -- no atomics, no zero-fill; csbsr_unpack_wgrad sums them).
  * Conv: A = dPre (output side), B = input.  Transposed conv: A = its input (LR side), B = dOut (HR side).

@@ -76,6 +76,12 @@ def main():
                              ("bs_all=2 final=2", [(gp["bs_conv0"], 2), (gp["bs_conv1"], 2), (gp["bs_cb"], 2), (gp["final"], 2)], False)]
             elif det == "PSPNet":
                 variants += [("up_1+2+3=2", [(gp["up_1"], 2), (gp["up_2"], 2), (gp["up_3"], 2)], False),
+                             # round 6: the decoder groups one at a time and together on tap-sum-rounded weights (review item 6)
+                             ("psp=2", [(gp["psp"], 2)], False), ("up_2=2", [(gp["up_2"], 2)], False), ("up_3=2", [(gp["up_3"], 2)], False),
+                             ("final=2", [(gp["final"], 2)], False),
+                             ("up_2+3+final=2", [(gp["up_2"], 2), (gp["up_3"], 2), (gp["final"], 2)], False),
+                             ("up_1+2+3+final=2", [(gp["up_1"], 2), (gp["up_2"], 2), (gp["up_3"], 2), (gp["final"], 2)], False),
+                             ("psp+up_1+2+3+final=2", [(gp["psp"], 2), (gp["up_1"], 2), (gp["up_2"], 2), (gp["up_3"], 2), (gp["final"], 2)], False),
                              ("up_1=2", [(gp["up_1"], 2)], False), ("aux=1", [(gp["aux"], 1)], False),
                              ("up_1=2 aux=1", [(gp["up_1"], 2), (gp["aux"], 1)], False)]
         res[case] = {}

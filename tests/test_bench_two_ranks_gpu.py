@@ -39,6 +39,24 @@ def test_bench_two_ranks_one_device():
     assert red["agreements"] == 1 and red["exposed_all_reduce_ms_per_step"] >= 0.0
 
 
+def test_bench_plain_command_starts_its_own_ranks():
+    """Round 6 (review item 2): `python bench.py --gpus 2` with NO launcher on the command line starts the two ranks itself (a
+    torch.distributed.run child, before the parent touches the GPU) and relays rank 0's line -- one command drives all GPUs, like the
+    reference's train.py:105-112.  Two ranks on one device over gloo, as above."""
+    env = dict(os.environ, CSBSR_DIST_BACKEND="gloo", CSBSR_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", CSBSR_BENCH_WATCHDOG="300")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--lr-size", "64", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    assert d["schedule"]["same_on_every_rank"] is True and len(d["schedule"]["step_ms_per_rank"]) == 2
+
+
 def test_bench_rccl_backend_one_rank():
     """The same N > 1 code path with the REAL backend: `nccl` (= RCCL on ROCm) with world size 1 on the one GPU of the test box.
     CSBSR_FORCE_DIST=1 makes the reducer and the parameter broadcast ISSUE their collectives in a one-rank group (they return early

@@ -760,6 +760,98 @@ def test_wide_3x3_kernel(cin, cout, H, W, mode):
     assert relmax(outs[0][0], outs[1][0]) < 1e-3 and relmax(outs[0][1], outs[1][1]) < 1e-3
 
 
+@pytest.mark.parametrize("cin,cout,H,W,mode", [
+    (128, 128, 19, 45, "lrelu"),            # ragged tiles on both axes, odd width (the last x-tile's second output is outside), four chunks
+    (384, 825, 16, 32, "lrelu"),            # SFT conv0 shape: 12 chunks, 7 cout tiles (the last one 57 wide), half a tile wide
+    (825, 384, 9, 40, "none_fma"),          # SFT conv1 shape (shift branch): 825 -> 832 padded input channels (26 chunks), out = conv + res * res2
+    (825, 384, 8, 64, "sigmoid"),           # SFT conv1 shape (scale branch)
+    (192, 100, 24, 133, "relu_add"),        # six chunks, three tile columns, padded couts, residual add
+    (96, 256, 8, 64, "none"),               # three chunks (odd: the V buffers alternate across tiles)
+    (256, 256, 12, 128, "none"),
+])
+def test_wide_3x3_winograd_kernel(cin, cout, H, W, mode):
+    """csrc/conv_x3w.hip (Winograd F(2, 3) along x: input transform registers -> LDS, transformed fp16 weights, output transform on the
+    accumulators, general fused epilogue) against F.conv2d on the same fp16-rounded operands and against the direct kernels: forward
+    with the fused epilogue modes the SFT layers use, and the dgrad (flipped, transposed weights) accumulating into an existing gradient.
+    The transformed operands are rounded to fp16 once more than the direct product's: the bound is the direct kernels' 2e-3."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv, pad8
+    torch.manual_seed(cin + cout + H)
+    eng = _eng()
+    lib = L.load()
+    N = 2
+    x = torch.randn(N, cin, H, W).half().float()
+    w = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).half().float()
+    b = torch.randn(cout) * 0.1
+    act = {"lrelu": L.ACT_LRELU, "relu": L.ACT_RELU, "none": L.ACT_NONE, "sigmoid": L.ACT_SIGMOID}[mode.split("_")[0]]
+    conv = Conv(eng, "l", {"l.weight": w.cuda(), "l.bias": b.cuda()}, 3, 1, 1, 1, bias=True, act=act, slope=0.1)
+    pre = F.conv2d(x, w, b, 1, 1)
+    ref = {L.ACT_LRELU: F.leaky_relu(pre, 0.1), L.ACT_RELU: F.relu(pre), L.ACT_NONE: pre, L.ACT_SIGMOID: torch.sigmoid(pre)}[act]
+    res = torch.randn_like(ref).half().float()
+    res2 = torch.randn_like(ref).half().float()
+    kw = {}
+    if mode.endswith("_add"):
+        ref = ref + res; kw = dict(res=res, res_mode=L.RES_ADD)
+    if mode.endswith("_fma"):
+        ref = ref + res * res2; kw = dict(res=res, res2=res2, res_mode=L.RES_FMA)
+    dpre = torch.randn(N, cout, H, W).half().float()
+    old = torch.randn(N, cin, H, W).half().float()
+    xr = torch.zeros(N, cin, H, W, requires_grad=True)
+    F.conv2d(xr, w, None, 1, 1).backward(dpre)
+    refd = xr.grad + old
+    outs = []
+    for xw_mode in (2, 0):
+        lib.csbsr_debug_set_conv_x3w(xw_mode)
+        try:
+            conv.invalidate()
+            y = conv.fwd(to_fm(eng, x), **{k_: (to_fm(eng, v) if isinstance(v, torch.Tensor) else v) for k_, v in kw.items()})
+            torch.cuda.synchronize()
+            assert ((lib.csbsr_debug_last_conv_kernel() & 255) == 19) == (xw_mode == 2 and pad8(cin) % 32 == 0 and pad8(cout) >= 72)
+            dx = to_fm(eng, old)
+            conv.bwd_input(to_fm(eng, dpre), out=dx, accumulate=True)
+            torch.cuda.synchronize()
+            assert ((lib.csbsr_debug_last_conv_kernel() & 255) == 19) == (xw_mode == 2 and pad8(cout) % 32 == 0 and pad8(cin) >= 72)
+        finally:
+            lib.csbsr_debug_set_conv_x3w(1)
+        outs.append((from_fm(y), from_fm(dx)))
+        print(f"   x3w mode {xw_mode}: forward {relmax(outs[-1][0], ref):.2e}  dgrad {relmax(outs[-1][1], refd):.2e}")
+        assert relmax(outs[-1][0], ref) < 2e-3
+        assert relmax(outs[-1][1], refd) < 2e-3
+    assert relmax(outs[0][0], outs[1][0]) < 2e-3 and relmax(outs[0][1], outs[1][1]) < 2e-3
+
+
+def test_wide_3x3_winograd_kernel_with_folded_constant_segment():
+    """SFT conv0 as the model runs it (Conv.fwd_folded: features through the conv kernel, the spatially constant kernel-code segment as a
+    per-border-class bias) on conv_x3w_kernel against the direct kernels and against F.conv2d on the concatenated input."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    torch.manual_seed(11)
+    eng = _eng()
+    lib = L.load()
+    N, cf, cc, cout, H, W = 2, 384, 21, 100, 12, 40
+    x = torch.randn(N, cf, H, W).half().float()
+    kv = (torch.rand(N, cc) / cc).half().float()
+    w = (torch.randn(cout, cf + cc, 3, 3) / ((cf + cc) * 9) ** 0.5).half().float()
+    b = torch.randn(cout) * 0.1
+    ref = F.leaky_relu(F.conv2d(torch.cat([x, kv[:, :, None, None].expand(N, cc, H, W)], 1), w, b, 1, 1), 0.1)
+    m = torch.ones(4, 3)
+    m[2, 0] = m[3, 0] = 0.0
+    m[1, 2] = m[3, 2] = 0.0
+    outs = []
+    for xw_mode in (2, 0):
+        lib.csbsr_debug_set_conv_x3w(xw_mode)
+        try:
+            conv = Conv(eng, "l", {"l.weight": w.cuda(), "l.bias": b.cuda()}, 3, 1, 1, 1, bias=True, act=L.ACT_LRELU, slope=0.1, split=(cf, cc))
+            y, _ = conv.fwd_folded(to_fm(eng, x), kv.cuda(), m.cuda())
+            torch.cuda.synchronize()
+            assert ((lib.csbsr_debug_last_conv_kernel() & 255) == 19) == (xw_mode == 2)
+        finally:
+            lib.csbsr_debug_set_conv_x3w(1)
+        outs.append(from_fm(y))
+        assert relmax(outs[-1], ref) < 2e-3
+    assert relmax(outs[0], outs[1]) < 2e-3
+
+
 def test_wide_3x3_kernel_with_folded_constant_segment():
     """SFT conv0 as the model runs it (Conv.fwd_folded: features through the conv kernel, the spatially constant kernel-code segment as a
     per-border-class bias) on conv_x3_kernel<3> against the implicit-GEMM kernel and against F.conv2d on the concatenated input."""

@@ -153,8 +153,8 @@ def test_residency_schedule_under_memory_pressure():
     x, hr, mask, k = make_batch(2, 112, seed=81)
     fl = lambda t: torch.cat([t, t.flip(-1), t.flip(-2), t.flip(-1, -2)]).contiguous()
     x8, hr8, mask8, k8 = (fl(t).cuda() for t in (_tile(x, 4), _tile(hr, 4), _tile(mask, 4), k))
-    seen = {}
-    for gb in (0, 4, 8, 12):
+    seen, used = {}, {}
+    for gb in (0, 4, 8, 12, 28):
         torch.cuda.empty_cache()
         hold = torch.empty(gb << 30, dtype=torch.uint8, device="cuda") if gb else None
         m = _model(8, 40000)                 # bench.py's default: one KBPN micro-batch of 8
@@ -172,11 +172,16 @@ def test_residency_schedule_under_memory_pressure():
             ms.append((time.perf_counter() - t0) * 1e3)
             assert bool(torch.isfinite(loss.detach())) and not m.last_step_overflowed
         seen[gb] = (m._n_res, m._lean)
-        print(f"   {gb:2d} GB reserved by another tenant: n_resident {m._n_res} of 1, lean saves {m._lean}, forward + backward {ms[1]:.0f} ms, "
+        used[gb] = m._mb_used
+        print(f"   {gb:2d} GB reserved by another tenant: micro-batch {m._mb_used}, n_resident {m._n_res}, lean saves {m._lean}, forward + backward {ms[1]:.0f} ms, "
               f"peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
         del m, hold, seg_l, sr_l, loss
         torch.cuda.reset_peak_memory_stats()
     assert seen[4] == seen[0], seen
+    # round 6 (advisor): a batch-of-8 micro-batch that no longer fits is split in two instead of recomputing every KBPN forward --
+    # whatever the pressure, part of the batch stays resident
+    assert all(n >= 1 for n, _ in seen.values()), seen
+    assert used[0] == 8 and used[28] in (4, 8), used
 
 
 def test_full_size_corner_matches_the_small_run():

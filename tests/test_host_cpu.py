@@ -294,3 +294,18 @@ def test_kernel_row_names_agree_between_bench_and_profiles():
                      (3, "void conv_wgrad_kernel<32, 128, 1, 4, true>(WgradK)"), (8, "void conv_wgrad_hr_kernel<7, 4, 4, 4>(WgradHrK)")]:
         assert wgrad_row(kid) == canon(raw), (kid, wgrad_row(kid), canon(raw))
     assert family("conv_tp_kernel<res=1,acc=0,mask=0,sums=0>") == "conv_tp_kernel" and family("epilogue_bwd_kernel") == "epilogue_bwd_kernel"
+
+
+def test_bench_refuses_a_rank_count_it_cannot_run():
+    """bench.py --gpus N must never fall back to a silent 1-GPU run (round-5 review): a launcher WORLD_SIZE that disagrees with --gpus, or
+    fewer visible devices than ranks, exits non-zero before anything touches a GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CSBSR_FORCE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr and not r.stdout.strip()
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n + 1)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "visible" in r.stderr and not r.stdout.strip()
