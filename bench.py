@@ -327,7 +327,7 @@ def main():
     roof = None
     if timing_log and args.dump_layers and rank == 0:
         json.dump([{"kind": t[0], "flops": t[1], "bytes": t[2], "ms": t[3].elapsed_time(t[4]), "layer": t[5], "shape": list(t[6]),
-                    "kernel": (t[7] if len(t) > 7 else -1)} for t in timing_log], open(args.dump_layers, "w"))
+                    "kernel": (t[7] if len(t) > 7 else -1), "executed": (t[8] if len(t) > 8 else 1)} for t in timing_log], open(args.dump_layers, "w"))
     if timing_log:
         # one roofline block = ONE kernel = one rocprofv3 ROW (template instance): the row with the largest share of the timed region.
         # csbsr_debug_last_conv_kernel / _wgrad_kernel tag every launch with the instance it dispatched to; csbsr_amd/utils/kernel_names.py

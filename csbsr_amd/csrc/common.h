@@ -30,9 +30,9 @@ void csbsr_set_error(const char* fmt, ...);
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {
-    case CSBSR_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CSBSR_ACT_RELU: return (v > 0.f || v != v) ? v : 0.f;      // NaN-propagating like the straight-line rows (an overflowed accumulator must reach the optimiser's overflow check)
     case CSBSR_ACT_LRELU:
-    case CSBSR_ACT_PRELU: return v > 0.f ? v : v * slope;
+    case CSBSR_ACT_PRELU: return v > 0.f ? v : v * slope;          // (NaN * slope = NaN)
     case CSBSR_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
     default: return v;
   }

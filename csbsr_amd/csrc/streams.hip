@@ -6,6 +6,7 @@
 //
 // Mask layout on this part (measured with csbsr_debug_cu_trace, scripts/overlap_pair.py): bit i of the mask handed to
 // hipExtStreamCreateWithCUMask selects a CU of XCD i % 8, so a prefix of the bit array spreads evenly over the eight XCDs (and their L2s).
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "common.h"
@@ -15,6 +16,7 @@ namespace {
 struct Budget { hipStream_t st; int ncu; };
 std::mutex g_mu;
 std::vector<Budget> g_budgets;
+std::atomic<int> g_nbudgets{0};      // == g_budgets.size(), readable without the lock (csbsr_cu_budget's fast path)
 }  // namespace
 
 static int32_t csbsr_device_cu_count(void) {
@@ -38,6 +40,7 @@ extern "C" int csbsr_debug_stream_create_cu_mask(void** out, const uint32_t* mas
   *out = (void*)st;
   std::lock_guard<std::mutex> lk(g_mu);
   g_budgets.push_back({st, bits});
+  g_nbudgets.store((int)g_budgets.size(), std::memory_order_release);
   return 0;
 }
 
@@ -49,6 +52,7 @@ extern "C" int csbsr_debug_stream_destroy(void* s) {
         g_budgets.erase(g_budgets.begin() + i);
         break;
       }
+    g_nbudgets.store((int)g_budgets.size(), std::memory_order_release);
   }
   hipError_t e = hipStreamDestroy((hipStream_t)s);
   if (e != hipSuccess) {
@@ -64,21 +68,34 @@ extern "C" int csbsr_debug_stream_set_cu_budget(void* s, int32_t ncu) {
   for (auto& b : g_budgets)
     if (b.st == (hipStream_t)s) {
       if (ncu == 0) { b = g_budgets.back(); g_budgets.pop_back(); } else b.ncu = ncu;
+      g_nbudgets.store((int)g_budgets.size(), std::memory_order_release);
       return 0;
     }
   if (ncu > 0) g_budgets.push_back({(hipStream_t)s, ncu});
+  g_nbudgets.store((int)g_budgets.size(), std::memory_order_release);
   return 0;
 }
 
 // CUs a persistent-grid kernel launched on ``st`` may count on: the stream's budget if it has one, else the whole device
+// (on the launch path of the persistent-grid kernels: no lock while the registry is empty -- the product never fills it, only the
+// measurement hooks do -- and the device's CU count is read once per device.  A stream given a budget must be destroyed through
+// csbsr_debug_stream_destroy, which removes its entry: a raw hipStreamDestroy would leave a stale handle behind.)
 int csbsr_cu_budget(hipStream_t st) {
-  {
+  if (g_nbudgets.load(std::memory_order_acquire) > 0) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (const auto& b : g_budgets)
       if (b.st == st) return b.ncu;
   }
-  int n = csbsr_device_cu_count();
-  return n > 0 ? n : 256;
+  static std::atomic<int> cached[CSBSR_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CSBSR_MAX_DEVICES) return 256;
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n <= 0) {
+    n = csbsr_device_cu_count();
+    if (n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
 }
 
 extern "C" int32_t csbsr_debug_stream_cu_budget(void* s) { return csbsr_cu_budget((hipStream_t)s); }

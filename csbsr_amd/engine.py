@@ -142,7 +142,8 @@ class Engine:
         self.wg_stream = None
         self._wg_on = os.environ.get("CSBSR_WGRAD_STREAM", "0") == "1"
         self._ws_by_stream = {}
-        self._zero_blk, self._zero_off = None, 0
+        self._zero_blk, self._zero_off, self._zero_key, self._zero_by_stream = None, 0, None, {}
+        self._probe_epoch = 0
         self.timing = None              # list of (kind, flops, bytes, start_event, end_event) when profiling is on
 
     @property
@@ -170,6 +171,13 @@ class Engine:
         if n == 0 or n > 65536:
             return torch.zeros(shape, dtype=torch.float32, device=self.device)
         n_al = (n + 63) // 64 * 64
+        # one arena per STREAM (as workspace()): the block's zero fill runs on the stream that creates it, so a cut handed to a consumer on
+        # another stream (the reducer's side stream, the opt-in wgrad stream, the CU-mask measurement streams) would have no ordering against it
+        skey = torch.cuda.current_stream(self.device).cuda_stream
+        if skey != self._zero_key:
+            self._zero_by_stream[self._zero_key] = (self._zero_blk, self._zero_off)
+            self._zero_blk, self._zero_off = self._zero_by_stream.get(skey, (None, 0))
+            self._zero_key = skey
         if self._zero_blk is None or self._zero_off + n_al > self.ZERO_ARENA:
             self._zero_blk, self._zero_off = torch.zeros(self.ZERO_ARENA, dtype=torch.float32, device=self.device), 0
         # (a fresh tensor on the block's storage, NOT a view of it: views share one autograd version counter, and an in-place update of any
@@ -203,23 +211,36 @@ class Engine:
     def prelu_fold_ok(self, p):
         """May a learned PReLU slope's layer take the FOLDED backward (Conv.bwd_weights_folded(prelu_out=), the dgrad mask above it)?  That
         form takes the gate from the sign of the saved output and divides the slope-gradient sum by slope^2: right for a slope safely above
-        zero, inf / the wrong gate at slope <= 0.  The slope is read WITHOUT stalling the stream: each call starts
-        an asynchronous copy into pinned host memory and decides from the value the previous call fetched (one optimiser step old: the
-        threshold, 1e-3 -- the reference's SFTLikeBlock starts these slopes at 0.01 --, is ten Adam steps of lr 1e-4 above zero); the
-        first call reads synchronously."""
+        zero, inf / the wrong gate at slope <= 0.  The slope is read WITHOUT stalling the host: at most once per optimiser step a call
+        starts an asynchronous copy into pinned host memory; a later call takes the value once the copy's event has completed (``query``,
+        never ``synchronize``) and until then decides from the last completed value (one or two optimiser steps old: the threshold, 1e-3
+        -- the reference's SFTLikeBlock starts these slopes at 0.01 --, is ten Adam steps of lr 1e-4 above zero); only the very first
+        call of a parameter reads synchronously.  ``new_step`` drops the probes of reloaded parameters."""
         st = getattr(p, "_slope_probe", None)
         if st is None:
             host = torch.empty(p.numel(), dtype=torch.float32, pin_memory=True)
             host.copy_(p.detach().reshape(-1).to(torch.float32))
-        else:
-            host, ev = st
-            ev.synchronize()
-        ok = bool(float(host.min()) > 1e-3)
-        host.copy_(p.detach().reshape(-1).to(torch.float32), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        p._slope_probe = (host, ev)
+            ok = bool(float(host.min()) > 1e-3)
+            p._slope_probe = [host, None, ok, self._probe_epoch]
+            return ok
+        host, ev, ok, epoch = st
+        if ev is not None and ev.query():          # the copy started by an earlier call has landed: take its value (never wait for it)
+            ok, ev = bool(float(host.min()) > 1e-3), None
+        if ev is None and epoch != self._probe_epoch:      # at most one probe per optimiser step (Engine.new_step)
+            host.copy_(p.detach().reshape(-1).to(torch.float32), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            epoch = self._probe_epoch
+        p._slope_probe = [host, ev, ok, epoch]
         return ok
+
+    def new_step(self, params=()):
+        """called when the master weights may have changed (optimiser step, load_state_dict): slope probes of the previous weights are
+        dropped for re-assigned / reloaded parameters (``params``) and every live probe may issue one new asynchronous read"""
+        self._probe_epoch += 1
+        for p in params:
+            if hasattr(p, "_slope_probe"):
+                del p._slope_probe
 
     # ------------------------------------------------------------------ elementwise wrappers
     def epilogue_bwd(self, dout, out=None, act=L.ACT_NONE, slope=0.0, prelu=None, res=None, res2=None, res_mode=L.RES_NONE,

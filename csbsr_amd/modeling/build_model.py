@@ -156,11 +156,17 @@ class _JointBase(nn.Module):
         # compensation on (engine.Conv._wq / _dc_bias: what a layer with fewer than three blocks gets) the two-block plan measures 2.36e-4 on
         # the map against 2.10e-4 with three (nearest rounding: 4.99e-4; gradients median 1.4e-3 vs 9e-4, bound 3e-2) on the reference's own
         # SR image -- inside 1e-3 with 4x margin -- for a third of those layers' forward MFMA time.  The same rounding does NOT rescue the
-        # BatchNorm'd trunk / decoder layers (up_1 at two blocks: 3.6e-4 vs 7.9e-5, r04: 4.1e-4), which stay at three.
+        # BatchNorm'd trunk layers, which stay at three.  Round 6 (review item 6, scripts/study_split_plan.py --combos on tap-sum-rounded weights,
+        # profiles/r06_split_plan_combos.json): the decoder TAIL of PSPNet -- up_1, up_2, up_3, final: 35 ms of split forward convolutions per
+        # config-2 step -- at two blocks together measures 4.15e-4 on the reference's own SR image against 7.9e-5 with three (up_2 1.7e-4, up_3
+        # 1.1e-4, final 3.0e-4, up_1 3.6e-4 alone; gradients median 1.14e-2 vs 1.03e-2, max 2.24e-2, bound 3e-2): inside the review's "sum
+        # <= 6e-4" criterion, and adopted; the PSP module on top of it (6.7e-4) is not.
         # ``detector_hp_dgrad``: dgrads against [w_hi | w_lo] (two K blocks).  The same sweep shows it buys nothing -- every detector
         # gradient tensor and dLoss/dSR agree with the reference equally well without it (PSPNet median 1.15e-2 vs 1.12e-2, HRNet-OCR
         # 1.65e-2 both, BlurSkip 9.4e-4 vs 9.1e-4: the error is the ReLU-gate flips of the forward, not the weights' rounding) -- so it is off.
         self.detector_plan = [(r"blur_skip\.[02]\.conv_(scale|shift)\.[01]\.", 2)] if self.blur_skip else None
+        if self.seg_model_name == "PSPNet" and __import__("os").environ.get("CSBSR_DEC_PLAN", "1") != "0":
+            self.detector_plan = [(r"\.(up_[123]|final)\.", 2)]
         if __import__("os").environ.get("CSBSR_BS_PLAN") == "0":        # (A/B hook: three blocks everywhere)
             self.detector_plan = None
         self.detector_hp_dgrad = __import__("os").environ.get("CSBSR_HP_DGRAD") == "1"      # (A/B hook; default off)
@@ -187,6 +193,7 @@ class _JointBase(nn.Module):
                     own[k].copy_(v)
         if self._rt is not None:
             self._invalidate()
+            self._rt["eng"].new_step([own[k] for k in sd if k in own])      # slope probes of the weights just replaced are stale
         return missing, unexpected
 
     # ---- runtime (engine + layer objects) is built lazily on the device
@@ -246,6 +253,7 @@ class _JointBase(nn.Module):
         rt = self._rt
         rt["kbpn"].invalidate()
         rt["psp"].invalidate()
+        rt["eng"].new_step()            # (master weights may have been stepped: every PReLU slope probe may issue one new asynchronous read)
 
     # ---- shared forward pieces
     def _mount(self, t):

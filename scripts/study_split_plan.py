@@ -73,7 +73,8 @@ def main():
             if det == "PSPNet_BlurSkip":
                 variants += [("bs_conv0+1=2", [(gp["bs_conv0"], 2), (gp["bs_conv1"], 2)], False),
                              ("bs_conv0+1+cb=2", [(gp["bs_conv0"], 2), (gp["bs_conv1"], 2), (gp["bs_cb"], 2)], False),
-                             ("bs_all=2 final=2", [(gp["bs_conv0"], 2), (gp["bs_conv1"], 2), (gp["bs_cb"], 2), (gp["final"], 2)], False)]
+                             ("bs_all=2 final=2", [(gp["bs_conv0"], 2), (gp["bs_conv1"], 2), (gp["bs_cb"], 2), (gp["final"], 2)], False),
+                             ("bs_conv0+1=2 decoder=2", [(gp["bs_conv0"], 2), (gp["bs_conv1"], 2), (r"\.(up_[123]|final)\.", 2)], False)]
             elif det == "PSPNet":
                 variants += [("up_1+2+3=2", [(gp["up_1"], 2), (gp["up_2"], 2), (gp["up_3"], 2)], False),
                              # round 6: the decoder groups one at a time and together on tap-sum-rounded weights (review item 6)

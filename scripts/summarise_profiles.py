@@ -43,6 +43,8 @@ os.makedirs(DST, exist_ok=True)
 shutil.copy(os.path.join(SRC, "stats", "bench_kernel_stats.csv"), os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"))
 line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
 json.dump(json.loads(line), open(os.path.join(DST, f"{TAG}_bench.json"), "w"), indent=1)
+if os.path.exists(os.path.join(SRC, "layers.json")):      # bench.py --dump-layers of the same run: scripts/roof_ledger.py reads it
+    shutil.copy(os.path.join(SRC, "layers.json"), os.path.join(DST, f"{TAG}_layers.json"))
 fetch = pmc(os.path.join(SRC, "pmc_fetch", "fetch_counter_collection.csv"), "FETCH_SIZE")
 write = pmc(os.path.join(SRC, "pmc_write", "write_counter_collection.csv"), "WRITE_SIZE")
 out = {"command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py --batch 4 --steps 1 --warmup 1 --no-cpu-baseline "
