@@ -42,7 +42,8 @@ struct ConvK {
   // each sample padded to hw_pad (a multiple of the pixel tile) positions, so a tile never straddles two samples.
   float* stat_part; long stat_ld; int hw_pad;
   long bias_sn;              // per-sample bias: element stride between the samples' bias rows (0: one row), csbsr_conv_desc_t::bias_sn
-  int fs;                    // 1: fused split-fp16 input (csbsr_conv_desc_t::split_fused): in[0] = [hi | lo], c0 = ctot = 2 x plane channels
+  int fs;                    // 1: fused split-fp16 input (csbsr_conv_desc_t::split_fused): in[0] = [hi | lo], c0 = ctot = 2 x plane channels; 2: the same stage
+                             // without the x_hi w_lo product ([x_hi | x_lo] w_hi: a layer whose precision plan keeps its weights' fp16 rounding)
 };
 
 // value -> (hi, lo) fp16 pair with hi + lo == value to ~2^-22 relative (lo is exact down to fp16's subnormal spacing, 6e-8)

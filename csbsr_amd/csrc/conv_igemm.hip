@@ -454,7 +454,7 @@ int conv_desc_to_k(const csbsr_conv_desc_t* d, ConvK& k) {
   k.bias_sn = d->bias_sn;
   CSBSR_CHECK(!d->bias_sn || (d->bias && !d->transposed && ((long)d->OH * d->OW) % 256 == 0),
               "conv: a per-sample bias needs a non-transposed layer whose samples are whole pixel tiles (OH * OW a multiple of 256)");
-  k.fs = d->split_fused ? 1 : 0;
+  k.fs = d->split_fused == 2 ? 2 : (d->split_fused ? 1 : 0);      // 2: the fused stage without the x_hi w_lo product (two-product plan)
   CSBSR_CHECK(!k.fs || (d->in[1].c == 0 && d->in[0].c % 16 == 0 && d->in[0].c >= 64 && !d->transposed), "conv: split_fused needs one [hi | lo] segment of 2 x (>= 32, a multiple of 8) channels");
   CSBSR_CHECK(d->stat_mode == CSBSR_STAT_NONE || d->stat, "conv: stat_mode set without stat buffer");
   return 0;

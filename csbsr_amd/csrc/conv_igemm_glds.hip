@@ -343,6 +343,9 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
     };
     if constexpr (FS) {
       // chunk pairs ks = 0, 1: channels 0..15 / 16..31 of the hi halves, ks = 2, 3: of the lo halves (pixel AND weight tile)
+      // (p.fs == 2, wave-uniform: the x_hi w_lo product is skipped -- the layer's plan keeps the weights' fp16 rounding, round 6 -- : four
+      // MFMA groups per stage instead of six from the same staged slice)
+      const bool wlo = p.fs != 2;
       h8 af[TA], bh[2], bl[2];
       load_w(0, af); load_x(0, bh);
       mm(af, bh);                      // x_hi w_hi
@@ -350,16 +353,20 @@ __global__ __launch_bounds__(NWM * 128) void conv_igemm_glds_kernel(const ConvK 
       load_x(2, bl);
       mm(af, bl);                      // x_lo w_hi
       hook(std::integral_constant<int, 1>{});
-      load_w(2, af);
-      mm(af, bh);                      // x_hi w_lo
+      if (wlo) {
+        load_w(2, af);
+        mm(af, bh);                    // x_hi w_lo
+      }
       hook(std::integral_constant<int, 2>{});
       load_w(1, af); load_x(1, bh);
       mm(af, bh);
       hook(std::integral_constant<int, 3>{});
       load_x(3, bl);
       mm(af, bl);
-      load_w(3, af);
-      mm(af, bh);
+      if (wlo) {
+        load_w(3, af);
+        mm(af, bh);
+      }
     } else if constexpr (CT == 2) {      // 8 MFMAs per sub-step cover the next fragment reads; one fragment set keeps the wave inside 256 registers
       auto kslice = [&](auto KS) __attribute__((always_inline)) {
         h8 af[TA], bf[2];

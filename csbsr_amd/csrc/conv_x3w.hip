@@ -14,23 +14,27 @@
 // output (which is what the 256 AGPRs of a one-wave-per-SIMD kernel can hold), no 2-D transform's 16-position accumulator blow-up.
 // Precision: tests/study_winograd.py (profiles/r06_winograd_study.txt) -- the SR image moves by < 3e-5 of its maximum.
 //
-// MEASURED (round 6, N = 8, 448^2, scripts/bench_conv.py; profiles/r06_winograd_kernel.txt) AND NOT THE DEFAULT: 825 -> 384 7.55 ms against
-// 7.49 ms for conv_x3<3>, 384 -> 825 9.12 / 8.73, 256 -> 697 5.78 / 5.70, dgrads alike: parity, not the 1.5x of the MFMA count.  The ablation
-// builds (CSBSR_X3W_ABLATE) say why: MFMAs + LDS fragment reads alone 4.51 ms (2030 TF/s of direct-equivalent work), + the weight stream
-// 5.44, + the halo stream 5.96, both 7.55; with every load served from L1 / L2-resident lines still 6.57.  F(2, 3) needs one fresh weight
-// fragment per two MFMAs where the direct kernel needs one per four: 4 waves x 8 KB per 512-cycle K step = 64 B/clk per CU for the weights
-// alone + 16 B/clk of halo pixels, against the ~64 B/clk a CU's vector-memory path delivers (the direct kernel asks 37).  The 256
-// accumulators of the four positions are the whole AGPR file, so the wave tile cannot grow to raise the reuse, LDS (at 80 of 128 B/clk with
-// the V fragments) has no room to share the weights between the two row-pair waves, and a deeper weight ring has no registers.  Winograd
-// removes MFMA work the chip has to spare and adds operand traffic it does not: kept as an opt-in (csbsr_debug_set_conv_x3w(1),
-// CSBSR_CONV_X3W=1) with its tests, off by default.
+// MEASURED (round 6, N = 8, 448^2, scripts/bench_conv.py; profiles/r06_winograd_kernel.txt) AND NOT THE DEFAULT: 825 -> 384 6.85 ms against
+// 7.49 ms for conv_x3<3>, 384 -> 825 8.47 / 8.73, 256 -> 697 5.47 / 5.70, 569 -> 128 1.87 / 2.05, dgrads alike: 3-9 % faster, not the 1.5x of
+// the MFMA count -- about 5 ms of a 1025 ms config-2 step, under the box-to-box noise, for a changed rounding in 24 launches: opt-in
+// (csbsr_debug_set_conv_x3w(1), CSBSR_CONV_X3W=1), with its tests.  The ablation builds (CSBSR_X3W_ABLATE) say where the time goes:
+// MFMAs + LDS fragment reads alone 4.41 ms (2070 TF/s of direct-equivalent work), + the weight stream 4.80, + the halo stream 6.12, both
+// 6.85.  F(2, 3) needs a fresh weight fragment per two MFMAs per position where the direct kernel reuses one over eight pixel blocks, and
+// a transformed pixel fragment per MFMA pair: twice the operand traffic per MFMA.  The first build split the waves by ROWS, so every weight
+// fragment crossed the CU's vector-memory path twice (64 B/clk for the weights alone, 7.55 ms: parity); this one splits them by POSITION
+// pair (each fragment loaded by one wave, the two halves of the output transform meet through LDS in the epilogue).  What is left is the
+// halo stream: 64-byte requests at a two-pixel stride, 12 per lane and chunk -- neither a deeper lead (loads two chunks ahead, registers
+// carried over the back edge), nor a weight ring of 6 instead of 3, nor four-tile runs per lane (10 loads for 4 tiles instead of 16: 7.32 ms,
+// the three staging waves fall behind the fourth) moved it.  The 256 accumulators of the positions are the whole AGPR file, so the tile
+// cannot grow to raise the reuse, and LDS (at ~80 of 128 B/clk with the V fragments) has no room to share more.
 //
-//  * one persistent workgroup per CU (4 waves) computes a 4-row x 64-pixel x 128-cout tile; a wave owns 64 couts x 2 rows x 32 x-tiles
-//    = acc[mt 2][row 2][position 4] 32x32 MFMA tiles, 256 accumulator registers;
+//  * one persistent workgroup per CU (4 waves) computes a 4-row x 64-pixel x 128-cout tile; a wave owns 64 couts x 4 rows x 32 x-tiles x TWO
+//    of the four positions = acc[mt 2][row 4][position 2] 32x32 MFMA tiles, 256 accumulator registers; the two position-pair waves of a
+//    cout half meet in the epilogue (one accumulator set each way through LDS);
 //  * the pixel operand is staged per 32-channel chunk: every lane loads the four pixels (16 bytes = 8 channels each) of three
 //    (halo row, x-tile, channel octet) items from L2 / HBM into registers -- buffer loads, zeros outside the image from the bounds
 //    check -- transforms them with 16 packed fp16 adds and writes the four V vectors to one of two 60 KB LDS buffers, all of it issued
-//    piece by piece INSIDE the previous chunk's K loop (loads in its first three K steps, transform + ds_write in its last three);
+//    INSIDE the previous chunk's K loop (the loads in its first K step, the transforms + ds_writes in its last three);
 //  * V layout [halo row 6][position 4][x-tile 32][4 channel octets + 1 pad]: the odd 80-byte tile pitch keeps the ds_read_b128 fragment
 //    reads of the MFMA B operand conflict-free;
 //  * weights as in conv_x3: packed in MFMA-fragment order per K step (row tap, 16-channel slice) x [position][mt], 8 KB per wave and
@@ -49,7 +53,7 @@
 #define XW_WSTEP 16384                    // bytes of one K step's weights for the 128-cout tile: [cout half mh][position][mt][lane][8]
 #define XW_STEPS 6                        // K steps per chunk: 3 row taps x 2 sixteen-channel slices
 #ifndef XW_RING
-#define XW_RING 3
+#define XW_RING 3                         // (6 measured the same: 6.85 vs 6.81 ms)
 #endif
 #define XW_DIST (XW_RING - 1)
 
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_x3w_kernel(const ConvK p, const XWEx
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tcol = lane & 31, hi = lane >> 5;
-  const int mh = wid & 1, rq = wid >> 1;
+  const int mh = wid & 1, pp = wid >> 1;      // cout half (64 couts), position pair (Winograd positions 2 pp, 2 pp + 1)
   const unsigned per_img = q.tiles_x * q.tiles_y, ntiles = per_img * (unsigned)p.N, items = ntiles * q.nct;
   unsigned it = blockIdx.x;
   if (it >= items) return;
@@ -159,17 +163,19 @@ __global__ __launch_bounds__(256) void conv_x3w_kernel(const ConvK p, const XWEx
     *reinterpret_cast<xw_u4*>(o + 2 * XW_NT * XW_TPITCH) = pk_sub(d[1], d[2]);
     *reinterpret_cast<xw_u4*>(o + 3 * XW_NT * XW_TPITCH) = pk_sub(d[1], d[3]);
   };
-  // a wave's weights of K step (ct, chunk, ky, kk): [position 4][mt 2] fragments, 8 KB, one 16-byte load per lane each
-  const unsigned wlane = (unsigned)(mh * 8192 + lane * 16);
-  auto load_w = [&](int ct, int step, h8 (&w)[4][2]) __attribute__((always_inline)) {
+  // a wave's weights of K step (ct, chunk, ky, kk): its two positions x [mt 2] fragments, 4 KB, one 16-byte load per lane each -- every
+  // fragment of the step's 16 KB is loaded by exactly ONE wave of the workgroup (the first build split the waves by rows: each fragment
+  // crossed the CU's vector-memory path twice, 64 B/clk for the weights alone)
+  const unsigned wlane = (unsigned)(mh * 8192 + pp * 4096 + lane * 16);
+  auto load_w = [&](int ct, int step, h8 (&w)[2][2]) __attribute__((always_inline)) {
     const char* b = reinterpret_cast<const char*>(p.wt) + ((size_t)ct * q.nch * XW_STEPS + step) * XW_WSTEP;
 #pragma unroll
-    for (int pos = 0; pos < 4; ++pos)
+    for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) w[pos][mt] = *reinterpret_cast<const h8*>(b + (wlane + (pos * 2 + mt) * 1024));
+      for (int mt = 0; mt < 2; ++mt) w[pl][mt] = *reinterpret_cast<const h8*>(b + (wlane + (pl * 2 + mt) * 1024));
   };
-  // this lane's B-operand fragments: V[halo row 2 rq + r + ky][position][x-tile tcol], channels 16 kk + 8 hi ..
-  const char* vl = smem + ((2 * rq * 4) * XW_NT + tcol) * XW_TPITCH + hi * 16;
+  // this lane's B-operand fragments: V[halo row r + ky][position 2 pp + pl][x-tile tcol], channels 16 kk + 8 hi ..
+  const char* vl = smem + ((2 * pp) * XW_NT + tcol) * XW_TPITCH + hi * 16;
 
   int ct, n, Y0, X0;
   decode(it, ct, n, Y0, X0);
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_x3w_kernel(const ConvK p, const XWEx
       store_item(d, i, 0);
     }
   }
-  h8 wreg[XW_RING][4][2];                  // K step g = chunk * 6 + s lives in wreg[s % 3]
+  h8 wreg[XW_RING][2][2];                  // K step g = chunk * 6 + s lives in wreg[s % XW_RING] (XW_RING divides 6)
 #pragma unroll
   for (int g = 0; g < XW_DIST; ++g) load_w(ct, g, wreg[g]);
   const int nsteps = (int)q.nch * XW_STEPS;
@@ -192,13 +198,13 @@ __global__ __launch_bounds__(256) void conv_x3w_kernel(const ConvK p, const XWEx
     int ctn = ct, nn = n, Y0n = Y0, X0n = X0;
     if (itn < items) decode(itn, ctn, nn, Y0n, X0n);
     const unsigned par = ((it - blockIdx.x) / gridDim.x) * q.nch;     // chunk c of this tile lives in buffer (par + c) & 1
-    f16v acc[2][2][4];
+    f16v acc[2][4][2];                       // [mt][row][local position]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int c_ = 0; c_ < 4; ++c_)
+        for (int c_ = 0; c_ < 2; ++c_)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][b][c_][r] = 0.f;
 
@@ -208,19 +214,21 @@ __global__ __launch_bounds__(256) void conv_x3w_kernel(const ConvK p, const XWEx
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const int bnext = (int)((par + c + 1) & 1);
-      // the next chunk (past the tile's last one: the next tile's first; past the last tile: a harmless refetch that keeps the
-      // instruction stream uniform), loaded, transformed and written piece by piece below
+      // the next chunk (past the tile's last one: the next tile's first; past the last tile: a harmless refetch that keeps the instruction
+      // stream uniform): all twelve loads in this chunk's FIRST K step, the transforms + writes in its last three -- three to five K steps
+      // (1500-2500 cycles) between a load and its use.  (Carrying the loaded registers over the loop's back edge for a six-step lead makes the
+      // compiler's s_waitcnt insertion give up on their age: it drained the whole weight ring at the top of every chunk.)
       const bool same = c + 1 < (int)q.nch;
       const int sn_ = same ? n : (itn < items ? nn : n), sY = same ? Y0 : (itn < items ? Y0n : Y0), sX = same ? X0 : (itn < items ? X0n : X0);
       const __amdgpu_buffer_rsrc_t nrs = xw_make_rs(chunk_src(sn_, sY, sX, same ? c + 1 : 0));
       asm volatile("" ::: "memory");
-      const char* vb = vl + ((par + c) & 1) * XW_BUF;
-      h8 bfr[4][2];
       xw_u4 stg[3][4];
+      const char* vb = vl + ((par + c) & 1) * XW_BUF;
+      h8 bfr[2][4];
 #pragma unroll
-      for (int pos = 0; pos < 4; ++pos)
+      for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) bfr[pos][r] = *reinterpret_cast<const h8*>(vb + ((r * 4 + pos) * XW_NT) * XW_TPITCH);      // row tap 0, slice 0
+        for (int r = 0; r < 4; ++r) bfr[pl][r] = *reinterpret_cast<const h8*>(vb + ((r * 4 + pl) * XW_NT) * XW_TPITCH);      // row tap 0, slice 0
 #pragma unroll
       for (int s = 0; s < XW_STEPS; ++s) {
         {   // weights XW_DIST K steps ahead (past the tile's last step: the next tile's first ones)
@@ -230,44 +238,69 @@ __global__ __launch_bounds__(256) void conv_x3w_kernel(const ConvK p, const XWEx
           else if (g < nsteps) load_w(ct, g, wreg[(s + XW_DIST) % XW_RING]);
           else load_w(ctn, g - nsteps, wreg[(s + XW_DIST) % XW_RING]);
         }
-        if (s < 3 && !(ABL & 1)) load_item(nrs, sY, sX, s, stg[s]);
         __builtin_amdgcn_sched_barrier(0);
-        const int ky = s >> 1, kk = s & 1;
         const int ky1 = (s + 1) >> 1, kk1 = (s + 1) & 1;
 #pragma unroll
-        for (int pos = 0; pos < 4; ++pos) {
+        for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            acc[0][r][pos] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s % XW_RING][pos][0], bfr[pos][r], acc[0][r][pos], 0, 0, 0);
-            acc[1][r][pos] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s % XW_RING][pos][1], bfr[pos][r], acc[1][r][pos], 0, 0, 0);
+          for (int r = 0; r < 4; ++r) {
+            acc[0][r][pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s % XW_RING][pl][0], bfr[pl][r], acc[0][r][pl], 0, 0, 0);
+            acc[1][r][pl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[s % XW_RING][pl][1], bfr[pl][r], acc[1][r][pl], 0, 0, 0);
             // the same (position, row) fragment of the next K step (the next chunk starts over after its barrier)
             if (s + 1 < XW_STEPS && !(ABL & 4))
-              bfr[pos][r] = *reinterpret_cast<const h8*>(vb + (((r + ky1) * 4 + pos) * XW_NT) * XW_TPITCH + kk1 * 32);
+              bfr[pl][r] = *reinterpret_cast<const h8*>(vb + (((r + ky1) * 4 + pl) * XW_NT) * XW_TPITCH + kk1 * 32);
             __builtin_amdgcn_sched_barrier(0);
+            if (s == 0 && pl == 0 && r < 3 && !(ABL & 1)) load_item(nrs, sY, sX, r, stg[r]);
+            if (s >= 3 && pl == 1 && r == 1 && !(ABL & 16)) store_item(stg[s - 3], s - 3, bnext);      // transform + four ds_write_b128 in the MFMAs' shadow
           }
-          if (s >= 3 && pos == 1 && !(ABL & 16)) store_item(stg[s - 3], s - 3, bnext);      // transform + four ds_write_b128 in the MFMAs' shadow
         }
       }
     }
 
-    // ---- epilogue: out[2t] = M0 + M1 + M2, out[2t + 1] = M1 - M2 - M3; acc[mt][r][pos][8 pair + e] = cout 128 ct + 64 mh + 32 mt + 16 pair
-    // + 8 hi + e of x-tile tcol in row Y0 + 2 rq + r
+    // ---- epilogue.  out[2t] = M0 + M1 + M2, out[2t + 1] = M1 - M2' ... with the kernel's sign of position 2 (V2' = -V2 against -U2: M2 is the
+    // plain product): the position-pair waves exchange ONE accumulator set each through LDS -- wave pp = 0 holds M0, M1: it keeps M0 + M1,
+    // sends M1, receives M2 and finishes the EVEN pixels; wave pp = 1 holds M2, M3: it keeps -(M2 + M3), sends M2, receives M1 and finishes
+    // the ODD pixels -- one (mt, row) block of 16 registers per round through one of two 16 KB regions of the V buffer the last chunk has
+    // just left (the other buffer already holds the next tile's first chunk).  acc[mt][row][pl][8 pair + e] = cout 128 ct + 64 mh + 32 mt +
+    // 16 pair + 8 hi + e of x-tile tcol in row Y0 + row.
+    {
+      char* xbase = smem + ((par + q.nch - 1) & 1) * XW_BUF;
+      char* xmine = xbase + wid * 4096 + lane * 16;
+      const char* xpart = xbase + (wid ^ 2) * 4096 + lane * 16;
+      const int ox = X0 + 2 * tcol + pp;
+      __builtin_amdgcn_s_barrier();              // every wave is out of the last chunk's K loop: its V buffer is free
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int oy = Y0 + 2 * rq + r;
+      for (int k = 0; k < 8; ++k) {
+        const int mt = k >> 2, r = k & 3;
+        char* wr = xmine + (k & 1) * 16384;
 #pragma unroll
-      for (int mp = 0; mp < 4; ++mp) {
-        const int mt = mp >> 1, pair = mp & 1;
-        const int co = 128 * ct + 64 * mh + 32 * mt + 16 * pair + 8 * hi;
+        for (int j = 0; j < 4; ++j) {
+          f4 t;
 #pragma unroll
-        for (int odd = 0; odd < 2; ++odd) {
-          const int ox = X0 + 2 * tcol + odd;
+          for (int e = 0; e < 4; ++e) t[e] = pp ? acc[mt][r][0][4 * j + e] : acc[mt][r][1][4 * j + e];      // pp = 0 sends M1 (pl 1), pp = 1 sends M2 (pl 0); a select: an index computed from pp would put the accumulators in scratch
+          *reinterpret_cast<f4*>(wr + j * 1024) = t;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* rd = xpart + (k & 1) * 16384;
+        float got[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f4 t = *reinterpret_cast<const f4*>(rd + j * 1024);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) got[4 * j + e] = t[e];
+        }
+        const int oy = Y0 + r;
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+          const int co = 128 * ct + 64 * mh + 32 * mt + 16 * pair + 8 * hi;
           if (oy >= p.OH || ox >= p.OW || co >= p.coutp) continue;
           float v[8], bias[8], s0[8], s1[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float m1 = acc[mt][r][1][8 * pair + e], m2 = acc[mt][r][2][8 * pair + e];
-            v[e] = odd ? (m1 - m2) - acc[mt][r][3][8 * pair + e] : (m1 + m2) + acc[mt][r][0][8 * pair + e];
+            const float a0 = acc[mt][r][0][8 * pair + e], a1 = acc[mt][r][1][8 * pair + e], g_ = got[8 * pair + e];
+            v[e] = pp ? g_ - (a0 + a1) : (a0 + a1) + g_;            // even: (M0 + M1) + M2;  odd: M1 - (M2 + M3)
             bias[e] = (p.bias && co + e < p.cout) ? p.bias[n * p.bias_sn + co + e] : 0.f;
           }
           if constexpr (EPI == 1) {
@@ -304,6 +337,10 @@ __global__ __launch_bounds__(256) void conv_x3w_kernel(const ConvK p, const XWEx
         }
       }
     }
+    // The epilogue's global STORES share vmcnt with the loads and complete out of order with them: left pending into the next tile's K loop
+    // they make the compiler's s_waitcnt insertion treat every loop-carried load there as of unknown age (it drained the weight ring to
+    // vmcnt(6) at the top of EVERY chunk with a ring of six).  Draining once per tile, through the builtin the pass understands, is cheap.
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
     ct = ctn; n = nn; Y0 = Y0n; X0 = X0n;
   }
 #endif

@@ -367,14 +367,14 @@ class Conv:
     # the epilogue's out_scale) so the lo halves of kaiming-sized weights stay in fp16's normal range
     WSCALE = 256.0
 
-    def _pack_split(self, key, kind, creal, nrows, stride, pad, k_off=0, layout=0, row_off=0):
+    def _pack_split(self, key, kind, creal, nrows, stride, pad, k_off=0, layout=0, row_off=0, tapsum=False):
         if key in self._packed:
             return self._packed[key]
         D0, D1 = self.w.shape[0], self.w.shape[1]
         n = L.load().csbsr_packed_weight_elems_split(kind, D0, D1, self.k, self.k, stride, creal, nrows, layout)
         dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
         # (layout 2 = [w_hi | w_hi], a layer whose plan drops the x_hi w_lo product: its one rounding of the weights is the tap-sum-preserving one)
-        src = self._wq() if layout == 2 else self.w
+        src = self._wq() if (layout == 2 or tapsum) else self.w
         L.call("csbsr_pack_weights_split", _ptr(src), _ptr(dst), kind, D0, D1, self.k, self.k, stride, pad, creal, row_off, nrows, k_off,
                self.WSCALE, layout, self.eng.stream)
         self._packed[key] = dst
@@ -392,6 +392,12 @@ class Conv:
             # debug mode, a tile they do not take -- _launch falls back to the three-block operand)
             self._fs_fallback = lambda: self._pack_split((key, 3), kind, creal, nrows, stride, pad, k_off=k_off, layout=0)
             return (x,), self._pack_split((key, "fs"), kind, creal, nrows, stride, pad, k_off=k_off, layout=3), 1.0 / self.WSCALE, 4
+        if nb == 2 and self.eng.split_fused and x.cp >= 32 and pad8(nrows) > 32 and kind == 0:
+            # the two-product plan in the fused stage (csbsr_conv_desc_t::split_fused = 2, round 6): [x_hi | x_lo] staged once against
+            # [w_hi | -] -- the two-block form below stages w_hi twice and measured no faster than the fused THREE products.  The hi halves
+            # are the tap-sum-preserving rounding (a layer that keeps its weights' rounding), so the packed lo halves are zero and unread
+            self._fs_fallback = lambda: self._pack_split((key, 2), kind, creal, nrows, stride, pad, k_off=k_off, layout=2)
+            return (x,), self._pack_split((key, "fs2"), kind, creal, nrows, stride, pad, k_off=k_off, layout=3, tapsum=True), 1.0 / self.WSCALE, 5
         wt = self._pack_split((key, nb), kind, creal, nrows, stride, pad, k_off=k_off, layout=0 if nb == 3 else 2)
         return (x,), wt, 1.0 / self.WSCALE, nb
 
@@ -451,12 +457,12 @@ class Conv:
         d = L.ConvDesc()
         x0 = xs[0]
         if x0.lo:                       # split-fp16 input: [hi | lo] (+ hi again for the x_hi w_lo block), weights from _pack_split
-            assert len(xs) == 1 and not transposed and split_blocks in (2, 3, 4)      # 4: the fused three-product form
+            assert len(xs) == 1 and not transposed and split_blocks in (2, 3, 4, 5)      # 4: the fused three-product form, 5: the fused two-product form
             s0, s1 = x0.split_segs()
             d.inp[0] = s0
             if split_blocks == 3:
                 d.inp[1] = s1
-            d.split_fused = int(split_blocks == 4)
+            d.split_fused = 1 if split_blocks == 4 else (2 if split_blocks == 5 else 0)
         else:
             d.inp[0] = x0.seg()
             if len(xs) > 1:
@@ -492,8 +498,11 @@ class Conv:
                 d.mask, d.m_sn, d.m_sy, d.m_sx, d.mask_slope, d.mask_prelu = _ptr(mfm.t), sn, sy, sx, 0.0, _ptr(mslope)
             else:
                 d.mask, d.m_sn, d.m_sy, d.m_sx, d.mask_slope = _ptr(mfm.t), sn, sy, sx, float(mslope)
-        if x0.lo and split_blocks == 4 and not L.load().csbsr_conv_split_fused_eligible(C.byref(d)):
-            d.split_fused, d.inp[1], d.wt, split_blocks = 0, x0.split_segs()[1], _ptr(self._fs_fallback()), 3
+        if x0.lo and split_blocks in (4, 5) and not L.load().csbsr_conv_split_fused_eligible(C.byref(d)):
+            if split_blocks == 4:
+                d.split_fused, d.inp[1], d.wt, split_blocks = 0, x0.split_segs()[1], _ptr(self._fs_fallback()), 3
+            else:
+                d.split_fused, d.wt, split_blocks = 0, _ptr(self._fs_fallback()), 2
         self.last_fused = False
         use_tp = tp is not None and self.eng.use_tp
         if dact is not None:
@@ -591,7 +600,7 @@ class Conv:
             # twice) -- which goes into the last field, not into the FLOPs
             twice = len(xs) == 2 and xs[0] is xs[1]
             ctot = xs[0].c if twice else sum(f.c for f in xs)
-            executed = min(split_blocks, 3) if x0.lo else (2 if twice else 1)
+            executed = (2 if split_blocks in (2, 5) else 3) if x0.lo else (2 if twice else 1)
             npx = x0.N * OH * OW
             taps = k * k if not transposed else ((k + stride - 1) // stride) ** 2
             flops = 2.0 * npx * cout * ctot * taps
@@ -622,7 +631,7 @@ class Conv:
             wt = self._pack("fwd", 0, self.split[0], self.split[1], 0, self.cout, self.stride, self.pad)
         hr = (0, self.cin, self.cout, 0) if (not sp and not self.transposed and self.k in (1, 3) and len(xs) == 1 and self.prelu is None) else None
         # (split inputs: only where the layer's plan keeps the weight's rounding, i.e. runs fewer than three products)
-        bias = self._dc_bias(x_in) if (self.dc_comp and self.eng.dc_comp and not self.transposed and (not sp or nb < 3)
+        bias = self._dc_bias(x_in) if (self.dc_comp and self.eng.dc_comp and not self.transposed and (not sp or self.fwd_blocks < 3)
                                        and (OH * OW) % 256 == 0 and self.cin > 8) else self.b
         self._launch(xs, wt, self.transposed, self.k, self.stride, self.pad, self.dil, H, W, OH, OW, self.cout, out, out32, bias,
                      self.act, self.slope, self.prelu, res, res2, res_mode, False, stat, stat_mode, osc, hr=hr,
@@ -702,7 +711,7 @@ class Conv:
         H, W = x.H, x.W
         if out is None:
             out = self.eng.new(B, H, W, self.cout, split=sp)
-        bias = self._dc_bias((x,)) if (self.dc_comp and self.eng.dc_comp and (not sp or nb < 3) and (x.H * x.W) % 256 == 0) else self.b      # (the feature segment; the constant one is an fp32 mat-vec)
+        bias = self._dc_bias((x,)) if (self.dc_comp and self.eng.dc_comp and (not sp or self.fwd_blocks < 3) and (x.H * x.W) % 256 == 0) else self.b      # (the feature segment; the constant one is an fp32 mat-vec)
         self._launch(xs, wt, False, 3, 1, self.pad, self.dil, H, W, H, W, self.cout, out, None, bias, self.act, self.slope, self.prelu,
                      None, None, L.RES_NONE, False, None, L.STAT_NONE, osc, cbias=cb,
                      x3=None if sp else (0, cf, self.cout, 0, 0), split_blocks=nb)

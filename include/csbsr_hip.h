@@ -108,7 +108,8 @@ typedef struct {
    * unused, weights from csbsr_pack_weights_split layout 3 ([w_hi | w_lo] per 32-channel slice).  One staged K slice then holds 32
    * channels of x_hi and x_lo against the same 32 of w_hi and w_lo and feeds all three products (x_hi w_hi + x_lo w_hi + x_hi w_lo)
    * from it: 2/3 of the operand traffic of the three-block form above for the same arithmetic.  LDS-DMA kernels only (> 32 padded
-   * output channels); the call fails otherwise. */
+   * output channels); the call fails otherwise.  2: the same fused stage WITHOUT the x_hi w_lo product ([x_hi | x_lo] w_hi, the two-product
+   * precision plan of a layer that keeps its weights' fp16 rounding; the w_lo halves of the layout-3 operand are not read). */
   int32_t split_fused; int32_t _pad_sf;
   /* csbsr_conv_forward / csbsr_conv_x3_forward: element stride between the samples' rows of ``bias`` (0 = one fp32[cout] row for the whole
    * batch, the reference's bias).  Non-zero = a per-sample bias [N][bias_sn]: the host's compensation of the forward weights' fp16
