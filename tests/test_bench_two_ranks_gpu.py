@@ -67,7 +67,7 @@ def test_bench_rccl_backend_one_rank():
     env.pop("CSBSR_DIST_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "2", "--lr-size", "64", "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline", "--no-h2d-leg", "--no-other-precision-leg"]
+           "--warmup", "1", "--no-cpu-baseline", "--no-h2d-leg", "--no-other-precision-leg", "--no-kernel-timing"]      # (no extra legs: exactly 1 + 2 steps)
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -309,3 +309,32 @@ def test_bench_refuses_a_rank_count_it_cannot_run():
     n = torch.cuda.device_count()
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n + 1)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "visible" in r.stderr and not r.stdout.strip()
+
+
+def test_dropin_resolves_the_references_import_name():
+    """csbsr_amd.dropin.install(): `from model.modeling.build_model import JointModelWithLoss, JointModel` -- the reference's own import line
+    (train.py:30, test.py:21) -- yields this build's classes; the names it does not build raise NotImplementedError on construction; nothing
+    else of the `model` package is shadowed.  Run in a child interpreter (the finder and the placeholder packages are process-global)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import csbsr_amd.dropin as d\n"
+        "assert d.install() and not d.install()\n"
+        "from model.modeling.build_model import JointModelWithLoss, JointModel, JointInvModelWithLoss, SRModelWithLoss, JointInvModel\n"
+        "from csbsr_amd.modeling import build_model as B\n"
+        "assert JointModelWithLoss is B.JointModelWithLoss and JointModel is B.JointModel\n"
+        "for c in (JointInvModelWithLoss, SRModelWithLoss, JointInvModel):\n"
+        "    try:\n"
+        "        c(None)\n"
+        "    except NotImplementedError:\n"
+        "        pass\n"
+        "    else:\n"
+        "        raise SystemExit('unbuilt class constructed')\n"
+        "import importlib.util\n"
+        "assert importlib.util.find_spec('model.engine') is None or 'csbsr' not in str(importlib.util.find_spec('model.engine').origin)\n"
+        "d.uninstall()\n"
+        "print('ok')\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
