@@ -810,22 +810,46 @@ __global__ void edt_cols_kernel(const float* mask, float* g, int N, int H, int W
     }
   }
 }
+// Row pass of the exact EDT: dist(x) = sqrt(min over x' of g(x')^2 + (x - x')^2), g = the column pass's vertical distance.  Every sum is an
+// integer below 2^24, so the minimum is exact whatever the search order.  Round 6: the search goes block by block (32 columns) with the
+// block minima of g^2 as lower bounds -- a block whose bound  bmin + gap^2  cannot beat the best candidate so far is skipped -- instead of
+// expanding column by column until r^2 >= best: with the sparse crack masks of full-size images (0.4 % foreground, nearest crack hundreds of
+// pixels away) the column-by-column form cost 5.8 ms per config-2 step (1.5 ms on the periodic masks of the earlier bench data).
 __global__ __launch_bounds__(256) void edt_rows_kernel(const float* g, float* dist, int H, int W, float* minmax /*[N][2] as ordered ints*/) {
-  extern __shared__ float srow[];
+  extern __shared__ float srow[];      // [W] squares, then [nb] block minima
   __shared__ float smx[4];
   const long row = blockIdx.x;       // n*H + y
   const float* gp = g + row * W;
+  const int nb = (W + 31) >> 5;
+  float* bmin = srow + W;
   for (int x = threadIdx.x; x < W; x += 256) { const float v = gp[x]; srow[x] = v >= 1e8f ? 1e18f : v * v; }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += 256) {
+    float m = 1e18f;
+    const int x1 = min(W, 32 * b + 32);
+    for (int x = 32 * b; x < x1; ++x) m = fminf(m, srow[x]);
+    bmin[b] = m;
+  }
   __syncthreads();
   float mx = 0.f;
   for (int x = threadIdx.x; x < W; x += 256) {
     float best = srow[x];
-    // candidates farther than sqrt(best) along the row cannot improve: expand outwards
-    for (int r = 1; r < W; ++r) {
-      const float rr = (float)r * r;
-      if (rr >= best) break;
-      if (x - r >= 0) best = fminf(best, srow[x - r] + rr);
-      if (x + r < W) best = fminf(best, srow[x + r] + rr);
+    const int bx = x >> 5;
+    auto scan = [&](int b) {
+      const int x1 = min(W, 32 * b + 32);
+      for (int xx = 32 * b; xx < x1; ++xx) {
+        const float d = (float)(x - xx);
+        best = fminf(best, srow[xx] + d * d);
+      }
+    };
+    if (bmin[bx] < best) scan(bx);
+    for (int d = 1; d < nb; ++d) {
+      const int bl = bx - d, br = bx + d;
+      const float gl = (float)(x - (32 * bl + 31)), gr = (float)(32 * br - x);      // gap to the nearest column of the block (>= 1)
+      const bool lin = bl >= 0 && gl * gl < best, rin = br < nb && gr * gr < best;
+      if (!lin && !rin) break;      // both sides out of range or out of reach: the gaps only grow and ``best`` only shrinks
+      if (lin && bmin[bl] + gl * gl < best) scan(bl);
+      if (rin && bmin[br] + gr * gr < best) scan(br);
     }
     const float dv = sqrtf(best);
     dist[row * W + x] = dv;
@@ -874,9 +898,9 @@ extern "C" int csbsr_sdf(const float* mask, float* sdf, float* scratch /*3*N*H*W
   hipStream_t st = ST(s);
   CSBSR_CHECK(hipMemsetAsync(mm, 0, 2 * N * sizeof(float), st) == hipSuccess, "sdf: memset failed");
   hipLaunchKernelGGL(edt_cols_kernel, dim3(grid_for((long)N * W, 64)), dim3(64), 0, st, mask, g, N, H, W, 0);
-  hipLaunchKernelGGL(edt_rows_kernel, dim3(N * H), dim3(256), W * sizeof(float), st, g, posdis, H, W, mm);
+  hipLaunchKernelGGL(edt_rows_kernel, dim3(N * H), dim3(256), (W + (W + 31) / 32) * sizeof(float), st, g, posdis, H, W, mm);
   hipLaunchKernelGGL(edt_cols_kernel, dim3(grid_for((long)N * W, 64)), dim3(64), 0, st, mask, g, N, H, W, 1);
-  hipLaunchKernelGGL(edt_rows_kernel, dim3(N * H), dim3(256), W * sizeof(float), st, g, negdis, H, W, mm + N);
+  hipLaunchKernelGGL(edt_rows_kernel, dim3(N * H), dim3(256), (W + (W + 31) / 32) * sizeof(float), st, g, negdis, H, W, mm + N);
   hipLaunchKernelGGL(sdf_combine_kernel, dim3(grid_for(npx)), dim3(256), 0, st, mask, posdis, negdis, mm, mm + N, sdf, N, H, W);
   CSBSR_LAUNCH_CHECK("csbsr_sdf");
   return 0;

@@ -324,6 +324,23 @@ def test_sdf_matches_reference_fixture_and_oracle():
     L.call("csbsr_sdf", P(m2.cuda()), P(s2), P(sc2), 2, 160, 192, eng.stream)
     torch.cuda.synchronize()
     assert np.abs(s2.cpu().numpy() - ref).max() < 2e-6
+    # sparse masks on a wide image (the full-size bench data: nearest crack hundreds of columns away, many 32-column blocks without any
+    # feature -- the block-skipping row pass of round 6), a ragged width, a single pixel in a corner, an empty and a full sample
+    Hs, Ws = 96, 1000
+    m3 = torch.zeros(5, 1, Hs, Ws)
+    m3[0, 0, 40:43, 700:960] = 1.0
+    m3[0, 0, 5:90, 17] = 1.0
+    m3[1, 0, Hs - 1, Ws - 1] = 1.0
+    m3[2, 0, 10:12, :] = 1.0
+    m3[4] = 1.0
+    ref3 = O.compute_sdf(m3.numpy())
+    s3 = torch.empty(5, 1, Hs, Ws, device="cuda")
+    sc3 = torch.empty(3 * 5 * Hs * Ws + 10, device="cuda")
+    L.call("csbsr_sdf", P(m3.cuda()), P(s3), P(sc3), 5, Hs, Ws, eng.stream)
+    torch.cuda.synchronize()
+    got3 = s3.cpu().numpy()
+    assert np.abs(got3[:4] - ref3[:4]).max() < 2e-6          # (sample 4, all foreground: the reference divides 0 / 0 there, the kernel writes 0)
+    assert np.isfinite(got3).all() and np.abs(got3[3]).max() == 0.0
 
 
 def test_segloss_and_l1():
