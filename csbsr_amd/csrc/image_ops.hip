@@ -266,6 +266,83 @@ __global__ __launch_bounds__(256) void blur_bwd_kernel_kernel(const float* dy, c
   }
 }
 
+// Stride-1 form (the loss's HR blur, sr_loss_functions.py:93; 80 % of the kernel-gradient time): a thread owns FOUR taps of one kernel row
+// (ky, 4 g .. 4 g + 3) and slides a register window along the tile row, so a pixel costs one x word and the broadcast dy word per four
+// FMAs instead of three words per two -- the two-taps-per-thread form above is LDS-bound at a sixth of the VALU rate (5.5 ms per config-2
+// step at HR, B = 8).  126 of each 128 threads hold taps (21 rows x 6 groups; the sixth group has one tap); the two halves of the workgroup
+// take the even / odd rows of the tile and meet in LDS, half 1 into half 0, before the one partial row is written.
+template <int K>
+__global__ __launch_bounds__(256) void blur_bwd_kernel_s1_kernel(const float* dy, const float* x, int C, int H, int W, int tiles_x, int tiles_y,
+                                                                 int tiles_per_wg, float* part) {
+  constexpr int TO = 32, P = (K - 1) / 2, XW = TO - 1 + K, NG = (K + 3) / 4;
+  static_assert(K * NG <= 128, "one tap group per thread of a half workgroup");
+  static_assert(XW % 4 == 0, "16-byte aligned window rows");
+  extern __shared__ float sm[];
+  float* sDy = sm;                 // TO*TO
+  float* sX = sm + TO * TO;        // XW*XW (+ 4 words of slack: the last group's window runs past its row)
+  __shared__ float sacc[512];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int half = tid >> 7, u = tid & 127;
+  const bool live = u < K * NG;
+  const int ky = live ? u / NG : 0, kx0 = live ? 4 * (u % NG) : 0;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const int total = C * tiles_y * tiles_x;
+  int tile = blockIdx.x * tiles_per_wg;
+  const int tend = tile + tiles_per_wg < total ? tile + tiles_per_wg : total;
+  for (; tile < tend; ++tile) {
+    const int c = tile / (tiles_y * tiles_x);
+    const int r = tile - c * tiles_y * tiles_x;
+    const int ty = r / tiles_x, tx = r - ty * tiles_x;
+    const float* dyp = dy + ((long)n * C + c) * H * W;
+    const float* xp = x + ((long)n * C + c) * H * W;
+    __syncthreads();
+    for (int i = tid; i < TO * TO; i += 256) {
+      const int oy = ty * TO + (i >> 5), ox = tx * TO + (i & 31);
+      sDy[i] = (oy < H && ox < W) ? dyp[(long)oy * W + ox] : 0.f;
+    }
+    const int iy0 = ty * TO - P, ix0 = tx * TO - P;
+    for (int i = tid; i < XW * XW + 4; i += 256) {
+      const int ry = i / XW, rx = i - ry * XW;
+      const int iy = iy0 + ry, ix = ix0 + rx;
+      sX[i] = (i < XW * XW && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? xp[(long)iy * W + ix] : 0.f;
+    }
+    __syncthreads();
+    if (live) {
+      for (int jy = half; jy < TO; jy += 2) {
+        // four pixels per step from two 16-byte LDS reads (x window words 4 q + 4 .. 4 q + 7, the broadcast dy quad): the window of pixel p is
+        // x[p .. p + 3]; kx0 and the row pitch XW = 52 are multiples of 4, so every read is aligned (the one-word-per-pixel form was LDS-issue bound)
+        const float4* xr4 = reinterpret_cast<const float4*>(sX + (jy + ky) * XW + kx0);
+        const float4* dr4 = reinterpret_cast<const float4*>(sDy + jy * TO);
+        float4 cur = xr4[0];
+#pragma unroll
+        for (int q = 0; q < TO / 4; ++q) {
+          const float4 nxt = xr4[q + 1], d = dr4[q];
+          a0 += d.x * cur.x; a1 += d.x * cur.y; a2 += d.x * cur.z; a3 += d.x * cur.w;
+          a0 += d.y * cur.y; a1 += d.y * cur.z; a2 += d.y * cur.w; a3 += d.y * nxt.x;
+          a0 += d.z * cur.z; a1 += d.z * cur.w; a2 += d.z * nxt.x; a3 += d.z * nxt.y;
+          a0 += d.w * cur.w; a1 += d.w * nxt.x; a2 += d.w * nxt.y; a3 += d.w * nxt.z;
+          cur = nxt;
+        }
+      }
+    }
+  }
+  const int t = ky * K + kx0;
+  if (live && half == 1) {
+    sacc[t] = a0;
+    if (kx0 + 1 < K) sacc[t + 1] = a1;
+    if (kx0 + 2 < K) sacc[t + 2] = a2;
+    if (kx0 + 3 < K) sacc[t + 3] = a3;
+  }
+  __syncthreads();
+  if (live && half == 0) {                     // row per (sample, workgroup), 512 floats: folded by csbsr_sum_partials
+    float* row = part + ((long)n * gridDim.x + blockIdx.x) * 512;
+    row[t] = a0 + sacc[t];
+    if (kx0 + 1 < K) row[t + 1] = a1 + sacc[t + 1];
+    if (kx0 + 2 < K) row[t + 2] = a2 + sacc[t + 2];
+    if (kx0 + 3 < K) row[t + 3] = a3 + sacc[t + 3];
+  }
+}
+
 #define BLUR_DISPATCH(K, CALL) \
   switch (K) {                 \
     case 21: { constexpr int KK = 21; CALL; break; } \
@@ -340,8 +417,12 @@ extern "C" int csbsr_blur_bwd_kernel(const float* dy, const float* x, float* dk,
   dim3 grid((total + tpw - 1) / tpw, N);
   float* part = csbsr_red_scratch((long)N * grid.x * 512);
   CSBSR_NEED_SCRATCH(part, "blur_bwd_kernel");
-  BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_bwd_kernel_kernel<KK>), grid, dim3(256), smem, ST(s), dy, x, dk, C, H, W, OH, OW, stride, TO, lgTO,
-                                      tiles_x, tiles_y, tpw, part));
+  if (stride == 1 && K == 21 && OH == H && OW == W) {
+    hipLaunchKernelGGL((blur_bwd_kernel_s1_kernel<21>), grid, dim3(256), smem + 16, ST(s), dy, x, C, H, W, tiles_x, tiles_y, tpw, part);
+  } else {
+    BLUR_DISPATCH(K, hipLaunchKernelGGL((blur_bwd_kernel_kernel<KK>), grid, dim3(256), smem, ST(s), dy, x, dk, C, H, W, OH, OW, stride, TO, lgTO,
+                                        tiles_x, tiles_y, tpw, part));
+  }
   if (csbsr_sum_partials_batched(part, (int)grid.x, 512, K * K, dk, N, (long)K * K, ST(s))) return 1;
   CSBSR_LAUNCH_CHECK("csbsr_blur_bwd_kernel");
   return 0;

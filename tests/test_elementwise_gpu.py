@@ -278,6 +278,30 @@ def test_blur_fwd_bwd(stride):
     assert relmax(dx2.cpu() - 1, x.grad) < 1e-5
 
 
+def test_blur_kernel_gradient_stride1_multi_tile():
+    """csbsr_blur_bwd_kernel, stride 1 (blur_bwd_kernel_s1_kernel: four taps per thread on a sliding register window, the two half
+    workgroups on alternate tile rows): several ragged 32 x 32 tiles per plane against autograd of the oracle's blur."""
+    from csbsr_amd import _lib as L
+    from oracle import csbsr_oracle as O
+    eng = _eng()
+    torch.manual_seed(15)
+    N, H, W, K = 2, 70, 97, 21
+    x = torch.rand(N, 3, H, W)
+    k = torch.rand(N, K * K)
+    k = (k / k.sum(1, keepdim=True)).requires_grad_(True)
+    y = O.blur_down(x, k, K, 1)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    dk = torch.zeros(N, K * K, device="cuda")
+    L.call("csbsr_blur_bwd_kernel", P(dy.cuda()), P(x.cuda()), P(dk), N, 3, H, W, K, 1, eng.stream)
+    torch.cuda.synchronize()
+    assert relmax(dk.cpu(), k.grad) < 1e-4
+    dk2 = torch.zeros(N, K * K, device="cuda")
+    L.call("csbsr_blur_bwd_kernel", P(dy.cuda()), P(x.cuda()), P(dk2), N, 3, H, W, K, 1, eng.stream)
+    torch.cuda.synchronize()
+    assert torch.equal(dk, dk2)          # order-fixed sums: bit-identical twice
+
+
 @pytest.mark.parametrize("aa", [1, 0])
 def test_bicubic_resizes(aa):
     from csbsr_amd import _lib as L
