@@ -77,6 +77,10 @@ SIGNATURES = {
     "csbsr_conv_x3_forward": (i32, [C.POINTER(ConvDesc), vp]),
     "csbsr_packed_weight_elems_x3": (i64, [i32, i32]),
     "csbsr_pack_weights_x3": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "csbsr_conv_x3n_eligible": (i32, [C.POINTER(ConvDesc)]),
+    "csbsr_conv_x3n_forward": (i32, [C.POINTER(ConvDesc), vp]),
+    "csbsr_packed_weight_elems_x3n": (i64, [i32, i32]),
+    "csbsr_pack_weights_x3n": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.c_float, vp]),
     "csbsr_conv_x3w_eligible": (i32, [C.POINTER(ConvDesc)]),
     "csbsr_conv_x3w_forward": (i32, [C.POINTER(ConvDesc), vp]),
     "csbsr_packed_weight_elems_x3w": (i64, [i32, i32]),
@@ -161,6 +165,7 @@ DEBUG_SIGNATURES = {
     "csbsr_debug_set_conv_tp": (None, [i32]),
     "csbsr_debug_set_conv_x3": (None, [i32]),
     "csbsr_debug_set_conv_x3w": (None, [i32]),
+    "csbsr_debug_set_conv_x3n": (None, [i32]),
     "csbsr_debug_set_wgrad_hr": (None, [i32]),
     "csbsr_debug_last_conv_kernel": (i32, []),
     "csbsr_debug_last_wgrad_kernel": (i32, []),
@@ -198,6 +203,8 @@ def load():
         lib.csbsr_debug_set_conv_x3(int(os.environ["CSBSR_CONV_X3"]))
     if os.environ.get("CSBSR_CONV_X3W"):           # A/B hook: 0 off, 1 default, 2 every eligible launch (+ 8 x min input channels / 32)
         lib.csbsr_debug_set_conv_x3w(int(os.environ["CSBSR_CONV_X3W"]))
+    if os.environ.get("CSBSR_CONV_X3N"):           # A/B hook: 0 off, 1 default, 2 every eligible launch
+        lib.csbsr_debug_set_conv_x3n(int(os.environ["CSBSR_CONV_X3N"]))
     if os.environ.get("CSBSR_WGRAD_HR"):           # A/B hook: 0 off, 1 default, 2 every eligible launch
         lib.csbsr_debug_set_wgrad_hr(int(os.environ["CSBSR_WGRAD_HR"]))
     if os.environ.get("CSBSR_CONV_TP"):            # A/B hook: 0 off, 1 default, 2 every eligible launch

@@ -341,7 +341,7 @@ __device__ __forceinline__ void conv_epilogue_direct_tile(const ConvK& p, const 
 
 // which kernel the last csbsr_conv_forward call of this thread dispatched to (csbsr_debug_last_conv_kernel): lets the host-side
 // timing attribute each launch to a kernel name, so bench.py's roofline block is about ONE kernel, the one rocprof lists
-enum { CONVK_IGEMM32 = 0, CONVK_IGEMM64, CONVK_IGEMM128, CONVK_GLDS128, CONVK_GLDS256, CONVK_THIN_COUT, CONVK_THIN_CIN, CONVK_GLDS256W, CONVK_HR, CONVK_TP, CONVK_X3, CONVK_THIN_TP, CONVK_X3S, CONVK_THIN_CIN2, CONVK_GLDS64, CONVK_THIN_SC, CONVK_THIN_TPD, CONVK_X3F, CONVK_X3SF, CONVK_X3W };
+enum { CONVK_IGEMM32 = 0, CONVK_IGEMM64, CONVK_IGEMM128, CONVK_GLDS128, CONVK_GLDS256, CONVK_THIN_COUT, CONVK_THIN_CIN, CONVK_GLDS256W, CONVK_HR, CONVK_TP, CONVK_X3, CONVK_THIN_TP, CONVK_X3S, CONVK_THIN_CIN2, CONVK_GLDS64, CONVK_THIN_SC, CONVK_THIN_TPD, CONVK_X3F, CONVK_X3SF, CONVK_X3W, CONVK_X3N };
 extern thread_local int g_last_conv_kernel;
 int conv_desc_to_k(const csbsr_conv_desc_t* d, ConvK& k);   // conv_igemm.hip: validation + argument block of csbsr_conv_forward
 bool conv_thin_eligible(const ConvK& k);                  // conv_thin.hip: 3-channel image heads

@@ -1,0 +1,319 @@
+// 3x3 stride-1 convolution from MANY input channels into <= 64 output channels at full resolution -- PSPNet_BlurSkip's conv_scale.1 /
+// conv_shift.1 (505 -> 64 at 1792^2, /root/reference/model/modeling/blocks.py:105-120; 20 % of a config-5 step) and the dgrads of its
+// 64 -> 505 conv0's -- built like csrc/conv_x3.hip (resident pixel tile, weights streamed from L2 in fragment order) with the tile turned
+// around for a NARROW output: the LDS-DMA implicit-GEMM kernel runs these layers on a 128-pixel x 64-cout tile, stages every input pixel
+// once per tap and measured 550-590 TF/s (43 flop per staged byte; DESIGN.md section 7.9 of round 5).  Here
+//
+//  * one persistent workgroup per CU (4 waves) computes an 8-row x 64-pixel x 64-cout tile; a wave owns ALL 64 couts x 4 rows x 32 pixels
+//    (2 x 4 MFMA tiles, 128 accumulator registers): the four waves are 2 row quads x 2 column halves and stream the same 4 KB of
+//    weights per K step (the second to fourth request hit L1);
+//  * the pixel operand is staged per 32-channel chunk: the chunk's (8+2) x (64+2) halo goes HBM / L2 -> LDS with buffer-load LDS-DMA
+//    (zeros outside the image from the bounds check) into one of two 52 KB buffers, one DMA piece per k-slice inside the previous chunk's
+//    K loop; every tap reads the same tile at a different offset, so an input pixel crosses the fabric 1.29 times instead of 9;
+//    pixel pitch 80 bytes (4 sixteen-byte channel slots + 1 pad: conflict-free ds_read_b128 rows);
+//  * split-precision inputs (the detector's hi + lo activation pairs) run the two-product plan  [x_hi | x_lo] w_hi  as a plain
+//    convolution over 2 x Cp input channels: the pack repeats the (tap-sum-rounded, pre-scaled) weights for the lo plane (``dup``), the
+//    epilogue stores hi + lo pairs (conv_common.h split_store) -- no kernel code knows about the planes;
+//  * synchronisation: one barrier and one counted s_waitcnt per chunk (nine K steps = 144 MFMAs per wave); the general fused epilogue
+//    rows of conv_common.h.
+#include "common.h"
+#include "conv_common.h"
+#include "csbsr_debug.h"
+
+#define XN_TH 8
+#define XN_TW 64
+#define XN_HW (XN_TW + 2)
+#define XN_HH (XN_TH + 2)
+#define XN_SLOTS 5                        // 32 channels = 4 sixteen-byte slots + 1 pad slot
+#define XN_PITCH (XN_SLOTS * 16)
+#define XN_NINST 52                       // ceil(10 * 66 * 5 / 64) = 52 wave instructions fill the halo tile (a multiple of 4)
+#define XN_BUF (XN_NINST * 1024)
+#define XN_WSTEP 4096                     // bytes of one K step's weights for the 64-cout tile: [mt 2][kk 2][lane][8]
+#define XN_NT 9
+#define XN_RING 3
+#define XN_DIST 2
+static_assert(XN_HH * XN_HW * XN_SLOTS <= XN_NINST * 64, "halo tile fits its DMA instructions");
+
+struct XNExtra {
+  unsigned tiles_x, tiles_y, nct, nch;   // pixel tiles, 64-cout tiles, 32-channel chunks
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t xn_make_rs(const half_t* base) {
+  const unsigned long a = reinterpret_cast<unsigned long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long)hi_ << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+#endif
+
+// FAST: straight-line epilogue rows (conv_epilogue_fast_ok), else the general fused row
+template <bool FAST>
+__global__ __launch_bounds__(256) void conv_x3n_kernel(const ConvK p, const XNExtra q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pix = lane & 31, hi = lane >> 5;
+  const int chf = wid & 1, rq = wid >> 1;            // column half (32 pixels), row quad
+  const unsigned per_img = q.tiles_x * q.tiles_y, ntiles = per_img * (unsigned)p.N, items = ntiles * q.nct;
+  unsigned it = blockIdx.x;
+  if (it >= items) return;
+  const float slope = (p.act == CSBSR_ACT_PRELU) ? *p.prelu : p.act_slope;
+  const EpiFast fe = conv_epilogue_fast_setup(p, slope);
+  const half_t* in0 = reinterpret_cast<const half_t*>(p.in[0].ptr);
+  const int isy = (int)p.in[0].sy, isx = (int)p.in[0].sx;
+
+  // halo DMA roles (the same for every tile and chunk): instruction i of this wave fills LDS bytes (wid + 4 i) * 1024 + lane * 16 =
+  // chunk-slot g = (wid + 4 i) * 64 + lane = (halo pixel g / 5, slot g % 5); slot 4 is the pad
+  constexpr int NFI = XN_NINST / 4;                  // 13 instructions per wave
+  constexpr int DQ = 256 / XN_SLOTS, DC = 256 % XN_SLOTS;
+  int voff[NFI], iy0[NFI], ix0[NFI];
+  {
+    const int g = wid * 64 + lane;
+    const int hq = g / XN_SLOTS;
+    int c = g - hq * XN_SLOTS, ty = hq / XN_HW, tx = hq - ty * XN_HW;
+#pragma unroll
+    for (int i = 0; i < NFI; ++i) {
+      const bool in = ty < XN_HH && c < 4;
+      voff[i] = 2 * (ty * isy + tx * isx + c * 8);
+      iy0[i] = in ? ty : 0x40000000;
+      ix0[i] = tx;
+      c += DC; tx += DQ;
+      if (c >= XN_SLOTS) { c -= XN_SLOTS; ++tx; }
+      if (tx >= XN_HW) { tx -= XN_HW; ++ty; }
+      if (tx >= XN_HW) { tx -= XN_HW; ++ty; }
+    }
+  }
+  // (uniform) address of halo pixel (0, 0), channel 32 chunk, of tile (n, Y0, X0): input pixel (Y0 - 1, X0 - 1)
+  auto chunk_src = [&](int n, int Y0, int X0, int chunk) -> const half_t* {
+    return in0 + n * p.in[0].sn + (long)(Y0 - 1) * p.in[0].sy + (long)(X0 - 1) * p.in[0].sx + chunk * 32;
+  };
+  auto issue_one = [&](__amdgpu_buffer_rsrc_t rs, int by, int bx, int i, int buf) __attribute__((always_inline)) {
+    const bool ok = (unsigned)(iy0[i] + by) < (unsigned)p.H && (unsigned)(ix0[i] + bx) < (unsigned)p.W;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + buf * XN_BUF + (wid + 4 * i) * 1024), 16,
+                                             ok ? voff[i] : -1, 0, 0, 0);
+  };
+  auto decode = [&](unsigned item, int& ct, int& n, int& Y0, int& X0) {
+    item = xcd_remap(item, items);           // the cout tiles of one pixel tile side by side on one XCD (csrc/conv_x3.hip)
+    const unsigned tile = item / q.nct;
+    ct = item - tile * q.nct;
+    n = tile / per_img;
+    const unsigned r_ = tile - n * per_img;
+    Y0 = (r_ / q.tiles_x) * XN_TH; X0 = (r_ % q.tiles_x) * XN_TW;
+  };
+  // the weights of K step (ct, chunk, tap): [mt 2][kk 2] fragments, one 16-byte load per lane each (the same 4 KB for all four waves)
+  const unsigned wlane = (unsigned)(lane * 16);
+  auto load_w = [&](int ct, int step, h8 (&w)[2][2]) __attribute__((always_inline)) {
+    const char* b = reinterpret_cast<const char*>(p.wt) + ((size_t)ct * q.nch * XN_NT + step) * XN_WSTEP;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) w[mt][kk] = *reinterpret_cast<const h8*>(b + (wlane + (mt * 2 + kk) * 1024));
+  };
+  const char* xl = smem + ((4 * rq) * XN_HW + 32 * chf + pix) * XN_PITCH + hi * 16;      // the wave's first row / column of the halo tile
+
+  int ct, n, Y0, X0;
+  decode(it, ct, n, Y0, X0);
+  {
+    const __amdgpu_buffer_rsrc_t rs = xn_make_rs(chunk_src(n, Y0, X0, 0));
+#pragma unroll
+    for (int i = 0; i < NFI; ++i) issue_one(rs, Y0 - 1, X0 - 1, i, 0);
+  }
+  h8 wreg[XN_RING][2][2];                                 // K step g = chunk * 9 + tap lives in wreg[tap % 3]
+#pragma unroll
+  for (int g = 0; g < XN_DIST; ++g) load_w(ct, g, wreg[g]);
+  const int nsteps = (int)q.nch * XN_NT;
+
+  for (; it < items; it += gridDim.x) {
+    const unsigned itn = it + gridDim.x;
+    int ctn = ct, nn = n, Y0n = Y0, X0n = X0;
+    if (itn < items) decode(itn, ctn, nn, Y0n, X0n);
+    const unsigned par = ((it - blockIdx.x) / gridDim.x) * q.nch;     // chunk c of this tile lives in buffer (par + c) & 1
+    f16v acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int c = 0; c < (int)q.nch; ++c) {
+      // chunk c's halo has landed everywhere, and every wave is done with the other buffer (chunk c - 1): refill that one.  The only
+      // vector-memory instructions issued after this chunk's last DMA piece (k-slice NFI - 1 = tap 6 of the previous chunk) are the
+      // weight loads of the taps that followed it (4 each) -- except right after an epilogue, where the count is simply drained.
+      if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (XN_NT - 1 - (NFI - 1) / 2)) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int bnext = (int)((par + c + 1) & 1);
+      const bool same = c + 1 < (int)q.nch;
+      const int sn_ = same ? n : (itn < items ? nn : n), sY = same ? Y0 : (itn < items ? Y0n : Y0), sX = same ? X0 : (itn < items ? X0n : X0);
+      const __amdgpu_buffer_rsrc_t nrs = xn_make_rs(chunk_src(sn_, sY, sX, same ? c + 1 : 0));
+      asm volatile("" ::: "memory");
+      const char* xb = xl + ((par + c) & 1) * XN_BUF;
+      h8 bfr[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bfr[nt] = *reinterpret_cast<const h8*>(xb + (nt * XN_HW) * XN_PITCH);      // tap (0, 0), k-slice 0
+#pragma unroll
+      for (int tap = 0; tap < XN_NT; ++tap) {
+        {   // weights XN_DIST K steps ahead (past the tile's last step: the next tile's first ones)
+          const int g = c * XN_NT + tap + XN_DIST;
+          if (g < nsteps) load_w(ct, g, wreg[(tap + XN_DIST) % XN_RING]);
+          else load_w(ctn, g - nsteps, wreg[(tap + XN_DIST) % XN_RING]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap % XN_RING][0][kk], bfr[i], acc[0][i], 0, 0, 0);
+            acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap % XN_RING][1][kk], bfr[i], acc[1][i], 0, 0, 0);
+            // the same row's fragment of the next k-slice / next tap (the next chunk starts over after its barrier)
+            if (kk < 1) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + ky) * XN_HW + kx) * XN_PITCH + (kk + 1) * 32);
+            else if (tap < XN_NT - 1) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + (tap + 1) / 3) * XN_HW + (tap + 1) % 3) * XN_PITCH);
+            if (i == 1 && tap * 2 + kk < NFI) issue_one(nrs, sY - 1, sX - 1, tap * 2 + kk, bnext);       // one DMA piece per k-slice
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: acc[mt][nt][8 pair + e] = cout 64 ct + 32 mt + 16 pair + 8 hi + e of pixel (row 4 rq + nt, column 32 chf + pix)
+    const int ox = X0 + 32 * chf + pix;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int oy = Y0 + 4 * rq + nt;
+#pragma unroll
+      for (int mp = 0; mp < 4; ++mp) {
+        const int mt = mp >> 1, pair = mp & 1;
+        const int co = 64 * ct + 32 * mt + 16 * pair + 8 * hi;
+        if (oy >= p.OH || ox >= p.OW || co >= p.coutp) continue;
+        float v[8], bias[8], s0[8], s1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = acc[mt][nt][8 * pair + e];
+          bias[e] = (p.bias && co + e < p.cout) ? p.bias[n * p.bias_sn + co + e] : 0.f;
+        }
+        if constexpr (FAST) {
+          half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
+          h8 rr = {0, 0, 0, 0, 0, 0, 0, 0}, oo = {0, 0, 0, 0, 0, 0, 0, 0}, mm = {1, 1, 1, 1, 1, 1, 1, 1};
+          if (fe.has_res) rr = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
+          if (fe.has_old) oo = *reinterpret_cast<const h8*>(o);
+          if (fe.has_mask) mm = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oy * p.m_sy + ox * p.m_sx + co);
+          float brow[8];
+          if (fe.has_cb) conv_class_bias_row(p, bias, co, n, oy, ox, brow);
+          else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) brow[e] = bias[e];
+          }
+          if (fe.has_res || fe.has_old || fe.has_mask) conv_epilogue_fast_row<true, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
+          else conv_epilogue_fast_row<false, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
+        } else {
+          conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, s0, s1);
+        }
+      }
+    }
+    ct = ctn; n = nn; Y0 = Y0n; X0 = X0n;
+  }
+#endif
+}
+
+// ---- weights in K-step order: dst[ct][chunk][tap][mt][kk][lane][e] = scale x W(row 64 ct + 32 mt + perm(lane % 32), channel, tap) with
+// input channel j = 32 chunk + 16 kk + 8 (lane / 32) + e and perm as in csbsr_pack_weights_x3 (a lane's accumulator registers 8 pair ..
+// 8 pair + 7 are consecutive channels).  ``plane`` > 0 (a split input run as 2 x plane plain channels): the weight of input channel j is
+// that of channel j mod plane -- [w | w].  kind 0: forward, W is OIHW; kind 1: dgrad of the stride-1 conv (rows = the conv's input
+// channels, contracted channels its outputs, taps flipped).
+struct PackXNK { const float* w; half_t* dst; int kind, D1, nch, nct, c_real, rows_real, row_off, k_off, plane; float scale; };
+__global__ void pack_weights_x3n_kernel(const PackXNK p, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), kk = (int)((i >> 9) & 1), mt = (int)((i >> 10) & 1);
+    const long step = i >> 11;
+    const int tap = (int)(step % XN_NT);
+    const long t2 = step / XN_NT;
+    const int chunk = (int)(t2 % p.nch), ct = (int)(t2 / p.nch);
+    const int m = lane & 31, q_ = m >> 3, h_ = (m >> 2) & 1;
+    const int row = 64 * ct + 32 * mt + 16 * (q_ >> 1) + 8 * h_ + 4 * (q_ & 1) + (m & 3);
+    int c = 32 * chunk + 16 * kk + 8 * (lane >> 5) + e;
+    if (p.plane > 0) c = c >= p.plane ? c - p.plane : c;
+    const int ky = tap / 3, kx = tap % 3;
+    float v = 0.f;
+    if (row < p.rows_real && c < p.c_real) {
+      const int rr = p.row_off + row, cc = p.k_off + c;
+      if (p.kind == 0) v = p.w[(((long)rr * p.D1 + cc) * 3 + ky) * 3 + kx];
+      else v = p.w[(((long)cc * p.D1 + rr) * 3 + (2 - ky)) * 3 + (2 - kx)];
+    }
+    p.dst[i] = (half_t)(v * p.scale);
+  }
+}
+
+// in_ch = padded input channels the kernel walks (a multiple of 32; for a split input: 2 x the plane's padded channels)
+extern "C" int64_t csbsr_packed_weight_elems_x3n(int32_t in_ch, int32_t rows_real) {
+  const int nch = (in_ch + 31) / 32, nct = (round_up(rows_real, 8) + 63) / 64;
+  return (int64_t)nct * nch * XN_NT * (XN_WSTEP / 2);
+}
+
+extern "C" int csbsr_pack_weights_x3n(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
+                                      int32_t row_off, int32_t k_off, int32_t in_ch, int32_t plane, float scale, csbsr_stream_t s) {
+  CSBSR_CHECK(w && dst && (kind == 0 || kind == 1), "pack_x3n: bad args");
+  const int kdim = kind == 0 ? D1 : D0, rdim = kind == 0 ? D0 : D1;
+  CSBSR_CHECK(c_real >= 1 && rows_real >= 1 && k_off >= 0 && k_off + c_real <= kdim && row_off >= 0 && row_off + rows_real <= rdim,
+              "pack_x3n: range out of bounds");
+  CSBSR_CHECK(in_ch % 32 == 0 && (plane == 0 ? in_ch >= c_real : (in_ch == 2 * plane && plane >= c_real)), "pack_x3n: bad channel geometry");
+  PackXNK p;
+  p.w = w; p.dst = reinterpret_cast<half_t*>(dst); p.kind = kind; p.D1 = D1;
+  p.nch = in_ch / 32; p.nct = (round_up(rows_real, 8) + 63) / 64;
+  p.c_real = c_real; p.rows_real = rows_real; p.row_off = row_off; p.k_off = k_off; p.plane = plane; p.scale = scale;
+  const long total = csbsr_packed_weight_elems_x3n(in_ch, rows_real);
+  const long nb = (total + 255) / 256;
+  hipLaunchKernelGGL(pack_weights_x3n_kernel, dim3((int)(nb > 8192 ? 8192 : nb)), dim3(256), 0, reinterpret_cast<hipStream_t>(s), p, total);
+  CSBSR_LAUNCH_CHECK("csbsr_pack_weights_x3n");
+  return 0;
+}
+
+static int g_conv_x3n_mode = 1;      // 0 off, 1 launches that fill the chip (default), 2 every eligible launch (tests)
+extern "C" void csbsr_debug_set_conv_x3n(int mode) { g_conv_x3n_mode = mode & 7; }
+
+// Which launches take this kernel: 3x3, stride 1, pad 1, dilation 1, ONE input segment of >= 256 (mode 2: >= 32) channels in whole 32-channel
+// chunks -- plain fp16, or a split [hi | lo] pair presented as one 2 x Cp-channel segment with split_fused = 2 (the two-product plan) --,
+// 33 .. 64 padded output channels, fp16 output (hi + lo pairs allowed), any fused epilogue of the general kernels except statistics, the
+// fp32 side output, split residual operands and the fused epilogue-backward sums.
+extern "C" int32_t csbsr_conv_x3n_eligible(const csbsr_conv_desc_t* d) {
+  if (!d || !g_conv_x3n_mode || d->transposed || d->KH != 3 || d->KW != 3 || d->dil != 1) return 0;
+  if (d->stride != 1 || d->pad != 1 || d->OH != d->H || d->OW != d->W) return 0;
+  if (d->in[0].c % 32 != 0 || d->in[0].c < (g_conv_x3n_mode == 2 ? 32 : 256)) return 0;
+  if (d->in[1].c != 0 || d->in[0].sx == 0 || (d->split_fused != 0 && d->split_fused != 2)) return 0;
+  if (d->coutp <= 32 || d->coutp > 64 || !d->out16 || d->out32 || d->r_lo || d->r2_lo) return 0;
+  if (d->stat_mode != CSBSR_STAT_NONE) return 0;
+  if (d->dact_bias || d->dact_prelu || d->dres) return 0;
+  if (d->in[0].sy >= (1l << 31) / 2 / (XN_HH + 1)) return 0;
+  if (g_conv_x3n_mode == 1 && (long)d->N * d->OH * d->OW < 512L * XN_TH * XN_TW) return 0;
+  return 1;
+}
+
+template <bool FAST>
+static int launch_x3n(const ConvK& k, const XNExtra& q, unsigned g, hipStream_t st) {
+  constexpr int SM_BYTES = 2 * XN_BUF;
+  static LdsAttrOnce attr;
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_x3n_kernel<FAST>), SM_BYTES, "conv_x3n")) return e;
+  hipLaunchKernelGGL((conv_x3n_kernel<FAST>), dim3(g), dim3(256), SM_BYTES, st, k, q);
+  CSBSR_LAUNCH_CHECK("csbsr_conv_x3n_forward");
+  return 0;
+}
+
+extern "C" int csbsr_conv_x3n_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) {
+  CSBSR_CHECK(csbsr_conv_x3n_eligible(d), "conv_x3n: launch not eligible (see csbsr_conv_x3n_eligible)");
+  csbsr_conv_desc_t dd = *d;
+  dd.split_fused = 0;                  // the planes are plain channels to this kernel (and to the argument-block validation)
+  ConvK k;
+  if (int rc = conv_desc_to_k(&dd, k)) return rc;
+  XNExtra q;
+  q.tiles_x = (unsigned)((d->OW + XN_TW - 1) / XN_TW); q.tiles_y = (unsigned)((d->OH + XN_TH - 1) / XN_TH);
+  q.nct = (unsigned)((d->coutp + 63) / 64); q.nch = (unsigned)(d->in[0].c / 32);
+  const int ncu = csbsr_cu_budget(reinterpret_cast<hipStream_t>(s));
+  const unsigned items = q.tiles_x * q.tiles_y * (unsigned)d->N * q.nct;
+  const unsigned g = items < (unsigned)ncu ? items : (unsigned)ncu;
+  const bool fast_rows = conv_epilogue_fast_ok(k);
+  g_last_conv_kernel = CONVK_X3N | (fast_rows ? 1 : 0) << 8;
+  return fast_rows ? launch_x3n<true>(k, q, g, reinterpret_cast<hipStream_t>(s)) : launch_x3n<false>(k, q, g, reinterpret_cast<hipStream_t>(s));
+}

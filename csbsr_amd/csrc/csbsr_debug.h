@@ -38,6 +38,8 @@ void csbsr_debug_set_conv_x3(int mode);
  * launch; bits 3..: smallest padded input-channel count taken in mode 1, in units of 32 (0 = keep the default 128);
  * bits 8..: ablation variant (CSBSR_X3W_ABLATE builds only) */
 void csbsr_debug_set_conv_x3w(int mode);
+/* narrow-output 3x3 kernel (csrc/conv_x3n.hip): 0 never eligible, 1 launches of >= 512 pixel tiles with >= 256 input channels (default), 2 every eligible launch */
+void csbsr_debug_set_conv_x3n(int mode);
 /* full-resolution thin 3x3 weight-gradient kernel (csrc/conv_wgrad_hr.hip): 0 never, 1 launches of >= 1024 tiles (default), 2 every eligible launch */
 void csbsr_debug_set_wgrad_hr(int mode);
 /* CU-partitioned streams (csrc/streams.hip) -- a MEASUREMENT hook, not product: round 5 measured a weight gradient and an HBM-bound link of

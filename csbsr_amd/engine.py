@@ -119,6 +119,7 @@ class Engine:
         # Winograd F(2,3)-along-x kernel for the wide 3x3 layers (csrc/conv_x3w.hip): built, parity-tested and measured AT PARITY with the
         # direct kernels in round 6 (bound by the CU's vector-memory path, see the kernel's header) -- opt-in: CSBSR_CONV_X3W=1
         self.use_x3w = os.environ.get("CSBSR_CONV_X3W", "0") != "0"
+        self.use_x3n = os.environ.get("CSBSR_CONV_X3N", "1") != "0"     # A/B hook: 0 keeps the many-channels -> <= 64-cout 3x3 layers on the LDS-DMA tiles (csrc/conv_x3n.hip)
         self.use_x3 = os.environ.get("CSBSR_CONV_X3", "1") != "0"       # A/B hook: 0 routes the wide 3x3 layers through the implicit-GEMM kernels
         self.use_tp = os.environ.get("CSBSR_CONV_TP", "1") != "0"       # A/B hook: 0 routes the 2x2-tap transposed layers through the implicit-GEMM kernels
         self.split_fused = os.environ.get("CSBSR_SPLIT_FUSED", "1") != "0"   # A/B hook: 0 = the three-block split forward (x_hi staged twice)
@@ -453,7 +454,7 @@ class Conv:
 
     def _launch(self, xs, wt, transposed, k, stride, pad, dil, H, W, OH, OW, cout, out, out32, bias, act, slope, prelu, res, res2,
                 res_mode, accumulate, stat, stat_mode, out_scale, cbias=None, mask=None, hr=None, tp=None, dact=None, x3=None, dres=None,
-                cb_mode=0, split_blocks=3):
+                cb_mode=0, split_blocks=3, x3n=None):
         d = L.ConvDesc()
         x0 = xs[0]
         if x0.lo:                       # split-fp16 input: [hi | lo] (+ hi again for the x_hi w_lo block), weights from _pack_split
@@ -547,6 +548,22 @@ class Conv:
                 self._packed[key] = dst
             d.wt = _ptr(self._packed[key])
             L.call("csbsr_conv_hr_forward", C.byref(d), self.eng.stream)
+        elif (x3n is not None and self.eng.use_x3n and (not x0.lo or split_blocks == 5) and L.load().csbsr_conv_x3n_eligible(C.byref(d))):
+            # many input channels -> <= 64 output channels at full resolution (PSPNet_BlurSkip's conv1's, the dgrads of its conv0's): resident
+            # pixel tile + streamed fragment-ordered weights (csrc/conv_x3n.hip); a split input runs its two-product plan as 2 x Cp plain
+            # channels against [w | w] (the tap-sum-rounded, pre-scaled weights repeated for the lo plane)
+            kind, c_real, rows_real, row_off, k_off = x3n
+            plane = x0.cp if x0.lo else 0
+            in_ch = 2 * x0.cp if x0.lo else x0.cp
+            key = ("x3n", kind, row_off, k_off, c_real, plane)
+            if key not in self._packed:
+                n = L.load().csbsr_packed_weight_elems_x3n(in_ch, rows_real)
+                dst = torch.empty(n, dtype=torch.float16, device=self.eng.device)
+                L.call("csbsr_pack_weights_x3n", _ptr(self._wq()), _ptr(dst), kind, self.w.shape[0], self.w.shape[1], c_real, rows_real, row_off,
+                       k_off, in_ch, plane, self.WSCALE if x0.lo else 1.0, self.eng.stream)
+                self._packed[key] = dst
+            d.wt = _ptr(self._packed[key])
+            L.call("csbsr_conv_x3n_forward", C.byref(d), self.eng.stream)
         elif x3 is not None and x3[0] in (0, 1) and self.eng.use_x3w and L.load().csbsr_conv_x3w_eligible(C.byref(d)):
             # wide low-resolution 3x3 stride-1 layers (SFT convs and their dgrads) as Winograd F(2, 3) along x: 2/3 of the direct kernel's
             # MFMA work, transformed fp16 weights packed once per optimiser step (csrc/conv_x3w.hip)
@@ -638,7 +655,8 @@ class Conv:
                      tp=(self.cin, self.cout, 0, 0) if (self.transposed and len(xs) == 1 and not sp) else None,
                      x3=((0 if self.k == 3 else 2, self.cin, self.cout, 0, 0)
                          if (not sp and not self.transposed and len(xs) == 1 and (self.k == 3 or self.k == 2 * self.stride)) else None),
-                     split_blocks=nb)
+                     split_blocks=nb,
+                     x3n=(0, self.cin, self.cout, 0, 0) if (not self.transposed and len(xs) == 1 and self.k == 3 and self.stride == 1 and stat is None) else None)
         return out
 
     def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None, mask=None, dact=None, dres=None):
@@ -684,7 +702,8 @@ class Conv:
                      1.0 / self.WSCALE if hp else 1.0, mask=mask, hr=hr,
                      tp=(self.cout, c_seg, row_off, 0) if (tr and not hp and stat is None) else None, dact=dact, dres=dres,
                      x3=((2, self.cout, c_seg, row_off, 0) if (self.transposed and not hp and stat is None and k == 2 * s) else
-                         (1, self.cout, c_seg, row_off, 0) if (not hp and not self.transposed and s == 1 and k == 3 and stat is None) else None))
+                         (1, self.cout, c_seg, row_off, 0) if (not hp and not self.transposed and s == 1 and k == 3 and stat is None) else None),
+                     x3n=(1, self.cout, c_seg, row_off, 0) if (not hp and not self.transposed and s == 1 and k == 3 and stat is None and dact is None) else None)
         return out
 
     # -- exact folding of a spatially constant second input segment (SFT conv0: cat(features, kernel code), kbpn.py:513)

@@ -28,6 +28,8 @@ def conv_row(kid):
         return "conv_x3_kernel<3,2048>"
     if base == 19:
         return f"conv_x3w_kernel<{var}>"
+    if base == 20:
+        return f"conv_x3n_kernel<{var}>"
     return _CONV.get(base, f"conv?{base}")
 
 
@@ -68,6 +70,9 @@ def canon(name):
     m = re.search(r"conv_tp_kernelILi\d+ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name) or re.search(r"conv_tp_kernel<\d+, (\w+), (\w+), (\w+), (\w+)>", name)
     if m:
         return "conv_tp_kernel<res=%s,acc=%s,mask=%s,sums=%s>" % tuple(_b(x) for x in m.groups())
+    m = re.search(r"conv_x3n_kernelILb(\d)E", name) or re.search(r"conv_x3n_kernel<(\w+)>", name)
+    if m:
+        return "conv_x3n_kernel<%s>" % _b(m.group(1))
     m = re.search(r"conv_x3w_kernelILi(\d)E", name) or re.search(r"conv_x3w_kernel<(\d)>", name)
     if m:
         return "conv_x3w_kernel<%s>" % m.group(1)

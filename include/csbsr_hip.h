@@ -168,6 +168,22 @@ int64_t csbsr_packed_weight_elems_x3_strided(int32_t stride, int32_t c_real, int
 int csbsr_pack_weights_x3_strided(const float* w, void* dst, int32_t D0, int32_t D1, int32_t ksize, int32_t stride, int32_t c_real,
                                   int32_t rows_real, int32_t row_off, int32_t k_off, csbsr_stream_t s);
 
+/* 3x3 stride-1 convolution from many input channels into <= 64 output channels at full resolution: the second convolutions of
+ * PSPNet_BlurSkip's SFT-like blocks, F.conv2d(505 -> 64) at 1792^2 (/root/reference/model/modeling/blocks.py:105-120, pspnet.py:176-190), and
+ * the dgrads of their 64 -> 505 first convolutions: 8-row x 64-pixel x 64-cout tile, per-32-channel halo tile in LDS shared by the nine
+ * taps, fragment-ordered weights from L2 -- see csrc/conv_x3n.hip.  Same descriptor and fused epilogue as csbsr_conv_forward except d->wt;
+ * a split [hi | lo] input is presented as ONE 2 x Cp-channel segment with split_fused = 2 (the two-product plan [x_hi | x_lo] w_hi; the
+ * pack repeats the weights for the lo plane), the output may be a hi + lo pair.  csbsr_conv_x3n_eligible: one input segment of >= 256
+ * channels in whole 32-channel chunks, 33 .. 64 padded output channels, no statistics / fp32 output / split residuals. */
+int32_t csbsr_conv_x3n_eligible(const csbsr_conv_desc_t* d);
+int csbsr_conv_x3n_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
+/* kind 0 forward (w = OIHW), 1 dgrad of the stride-1 conv; in_ch = padded input channels the kernel walks (2 x plane for a split input),
+ * plane = padded channels of one plane of a split input (0: plain input), scale = factor folded into the fp16 weights (the split path's
+ * 256, undone by csbsr_conv_desc_t::out_scale) */
+int64_t csbsr_packed_weight_elems_x3n(int32_t in_ch, int32_t rows_real);
+int csbsr_pack_weights_x3n(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
+                           int32_t row_off, int32_t k_off, int32_t in_ch, int32_t plane, float scale, csbsr_stream_t s);
+
 /* Winograd F(2, 3) along x for the same wide 3x3 stride-1 layers (the SFT convolutions F.conv2d(cat(fea, k), w, b, 1, 1) of
  * /root/reference/model/modeling/kbpn.py:505-520 and their dgrads): two neighbouring output pixels from four products per (channel, row tap)
  * instead of six -- 2/3 of the MFMA work of csbsr_conv_x3_forward; input transform on the fly (registers -> LDS), weights transformed by the

@@ -71,6 +71,7 @@ if __name__ == "__main__":
         "up2_256_64": (1, 896, 896, 256, 64, 3, 1, 1),
         "l1_64": (1, 448, 448, 64, 64, 3, 1, 1),
         "bs_scale1": (1, 1792, 1792, 505, 64, 3, 1, 1),        # PSPNet_BlurSkip conv_scale.1 (config 5)
+        "bs_conv0": (1, 1792, 1792, 64, 505, 3, 1, 1),         # PSPNet_BlurSkip conv_scale.0 (config 5), folded: 64 feature channels -> 505
         "lz16": (1, 1792, 1792, 16, 128, 3, 1, 1),             # gathered thin dgrads into one stage's slice of the concatenated gradient
         "lz24": (1, 1792, 1792, 24, 128, 3, 1, 1),
         "lz32": (1, 1792, 1792, 32, 128, 3, 1, 1),

