@@ -46,8 +46,11 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t xn_make_rs(const half_t
 }
 #endif
 
-// FAST: straight-line epilogue rows (conv_epilogue_fast_ok), else the general fused row
-template <bool FAST>
+// FAST: straight-line epilogue rows (conv_epilogue_fast_ok), else the general fused row.  BNS (with FAST, one cout tile): fused BatchNorm
+// statistics -- every lane keeps the sum and the sum of squares of its 32 output channels over all its tiles in registers, the lanes of a
+// wave fold by xor-shuffles, the four waves through LDS in wave order, and the workgroup writes ONE partial row; the launcher folds the rows
+// in a fixed tree (csbsr_sum_partials): order-fixed like every reduction of the library.
+template <bool FAST, bool BNS = false>
 __global__ __launch_bounds__(256) void conv_x3n_kernel(const ConvK p, const XNExtra q) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -111,6 +114,12 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const ConvK p, const XNEx
       for (int kk = 0; kk < 2; ++kk) w[mt][kk] = *reinterpret_cast<const h8*>(b + (wlane + (mt * 2 + kk) * 1024));
   };
   const char* xl = smem + ((4 * rq) * XN_HW + 32 * chf + pix) * XN_PITCH + hi * 16;      // the wave's first row / column of the halo tile
+
+  float bsum[4][8], bsq[4][8];          // BNS: [mt * 2 + pair][e] = channel 32 mt + 16 pair + 8 hi + e
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[a][e] = bsq[a][e] = 0.f;
 
   int ct, n, Y0, X0;
   decode(it, ct, n, Y0, X0);
@@ -207,7 +216,10 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const ConvK p, const XNEx
 #pragma unroll
             for (int e = 0; e < 8; ++e) brow[e] = bias[e];
           }
-          if (fe.has_res || fe.has_old || fe.has_mask) conv_epilogue_fast_row<true, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
+          if constexpr (BNS) {
+            if (fe.has_res || fe.has_old || fe.has_mask) conv_epilogue_fast_row<true, true>(fe, v, brow, co, o, rr, oo, bsum[mp], bsq[mp], mm);
+            else conv_epilogue_fast_row<false, true>(fe, v, brow, co, o, rr, oo, bsum[mp], bsq[mp], mm);
+          } else if (fe.has_res || fe.has_old || fe.has_mask) conv_epilogue_fast_row<true, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
           else conv_epilogue_fast_row<false, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
         } else {
           conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, s0, s1);
@@ -215,6 +227,29 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const ConvK p, const XNEx
       }
     }
     ct = ctn; n = nn; Y0 = Y0n; X0 = X0n;
+  }
+  if constexpr (BNS) {
+    // lanes of a half-wave hold different pixels of the same channels: fold over the 32 pixel lanes, then the waves in wave order
+    float* sS = reinterpret_cast<float*>(smem);          // [wave 4][128]: sums of channels 0..63, then sums of squares
+    __syncthreads();                                     // (everybody is done with the halo buffers)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float u = bsum[a][e], w_ = bsq[a][e];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { u += __shfl_xor(u, o, 64); w_ += __shfl_xor(w_, o, 64); }
+        if (pix == 0) {
+          const int ch = 32 * (a >> 1) + 16 * (a & 1) + 8 * hi + e;
+          sS[wid * 128 + ch] = u; sS[wid * 128 + 64 + ch] = w_;
+        }
+      }
+    __syncthreads();
+    if (tid < 128) {
+      const float t = ((sS[tid] + sS[128 + tid]) + sS[256 + tid]) + sS[384 + tid];
+      const int ch = tid & 63;
+      if (ch < p.coutp) p.stat_part[(size_t)blockIdx.x * p.stat_ld + (tid < 64 ? ch : p.coutp + ch)] = t;
+    }
   }
 #endif
 }
@@ -274,29 +309,29 @@ extern "C" int csbsr_pack_weights_x3n(const float* w, void* dst, int32_t kind, i
 static int g_conv_x3n_mode = 1;      // 0 off, 1 launches that fill the chip (default), 2 every eligible launch (tests)
 extern "C" void csbsr_debug_set_conv_x3n(int mode) { g_conv_x3n_mode = mode & 7; }
 
-// Which launches take this kernel: 3x3, stride 1, pad 1, dilation 1, ONE input segment of >= 256 (mode 2: >= 32) channels in whole 32-channel
+// Which launches take this kernel: 3x3, stride 1, pad 1, dilation 1, ONE input segment of >= 64 (mode 2: >= 32) channels in whole 32-channel
 // chunks -- plain fp16, or a split [hi | lo] pair presented as one 2 x Cp-channel segment with split_fused = 2 (the two-product plan) --,
 // 33 .. 64 padded output channels, fp16 output (hi + lo pairs allowed), any fused epilogue of the general kernels except statistics, the
 // fp32 side output, split residual operands and the fused epilogue-backward sums.
 extern "C" int32_t csbsr_conv_x3n_eligible(const csbsr_conv_desc_t* d) {
   if (!d || !g_conv_x3n_mode || d->transposed || d->KH != 3 || d->KW != 3 || d->dil != 1) return 0;
   if (d->stride != 1 || d->pad != 1 || d->OH != d->H || d->OW != d->W) return 0;
-  if (d->in[0].c % 32 != 0 || d->in[0].c < (g_conv_x3n_mode == 2 ? 32 : 256)) return 0;
+  if (d->in[0].c % 32 != 0 || d->in[0].c < (g_conv_x3n_mode == 2 ? 32 : 64)) return 0;
   if (d->in[1].c != 0 || d->in[0].sx == 0 || (d->split_fused != 0 && d->split_fused != 2)) return 0;
   if (d->coutp <= 32 || d->coutp > 64 || !d->out16 || d->out32 || d->r_lo || d->r2_lo) return 0;
-  if (d->stat_mode != CSBSR_STAT_NONE) return 0;
+  if (d->stat_mode != CSBSR_STAT_NONE && d->stat_mode != CSBSR_STAT_BN) return 0;      // (BatchNorm sums: the straight-line rows only, see the launcher)
   if (d->dact_bias || d->dact_prelu || d->dres) return 0;
   if (d->in[0].sy >= (1l << 31) / 2 / (XN_HH + 1)) return 0;
   if (g_conv_x3n_mode == 1 && (long)d->N * d->OH * d->OW < 512L * XN_TH * XN_TW) return 0;
   return 1;
 }
 
-template <bool FAST>
+template <bool FAST, bool BNS = false>
 static int launch_x3n(const ConvK& k, const XNExtra& q, unsigned g, hipStream_t st) {
   constexpr int SM_BYTES = 2 * XN_BUF;
   static LdsAttrOnce attr;
-  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_x3n_kernel<FAST>), SM_BYTES, "conv_x3n")) return e;
-  hipLaunchKernelGGL((conv_x3n_kernel<FAST>), dim3(g), dim3(256), SM_BYTES, st, k, q);
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_x3n_kernel<FAST, BNS>), SM_BYTES, "conv_x3n")) return e;
+  hipLaunchKernelGGL((conv_x3n_kernel<FAST, BNS>), dim3(g), dim3(256), SM_BYTES, st, k, q);
   CSBSR_LAUNCH_CHECK("csbsr_conv_x3n_forward");
   return 0;
 }
@@ -314,6 +349,16 @@ extern "C" int csbsr_conv_x3n_forward(const csbsr_conv_desc_t* d, csbsr_stream_t
   const unsigned items = q.tiles_x * q.tiles_y * (unsigned)d->N * q.nct;
   const unsigned g = items < (unsigned)ncu ? items : (unsigned)ncu;
   const bool fast_rows = conv_epilogue_fast_ok(k);
+  hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  if (k.stat_mode == CSBSR_STAT_BN) {
+    CSBSR_CHECK(fast_rows && q.nct == 1 && k.stat, "conv_x3n: fused BatchNorm sums need the straight-line epilogue rows and one cout tile");
+    k.stat_ld = 2 * (long)k.coutp;
+    k.stat_part = csbsr_red_scratch((long)g * k.stat_ld);
+    CSBSR_NEED_SCRATCH(k.stat_part, "conv_x3n (fused statistics)");
+    g_last_conv_kernel = CONVK_X3N | 3 << 8;
+    if (int rc = launch_x3n<true, true>(k, q, g, st)) return rc;
+    return csbsr_sum_partials(k.stat_part, (int)g, k.stat_ld, 2 * k.coutp, k.stat, st);
+  }
   g_last_conv_kernel = CONVK_X3N | (fast_rows ? 1 : 0) << 8;
-  return fast_rows ? launch_x3n<true>(k, q, g, reinterpret_cast<hipStream_t>(s)) : launch_x3n<false>(k, q, g, reinterpret_cast<hipStream_t>(s));
+  return fast_rows ? launch_x3n<true>(k, q, g, st) : launch_x3n<false>(k, q, g, st);
 }

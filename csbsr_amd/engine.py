@@ -656,7 +656,8 @@ class Conv:
                      x3=((0 if self.k == 3 else 2, self.cin, self.cout, 0, 0)
                          if (not sp and not self.transposed and len(xs) == 1 and (self.k == 3 or self.k == 2 * self.stride)) else None),
                      split_blocks=nb,
-                     x3n=(0, self.cin, self.cout, 0, 0) if (not self.transposed and len(xs) == 1 and self.k == 3 and self.stride == 1 and stat is None) else None)
+                     x3n=(0, self.cin, self.cout, 0, 0) if (not self.transposed and len(xs) == 1 and self.k == 3 and self.stride == 1
+                                                           and (stat is None or stat_mode == L.STAT_BN)) else None)
         return out
 
     def bwd_input(self, dpre, seg=0, out=None, accumulate=False, out32=None, stat=None, in_hw=None, mask=None, dact=None, dres=None):

@@ -29,7 +29,7 @@ def conv_row(kid):
     if base == 19:
         return f"conv_x3w_kernel<{var}>"
     if base == 20:
-        return f"conv_x3n_kernel<{var}>"
+        return "conv_x3n_kernel<%d,%d>" % (var & 1, var >> 1)
     return _CONV.get(base, f"conv?{base}")
 
 
@@ -70,9 +70,9 @@ def canon(name):
     m = re.search(r"conv_tp_kernelILi\d+ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name) or re.search(r"conv_tp_kernel<\d+, (\w+), (\w+), (\w+), (\w+)>", name)
     if m:
         return "conv_tp_kernel<res=%s,acc=%s,mask=%s,sums=%s>" % tuple(_b(x) for x in m.groups())
-    m = re.search(r"conv_x3n_kernelILb(\d)E", name) or re.search(r"conv_x3n_kernel<(\w+)>", name)
+    m = re.search(r"conv_x3n_kernelILb(\d)ELb(\d)E", name) or re.search(r"conv_x3n_kernel<(\w+), (\w+)>", name)
     if m:
-        return "conv_x3n_kernel<%s>" % _b(m.group(1))
+        return "conv_x3n_kernel<%s,%s>" % (_b(m.group(1)), _b(m.group(2)))
     m = re.search(r"conv_x3w_kernelILi(\d)E", name) or re.search(r"conv_x3w_kernel<(\d)>", name)
     if m:
         return "conv_x3w_kernel<%s>" % m.group(1)

@@ -1223,6 +1223,42 @@ def test_narrow_output_3x3_kernel_split_input(cin, cout, H, W):
     assert e_ref < 2e-3               # the two-product plan keeps the weights' fp16 rounding (minus its mean response)
 
 
+@pytest.mark.parametrize("split", [0, 1])
+def test_narrow_output_3x3_kernel_fused_batchnorm_sums(split):
+    """conv_x3n with the fused BatchNorm statistics (per-lane register sums over a workgroup's tiles, xor-shuffle + wave-ordered LDS fold,
+    one partial row per workgroup, fixed-order fold by csbsr_sum_partials): sum and sum of squares per channel against fp64 on the kernel's own
+    output, bit-identical twice, for a plain input and for the two-product plan of a split input (the PSPNet decoder's up_2 / up_3 shape)."""
+    from csbsr_amd.engine import Conv, pad8
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    lib = L.load()
+    N, cin, cout, H, W = 2, 128, 64, 21, 100
+    g = torch.Generator().manual_seed(31 + split)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    xs = to_fm_split(eng, x) if split else to_fm(eng, x)
+    stats = []
+    lib.csbsr_debug_set_conv_x3n(2)
+    try:
+        for rep in range(2):
+            conv = Conv(eng, "l", {"l.weight": w.cuda()}, 3, 1, 1, 1, bias=False)
+            if split:
+                conv.fwd_blocks, conv.dc_comp = 2, True
+            stat = eng.f32(2, pad8(cout))
+            out = conv.fwd(xs, stat=stat, stat_mode=L.STAT_BN)
+            torch.cuda.synchronize()
+            assert (lib.csbsr_debug_last_conv_kernel() & 255) == 20
+            stats.append(stat.clone())
+    finally:
+        lib.csbsr_debug_set_conv_x3n(1)
+    got = (from_fm_split(out) if split else from_fm(out)).double()
+    s_ref = torch.stack([got.sum((0, 2, 3)), (got * got).sum((0, 2, 3))])
+    e_stat = float((stats[0][:, :cout].double().cpu() - s_ref).abs().max() / s_ref.abs().max())
+    print(f"   conv_x3n fused BN sums (split={split}): {e_stat:.2e}")
+    assert e_stat < (1e-5 if split else 1e-3)       # (plain mode: the sums are of the fp32 values, the output is their fp16 rounding)
+    assert torch.equal(stats[0], stats[1])
+
+
 def test_fused_split_launch_falls_back_when_the_lds_dma_kernels_are_off():
     """engine.Conv._launch asks csbsr_conv_split_fused_eligible before it hands over the fused [w_hi | w_lo] operand: with the LDS-DMA
     kernels switched off (csbsr_debug_set_conv_glds(0), the debug mode the tests use to reach the register-staged kernels) the launch
