@@ -202,7 +202,7 @@ def load():
     if os.environ.get("CSBSR_CONV_X3"):            # A/B hook: 0 off, 1 default, 2 every eligible launch
         lib.csbsr_debug_set_conv_x3(int(os.environ["CSBSR_CONV_X3"]))
     if os.environ.get("CSBSR_CONV_X3W"):           # A/B hook: 0 off, 1 default, 2 every eligible launch (+ 8 x min input channels / 32)
-        lib.csbsr_debug_set_conv_x3w(int(os.environ["CSBSR_CONV_X3W"]))
+        lib.csbsr_debug_set_conv_x3w(1 if os.environ["CSBSR_CONV_X3W"] == "all" else int(os.environ["CSBSR_CONV_X3W"]))
     if os.environ.get("CSBSR_CONV_X3N"):           # A/B hook: 0 off, 1 default, 2 every eligible launch
         lib.csbsr_debug_set_conv_x3n(int(os.environ["CSBSR_CONV_X3N"]))
     if os.environ.get("CSBSR_WGRAD_HR"):           # A/B hook: 0 off, 1 default, 2 every eligible launch

@@ -16,8 +16,8 @@
 //
 // MEASURED (round 6, N = 8, 448^2, scripts/bench_conv.py; profiles/r06_winograd_kernel.txt) AND NOT THE DEFAULT: 825 -> 384 6.85 ms against
 // 7.49 ms for conv_x3<3>, 384 -> 825 8.47 / 8.73, 256 -> 697 5.47 / 5.70, 569 -> 128 1.87 / 2.05, dgrads alike: 3-9 % faster, not the 1.5x of
-// the MFMA count -- about 5 ms of a 1025 ms config-2 step, under the box-to-box noise, for a changed rounding in 24 launches: opt-in
-// (csbsr_debug_set_conv_x3w(1), CSBSR_CONV_X3W=1), with its tests.  The ablation builds (CSBSR_X3W_ABLATE) say where the time goes:
+// the MFMA count -- 9 ms of a 1007 ms config-2 step on the SFT convs (7.94 -> 8.02 img/s), for a composed segmentation map that moves from
+// 1.11e-3 to 1.25e-3 of the reference's: opt-in (csbsr_debug_set_conv_x3w(1), CSBSR_CONV_X3W=1), with its tests.  The ablation builds (CSBSR_X3W_ABLATE) say where the time goes:
 // MFMAs + LDS fragment reads alone 4.41 ms (2070 TF/s of direct-equivalent work), + the weight stream 4.80, + the halo stream 6.12, both
 // 6.85.  F(2, 3) needs a fresh weight fragment per two MFMAs per position where the direct kernel reuses one over eight pixel blocks, and
 // a transformed pixel fragment per MFMA pair: twice the operand traffic per MFMA.  The first build split the waves by ROWS, so every weight

@@ -116,9 +116,10 @@ class Engine:
         self._red = _reduction_scratch(self.device) if torch.cuda.is_available() else None
         self.training = True
         self.use_hr = os.environ.get("CSBSR_CONV_HR", "1") != "0"       # A/B hook: 0 routes the HR small-channel layers through the implicit-GEMM kernels
-        # Winograd F(2,3)-along-x kernel for the wide 3x3 layers (csrc/conv_x3w.hip): built, parity-tested and measured AT PARITY with the
-        # direct kernels in round 6 (bound by the CU's vector-memory path, see the kernel's header) -- opt-in: CSBSR_CONV_X3W=1
-        self.use_x3w = os.environ.get("CSBSR_CONV_X3W", "0") != "0"
+        # Winograd F(2,3)-along-x kernel for the wide 3x3 layers (csrc/conv_x3w.hip): built, parity-tested, 3-9 % faster per launch than the
+        # direct kernels (−9 ms per config-2 step on the SFT convs) for a composed map 13 % further from the reference --
+        # opt-in: CSBSR_CONV_X3W=1
+        self.use_x3w = {"0": 0, "all": 2}.get(os.environ.get("CSBSR_CONV_X3W", "0"), 1)      # 0 off, 1 the SFT convs (Conv.winograd), "all": every eligible 3x3 layer
         self.use_x3n = os.environ.get("CSBSR_CONV_X3N", "1") != "0"     # A/B hook: 0 keeps the many-channels -> <= 64-cout 3x3 layers on the LDS-DMA tiles (csrc/conv_x3n.hip)
         self.use_x3 = os.environ.get("CSBSR_CONV_X3", "1") != "0"       # A/B hook: 0 routes the wide 3x3 layers through the implicit-GEMM kernels
         self.use_tp = os.environ.get("CSBSR_CONV_TP", "1") != "0"       # A/B hook: 0 routes the 2x2-tap transposed layers through the implicit-GEMM kernels
@@ -327,6 +328,7 @@ class Conv:
         self.fwd_blocks = 3
         # KBPN (plain fp16 operands): first-order compensation of the forward weights' fp16 rounding, see _dc_bias
         self.dc_comp = False
+        self.winograd = False        # True: the layer may run as Winograd F(2,3) along x (KBPN's SFT convs: the set tests/study_winograd.py validates)
 
     # -- packed operand cache (invalidated by the model at every optimiser step)
     def invalidate(self):
@@ -564,7 +566,8 @@ class Conv:
                 self._packed[key] = dst
             d.wt = _ptr(self._packed[key])
             L.call("csbsr_conv_x3n_forward", C.byref(d), self.eng.stream)
-        elif x3 is not None and x3[0] in (0, 1) and self.eng.use_x3w and L.load().csbsr_conv_x3w_eligible(C.byref(d)):
+        elif (x3 is not None and x3[0] in (0, 1) and self.eng.use_x3w and (self.winograd or self.eng.use_x3w == 2)
+              and L.load().csbsr_conv_x3w_eligible(C.byref(d))):
             # wide low-resolution 3x3 stride-1 layers (SFT convs and their dgrads) as Winograd F(2, 3) along x: 2/3 of the direct kernel's
             # MFMA work, transformed fp16 weights packed once per optimiser step (csrc/conv_x3w.hip)
             kind, c_real, rows_real, row_off, k_off = x3

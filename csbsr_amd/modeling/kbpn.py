@@ -130,6 +130,8 @@ class KBPN:
                 o.sc1 = mk(sf + ".SFT_scale_conv1", 3, 1, 1, act=A_SIG)
                 o.sh0 = mk(sf + ".SFT_shift_conv0", 3, 1, 1, act=A_LRELU, slope=0.1, split=(md * st, self.kk))
                 o.sh1 = mk(sf + ".SFT_shift_conv1", 3, 1, 1, act=A_NONE)
+                for c_ in (o.sc0, o.sc1, o.sh0, o.sh1):
+                    c_.winograd = True          # the layers the Winograd study covers (tests/study_winograd.py): engine.Conv._launch, csrc/conv_x3w.hip
             self.stages.append(o)
         self.output_conv = block(f"{prefix}.output_conv", 3, 1, 1, A_NONE)
         # compensation of the forward weights' fp16 rounding (Conv._dc_bias) on the (non-transposed) layers whose kernels take a

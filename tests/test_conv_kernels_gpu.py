@@ -778,7 +778,7 @@ def test_wide_3x3_winograd_kernel(cin, cout, H, W, mode):
     from csbsr_amd.engine import Conv, pad8
     torch.manual_seed(cin + cout + H)
     eng = _eng()
-    eng.use_x3w = True          # opt-in kernel (measured at parity with the direct ones, csrc/conv_x3w.hip)
+    eng.use_x3w = 2             # opt-in kernel; 2 = any eligible layer (1 = the layers marked Conv.winograd: KBPN's SFT convs)
     lib = L.load()
     N = 2
     x = torch.randn(N, cin, H, W).half().float()
@@ -828,7 +828,7 @@ def test_wide_3x3_winograd_kernel_with_folded_constant_segment():
     from csbsr_amd.engine import Conv
     torch.manual_seed(11)
     eng = _eng()
-    eng.use_x3w = True          # opt-in kernel (measured at parity with the direct ones, csrc/conv_x3w.hip)
+    eng.use_x3w = 2             # opt-in kernel; 2 = any eligible layer (1 = the layers marked Conv.winograd: KBPN's SFT convs)
     lib = L.load()
     N, cf, cc, cout, H, W = 2, 384, 21, 100, 12, 40
     x = torch.randn(N, cf, H, W).half().float()
