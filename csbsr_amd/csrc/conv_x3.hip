@@ -424,7 +424,10 @@ extern "C" int32_t csbsr_conv_x3_eligible(const csbsr_conv_desc_t* d) {
     if (d->in[0].c < 64 || d->in[0].c > 512 || d->in[0].c % 64 != 0) return 0;
   } else {
     if (d->KH != 3 || d->stride != 1 || d->pad != 1 || d->OH != d->H || d->OW != d->W) return 0;
-    if (d->in[0].c < (g_conv_x3_mode == 2 ? 128 : 384) || d->in[0].c % 64 != 0) return 0;
+    // (>= 384 input channels, or >= 128 on launches of >= 1.5 M pixels: round 6, N = 8 at 448^2: 128 -> 569 2.89 ms against 3.20 on the
+    // LDS-ring kernel, 256 -> 697 5.35 / 5.60; at N = 4 the round-2 measurement stands: 256 -> 697 641 against 817 TF/s)
+    const int min_c = g_conv_x3_mode == 2 ? 128 : ((long)d->N * d->OH * d->OW >= 1500000L ? 128 : 384);
+    if (d->in[0].c < min_c || d->in[0].c % 64 != 0) return 0;
   }
   if (d->in[1].c != 0 || d->in[0].sx == 0) return 0;
   if (d->coutp < 72 || !d->out16 || d->out32 || d->o_lo || d->r_lo || d->r2_lo) return 0;
