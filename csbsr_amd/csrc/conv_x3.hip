@@ -407,7 +407,7 @@ static int g_conv_x3_ct_major = 0;  // bit 3 of the debug mode: the old cout-til
 extern "C" void csbsr_debug_set_conv_x3(int mode) { g_conv_x3_mode = mode & 7; g_conv_x3_ct_major = (mode >> 3) & 1; g_conv_x3_abl = mode >> 4; }
 
 // Which launches take this kernel.  3x3, stride 1, pad 1, dilation 1: ONE plain-fp16 input segment whose padded channels are a multiple of
-// 64, >= 384 by default (measured at N = 4, 448^2, with the halo DMA issued inside the K loop: 825 -> 384 1041 TF/s against 899 for the
+// 64, >= 128 (measured at N = 4, 448^2, with the halo DMA issued inside the K loop: 825 -> 384 1041 TF/s against 899 for the
 // LDS-ring implicit GEMM, its dgrad-shaped twin 1069, 384 -> 825 809 against 800, but 256 -> 697 641 against 817: with few chunks the
 // per-tile epilogue and pipeline restart outweigh the K loop's gain; >= 128 when forced by csbsr_debug_set_conv_x3(2)).  k = 2 x stride
 // (8x8 stride 4): see below.  Both: >= 72 padded output channels, fp16 output; any fused epilogue of the general kernels except
@@ -424,9 +424,9 @@ extern "C" int32_t csbsr_conv_x3_eligible(const csbsr_conv_desc_t* d) {
     if (d->in[0].c < 64 || d->in[0].c > 512 || d->in[0].c % 64 != 0) return 0;
   } else {
     if (d->KH != 3 || d->stride != 1 || d->pad != 1 || d->OH != d->H || d->OW != d->W) return 0;
-    // (>= 384 input channels, or >= 128 on launches of >= 1.5 M pixels: round 6, N = 8 at 448^2: 128 -> 569 2.89 ms against 3.20 on the
-    // LDS-ring kernel, 256 -> 697 5.35 / 5.60; at N = 4 the round-2 measurement stands: 256 -> 697 641 against 817 TF/s)
-    const int min_c = g_conv_x3_mode == 2 ? 128 : ((long)d->N * d->OH * d->OW >= 1500000L ? 128 : 384);
+    // (>= 128 input channels since round 6 -- 128 -> 569 at 448^2: 2.89 ms against 3.20 on the LDS-ring kernel at N = 8, 1.53 / 1.69 at N = 4;
+    // 256 -> 697: 5.35 / 5.60 and 2.84 / 2.88 -- ; the >= 384 of rounds 2-5 was measured on round 2's kernel: 256 -> 697 641 against 817 TF/s)
+    const int min_c = 128;
     if (d->in[0].c < min_c || d->in[0].c % 64 != 0) return 0;
   }
   if (d->in[1].c != 0 || d->in[0].sx == 0) return 0;
