@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--cpu-baseline-lr", type=int, default=64, help="LR size of the bounded CPU sample (64: three timed B=2 steps fit ~25 s; 112 = BASELINE.md section 2's size, ~24 s per step)")
     ap.add_argument("--cpu-baseline-threads", type=int, default=0, help="intra-op threads of the CPU sample (0 = min(host threads, 16), see cpu_baseline)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of csbsr_amd.optim.Adam (A/B timing)")
     ap.add_argument("--watchdog-s", type=int, default=int(os.environ.get("CSBSR_BENCH_WATCHDOG", "0")),
                     help="dump every thread's Python stack to stderr and exit if the run is still going after this many seconds (0 = off): a hung "
                          "collective in a multi-rank run then says where each rank stands instead of timing out silently")
@@ -190,7 +191,11 @@ def main():
     if dist_on:
         n_bcast = broadcast_parameters(model)
         model.reducer = GradBucketReducer(side_stream=torch.cuda.Stream(dev))
-    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.SOLVER.LR, betas=(0.9, 0.999), eps=1e-8)    # train.py:91
+    # Adam with the reference's hyper-parameters (train.py:91) as one multi-tensor HIP launch (csbsr_amd/optim.py: a torch.optim.Optimizer
+    # drop-in, same state keys, agreement with torch.optim.Adam to fp32 rounding); --torch-adam times torch's own foreach kernels instead
+    from csbsr_amd.optim import Adam as HipAdam
+    Opt = torch.optim.Adam if args.torch_adam else HipAdam
+    opt = Opt([p for p in model.parameters() if p.requires_grad], lr=cfg.SOLVER.LR, betas=(0.9, 0.999), eps=1e-8)
 
     B, lr = args.batch, args.lr_size
     # synthetic minibatch (seed differs per rank: each GPU gets its own shard of the global batch), resident in HBM when the timed region

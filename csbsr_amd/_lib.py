@@ -156,6 +156,7 @@ SIGNATURES = {
     "csbsr_gaussian_kernels": (i32, [vp, vp, i32, i32, vp]),
     "csbsr_iou_sweep": (i32, [vp, vp, vp, i32, i64, i32, f32, vp, vp, vp, vp, vp]),
     "csbsr_psnr_ssim": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "csbsr_adam_step": (i32, [vp, vp, vp, i32, C.c_double, C.c_double, C.c_float, vp]),
 }
 
 # private hooks (csbsr_amd/csrc/csbsr_debug.h): kernel selection for A/B timing and kernel attribution for bench.py

@@ -271,6 +271,50 @@ __global__ void axpby_kernel(long npix, int c8, const half_t* x, long x_ld, long
     }
   }
 }
+// ---- multi-tensor Adam (csbsr_hip.h): one workgroup per 8192-element chunk of one tensor, 16-byte accesses (torch allocations are 256-byte
+// aligned and the chunk size keeps every chunk start aligned), a scalar tail.  The arithmetic follows torch's own kernels operation by
+// operation (lerp as m + w (g - m), addcmul, sqrt / bias-correction + eps, addcdiv) so that the two optimisers agree to fp32 rounding.
+#define ADAM_CHUNK 8192
+__global__ __launch_bounds__(256) void adam_step_kernel(const csbsr_adam_tensor_t* __restrict__ tt, const int* __restrict__ bt,
+                                                        const int* __restrict__ bc, float w1, float beta2, float w2, float eps) {
+  const csbsr_adam_tensor_t t = tt[bt[blockIdx.x]];
+  const long base = (long)bc[blockIdx.x] * ADAM_CHUNK;
+  const long rem = t.n - base;
+  const int cnt = rem < ADAM_CHUNK ? (int)rem : ADAM_CHUNK;
+  auto upd = [&](float& p, float g, float& m, float& v) {
+    m = m + w1 * (g - m);
+    v = v * beta2 + w2 * g * g;
+    const float denom = sqrtf(v) / t.bc2_sqrt + eps;
+    p = p - t.step_size * (m / denom);
+  };
+  const int nv = cnt >> 2;
+  float4* p4 = reinterpret_cast<float4*>(t.p + base);
+  const float4* g4 = reinterpret_cast<const float4*>(t.g + base);
+  float4* m4 = reinterpret_cast<float4*>(t.m + base);
+  float4* v4 = reinterpret_cast<float4*>(t.v + base);
+  for (int i = threadIdx.x; i < nv; i += 256) {
+    float4 p = p4[i], m = m4[i], v = v4[i];
+    const float4 g = g4[i];
+    upd(p.x, g.x, m.x, v.x); upd(p.y, g.y, m.y, v.y); upd(p.z, g.z, m.z, v.z); upd(p.w, g.w, m.w, v.w);
+    p4[i] = p; m4[i] = m; v4[i] = v;
+  }
+  for (int i = 4 * nv + threadIdx.x; i < cnt; i += 256) {
+    float p = t.p[base + i], m = t.m[base + i], v = t.v[base + i];
+    upd(p, t.g[base + i], m, v);
+    t.p[base + i] = p; t.m[base + i] = m; t.v[base + i] = v;
+  }
+}
+extern "C" int csbsr_adam_step(const csbsr_adam_tensor_t* tensors, const int32_t* block_tensor, const int32_t* block_chunk, int32_t nblocks,
+                               double beta1_d, double beta2_d, float eps, csbsr_stream_t s) {
+  CSBSR_CHECK(tensors && block_tensor && block_chunk && nblocks >= 0, "adam_step: bad arguments");
+  if (nblocks == 0) return 0;
+  // (1 - beta in DOUBLE, then rounded: torch passes the Python float 1 - beta2 = 0.001, where 1.f - 0.999f is 0.99998713e-3)
+  hipLaunchKernelGGL(adam_step_kernel, dim3(nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(s), tensors, block_tensor, block_chunk,
+                     (float)(1.0 - (double)beta1_d), (float)beta2_d, (float)(1.0 - beta2_d), eps);
+  CSBSR_LAUNCH_CHECK("csbsr_adam_step");
+  return 0;
+}
+
 extern "C" int csbsr_axpby_split(int64_t npix, int32_t c, const void* x, int64_t x_ld, int64_t x_lo, float a, const void* z, int64_t z_ld,
                                  int64_t z_lo, float b, void* y, int64_t y_ld, int64_t y_lo, csbsr_stream_t s) {
   CSBSR_CHECK(c % 8 == 0 && x && y, "axpby: bad args");

@@ -285,6 +285,19 @@ int csbsr_epilogue_backward(const csbsr_epi_bwd_desc_t* d, csbsr_stream_t s);
  * (status 1, csbsr_last_error): there is no atomics fallback. */
 int csbsr_set_reduction_scratch(float* buf, int64_t elems);
 
+/* Adam step (torch.optim.Adam as /root/reference/train.py:91 builds it: lr, betas = (0.9, 0.999), eps = 1e-8, no weight decay, no amsgrad) for a
+ * LIST of fp32 tensors in one launch: m = lerp(m, g, 1 - beta1); v = beta2 v + (1 - beta2) g g; p -= step_size m / (sqrt(v) / bc2_sqrt + eps), with
+ * step_size = lr / (1 - beta1^t) and bc2_sqrt = sqrt(1 - beta2^t) per tensor (a parameter whose gradient was None in some step has a smaller t,
+ * exactly like torch's per-parameter state["step"]).  ``tensors`` (device memory): the table; ``block_tensor`` / ``block_chunk`` (device, int32
+ * [nblocks]): workgroup b updates elements [8192 block_chunk[b], 8192 (block_chunk[b] + 1)) of tensor block_tensor[b]. */
+typedef struct {
+  float* p; const float* g; float* m; float* v;
+  int64_t n;
+  float step_size, bc2_sqrt;
+} csbsr_adam_tensor_t;
+int csbsr_adam_step(const csbsr_adam_tensor_t* tensors, const int32_t* block_tensor, const int32_t* block_chunk, int32_t nblocks,
+                    double beta1, double beta2, float eps, csbsr_stream_t s);
+
 int csbsr_axpby(int64_t npix, int32_t c, const void* x, int64_t x_ld, float a, const void* z, int64_t z_ld,
                 float b, void* y, int64_t y_ld, csbsr_stream_t s);
 int csbsr_fill_f16(void* p, int64_t npix, int32_t c, int64_t ld, float v, csbsr_stream_t s);

@@ -611,3 +611,42 @@ def test_tap_sum_preserving_weight_rounding(shape, mode):
     assert float(d.pow(2).mean().sqrt()) < 1.35 * float(d0.pow(2).mean().sqrt())      # the price: a few taps one step further away
     ref = tapsum_round(w, transposed=mode > 1, stride=mode)
     assert float((ref == q).float().mean()) > 0.995
+
+
+def test_adam_step_matches_torch():
+    """csbsr_amd.optim.Adam (one multi-tensor HIP launch per group) against torch.optim.Adam with the reference's hyper-parameters
+    (/root/reference/train.py:91) over six steps: odd sizes (scalar, a tail that is not a multiple of four, several 8192-element chunks), a
+    parameter whose gradient is None in two of the steps (its moments and step count must not advance), a learning-rate change between
+    steps (what LambdaLR does), and the state_dict interchange both ways."""
+    from csbsr_amd.optim import Adam
+    torch.manual_seed(21)
+    shapes = [(1,), (7,), (3, 3, 3, 3), (64, 33, 3, 3), (20000,), (8192,), (128, 128, 8, 8)]
+    P0 = [torch.randn(s) * 0.1 for s in shapes]
+    pa = [torch.nn.Parameter(t.clone().cuda()) for t in P0]
+    pb = [torch.nn.Parameter(t.clone().cuda()) for t in P0]
+    oa = Adam(pa, lr=2e-5, betas=(0.9, 0.999), eps=1e-8)
+    ob = torch.optim.Adam(pb, lr=2e-5, betas=(0.9, 0.999), eps=1e-8)
+    for it in range(6):
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            if k == 3 and it in (1, 4):
+                a.grad = b.grad = None
+                continue
+            g = torch.randn_like(a) * (10.0 ** (-(k % 4)))
+            a.grad, b.grad = g.clone(), g.clone()
+        if it == 3:
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 5e-4
+        oa.step(); ob.step()
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(zip(pa, pb)):
+        sa, sb = oa.state[a], ob.state[b]
+        assert float(sa["step"]) == float(sb["step"]) == (4.0 if k == 3 else 6.0)
+        for key in ("exp_avg", "exp_avg_sq"):
+            assert float((sa[key] - sb[key]).abs().max()) <= 2e-6 * float(sb[key].abs().max()) + 1e-30, (k, key)
+        assert float((a - b).abs().max()) <= 1e-6 * 5e-4 * 6 + 2e-7 * float(b.abs().max()), k      # (six steps of at most ~lr each)
+    # state_dict interchange: torch -> ours -> one more identical step
+    oa2 = Adam(pa, lr=5e-4, betas=(0.9, 0.999), eps=1e-8)
+    oa2.load_state_dict(oa.state_dict())
+    ob2 = torch.optim.Adam(pa, lr=5e-4, betas=(0.9, 0.999), eps=1e-8)
+    ob2.load_state_dict(oa.state_dict())
+    assert float(oa2.state[pa[0]]["step"]) == 6.0 and set(ob2.state_dict()["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}

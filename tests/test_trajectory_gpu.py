@@ -41,8 +41,8 @@ GNORM_BAND = {"fp16": 0.15, "split": 0.15}
 MOVED_BAND = {"fp16": 1e-2, "split": 1e-2}
 
 
-@pytest.mark.parametrize("precision", ["fp16", "split"])
-def test_joint_phase_trajectory_follows_the_reference(precision):
+@pytest.mark.parametrize("precision,optim", [("fp16", "torch"), ("split", "torch"), ("split", "hip")])
+def test_joint_phase_trajectory_follows_the_reference(precision, optim):
     from csbsr_amd.config import cfg as base_cfg
     from csbsr_amd.modeling.build_model import JointModelWithLoss
     from csbsr_amd.utils.detfill import deterministic_fill
@@ -58,8 +58,12 @@ def test_joint_phase_trajectory_follows_the_reference(precision):
     m.micro_batch, m.max_resident = 8, 8
     m.train()
     params = [p for p in m.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=float(g["lr_rate"]), betas=(0.9, 0.999), eps=1e-8)
     m._runtime()                                         # parameters move to the device here
+    if optim == "hip":        # the hand-written multi-tensor Adam (csbsr_amd/optim.py, what bench.py steps with) on the same curve
+        from csbsr_amd.optim import Adam as HipAdam
+        opt = HipAdam(params, lr=float(g["lr_rate"]), betas=(0.9, 0.999), eps=1e-8)
+    else:
+        opt = torch.optim.Adam(params, lr=float(g["lr_rate"]), betas=(0.9, 0.999), eps=1e-8)
     named = [(k, v) for k, v in m._named_full() if isinstance(v, torch.nn.Parameter)]
     start = {k: v.detach().clone() for k, v in named}
     S = m.pc.num_stages
