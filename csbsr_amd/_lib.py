@@ -156,6 +156,8 @@ SIGNATURES = {
     "csbsr_gaussian_kernels": (i32, [vp, vp, i32, i32, vp]),
     "csbsr_iou_sweep": (i32, [vp, vp, vp, i32, i64, i32, f32, vp, vp, vp, vp, vp]),
     "csbsr_psnr_ssim": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "csbsr_head1_fwd": (i32, [vp, i64, i64, i32, vp, vp, i32, vp, i64, vp]),
+    "csbsr_head1_bwd_input": (i32, [vp, i64, vp, i32, vp, i64, i64, vp]),
     "csbsr_adam_step": (i32, [vp, vp, vp, i32, C.c_double, C.c_double, C.c_float, vp]),
 }
 

@@ -865,6 +865,74 @@ extern "C" int csbsr_sigmoid_bwd_to_nhwc8(const float* dp, const float* p, void*
   return 0;
 }
 
+// ---- 1-channel heads (PSPNet's final 1x1 conv 64 -> 1 + sigmoid at full resolution, pspnet.py:117-121; its aux head 256 -> 1): the
+// general kernels pad the single output channel to a 32-row MFMA tile.  Forward: a pixel's C channels (an fp16 hi plane, optionally + the lo
+// plane of a split map) against the fp32 weight row in fp32 VALU arithmetic -- LPP = C / 8 lanes per pixel, 16 bytes per lane and plane,
+// xor-shuffle fold -- then bias and sigmoid, fp32 planar output: one pass over the input at the streaming rate, and MORE exact than the
+// split products it replaces (the weights are not rounded at all).  Input gradient: dX[pixel][c] = dPre[pixel] w[c], one 16-byte store per lane.
+template <int LPP>
+__global__ __launch_bounds__(256) void head1_fwd_kernel(const half_t* __restrict__ x, long ld, long lo, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int sigmoid, float* __restrict__ out, long npix) {
+  const int lane = threadIdx.x & (LPP - 1);
+  float wr[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) wr[e] = w[8 * lane + e];
+  const float b = bias ? bias[0] : 0.f;
+  const long ppb = 256 / LPP;
+  for (long px = (long)blockIdx.x * ppb + threadIdx.x / LPP; px < npix; px += (long)gridDim.x * ppb) {
+    const half_t* xp = x + px * ld + 8 * lane;
+    const h8 hv = *reinterpret_cast<const h8*>(xp);
+    float acc = 0.f;
+    if (lo) {
+      const h8 lv = *reinterpret_cast<const h8*>(xp + lo);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += ((float)hv[e] + (float)lv[e]) * wr[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += (float)hv[e] * wr[e];
+    }
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+      const float t = acc + b;
+      out[px] = sigmoid ? 1.f / (1.f + __expf(-t)) : t;
+    }
+  }
+}
+extern "C" int csbsr_head1_fwd(const void* x, int64_t ld, int64_t lo, int32_t c, const float* w, const float* bias, int32_t sigmoid,
+                               float* out, int64_t npix, csbsr_stream_t s) {
+  CSBSR_CHECK(x && w && out && (c == 64 || c == 128 || c == 256) && ld >= c, "head1_fwd: bad arguments (64, 128 or 256 channels)");
+  const half_t* xp = reinterpret_cast<const half_t*>(x);
+  const int lpp = c / 8;
+  const unsigned g = (unsigned)grid_for(npix * lpp);
+  if (lpp == 8) hipLaunchKernelGGL(head1_fwd_kernel<8>, dim3(g), dim3(256), 0, ST(s), xp, (long)ld, (long)lo, w, bias, sigmoid, out, (long)npix);
+  else if (lpp == 16) hipLaunchKernelGGL(head1_fwd_kernel<16>, dim3(g), dim3(256), 0, ST(s), xp, (long)ld, (long)lo, w, bias, sigmoid, out, (long)npix);
+  else hipLaunchKernelGGL(head1_fwd_kernel<32>, dim3(g), dim3(256), 0, ST(s), xp, (long)ld, (long)lo, w, bias, sigmoid, out, (long)npix);
+  CSBSR_LAUNCH_CHECK("csbsr_head1_fwd");
+  return 0;
+}
+__global__ void head1_bwd_input_kernel(const half_t* __restrict__ dpre, long dpre_ld, const float* __restrict__ w, int c8, half_t* __restrict__ dx,
+                                       long ld, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long px = i / c8;
+    const int oct = (int)(i - px * c8);
+    const float d = (float)dpre[px * dpre_ld];
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)(d * w[8 * oct + e]);
+    *reinterpret_cast<h8*>(dx + px * ld + 8 * oct) = o;
+  }
+}
+extern "C" int csbsr_head1_bwd_input(const void* dpre, int64_t dpre_ld, const float* w, int32_t c, void* dx, int64_t ld, int64_t npix,
+                                     csbsr_stream_t s) {
+  CSBSR_CHECK(dpre && w && dx && c % 8 == 0 && c >= 8 && ld >= c, "head1_bwd_input: bad arguments");
+  const long total = (long)npix * (c / 8);
+  hipLaunchKernelGGL(head1_bwd_input_kernel, dim3(grid_for(total)), dim3(256), 0, ST(s), reinterpret_cast<const half_t*>(dpre), (long)dpre_ld, w,
+                     c / 8, reinterpret_cast<half_t*>(dx), (long)ld, total);
+  CSBSR_LAUNCH_CHECK("csbsr_head1_bwd_input");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------- exact EDT / SDF
 // Squared Euclidean distance to the nearest zero pixel of `img` (distance_transform_edt semantics) by the exact
 // two-pass method: (1) per column, nearest zero above/below (1-D scan); (2) per row, lower envelope of parabolas

@@ -121,6 +121,7 @@ class Engine:
         # opt-in: CSBSR_CONV_X3W=1
         self.use_x3w = {"0": 0, "all": 2}.get(os.environ.get("CSBSR_CONV_X3W", "0"), 1)      # 0 off, 1 the SFT convs (Conv.winograd), "all": every eligible 3x3 layer
         self.use_x3n = os.environ.get("CSBSR_CONV_X3N", "1") != "0"     # A/B hook: 0 keeps the many-channels -> <= 64-cout 3x3 layers on the LDS-DMA tiles (csrc/conv_x3n.hip)
+        self.use_head1 = os.environ.get("CSBSR_HEAD1", "1") != "0"       # A/B hook: 0 runs the 1-channel heads on the general conv kernels
         self.use_x3 = os.environ.get("CSBSR_CONV_X3", "1") != "0"       # A/B hook: 0 routes the wide 3x3 layers through the implicit-GEMM kernels
         self.use_tp = os.environ.get("CSBSR_CONV_TP", "1") != "0"       # A/B hook: 0 routes the 2x2-tap transposed layers through the implicit-GEMM kernels
         self.split_fused = os.environ.get("CSBSR_SPLIT_FUSED", "1") != "0"   # A/B hook: 0 = the three-block split forward (x_hi staged twice)
@@ -448,6 +449,17 @@ class Conv:
                0 if m1 is None else xs[1].c, _ptr(self.b), N, _ptr(out), self.eng.stream)
         return out                                        # [N, cout] per-sample bias rows, csbsr_conv_desc_t::bias_sn = cout
 
+    def _head1_ok(self, xs, out, out32, res, stat):
+        f = xs[0]
+        return (self.eng.use_head1 and self.cout == 1 and self.k == 1 and self.stride == 1 and not self.transposed and len(xs) == 1
+                and out is None and out32 is not None and res is None and stat is None and self.prelu is None
+                and self.act in (L.ACT_NONE, L.ACT_SIGMOID) and f.cp in (64, 128, 256) and f.c == f.cp and not f.bcast and f.flat_ok()
+                and (f.lo in (0, f.cp)))
+
+    def _head1_w(self):
+        """the head's weight row as a contiguous fp32 vector (a view of the master weights: [1, C, 1, 1])"""
+        return self.w.reshape(-1)
+
     def out_size(self, H, W):
         k, s, p, d = self.k, self.stride, self.pad, self.dil
         if self.transposed:
@@ -638,6 +650,21 @@ class Conv:
         H, W = xs[0].H, xs[0].W
         OH, OW = self.out_size(H, W)
         sp = bool(xs[0].lo)
+        if self._head1_ok(xs, out, out32, res, stat):
+            # 1-channel head (PSPNet's ``final`` / aux classifier): fp32 VALU dot product over the pixel's channels, one streaming pass
+            # (csbsr_head1_fwd) instead of a 32-row MFMA tile for one output channel; the split planes are summed, the weights not rounded
+            f = xs[0]
+            tm = self.eng.timing
+            if tm is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            L.call("csbsr_head1_fwd", _ptr(f.t), f.ld, f.lo, f.cp, _ptr(self._head1_w()), _ptr(self.b), int(self.act == L.ACT_SIGMOID),
+                   _ptr(out32), f.npix, self.eng.stream)
+            if tm is not None:
+                ev1.record()
+                tm.append(("conv", 2.0 * f.npix * f.c, 2.0 * f.npix * f.c * (2 if sp else 1) + 4.0 * f.npix, ev0, ev1, self.name,
+                           (f.N, H, W, f.c, 1, 1, 1, 0), 21, 1))
+            return None
         if out is None and store and out32 is None:
             out = self.eng.new(xs[0].N, OH, OW, self.cout, split=sp)
         osc, nb = 1.0, 3
@@ -674,6 +701,23 @@ class Conv:
         row_off = 0 if seg == 0 else self.split[0]
         k, s, p, d = self.k, self.stride, self.pad, self.dil
         H, W = dpre.H, dpre.W
+        if (self.eng.use_head1 and self.cout == 1 and k == 1 and s == 1 and not self.transposed and seg == 0 and self.split[1] == 0
+                and c_seg % 8 == 0 and not accumulate and out32 is None and stat is None and mask is None and dact is None and dres is None
+                and not dpre.bcast and dpre.flat_ok()):
+            # dgrad of a 1-channel head: dX[pixel][c] = dPre[pixel] w[c] as one streaming store pass (csbsr_head1_bwd_input)
+            if out is None:
+                out = self.eng.new(dpre.N, H, W, c_seg)
+            if out.flat_ok() and not out.lo:
+                tm = self.eng.timing
+                if tm is not None:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                L.call("csbsr_head1_bwd_input", _ptr(dpre.t), dpre.ld, _ptr(self._head1_w()), c_seg, _ptr(out.t), out.ld, dpre.npix, self.eng.stream)
+                if tm is not None:
+                    ev1.record()
+                    tm.append(("conv", 2.0 * dpre.npix * c_seg, 2.0 * dpre.npix * (c_seg + 8), ev0, ev1, self.name,
+                               (dpre.N, H, W, 1, c_seg, 1, 1, 0), 22, 1))
+                return out
         hp = self.hp_dgrad and not dpre.bcast and not self.transposed
         if hp:       # weights as fp16 hi + lo pairs against the (plain fp16) gradient passed twice
             kind = 1 if s == 1 else 2

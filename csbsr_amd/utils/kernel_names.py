@@ -28,6 +28,8 @@ def conv_row(kid):
         return "conv_x3_kernel<3,2048>"
     if base == 19:
         return f"conv_x3w_kernel<{var}>"
+    if base in (21, 22):
+        return "head1_fwd_kernel" if base == 21 else "head1_bwd_input_kernel"
     if base == 20:
         return "conv_x3n_kernel<%d,%d>" % (var & 1, var >> 1)
     return _CONV.get(base, f"conv?{base}")
@@ -81,7 +83,7 @@ def canon(name):
         return "conv_x3_kernel<%s>" % m.group(1) if m.group(2) == "0" else "conv_x3_kernel<%s,%s>" % m.groups()
     for k in ("conv_wgrad_hr_kernel", "conv_wgrad_thin_kernel", "conv_wgrad_kernel", "conv_thin_cout_kernel", "conv_thin_cin2_kernel", "conv_thin_cin_kernel",
               "conv_thin_tpd_kernel", "conv_thin_tp_kernel", "conv_thin_sc_kernel", "thin_tp_bwd_kernel", "epilogue_bwd_kernel", "unpack_wgrad_kernel",
-              "bn_bwd_apply_kernel", "bn_bwd_reduce_kernel", "bn_apply_kernel", "channel_mean_sub_kernel", "round_weights_kernel"):
+              "head1_fwd_kernel", "head1_bwd_input_kernel", "bn_bwd_apply_kernel", "bn_bwd_reduce_kernel", "bn_apply_kernel", "channel_mean_sub_kernel", "round_weights_kernel"):
         if k in name:
             return k
     return name[:60]

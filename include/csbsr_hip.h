@@ -473,6 +473,13 @@ int csbsr_l1_fwd_bwd(const float* a, const float* b, const float* wmap, int32_t 
 int csbsr_sigmoid_bwd_to_nhwc8(const float* dp, const float* p, void* out, int64_t npix, float scale,
                                csbsr_stream_t s);
 
+/* 1-channel heads: F.conv2d(x, w[1, C, 1, 1], b) (+ sigmoid) of PSPNet's ``final`` and aux classifiers (/root/reference/model/modeling/pspnet.py:
+ * 117-121, 100-106).  x: fp16 NHWC, pixel stride ld, C in {64, 128, 256}; lo != 0: a split map, value = x[.] + x[. + lo]; w fp32 [C] (NOT rounded);
+ * out fp32 [npix].  csbsr_head1_bwd_input: dx[pixel][c] = dpre[pixel * dpre_ld] * w[c] (fp16 NHWC, the dgrad of the same conv). */
+int csbsr_head1_fwd(const void* x, int64_t ld, int64_t lo, int32_t c, const float* w, const float* bias, int32_t sigmoid, float* out,
+                    int64_t npix, csbsr_stream_t s);
+int csbsr_head1_bwd_input(const void* dpre, int64_t dpre_ld, const float* w, int32_t c, void* dx, int64_t ld, int64_t npix, csbsr_stream_t s);
+
 /* ------------------------------------------------------------------------------------------- data path either side of the hot path */
 /* Anisotropic Gaussian blur kernels, out[n] = exp(-(a x^2 + 2 b x y + c y^2)) / sum on linspace(-K/2, K/2, K)^2 with (a, b, c) from
  * params[n] = (sigma_x, sigma_y, theta in radians): GaussianBlur.make(), model/data/blur/blur.py:121-167 (the degradation batch

@@ -1287,3 +1287,37 @@ def test_fused_split_launch_falls_back_when_the_lds_dma_kernels_are_off():
     finally:
         L.load().csbsr_debug_set_conv_glds(2)
     assert float((outs[0] - outs[1]).abs().max() / ref.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("cin,split", [(64, 1), (64, 0), (256, 1), (128, 0)])
+def test_one_channel_head_kernels(cin, split):
+    """csbsr_head1_fwd / csbsr_head1_bwd_input (the 1-channel sigmoid heads of PSPNet: fp32 VALU dot product over a pixel's channels, the
+    split planes summed, weights unrounded) through engine.Conv against fp64 torch on the same (hi + lo) input, and against the general
+    convolution kernels (CSBSR_HEAD1 = 0 path)."""
+    from csbsr_amd.engine import Conv
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    N, H, W = 2, 19, 37
+    g = torch.Generator().manual_seed(5 + cin + split)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(1, cin, 1, 1, generator=g) * (1.0 / cin) ** 0.5
+    b = torch.tensor([0.3])
+    xs = to_fm_split(eng, x) if split else to_fm(eng, x)
+    xv = (from_fm_split(xs) if split else from_fm(xs)).double()
+    ref = torch.sigmoid(F.conv2d(xv, w.double(), b.double()))
+    dpre = torch.randn(N, 1, H, W, generator=g).half().float()
+    refd = (dpre.double() * w.double().reshape(1, cin, 1, 1))
+    outs = []
+    for on in (True, False):
+        eng.use_head1 = on
+        conv = Conv(eng, "l", {"l.weight": w.cuda(), "l.bias": b.cuda()}, 1, bias=True, act=L.ACT_SIGMOID)
+        o32 = torch.empty(N, 1, H, W, device="cuda")
+        conv.fwd(xs, out32=o32)
+        dx = conv.bwd_input(to_fm(eng, dpre))
+        torch.cuda.synchronize()
+        kid = L.load().csbsr_debug_last_conv_kernel() & 255
+        outs.append((o32.cpu().double(), from_fm(dx).double()))
+        assert float((outs[-1][0] - ref).abs().max()) < (2e-6 if (on or split) else 2e-3), (on, float((outs[-1][0] - ref).abs().max()))
+        assert relmax(outs[-1][1], refd) < 2e-3
+    eng.use_head1 = True
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-3 and relmax(outs[0][1], outs[1][1]) < 2e-3
