@@ -21,21 +21,29 @@
 #include "csbsr_debug.h"
 
 #define XN_TH 8
-#define XN_TW 64
-#define XN_HW (XN_TW + 2)
 #define XN_HH (XN_TH + 2)
 #define XN_SLOTS 5                        // 32 channels = 4 sixteen-byte slots + 1 pad slot
 #define XN_PITCH (XN_SLOTS * 16)
-#define XN_NINST 52                       // ceil(10 * 66 * 5 / 64) = 52 wave instructions fill the halo tile (a multiple of 4)
-#define XN_BUF (XN_NINST * 1024)
-#define XN_WSTEP 4096                     // bytes of one K step's weights for the 64-cout tile: [mt 2][kk 2][lane][8]
 #define XN_NT 9
 #define XN_RING 3
 #define XN_DIST 2
-static_assert(XN_HH * XN_HW * XN_SLOTS <= XN_NINST * 64, "halo tile fits its DMA instructions");
+// The tile geometry of the two forms.  NARROW (<= 64 couts): 8 x 64 pixels x 64 couts, one workgroup per CU.  WIDE (> 64 couts from 64 .. 128
+// input channels -- BlurSkip's 64 -> 505 conv0's and the dgrads of its conv1's, one or two chunks of K per tile, where the fused epilogue of
+// 128 accumulator registers per lane is a third of a tile's time): 8 x 32 pixels x 128 couts, the four waves 2 cout halves x 2 row quads as
+// in csrc/conv_x3.hip, 56 KB of LDS and <= 256 registers so that TWO workgroups share a CU -- one's epilogue (VALU + stores) runs under the
+// other's K loop (MFMA), which a single workgroup's program order cannot do.
+template <bool WIDE> struct XNGeo {
+  static constexpr int TW = WIDE ? 32 : 64;               // tile width in pixels
+  static constexpr int HW = TW + 2;
+  static constexpr int NINST = WIDE ? 28 : 52;            // wave instructions that fill the halo tile: ceil(10 * HW * 5 / 64) rounded to 4
+  static constexpr int BUF = NINST * 1024;
+  static constexpr int CT = WIDE ? 128 : 64;              // couts per tile
+  static constexpr int WSTEP = WIDE ? 8192 : 4096;        // bytes of one K step's weights: [mh 2 (wide)][mt 2][kk 2][lane][8]
+  static_assert(XN_HH * HW * XN_SLOTS <= NINST * 64, "halo tile fits its DMA instructions");
+};
 
 struct XNExtra {
-  unsigned tiles_x, tiles_y, nct, nch;   // pixel tiles, 64-cout tiles, 32-channel chunks
+  unsigned tiles_x, tiles_y, nct, nch;   // pixel tiles, cout tiles (64 or 128 channels), 32-channel chunks
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -50,14 +58,18 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t xn_make_rs(const half_t
 // statistics -- every lane keeps the sum and the sum of squares of its 32 output channels over all its tiles in registers, the lanes of a
 // wave fold by xor-shuffles, the four waves through LDS in wave order, and the workgroup writes ONE partial row; the launcher folds the rows
 // in a fixed tree (csbsr_sum_partials): order-fixed like every reduction of the library.
-template <bool FAST, bool BNS = false>
-__global__ __launch_bounds__(256) void conv_x3n_kernel(const ConvK p, const XNExtra q) {
+template <bool FAST, bool BNS = false, bool WIDE = false>
+__global__ __launch_bounds__(256, WIDE ? 2 : 1) void conv_x3n_kernel(const ConvK p, const XNExtra q) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(!(BNS && WIDE), "fused BatchNorm sums: the narrow form");
+  using G = XNGeo<WIDE>;
+  constexpr int XN_TW = G::TW, XN_HW = G::HW, XN_NINST = G::NINST, XN_BUF = G::BUF, XN_WSTEP = G::WSTEP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pix = lane & 31, hi = lane >> 5;
-  const int chf = wid & 1, rq = wid >> 1;            // column half (32 pixels), row quad
+  const int chf = WIDE ? 0 : (wid & 1), rq = wid >> 1;     // column half (32 pixels; narrow), row quad
+  const int mh = WIDE ? (wid & 1) : 0;                     // cout half of the 128-cout tile (wide)
   const unsigned per_img = q.tiles_x * q.tiles_y, ntiles = per_img * (unsigned)p.N, items = ntiles * q.nct;
   unsigned it = blockIdx.x;
   if (it >= items) return;
@@ -104,8 +116,9 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const ConvK p, const XNEx
     const unsigned r_ = tile - n * per_img;
     Y0 = (r_ / q.tiles_x) * XN_TH; X0 = (r_ % q.tiles_x) * XN_TW;
   };
-  // the weights of K step (ct, chunk, tap): [mt 2][kk 2] fragments, one 16-byte load per lane each (the same 4 KB for all four waves)
-  const unsigned wlane = (unsigned)(lane * 16);
+  // the weights of K step (ct, chunk, tap): [mt 2][kk 2] fragments, one 16-byte load per lane each (narrow: the same 4 KB for all four
+  // waves; wide: the wave's cout half of 8 KB)
+  const unsigned wlane = (unsigned)(lane * 16 + mh * 4096);
   auto load_w = [&](int ct, int step, h8 (&w)[2][2]) __attribute__((always_inline)) {
     const char* b = reinterpret_cast<const char*>(p.wt) + ((size_t)ct * q.nch * XN_NT + step) * XN_WSTEP;
 #pragma unroll
@@ -146,6 +159,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const ConvK p, const XNEx
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    if constexpr (WIDE) __builtin_amdgcn_s_setprio(1);      // the K loop's MFMA issue ahead of the co-resident workgroup's epilogue
     for (int c = 0; c < (int)q.nch; ++c) {
       // chunk c's halo has landed everywhere, and every wave is done with the other buffer (chunk c - 1): refill that one.  The only
       // vector-memory instructions issued after this chunk's last DMA piece (k-slice NFI - 1 = tap 6 of the previous chunk) are the
@@ -188,7 +202,8 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const ConvK p, const XNEx
       }
     }
 
-    // ---- epilogue: acc[mt][nt][8 pair + e] = cout 64 ct + 32 mt + 16 pair + 8 hi + e of pixel (row 4 rq + nt, column 32 chf + pix)
+    if constexpr (WIDE) __builtin_amdgcn_s_setprio(0);
+    // ---- epilogue: acc[mt][nt][8 pair + e] = cout CT ct + 64 mh + 32 mt + 16 pair + 8 hi + e of pixel (row 4 rq + nt, column 32 chf + pix)
     const int ox = X0 + 32 * chf + pix;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const ConvK p, const XNEx
 #pragma unroll
       for (int mp = 0; mp < 4; ++mp) {
         const int mt = mp >> 1, pair = mp & 1;
-        const int co = 64 * ct + 32 * mt + 16 * pair + 8 * hi;
+        const int co = G::CT * ct + 64 * mh + 32 * mt + 16 * pair + 8 * hi;
         if (oy >= p.OH || ox >= p.OW || co >= p.coutp) continue;
         float v[8], bias[8], s0[8], s1[8];
 #pragma unroll
@@ -254,21 +269,22 @@ __global__ __launch_bounds__(256) void conv_x3n_kernel(const ConvK p, const XNEx
 #endif
 }
 
-// ---- weights in K-step order: dst[ct][chunk][tap][mt][kk][lane][e] = scale x W(row 64 ct + 32 mt + perm(lane % 32), channel, tap) with
-// input channel j = 32 chunk + 16 kk + 8 (lane / 32) + e and perm as in csbsr_pack_weights_x3 (a lane's accumulator registers 8 pair ..
-// 8 pair + 7 are consecutive channels).  ``plane`` > 0 (a split input run as 2 x plane plain channels): the weight of input channel j is
-// that of channel j mod plane -- [w | w].  kind 0: forward, W is OIHW; kind 1: dgrad of the stride-1 conv (rows = the conv's input
-// channels, contracted channels its outputs, taps flipped).
-struct PackXNK { const float* w; half_t* dst; int kind, D1, nch, nct, c_real, rows_real, row_off, k_off, plane; float scale; };
+// ---- weights in K-step order: dst[ct][chunk][tap]([mh] wide)[mt][kk][lane][e] = scale x W(row CT ct + 64 mh + 32 mt + perm(lane % 32), channel,
+// tap) with input channel j = 32 chunk + 16 kk + 8 (lane / 32) + e and perm as in csbsr_pack_weights_x3 (a lane's accumulator registers
+// 8 pair .. 8 pair + 7 are consecutive channels); the WIDE layout (CT = 128) whenever the rows pad to more than 64.  ``plane`` > 0 (a split
+// input run as 2 x plane plain channels): the weight of input channel j is that of channel j mod plane -- [w | w].  kind 0: forward, W is
+// OIHW; kind 1: dgrad of the stride-1 conv (rows = the conv's input channels, contracted channels its outputs, taps flipped).
+struct PackXNK { const float* w; half_t* dst; int kind, D1, nch, nct, c_real, rows_real, row_off, k_off, plane, wide; float scale; };
 __global__ void pack_weights_x3n_kernel(const PackXNK p, long total) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), kk = (int)((i >> 9) & 1), mt = (int)((i >> 10) & 1);
-    const long step = i >> 11;
+    const int mh = p.wide ? (int)((i >> 11) & 1) : 0;
+    const long step = i >> (p.wide ? 12 : 11);
     const int tap = (int)(step % XN_NT);
     const long t2 = step / XN_NT;
     const int chunk = (int)(t2 % p.nch), ct = (int)(t2 / p.nch);
     const int m = lane & 31, q_ = m >> 3, h_ = (m >> 2) & 1;
-    const int row = 64 * ct + 32 * mt + 16 * (q_ >> 1) + 8 * h_ + 4 * (q_ & 1) + (m & 3);
+    const int row = (p.wide ? 128 : 64) * ct + 64 * mh + 32 * mt + 16 * (q_ >> 1) + 8 * h_ + 4 * (q_ & 1) + (m & 3);
     int c = 32 * chunk + 16 * kk + 8 * (lane >> 5) + e;
     if (p.plane > 0) c = c >= p.plane ? c - p.plane : c;
     const int ky = tap / 3, kx = tap % 3;
@@ -282,10 +298,13 @@ __global__ void pack_weights_x3n_kernel(const PackXNK p, long total) {
   }
 }
 
+static inline bool xn_wide_rows(int rows_real) { return round_up(rows_real, 8) > 64; }
+
 // in_ch = padded input channels the kernel walks (a multiple of 32; for a split input: 2 x the plane's padded channels)
 extern "C" int64_t csbsr_packed_weight_elems_x3n(int32_t in_ch, int32_t rows_real) {
-  const int nch = (in_ch + 31) / 32, nct = (round_up(rows_real, 8) + 63) / 64;
-  return (int64_t)nct * nch * XN_NT * (XN_WSTEP / 2);
+  const bool wide = xn_wide_rows(rows_real);
+  const int nch = (in_ch + 31) / 32, ct = wide ? 128 : 64, nct = (round_up(rows_real, 8) + ct - 1) / ct;
+  return (int64_t)nct * nch * XN_NT * ((wide ? XNGeo<true>::WSTEP : XNGeo<false>::WSTEP) / 2);
 }
 
 extern "C" int csbsr_pack_weights_x3n(const float* w, void* dst, int32_t kind, int32_t D0, int32_t D1, int32_t c_real, int32_t rows_real,
@@ -297,7 +316,8 @@ extern "C" int csbsr_pack_weights_x3n(const float* w, void* dst, int32_t kind, i
   CSBSR_CHECK(in_ch % 32 == 0 && (plane == 0 ? in_ch >= c_real : (in_ch == 2 * plane && plane >= c_real)), "pack_x3n: bad channel geometry");
   PackXNK p;
   p.w = w; p.dst = reinterpret_cast<half_t*>(dst); p.kind = kind; p.D1 = D1;
-  p.nch = in_ch / 32; p.nct = (round_up(rows_real, 8) + 63) / 64;
+  p.wide = xn_wide_rows(rows_real) ? 1 : 0;
+  p.nch = in_ch / 32; p.nct = (round_up(rows_real, 8) + (p.wide ? 127 : 63)) / (p.wide ? 128 : 64);
   p.c_real = c_real; p.rows_real = rows_real; p.row_off = row_off; p.k_off = k_off; p.plane = plane; p.scale = scale;
   const long total = csbsr_packed_weight_elems_x3n(in_ch, rows_real);
   const long nb = (total + 255) / 256;
@@ -306,50 +326,68 @@ extern "C" int csbsr_pack_weights_x3n(const float* w, void* dst, int32_t kind, i
   return 0;
 }
 
-static int g_conv_x3n_mode = 1;      // 0 off, 1 launches that fill the chip (default), 2 every eligible launch (tests)
+static int g_conv_x3n_mode = 1;      // 0 off, 1 launches that fill the chip (default), 2 every eligible launch (tests), 3 narrow form only; +4: the wide form at any input width
 extern "C" void csbsr_debug_set_conv_x3n(int mode) { g_conv_x3n_mode = mode & 7; }
 
-// Which launches take this kernel: 3x3, stride 1, pad 1, dilation 1, ONE input segment of >= 64 (mode 2: >= 32) channels in whole 32-channel
-// chunks -- plain fp16, or a split [hi | lo] pair presented as one 2 x Cp-channel segment with split_fused = 2 (the two-product plan) --,
-// 33 .. 64 padded output channels, fp16 output (hi + lo pairs allowed), any fused epilogue of the general kernels except statistics, the
-// fp32 side output, split residual operands and the fused epilogue-backward sums.
+// Which launches take this kernel (return value 1: the narrow form, 2: the wide form): 3x3, stride 1, pad 1, dilation 1, ONE input segment in
+// whole 32-channel chunks -- plain fp16, or a split [hi | lo] pair presented as one 2 x Cp-channel segment with split_fused = 2 (the
+// two-product plan) --, fp16 output (hi + lo pairs allowed), any fused epilogue of the general kernels (split residual operands included:
+// BlurSkip's conv_shift.1 combines x * scale + shift on hi + lo pairs) except sample statistics, the fp32 side output and the fused
+// epilogue-backward sums.  Narrow: 33 .. 64 padded output channels from >= 64 (mode 2: >= 32) input channels, BatchNorm sums allowed.  Wide:
+// more than 64 padded output channels from 64 .. 384 input channels (measured against csrc/conv_x3.hip's whole-K-resident tile, one launch
+// of the batch of 8 at 448^2: 128 -> 569 2.94 -> 2.42 ms, 256 -> 697 5.39 -> 4.94, 384 -> 825 8.47 -> 8.25, 825 -> 825 16.7 -> 17.2: the
+// overlapped epilogue is worth less and the twice-staged weights more as K grows).
 extern "C" int32_t csbsr_conv_x3n_eligible(const csbsr_conv_desc_t* d) {
-  if (!d || !g_conv_x3n_mode || d->transposed || d->KH != 3 || d->KW != 3 || d->dil != 1) return 0;
+  const int mode = g_conv_x3n_mode & 3;
+  if (!d || !mode || d->transposed || d->KH != 3 || d->KW != 3 || d->dil != 1) return 0;
   if (d->stride != 1 || d->pad != 1 || d->OH != d->H || d->OW != d->W) return 0;
-  if (d->in[0].c % 32 != 0 || d->in[0].c < (g_conv_x3n_mode == 2 ? 32 : 64)) return 0;
+  if (d->in[0].c % 32 != 0 || d->in[0].c < (mode == 2 ? 32 : 64)) return 0;
   if (d->in[1].c != 0 || d->in[0].sx == 0 || (d->split_fused != 0 && d->split_fused != 2)) return 0;
-  if (d->coutp <= 32 || d->coutp > 64 || !d->out16 || d->out32 || d->r_lo || d->r2_lo) return 0;
-  if (d->stat_mode != CSBSR_STAT_NONE && d->stat_mode != CSBSR_STAT_BN) return 0;      // (BatchNorm sums: the straight-line rows only, see the launcher)
+  if (d->coutp <= 32 || !d->out16 || d->out32) return 0;
   if (d->dact_bias || d->dact_prelu || d->dres) return 0;
   if (d->in[0].sy >= (1l << 31) / 2 / (XN_HH + 1)) return 0;
-  if (g_conv_x3n_mode == 1 && (long)d->N * d->OH * d->OW < 512L * XN_TH * XN_TW) return 0;
-  return 1;
+  const bool wide = d->coutp > 64;
+  if (wide) {
+    if (mode == 3 || d->stat_mode != CSBSR_STAT_NONE || d->in[0].c > ((g_conv_x3n_mode & 4) ? (1 << 20) : 384)) return 0;
+  } else {
+    if (d->stat_mode != CSBSR_STAT_NONE && d->stat_mode != CSBSR_STAT_BN) return 0;    // (BatchNorm sums: the straight-line rows only, see the launcher)
+    if (d->stat_mode == CSBSR_STAT_BN && (d->r_lo || d->r2_lo)) return 0;              // (split residual operands: the general row)
+  }
+  if (mode != 2 && (long)d->N * d->OH * d->OW < 512L * XN_TH * 64) return 0;
+  return wide ? 2 : 1;
 }
 
-template <bool FAST, bool BNS = false>
+template <bool FAST, bool BNS = false, bool WIDE = false>
 static int launch_x3n(const ConvK& k, const XNExtra& q, unsigned g, hipStream_t st) {
-  constexpr int SM_BYTES = 2 * XN_BUF;
+  constexpr int SM_BYTES = 2 * XNGeo<WIDE>::BUF;
   static LdsAttrOnce attr;
-  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_x3n_kernel<FAST, BNS>), SM_BYTES, "conv_x3n")) return e;
-  hipLaunchKernelGGL((conv_x3n_kernel<FAST, BNS>), dim3(g), dim3(256), SM_BYTES, st, k, q);
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_x3n_kernel<FAST, BNS, WIDE>), SM_BYTES, "conv_x3n")) return e;
+  hipLaunchKernelGGL((conv_x3n_kernel<FAST, BNS, WIDE>), dim3(g), dim3(256), SM_BYTES, st, k, q);
   CSBSR_LAUNCH_CHECK("csbsr_conv_x3n_forward");
   return 0;
 }
 
 extern "C" int csbsr_conv_x3n_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s) {
-  CSBSR_CHECK(csbsr_conv_x3n_eligible(d), "conv_x3n: launch not eligible (see csbsr_conv_x3n_eligible)");
+  const int form = csbsr_conv_x3n_eligible(d);
+  CSBSR_CHECK(form, "conv_x3n: launch not eligible (see csbsr_conv_x3n_eligible)");
+  const bool wide = form == 2;
   csbsr_conv_desc_t dd = *d;
   dd.split_fused = 0;                  // the planes are plain channels to this kernel (and to the argument-block validation)
   ConvK k;
   if (int rc = conv_desc_to_k(&dd, k)) return rc;
+  const int tw = wide ? XNGeo<true>::TW : XNGeo<false>::TW, ctile = wide ? XNGeo<true>::CT : XNGeo<false>::CT;
   XNExtra q;
-  q.tiles_x = (unsigned)((d->OW + XN_TW - 1) / XN_TW); q.tiles_y = (unsigned)((d->OH + XN_TH - 1) / XN_TH);
-  q.nct = (unsigned)((d->coutp + 63) / 64); q.nch = (unsigned)(d->in[0].c / 32);
-  const int ncu = csbsr_cu_budget(reinterpret_cast<hipStream_t>(s));
+  q.tiles_x = (unsigned)((d->OW + tw - 1) / tw); q.tiles_y = (unsigned)((d->OH + XN_TH - 1) / XN_TH);
+  q.nct = (unsigned)((d->coutp + ctile - 1) / ctile); q.nch = (unsigned)(d->in[0].c / 32);
+  const int slots = csbsr_cu_budget(reinterpret_cast<hipStream_t>(s)) * (wide ? 2 : 1);      // (wide: two workgroups per CU)
   const unsigned items = q.tiles_x * q.tiles_y * (unsigned)d->N * q.nct;
-  const unsigned g = items < (unsigned)ncu ? items : (unsigned)ncu;
+  const unsigned g = items < (unsigned)slots ? items : (unsigned)slots;
   const bool fast_rows = conv_epilogue_fast_ok(k);
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  if (wide) {
+    g_last_conv_kernel = CONVK_X3N | (fast_rows ? 1 : 0) << 8 | 4 << 8;
+    return fast_rows ? launch_x3n<true, false, true>(k, q, g, st) : launch_x3n<false, false, true>(k, q, g, st);
+  }
   if (k.stat_mode == CSBSR_STAT_BN) {
     CSBSR_CHECK(fast_rows && q.nct == 1 && k.stat, "conv_x3n: fused BatchNorm sums need the straight-line epilogue rows and one cout tile");
     k.stat_ld = 2 * (long)k.coutp;

@@ -781,7 +781,7 @@ class Conv:
         bias = self._dc_bias((x,)) if (self.dc_comp and self.eng.dc_comp and (not sp or self.fwd_blocks < 3) and (x.H * x.W) % 256 == 0) else self.b      # (the feature segment; the constant one is an fp32 mat-vec)
         self._launch(xs, wt, False, 3, 1, self.pad, self.dil, H, W, H, W, self.cout, out, None, bias, self.act, self.slope, self.prelu,
                      None, None, L.RES_NONE, False, None, L.STAT_NONE, osc, cbias=cb,
-                     x3=None if sp else (0, cf, self.cout, 0, 0), split_blocks=nb)
+                     x3=None if sp else (0, cf, self.cout, 0, 0), split_blocks=nb, x3n=(0, cf, self.cout, 0, 0))
         return out, (w16c, k16)
 
     def fwd_classbias(self, x, cb, cb_mode, out=None):

@@ -164,7 +164,10 @@ class _JointBase(nn.Module):
         # ``detector_hp_dgrad``: dgrads against [w_hi | w_lo] (two K blocks).  The same sweep shows it buys nothing -- every detector
         # gradient tensor and dLoss/dSR agree with the reference equally well without it (PSPNet median 1.15e-2 vs 1.12e-2, HRNet-OCR
         # 1.65e-2 both, BlurSkip 9.4e-4 vs 9.1e-4: the error is the ReLU-gate flips of the forward, not the weights' rounding) -- so it is off.
-        self.detector_plan = [(r"blur_skip\.[02]\.conv_(scale|shift)\.[01]\.", 2)] if self.blur_skip else None
+        # BlurSkip's two conv blocks between the SFT layers (blur_skip.1 / .3: 64 -> 64 at full resolution, BatchNorm'd) join the plan in round 6:
+        # 2.36e-4 -> 3.79e-4 on the map, gradients unchanged (median 1.5e-3, max 3.6e-3; scripts/study_split_plan.py --combos,
+        # profiles/r06_split_plan_combos.json); the decoder tail on top of that measures 8.8e-4 on this detector and stays at three.
+        self.detector_plan = [(r"blur_skip\.[02]\.conv_(scale|shift)\.[01]\.|blur_skip\.[13]\.layer", 2)] if self.blur_skip else None
         if self.seg_model_name == "PSPNet" and __import__("os").environ.get("CSBSR_DEC_PLAN", "1") != "0":
             self.detector_plan = [(r"\.(up_[123]|final)\.", 2)]
         if __import__("os").environ.get("CSBSR_BS_PLAN") == "0":        # (A/B hook: three blocks everywhere)

@@ -1131,6 +1131,9 @@ def test_split_precision_forward_conv(case, fused):
     (505, 64, 9, 130, "sigmoid"),           # three tile columns, the general (non-straight-line) epilogue row
     (96, 40, 8, 64, "relu"),                # three chunks (odd: the halo buffers alternate across tiles), 40 -> 40 padded couts
     (288, 64, 24, 33, "none"),
+    (64, 505, 19, 70, "lrelu"),             # the WIDE form (8 x 32 pixels x 128 couts, two workgroups per CU): blur_skip conv0 shape, ragged tiles
+    (128, 200, 9, 40, "none_add"),          # four chunks, 200 -> 256 padded weight rows (the second cout tile half empty), residual add
+    (96, 136, 8, 33, "sigmoid"),            # three chunks, the general epilogue row
 ])
 def test_narrow_output_3x3_kernel(cin, cout, H, W, mode):
     """csrc/conv_x3n.hip (8 x 64-pixel x 64-cout tile, per-32-channel halo tile in LDS, fragment-ordered weights from L2) against F.conv2d
@@ -1162,7 +1165,7 @@ def test_narrow_output_3x3_kernel(cin, cout, H, W, mode):
     F.conv2d(xr, w2, None, 1, 1).backward(dpre)
     refd = xr.grad + old
     outs = []
-    elig = pad8(cin) % 32 == 0 and 32 < pad8(cout) <= 64
+    elig = pad8(cin) % 32 == 0 and (32 < pad8(cout) <= 64 or (pad8(cout) > 64 and pad8(cin) <= 128))
     for xn_mode in (2, 0):
         lib.csbsr_debug_set_conv_x3n(xn_mode)
         try:
@@ -1182,7 +1185,7 @@ def test_narrow_output_3x3_kernel(cin, cout, H, W, mode):
     assert relmax(outs[0][0], outs[1][0]) < 1e-3 and relmax(outs[0][1], outs[1][1]) < 1e-3
 
 
-@pytest.mark.parametrize("cin,cout,H,W", [(505, 64, 16, 70), (256, 64, 9, 64)])
+@pytest.mark.parametrize("cin,cout,H,W", [(505, 64, 16, 70), (256, 64, 9, 64), (64, 505, 16, 70)])
 def test_narrow_output_3x3_kernel_split_input(cin, cout, H, W):
     """The two-product plan of a split (hi + lo) input on conv_x3n -- [x_hi | x_lo] w_hi as a plain convolution over 2 x Cp channels, the pack
     repeating the tap-sum-rounded weights for the lo plane, hi + lo output -- against fp64 torch on the SAME hi + lo input and the SAME
@@ -1221,6 +1224,41 @@ def test_narrow_output_3x3_kernel_split_input(cin, cout, H, W):
     print(f"   conv_x3n split {cin}->{cout}: vs the fused LDS-DMA stage {e01:.2e}, vs fp64 on unrounded weights {e_ref:.2e}")
     assert e01 < 2e-5                 # the same arithmetic in a different summation order
     assert e_ref < 2e-3               # the two-product plan keeps the weights' fp16 rounding (minus its mean response)
+
+
+def test_narrow_output_3x3_kernel_split_fma_residual():
+    """BlurSkip's conv_shift.1 launch (csbsr_amd/modeling/pspnet.py: y = q * scale + shift, all three operands hi + lo pairs) on conv_x3n:
+    the general epilogue row reads the split residual operands; against fp64 torch on the same hi + lo values and against the fused
+    LDS-DMA stage."""
+    from csbsr_amd.engine import Conv
+    from csbsr_amd import _lib as L
+    eng = _eng()
+    lib = L.load()
+    N, cin, cout, H, W = 2, 505, 64, 11, 70
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, cin, H, W, generator=g)
+    qv = torch.randn(N, cout, H, W, generator=g)
+    sc = torch.randn(N, cout, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xs, qs, ss = to_fm_split(eng, x), to_fm_split(eng, qv), to_fm_split(eng, sc)
+    outs = []
+    for xn_mode in (2, 0):
+        lib.csbsr_debug_set_conv_x3n(xn_mode)
+        try:
+            conv = Conv(eng, "l", {"l.weight": w.cuda(), "l.bias": b.cuda()}, 3, 1, 1, 1, bias=True)
+            conv.fwd_blocks, conv.dc_comp = 2, True
+            out = conv.fwd(xs, res=qs, res2=ss, res_mode=L.RES_FMA)
+            torch.cuda.synchronize()
+            assert ((lib.csbsr_debug_last_conv_kernel() & 255) == 20) == (xn_mode == 2)
+        finally:
+            lib.csbsr_debug_set_conv_x3n(1)
+        outs.append(from_fm_split(out).double())
+    ref = F.conv2d(from_fm_split(xs).double(), w.double(), b.double(), 1, 1) + from_fm_split(qs).double() * from_fm_split(ss).double()
+    e01 = float((outs[0] - outs[1]).abs().max() / ref.abs().max())
+    e_ref = float((outs[0] - ref).abs().max() / ref.abs().max())
+    print(f"   conv_x3n split FMA residual: vs the fused LDS-DMA stage {e01:.2e}, vs fp64 {e_ref:.2e}")
+    assert e01 < 2e-5 and e_ref < 2e-3
 
 
 @pytest.mark.parametrize("split", [0, 1])
