@@ -163,7 +163,7 @@ __device__ __forceinline__ void conv_epilogue_row(const ConvK& p, float (&v)[8],
 // the select t > 0 ? t : t * sneg), residual add or subtract, optional accumulate, optional BatchNorm sums: the mode switches of
 // conv_epilogue_row become two multipliers picked once per kernel.  The general row re-tests every mode per element (~100 scalar
 // branches per row): its 8 rows took 7.7 us of an 18 us transposed-conv workgroup whose 8 K slices take 5.9 us (CSBSR_TS build).
-struct EpiFast { bool ok, has_res, has_old, has_mask, bn, masked, has_cb; float sneg, rsign, osc, mslope; int cout; long o_lo; };
+struct EpiFast { bool ok, has_res, has_old, has_mask, bn, masked, has_cb, amax; float sneg, rsign, osc, mslope; int cout; long o_lo; };
 // which launches the straight-line rows cover (host and device: conv_x3 picks its kernel instance by it).  The activation is
 // the select t > 0 ? t : t * sneg with a kernel-uniform sneg: exact for any slope (a learned PReLU slope may exceed 1) and NaN-
 // preserving (round 4's max(t, 0) + sneg * min(t, 0) zeroed a NaN accumulator: maxnum / minnum return the non-NaN operand).
@@ -177,6 +177,7 @@ __device__ __forceinline__ EpiFast conv_epilogue_fast_setup(const ConvK& p, floa
   f.ok = conv_epilogue_fast_ok(p);
   f.o_lo = p.o_lo;
   f.sneg = p.act == CSBSR_ACT_NONE ? 1.f : (p.act == CSBSR_ACT_RELU ? 0.f : slope);
+  f.amax = f.sneg >= 0.f && f.sneg < 1.f;      // the activation as max(t, t * sneg): two operations per element instead of compare + select + multiply, NaN in = NaN out
   f.rsign = p.res_mode == CSBSR_RES_ADD ? 1.f : (p.res_mode == CSBSR_RES_SUB ? -1.f : 0.f);
   f.has_res = p.res_mode != CSBSR_RES_NONE; f.has_old = p.accumulate != 0; f.bn = p.stat_mode == CSBSR_STAT_BN;
   f.has_mask = p.mask != nullptr; f.mslope = (p.mask && p.mask_prelu) ? *p.mask_prelu : p.mask_slope;
@@ -200,30 +201,212 @@ __device__ __forceinline__ void conv_class_bias_row(const ConvK& p, const float 
 // one pixel x 8 channels co..co+7; o = &out16[pixel][co]; rr / oo / mm = residual / old output / activation mask (zeros when absent;
 // only read when EXTRA)
 template <bool EXTRA, bool BNSTAT>
-__device__ __forceinline__ void conv_epilogue_fast_row(const EpiFast& f, const float (&v)[8], const float (&bias)[8], int co, half_t* o,
-                                                       const h8& rr, const h8& oo, float (&ssum)[8], float (&ssq)[8],
-                                                       const h8& mm = h8{1, 1, 1, 1, 1, 1, 1, 1}) {
-  float t[8];
+__device__ __forceinline__ void conv_epilogue_fast_values(const EpiFast& f, const float (&v)[8], const float (&bias)[8], int co, const h8& rr,
+                                                          const h8& oo, float (&ssum)[8], float (&ssq)[8], const h8& mm, float (&t)[8],
+                                                          bool valid = true) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    t[e] = v[e] * f.osc + bias[e];
-    t[e] = t[e] > 0.f ? t[e] : t[e] * f.sneg;      // a select, not max / min: fmaxf / fminf return the non-NaN operand and would turn an overflowed (NaN) accumulator into 0, hiding it from the optimiser's overflow check
+  for (int e = 0; e < 8; ++e) t[e] = v[e] * f.osc + bias[e];
+  // the activation t > 0 ? t : t * sneg (never max(t, 0): fmaxf returns the non-NaN operand and would turn an overflowed -- NaN -- accumulator
+  // into 0, hiding it from the optimiser's overflow check).  For 0 <= sneg < 1 that select equals max(t, t * sneg) for every finite t, and a
+  // NaN t makes both operands NaN; the identity (sneg = 1) does nothing; a learned PReLU slope outside [0, 1) keeps the select.
+  if (f.amax) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = __builtin_fmaxf(t[e], t[e] * f.sneg);
+  } else if (f.sneg != 1.f) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = t[e] > 0.f ? t[e] : t[e] * f.sneg;
   }
-  if (f.masked) {
+  if (f.masked && co + 8 > f.cout) {      // (only the last channel octet is partly padding)
 #pragma unroll
     for (int e = 0; e < 8; ++e) t[e] = (co + e < f.cout) ? t[e] : 0.f;
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    if constexpr (BNSTAT) { ssum[e] += t[e]; ssq[e] += t[e] * t[e]; }
+    if constexpr (BNSTAT) { const float ts = valid ? t[e] : 0.f; ssum[e] += ts; ssq[e] += ts * ts; }      // (valid: the lane's pixel / octet exists)
     if constexpr (EXTRA) {
       t[e] += f.rsign * (float)rr[e];
       t[e] += (float)oo[e];
       if (f.has_mask) t[e] *= ((float)mm[e] > 0.f ? 1.f : f.mslope);
     }
   }
+}
+template <bool EXTRA, bool BNSTAT>
+__device__ __forceinline__ void conv_epilogue_fast_row(const EpiFast& f, const float (&v)[8], const float (&bias)[8], int co, half_t* o,
+                                                       const h8& rr, const h8& oo, float (&ssum)[8], float (&ssq)[8],
+                                                       const h8& mm = h8{1, 1, 1, 1, 1, 1, 1, 1}) {
+  float t[8];
+  conv_epilogue_fast_values<EXTRA, BNSTAT>(f, v, bias, co, rr, oo, ssum, ssq, mm, t);
   split_store(o, f.o_lo, t);
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Stores that are UNCONDITIONAL in control flow: a buffer store whose lanes outside the image / past the last channel octet carry an
+// out-of-range offset (dropped by the bounds check) instead of sitting behind an exec-mask branch.  The compiler's waitcnt pass merges the
+// paths of a branch to the FEWEST operations in flight, so one skippable store makes every later counted wait a full drain (vmcnt(0) =
+// the write acknowledgement of everything before it); with these, a tile's sixteen stores are sixteen on every path.
+typedef unsigned conv_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t conv_make_rs(const void* base) {
+  const unsigned long a = reinterpret_cast<unsigned long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long)hi_ << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+// voff: byte offset of the 8 channels from the resource base, bit 31 set = masked lane
+__device__ __forceinline__ void split_store_rs(__amdgpu_buffer_rsrc_t rs, int voff, long lo_off, const float (&v)[8]) {
+  h8 hv, lv;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { hv[e] = (half_t)v[e]; lv[e] = (half_t)(v[e] - (float)hv[e]); }
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(conv_u4, hv), rs, voff, 0, 0);
+  if (lo_off) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(conv_u4, lv), rs, voff + 2 * (int)lo_off, 0, 0);
+}
+#endif
+
+// The straight-line epilogue of a RESIDENT-PIXEL tile (csrc/conv_x3.hip, csrc/conv_x3n.hip): a lane holds, for each of its 4 tile rows nt, 4
+// pieces mp = 2 mt + pair of 8 consecutive couts co0 + 16 mp .. of ONE pixel (row oy0 + nt, column ox): acc[mt][nt][8 pair + e].
+//
+// What a tile's epilogue costs is not its arithmetic but the ORDER of its memory operations: gfx9's vmcnt counts loads and stores in one
+// in-order queue, so a load issued after a store cannot be waited for without sitting out that store's write acknowledgement (~2 us, more
+// while HBM absorbs a write stream).  As sixteen rows each loading its bias / operands and then storing, a tile paid sixteen of those in a
+// row (measured on the 64 -> 505 layer of config 5, N = 4: 9.8 ms per launch of which the K loop is 5.8, profiles/r06_x3n_ablation.txt).
+// Here: the bias -- plus the class-0 row of a position-class bias when the whole tile is interior -- is loaded for all four pieces BEFORE
+// the first store; launches with per-pixel operands (residual, old output, activation mask) load batch k + 1's operands before batch k's
+// stores (a batch = NB rows of one piece column), so every wait the compiler inserts is a counted one that leaves the stores in flight;
+// and the stores are unconditional in control flow (split_store_rs), so that the K loop that follows can start under them: the caller's
+// wait for the next tile's first halo chunk may leave CONV_TILE_STORES operations outstanding.
+// Loads of lanes outside the image / past the last channel octet go to clamped (valid) addresses and are discarded.
+// ``interior``: every pixel of the lane's four rows has position class 0 (the caller's wave-uniform test); border tiles of a class-bias
+// launch take the row-by-row path (class rows per pixel).
+#define CONV_TILE_STORES 16      // vector-memory stores every path of conv_epilogue_fast_tile issues per wave, at least
+#if defined(__HIP_DEVICE_COMPILE__)
+template <bool BNSTAT, int NB = 2>
+__device__ __forceinline__ void conv_epilogue_fast_tile(const ConvK& p, const EpiFast& fe, const f16v (&acc)[2][4], int co0, int n, int oy0,
+                                                        int ox, bool interior, float (&bsum)[4][8], float (&bsq)[4][8]) {
+  const int oxc = ox < p.OW ? ox : p.OW - 1;
+  const bool extra = fe.has_res || fe.has_old || fe.has_mask;
+  // one buffer resource per tile (wave-uniform base: the tile's first row), the lane's row / pixel / channel offset in the vector offset
+  const __amdgpu_buffer_rsrc_t rs = conv_make_rs(p.out16 + n * p.o_sn + (long)oy0 * p.o_sy);      // (the tile's first row is inside the image)
+  int oyc[4], rowoff[4];
+  bool valid[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int oy = oy0 + nt;
+    oyc[nt] = oy < p.OH ? oy : p.OH - 1;
+    valid[nt] = oy < p.OH && ox < p.OW;
+    rowoff[nt] = (2 * nt * (int)p.o_sy) | (valid[nt] ? 0 : (int)0x80000000);
+  }
+  const int pixoff = 2 * (int)(oxc * p.o_sx);
+  if (fe.has_cb && !interior) {
+    // border tile of a class-bias launch: row by row (1-2 % of the tiles)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+      for (int mp = 0; mp < 4; ++mp) {
+        const int co = co0 + 16 * mp;
+        const int coc = co < p.coutp ? co : p.coutp - 8;
+        float v[8], bias[8], brow[8], t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = acc[mp >> 1][nt][8 * (mp & 1) + e];
+          bias[e] = 0.f;
+        }
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int i = coc + e;
+            const float tb = p.bias[n * p.bias_sn + (i < p.cout ? i : p.cout - 1)];
+            bias[e] = i < p.cout ? tb : 0.f;
+          }
+        }
+        conv_class_bias_row(p, bias, coc, n, oyc[nt], oxc, brow);
+        h8 rr = {0, 0, 0, 0, 0, 0, 0, 0}, oo = {0, 0, 0, 0, 0, 0, 0, 0}, mm = {1, 1, 1, 1, 1, 1, 1, 1};
+        if (fe.has_res) rr = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oyc[nt] * p.r_sy + oxc * p.r_sx + coc);
+        if (fe.has_old) oo = *reinterpret_cast<const h8*>(p.out16 + n * p.o_sn + oyc[nt] * p.o_sy + oxc * p.o_sx + coc);
+        if (fe.has_mask) mm = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oyc[nt] * p.m_sy + oxc * p.m_sx + coc);
+        if (extra && !BNSTAT) conv_epilogue_fast_values<true, BNSTAT>(fe, v, brow, co, rr, oo, bsum[mp], bsq[mp], mm, t, valid[nt] && co < p.coutp);
+        else conv_epilogue_fast_values<false, BNSTAT>(fe, v, brow, co, rr, oo, bsum[mp], bsq[mp], mm, t, valid[nt] && co < p.coutp);
+        split_store_rs(rs, (rowoff[nt] + pixoff + 2 * coc) | (co >= p.coutp ? (int)0x80000000 : 0), fe.o_lo, t);
+        __builtin_amdgcn_sched_barrier(0);      // (keeps a piece's temporaries from being hoisted across the straight-line pieces: registers)
+      }
+    }
+    return;
+  }
+  // ---- bias (+ the interior class row) of the four pieces, before any store
+  float bias[4][8];
+#pragma unroll
+  for (int mp = 0; mp < 4; ++mp) {
+    const int co = co0 + 16 * mp;
+    const int coc = co < p.coutp ? co : p.coutp - 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[mp][e] = 0.f;
+    if (p.bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int i = coc + e;
+        const float t = p.bias[n * p.bias_sn + (i < p.cout ? i : p.cout - 1)];
+        bias[mp][e] = i < p.cout ? t : 0.f;
+      }
+    }
+    if (fe.has_cb) {
+      const float* cb = p.cbias + (size_t)n * (p.cb_mode == 0 ? 16 : 25) * p.coutp + (p.cb_mode == 0 ? 0 : 12 * (size_t)p.coutp) + coc;      // class 0 / the centre class (2, 2)
+      const f4 c0 = *reinterpret_cast<const f4*>(cb), c1 = *reinterpret_cast<const f4*>(cb + 4);
+      bias[mp][0] += c0[0]; bias[mp][1] += c0[1]; bias[mp][2] += c0[2]; bias[mp][3] += c0[3];
+      bias[mp][4] += c1[0]; bias[mp][5] += c1[1]; bias[mp][6] += c1[2]; bias[mp][7] += c1[3];
+    }
+  }
+  if (!extra) {
+    const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+      for (int mp = 0; mp < 4; ++mp) {
+        const int co = co0 + 16 * mp;
+        const int coc = co < p.coutp ? co : p.coutp - 8;
+        float v[8], t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[mp >> 1][nt][8 * (mp & 1) + e];
+        conv_epilogue_fast_values<false, BNSTAT>(fe, v, bias[mp], co, z, z, bsum[mp], bsq[mp], z, t, valid[nt] && co < p.coutp);
+        split_store_rs(rs, (rowoff[nt] + pixoff + 2 * coc) | (co >= p.coutp ? (int)0x80000000 : 0), fe.o_lo, t);
+        __builtin_amdgcn_sched_barrier(0);      // (keeps a piece's temporaries from being hoisted across the straight-line pieces: registers)
+      }
+    }
+    return;
+  }
+  // ---- per-pixel operands: batches b = (piece column mp, rows nb .. nb + NB - 1), batch b + 1's loads ahead of batch b's stores
+  // (not together with fused BatchNorm sums: no such launch in the model, and that instance has no registers for both -- the launcher refuses)
+  if constexpr (BNSTAT) return;
+  constexpr int NBATCH = 4 * (4 / NB);
+  h8 rr[2][NB], oo[2][NB], mm[2][NB];
+  auto load_batch = [&](int b, int st) __attribute__((always_inline)) {
+    const int mp = b / (4 / NB), nb = (b % (4 / NB)) * NB;
+    const int co = co0 + 16 * mp;
+    const int coc = co < p.coutp ? co : p.coutp - 8;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const int oyr = oyc[nb + r];
+      rr[st][r] = h8{0, 0, 0, 0, 0, 0, 0, 0}; oo[st][r] = h8{0, 0, 0, 0, 0, 0, 0, 0}; mm[st][r] = h8{1, 1, 1, 1, 1, 1, 1, 1};
+      if (fe.has_res) rr[st][r] = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oyr * p.r_sy + oxc * p.r_sx + coc);
+      if (fe.has_old) oo[st][r] = *reinterpret_cast<const h8*>(p.out16 + n * p.o_sn + oyr * p.o_sy + oxc * p.o_sx + coc);
+      if (fe.has_mask) mm[st][r] = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oyr * p.m_sy + oxc * p.m_sx + coc);
+    }
+  };
+  load_batch(0, 0);
+#pragma unroll
+  for (int b = 0; b < NBATCH; ++b) {
+    if (b + 1 < NBATCH) load_batch(b + 1, (b + 1) & 1);
+    const int mp = b / (4 / NB), nb = (b % (4 / NB)) * NB;
+    const int co = co0 + 16 * mp;
+    const int coc = co < p.coutp ? co : p.coutp - 8;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      float v[8], t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = acc[mp >> 1][nb + r][8 * (mp & 1) + e];
+      conv_epilogue_fast_values<true, BNSTAT>(fe, v, bias[mp], co, rr[b & 1][r], oo[b & 1][r], bsum[mp], bsq[mp], mm[b & 1][r], t, valid[nb + r] && co < p.coutp);
+      split_store_rs(rs, (rowoff[nb + r] + pixoff + 2 * coc) | (co >= p.coutp ? (int)0x80000000 : 0), fe.o_lo, t);
+        __builtin_amdgcn_sched_barrier(0);      // (keeps a piece's temporaries from being hoisted across the straight-line pieces: registers)
+    }
+  }
+}
+#endif
 
 // per-thread partial statistics -> the workgroup's LDS bins sStat[2][BN], in a FIXED order.
 // CPR = channel chunks per staged row: lanes l, l+CPR, l+2CPR .. of a wave own the same 8 channels, so they are folded with

@@ -212,8 +212,11 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
       // vector-memory instructions issued after this chunk's last DMA piece (k-slice NFI - 1 of the previous chunk) are the weight
       // loads of the taps that followed it (8 each) -- except right after an epilogue, where the count is simply drained.
       if constexpr (STG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's staged pieces are in LDS
-      else if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NT - 1 - (NFI - 1) / 4)) : "memory");
+      else if (c == 0) {
+        // after an epilogue of the straight-line rows its CONV_TILE_STORES (unconditional buffer) stores may stay in flight (conv_common.h)
+        if ((ABL & 1024) != 0 && it != blockIdx.x) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((8 * (NT - 1 - (NFI - 1) / 4) + CONV_TILE_STORES) > 63 ? 63 : (8 * (NT - 1 - (NFI - 1) / 4) + CONV_TILE_STORES)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NT - 1 - (NFI - 1) / 4)) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const int bnext = (int)((par + c + 1) & 1);
@@ -265,50 +268,76 @@ __global__ __launch_bounds__(256) void conv_x3_kernel(const ConvK p, const X3Ext
 
     // ---- epilogue: acc[mt][nt][8 pair + e] = cout 128 ct + 64 mh + 32 mt + 16 pair + 8 hi + e of pixel (row 4 rq + nt, column pix)
     const int ox = X0 + pix;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int oy = Y0 + 4 * rq + nt;
+    if constexpr ((ABL & 1024) != 0) {
+      // straight-line rows (conv_common.h; the host picks the instance by conv_epilogue_fast_ok), every load ahead of the stores
+      float d0[4][8], d1[4][8];
+      const bool interior = Y0 + 4 * rq >= 2 && Y0 + 4 * rq + 3 <= p.OH - 3 && X0 >= 2 && X0 + 31 <= p.OW - 3;
+      conv_epilogue_fast_tile<false>(p, fe, acc, 128 * ct + 64 * mh + 8 * hi, n, Y0 + 4 * rq, ox, interior, d0, d1);
+    } else if constexpr ((ABL & 2048) != 0) {
+      // the SFT conv1's (kbpn.py:505-516): bias + sigmoid (the scale branch) or bias + res x res2 (the shift branch, whose epilogue
+      // finishes the layer: f x scale + shift) -- plain fp16 output, nothing else (x3_sft_rows_ok on the host); the same batching
+      const int oxc = ox < p.OW ? ox : p.OW - 1;
 #pragma unroll
       for (int mp = 0; mp < 4; ++mp) {
-        const int mt = mp >> 1, pair = mp & 1;
-        const int co = 128 * ct + 64 * mh + 32 * mt + 16 * pair + 8 * hi;
-        if (oy >= p.OH || ox >= p.OW || co >= p.coutp) continue;
-        float v[8], bias[8], s0[8], s1[8];
+        const int co = 128 * ct + 64 * mh + 16 * mp + 8 * hi;
+        const int coc = co < p.coutp ? co : p.coutp - 8;
+        float bias[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] = acc[mt][nt][8 * pair + e];
-          bias[e] = (p.bias && co + e < p.cout) ? p.bias[n * p.bias_sn + co + e] : 0.f;
-        }
-        if constexpr ((ABL & 1024) != 0) {      // straight-line row (conv_common.h; the host picks the instance by conv_epilogue_fast_ok): with one wave per SIMD nothing runs beside the 16 row pieces of a tile
-          half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
-          h8 rr = {0, 0, 0, 0, 0, 0, 0, 0}, oo = {0, 0, 0, 0, 0, 0, 0, 0}, mm = {1, 1, 1, 1, 1, 1, 1, 1};
-          if (fe.has_res) rr = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
-          if (fe.has_old) oo = *reinterpret_cast<const h8*>(o);
-          if (fe.has_mask) mm = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oy * p.m_sy + ox * p.m_sx + co);
-          float brow[8];
-          if (fe.has_cb) conv_class_bias_row(p, bias, co, n, oy, ox, brow);
-          else {
+        for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+        if (p.bias) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) brow[e] = bias[e];
+          for (int e = 0; e < 8; ++e) {
+            const int i_ = coc + e;
+            const float t = p.bias[n * p.bias_sn + (i_ < p.cout ? i_ : p.cout - 1)];
+            bias[e] = i_ < p.cout ? t : 0.f;
           }
-          if (fe.has_res || fe.has_old || fe.has_mask) conv_epilogue_fast_row<true, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
-          else conv_epilogue_fast_row<false, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
-        } else if constexpr ((ABL & 2048) != 0) {
-          // the SFT conv1's (kbpn.py:505-516): bias + sigmoid (the scale branch) or bias + res x res2 (the shift branch, whose epilogue
-          // finishes the layer: f x scale + shift) -- plain fp16 output, nothing else (x3_sft_rows_ok on the host)
+        }
+        h8 r1[4], r2[4];
+        int oyc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int oy = Y0 + 4 * rq + nt;
+          oyc[nt] = oy < p.OH ? oy : p.OH - 1;
+        }
+        if (p.act != CSBSR_ACT_SIGMOID) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            r1[nt] = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oyc[nt] * p.r_sy + oxc * p.r_sx + coc);
+            r2[nt] = *reinterpret_cast<const h8*>(p.res2 + n * p.r2_sn + oyc[nt] * p.r2_sy + oxc * p.r2_sx + coc);
+          }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int oy = Y0 + 4 * rq + nt;
+          if (oy >= p.OH || ox >= p.OW || co >= p.coutp) continue;
           half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
           h8 hv;
           if (p.act == CSBSR_ACT_SIGMOID) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = (half_t)(co + e < p.cout ? 1.f / (1.f + __expf(-(v[e] * p.out_scale + bias[e]))) : 0.f);
+            for (int e = 0; e < 8; ++e) hv[e] = (half_t)(co + e < p.cout ? 1.f / (1.f + __expf(-(acc[mp >> 1][nt][8 * (mp & 1) + e] * p.out_scale + bias[e]))) : 0.f);
           } else {
-            const h8 r1 = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
-            const h8 r2 = *reinterpret_cast<const h8*>(p.res2 + n * p.r2_sn + oy * p.r2_sy + ox * p.r2_sx + co);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hv[e] = (half_t)((co + e < p.cout ? v[e] * p.out_scale + bias[e] : 0.f) + (float)r1[e] * (float)r2[e]);
+            for (int e = 0; e < 8; ++e)
+              hv[e] = (half_t)((co + e < p.cout ? acc[mp >> 1][nt][8 * (mp & 1) + e] * p.out_scale + bias[e] : 0.f) + (float)r1[nt][e] * (float)r2[nt][e]);
           }
           *reinterpret_cast<h8*>(o) = hv;
-        } else {
+        }
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int oy = Y0 + 4 * rq + nt;
+#pragma unroll
+        for (int mp = 0; mp < 4; ++mp) {
+          const int mt = mp >> 1, pair = mp & 1;
+          const int co = 128 * ct + 64 * mh + 32 * mt + 16 * pair + 8 * hi;
+          if (oy >= p.OH || ox >= p.OW || co >= p.coutp) continue;
+          float v[8], bias[8], s0[8], s1[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] = acc[mt][nt][8 * pair + e];
+            bias[e] = (p.bias && co + e < p.cout) ? p.bias[n * p.bias_sn + co + e] : 0.f;
+          }
           conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, s0, s1);
         }
       }

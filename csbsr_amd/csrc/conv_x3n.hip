@@ -20,10 +20,14 @@
 #include "conv_common.h"
 #include "csbsr_debug.h"
 
+#ifndef XN_ABL
+#define XN_ABL 0                          // timing ablations (variant builds only): 1 no epilogue, 2 no MFMAs, 4 one wide workgroup per CU, 16 lean stores dropped
+#endif
 #define XN_TH 8
 #define XN_HH (XN_TH + 2)
 #define XN_SLOTS 5                        // 32 channels = 4 sixteen-byte slots + 1 pad slot
 #define XN_PITCH (XN_SLOTS * 16)
+#define XN_TPITCH 144                     // pitch of a pixel in the wide form's output transposition tile: 64 couts x 2 bytes + 16
 #define XN_NT 9
 #define XN_RING 3
 #define XN_DIST 2
@@ -58,10 +62,13 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t xn_make_rs(const half_t
 // statistics -- every lane keeps the sum and the sum of squares of its 32 output channels over all its tiles in registers, the lanes of a
 // wave fold by xor-shuffles, the four waves through LDS in wave order, and the workgroup writes ONE partial row; the launcher folds the rows
 // in a fixed tree (csbsr_sum_partials): order-fixed like every reduction of the library.
-template <bool FAST, bool BNS = false, bool WIDE = false>
+// LEAN (the wide form with FAST): the launch has no per-pixel epilogue operand (residual, accumulated-into output, activation mask); its epilogue
+// issues no vector-memory load between its stores (below).
+template <bool FAST, bool BNS = false, bool WIDE = false, bool LEAN = false>
 __global__ __launch_bounds__(256, WIDE ? 2 : 1) void conv_x3n_kernel(const ConvK p, const XNExtra q) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(!(BNS && WIDE), "fused BatchNorm sums: the narrow form");
+  static_assert(!LEAN || (WIDE && FAST), "LEAN: an instance of the wide form's straight-line rows");
   using G = XNGeo<WIDE>;
   constexpr int XN_TW = G::TW, XN_HW = G::HW, XN_NINST = G::NINST, XN_BUF = G::BUF, XN_WSTEP = G::WSTEP;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -160,12 +167,29 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 1) void conv_x3n_kernel(const ConvK
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     if constexpr (WIDE) __builtin_amdgcn_s_setprio(1);      // the K loop's MFMA issue ahead of the co-resident workgroup's epilogue
+    // WIDE: the tile's bias (plus the interior class row of a position-class bias) for the wave's 64 couts, one value per lane, loaded here
+    // and handed to the epilogue through LDS: no register of the 256 is free for 32 bias values, and a load issued between the
+    // epilogue's stores would have to sit out their write acknowledgement (conv_common.h, conv_epilogue_fast_tile)
+    float bv = 0.f, bcv = 0.f;
+    const bool interior = Y0 + 4 * rq >= 2 && Y0 + 4 * rq + 3 <= p.OH - 3 && X0 + 32 * chf >= 2 && X0 + 32 * chf + 31 <= p.OW - 3;      // (wave-uniform: position class 0 everywhere)
+    if constexpr (LEAN) {
+      const int cl = G::CT * ct + 64 * mh + lane;
+      const int clc = cl < p.cout ? cl : p.cout - 1;
+      if (p.bias) bv = p.bias[n * p.bias_sn + clc];
+      if (fe.has_cb && interior) bcv = p.cbias[((size_t)n * (p.cb_mode == 0 ? 16 : 25) + (p.cb_mode == 0 ? 0 : 12)) * p.coutp + (cl < p.coutp ? cl : p.coutp - 1)];
+      // (combined and written to the wave's LDS slot at the end of the first chunk: a counted wait, nine taps later)
+    }
     for (int c = 0; c < (int)q.nch; ++c) {
       // chunk c's halo has landed everywhere, and every wave is done with the other buffer (chunk c - 1): refill that one.  The only
       // vector-memory instructions issued after this chunk's last DMA piece (k-slice NFI - 1 = tap 6 of the previous chunk) are the
       // weight loads of the taps that followed it (4 each) -- except right after an epilogue, where the count is simply drained.
-      if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (XN_NT - 1 - (NFI - 1) / 2)) : "memory");
+      // The first chunk of a tile that follows an epilogue of the straight-line rows: that epilogue's CONV_TILE_STORES stores (at least:
+      // unconditional buffer stores, conv_common.h) were issued after the DMA pieces too and may stay in flight -- draining them here
+      // (vmcnt(0)) meant sitting out their write acknowledgement once per tile.
+      if (c == 0) {
+        if (((FAST && !WIDE) || LEAN) && it != blockIdx.x) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (XN_NT - 1 - (NFI - 1) / 2) + CONV_TILE_STORES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (XN_NT - 1 - (NFI - 1) / 2)) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       const int bnext = (int)((par + c + 1) & 1);
@@ -190,8 +214,13 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 1) void conv_x3n_kernel(const ConvK
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
+#if XN_ABL & 2
+            acc[0][i][0] += (float)wreg[tap % XN_RING][0][kk][0] * (float)bfr[i][0];
+            acc[1][i][0] += (float)wreg[tap % XN_RING][1][kk][0] * (float)bfr[i][0];
+#else
             acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap % XN_RING][0][kk], bfr[i], acc[0][i], 0, 0, 0);
             acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap % XN_RING][1][kk], bfr[i], acc[1][i], 0, 0, 0);
+#endif
             // the same row's fragment of the next k-slice / next tap (the next chunk starts over after its barrier)
             if (kk < 1) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + ky) * XN_HW + kx) * XN_PITCH + (kk + 1) * 32);
             else if (tap < XN_NT - 1) bfr[i] = *reinterpret_cast<const h8*>(xb + ((i + (tap + 1) / 3) * XN_HW + (tap + 1) % 3) * XN_PITCH);
@@ -200,44 +229,113 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 1) void conv_x3n_kernel(const ConvK
           }
         }
       }
+      if constexpr (LEAN) {
+        if (c == 0) reinterpret_cast<float*>(smem + 2 * XN_BUF)[wid * 64 + lane] = (G::CT * ct + 64 * mh + lane < p.cout) ? bv + bcv : 0.f;
+      }
     }
 
     if constexpr (WIDE) __builtin_amdgcn_s_setprio(0);
     // ---- epilogue: acc[mt][nt][8 pair + e] = cout CT ct + 64 mh + 32 mt + 16 pair + 8 hi + e of pixel (row 4 rq + nt, column 32 chf + pix)
     const int ox = X0 + 32 * chf + pix;
+#if XN_ABL & 1
+    if (p.N == 12345)
+#endif
+    if constexpr (FAST && !WIDE) {
+      // straight-line rows with every load ahead of the stores (conv_common.h)
+      conv_epilogue_fast_tile<BNS>(p, fe, acc, G::CT * ct + 64 * mh + 8 * hi, n, Y0 + 4 * rq, ox, interior, bsum, bsq);
+    } else if constexpr (LEAN) {
+      // the wide form's launches without per-pixel operands: bias through LDS (no vector-memory load in the epilogue; border tiles of a
+      // class-bias launch load the pixel's class row per piece), and the output TRANSPOSED through a wave-private LDS tile so that a store
+      // instruction writes whole lines: in the accumulator layout a lane owns 16 bytes of a pixel and its neighbour lane the next PIXEL
+      // (coutp x 2 bytes away) -- 64 separate 16-byte write requests per instruction, and the 64 -> 505 layer (13 GB of output) ran at the
+      // L2's request rate: 9.1 ms per launch against 6.8 with coalesced stores and 5.6 with none (profiles/r06_x3n_ablation.txt).  Row by
+      // row: the four pieces of a row go to LDS as [pixel][64 couts] (pitch 144 bytes: conflict-free 16-byte writes), come back as 8 lanes per
+      // pixel, and leave as four stores of 8 pixels x 128 bytes.  Unconditional buffer stores (conv_common.h).
+      const __amdgpu_buffer_rsrc_t rs = conv_make_rs(p.out16 + n * p.o_sn + (long)(Y0 + 4 * rq) * p.o_sy);
+      const int oxc = ox < p.OW ? ox : p.OW - 1;
+      const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      float s0[8], s1[8];
+      const float* bl = reinterpret_cast<const float*>(smem + 2 * XN_BUF) + wid * 64;
+      char* tt = smem + 2 * XN_BUF + 1024 + wid * (32 * XN_TPITCH);
+      const bool border_cb = fe.has_cb && !interior;
+      const int rpix = lane >> 3, rchunk = lane & 7;                       // read-back role: pixel rpix + 8 k, 16-byte chunk rchunk
+      const int rco = G::CT * ct + 64 * mh + 8 * rchunk;
+      const int rcobad = rco >= p.coutp ? (int)0x80000000 : 0;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int oy = Y0 + 4 * rq + nt;
+      for (int nt = 0; nt < 4; ++nt) {
+        const int oy = Y0 + 4 * rq + nt;
+        const int rowbad = oy >= p.OH ? (int)0x80000000 : 0;
+        // plane 0: the fp16 values; plane 1 (hi + lo outputs): the remainders, recomputed rather than kept (registers)
 #pragma unroll
-      for (int mp = 0; mp < 4; ++mp) {
-        const int mt = mp >> 1, pair = mp & 1;
-        const int co = G::CT * ct + 64 * mh + 32 * mt + 16 * pair + 8 * hi;
-        if (oy >= p.OH || ox >= p.OW || co >= p.coutp) continue;
-        float v[8], bias[8], s0[8], s1[8];
+        for (int plane = 0; plane < 2; ++plane) {
+          if (plane == 1 && !fe.o_lo) break;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] = acc[mt][nt][8 * pair + e];
-          bias[e] = (p.bias && co + e < p.cout) ? p.bias[n * p.bias_sn + co + e] : 0.f;
-        }
-        if constexpr (FAST) {
-          half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
-          h8 rr = {0, 0, 0, 0, 0, 0, 0, 0}, oo = {0, 0, 0, 0, 0, 0, 0, 0}, mm = {1, 1, 1, 1, 1, 1, 1, 1};
-          if (fe.has_res) rr = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
-          if (fe.has_old) oo = *reinterpret_cast<const h8*>(o);
-          if (fe.has_mask) mm = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oy * p.m_sy + ox * p.m_sx + co);
-          float brow[8];
-          if (fe.has_cb) conv_class_bias_row(p, bias, co, n, oy, ox, brow);
-          else {
+          for (int mp = 0; mp < 4; ++mp) {
+            const int co = G::CT * ct + 64 * mh + 16 * mp + 8 * hi;
+            const int coc = co < p.coutp ? co : p.coutp - 8;
+            const f4 b0 = *reinterpret_cast<const f4*>(bl + 16 * mp + 8 * hi), b1 = *reinterpret_cast<const f4*>(bl + 16 * mp + 8 * hi + 4);
+            float v[8], t[8], brow[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) brow[e] = bias[e];
+            for (int e = 0; e < 8; ++e) v[e] = acc[mp >> 1][nt][8 * (mp & 1) + e];
+            if (border_cb) {
+              const float bias[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+              conv_class_bias_row(p, bias, coc, n, oy < p.OH ? oy : p.OH - 1, oxc, brow);
+            }
+            conv_epilogue_fast_values<false, false>(fe, v, brow, co, z, z, s0, s1, z, t);
+            h8 hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              hv[e] = (half_t)t[e];
+              if (plane == 1) hv[e] = (half_t)(t[e] - (float)hv[e]);
+            }
+            *reinterpret_cast<h8*>(tt + pix * XN_TPITCH + (16 * mp + 8 * hi) * 2) = hv;
           }
-          if constexpr (BNS) {
-            if (fe.has_res || fe.has_old || fe.has_mask) conv_epilogue_fast_row<true, true>(fe, v, brow, co, o, rr, oo, bsum[mp], bsq[mp], mm);
-            else conv_epilogue_fast_row<false, true>(fe, v, brow, co, o, rr, oo, bsum[mp], bsq[mp], mm);
-          } else if (fe.has_res || fe.has_old || fe.has_mask) conv_epilogue_fast_row<true, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
-          else conv_epilogue_fast_row<false, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
-        } else {
-          conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, s0, s1);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int px = rpix + 8 * k;
+            const h8 o = *reinterpret_cast<const h8*>(tt + px * XN_TPITCH + rchunk * 16);
+            const int voff = (2 * nt * (int)p.o_sy + 2 * (int)((X0 + px) * p.o_sx) + 2 * rco) | rowbad | rcobad | (X0 + px >= p.OW ? (int)0x80000000 : 0);
+#if XN_ABL & 16
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(conv_u4, o), rs, voff | (int)0x80000000, 0, 0);
+#else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(conv_u4, o), rs, voff + (plane ? 2 * (int)fe.o_lo : 0), 0, 0);
+#endif
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int oy = Y0 + 4 * rq + nt;
+#pragma unroll
+        for (int mp = 0; mp < 4; ++mp) {
+          const int mt = mp >> 1, pair = mp & 1;
+          const int co = G::CT * ct + 64 * mh + 32 * mt + 16 * pair + 8 * hi;
+          if (oy >= p.OH || ox >= p.OW || co >= p.coutp) continue;
+          float v[8], bias[8], s0[8], s1[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] = acc[mt][nt][8 * pair + e];
+            bias[e] = (p.bias && co + e < p.cout) ? p.bias[n * p.bias_sn + co + e] : 0.f;
+          }
+          if constexpr (FAST) {      // (the wide form with per-pixel operands: row by row)
+            half_t* o = p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co;
+            h8 rr = {0, 0, 0, 0, 0, 0, 0, 0}, oo = {0, 0, 0, 0, 0, 0, 0, 0}, mm = {1, 1, 1, 1, 1, 1, 1, 1};
+            if (fe.has_res) rr = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
+            if (fe.has_old) oo = *reinterpret_cast<const h8*>(o);
+            if (fe.has_mask) mm = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oy * p.m_sy + ox * p.m_sx + co);
+            float brow[8];
+            if (fe.has_cb) conv_class_bias_row(p, bias, co, n, oy, ox, brow);
+            else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) brow[e] = bias[e];
+            }
+            if (fe.has_res || fe.has_old || fe.has_mask) conv_epilogue_fast_row<true, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
+            else conv_epilogue_fast_row<false, false>(fe, v, brow, co, o, rr, oo, s0, s1, mm);
+          } else {
+            conv_epilogue_row(p, v, bias, slope, co, n, oy, ox, s0, s1);
+          }
         }
       }
     }
@@ -351,18 +449,18 @@ extern "C" int32_t csbsr_conv_x3n_eligible(const csbsr_conv_desc_t* d) {
     if (mode == 3 || d->stat_mode != CSBSR_STAT_NONE || d->in[0].c > ((g_conv_x3n_mode & 4) ? (1 << 20) : 384)) return 0;
   } else {
     if (d->stat_mode != CSBSR_STAT_NONE && d->stat_mode != CSBSR_STAT_BN) return 0;    // (BatchNorm sums: the straight-line rows only, see the launcher)
-    if (d->stat_mode == CSBSR_STAT_BN && (d->r_lo || d->r2_lo)) return 0;              // (split residual operands: the general row)
+    if (d->stat_mode == CSBSR_STAT_BN && (d->r_lo || d->r2_lo || d->res_mode != CSBSR_RES_NONE || d->accumulate || d->mask)) return 0;      // (BatchNorm sums: no per-pixel operand)
   }
   if (mode != 2 && (long)d->N * d->OH * d->OW < 512L * XN_TH * 64) return 0;
   return wide ? 2 : 1;
 }
 
-template <bool FAST, bool BNS = false, bool WIDE = false>
+template <bool FAST, bool BNS = false, bool WIDE = false, bool LEAN = false>
 static int launch_x3n(const ConvK& k, const XNExtra& q, unsigned g, hipStream_t st) {
-  constexpr int SM_BYTES = 2 * XNGeo<WIDE>::BUF;
+  constexpr int SM_BYTES = 2 * XNGeo<WIDE>::BUF + (WIDE ? 1024 + 4 * 32 * XN_TPITCH : 0);      // (wide: + the four waves' bias slots and output transposition tiles)
   static LdsAttrOnce attr;
-  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_x3n_kernel<FAST, BNS, WIDE>), SM_BYTES, "conv_x3n")) return e;
-  hipLaunchKernelGGL((conv_x3n_kernel<FAST, BNS, WIDE>), dim3(g), dim3(256), SM_BYTES, st, k, q);
+  if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_x3n_kernel<FAST, BNS, WIDE, LEAN>), SM_BYTES, "conv_x3n")) return e;
+  hipLaunchKernelGGL((conv_x3n_kernel<FAST, BNS, WIDE, LEAN>), dim3(g), dim3(256), SM_BYTES, st, k, q);
   CSBSR_LAUNCH_CHECK("csbsr_conv_x3n_forward");
   return 0;
 }
@@ -379,17 +477,20 @@ extern "C" int csbsr_conv_x3n_forward(const csbsr_conv_desc_t* d, csbsr_stream_t
   XNExtra q;
   q.tiles_x = (unsigned)((d->OW + tw - 1) / tw); q.tiles_y = (unsigned)((d->OH + XN_TH - 1) / XN_TH);
   q.nct = (unsigned)((d->coutp + ctile - 1) / ctile); q.nch = (unsigned)(d->in[0].c / 32);
-  const int slots = csbsr_cu_budget(reinterpret_cast<hipStream_t>(s)) * (wide ? 2 : 1);      // (wide: two workgroups per CU)
+  const int slots = csbsr_cu_budget(reinterpret_cast<hipStream_t>(s)) * ((wide && !(XN_ABL & 4)) ? 2 : 1);      // (wide: two workgroups per CU)
   const unsigned items = q.tiles_x * q.tiles_y * (unsigned)d->N * q.nct;
   const unsigned g = items < (unsigned)slots ? items : (unsigned)slots;
   const bool fast_rows = conv_epilogue_fast_ok(k);
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   if (wide) {
-    g_last_conv_kernel = CONVK_X3N | (fast_rows ? 1 : 0) << 8 | 4 << 8;
+    const bool lean = fast_rows && k.res_mode == CSBSR_RES_NONE && !k.accumulate && !k.mask;
+    g_last_conv_kernel = CONVK_X3N | (fast_rows ? 1 : 0) << 8 | 4 << 8 | (lean ? 8 : 0) << 8;
+    if (lean) return launch_x3n<true, false, true, true>(k, q, g, st);
     return fast_rows ? launch_x3n<true, false, true>(k, q, g, st) : launch_x3n<false, false, true>(k, q, g, st);
   }
   if (k.stat_mode == CSBSR_STAT_BN) {
-    CSBSR_CHECK(fast_rows && q.nct == 1 && k.stat, "conv_x3n: fused BatchNorm sums need the straight-line epilogue rows and one cout tile");
+    CSBSR_CHECK(fast_rows && q.nct == 1 && k.stat && k.res_mode == CSBSR_RES_NONE && !k.accumulate && !k.mask,
+                "conv_x3n: fused BatchNorm sums need the straight-line epilogue rows without per-pixel operands and one cout tile");
     k.stat_ld = 2 * (long)k.coutp;
     k.stat_part = csbsr_red_scratch((long)g * k.stat_ld);
     CSBSR_NEED_SCRATCH(k.stat_part, "conv_x3n (fused statistics)");
