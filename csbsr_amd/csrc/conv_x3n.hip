@@ -432,14 +432,14 @@ extern "C" void csbsr_debug_set_conv_x3n(int mode) { g_conv_x3n_mode = mode & 7;
 // two-product plan) --, fp16 output (hi + lo pairs allowed), any fused epilogue of the general kernels (split residual operands included:
 // BlurSkip's conv_shift.1 combines x * scale + shift on hi + lo pairs) except sample statistics, the fp32 side output and the fused
 // epilogue-backward sums.  Narrow: 33 .. 64 padded output channels from >= 64 (mode 2: >= 32) input channels, BatchNorm sums allowed.  Wide:
-// more than 64 padded output channels from 64 .. 384 input channels (measured against csrc/conv_x3.hip's whole-K-resident tile, one launch
+// more than 64 padded output channels from 32 .. 384 input channels (measured against csrc/conv_x3.hip's whole-K-resident tile, one launch
 // of the batch of 8 at 448^2: 128 -> 569 2.94 -> 2.42 ms, 256 -> 697 5.39 -> 4.94, 384 -> 825 8.47 -> 8.25, 825 -> 825 16.7 -> 17.2: the
 // overlapped epilogue is worth less and the twice-staged weights more as K grows).
 extern "C" int32_t csbsr_conv_x3n_eligible(const csbsr_conv_desc_t* d) {
   const int mode = g_conv_x3n_mode & 3;
   if (!d || !mode || d->transposed || d->KH != 3 || d->KW != 3 || d->dil != 1) return 0;
   if (d->stride != 1 || d->pad != 1 || d->OH != d->H || d->OW != d->W) return 0;
-  if (d->in[0].c % 32 != 0 || d->in[0].c < (mode == 2 ? 32 : 64)) return 0;
+  if (d->in[0].c % 32 != 0 || d->in[0].c < ((mode == 2 || d->coutp > 64) ? 32 : 64)) return 0;
   if (d->in[1].c != 0 || d->in[0].sx == 0 || (d->split_fused != 0 && d->split_fused != 2)) return 0;
   if (d->coutp <= 32 || !d->out16 || d->out32) return 0;
   if (d->dact_bias || d->dact_prelu || d->dres) return 0;

@@ -551,7 +551,10 @@ class Conv:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         # full-resolution 32 / 49-channel 3x3 layers: the direct kernel (csrc/conv_hr.hip) with its own fragment-ordered weights
-        if hr is not None and self.eng.use_hr and L.load().csbsr_conv_hr_eligible(C.byref(d)):
+        # (the wide form of conv_x3n goes first: the one launch both take -- the 32 -> 128-channel gather of a stage's thin dgrads at full
+        # resolution -- measured 4.8 -> 2.6 ms on it, csrc/conv_x3n.hip)
+        xn = (L.load().csbsr_conv_x3n_eligible(C.byref(d)) if (x3n is not None and self.eng.use_x3n and (not x0.lo or split_blocks == 5)) else 0)
+        if xn != 2 and hr is not None and self.eng.use_hr and L.load().csbsr_conv_hr_eligible(C.byref(d)):
             kind, c_real, rows_real, row_off = hr
             key = ("hr", kind, row_off)
             if key not in self._packed:
@@ -562,7 +565,7 @@ class Conv:
                 self._packed[key] = dst
             d.wt = _ptr(self._packed[key])
             L.call("csbsr_conv_hr_forward", C.byref(d), self.eng.stream)
-        elif (x3n is not None and self.eng.use_x3n and (not x0.lo or split_blocks == 5) and L.load().csbsr_conv_x3n_eligible(C.byref(d))):
+        elif xn:
             # many input channels -> <= 64 output channels at full resolution (PSPNet_BlurSkip's conv1's, the dgrads of its conv0's): resident
             # pixel tile + streamed fragment-ordered weights (csrc/conv_x3n.hip); a split input runs its two-product plan as 2 x Cp plain
             # channels against [w | w] (the tap-sum-rounded, pre-scaled weights repeated for the lo plane)

@@ -536,31 +536,43 @@ def test_thin_strided_dgrad_kernel(k, s, N, h, w):
 
 
 def test_hr_direct_conv_kernel_128_couts():
-    """32 -> 128 channels on the direct kernel (two groups of workgroups, two 32-cout tiles each): the launch that gathers a stage's slice
-    of the concatenated feature gradient from the 3-channel dPre slots (KBPN._gather_conv) -- forward form, and the dgrad form the
-    backward actually uses (a conv with 32 'output' channels whose dgrad has 128), plain epilogue, ragged tiles."""
+    """32 -> 128 channels: the launch that gathers a stage's slice of the concatenated feature gradient from the 3-channel dPre slots
+    (KBPN._gather_conv) -- forward form, and the dgrad form the backward actually uses (a conv with 32 'output' channels whose dgrad has
+    128), plain epilogue, ragged tiles.  Since round 6 the wide form of conv_x3n takes it (one 32-channel chunk of K, LDS-transposed
+    whole-line stores: 4.8 -> 2.6 ms at the model's size); with that form off (debug mode 3) the direct kernel (two groups of workgroups,
+    two 32-cout tiles each) still does.  Both against autograd, and against each other."""
     from csbsr_amd import _lib as L
     from csbsr_amd.engine import Conv
     torch.manual_seed(5)
     eng = _eng()
+    lib = L.load()
     N, H, W = 2, 363, 371
     x = torch.randn(N, 32, H, W).half().float()
     x[:, 3:8] = 0
     w = (torch.randn(128, 32, 3, 3) / 17.0).half().float()
-    conv = Conv(eng, "l", {"l.weight": w.cuda()}, 3, 1, 1, 1, bias=False)
-    y = conv.fwd(to_fm(eng, x))
-    torch.cuda.synchronize()
-    assert (L.load().csbsr_debug_last_conv_kernel() & 255) == 8
-    assert relmax(from_fm(y), F.conv2d(x, w, None, 1, 1)) < 2e-3
     wt = (torch.randn(32, 128, 3, 3) / 17.0).half().float()          # a conv 128 -> 32: its dgrad maps 32 channels to 128
-    conv2 = Conv(eng, "m", {"m.weight": wt.cuda()}, 3, 1, 1, 1, bias=False)
     xr = torch.zeros(N, 128, H, W, requires_grad=True)
     F.conv2d(xr, wt, None, 1, 1).backward(x)
-    out = eng.new(N, H, W, 128)
-    conv2.bwd_input(to_fm(eng, x), out=out, accumulate=False)
-    torch.cuda.synchronize()
-    assert (L.load().csbsr_debug_last_conv_kernel() & 255) == 8
-    assert relmax(from_fm(out), xr.grad) < 2e-3
+    ref = F.conv2d(x, w, None, 1, 1)
+    outs = []
+    for xn_mode, kid in ((1, 20), (3, 8)):
+        lib.csbsr_debug_set_conv_x3n(xn_mode)
+        try:
+            conv = Conv(eng, "l", {"l.weight": w.cuda()}, 3, 1, 1, 1, bias=False)
+            y = conv.fwd(to_fm(eng, x))
+            torch.cuda.synchronize()
+            assert (lib.csbsr_debug_last_conv_kernel() & 255) == kid
+            conv2 = Conv(eng, "m", {"m.weight": wt.cuda()}, 3, 1, 1, 1, bias=False)
+            out = eng.new(N, H, W, 128)
+            conv2.bwd_input(to_fm(eng, x), out=out, accumulate=False)
+            torch.cuda.synchronize()
+            assert (lib.csbsr_debug_last_conv_kernel() & 255) == kid
+        finally:
+            lib.csbsr_debug_set_conv_x3n(1)
+        outs.append((from_fm(y), from_fm(out)))
+        assert relmax(outs[-1][0], ref) < 2e-3
+        assert relmax(outs[-1][1], xr.grad) < 2e-3
+    assert relmax(outs[0][0], outs[1][0]) < 1e-3 and relmax(outs[0][1], outs[1][1]) < 1e-3
 
 
 @pytest.mark.parametrize("k,s,p,cin,cout,H,W,mode", [
