@@ -15,8 +15,8 @@
 //  * pixel fragments are ds_read_b128 at (per-phase lane base + compile-time offset): odd 16-byte pixel pitch, no swizzle, 0 bank
 //    conflicts (SQ_LDS_BANK_CONFLICT); one read per MFMA, issued eight MFMAs ahead into the register the MFMA has just consumed;
 //  * D = W x X^T orientation with the couts of a 32-row tile permuted in the pack (cout 16 (q/2) + 8 h + 4 (q%2) + j on MFMA row 8 q + 4 h + j): a
-//    lane's accumulator registers are two octets of consecutive output channels of one pixel, no cross-lane exchange -- the epilogue (bias, PReLU, residual add / subtract, accumulate, activation-derivative mask) runs in registers with 16-byte loads and
-//    stores, no LDS staging;
+//    lane's accumulator registers are two octets of consecutive output channels of one pixel, no cross-lane exchange -- the epilogue (bias, PReLU, residual add / subtract, accumulate, activation-derivative mask) runs in registers with 16-byte operand loads;
+//    the finished row is transposed through a wave-private 2.5 KB LDS tile so that its stores are 64 contiguous bytes per pixel (round 6);
 //  * the epilogue of phase i is software-pipelined under the K loop of phase i + 1 (second accumulator set): two 8-cout x 32-pixel
 //    pieces per K step, their residual / old-output / mask operands loaded one step ahead, their arithmetic cut into chunks that sit
 //    in the MFMA shadows (the wave is alone on its SIMD and issues in order; __builtin_amdgcn_sched_barrier pins the order).  Which
@@ -37,6 +37,7 @@
 #define TP_NPIX (TP_HH * TP_HW)          // 340 halo pixels
 #define TP_STAGE 16384                   // bytes of one K step's weights: 128 couts x 64 channels, [cout tile][k-slice][lane][8]
 #define TP_MAXPG 8                       // phases per work item
+#define TP_TPITCH 80                     // pitch of a pixel in a wave's output transposition tile: its 32 couts x 2 bytes + 16
 
 struct ConvTpK {
   const half_t* in; long i_sn, i_sy, i_sx;
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
   constexpr int BOFF = XBYTES;                          // 128 biases
   constexpr int DOFF = BOFF + 512;                      // 1 KB landing area for the halo DMA's padding instructions
   constexpr int SOFF = DOFF + 1024;                     // HAS_STAT: per-lane bias-gradient partial sums, [wave][octet half 0..3][lane] float4
+  constexpr int TOFF = SOFF + 4 * 256 * 16 + 1024;      // output transposition tiles: [wave][32 pixels][TP_TPITCH]
   constexpr int NKS = 4 * NKC;                          // K steps per phase (64 channels of one tap each)
   constexpr int PPS = 16 / NKS;                         // epilogue pieces (of the previous phase) drained per K step
   constexpr int NFI = (NINST + 3) / 4;
@@ -190,28 +192,50 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
       }
     }
   };
-  auto store_fin = [&](const TpCtx& c, int pi, const float (&v)[8], const float (&vd)[9]) __attribute__((always_inline)) {
+  // A row's two pieces leave TRANSPOSED: in the accumulator layout a lane owns 16 bytes of its pixel and the neighbour lane the next pixel
+  // of the phase (stride x coutp x 2 bytes away), so a store instruction was 64 separate 16-byte write requests.  The two octet pairs of
+  // a row go to a wave-private LDS tile [pixel][32 couts] (pitch 80 bytes: conflict-free 16-byte writes), come back as four lanes per
+  // pixel, and leave as two stores of 16 pixels x 64 bytes.  Measured in the training step (config 2, same-box ABAB x 4, the 21 launches per
+  // micro-batch): 974.1 -> 966.9 ms per step; a plain launch alone (N = 8, nothing but stores in its epilogue) does not move (3.61 -> 3.66
+  // ms; 3.14 with the stores sent to the contiguous sink): what the fewer, larger write requests buy is room for the OTHER requests -- the
+  // residual / old-output / mask reads of the launches that have them.  (Those reads fetched the same way -- LDS-DMA into a ring, read back
+  // in the accumulator layout -- measured worse, 966.9 -> 971.5: the counted wait and the extra LDS reads sit in the K loop; not kept.)
+  char* const tt = smem + TOFF + wid * (32 * TP_TPITCH);
+  const int rpx = lane >> 2, rch = lane & 3;                     // read-back role: pixel rpx + 16 k, 16-byte chunk rch
+  const unsigned lane_o2 = 2u * (unsigned)((s * rpx) * (int)p.o_sx + 32 * wid + 8 * rch), half_o2 = 2u * (unsigned)((s * 16) * (int)p.o_sx);
+  auto fin_piece = [&](const TpCtx& c, int pi, const float (&v)[8], const float (&vd)[9]) __attribute__((always_inline)) {
     const int nt = pi >> 1, pair = pi & 1;
     h8 hv;
 #pragma unroll
     for (int e = 0; e < 8; ++e) hv[e] = (half_t)v[e];
-    const bool lv = pix < c.xlim && nt < c.ylim && 32 * wid + 16 * pair + 8 * hi < p.coutp && !(p.dbg & 1);
-    const unsigned off = lane_o + c.to + nt * row_o + 32 * pair;
-    char* dst = lv ? const_cast<char*>(c.ob) + off : sink_l;
-    *reinterpret_cast<h8*>(dst) = hv;
+    *reinterpret_cast<h8*>(tt + pix * TP_TPITCH + pair * 32 + hi * 16) = hv;
     if (HAS_STAT) {
       f4 a = sSb[64 * (2 * pair)], b = sSb[64 * (2 * pair + 1)];
       a += f4{v[0], v[1], v[2], v[3]}; b += f4{v[4], v[5], v[6], v[7]};
       sSb[64 * (2 * pair)] = a; sSb[64 * (2 * pair + 1)] = b;
       *sSpL += vd[8];
     }
-    if (HAS_STAT && HAS_RES) {
+    if (HAS_STAT && HAS_RES) {      // (the second output of the three residual + mask launches: as before, 16 bytes per lane)
       h8 hd;
 #pragma unroll
       for (int e = 0; e < 8; ++e) hd[e] = (half_t)vd[e];
+      const bool lv = pix < c.xlim && nt < c.ylim && 32 * wid + 16 * pair + 8 * hi < p.coutp && !(p.dbg & 1);
       const unsigned offd = lane_d + c.td + nt * row_d + 32 * pair;
       char* dd = lv ? const_cast<char*>(c.db) + offd : sink_l;
       *reinterpret_cast<h8*>(dd) = hd;
+    }
+  };
+  auto fin_read = [&](h8 (&tro)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) tro[k] = *reinterpret_cast<const h8*>(tt + (rpx + 16 * k) * TP_TPITCH + rch * 16);
+  };
+  auto fin_store = [&](const TpCtx& c, int nt, const h8 (&tro)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool lv = rpx + 16 * k < c.xlim && nt < c.ylim && 32 * wid + 8 * rch < p.coutp && !(p.dbg & 1);
+      const unsigned off = lane_o2 + k * half_o2 + c.to + nt * row_o;
+      char* dst = lv ? const_cast<char*>(c.ob) + off : sink_l;
+      *reinterpret_cast<h8*>(dst) = tro[k];
     }
   };
 
@@ -319,6 +343,7 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
       __builtin_amdgcn_sched_barrier(0);
       float v[PPS][8], vdd[HAS_STAT ? PPS : 1][9];     // [8]: the piece's slope-gradient sum
       f4 bq[PPS][2];
+      h8 tro[2];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const h8 af = wreg[ks % (WD + 1)][kk];
@@ -331,13 +356,17 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
           else if (ks + 1 < NKS) bfr[i] = rdb(xph, ks + 1, 0, i);
           else bfr[i] = rdb(xphn, 0, 0, i);
           // the pending pieces' arithmetic and stores, one chunk per MFMA shadow, spread over the four k-slices
-          if (PIPE)
-#pragma unroll
-          for (int pp = 0; pp < PPS; ++pp) {
-            const int k_act = 2 * pp, k_st = k_act + 1;
-            if (kk == k_act && i < 4) act_chunk(pd, ks * PPS + pp, i, v[pp], bq[pp]);
-            if (kk == k_st && i < 4) store_chunk((ks * PPS + pp) & 1, i, v[pp], vdd[HAS_STAT ? pp : 0], lr[ks % NB][pp], lo[ks % NB][pp], lm[ks % NB][pp]);
-            if (kk == k_st && i == 4) store_fin(pend, ks * PPS + pp, v[pp], vdd[HAS_STAT ? pp : 0]);
+          // piece 0 (octet pair 0 of row ks): activation in k-slice 0, operands in 1, to the transposition tile at (1, 4); piece 1: (1, 4..7),
+          // 2, (2, 4); the row comes back at (2, 6) and leaves at (3, 4) -- five MFMAs between the LDS reads and their use
+          if (PIPE) {
+            if (kk == 0 && i < 4) act_chunk(pd, ks * PPS, i, v[0], bq[0]);
+            if (kk == 1 && i < 4) store_chunk(0, i, v[0], vdd[0], lr[ks % NB][0], lo[ks % NB][0], lm[ks % NB][0]);
+            if (kk == 1 && i == 4) fin_piece(pend, ks * PPS, v[0], vdd[0]);
+            if (kk == 1 && i >= 4) act_chunk(pd, ks * PPS + 1, i - 4, v[1], bq[1]);
+            if (kk == 2 && i < 4) store_chunk(1, i, v[1], vdd[HAS_STAT ? 1 : 0], lr[ks % NB][1], lo[ks % NB][1], lm[ks % NB][1]);
+            if (kk == 2 && i == 4) fin_piece(pend, ks * PPS + 1, v[1], vdd[HAS_STAT ? 1 : 0]);
+            if (kk == 2 && i == 6) fin_read(tro);
+            if (kk == 3 && i == 4) fin_store(pend, ks, tro);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -377,7 +406,12 @@ __global__ __launch_bounds__(256) void conv_tp_kernel(const ConvTpK p, const hal
     float vd[9];
 #pragma unroll
     for (int c = 0; c < 4; ++c) store_chunk(pi & 1, c, v, vd, r, o, m);
-    store_fin(pend, pi, v, vd);
+    fin_piece(pend, pi, v, vd);
+    if (pi & 1) {
+      h8 tro[2];
+      fin_read(tro);
+      fin_store(pend, pi >> 1, tro);
+    }
   }
   if (HAS_STAT) {
     // lanes of one half-wave hold the same couts (32 wid + 16 pair + 8 hi + e at sb[8 pair + e]) for 32 different pixels
@@ -497,7 +531,7 @@ template <int NKC, bool R, bool A, bool M, bool S>
 static int launch_tp(ConvTpK& k, hipStream_t st, half_t* zp, float* dbias, float* dprelu) {
   constexpr int SLOTS = NKC * 8 + 1;
   constexpr int NINST = (TP_NPIX * SLOTS + 63) / 64;
-  constexpr int SM_BYTES = NINST * 1024 + 128 * 4 + 1024 + 4 * 256 * 16 + 1024;
+  constexpr int SM_BYTES = NINST * 1024 + 128 * 4 + 1024 + 4 * 256 * 16 + 1024 + 4 * 32 * TP_TPITCH;
   static_assert(SM_BYTES <= 160 * 1024, "LDS budget");
   static LdsAttrOnce attr;
   if (int e = csbsr_lds_attr(attr, reinterpret_cast<const void*>(conv_tp_kernel<NKC, R, A, M, S>), SM_BYTES, "conv_tp")) return e;
