@@ -31,7 +31,7 @@ def conv_row(kid):
     if base in (21, 22):
         return "head1_fwd_kernel" if base == 21 else "head1_bwd_input_kernel"
     if base == 20:
-        return "conv_x3n_kernel<%d,%d%s>" % (var & 1, (var >> 1) & 1, ",wide" if var & 4 else "")
+        return "conv_x3n_kernel<%d,%d%s%s>" % (var & 1, (var >> 1) & 1, ",wide" if var & 4 else "", ",lean" if var & 8 else "")
     return _CONV.get(base, f"conv?{base}")
 
 
@@ -72,9 +72,11 @@ def canon(name):
     m = re.search(r"conv_tp_kernelILi\d+ELb(\d)ELb(\d)ELb(\d)ELb(\d)E", name) or re.search(r"conv_tp_kernel<\d+, (\w+), (\w+), (\w+), (\w+)>", name)
     if m:
         return "conv_tp_kernel<res=%s,acc=%s,mask=%s,sums=%s>" % tuple(_b(x) for x in m.groups())
-    m = re.search(r"conv_x3n_kernelILb(\d)ELb(\d)ELb(\d)E", name) or re.search(r"conv_x3n_kernel<(\w+), (\w+), (\w+)>", name)
+    m = (re.search(r"conv_x3n_kernelILb(\d)ELb(\d)ELb(\d)ELb(\d)E", name)
+         or re.search(r"conv_x3n_kernel<(\w+), (\w+), (\w+), (\w+)>", name))
     if m:
-        return "conv_x3n_kernel<%s,%s%s>" % (_b(m.group(1)), _b(m.group(2)), ",wide" if _b(m.group(3)) == "1" else "")
+        return "conv_x3n_kernel<%s,%s%s%s>" % (_b(m.group(1)), _b(m.group(2)), ",wide" if _b(m.group(3)) == "1" else "",
+                                               ",lean" if _b(m.group(4)) == "1" else "")
     m = re.search(r"conv_x3w_kernelILi(\d)E", name) or re.search(r"conv_x3w_kernel<(\d)>", name)
     if m:
         return "conv_x3w_kernel<%s>" % m.group(1)

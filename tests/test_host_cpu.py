@@ -286,6 +286,10 @@ def test_kernel_row_names_agree_between_bench_and_profiles():
         (10 | (1 << 8), "_Z14conv_x3_kernelILi3ELi2048EEv5ConvK7X3ExtraPKDF16_"),
         (18, "_Z14conv_x3_kernelILi2ELi1024EEv5ConvK7X3ExtraPKDF16_"),
         (13, "void conv_thin_cin2_kernel<false>(ConvK, int, int, int, int, Cin2Dact)"),
+        (20 | ((1 | 4 | 8) << 8), "void conv_x3n_kernel<true, false, true, true>(ConvK, XNExtra)"),
+        (20 | ((1 | 4) << 8), "_Z15conv_x3n_kernelILb1ELb0ELb1ELb0EEv5ConvK7XNExtra"),
+        (20 | (3 << 8), "_Z15conv_x3n_kernelILb1ELb1ELb0ELb0EEv5ConvK7XNExtra"),
+        (20, "void conv_x3n_kernel<false, false, false, false>(ConvK, XNExtra)"),
     ]
     for kid, raw in pairs:
         assert conv_row(kid) == canon(raw), (kid, conv_row(kid), canon(raw))
