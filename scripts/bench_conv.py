@@ -57,6 +57,7 @@ if __name__ == "__main__":
         "hr32_49": (1, 1792, 1792, 32, 49, 3, 1, 1),
         "hr49_32": (1, 1792, 1792, 49, 32, 3, 1, 1),
         "hr1x1_32_49": (1, 1792, 1792, 32, 49, 1, 1, 0),
+        "thin3_49": (1, 1792, 1792, 3, 49, 3, 1, 1),           # fe_SR.0 forward (bias-free: BENCH_NOBIAS=1 reaches the streaming kernel)
         "thin3_128": (1, 1792, 1792, 3, 128, 3, 1, 1),
         "thin3_512": (1, 1792, 1792, 3, 512, 3, 1, 1),
         "thin512_3": (1, 1792, 1792, 512, 3, 3, 1, 1),         # output_conv / kb.sr_reconst of the last stage: the 3-channel image heads (conv_thin_cout)
