@@ -898,6 +898,52 @@ def test_wide_3x3_kernel_with_folded_constant_segment():
     assert relmax(outs[0], outs[1]) < 1e-3
 
 
+@pytest.mark.parametrize("split", [0, 1])
+def test_wide_form_of_narrow_kernel_with_folded_constant_segment(split):
+    """Conv.fwd_folded on the WIDE form of conv_x3n (its LEAN instance: bias + the interior class row through LDS, the pixel's class row per
+    piece on border tiles, rows transposed through LDS into whole-line stores): a map large enough to have interior tiles (rows 8..15,
+    columns 32..63) next to border tiles and ragged edges; plain input (KBPN's SFT conv0 of stage 1) and split hi + lo input / output in the
+    two-product plan (BlurSkip's conv0's); against the kernels that ran these launches before and against fp64 on the concatenated input."""
+    from csbsr_amd import _lib as L
+    from csbsr_amd.engine import Conv
+    torch.manual_seed(13 + split)
+    eng = _eng()
+    lib = L.load()
+    N, cf, cc, cout, H, W = 2, (64 if split else 128), 21, 200, 27, 100
+    x = torch.randn(N, cf, H, W)
+    if not split:
+        x = x.half().float()
+    kv = (torch.rand(N, cc) / cc).half().float()
+    w = (torch.randn(cout, cf + cc, 3, 3) / ((cf + cc) * 9) ** 0.5).half().float()
+    b = torch.randn(cout) * 0.1
+    m = torch.ones(4, 3)
+    m[2, 0] = m[3, 0] = 0.0
+    m[1, 2] = m[3, 2] = 0.0
+    xs = to_fm_split(eng, x) if split else to_fm(eng, x)
+    xv = from_fm_split(xs).double() if split else x.double()
+    ref = F.leaky_relu(F.conv2d(torch.cat([xv, kv.double()[:, :, None, None].expand(N, cc, H, W)], 1), w.double(), b.double(), 1, 1), 0.1)
+    outs = []
+    for xn_mode in (2, 0):
+        lib.csbsr_debug_set_conv_x3n(xn_mode)
+        try:
+            conv = Conv(eng, "l", {"l.weight": w.cuda(), "l.bias": b.cuda()}, 3, 1, 1, 1, bias=True, act=L.ACT_LRELU, slope=0.1, split=(cf, cc))
+            if split:
+                conv.fwd_blocks, conv.dc_comp = 2, True
+            y, _ = conv.fwd_folded(xs, kv.cuda(), m.cuda())
+            torch.cuda.synchronize()
+            kid = lib.csbsr_debug_last_conv_kernel()
+            assert ((kid & 255) == 20) == (xn_mode == 2), kid
+            if xn_mode == 2:
+                assert (kid >> 8) & 8, "the LEAN instance"
+        finally:
+            lib.csbsr_debug_set_conv_x3n(1)
+        outs.append((from_fm_split(y) if split else from_fm(y)).double())
+        assert float((outs[-1] - ref).abs().max() / ref.abs().max()) < 2e-3
+    e01 = float((outs[0] - outs[1]).abs().max() / ref.abs().max())
+    print(f"   wide form, folded segment (split={split}): vs the previous kernel {e01:.2e}")
+    assert e01 < (2e-5 if split else 1e-3)
+
+
 @pytest.mark.parametrize("H,W", [(5, 5), (12, 40), (33, 70), (363, 371)])
 def test_conv_with_two_ring_class_bias(H, W):
     """fe_cat.0 as the model runs it (Conv.fwd_classbias, conv desc cbias_mode 1): a 1x1 conv over cat(features, a map that is the
