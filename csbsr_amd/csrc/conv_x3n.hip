@@ -304,6 +304,54 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 1) void conv_x3n_kernel(const ConvK
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+    } else if (WIDE && FAST && !fe.o_lo) {
+      // the wide form with per-pixel operands (the masked / accumulating dgrads), plain fp16 output: the operands are loaded row piece by
+      // row piece as before (a piece's 16 bytes per lane share their 128-byte line with the neighbouring pieces: L1 hits), but the finished
+      // row leaves through the wave's LDS tile as whole lines like the LEAN instance's -- stores are what the L2 sees one request per
+      // 16 bytes of
+      const __amdgpu_buffer_rsrc_t rs = conv_make_rs(p.out16 + n * p.o_sn + (long)(Y0 + 4 * rq) * p.o_sy);
+      char* tt = smem + 2 * XN_BUF + 1024 + wid * (32 * XN_TPITCH);
+      const int rpix = lane >> 3, rchunk = lane & 7;
+      const int rco = G::CT * ct + 64 * mh + 8 * rchunk;
+      const int rcobad = rco >= p.coutp ? (int)0x80000000 : 0;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int oy = Y0 + 4 * rq + nt;
+        const int rowbad = oy >= p.OH ? (int)0x80000000 : 0;
+#pragma unroll
+        for (int mp = 0; mp < 4; ++mp) {
+          const int mt = mp >> 1, pair = mp & 1;
+          const int co = G::CT * ct + 64 * mh + 32 * mt + 16 * pair + 8 * hi;
+          if (oy >= p.OH || ox >= p.OW || co >= p.coutp) continue;
+          float v[8], bias[8], s0[8], s1[8], brow[8], t[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] = acc[mt][nt][8 * pair + e];
+            bias[e] = (p.bias && co + e < p.cout) ? p.bias[n * p.bias_sn + co + e] : 0.f;
+          }
+          h8 rr = {0, 0, 0, 0, 0, 0, 0, 0}, oo = {0, 0, 0, 0, 0, 0, 0, 0}, mm = {1, 1, 1, 1, 1, 1, 1, 1};
+          if (fe.has_res) rr = *reinterpret_cast<const h8*>(p.res + n * p.r_sn + oy * p.r_sy + ox * p.r_sx + co);
+          if (fe.has_old) oo = *reinterpret_cast<const h8*>(p.out16 + n * p.o_sn + oy * p.o_sy + ox * p.o_sx + co);
+          if (fe.has_mask) mm = *reinterpret_cast<const h8*>(p.mask + n * p.m_sn + oy * p.m_sy + ox * p.m_sx + co);
+          if (fe.has_cb) conv_class_bias_row(p, bias, co, n, oy, ox, brow);
+          else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) brow[e] = bias[e];
+          }
+          conv_epilogue_fast_values<true, false>(fe, v, brow, co, rr, oo, s0, s1, mm, t);
+          h8 hv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hv[e] = (half_t)t[e];
+          *reinterpret_cast<h8*>(tt + pix * XN_TPITCH + (16 * mp + 8 * hi) * 2) = hv;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int px = rpix + 8 * k;
+          const h8 o = *reinterpret_cast<const h8*>(tt + px * XN_TPITCH + rchunk * 16);
+          const int voff = (2 * nt * (int)p.o_sy + 2 * (int)((X0 + px) * p.o_sx) + 2 * rco) | rowbad | rcobad | (X0 + px >= p.OW ? (int)0x80000000 : 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(conv_u4, o), rs, voff, 0, 0);
+        }
+      }
     } else {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
