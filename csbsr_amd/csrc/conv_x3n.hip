@@ -472,7 +472,7 @@ extern "C" int csbsr_pack_weights_x3n(const float* w, void* dst, int32_t kind, i
   return 0;
 }
 
-static int g_conv_x3n_mode = 1;      // 0 off, 1 launches that fill the chip (default), 2 every eligible launch (tests), 3 narrow form only; +4: the wide form at any input width
+static int g_conv_x3n_mode = 1;      // 0 off, 1 launches that fill the chip (default), 2 every eligible launch (tests), 3 narrow form only; +4: the wide form only up to 384 input channels
 extern "C" void csbsr_debug_set_conv_x3n(int mode) { g_conv_x3n_mode = mode & 7; }
 
 // Which launches take this kernel (return value 1: the narrow form, 2: the wide form): 3x3, stride 1, pad 1, dilation 1, ONE input segment in
@@ -482,7 +482,9 @@ extern "C" void csbsr_debug_set_conv_x3n(int mode) { g_conv_x3n_mode = mode & 7;
 // epilogue-backward sums.  Narrow: 33 .. 64 padded output channels from >= 64 (mode 2: >= 32) input channels, BatchNorm sums allowed.  Wide:
 // more than 64 padded output channels from 32 .. 384 input channels (measured against csrc/conv_x3.hip's whole-K-resident tile, one launch
 // of the batch of 8 at 448^2: 128 -> 569 2.94 -> 2.42 ms, 256 -> 697 5.39 -> 4.94, 384 -> 825 8.47 -> 8.25, 825 -> 825 16.7 -> 17.2: the
-// overlapped epilogue is worth less and the twice-staged weights more as K grows).
+// overlapped epilogue is worth less and the twice-staged weights more as K grows).  With the epilogue of the later commits (loads ahead of
+// stores, whole-line stores) the wide form wins at every width -- 825 -> 825 16.74 -> 16.36 ms forward, 16.46 -> 15.89 dgrad, 825 -> 384
+// 7.38 -> 7.20, 384 <- 825 dgrad 7.20 -> 6.93 -- and takes them all.
 extern "C" int32_t csbsr_conv_x3n_eligible(const csbsr_conv_desc_t* d) {
   const int mode = g_conv_x3n_mode & 3;
   if (!d || !mode || d->transposed || d->KH != 3 || d->KW != 3 || d->dil != 1) return 0;
@@ -494,7 +496,12 @@ extern "C" int32_t csbsr_conv_x3n_eligible(const csbsr_conv_desc_t* d) {
   if (d->in[0].sy >= (1l << 31) / 2 / (XN_HH + 1)) return 0;
   const bool wide = d->coutp > 64;
   if (wide) {
-    if (mode == 3 || d->stat_mode != CSBSR_STAT_NONE || d->in[0].c > ((g_conv_x3n_mode & 4) ? (1 << 20) : 384)) return 0;
+    if (mode == 3 || d->stat_mode != CSBSR_STAT_NONE) return 0;
+    // above 384 input channels only the launches of the straight-line rows (the SFT conv1 epilogues -- sigmoid, f x scale + shift -- have
+    // their own instance of conv_x3; +4 in the debug mode: the old limit, everything above 384 channels stays on conv_x3)
+    const bool fast_like = d->act != CSBSR_ACT_SIGMOID && !d->r_lo &&
+                           (d->res_mode == CSBSR_RES_NONE || d->res_mode == CSBSR_RES_ADD || d->res_mode == CSBSR_RES_SUB);
+    if (d->in[0].c > 384 && (!fast_like || (g_conv_x3n_mode & 4))) return 0;
   } else {
     if (d->stat_mode != CSBSR_STAT_NONE && d->stat_mode != CSBSR_STAT_BN) return 0;    // (BatchNorm sums: the straight-line rows only, see the launcher)
     if (d->stat_mode == CSBSR_STAT_BN && (d->r_lo || d->r2_lo || d->res_mode != CSBSR_RES_NONE || d->accumulate || d->mask)) return 0;      // (BatchNorm sums: no per-pixel operand)
