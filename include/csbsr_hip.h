@@ -175,12 +175,13 @@ int csbsr_pack_weights_x3_strided(const float* w, void* dst, int32_t D0, int32_t
  * a split [hi | lo] input is presented as ONE 2 x Cp-channel segment with split_fused = 2 (the two-product plan [x_hi | x_lo] w_hi; the
  * pack repeats the weights for the lo plane), the output may be a hi + lo pair.
  * The WIDE form of the same kernel (8 x 32 pixels x 128 couts, two workgroups per CU) takes the layers with MORE than 64 padded output
- * channels from 32 .. 384 input channels -- the 64 -> 505 first convolutions of those blocks, KBPN's SFT convolutions of stages 1-3
+ * channels from 32 input channels up -- the 64 -> 505 first convolutions of those blocks, KBPN's SFT convolutions
  * (kbpn.py:505-520) with the constant segment folded into a class bias, the 32 -> 128 gather of a stage's thin dgrads -- same entry
  * points, same pack (its layout follows the padded row count).
  * csbsr_conv_x3n_eligible returns 0 (not taken), 1 (narrow form: one input segment of >= 64 channels in whole 32-channel chunks, 33 .. 64
  * padded output channels; BatchNorm sums allowed when no per-pixel epilogue operand is fused) or 2 (wide form: > 64 padded output
- * channels, 32 .. 384 input channels, no statistics); neither takes the fp32 side output or the fused epilogue-backward sums. */
+ * channels, >= 32 input channels -- above 384 only launches without a sigmoid / multiply epilogue --, no statistics); neither takes the fp32
+ * side output or the fused epilogue-backward sums. */
 int32_t csbsr_conv_x3n_eligible(const csbsr_conv_desc_t* d);
 int csbsr_conv_x3n_forward(const csbsr_conv_desc_t* d, csbsr_stream_t s);
 /* kind 0 forward (w = OIHW), 1 dgrad of the stride-1 conv; in_ch = padded input channels the kernel walks (2 x plane for a split input),
